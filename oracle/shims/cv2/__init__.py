@@ -1,0 +1,233 @@
+"""TEST INFRASTRUCTURE (oracle harness) -- stand-in for `cv2` so the reference's optimisation modules import.
+
+opencv-contrib-python (>=4.5.0.0,<=4.7.0; /root/reference/setup.py:43) is NOT installed in this image and
+cannot be fetched.  Only two functions on the bundle-adjustment path come from it:
+
+  * cv2.projectPoints          (call site /root/reference/multical/camera.py:124-128)
+  * cv2.fisheye.projectPoints  (call site /root/reference/multical/camera_fisheye.py:113-117)
+
+They are RESTATED here in float64 numpy from OpenCV's published algorithm (calib3d
+`cvProjectPoints2Internal` / `cv::fisheye::projectPoints`, OpenCV 4.5-4.7; formulae in the calib3d docs
+"Camera Calibration and 3D Reconstruction" and `distortion_model.hpp:computeTiltProjectionMatrix`).
+The rvec/tvec arguments are honoured (the reference always passes zeros).
+
+PARITY NOTE: bit-level agreement with the real OpenCV binary cannot be checked in this container
+(no cv2) -> "parity unpinned" at this boundary; formula-level agreement is what the oracle asserts.
+
+Everything else exposed here is constants read at import / class-body time
+(camera.py:43-48, camera_fisheye.py:43-49,68, board/aprilgrid.py:102-107, hand_eye/hand_eye.py:113).
+Nothing under multical_amd/ may import this module.
+"""
+import numpy as np
+
+__version__ = "4.6.0-oracle-shim"
+
+# --- constants (values as in OpenCV 4.x headers; only identity matters for the reference) ---------
+CALIB_USE_INTRINSIC_GUESS = 0x00001
+CALIB_FIX_ASPECT_RATIO = 0x00002
+CALIB_FIX_INTRINSIC = 0x00100
+CALIB_RATIONAL_MODEL = 0x04000
+CALIB_THIN_PRISM_MODEL = 0x08000
+CALIB_TILTED_MODEL = 0x40000
+CALIB_ROBOT_WORLD_HAND_EYE_SHAH = 0
+CALIB_ROBOT_WORLD_HAND_EYE_LI = 1
+CALIB_HAND_EYE_TSAI = 0
+TERM_CRITERIA_MAX_ITER = 1
+TERM_CRITERIA_EPS = 2
+CV_32FC2 = 13
+CV_16SC2 = 11
+INTER_CUBIC = 2
+FILLED = -1
+LINE_AA = 16
+FONT_HERSHEY_SIMPLEX = 0
+COLOR_GRAY2BGR = 8
+COLOR_GRAY2RGB = 8
+IMREAD_GRAYSCALE = 0
+WINDOW_NORMAL = 0
+WINDOW_AUTOSIZE = 1
+WND_PROP_VISIBLE = 4
+
+
+class UMat(object):
+  """cv2.UMat stand-in: the reference wraps the point array (camera.py:127) and calls .get() on the result."""
+
+  def __init__(self, arr):
+    self.arr = np.asarray(arr)
+
+  def get(self):
+    return self.arr
+
+
+def _unwrap(x):
+  return x.arr if isinstance(x, UMat) else np.asarray(x)
+
+
+def _rodrigues(rvec):
+  r = np.asarray(rvec, dtype=np.float64).reshape(3)
+  theta = np.linalg.norm(r)
+  if theta < 2.220446049250313e-16:
+    return np.eye(3)
+  k = r / theta
+  K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+  return np.cos(theta) * np.eye(3) + (1 - np.cos(theta)) * np.outer(k, k) + np.sin(theta) * K
+
+
+def tilt_matrix(tau_x, tau_y):
+  """OpenCV distortion_model.hpp: computeTiltProjectionMatrix (forward matrix only)."""
+  ctx, stx = np.cos(tau_x), np.sin(tau_x)
+  cty, sty = np.cos(tau_y), np.sin(tau_y)
+  rot_x = np.array([[1, 0, 0], [0, ctx, stx], [0, -stx, ctx]])
+  rot_y = np.array([[cty, 0, -sty], [0, 1, 0], [sty, 0, cty]])
+  rot_xy = rot_y @ rot_x
+  proj_z = np.array([[rot_xy[2, 2], 0, -rot_xy[0, 2]], [0, rot_xy[2, 2], -rot_xy[1, 2]], [0, 0, 1]])
+  return proj_z @ rot_xy
+
+
+def projectPoints(objectPoints, rvec, tvec, cameraMatrix, distCoeffs, *args, **kwargs):
+  """Pinhole + Brown-Conrady (k1,k2,p1,p2[,k3[,k4,k5,k6[,s1,s2,s3,s4[,taux,tauy]]]]).
+
+  Follows cvProjectPoints2Internal: x=X/Z, y=Y/Z (1/Z := 1 when Z == 0, no behind-camera clamp);
+  only fx, fy, cx, cy are read from the camera matrix (K[0,1] is ignored).
+  Returns (image_points [N,1,2] wrapped like the input, None).
+  """
+  wrapped = isinstance(objectPoints, UMat)
+  pts = _unwrap(objectPoints).astype(np.float64).reshape(-1, 3)
+  R = _rodrigues(_unwrap(rvec))
+  t = _unwrap(tvec).astype(np.float64).reshape(3)
+  K = np.asarray(cameraMatrix, dtype=np.float64)
+  fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+
+  k = np.zeros(14)
+  if distCoeffs is not None:
+    d = np.asarray(distCoeffs, dtype=np.float64).ravel()
+    assert d.size in (4, 5, 8, 12, 14), f"bad distCoeffs size {d.size}"
+    k[:d.size] = d
+
+  P = pts @ R.T + t
+  X, Y, Z = P[:, 0], P[:, 1], P[:, 2]
+  with np.errstate(divide='ignore', invalid='ignore'):
+    iz = np.where(Z != 0, 1.0 / Z, 1.0)
+  x, y = X * iz, Y * iz
+
+  r2 = x * x + y * y
+  r4 = r2 * r2
+  r6 = r4 * r2
+  a1 = 2 * x * y
+  a2 = r2 + 2 * x * x
+  a3 = r2 + 2 * y * y
+  cdist = 1 + k[0] * r2 + k[1] * r4 + k[4] * r6
+  icdist2 = 1.0 / (1 + k[5] * r2 + k[6] * r4 + k[7] * r6)
+  xd0 = x * cdist * icdist2 + k[2] * a1 + k[3] * a2 + k[8] * r2 + k[9] * r4
+  yd0 = y * cdist * icdist2 + k[2] * a3 + k[3] * a1 + k[10] * r2 + k[11] * r4
+
+  if k[12] != 0 or k[13] != 0:
+    T = tilt_matrix(k[12], k[13])
+    vx = T[0, 0] * xd0 + T[0, 1] * yd0 + T[0, 2]
+    vy = T[1, 0] * xd0 + T[1, 1] * yd0 + T[1, 2]
+    vz = T[2, 0] * xd0 + T[2, 1] * yd0 + T[2, 2]
+    inv = np.where(vz != 0, 1.0 / vz, 1.0)
+    xd, yd = inv * vx, inv * vy
+  else:
+    xd, yd = xd0, yd0
+
+  out = np.stack([xd * fx + cx, yd * fy + cy], axis=-1).reshape(-1, 1, 2)
+  return (UMat(out) if wrapped else out), None
+
+
+class _Fisheye(object):
+  CALIB_USE_INTRINSIC_GUESS = 1 << 0
+  CALIB_RECOMPUTE_EXTRINSIC = 1 << 1
+  CALIB_CHECK_COND = 1 << 2
+  CALIB_FIX_SKEW = 1 << 3
+  CALIB_FIX_K1 = 1 << 4
+  CALIB_FIX_K2 = 1 << 5
+  CALIB_FIX_K3 = 1 << 6
+  CALIB_FIX_K4 = 1 << 7
+  CALIB_FIX_INTRINSIC = 1 << 8
+
+  @staticmethod
+  def projectPoints(objectPoints, rvec, tvec, K, D, alpha=0, *args, **kwargs):
+    """Kannala-Brandt (cv::fisheye::projectPoints): theta_d = theta(1+k1 th^2+k2 th^4+k3 th^6+k4 th^8),
+    u = fx (x' + alpha y') + cx with alpha = K[0,1]/fx when called with the camera matrix (the python
+    binding's `alpha` argument defaults to 0 and the skew is taken from K), v = fy y' + cy."""
+    wrapped = isinstance(objectPoints, UMat)
+    pts = _unwrap(objectPoints).astype(np.float64).reshape(-1, 3)
+    R = _rodrigues(_unwrap(rvec))
+    t = _unwrap(tvec).astype(np.float64).reshape(3)
+    K = np.asarray(K, dtype=np.float64)
+    fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+    # cv::fisheye::projectPoints(objectPoints, imagePoints, rvec, tvec, K, D, alpha): the K-taking
+    # overload uses `alpha` (default 0) and ignores K(0,1).  The Affine3d overload does the same.
+    # OpenCV 4.5-4.7 source: `Vec2d f(K(0,0),K(1,1)); Vec2d c(K(0,2),K(1,2));` and
+    # `xd3(xd1[0] + alpha*xd1[1], xd1[1])`.  => skew in K is NOT read; alpha argument is.
+    k = np.zeros(4)
+    d = np.asarray(D, dtype=np.float64).ravel()
+    k[:min(4, d.size)] = d[:4]
+
+    P = pts @ R.T + t
+    with np.errstate(divide='ignore', invalid='ignore'):
+      a = P[:, 0] / P[:, 2]
+      b = P[:, 1] / P[:, 2]
+    r2 = a * a + b * b
+    r = np.sqrt(r2)
+    theta = np.arctan(r)
+    th2 = theta * theta
+    th4 = th2 * th2
+    th6 = th4 * th2
+    th8 = th4 * th4
+    theta_d = theta * (1 + k[0] * th2 + k[1] * th4 + k[2] * th6 + k[3] * th8)
+    with np.errstate(divide='ignore', invalid='ignore'):
+      inv_r = np.where(r > 1e-8, 1.0 / r, 1.0)
+    cdist = np.where(r > 1e-8, theta_d * inv_r, 1.0)
+    xd, yd = a * cdist, b * cdist
+    out = np.stack([fx * (xd + alpha * yd) + cx, fy * yd + cy], axis=-1).reshape(-1, 1, 2)
+    return (UMat(out) if wrapped else out), None
+
+
+fisheye = _Fisheye()
+
+
+class _Dictionary(object):
+  def __init__(self, dict_id):
+    self.dict_id = dict_id
+    self.bytesList = np.zeros((1000, 1, 1), dtype=np.uint8)
+
+
+class _CharucoBoard(object):
+  """Geometry of cv2.aruco.CharucoBoard_create(w, h, square, marker, dict) in the OpenCV 4.5-4.7 (legacy aruco)
+  layout: interior chessboard corners, float32 Point3f ((i+1)*sq, (j+1)*sq, 0), x fastest (charuco.cpp
+  `CharucoBoard::create`: `for y in 0..squaresY-2: for x in 0..squaresX-2`)."""
+
+  def __init__(self, w, h, square_length, marker_length, dictionary):
+    self.dictionary = dictionary
+    self.chessboardCorners = np.array(
+      [((i + 1) * square_length, (j + 1) * square_length, 0.0) for j in range(h - 1) for i in range(w - 1)],
+      dtype=np.float32)
+    self.ids = np.arange((w * h) // 2)
+
+
+class _Aruco(object):
+  @staticmethod
+  def getPredefinedDictionary(dict_id):
+    return _Dictionary(dict_id)
+
+  @staticmethod
+  def CharucoBoard_create(w, h, square_length, marker_length, dictionary):
+    return _CharucoBoard(w, h, square_length, marker_length, dictionary)
+
+  DICT_APRILTAG_16h5 = 17
+  DICT_APRILTAG_25h9 = 18
+  DICT_APRILTAG_36h10 = 19
+  DICT_APRILTAG_36h11 = 20
+
+  def __getattr__(self, name):
+    if name.startswith('DICT_'):
+      return hash(name) & 0xffff
+    raise AttributeError(f"oracle cv2 shim: cv2.aruco.{name} is out of scope (detection / drawing)")
+
+
+aruco = _Aruco()
+
+
+def __getattr__(name):
+  raise AttributeError(f"oracle cv2 shim: cv2.{name} is not on the bundle-adjustment path")
