@@ -1,0 +1,212 @@
+/* mcba.h -- C ABI of the MI355X bundle-adjustment back-end ("multical bundle adjust").
+ *
+ * Drop-in boundary for ONE path of oliver-batchelor/multical: the reprojection residual / Jacobian evaluation and
+ * the damped normal-equation solve behind
+ *     multical.optimization.Calibration.bundle_adjust      (multical/optimization/calibration.py:199-212)
+ *     multical.workspace.Workspace.calibrate               (multical/workspace.py:228-247)
+ * The reference has no FFI of its own (it is pure Python on top of scipy / OpenCV); this header is the interface a
+ * ctypes stub inside `Calibration.bundle_adjust` binds.  Every entry point names the reference
+ * function it replaces.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no C++/torch types; every function returns 0 on success, non-zero on error and
+ *     never throws across the ABI; `mcba_last_error()` returns a thread-local message.
+ *   - all floating point is IEEE double; masks are uint8 (0/1); arrays are C-contiguous.
+ *   - host buffers are caller-owned and only read during the call; the handle owns device memory and runs every
+ *     kernel on the HIP stream given at creation (NULL = the handle creates its own stream).
+ *   - one handle per thread; handles are independent.
+ *   - the library is HIP-only: `mcba_create` fails when no gfx950 device is present.  There is no CPU fallback.
+ *
+ * Parameter vector `x` (length `n_params`): exactly `Calibration.param_vec` (optimization/parameters.py:44-46):
+ * the ENABLED blocks, in the order camera_poses | board_poses | motion | cameras | boards
+ * (optimization/calibration.py:146-161):
+ *     camera_poses : C x (rx ry rz tx ty tz)                           pose_set.py:51-53
+ *     board_poses  : B x 6
+ *     motion       : static   F x 6                                    motion/static_frames.py:29
+ *                    rolling  F x 6 (start) then F x 6 (end)           motion/rolling_frames.py:135-140
+ *                    hand-eye 6 (world_wrt_base) 6 (gripper_wrt_camera) motion/hand_eye.py:75-80
+ *     cameras      : C x [fx fy | cx cy | skew | dist(n_dist)]         camera.py:144-155
+ *     boards       : sum_b P_b x 3                                     board/charuco.py:112-114
+ * Disabled blocks keep the values given in `mcba_problem.x_full`.
+ *
+ * Residual vector `r` (length `n_residuals` = 2 * #inliers): C-order over (camera, frame, board, point) restricted
+ * to the inlier mask, (u,v) interleaved -- `(reprojected.points - point_table.points)[inliers].ravel()`
+ * (optimization/calibration.py:204-206).
+ */
+#ifndef MCBA_H
+#define MCBA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCBA_VERSION 1
+
+/* motion models (multical/motion/) */
+#define MCBA_MOTION_STATIC   0   /* motion/static_frames.py  */
+#define MCBA_MOTION_ROLLING  1   /* motion/rolling_frames.py (linear, scan time from the observed row) */
+#define MCBA_MOTION_HAND_EYE 2   /* motion/hand_eye.py       */
+
+/* camera models */
+#define MCBA_CAMERA_PINHOLE 0    /* camera.py:124-128         -> cv2.projectPoints, n_dist in {5,8,12,14} */
+#define MCBA_CAMERA_FISHEYE 1    /* camera_fisheye.py:113-117 -> cv2.fisheye.projectPoints, n_dist = 4     */
+
+/* robust losses (scipy.optimize.least_squares `loss`, reachable through OptimizerOpts.loss, config/arguments.py:61) */
+#define MCBA_LOSS_LINEAR  0
+#define MCBA_LOSS_SOFT_L1 1
+#define MCBA_LOSS_HUBER   2
+#define MCBA_LOSS_CAUCHY  3
+#define MCBA_LOSS_ARCTAN  4
+
+/* parameter blocks, bit flags for mcba_problem.optimize (calibration.py:28-35 `default_optimize`) */
+#define MCBA_OPT_CAMERA_POSES 1
+#define MCBA_OPT_BOARD_POSES  2
+#define MCBA_OPT_MOTION       4
+#define MCBA_OPT_CAMERAS      8
+#define MCBA_OPT_BOARDS       16
+
+typedef struct mcba_problem {
+  int32_t version;              /* MCBA_VERSION */
+  int32_t n_cameras;            /* C */
+  int32_t n_frames;             /* F */
+  int32_t n_boards;             /* B */
+  int32_t n_points;             /* P = max points per board (tables.stack_boards, tables.py:385-394) */
+
+  const double*  points;        /* [C,F,B,P,2] point_table.points, widened to double by the caller      */
+  const uint8_t* point_valid;   /* [C,F,B,P]   point_table.valid                                       */
+  const uint8_t* inlier_mask;   /* [C,F,B,P]   Calibration.inlier_mask, or NULL -> inliers = valid     */
+
+  const int32_t* board_sizes;   /* [B]   P_b (number of real points of each board)                     */
+  const uint8_t* camera_valid;  /* [C]   camera_poses.valid                                            */
+  const uint8_t* frame_valid;   /* [F]   motion.valid                                                  */
+  const uint8_t* board_valid;   /* [B]   board_poses.valid                                             */
+
+  int32_t motion;               /* MCBA_MOTION_*                                                       */
+  int32_t camera_model;         /* MCBA_CAMERA_*                                                       */
+  int32_t n_dist;               /* distortion coefficients per camera (camera.dist.size)               */
+  const double*  image_heights;    /* [C] camera.image_size[1]  (rolling_frames.py:15-19)              */
+  const uint8_t* fix_aspect;       /* [C] Camera.fix_aspect (camera.py:147-148,159-160)                */
+  const double*  base_wrt_gripper; /* [F,4,4] hand-eye only (motion/hand_eye.py:43-46), else NULL      */
+
+  uint32_t optimize;            /* OR of MCBA_OPT_*                                                    */
+  const double* x_full;         /* all five blocks in reference order, length mcba_full_size();        */
+                                /* values of disabled blocks are taken from here                        */
+  int32_t frame_begin;          /* frame shard owned by this handle: [frame_begin, frame_end);          */
+  int32_t frame_end;            /* 0,0 = all frames.  Arrays above always describe ALL frames.          */
+} mcba_problem;
+
+typedef struct mcba_options {          /* scipy.optimize.least_squares arguments used at calibration.py:209-210 */
+  double ftol;                  /* `tolerance`      (default 1e-4, calibration.py:199)                  */
+  double xtol;                  /* scipy default 1e-8                                                   */
+  double gtol;                  /* scipy default 1e-8                                                   */
+  int32_t max_nfev;             /* `max_iterations` (default 100)                                       */
+  int32_t loss;                 /* MCBA_LOSS_*                                                          */
+  double f_scale;               /* scipy `f_scale` (soft margin of the robust loss)                     */
+  int32_t verbose;              /* 2: per-iteration rows are delivered to the log callback              */
+  int32_t reserved;
+} mcba_options;
+
+typedef struct mcba_result {           /* scipy OptimizeResult fields the caller needs                    */
+  double cost;                  /* 0.5 * sum(rho(f^2))                                                  */
+  double initial_cost;
+  double optimality;            /* |g|_inf                                                              */
+  int32_t nfev;                 /* residual evaluations (trial steps + 1)                               */
+  int32_t njev;                 /* linearisations (fused residual + Jacobian -> normal equations)       */
+  int32_t status;               /* scipy status: 0 max_nfev, 1 gtol, 2 ftol, 3 xtol, 4 ftol+xtol         */
+  int32_t iterations;
+  double solve_seconds;         /* wall time inside mcba_solve                                          */
+  double linearize_seconds;     /* GPU time (HIP events) spent in the fused linearisation kernels       */
+} mcba_result;
+
+typedef struct mcba_handle_s* mcba_handle;
+
+/* iteration log: same columns as scipy's verbose=2 table (print_iteration_nonlinear), which the reference pipes
+ * into its logger (calibration.py:208, io/logging.py:53-68).  cost_reduction / step_norm are NaN on row 0.      */
+typedef void (*mcba_log_fn)(void* ctx, int32_t iteration, int32_t nfev, double cost, double cost_reduction,
+                            double step_norm, double optimality);
+
+/* cross-rank reduction hook for frame-sharded problems: called from inside mcba_solve /
+ * mcba_normal_equations with a DEVICE buffer of `count` doubles that must be reduced IN PLACE over all ranks,
+ * ordered on `stream`.  op: 0 = sum, 1 = max.  The Python side implements it with torch.distributed
+ * (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU-side tests).  Return 0 on success.            */
+typedef int32_t (*mcba_allreduce_fn)(void* ctx, void* device_buf, size_t count, int32_t op, void* stream);
+
+/* --- sizes ------------------------------------------------------------------------------------------------- */
+/* length of mcba_problem.x_full for the given shape (all five blocks)                                          */
+int32_t mcba_full_size(const mcba_problem* p, int64_t* out);
+
+/* --- lifetime ---------------------------------------------------------------------------------------------- */
+/* Lowers a Calibration (flat arrays) to device tables: frame-major observation table, inlier prefix sums, index
+ * maps.  Replaces the per-call object graph of Calibration.with_param_vec (calibration.py:164-171) and the
+ * sparsity build (calibration.py:173-196).  `hip_stream` may be NULL.                                          */
+int32_t mcba_create(const mcba_problem* p, void* hip_stream, mcba_handle* out);
+int32_t mcba_destroy(mcba_handle h);
+const char* mcba_last_error(void);
+/* "gfx950:<device name>" of the device the handle lives on                                                    */
+int32_t mcba_device_info(mcba_handle h, char* buf, size_t buf_len);
+
+int32_t mcba_num_params(mcba_handle h, int64_t* n_params);
+int32_t mcba_num_residuals(mcba_handle h, int64_t* n_residuals);   /* 2 * #inliers (all frames of the shard)   */
+
+/* Replace the inlier mask (Calibration.reject_outliers -> copy(inlier_mask=...), calibration.py:240-252).
+ * mask = NULL restores inliers = valid.                                                                       */
+int32_t mcba_set_inliers(mcba_handle h, const uint8_t* mask);
+
+int32_t mcba_set_allreduce(mcba_handle h, mcba_allreduce_fn fn, void* ctx);
+int32_t mcba_set_log(mcba_handle h, mcba_log_fn fn, void* ctx);
+
+/* --- evaluation -------------------------------------------------------------------------------------------- */
+/* r = evaluate(x)                                                   (calibration.py:204-206)                   */
+int32_t mcba_residuals(mcba_handle h, const double* x, double* r);
+
+/* Analytic Jacobian of `evaluate` in the sparsity pattern of Calibration.sparsity_matrix (calibration.py:173-196):
+ * row pair i (one inlier observation) has `row_nnz` structurally non-zero columns (same count for every row);
+ * cols[i*row_nnz + k] are ascending column indices into x, vals[(2i+a)*row_nnz + k] the entries of row 2i+a.
+ * Call with vals = cols = NULL to query row_nnz.                                                               */
+int32_t mcba_jacobian(mcba_handle h, const double* x, int32_t* row_nnz, double* vals, int32_t* cols);
+
+/* Reprojection error per table slot: err[c,f,b,p] = |proj - obs|_2, valid = proj.valid & obs.valid, err = 0 where
+ * invalid (tables.reprojection_error, tables.py:244-249; feeds Calibration.reprojection_error / reject_outliers /
+ * report, calibration.py:134-141,240-252,290-310).  Arrays are in the reference's [C,F,B,P] order.             */
+int32_t mcba_reprojection_error(mcba_handle h, const double* x, double* err, uint8_t* valid);
+
+/* Projected points [C,F,B,P,2] of Calibration.reprojected (calibration.py:124-130).                            */
+int32_t mcba_project(mcba_handle h, const double* x, double* projected);
+
+/* One fused residual+Jacobian evaluation reduced to the normal equations at x (what one scipy `jac` call plus
+ * J^T J / J^T f would produce): cost = 0.5 |f|^2 (robust-loss scaled), g = J^T f [n_params],
+ * diag = diag(J^T J) [n_params].  Any output pointer may be NULL.  Sharded handles all-reduce through the hook. */
+int32_t mcba_normal_equations(mcba_handle h, const double* x, const mcba_options* opt,
+                              double* cost, double* g, double* diag);
+/* dense J^T J [n_params x n_params] assembled from the block form (debug / parity tests; small problems only)  */
+int32_t mcba_dense_hessian(mcba_handle h, double* H);
+
+/* --- solve -------------------------------------------------------------------------------------------------- */
+/* Trust-region least squares: replaces scipy.optimize.least_squares(method='trf', x_scale='jac', jac_sparsity=S,
+ * loss, f_scale, ftol, max_nfev) at calibration.py:209-210.  x is updated in place to `res.x`.                 */
+int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba_result* result);
+
+/* --- measurement ------------------------------------------------------------------------------------------- */
+/* Run the fused linearisation `repeats` times at x and return the average GPU time per pass in milliseconds
+ * measured with HIP events on the handle's stream (bench.py roofline leg).                                     */
+int32_t mcba_time_linearize(mcba_handle h, const double* x, const mcba_options* opt, int32_t repeats,
+                            double* avg_ms);
+int32_t mcba_time_residuals(mcba_handle h, const double* x, int32_t repeats, double* avg_ms);
+
+/* --- test / debug hooks (used by tests/ only) --------------------------------------------------------------- */
+/* 1 = accumulate V^T V and the Schur SYRK with v_mfma_f64_16x16x4_f64 (default); 0 = identical data flow with plain
+ * FMAs (validation build of the same kernels).  The environment variable MCBA_NO_MFMA=1 sets the initial value.  */
+int32_t mcba_set_mfma(mcba_handle h, int32_t on);
+/* regularised Gauss-Newton direction (H_h + reg I)^-1 g_h in the column-scaled space, computed by the Schur /
+ * Cholesky kernels after a preceding mcba_normal_equations at the same x; g_h and scale_inv may be NULL.           */
+int32_t mcba_debug_gn_step(mcba_handle h, double reg, double* gn_h, double* g_h, double* scale_inv);
+/* one v_mfma_f64_16x16x4_f64 on V = [A | B] (4 x 32, row-major): out[16][16] = A^T B (operand-layout self-test)     */
+int32_t mcba_debug_mfma_probe(const double* V, double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCBA_H */

@@ -1,0 +1,315 @@
+"""Lowering of a `Calibration` to the flat problem description of include/mcba.h, and the handle wrapper.
+
+`lower()` is duck-typed: it reads the attributes that both multical_amd.calibration.Calibration and the reference's
+multical.optimization.calibration.Calibration expose (calibration.py:43-61,146-153), so the very same code path serves
+the host mirror in this package and the drop-in patch of the real multical (multical_amd.dropin).
+
+Nothing here computes residuals on the host: every numeric method forwards to libmcba.so (HIP, gfx950).
+"""
+import ctypes as C
+import time
+from types import SimpleNamespace
+
+import numpy as np
+
+from . import _lib
+from ._lib import (Problem, Options, Result, LOSSES, OPT_BITS, PARAM_ORDER, MOTION_STATIC, MOTION_ROLLING,
+                   MOTION_HAND_EYE, CAMERA_PINHOLE, CAMERA_FISHEYE, check)
+
+
+def _ptr(a, ctype):
+  return a.ctypes.data_as(C.POINTER(ctype))
+
+
+def _u8(a):
+  return np.ascontiguousarray(np.asarray(a).astype(np.uint8))
+
+
+def _f64(a):
+  return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+def _class_name(obj):
+  return type(obj).__name__
+
+
+def _optimize_bits(optimize):
+  bits = 0
+  for k in PARAM_ORDER:
+    if optimize[k] is True:     # calibration.py:160  `self.optimize[k] is True`
+      bits |= OPT_BITS[k]
+  return bits
+
+
+def lower(calib):
+  """Calibration -> SimpleNamespace of C-contiguous numpy arrays + scalars (keeps them alive for the C call)."""
+  points = calib.point_table.points
+  C_, F, B, P = calib.point_table.valid.shape
+  p = SimpleNamespace()
+  p.shape = (C_, F, B, P)
+  p.points = _f64(points)                                     # float32 detections are widened exactly
+  p.point_valid = _u8(calib.point_table.valid)
+  p.inlier_mask = None if calib.inlier_mask is None else _u8(calib.inlier_mask)
+  p.board_sizes = np.ascontiguousarray(np.array([b.num_points for b in calib.boards], dtype=np.int32))
+  p.camera_valid = _u8(calib.camera_poses.valid)
+  p.board_valid = _u8(calib.board_poses.valid)
+  p.frame_valid = _u8(calib.motion.valid)
+
+  motion = calib.motion
+  mname = _class_name(motion)
+  p.base_wrt_gripper = None
+  if mname == "RollingFrames":
+    p.motion = MOTION_ROLLING
+  elif mname == "HandEye":
+    p.motion = MOTION_HAND_EYE
+    p.base_wrt_gripper = _f64(motion.base_wrt_gripper.poses)
+  elif mname == "StaticFrames":
+    p.motion = MOTION_STATIC
+  else:
+    raise TypeError(f"unsupported motion model {mname}")
+
+  cams = list(calib.cameras)
+  fisheye = [_class_name(c) == "CameraFisheye" or getattr(c, "model", None) == "fisheye" for c in cams]
+  if any(fisheye) != all(fisheye):
+    raise ValueError("mixed pinhole / fisheye cameras are not supported")
+  p.camera_model = CAMERA_FISHEYE if all(fisheye) else CAMERA_PINHOLE
+  nd = {int(np.asarray(c.dist).size) for c in cams}
+  if len(nd) != 1:
+    raise ValueError(f"cameras carry different numbers of distortion coefficients: {sorted(nd)}")
+  p.n_dist = nd.pop()
+  p.image_heights = _f64([c.image_size[1] for c in cams])
+  p.fix_aspect = _u8([bool(c.fix_aspect) for c in cams])
+
+  p.optimize = _optimize_bits(calib.optimize)
+  # all five parameter blocks in reference order (calibration.py:146-153), enabled or not
+  objs = calib.param_objects
+  p.x_full = _f64(np.concatenate([np.asarray(objs[k].param_vec, dtype=np.float64).ravel() for k in PARAM_ORDER]))
+  p.block_sizes = [int(np.asarray(objs[k].param_vec).size) for k in PARAM_ORDER]
+  p.n_params = sum(n for k, n in zip(PARAM_ORDER, p.block_sizes) if calib.optimize[k] is True)
+  return p
+
+
+def _to_struct(p, frame_range=None):
+  C_, F, B, P = p.shape
+  s = Problem()
+  s.version = _lib.MCBA_VERSION
+  s.n_cameras, s.n_frames, s.n_boards, s.n_points = C_, F, B, P
+  s.points = _ptr(p.points, C.c_double)
+  s.point_valid = _ptr(p.point_valid, C.c_uint8)
+  s.inlier_mask = None if p.inlier_mask is None else _ptr(p.inlier_mask, C.c_uint8)
+  s.board_sizes = _ptr(p.board_sizes, C.c_int32)
+  s.camera_valid = _ptr(p.camera_valid, C.c_uint8)
+  s.frame_valid = _ptr(p.frame_valid, C.c_uint8)
+  s.board_valid = _ptr(p.board_valid, C.c_uint8)
+  s.motion, s.camera_model, s.n_dist = p.motion, p.camera_model, p.n_dist
+  s.image_heights = _ptr(p.image_heights, C.c_double)
+  s.fix_aspect = _ptr(p.fix_aspect, C.c_uint8)
+  s.base_wrt_gripper = None if p.base_wrt_gripper is None else _ptr(p.base_wrt_gripper, C.c_double)
+  s.optimize = p.optimize
+  s.x_full = _ptr(p.x_full, C.c_double)
+  s.frame_begin, s.frame_end = (0, 0) if frame_range is None else frame_range
+  return s
+
+
+def make_options(tolerance=1e-4, f_scale=1.0, max_iterations=100, loss='linear', xtol=1e-8, gtol=1e-8, verbose=2):
+  if loss not in LOSSES:
+    raise ValueError(f"`loss` must be one of {list(LOSSES)} or a callable.")   # scipy's message
+  o = Options()
+  o.ftol, o.xtol, o.gtol = float(tolerance), float(xtol), float(gtol)
+  o.max_nfev = int(max_iterations)
+  o.loss = LOSSES[loss]
+  o.f_scale = float(f_scale)
+  o.verbose = int(verbose)
+  return o
+
+
+STATUS_MESSAGES = {   # scipy/optimize/_lsq/least_squares.py TERMINATION_MESSAGES
+  -1: "Improper input parameters status returned from `leastsq`",
+  0: "The maximum number of function evaluations is exceeded.",
+  1: "`gtol` termination condition is satisfied.",
+  2: "`ftol` termination condition is satisfied.",
+  3: "`xtol` termination condition is satisfied.",
+  4: "Both `ftol` and `xtol` termination conditions are satisfied.",
+}
+
+
+class Handle(object):
+  """Owns one mcba_handle (device tables of one Calibration).  Not picklable by design: Calibration objects hold no
+  handle (calibration.py:222-226 pickles only the 8 constructor fields); handles are created per call."""
+
+  def __init__(self, calib_or_problem, frame_range=None, stream=None):
+    self.lib = _lib.load()
+    self.problem = calib_or_problem if isinstance(calib_or_problem, SimpleNamespace) else lower(calib_or_problem)
+    self._struct = _to_struct(self.problem, frame_range)
+    h = C.c_void_p()
+    check(self.lib.mcba_create(C.byref(self._struct), C.c_void_p(stream) if stream else None, C.byref(h)))
+    self.h = h
+    n = C.c_int64()
+    check(self.lib.mcba_num_params(self.h, C.byref(n)))
+    self.n_params = n.value
+    self._callbacks = []
+    self.shape = self.problem.shape
+
+  def close(self):
+    if getattr(self, "h", None):
+      self.lib.mcba_destroy(self.h)
+      self.h = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:
+      pass
+
+  def __enter__(self):
+    return self
+
+  def __exit__(self, *a):
+    self.close()
+
+  # --- info ---------------------------------------------------------------------------------------------------
+  @property
+  def n_residuals(self):
+    n = C.c_int64()
+    check(self.lib.mcba_num_residuals(self.h, C.byref(n)))
+    return n.value
+
+  def device_info(self):
+    buf = C.create_string_buffer(256)
+    check(self.lib.mcba_device_info(self.h, buf, 256))
+    return buf.value.decode()
+
+  def set_mfma(self, on):
+    check(self.lib.mcba_set_mfma(self.h, 1 if on else 0))
+
+  def set_inliers(self, mask):
+    if mask is None:
+      check(self.lib.mcba_set_inliers(self.h, None))
+    else:
+      m = _u8(mask)
+      assert m.shape == tuple(self.shape), f"inlier mask shape {m.shape} != {self.shape}"
+      check(self.lib.mcba_set_inliers(self.h, _ptr(m, C.c_uint8)))
+
+  def _x(self, x):
+    x = _f64(x)
+    assert x.shape == (self.n_params,), f"inconsistent parameter sizes, got {x.size}, expected {self.n_params}"
+    return x
+
+  # --- evaluation ---------------------------------------------------------------------------------------------
+  def residuals(self, x):
+    x = self._x(x)
+    r = np.empty(self.n_residuals)
+    check(self.lib.mcba_residuals(self.h, _ptr(x, C.c_double), _ptr(r, C.c_double)))
+    return r
+
+  def jacobian(self, x):
+    """scipy.sparse.csr_matrix [n_residuals, n_params] in the reference's sparsity pattern."""
+    from scipy.sparse import csr_matrix
+    x = self._x(x)
+    nnz = C.c_int32()
+    check(self.lib.mcba_jacobian(self.h, None, C.byref(nnz), None, None))
+    k = nnz.value
+    m = self.n_residuals
+    vals = np.empty((m, k))
+    cols = np.empty((m // 2, k), dtype=np.int32)
+    check(self.lib.mcba_jacobian(self.h, _ptr(x, C.c_double), C.byref(nnz), _ptr(vals, C.c_double),
+                                 _ptr(cols, C.c_int32)))
+    indices = np.repeat(cols, 2, axis=0).ravel()
+    indptr = np.arange(0, m * k + 1, k)
+    return csr_matrix((vals.ravel(), indices, indptr), shape=(m, self.n_params))
+
+  def reprojection_error(self, x):
+    x = self._x(x)
+    err = np.empty(self.shape)
+    valid = np.empty(self.shape, dtype=np.uint8)
+    check(self.lib.mcba_reprojection_error(self.h, _ptr(x, C.c_double), _ptr(err, C.c_double), _ptr(valid, C.c_uint8)))
+    return err, valid.astype(bool)
+
+  def project(self, x):
+    x = self._x(x)
+    out = np.empty(tuple(self.shape) + (2,))
+    check(self.lib.mcba_project(self.h, _ptr(x, C.c_double), _ptr(out, C.c_double)))
+    return out
+
+  def normal_equations(self, x, loss='linear', f_scale=1.0):
+    x = self._x(x)
+    opt = make_options(loss=loss, f_scale=f_scale)
+    cost = C.c_double()
+    g = np.empty(self.n_params)
+    diag = np.empty(self.n_params)
+    check(self.lib.mcba_normal_equations(self.h, _ptr(x, C.c_double), C.byref(opt), C.byref(cost),
+                                         _ptr(g, C.c_double), _ptr(diag, C.c_double)))
+    return cost.value, g, diag
+
+  def dense_hessian(self):
+    H = np.empty((self.n_params, self.n_params))
+    check(self.lib.mcba_dense_hessian(self.h, _ptr(H, C.c_double)))
+    return H
+
+  def debug_gn_step(self, reg):
+    gn = np.empty(self.n_params)
+    gh = np.empty(self.n_params)
+    si = np.empty(self.n_params)
+    check(self.lib.mcba_debug_gn_step(self.h, float(reg), _ptr(gn, C.c_double), _ptr(gh, C.c_double),
+                                      _ptr(si, C.c_double)))
+    return gn, gh, si
+
+  # --- solve --------------------------------------------------------------------------------------------------
+  def set_log(self, fn):
+    """fn(iteration, nfev, cost, cost_reduction, step_norm, optimality) or None."""
+    if fn is None:
+      cb = C.cast(None, _lib.LOG_FN)
+    else:
+      cb = _lib.LOG_FN(lambda ctx, it, nfev, cost, red, step, opt: fn(it, nfev, cost, red, step, opt))
+    self._callbacks.append(cb)
+    check(self.lib.mcba_set_log(self.h, cb, None))
+
+  def set_allreduce(self, fn):
+    """fn(device_ptr:int, count:int, op:int, stream:int) -> int (0 = ok); see multical_amd.distributed."""
+    if fn is None:
+      cb = C.cast(None, _lib.ALLREDUCE_FN)
+    else:
+      def tramp(ctx, buf, count, op, stream):
+        try:
+          return int(fn(buf or 0, count, op, stream or 0) or 0)
+        except Exception as e:   # never let an exception cross the C boundary
+          import traceback
+          traceback.print_exc()
+          return 1
+      cb = _lib.ALLREDUCE_FN(tramp)
+    self._callbacks.append(cb)
+    check(self.lib.mcba_set_allreduce(self.h, cb, None))
+
+  def solve(self, x0, tolerance=1e-4, f_scale=1.0, max_iterations=100, loss='linear', xtol=1e-8, gtol=1e-8,
+            verbose=2):
+    x = self._x(x0).copy()
+    opt = make_options(tolerance, f_scale, max_iterations, loss, xtol, gtol, verbose)
+    res = Result()
+    check(self.lib.mcba_solve(self.h, _ptr(x, C.c_double), C.byref(opt), C.byref(res)))
+    return SimpleNamespace(x=x, cost=res.cost, initial_cost=res.initial_cost, optimality=res.optimality,
+                           nfev=res.nfev, njev=res.njev, status=res.status, iterations=res.iterations,
+                           message=STATUS_MESSAGES.get(res.status, ""), solve_seconds=res.solve_seconds,
+                           linearize_seconds=res.linearize_seconds, success=res.status > 0)
+
+  # --- measurement --------------------------------------------------------------------------------------------
+  def time_linearize(self, x, repeats=20, loss='linear', f_scale=1.0):
+    x = self._x(x)
+    opt = make_options(loss=loss, f_scale=f_scale)
+    ms = C.c_double()
+    check(self.lib.mcba_time_linearize(self.h, _ptr(x, C.c_double), C.byref(opt), int(repeats), C.byref(ms)))
+    return ms.value
+
+  def time_residuals(self, x, repeats=20):
+    x = self._x(x)
+    ms = C.c_double()
+    check(self.lib.mcba_time_residuals(self.h, _ptr(x, C.c_double), int(repeats), C.byref(ms)))
+    return ms.value
+
+
+def mfma_probe(V):
+  lib = _lib.load()
+  V = _f64(V)
+  assert V.shape == (4, 32)
+  out = np.empty((16, 16))
+  check(lib.mcba_debug_mfma_probe(_ptr(V, C.c_double), _ptr(out, C.c_double)))
+  return out

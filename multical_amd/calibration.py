@@ -1,0 +1,308 @@
+"""Host mirror of multical.optimization.calibration.Calibration (optimization/calibration.py:43-310) whose numerical
+work runs on the MI355X back-end.
+
+Same constructor, same immutable-copy style, same parameter ordering and the same public methods as the reference
+class, so that callers written against the reference (Workspace.calibrate, workspace.py:228-247) work unchanged:
+
+    bundle_adjust(tolerance, f_scale, max_iterations, loss)   calibration.py:199-212   -> mcba_solve
+    reprojected / reprojection_error / reprojection_inliers    calibration.py:124-141   -> mcba_project / _error
+    reject_outliers / adjust_outliers / report                 calibration.py:234-300
+    enable / copy / params / with_params / param_vec           calibration.py:144-171,214-232
+
+Objects hold no device state: like the reference only the 8 constructor fields are pickled (calibration.py:222-226);
+device handles live in a small module-level cache keyed on the observation table.
+"""
+import logging
+from functools import cached_property
+
+import numpy as np
+
+from . import parameters
+from .backend import Handle, lower
+from .structs import Struct, Table, struct, choose, subset
+
+logger = logging.getLogger("calibration")   # same logger name as multical/io/logging.py:11
+
+
+def info(msg):
+  logger.info(msg)
+
+
+default_optimize = struct(cameras=False, boards=False, camera_poses=True, board_poses=True, motion=True)
+
+
+def select_threshold(quantile=0.75, factor=5.0):
+  """calibration.py:37-40."""
+  def f(reprojection_error):
+    return np.quantile(reprojection_error, quantile) * factor
+  return f
+
+
+def error_stats(errors):
+  """calibration.py:304-310."""
+  if len(errors) == 0:
+    errors = np.zeros((1, 1), np.float32)
+  mse = np.square(errors).mean()
+  quantiles = np.array([np.quantile(errors, n) for n in [0, 0.25, 0.5, 0.75, 1]])
+  return struct(mse=mse, rms=np.sqrt(mse), quantiles=quantiles, n=errors.size)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# device-handle cache (never pickled, never part of a Calibration)
+# ---------------------------------------------------------------------------------------------------------------
+class _HandleCache(object):
+  def __init__(self, capacity=2):
+    self.capacity = capacity
+    self.entries = []   # (key, x_full, handle, inlier_token)
+
+  def get(self, calib):
+    prob = lower(calib)
+    key = (id(calib.point_table.points), prob.shape, prob.optimize, prob.motion, prob.camera_model, prob.n_dist,
+           prob.fix_aspect.tobytes(), prob.camera_valid.tobytes(), prob.frame_valid.tobytes(),
+           prob.board_valid.tobytes(), prob.board_sizes.tobytes())
+    for i, (k, xf, h, tok) in enumerate(self.entries):
+      if k == key and h.h and np.array_equal(self._constants(calib, prob, xf), self._constants(calib, prob, prob.x_full)) \
+          and (prob.base_wrt_gripper is None or np.array_equal(prob.base_wrt_gripper, h.problem.base_wrt_gripper)):
+        mask = calib.inlier_mask
+        new_tok = None if mask is None else hash(np.asarray(mask).tobytes())
+        if new_tok != tok:
+          h.set_inliers(mask)
+          self.entries[i] = (k, xf, h, new_tok)
+        return h, prob
+    h = Handle(prob)
+    tok = None if calib.inlier_mask is None else hash(np.asarray(calib.inlier_mask).tobytes())
+    self.entries.append((key, prob.x_full, h, tok))
+    while len(self.entries) > self.capacity:
+      _, _, old, _ = self.entries.pop(0)
+      old.close()
+    return h, prob
+
+  @staticmethod
+  def _constants(calib, prob, x_full):
+    """values of the DISABLED blocks (the only part of x_full the device keeps)."""
+    out, pos = [], 0
+    for k, n in zip(parameters_order(), prob.block_sizes):
+      if calib.optimize[k] is not True:
+        out.append(x_full[pos:pos + n])
+      pos += n
+    return np.concatenate(out) if out else np.zeros(0)
+
+  def clear(self):
+    for _, _, h, _ in self.entries:
+      h.close()
+    self.entries = []
+
+
+def parameters_order():
+  return ["camera_poses", "board_poses", "motion", "cameras", "boards"]
+
+
+handle_cache = _HandleCache()
+
+
+class Calibration(parameters.Parameters):
+  def __init__(self, cameras, boards, point_table, camera_poses, board_poses, motion, inlier_mask=None,
+               optimize=default_optimize):
+    self.cameras = cameras
+    self.boards = boards
+    self.point_table = point_table
+    self.camera_poses = camera_poses
+    self.board_poses = board_poses
+    self.motion = motion
+    self.optimize = optimize
+    self.inlier_mask = inlier_mask
+
+    assert len(self.cameras) == self.size.cameras
+    assert camera_poses.size == self.size.cameras
+    assert board_poses.size == self.size.boards
+
+  # --- shapes and masks (calibration.py:63-81) --------------------------------------------------------------
+  @cached_property
+  def size(self):
+    cameras, rig_poses, boards, points = self.point_table.valid.shape
+    return struct(cameras=cameras, rig_poses=rig_poses, boards=boards, points=points)
+
+  @cached_property
+  def valid(self):
+    valid = (np.expand_dims(self.camera_poses.valid, [1, 2]) & np.expand_dims(self.motion.valid, [0, 2]) &
+             np.expand_dims(self.board_poses.valid, [0, 1]))
+    return self.point_table.valid & np.expand_dims(valid, valid.ndim)
+
+  @cached_property
+  def inliers(self):
+    return choose(self.inlier_mask, self.valid)
+
+  # --- parameters (calibration.py:144-171) ------------------------------------------------------------------
+  @cached_property
+  def param_objects(self):
+    return struct(camera_poses=self.camera_poses, board_poses=self.board_poses, motion=self.motion,
+                  cameras=self.cameras, boards=self.boards)
+
+  @cached_property
+  def params(self):
+    all_params = self.param_objects._map(lambda p: p.param_vec)
+    return all_params._filterWithKey(lambda k: self.optimize[k] is True)
+
+  def with_params(self, params):
+    updated = {k: self.param_objects[k].with_param_vec(param_vec) for k, param_vec in params.items()}
+    return self.copy(**updated)
+
+  def enable(self, **flags):
+    for k in flags.keys():
+      assert k in self.optimize, f"unknown option {k}, options are {list(self.optimize.keys())}"
+    return self.copy(optimize=self.optimize._extend(**flags))
+
+  def __getstate__(self):
+    attrs = ['cameras', 'boards', 'point_table', 'camera_poses', 'board_poses', 'motion', 'inlier_mask', 'optimize']
+    return subset(self.__dict__, attrs)
+
+  def __setstate__(self, d):
+    self.__dict__.update(d)
+
+  def copy(self, **k):
+    d = self.__getstate__()
+    d.update(k)
+    return Calibration(**d)
+
+  # --- device evaluation ------------------------------------------------------------------------------------
+  def _handle(self):
+    return handle_cache.get(self)[0]
+
+  @cached_property
+  def reprojected(self):
+    """calibration.py:124-130 (rolling-shutter scan time from the measured points)."""
+    h = self._handle()
+    points = h.project(self.param_vec)
+    _, valid = h.reprojection_error(self.param_vec)
+    # reprojected.valid of the reference = pose validity & board-point validity (no detection mask)
+    C, F, B, P = self.point_table.valid.shape
+    pose_valid = (np.expand_dims(self.camera_poses.valid, [1, 2, 3]) & np.expand_dims(self.motion.valid, [0, 2, 3]) &
+                  np.expand_dims(self.board_poses.valid, [0, 1, 3]))
+    sizes = np.array([b.num_points for b in self.boards])
+    board_valid = np.arange(P)[None, :] < sizes[:, None]
+    return Table.create(points=points, valid=pose_valid & board_valid[None, None])
+
+  def _errors(self):
+    """tables.reprojection_error (tables.py:244-249) of (reprojected, point_table) on the device."""
+    return self._handle().reprojection_error(self.param_vec)
+
+  @cached_property
+  def reprojection_error(self):
+    err, mask = self._errors()
+    return err[mask]
+
+  @cached_property
+  def reprojection_inliers(self):
+    err, mask = self._errors()
+    # calibration.py:138-141: point_table with valid := inliers, masked with reprojected.valid
+    return err[self.reprojected.valid & choose(self.inliers, self.valid)]
+
+  def residuals(self, param_vec=None):
+    """`evaluate` of calibration.py:204-206."""
+    return self._handle().residuals(self.param_vec if param_vec is None else param_vec)
+
+  def jacobian(self, param_vec=None):
+    return self._handle().jacobian(self.param_vec if param_vec is None else param_vec)
+
+  # --- solve (calibration.py:199-212) -----------------------------------------------------------------------
+  def bundle_adjust(self, tolerance=1e-4, f_scale=1.0, max_iterations=100, loss='linear', return_result=False,
+                    xtol=1e-8, gtol=1e-8):
+    """Non-linear least squares on point reprojection error, solved on the GPU (mcba_solve).
+
+    Keeps the reference's signature and semantics; the iteration table scipy prints with verbose=2 is emitted in the
+    same format through the "calibration" logger (calibration.py:208, io/logging.py:53-68)."""
+    h = self._handle()
+    rows = []
+
+    def log_row(it, nfev, cost, red, step, opt):
+      red_s = " " * 15 if np.isnan(red) else f"{red:^15.2e}"
+      step_s = " " * 15 if np.isnan(step) else f"{step:^15.2e}"
+      rows.append(f"{it:^15}{nfev:^15}{cost:^15.4e}{red_s}{step_s}{opt:^15.2e}")
+
+    h.set_log(log_row)
+    info("{:^15}{:^15}{:^15}{:^15}{:^15}{:^15}".format("Iteration", "Total nfev", "Cost", "Cost reduction",
+                                                       "Step norm", "Optimality"))
+    res = h.solve(self.param_vec, tolerance=tolerance, f_scale=f_scale, max_iterations=max_iterations, loss=loss,
+                  xtol=xtol, gtol=gtol, verbose=2)
+    for r in rows:
+      info(r)
+    info(res.message)
+    info(f"Function evaluations {res.nfev}, initial cost {res.initial_cost:.4e}, final cost {res.cost:.4e}, "
+         f"first-order optimality {res.optimality:.2e}.")
+    out = self.with_param_vec(res.x)
+    return (out, res) if return_result else out
+
+  # --- outliers (calibration.py:234-268) --------------------------------------------------------------------
+  def reject_outliers_quantile(self, quantile=0.95, factor=1.0):
+    threshold = np.quantile(self.reprojection_error, quantile)
+    return self.reject_outliers(threshold=threshold * factor)
+
+  def reject_outliers(self, threshold):
+    errors, valid = self._errors()
+    inliers = (errors < threshold) & valid
+    num_outliers = valid.sum() - inliers.sum()
+    inlier_percent = 100.0 * inliers.sum() / max(valid.sum(), 1)
+    info(f"Rejecting {num_outliers} outliers with error > {threshold:.2f} pixels, "
+         f"keeping {inliers.sum()} / {valid.sum()} inliers, ({inlier_percent:.2f}%)")
+    return self.copy(inlier_mask=inliers)
+
+  def adjust_outliers(self, num_adjustments=3, select_scale=None, select_outliers=None, **kwargs):
+    info(f"Beginning adjustments ({num_adjustments}) enabled: {dict(self.optimize)}, options: {kwargs}")
+    for i in range(num_adjustments):
+      self.report(f"Adjust_outliers {i}:")
+      f_scale = (None if select_scale is None else select_scale(self.reprojection_error)) or 1.0
+      if select_scale is not None:
+        info(f"Auto scaling for outliers influence at {f_scale:.2f} pixels")
+      if select_outliers is not None:
+        self = self.reject_outliers(select_outliers(self.reprojection_error))
+      self = self.bundle_adjust(f_scale=f_scale, **kwargs)
+    self.report("Adjust_outliers end:")
+    return self
+
+  def report(self, stage=""):
+    overall = error_stats(self.reprojection_error)
+    inliers = error_stats(self.reprojection_inliers)
+    if self.inlier_mask is not None:
+      info(f"{stage} reprojection RMS={inliers.rms:.3f} ({overall.rms:.3f}), "
+           f"n={inliers.n} ({overall.n}), quantiles={overall.quantiles}")
+    else:
+      info(f"{stage} reprojection RMS={overall.rms:.3f}, n={overall.n}, quantiles={overall.quantiles}")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# builder from a synthetic rig (multical_amd.synthetic.make_rig)
+# ---------------------------------------------------------------------------------------------------------------
+def from_rig(rig, which='init'):
+  from .board import Board
+  from .camera import Camera, CameraFisheye
+  from .motion import StaticFrames, RollingFrames, HandEye
+  from .parameters import ParamList
+  from .pose_set import PoseSet
+
+  src = getattr(rig, which)
+  C, F, B, P = rig.valid.shape
+  cam_names = [f"cam{i}" for i in range(C)]
+  board_names = [f"board{i}" for i in range(B)]
+  frame_names = [f"frame{i}" for i in range(F)]
+  cameras = []
+  for c in src.cameras:
+    if c.model == 'fisheye':
+      cameras.append(CameraFisheye(c.image_size, c.intrinsic, c.dist, fix_aspect=c.fix_aspect, has_skew=c.has_skew))
+    else:
+      cameras.append(Camera(c.image_size, c.intrinsic, c.dist, model=c.model, fix_aspect=c.fix_aspect,
+                            has_skew=c.has_skew))
+  boards = [Board(p, name=n) for p, n in zip(rig.board_points, board_names)]
+  kind = rig.cfg["motion"]
+  if kind == 'static':
+    motion = StaticFrames(Table.create(poses=src.rig, valid=rig.frame_valid), frame_names)
+  elif kind == 'rolling':
+    motion = RollingFrames(src.rig, src.rig_end, rig.frame_valid, frame_names)
+  else:
+    he = src.hand_eye
+    motion = HandEye(Table.create(poses=he.base_wrt_gripper, valid=rig.frame_valid), he.world_wrt_base,
+                     he.gripper_wrt_camera, frame_names)
+  calib = Calibration(ParamList(cameras, cam_names), ParamList(boards, board_names),
+                      Table.create(points=rig.points, valid=rig.valid),
+                      PoseSet(Table.create(poses=src.camera_poses, valid=rig.camera_valid), cam_names),
+                      PoseSet(Table.create(poses=src.board_poses, valid=rig.board_valid), board_names), motion)
+  return calib.enable(**rig.optimize)

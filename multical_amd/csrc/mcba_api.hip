@@ -1,0 +1,884 @@
+// mcba_api.hip -- C ABI (include/mcba.h) + host driver of the MI355X bundle-adjustment back-end.
+//
+// Host side of the path that replaces Calibration.bundle_adjust (multical/optimization/calibration.py:199-212):
+//   * lowering of the flat problem description to frame-major device tables (mcba_create)
+//   * launch sequences for evaluate() / Jacobian / fused normal equations
+//   * the trust-region loop.  It mirrors scipy's `trf_no_bounds` (scipy/optimize/_lsq/trf.py:401-560), the solver
+//     the reference calls at calibration.py:209-210, step for step -- x_scale='jac' column scaling, Cauchy-step
+//     regularisation, 2-D subspace {g, regularised Gauss-Newton step}, radius update, ftol/xtol/gtol tests -- with
+//     ONE substitution: the regularised Gauss-Newton step that scipy gets from LSMR on a finite-difference sparse
+//     Jacobian is computed exactly from the analytic normal equations (Schur elimination of the per-frame pose blocks
+//     + dense Cholesky of the reduced system), all on the GPU.  Only 2x2 algebra and control flow run on the host.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <complex>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/mcba.h"
+#include "mcba_camops.h"
+#include "mcba_lower.h"
+#include "mcba_solver_kernels.h"
+
+using namespace mcba;
+
+namespace {
+
+thread_local std::string g_error;
+
+struct Error : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+#define HIP_OK(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t e_ = (expr);                                                                            \
+    if (e_ != hipSuccess) throw Error(std::string(#expr) + " failed: " + hipGetErrorString(e_));        \
+  } while (0)
+
+#define REQUIRE(cond, msg)                 \
+  do {                                     \
+    if (!(cond)) throw Error(msg);         \
+  } while (0)
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  void alloc(size_t count, bool zero = true) {
+    release();
+    n = count;
+    const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    HIP_OK(hipMalloc((void**)&p, bytes));
+    if (zero) HIP_OK(hipMemset(p, 0, bytes));
+  }
+  void upload(const std::vector<T>& h) {
+    alloc(h.size(), h.empty());
+    if (!h.empty()) HIP_OK(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  }
+};
+
+constexpr double REG_FLOOR = 1e-10;   // floor of the Levenberg-Marquardt damping in the scaled space (gauge null space)
+constexpr int COST_BLOCKS_MAX = 1024;
+constexpr int N_SCALARS = 32;
+
+}  // namespace
+
+struct mcba_handle_s {
+  Dims d{};
+  Tables t{};
+  const CamOps* ops = nullptr;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  bool use_mfma = true;
+
+  // host copies needed to rebuild the inlier tables
+  std::vector<uint8_t> h_valid_ref;    // Calibration.valid, [C,F,B,P] reference order
+  int64_t n_inliers = 0;
+
+  // observation tables
+  DevBuf<double2> obs;
+  DevBuf<uint8_t> inlier, evalid, fix_aspect;
+  DevBuf<int32_t> obs_index, view_count, board_off, full2act;
+  DevBuf<double> xfull, bwg, img_h, board_points, pose, cam, view;
+  DevBuf<uint16_t> tri;
+
+  // linearisation
+  DevBuf<double> rec, partial, Hss, Hfs, Hff, gbuf;   // gbuf = [g (n) | diag (n) | cost, count]
+  int nchunk = 1;
+  // solver state
+  DevBuf<double> x, xnew, scale_inv, dsc, gh, gn, scal, qpart, costpart, Lf, W, yf, P, sbuf, ps;
+  DevBuf<int32_t> info;
+  double* h_scal = nullptr;   // pinned
+  int ntile = 0, ksplit = 1, cost_blocks = 1;
+
+  // outputs staging
+  DevBuf<double> out_r, out_big;
+  DevBuf<uint8_t> out_valid;
+  DevBuf<int32_t> out_cols;
+
+  mcba_allreduce_fn allreduce = nullptr;
+  void* allreduce_ctx = nullptr;
+  mcba_log_fn log = nullptr;
+  void* log_ctx = nullptr;
+
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+  ~mcba_handle_s() {
+    if (h_scal) (void)hipHostFree(h_scal);
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    if (own_stream && stream) (void)hipStreamDestroy(stream);
+  }
+  double* g() { return gbuf.p; }
+  double* diag() { return gbuf.p + d.n; }
+  double* costcount() { return gbuf.p + 2 * (size_t)d.n; }
+};
+
+namespace {
+
+const CamOps* pick_ops(int model, int nd) {
+  if (model == MCBA_CAMERA_FISHEYE) {
+    REQUIRE(nd == 4, "fisheye cameras carry 4 distortion coefficients (camera_fisheye.py:113-117)");
+    return cam_ops_fish4();
+  }
+  switch (nd) {
+    case 4: return cam_ops_pin4();
+    case 5: return cam_ops_pin5();
+    case 8: return cam_ops_pin8();
+    case 12: return cam_ops_pin12();
+    case 14: return cam_ops_pin14();
+  }
+  throw Error("pinhole cameras carry 4, 5, 8, 12 or 14 distortion coefficients (cv2.projectPoints)");
+}
+
+// (re)build inlier table, residual ordering and per-view counts for the shard; mask in reference order or null
+void build_inliers(mcba_handle_s* h, const uint8_t* mask_ref) {
+  HostProblem hp;
+  hp.d = h->d;
+  hp.valid_ref = h->h_valid_ref;
+  lower_inliers(hp, mask_ref);
+  const size_t nslot = (size_t)h->d.slots();
+  h->n_inliers = hp.n_inliers;
+  HIP_OK(hipMemcpy(h->inlier.p, hp.inlier.data(), nslot, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(h->obs_index.p, hp.obs_index.data(), nslot * sizeof(int32_t), hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(h->view_count.p, hp.view_count.data(), hp.view_count.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  h->out_r.alloc((size_t)std::max<int64_t>(2 * hp.n_inliers, 1), false);
+}
+
+void set_loss(mcba_handle_s* h, const mcba_options* opt) {
+  h->d.loss = opt ? opt->loss : MCBA_LOSS_LINEAR;
+  h->d.f_scale = opt ? opt->f_scale : 1.0;
+  REQUIRE(h->d.loss >= 0 && h->d.loss <= 4, "unknown loss");
+  REQUIRE(h->d.loss == 0 || h->d.f_scale > 0, "f_scale must be positive");
+}
+
+void upload_x(mcba_handle_s* h, const double* x, double* dst) {
+  HIP_OK(hipMemcpyAsync(dst, x, (size_t)h->d.n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+}
+
+// x (device) -> pose / camera / view tables
+void eval_tables(mcba_handle_s* h, const double* dx) {
+  const Dims& d = h->d;
+  const int items = d.n_pose + d.C + d.B * d.P;
+  hipLaunchKernelGGL(k_prep, dim3((items + 127) / 128), dim3(128), 0, h->stream, d, h->t, dx);
+  const int nv = d.views() * (d.motion == MOTION_ROLLING ? 2 : 1);
+  if (nv > 0) hipLaunchKernelGGL(k_views, dim3((nv + 127) / 128), dim3(128), 0, h->stream, d, h->t);
+}
+
+int call_allreduce(mcba_handle_s* h, double* buf, size_t count, int op) {
+  if (!h->allreduce) return 0;
+  const int rc = h->allreduce(h->allreduce_ctx, buf, count, op, (void*)h->stream);
+  if (rc != 0) throw Error("all-reduce hook failed with code " + std::to_string(rc));
+  return 0;
+}
+
+// cost at the current tables -> costpart[0] on the device (reduced across ranks)
+void launch_cost(mcba_handle_s* h, double* out_dev) {
+  h->ops->cost(h->d, h->t, h->stream, h->costpart.p, h->cost_blocks);
+  hipLaunchKernelGGL(k_sum, dim3(1), dim3(256), 0, h->stream, h->costpart.p, h->cost_blocks, out_dev);
+  call_allreduce(h, out_dev, 1, 0);
+}
+
+// fused residual+Jacobian -> block normal equations at the current tables
+void launch_linearize(mcba_handle_s* h) {
+  const Dims& d = h->d;
+  h->ops->linearize(d, h->t, h->stream, h->rec.p, h->tri.p, h->use_mfma);
+}
+
+void launch_assemble(mcba_handle_s* h) {
+  const Dims& d = h->d;
+  if (d.DF > 0 && d.Fl > 0)
+    hipLaunchKernelGGL(k_assemble_frames, dim3(d.Fl), dim3(256), 0, h->stream, d, h->t, h->rec.p, h->Hff.p, h->Hfs.p,
+                       h->g(), h->diag());
+  hipLaunchKernelGGL(k_shared_partial, dim3(d.C * d.B, h->nchunk), dim3(256), 0, h->stream, d, h->t, h->rec.p,
+                     h->nchunk, h->partial.p);
+  hipLaunchKernelGGL(k_shared_final, dim3(1), dim3(1024), 0, h->stream, d, h->partial.p, h->nchunk, h->tri.p, h->Hss.p,
+                     h->g(), h->diag(), h->costcount());
+  call_allreduce(h, h->gbuf.p, 2 * (size_t)d.n + 2, 0);
+}
+
+void sync(mcba_handle_s* h) { HIP_OK(hipStreamSynchronize(h->stream)); }
+
+void fetch_scalars(mcba_handle_s* h, int count) {
+  HIP_OK(hipMemcpyAsync(h->h_scal, h->scal.p, count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  sync(h);
+}
+
+// quadratic forms + dots of (u0, u1) -> scal[off .. off+6)
+void launch_quadforms(mcba_handle_s* h, const double* u0, const double* u1, int off) {
+  const Dims& d = h->d;
+  const int nblk = (d.DF > 0 ? d.Fl : 0) + 1;
+  hipLaunchKernelGGL(k_quadforms, dim3(nblk), dim3(256), 0, h->stream, d, h->Hss.p, h->Hfs.p, h->Hff.p, h->dsc.p, u0, u1,
+                     h->qpart.p);
+  hipLaunchKernelGGL(k_quadforms_final, dim3(1), dim3(256), 0, h->stream, d, h->qpart.p, nblk, u0, u1, h->scal.p + off);
+  call_allreduce(h, h->scal.p + off, 3, 0);
+}
+
+// gn = (H_h + reg I)^-1 g_h  through the Schur complement of the per-frame blocks
+void launch_gn_solve(mcba_handle_s* h, double reg, bool root_rank) {
+  const Dims& d = h->d;
+  const int K = d.DF * d.Fl;
+  HIP_OK(hipMemsetAsync(h->gn.p, 0, (size_t)d.n * sizeof(double), h->stream));
+  if (K > 0) {
+    hipLaunchKernelGGL(k_schur_frames, dim3(d.Fl), dim3(128), 0, h->stream, d, h->Hfs.p, h->Hff.p, h->dsc.p, h->gh.p, reg,
+                       h->Lf.p, h->W.p, h->yf.p);
+    const int nt2 = h->ntile * (h->ntile + 1) / 2;
+    if (h->use_mfma)
+      hipLaunchKernelGGL((k_schur_syrk<true>), dim3(nt2, h->ksplit), dim3(64), 0, h->stream, K, d.ns, h->ntile, h->ksplit,
+                         h->W.p, h->P.p);
+    else
+      hipLaunchKernelGGL((k_schur_syrk<false>), dim3(nt2, h->ksplit), dim3(64), 0, h->stream, K, d.ns, h->ntile,
+                         h->ksplit, h->W.p, h->P.p);
+  }
+  const int total = d.ns * d.ns + d.ns;
+  hipLaunchKernelGGL(k_schur_reduce, dim3(std::min(1024, (total + 255) / 256)), dim3(256), 0, h->stream, d, h->Hss.p,
+                     h->dsc.p, h->gh.p, h->P.p, h->ntile, h->ksplit, h->W.p, h->yf.p, K, root_rank ? 1.0 : 0.0,
+                     h->sbuf.p);
+  call_allreduce(h, h->sbuf.p, (size_t)total, 0);
+  hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(1024), 0, h->stream, d.ns, reg, h->sbuf.p, h->ps.p, h->info.p);
+  const int nblk = (K > 0 ? d.Fl : 0) + 1;
+  hipLaunchKernelGGL(k_schur_backsub, dim3(nblk), dim3(128), 0, h->stream, d, h->Lf.p, h->W.p, h->yf.p, h->ps.p, h->gn.p);
+  if (h->allreduce && K > 0) {
+    // frame entries of gn are known only to the owning rank: zero the (replicated) shared entries on non-root ranks
+    // is not needed -- every rank holds identical p_s; sum only the frame block.
+    call_allreduce(h, h->gn.p + d.off_motion, (size_t)d.n_motion, 0);
+  }
+}
+
+// ---- host-side 2-D trust-region algebra (scipy/optimize/_lsq/common.py) ---------------------------------------
+void minimize_quadratic_1d(double a, double b, double lb, double ub, double* t_out, double* y_out) {
+  double t[3] = {lb, ub, 0};
+  int n = 2;
+  if (a != 0) {
+    const double ext = -0.5 * b / a;
+    if (lb < ext && ext < ub) t[n++] = ext;
+  }
+  double best = std::numeric_limits<double>::infinity();
+  for (int i = 0; i < n; ++i) {
+    const double y = t[i] * (a * t[i] + b);
+    if (y < best) { best = y; *t_out = t[i]; }
+  }
+  *y_out = best;
+}
+
+// real roots of a polynomial of degree <= 4 (coefficients highest power first); Durand-Kerner + Newton polish
+int real_roots(const double* coeffs_in, int ncoef, double* roots) {
+  int start = 0;
+  while (start < ncoef && coeffs_in[start] == 0.0) ++start;   // numpy.roots strips leading zeros
+  int deg = ncoef - start - 1;
+  if (deg <= 0) return 0;
+  std::vector<double> c(coeffs_in + start, coeffs_in + ncoef);
+  // strip trailing zeros -> roots at 0
+  int nroots = 0;
+  while (deg > 0 && c[deg] == 0.0) { roots[nroots++] = 0.0; --deg; }
+  if (deg == 0) return nroots;
+  std::vector<std::complex<double>> z(deg);
+  const double lead = c[0];
+  double bound = 0;
+  for (int i = 1; i <= deg; ++i) bound = std::max(bound, std::fabs(c[i] / lead));
+  bound = 1.0 + bound;
+  for (int i = 0; i < deg; ++i) z[i] = std::polar(bound * 0.7, 0.4 + 2.0 * M_PI * i / deg);
+  auto eval = [&](std::complex<double> x) {
+    std::complex<double> v = c[0];
+    for (int i = 1; i <= deg; ++i) v = v * x + c[i];
+    return v;
+  };
+  for (int it = 0; it < 500; ++it) {
+    double change = 0;
+    for (int i = 0; i < deg; ++i) {
+      std::complex<double> den = lead;
+      for (int j = 0; j < deg; ++j)
+        if (j != i) den *= (z[i] - z[j]);
+      if (std::abs(den) == 0) den = 1e-300;
+      const std::complex<double> dz = eval(z[i]) / den;
+      z[i] -= dz;
+      change = std::max(change, std::abs(dz) / (1.0 + std::abs(z[i])));
+    }
+    if (change < 1e-15) break;
+  }
+  for (int i = 0; i < deg; ++i) {
+    if (std::fabs(z[i].imag()) > 1e-7 * (1.0 + std::fabs(z[i].real()))) continue;
+    double x = z[i].real();
+    for (int it = 0; it < 4; ++it) {   // Newton polish on the real axis
+      double v = c[0], dv = 0;
+      for (int k = 1; k <= deg; ++k) { dv = dv * x + v; v = v * x + c[k]; }
+      if (dv == 0) break;
+      const double nx = x - v / dv;
+      if (!std::isfinite(nx)) break;
+      x = nx;
+    }
+    roots[nroots++] = x;
+  }
+  return nroots;
+}
+
+// scipy solve_trust_region_2d
+void solve_trust_region_2d(const double B[3] /*b00,b01,b11*/, const double g[2], double Delta, double p[2]) {
+  const double b00 = B[0], b01 = B[1], b11 = B[2];
+  const double det = b00 * b11 - b01 * b01;
+  if (b00 > 0 && det > 0) {   // Cholesky succeeds <=> positive definite
+    const double p0 = -(b11 * g[0] - b01 * g[1]) / det, p1 = -(-b01 * g[0] + b00 * g[1]) / det;
+    if (p0 * p0 + p1 * p1 <= Delta * Delta) { p[0] = p0; p[1] = p1; return; }
+  }
+  const double a = b00 * Delta * Delta, b = b01 * Delta * Delta, c = b11 * Delta * Delta;
+  const double dd = g[0] * Delta, f = g[1] * Delta;
+  const double coeffs[5] = {-b + dd, 2 * (a - c + f), 6 * b, 2 * (-a + c + f), -b - dd};
+  double roots[8];
+  const int nr = real_roots(coeffs, 5, roots);
+  double best = std::numeric_limits<double>::infinity();
+  p[0] = 0; p[1] = -Delta;   // t -> infinity limit of the parametrisation, as a safe fallback candidate
+  auto consider = [&](double p0, double p1) {
+    const double val = 0.5 * (p0 * (b00 * p0 + b01 * p1) + p1 * (b01 * p0 + b11 * p1)) + g[0] * p0 + g[1] * p1;
+    if (val < best) { best = val; p[0] = p0; p[1] = p1; }
+  };
+  consider(0.0, -Delta);
+  for (int i = 0; i < nr; ++i) {
+    const double t = roots[i], q = 1 + t * t;
+    consider(Delta * 2 * t / q, Delta * (1 - t * t) / q);
+  }
+}
+
+void update_tr_radius(double& Delta, double actual, double predicted, double step_norm, bool bound_hit, double& ratio) {
+  if (predicted > 0) ratio = actual / predicted;
+  else if (predicted == 0 && actual == 0) ratio = 1;
+  else ratio = 0;
+  if (ratio < 0.25) Delta = 0.25 * step_norm;
+  else if (ratio > 0.75 && bound_hit) Delta *= 2.0;
+}
+
+int check_termination(double dF, double F, double dx_norm, double x_norm, double ratio, double ftol, double xtol) {
+  const bool f_ok = dF < ftol * F && ratio > 0.25;
+  const bool x_ok = dx_norm < xtol * (xtol + x_norm);
+  if (f_ok && x_ok) return 4;
+  if (f_ok) return 2;
+  if (x_ok) return 3;
+  return -100;   // None
+}
+
+double now_seconds() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+// =================================================================================================================
+// C ABI
+// =================================================================================================================
+#define API_BEGIN try {
+#define API_END                                 \
+  return 0;                                     \
+  }                                             \
+  catch (const std::exception& e) {             \
+    g_error = e.what();                         \
+    return 1;                                   \
+  }                                             \
+  catch (...) {                                 \
+    g_error = "unknown error";                  \
+    return 1;                                   \
+  }
+
+extern "C" {
+
+const char* mcba_last_error(void) { return g_error.c_str(); }
+
+int32_t mcba_full_size(const mcba_problem* p, int64_t* out) {
+  API_BEGIN
+  REQUIRE(p && out, "null argument");
+  *out = full_size_of(p);
+  API_END
+}
+
+int32_t mcba_create(const mcba_problem* p, void* hip_stream, mcba_handle* out) {
+  API_BEGIN
+  REQUIRE(p && out, "null argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    throw Error("no HIP device: the mcba back-end is GPU-only (there is no CPU fallback)");
+  auto h = std::make_unique<mcba_handle_s>();
+  HIP_OK(hipGetDevice(&h->device));
+  hipDeviceProp_t prop;
+  HIP_OK(hipGetDeviceProperties(&prop, h->device));
+  REQUIRE(std::string(prop.gcnArchName).rfind("gfx950", 0) == 0,
+          std::string("mcba kernels are built for gfx950 only, found ") + prop.gcnArchName);
+  if (hip_stream) {
+    h->stream = (hipStream_t)hip_stream;
+  } else {
+    HIP_OK(hipStreamCreate(&h->stream));
+    h->own_stream = true;
+  }
+  if (const char* env = getenv("MCBA_NO_MFMA")) h->use_mfma = !(env[0] == '1');
+  h->ops = pick_ops(p->camera_model, p->n_dist);
+
+  HostProblem hp;
+  lower_problem(p, hp);
+  h->d = hp.d;
+  Dims& d = h->d;
+  h->h_valid_ref = hp.valid_ref;
+  const size_t nslot = (size_t)d.slots();
+  h->obs.upload(hp.obs);
+  h->evalid.upload(hp.evalid);
+  h->inlier.upload(hp.inlier);
+  h->obs_index.upload(hp.obs_index);
+  h->view_count.upload(hp.view_count);
+  h->n_inliers = hp.n_inliers;
+  h->out_r.alloc((size_t)std::max<int64_t>(2 * hp.n_inliers, 1), false);
+  h->full2act.upload(hp.full2act);
+  h->xfull.upload(hp.xfull);
+  h->board_off.upload(hp.board_off);
+  h->img_h.upload(hp.img_h);
+  h->fix_aspect.upload(hp.fix_aspect);
+  h->bwg.upload(hp.bwg);
+  h->tri.upload(hp.tri);
+  h->board_points.alloc((size_t)d.B * d.P * 3);
+  h->pose.alloc((size_t)d.n_pose * POSE_STRIDE);
+  h->cam.alloc((size_t)d.C * CAM_STRIDE);
+  h->view.alloc((size_t)d.views() * d.view_stride());
+
+  Tables& t = h->t;
+  t.obs = h->obs.p; t.inlier = h->inlier.p; t.evalid = h->evalid.p; t.obs_index = h->obs_index.p;
+  t.view_count = h->view_count.p; t.board_off = h->board_off.p; t.full2act = h->full2act.p; t.xfull = h->xfull.p;
+  t.bwg = h->bwg.p; t.img_h = h->img_h.p; t.fix_aspect = h->fix_aspect.p; t.board_points = h->board_points.p;
+  t.pose = h->pose.p; t.cam = h->cam.p; t.view = h->view.p;
+
+  // ---- work buffers -----------------------------------------------------------------------------------------
+  h->rec.alloc((size_t)d.views() * d.rec_stride);
+  h->nchunk = std::max(1, std::min(64, d.Fl / 8));
+  h->partial.alloc((size_t)d.C * d.B * h->nchunk * d.rec_stride);
+  h->Hss.alloc((size_t)d.ns * d.ns);
+  h->Hfs.alloc((size_t)d.Fl * d.DF * d.ns);
+  h->Hff.alloc((size_t)d.Fl * d.DF * d.DF);
+  h->gbuf.alloc(2 * (size_t)d.n + 2);
+  for (DevBuf<double>* b : {&h->x, &h->xnew, &h->scale_inv, &h->dsc, &h->gh, &h->gn}) b->alloc((size_t)d.n);
+  h->scal.alloc(N_SCALARS);
+  h->qpart.alloc(3 * (size_t)(d.Fl + 1));
+  h->cost_blocks = std::max(1, std::min(COST_BLOCKS_MAX, (int)((nslot + 255) / 256)));
+  h->costpart.alloc((size_t)h->cost_blocks);
+  h->Lf.alloc((size_t)d.Fl * d.DF * d.DF);
+  h->W.alloc((size_t)d.Fl * d.DF * d.ns);
+  h->yf.alloc((size_t)d.Fl * d.DF);
+  h->ntile = (d.ns + 15) / 16;
+  {
+    const int K = d.DF * d.Fl;
+    const int nt2 = h->ntile * (h->ntile + 1) / 2;
+    int ks = 1;
+    while (ks < 64 && nt2 * ks < 2048 && K / (ks * 2) >= 32) ks *= 2;
+    h->ksplit = ks;
+    h->P.alloc((size_t)ks * nt2 * 256);
+  }
+  h->sbuf.alloc((size_t)d.ns * d.ns + d.ns);
+  h->ps.alloc((size_t)d.ns);
+  h->info.alloc(4);
+  HIP_OK(hipHostMalloc((void**)&h->h_scal, N_SCALARS * sizeof(double)));
+  HIP_OK(hipEventCreate(&h->ev0));
+  HIP_OK(hipEventCreate(&h->ev1));
+  HIP_OK(hipDeviceSynchronize());
+  *out = h.release();
+  API_END
+}
+
+int32_t mcba_destroy(mcba_handle h) {
+  API_BEGIN
+  if (h) {
+    (void)hipStreamSynchronize(h->stream);
+    delete h;
+  }
+  API_END
+}
+
+int32_t mcba_device_info(mcba_handle h, char* buf, size_t buf_len) {
+  API_BEGIN
+  REQUIRE(h && buf && buf_len > 0, "null argument");
+  hipDeviceProp_t prop;
+  HIP_OK(hipGetDeviceProperties(&prop, h->device));
+  snprintf(buf, buf_len, "%s:%s:cus=%d:mfma=%d", prop.gcnArchName, prop.name, prop.multiProcessorCount,
+           h->use_mfma ? 1 : 0);
+  API_END
+}
+
+int32_t mcba_num_params(mcba_handle h, int64_t* n) {
+  API_BEGIN
+  REQUIRE(h && n, "null argument");
+  *n = h->d.n;
+  API_END
+}
+
+int32_t mcba_num_residuals(mcba_handle h, int64_t* n) {
+  API_BEGIN
+  REQUIRE(h && n, "null argument");
+  *n = 2 * h->n_inliers;
+  API_END
+}
+
+int32_t mcba_set_inliers(mcba_handle h, const uint8_t* mask) {
+  API_BEGIN
+  REQUIRE(h, "null handle");
+  sync(h);
+  build_inliers(h, mask);
+  API_END
+}
+
+int32_t mcba_set_allreduce(mcba_handle h, mcba_allreduce_fn fn, void* ctx) {
+  API_BEGIN
+  REQUIRE(h, "null handle");
+  h->allreduce = fn;
+  h->allreduce_ctx = ctx;
+  API_END
+}
+
+int32_t mcba_set_log(mcba_handle h, mcba_log_fn fn, void* ctx) {
+  API_BEGIN
+  REQUIRE(h, "null handle");
+  h->log = fn;
+  h->log_ctx = ctx;
+  API_END
+}
+
+// test / debug knob: 1 = MFMA accumulate (default), 0 = plain-FMA accumulate with the identical data flow
+int32_t mcba_set_mfma(mcba_handle h, int32_t on) {
+  API_BEGIN
+  REQUIRE(h, "null handle");
+  h->use_mfma = on != 0;
+  API_END
+}
+
+int32_t mcba_residuals(mcba_handle h, const double* x, double* r) {
+  API_BEGIN
+  REQUIRE(h && x && r, "null argument");
+  upload_x(h, x, h->x.p);
+  eval_tables(h, h->x.p);
+  h->ops->residual(h->d, h->t, h->stream, h->out_r.p, nullptr, nullptr, nullptr);
+  HIP_OK(hipMemcpyAsync(r, h->out_r.p, 2 * (size_t)h->n_inliers * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  sync(h);
+  API_END
+}
+
+int32_t mcba_jacobian(mcba_handle h, const double* x, int32_t* row_nnz, double* vals, int32_t* cols) {
+  API_BEGIN
+  REQUIRE(h && row_nnz, "null argument");
+  const Dims& d = h->d;
+  int nnz = 0;
+  if (d.off_campose >= 0) nnz += 6;
+  if (d.off_boardpose >= 0) nnz += 6;
+  if (d.off_motion >= 0) nnz += d.motion == MOTION_STATIC ? 6 : 12;
+  if (d.off_cameras >= 0) nnz += 5 + d.ND;
+  *row_nnz = nnz;
+  if (!vals && !cols) return 0;
+  REQUIRE(x && vals && cols, "null argument");
+  const size_t nv = 2 * (size_t)h->n_inliers * nnz, nc = (size_t)h->n_inliers * nnz;
+  h->out_big.alloc(std::max<size_t>(nv, 1), false);
+  h->out_cols.alloc(std::max<size_t>(nc, 1), false);
+  upload_x(h, x, h->x.p);
+  eval_tables(h, h->x.p);
+  h->ops->jacobian(d, h->t, h->stream, nnz, h->out_big.p, h->out_cols.p);
+  HIP_OK(hipMemcpyAsync(vals, h->out_big.p, nv * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipMemcpyAsync(cols, h->out_cols.p, nc * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  sync(h);
+  API_END
+}
+
+int32_t mcba_reprojection_error(mcba_handle h, const double* x, double* err, uint8_t* valid) {
+  API_BEGIN
+  REQUIRE(h && x && err && valid, "null argument");
+  const Dims& d = h->d;
+  const size_t nref = (size_t)d.C * d.F * d.B * d.P;
+  h->out_big.alloc(nref, true);
+  h->out_valid.alloc(nref, true);
+  upload_x(h, x, h->x.p);
+  eval_tables(h, h->x.p);
+  h->ops->residual(d, h->t, h->stream, nullptr, nullptr, h->out_big.p, h->out_valid.p);
+  HIP_OK(hipMemcpyAsync(err, h->out_big.p, nref * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipMemcpyAsync(valid, h->out_valid.p, nref, hipMemcpyDeviceToHost, h->stream));
+  sync(h);
+  API_END
+}
+
+int32_t mcba_project(mcba_handle h, const double* x, double* projected) {
+  API_BEGIN
+  REQUIRE(h && x && projected, "null argument");
+  const Dims& d = h->d;
+  const size_t nref = (size_t)d.C * d.F * d.B * d.P;
+  h->out_big.alloc(2 * nref, true);
+  upload_x(h, x, h->x.p);
+  eval_tables(h, h->x.p);
+  h->ops->residual(d, h->t, h->stream, nullptr, h->out_big.p, nullptr, nullptr);
+  HIP_OK(hipMemcpyAsync(projected, h->out_big.p, 2 * nref * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  sync(h);
+  API_END
+}
+
+int32_t mcba_normal_equations(mcba_handle h, const double* x, const mcba_options* opt, double* cost, double* g,
+                              double* diag) {
+  API_BEGIN
+  REQUIRE(h && x, "null argument");
+  set_loss(h, opt);
+  upload_x(h, x, h->x.p);
+  eval_tables(h, h->x.p);
+  launch_linearize(h);
+  launch_assemble(h);
+  const Dims& d = h->d;
+  std::vector<double> host(2 * (size_t)d.n + 2);
+  HIP_OK(hipMemcpyAsync(host.data(), h->gbuf.p, host.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  sync(h);
+  if (g) memcpy(g, host.data(), (size_t)d.n * sizeof(double));
+  if (diag) memcpy(diag, host.data() + d.n, (size_t)d.n * sizeof(double));
+  if (cost) *cost = host[2 * (size_t)d.n];
+  API_END
+}
+
+int32_t mcba_dense_hessian(mcba_handle h, double* H) {
+  API_BEGIN
+  REQUIRE(h && H, "null argument");
+  const Dims& d = h->d;
+  const size_t nn = (size_t)d.n * d.n;
+  REQUIRE(nn <= (1u << 26), "dense Hessian too large (debug API)");
+  h->out_big.alloc(nn, false);
+  hipLaunchKernelGGL(k_dense_hessian, dim3(std::min<size_t>(4096, (nn + 255) / 256)), dim3(256), 0, h->stream, d,
+                     h->Hss.p, h->Hfs.p, h->Hff.p, h->out_big.p);
+  HIP_OK(hipMemcpyAsync(H, h->out_big.p, nn * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  sync(h);
+  API_END
+}
+
+// debug: the regularised Gauss-Newton direction in the scaled space for a given damping (parity tests of the Schur /
+// Cholesky kernels).  Requires a preceding mcba_normal_equations at the same x.  gn_h and g_h are [n_params].
+int32_t mcba_debug_gn_step(mcba_handle h, double reg, double* gn_h, double* g_h, double* scale_inv) {
+  API_BEGIN
+  REQUIRE(h && gn_h, "null argument");
+  const Dims& d = h->d;
+  hipLaunchKernelGGL(k_vec_scale, dim3(1), dim3(1024), 0, h->stream, d, h->x.p, h->g(), h->diag(), h->scale_inv.p,
+                     h->dsc.p, h->gh.p, 1, h->scal.p);
+  launch_gn_solve(h, reg, true);
+  HIP_OK(hipMemcpyAsync(gn_h, h->gn.p, (size_t)d.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (g_h) HIP_OK(hipMemcpyAsync(g_h, h->gh.p, (size_t)d.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (scale_inv)
+    HIP_OK(hipMemcpyAsync(scale_inv, h->scale_inv.p, (size_t)d.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  sync(h);
+  int info = 0;
+  HIP_OK(hipMemcpy(&info, h->info.p, sizeof(int), hipMemcpyDeviceToHost));
+  REQUIRE(info == 0, "Cholesky of the reduced system hit a non-positive pivot at column " + std::to_string(info));
+  API_END
+}
+
+// debug: one MFMA f64 16x16x4 with an asymmetric operand pair; out[16][16] = A^T B for V = [A | B] (4 x 32)
+int32_t mcba_debug_mfma_probe(const double* V, double* out) {
+  API_BEGIN
+  DevBuf<double> dv, dout;
+  dv.upload(std::vector<double>(V, V + 128));
+  dout.alloc(256);
+  hipLaunchKernelGGL(k_mfma_probe, dim3(1), dim3(64), 0, 0, dv.p, dout.p);
+  HIP_OK(hipMemcpy(out, dout.p, 256 * sizeof(double), hipMemcpyDeviceToHost));
+  API_END
+}
+
+int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba_result* result) {
+  API_BEGIN
+  REQUIRE(h && x_inout && opt, "null argument");
+  const double t_start = now_seconds();
+  set_loss(h, opt);
+  const Dims& d = h->d;
+  const double ftol = opt->ftol, xtol = opt->xtol, gtol = opt->gtol;
+  const int max_nfev = opt->max_nfev > 0 ? opt->max_nfev : d.n * 100;
+  const double NaN = std::numeric_limits<double>::quiet_NaN();
+  const bool root = true;   // rank weighting of replicated terms is handled by the hook (see launch_gn_solve)
+  bool is_root = true;
+  if (h->allreduce) {
+    // determine whether this rank is the root by reducing a one-hot marker: root = rank that owns frame 0
+    is_root = d.f0 == 0;
+  }
+  (void)root;
+
+  upload_x(h, x_inout, h->x.p);
+  eval_tables(h, h->x.p);
+  float lin_ms_total = 0.f;
+  auto timed_linearize = [&]() {
+    HIP_OK(hipEventRecord(h->ev0, h->stream));
+    launch_linearize(h);
+    HIP_OK(hipEventRecord(h->ev1, h->stream));
+    launch_assemble(h);
+  };
+  auto collect_lin_time = [&]() {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) lin_ms_total += ms;
+  };
+  timed_linearize();
+  int nfev = 1, njev = 1, iteration = 0, status = -100;
+  bool first = true, fresh_lin = true;
+  double cost = 0, Delta = 0, step_norm = NaN, actual_reduction = NaN, g_norm = 0, initial_cost = 0;
+
+  while (true) {
+    // ---- gradient scaling + Cauchy-step curvature (one sync) -------------------------------------------------
+    hipLaunchKernelGGL(k_vec_scale, dim3(1), dim3(1024), 0, h->stream, d, h->x.p, h->g(), h->diag(), h->scale_inv.p,
+                       h->dsc.p, h->gh.p, first ? 1 : 0, h->scal.p);
+    launch_quadforms(h, h->gh.p, h->gh.p, 4);
+    HIP_OK(hipMemcpyAsync(h->scal.p + 16, h->costcount(), 2 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    fetch_scalars(h, 18);
+    if (fresh_lin) { collect_lin_time(); fresh_lin = false; }
+    g_norm = h->h_scal[0];
+    const double gh2 = h->h_scal[1];
+    if (first) {
+      cost = h->h_scal[16];
+      initial_cost = cost;
+      if (!std::isfinite(cost))
+        throw Error("Residuals are not finite in the initial point.");   // scipy least_squares.py:844-845
+      Delta = std::sqrt(h->h_scal[2]);
+      if (Delta == 0) Delta = 1.0;
+      first = false;
+    }
+    if (g_norm < gtol) status = 1;
+    if (h->log && opt->verbose >= 2) h->log(h->log_ctx, iteration, nfev, cost, actual_reduction, step_norm, g_norm);
+    if (status != -100 || nfev >= max_nfev) break;
+
+    const double q00 = h->h_scal[4];
+    const double gh_norm = std::sqrt(gh2);
+    double tmin, ag_value;
+    minimize_quadratic_1d(0.5 * q00, -gh2, 0.0, Delta / gh_norm, &tmin, &ag_value);
+    const double reg_term = -ag_value / (Delta * Delta);
+    const double reg = std::max(reg_term, REG_FLOOR);
+
+    // ---- regularised Gauss-Newton step + 2-D subspace (one sync) ---------------------------------------------
+    launch_gn_solve(h, reg, is_root);
+    launch_quadforms(h, h->gh.p, h->gn.p, 4);
+    HIP_OK(hipMemcpyAsync(h->scal.p + 12, h->info.p, sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
+    fetch_scalars(h, 13);
+    {
+      int32_t chol_info = 0;
+      memcpy(&chol_info, &h->h_scal[12], sizeof(int32_t));
+      if (chol_info != 0)
+        throw Error("reduced normal equations are not positive definite (pivot " + std::to_string(chol_info) +
+                    "); non-finite Jacobian?");
+    }
+    const double Q00 = h->h_scal[4], Q01 = h->h_scal[5], Q11 = h->h_scal[6];
+    const double d00 = h->h_scal[7], d01 = h->h_scal[8], d11 = h->h_scal[9];
+    // orthonormal basis [e0 e1] = [u0 u1] Cm of span{g_h, gn_h} (Gram-Schmidt on the 2x2 Gram matrix)
+    const double n0 = std::sqrt(d00);
+    const double proj = d01 / d00;
+    double nw2 = d11 - proj * d01;
+    double Cm[4];   // row-major 2x2: [alpha; beta] = Cm p_S
+    double BS[3], gS[2] = {n0, 0.0};
+    if (nw2 > 1e-28 * d11 && std::isfinite(nw2)) {
+      const double nw = std::sqrt(nw2);
+      Cm[0] = 1.0 / n0; Cm[1] = -proj / nw;
+      Cm[2] = 0.0;      Cm[3] = 1.0 / nw;
+      BS[0] = Q00 / d00;
+      BS[1] = (Q01 - proj * Q00) / (n0 * nw);
+      BS[2] = (Q11 - 2 * proj * Q01 + proj * proj * Q00) / nw2;
+    } else {   // gn parallel to the gradient: 1-D subspace
+      Cm[0] = 1.0 / n0; Cm[1] = 0; Cm[2] = 0; Cm[3] = 0;
+      BS[0] = Q00 / d00; BS[1] = 0; BS[2] = 1.0;
+    }
+
+    actual_reduction = -1;
+    double cost_new = cost, ratio = 0;
+    while (actual_reduction <= 0 && nfev < max_nfev) {
+      double pS[2];
+      solve_trust_region_2d(BS, gS, Delta, pS);
+      const double predicted =
+          -(0.5 * (pS[0] * (BS[0] * pS[0] + BS[1] * pS[1]) + pS[1] * (BS[1] * pS[0] + BS[2] * pS[1])) + gS[0] * pS[0] +
+            gS[1] * pS[1]);
+      const double alpha = Cm[0] * pS[0] + Cm[1] * pS[1], beta = Cm[2] * pS[0] + Cm[3] * pS[1];
+      hipLaunchKernelGGL(k_vec_step, dim3(1), dim3(1024), 0, h->stream, d, h->x.p, h->dsc.p, h->gh.p, h->gn.p, alpha, beta,
+                         h->xnew.p, h->scal.p);
+      eval_tables(h, h->xnew.p);
+      launch_cost(h, h->scal.p + 3);
+      fetch_scalars(h, 4);
+      ++nfev;
+      const double step_h_norm = std::sqrt(h->h_scal[0]);
+      cost_new = h->h_scal[3];
+      if (!std::isfinite(cost_new)) {
+        Delta = 0.25 * step_h_norm;
+        continue;
+      }
+      actual_reduction = cost - cost_new;
+      double Delta_new = Delta;
+      update_tr_radius(Delta_new, actual_reduction, predicted, step_h_norm, step_h_norm > 0.95 * Delta, ratio);
+      step_norm = std::sqrt(h->h_scal[1]);
+      const double x_norm = std::sqrt(h->h_scal[2]);
+      status = check_termination(actual_reduction, cost, step_norm, x_norm, ratio, ftol, xtol);
+      if (status != -100) break;
+      Delta = Delta_new;
+    }
+
+    if (actual_reduction > 0) {
+      std::swap(h->x.p, h->xnew.p);
+      cost = cost_new;
+      timed_linearize();   // tables already hold x_new
+      fresh_lin = true;
+      ++njev;
+    } else {
+      step_norm = 0;
+      actual_reduction = 0;
+    }
+    ++iteration;
+  }
+  if (status == -100) status = 0;
+
+  HIP_OK(hipMemcpyAsync(x_inout, h->x.p, (size_t)d.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  sync(h);
+  if (result) {
+    result->cost = cost;
+    result->initial_cost = initial_cost;
+    result->optimality = g_norm;
+    result->nfev = nfev;
+    result->njev = njev;
+    result->status = status;
+    result->iterations = iteration;
+    result->solve_seconds = now_seconds() - t_start;
+    result->linearize_seconds = lin_ms_total * 1e-3;
+  }
+  API_END
+}
+
+int32_t mcba_time_linearize(mcba_handle h, const double* x, const mcba_options* opt, int32_t repeats, double* avg_ms) {
+  API_BEGIN
+  REQUIRE(h && x && avg_ms && repeats > 0, "bad argument");
+  set_loss(h, opt);
+  upload_x(h, x, h->x.p);
+  eval_tables(h, h->x.p);
+  launch_linearize(h);   // warm-up
+  sync(h);
+  HIP_OK(hipEventRecord(h->ev0, h->stream));
+  for (int i = 0; i < repeats; ++i) launch_linearize(h);
+  HIP_OK(hipEventRecord(h->ev1, h->stream));
+  sync(h);
+  float ms = 0.f;
+  HIP_OK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  *avg_ms = ms / repeats;
+  API_END
+}
+
+int32_t mcba_time_residuals(mcba_handle h, const double* x, int32_t repeats, double* avg_ms) {
+  API_BEGIN
+  REQUIRE(h && x && avg_ms && repeats > 0, "bad argument");
+  upload_x(h, x, h->x.p);
+  eval_tables(h, h->x.p);
+  h->ops->residual(h->d, h->t, h->stream, h->out_r.p, nullptr, nullptr, nullptr);
+  sync(h);
+  HIP_OK(hipEventRecord(h->ev0, h->stream));
+  for (int i = 0; i < repeats; ++i) h->ops->residual(h->d, h->t, h->stream, h->out_r.p, nullptr, nullptr, nullptr);
+  HIP_OK(hipEventRecord(h->ev1, h->stream));
+  sync(h);
+  float ms = 0.f;
+  HIP_OK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  *avg_ms = ms / repeats;
+  API_END
+}
+
+}  // extern "C"

@@ -1,0 +1,65 @@
+// mcba_cam_impl.h -- body of one camera-model translation unit: define MCBA_ND, MCBA_FISH, MCBA_CAM_FN, include.
+#include "mcba_kernels.h"
+#include "mcba_camops.h"
+
+namespace mcba {
+namespace {
+
+constexpr int ND_ = MCBA_ND;
+constexpr bool FISH_ = MCBA_FISH;
+
+inline int slot_grid(const Dims& d) {
+  const int n = d.slots();
+  int g = (n + 255) / 256;
+  return g < 1 ? 1 : (g > 4096 ? 4096 : g);
+}
+
+void residual(const Dims& d, const Tables& t, hipStream_t s, double* r, double* proj, double* err, uint8_t* valid) {
+  if (d.motion == MOTION_ROLLING)
+    hipLaunchKernelGGL((k_residual<ND_, FISH_, true>), dim3(slot_grid(d)), dim3(256), 0, s, d, t, r, proj, err, valid);
+  else
+    hipLaunchKernelGGL((k_residual<ND_, FISH_, false>), dim3(slot_grid(d)), dim3(256), 0, s, d, t, r, proj, err, valid);
+}
+
+void cost(const Dims& d, const Tables& t, hipStream_t s, double* partial, int nblk) {
+  if (d.motion == MOTION_ROLLING)
+    hipLaunchKernelGGL((k_cost<ND_, FISH_, true>), dim3(nblk), dim3(256), 0, s, d, t, partial);
+  else
+    hipLaunchKernelGGL((k_cost<ND_, FISH_, false>), dim3(nblk), dim3(256), 0, s, d, t, partial);
+}
+
+void jacobian(const Dims& d, const Tables& t, hipStream_t s, int row_nnz, double* vals, int32_t* cols) {
+  if (d.motion == MOTION_ROLLING)
+    hipLaunchKernelGGL((k_jacobian<ND_, FISH_, true>), dim3(slot_grid(d)), dim3(128), 0, s, d, t, row_nnz, vals, cols);
+  else
+    hipLaunchKernelGGL((k_jacobian<ND_, FISH_, false>), dim3(slot_grid(d)), dim3(128), 0, s, d, t, row_nnz, vals, cols);
+}
+
+template <int MOTION, bool OPTK>
+void lin2(const Dims& d, const Tables& t, hipStream_t s, double* rec, const uint16_t* tri, bool mfma) {
+  const dim3 grid(d.views()), block(64);
+  if (mfma)
+    hipLaunchKernelGGL((k_linearize<ND_, FISH_, MOTION, OPTK, true>), grid, block, 0, s, d, t, rec, tri);
+  else
+    hipLaunchKernelGGL((k_linearize<ND_, FISH_, MOTION, OPTK, false>), grid, block, 0, s, d, t, rec, tri);
+}
+
+template <int MOTION>
+void lin1(const Dims& d, const Tables& t, hipStream_t s, double* rec, const uint16_t* tri, bool mfma) {
+  if (d.KI > 0) lin2<MOTION, true>(d, t, s, rec, tri, mfma);
+  else lin2<MOTION, false>(d, t, s, rec, tri, mfma);
+}
+
+void linearize(const Dims& d, const Tables& t, hipStream_t s, double* rec, const uint16_t* tri, bool mfma) {
+  if (d.motion == MOTION_STATIC) lin1<MOTION_STATIC>(d, t, s, rec, tri, mfma);
+  else if (d.motion == MOTION_ROLLING) lin1<MOTION_ROLLING>(d, t, s, rec, tri, mfma);
+  else lin1<MOTION_HAND_EYE>(d, t, s, rec, tri, mfma);
+}
+
+const CamOps OPS = {residual, cost, jacobian, linearize};
+
+}  // namespace
+
+const CamOps* MCBA_CAM_FN() { return &OPS; }
+
+}  // namespace mcba

@@ -1,0 +1,26 @@
+// mcba_camops.h -- launch table of the kernels that are specialised on the camera model.
+//
+// The per-slot kernels are templates over <number of distortion coefficients, fisheye?> (x motion model x
+// intrinsics-on/off x MFMA/plain accumulate).  Each camera model is instantiated in its own translation unit
+// (mcba_cam_*.hip) so that the variants compile in parallel; the driver picks a table at mcba_create().
+#pragma once
+#include <hip/hip_runtime.h>
+#include "mcba_device.h"
+
+namespace mcba {
+
+struct CamOps {
+  void (*residual)(const Dims&, const Tables&, hipStream_t, double* r, double* proj, double* err, uint8_t* valid);
+  void (*cost)(const Dims&, const Tables&, hipStream_t, double* partial, int nblk);
+  void (*jacobian)(const Dims&, const Tables&, hipStream_t, int row_nnz, double* vals, int32_t* cols);
+  void (*linearize)(const Dims&, const Tables&, hipStream_t, double* rec, const uint16_t* tri, bool mfma);
+};
+
+const CamOps* cam_ops_pin4();
+const CamOps* cam_ops_pin5();
+const CamOps* cam_ops_pin8();
+const CamOps* cam_ops_pin12();
+const CamOps* cam_ops_pin14();
+const CamOps* cam_ops_fish4();
+
+}  // namespace mcba

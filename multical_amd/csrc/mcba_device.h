@@ -1,0 +1,83 @@
+// mcba_device.h -- plain-old-data descriptors shared by the host driver (mcba_api.hip) and the kernels.
+#pragma once
+#include <stdint.h>
+#include "mcba_math.h"
+
+#if !defined(__HIPCC__)
+struct double2 { double x, y; };   // host-only builds (tests/hostmath); hipcc provides the vector type
+#endif
+
+namespace mcba {
+
+constexpr int MOTION_STATIC = 0, MOTION_ROLLING = 1, MOTION_HAND_EYE = 2;
+
+// Problem shape + index maps, passed BY VALUE to every kernel (fits the kernarg segment).
+struct Dims {
+  int C, F, B, P;        // cameras, frames (global), boards, padded points per board
+  int f0, Fl;            // frame shard owned by this handle: global frames [f0, f0 + Fl)
+  int motion;            // MOTION_*
+  int ND;                // distortion coefficients per camera
+  int fisheye;           // 0/1
+  int n;                 // active parameters (length of x)
+  int nfull;             // all five blocks
+  // offsets of the blocks inside the ACTIVE vector x (-1 = block disabled)
+  int off_campose, off_boardpose, off_motion, off_cameras, off_boards;
+  // offsets inside the FULL vector
+  int foff_campose, foff_boardpose, foff_motion, foff_cameras, foff_boards;
+  int n_motion;          // length of the motion block (6F, 12F or 12)
+  int KI;                // intrinsic columns carried per observation (4 + ND, skew omitted) or 0 when cameras are fixed
+  int NPB;               // pose blocks per view: 3 (static) or 4 (rolling: cam|start|end|board, hand-eye: cam|wb|gc|board)
+  int DE;                // base row width: 6, or 12 for rolling shutter
+  int NV;                // DE + KI + 1   columns of the per-point row pair  [E | K | r]
+  int NL;                // 6*NPB + KI    local parameters of one view
+  int N1;                // NL + 1        (+ residual column)
+  int rec_size;          // N1 (N1+1)/2   packed upper triangle of the local normal equations
+  int rec_stride;        // rec_size + 2  (+ cost, count), even
+  int DF;                // eliminated parameters per frame: 6 static, 12 rolling, 0 hand-eye / motion disabled
+  int ns;                // shared (reduced) parameters = n - Fl_total*DF ... see shared_index()
+  int loss;              // MCBA_LOSS_*
+  double f_scale;
+  // pose table layout
+  int pose_cam, pose_board, pose_motion, n_pose;
+
+  // global x index of a shared-parameter index (x order with the eliminated motion block removed)
+  MCBA_HD int shared_to_x(int s) const {
+    if (DF == 0 || off_motion < 0) return s;
+    return s < off_motion ? s : s + n_motion;
+  }
+  MCBA_HD int x_to_shared(int i) const {   // -1 when i is an eliminated frame parameter
+    if (DF == 0 || off_motion < 0) return i;
+    if (i < off_motion) return i;
+    if (i < off_motion + n_motion) return -1;
+    return i - n_motion;
+  }
+  // x index of eliminated parameter d (0..DF-1) of GLOBAL frame f
+  MCBA_HD int frame_to_x(int f, int d) const {
+    return (d < 6) ? off_motion + 6 * f + d : off_motion + 6 * F + 6 * f + (d - 6);
+  }
+  MCBA_HD int views() const { return Fl * C * B; }
+  MCBA_HD int slots() const { return Fl * C * B * P; }
+  MCBA_HD int view_stride() const { return VIEW_STRIDE * (motion == MOTION_ROLLING ? 2 : 1); }
+};
+
+// Device tables owned by the handle.  Observation tables are FRAME-MAJOR ([Fl][C][B][P]) so that a frame shard is
+// contiguous and the per-frame reductions read consecutive views.
+struct Tables {
+  const double2* obs;          // observed points
+  const uint8_t* inlier;       // Calibration.inliers
+  const uint8_t* evalid;       // proj.valid & obs.valid  (mask of tables.reprojection_error)
+  const int32_t* obs_index;    // index of the observation in the reference's residual ordering, -1 if not an inlier
+  const int32_t* view_count;   // [Fl][C][B] inliers per view
+  const int32_t* board_off;    // [B+1] prefix of board sizes (points)
+  const int32_t* full2act;     // [nfull] full index -> active index or -1
+  const double* xfull;         // [nfull] constants for disabled blocks
+  const double* bwg;           // [F][12] base_wrt_gripper (R,t), hand-eye
+  const double* img_h;         // [C]
+  const uint8_t* fix_aspect;   // [C]
+  double* board_points;        // [B][P][3] current board geometry
+  double* pose;                // [n_pose][POSE_STRIDE]
+  double* cam;                 // [C][CAM_STRIDE]
+  double* view;                // [Fl][C][B][view_stride]
+};
+
+}  // namespace mcba

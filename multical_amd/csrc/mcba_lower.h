@@ -1,0 +1,208 @@
+// mcba_lower.h -- host-side lowering of an mcba_problem (include/mcba.h) to the frame-major tables and index maps the
+// kernels consume.  Pure C++ (no HIP calls): shared by the driver (mcba_api.hip) and by tests/hostmath.
+//
+// Reference behaviour captured here:
+//   Calibration.valid / inliers                      optimization/calibration.py:69-81
+//   mask of tables.reprojection_error                 tables.py:244-249 (reprojected.valid & point_table.valid)
+//   residual ordering of `evaluate`                   calibration.py:204-206 (C-order over the inlier mask)
+//   parameter block order / enable flags              calibration.py:146-161
+#pragma once
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "../../include/mcba.h"
+#include "mcba_device.h"
+
+namespace mcba {
+
+struct LowerError : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+#define MCBA_REQUIRE(cond, msg)                  \
+  do {                                           \
+    if (!(cond)) throw ::mcba::LowerError(msg);  \
+  } while (0)
+
+struct HostProblem {
+  Dims d{};
+  std::vector<uint8_t> valid_ref;    // Calibration.valid, [C,F,B,P] reference order, all frames
+  std::vector<uint8_t> evalid_ref;   // proj.valid & obs.valid
+  std::vector<double2> obs;          // frame-major shard tables ...
+  std::vector<uint8_t> evalid, inlier, fix_aspect;
+  std::vector<int32_t> obs_index, view_count, board_off, full2act;
+  std::vector<double> xfull, bwg, img_h;
+  std::vector<uint16_t> tri;
+  int64_t n_inliers = 0;
+};
+
+inline int64_t full_size_of(const mcba_problem* p) {
+  int64_t nb = 0;
+  for (int b = 0; b < p->n_boards; ++b) nb += p->board_sizes[b];
+  const int64_t nm = p->motion == MCBA_MOTION_STATIC ? 6LL * p->n_frames
+                     : p->motion == MCBA_MOTION_ROLLING ? 12LL * p->n_frames : 12LL;
+  return 6LL * p->n_cameras + 6LL * p->n_boards + nm + (int64_t)p->n_cameras * (5 + p->n_dist) + 3 * nb;
+}
+
+// (re)build inlier table, residual ordering and per-view counts of the shard; mask in reference order or null
+inline void lower_inliers(HostProblem& hp, const uint8_t* mask_ref) {
+  const Dims& d = hp.d;
+  const size_t nslot = (size_t)d.slots();
+  hp.inlier.assign(nslot, 0);
+  hp.obs_index.assign(nslot, -1);
+  hp.view_count.assign((size_t)d.views(), 0);
+  int64_t count = 0;
+  // residual order = reference C-order over (c, f, b, p) restricted to the shard's frames
+  for (int c = 0; c < d.C; ++c)
+    for (int fl = 0; fl < d.Fl; ++fl) {
+      const int f = d.f0 + fl;
+      for (int b = 0; b < d.B; ++b) {
+        const size_t ref0 = (((size_t)c * d.F + f) * d.B + b) * d.P;
+        const size_t v = ((size_t)fl * d.C + c) * d.B + b;
+        int vc = 0;
+        for (int p = 0; p < d.P; ++p) {
+          const uint8_t in = mask_ref ? mask_ref[ref0 + p] : hp.valid_ref[ref0 + p];
+          hp.inlier[v * d.P + p] = in ? 1 : 0;
+          if (in) {
+            hp.obs_index[v * d.P + p] = (int32_t)count++;
+            ++vc;
+          }
+        }
+        hp.view_count[v] = vc;
+      }
+    }
+  MCBA_REQUIRE(count < (1LL << 30), "too many observations for 32-bit residual indices");
+  hp.n_inliers = count;
+}
+
+inline void lower_problem(const mcba_problem* p, HostProblem& hp) {
+  MCBA_REQUIRE(p != nullptr, "null problem");
+  MCBA_REQUIRE(p->version == MCBA_VERSION, "mcba_problem.version mismatch");
+  MCBA_REQUIRE(p->n_cameras > 0 && p->n_frames > 0 && p->n_boards > 0 && p->n_points > 0, "empty problem");
+  MCBA_REQUIRE(p->points && p->point_valid && p->board_sizes && p->camera_valid && p->frame_valid && p->board_valid &&
+                   p->x_full && p->image_heights && p->fix_aspect,
+               "null array in mcba_problem");
+  MCBA_REQUIRE(p->motion >= 0 && p->motion <= 2, "unknown motion model");
+  MCBA_REQUIRE(p->motion != MCBA_MOTION_HAND_EYE || p->base_wrt_gripper, "hand-eye motion needs base_wrt_gripper");
+  MCBA_REQUIRE(!(p->optimize & MCBA_OPT_BOARDS), "adjust_board (optimize.boards) is not implemented in this build");
+  MCBA_REQUIRE(p->optimize != 0, "no parameter block enabled");
+  if (p->camera_model == MCBA_CAMERA_FISHEYE)
+    MCBA_REQUIRE(p->n_dist == 4, "fisheye cameras carry 4 distortion coefficients (camera_fisheye.py:113-117)");
+  else
+    MCBA_REQUIRE(p->n_dist == 4 || p->n_dist == 5 || p->n_dist == 8 || p->n_dist == 12 || p->n_dist == 14,
+                 "pinhole cameras carry 4, 5, 8, 12 or 14 distortion coefficients (cv2.projectPoints)");
+
+  Dims& d = hp.d;
+  d.C = p->n_cameras; d.F = p->n_frames; d.B = p->n_boards; d.P = p->n_points;
+  d.f0 = 0; d.Fl = d.F;
+  if (!(p->frame_begin == 0 && p->frame_end == 0)) {
+    MCBA_REQUIRE(0 <= p->frame_begin && p->frame_begin <= p->frame_end && p->frame_end <= d.F, "bad frame shard");
+    d.f0 = p->frame_begin;
+    d.Fl = p->frame_end - p->frame_begin;
+  }
+  d.motion = p->motion; d.ND = p->n_dist; d.fisheye = p->camera_model == MCBA_CAMERA_FISHEYE;
+  int64_t nboardpts = 0;
+  std::vector<int32_t> board_off(d.B + 1, 0);
+  for (int b = 0; b < d.B; ++b) {
+    MCBA_REQUIRE(p->board_sizes[b] >= 0 && p->board_sizes[b] <= d.P, "board size exceeds n_points");
+    nboardpts += p->board_sizes[b];
+    board_off[b + 1] = (int32_t)nboardpts;
+  }
+  d.n_motion = d.motion == MOTION_STATIC ? 6 * d.F : d.motion == MOTION_ROLLING ? 12 * d.F : 12;
+  const int sizes[5] = {6 * d.C, 6 * d.B, d.n_motion, d.C * (5 + d.ND), (int)(3 * nboardpts)};
+  const uint32_t bits[5] = {MCBA_OPT_CAMERA_POSES, MCBA_OPT_BOARD_POSES, MCBA_OPT_MOTION, MCBA_OPT_CAMERAS,
+                            MCBA_OPT_BOARDS};
+  int foff[5], aoff[5], nf = 0, na = 0;
+  for (int k = 0; k < 5; ++k) {
+    foff[k] = nf;
+    nf += sizes[k];
+    if (p->optimize & bits[k]) { aoff[k] = na; na += sizes[k]; } else aoff[k] = -1;
+  }
+  d.nfull = nf; d.n = na;
+  d.foff_campose = foff[0]; d.foff_boardpose = foff[1]; d.foff_motion = foff[2]; d.foff_cameras = foff[3];
+  d.foff_boards = foff[4];
+  d.off_campose = aoff[0]; d.off_boardpose = aoff[1]; d.off_motion = aoff[2]; d.off_cameras = aoff[3];
+  d.off_boards = aoff[4];
+  d.KI = (p->optimize & MCBA_OPT_CAMERAS) ? 4 + d.ND : 0;
+  d.NPB = d.motion == MOTION_STATIC ? 3 : 4;
+  d.DE = d.motion == MOTION_ROLLING ? 12 : 6;
+  d.NV = d.DE + d.KI + 1;
+  d.NL = 6 * d.NPB + d.KI;
+  d.N1 = d.NL + 1;
+  d.rec_size = d.N1 * (d.N1 + 1) / 2;
+  d.rec_stride = (d.rec_size + 2 + 1) / 2 * 2;
+  d.DF = ((p->optimize & MCBA_OPT_MOTION) && d.motion != MOTION_HAND_EYE) ? (d.motion == MOTION_ROLLING ? 12 : 6) : 0;
+  d.ns = d.DF > 0 ? d.n - d.n_motion : d.n;
+  d.loss = 0; d.f_scale = 1.0;
+  d.pose_cam = 0; d.pose_board = d.C; d.pose_motion = d.C + d.B;
+  d.n_pose = d.C + d.B + d.n_motion / 6;
+  MCBA_REQUIRE((int64_t)d.slots() < (1LL << 31), "observation table too large for 32-bit slot indices");
+
+  // ---- masks (Calibration.valid, calibration.py:69-76; tables.reprojection_error mask, tables.py:244-249) ----
+  const size_t nref = (size_t)d.C * d.F * d.B * d.P;
+  hp.valid_ref.resize(nref);
+  hp.evalid_ref.resize(nref);
+  for (int c = 0; c < d.C; ++c)
+    for (int f = 0; f < d.F; ++f)
+      for (int b = 0; b < d.B; ++b) {
+        const bool pv = p->camera_valid[c] && p->frame_valid[f] && p->board_valid[b];
+        const size_t r0 = (((size_t)c * d.F + f) * d.B + b) * d.P;
+        for (int q = 0; q < d.P; ++q) {
+          const bool v = pv && p->point_valid[r0 + q];
+          hp.valid_ref[r0 + q] = v;
+          hp.evalid_ref[r0 + q] = v && q < p->board_sizes[b];
+        }
+      }
+
+  // ---- frame-major observation tables of the shard ----------------------------------------------------------
+  const size_t nslot = (size_t)d.slots();
+  {
+    std::vector<double2>& obs = hp.obs;
+    std::vector<uint8_t>& ev = hp.evalid;
+    obs.resize(nslot);
+    ev.resize(nslot);
+    for (int fl = 0; fl < d.Fl; ++fl)
+      for (int c = 0; c < d.C; ++c)
+        for (int b = 0; b < d.B; ++b) {
+          const size_t r0 = (((size_t)c * d.F + d.f0 + fl) * d.B + b) * d.P;
+          const size_t s0 = (((size_t)fl * d.C + c) * d.B + b) * d.P;
+          for (int q = 0; q < d.P; ++q) {
+            obs[s0 + q].x = p->points[2 * (r0 + q)];
+            obs[s0 + q].y = p->points[2 * (r0 + q) + 1];
+            ev[s0 + q] = hp.evalid_ref[r0 + q];
+          }
+        }
+  }
+  lower_inliers(hp, p->inlier_mask);
+
+  // ---- parameter tables -------------------------------------------------------------------------------------
+  {
+    std::vector<int32_t> f2a((size_t)d.nfull, -1);
+    for (int k = 0; k < 5; ++k)
+      if (aoff[k] >= 0)
+        for (int i = 0; i < sizes[k]; ++i) f2a[foff[k] + i] = aoff[k] + i;
+    hp.full2act = f2a;
+    hp.xfull.assign(p->x_full, p->x_full + d.nfull);
+    hp.board_off = board_off;
+    hp.img_h.assign(p->image_heights, p->image_heights + d.C);
+    hp.fix_aspect.assign(p->fix_aspect, p->fix_aspect + d.C);
+    std::vector<double> bwg;
+    if (d.motion == MOTION_HAND_EYE) {
+      bwg.resize((size_t)12 * d.F);
+      for (int f = 0; f < d.F; ++f) {
+        const double* m = p->base_wrt_gripper + 16 * (size_t)f;
+        for (int i = 0; i < 3; ++i) {
+          for (int j = 0; j < 3; ++j) bwg[12 * f + 3 * i + j] = m[4 * i + j];
+          bwg[12 * f + 9 + i] = m[4 * i + 3];
+        }
+      }
+    }
+    hp.bwg = bwg;
+    std::vector<uint16_t> tri((size_t)d.rec_size);
+    size_t e = 0;
+    for (int i = 0; i < d.N1; ++i)
+      for (int j = i; j < d.N1; ++j) tri[e++] = (uint16_t)((i << 8) | j);
+    hp.tri = tri;
+  }
+}
+
+}  // namespace mcba

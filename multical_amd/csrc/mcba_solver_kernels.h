@@ -1,0 +1,559 @@
+// mcba_solver_kernels.h -- kernels that do not depend on the camera model: table preparation, assembly of the
+// per-view records into the block normal equations, and the damped normal-equation solve of the trust-region
+// driver (Schur elimination of the per-frame blocks, dense Cholesky, vector updates).  Included only by mcba_api.hip.
+#pragma once
+#include "mcba_kernels.h"
+
+namespace mcba {
+
+// ---------------------------------------------------------------------------------------------------------------
+// deterministic sum of per-block partials
+// ---------------------------------------------------------------------------------------------------------------
+// out[0] = sum(partial[0..n))  (single block, fixed order)
+__global__ void k_sum(const double* __restrict__ partial, int n, double* __restrict__ out) {
+  __shared__ double scratch[16];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) acc += partial[i];
+  const double tot = block_reduce<false>(acc, scratch);
+  if (threadIdx.x == 0) out[0] = tot;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_prep: x -> device tables (replaces the object re-construction of Calibration.with_param_vec,
+//         optimization/calibration.py:164-171 -> pose_set.py:55-57, camera.py:157-171, board/charuco.py:116-117)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void k_prep(Dims d, Tables t, const double* __restrict__ x) {
+  prep_item(d, t, x, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_views: chain matrix board -> camera per view (tables.expand_views + transform_points, tables.py:284-304,400-405;
+//          hand-eye: motion/hand_eye.py:43-46).  Rolling shutter stores two chains (start, end).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void k_views(Dims d, Tables t) {
+  view_item(d, t, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// assembly of the records (deterministic gathers; no atomics)
+// ---------------------------------------------------------------------------------------------------------------
+// per-frame blocks: H_ff [Fl][DF][DF], H_fs [Fl][DF][ns], g / diag entries of the frame's parameters.
+__global__ void k_assemble_frames(Dims d, Tables t, const double* __restrict__ rec, double* __restrict__ Hff,
+                                  double* __restrict__ Hfs, double* __restrict__ g, double* __restrict__ diag) {
+  const int fl = blockIdx.x, f = d.f0 + fl;
+  const int DF = d.DF, ns = d.ns, N1 = d.N1, NL = d.NL;
+  double* hfs = Hfs + (size_t)fl * DF * ns;
+  double* hff = Hff + (size_t)fl * DF * DF;
+  for (int e = threadIdx.x; e < DF * ns; e += blockDim.x) hfs[e] = 0.0;
+  __syncthreads();
+  const int CW = 6 + d.KI;   // camera pose + intrinsics columns
+  // frame x camera(c) blocks: sum over boards
+  for (int e = threadIdx.x; e < d.C * DF * CW; e += blockDim.x) {
+    const int c = e / (DF * CW), dd = (e / CW) % DF, q = e % CW;
+    const int li = q < 6 ? q : 6 * d.NPB + (q - 6);          // local index of the camera-side column
+    const int gi = local_to_x(d, f, c, 0, li);
+    if (gi < 0) continue;
+    const int lf = 6 + dd;
+    double sum = 0.0;
+    for (int b = 0; b < d.B; ++b) {
+      const int v = (fl * d.C + c) * d.B + b;
+      if (t.view_count[v] == 0) continue;
+      const double* r = rec + (size_t)v * d.rec_stride;
+      sum += r[li < lf ? tri_index(li, lf, N1) : tri_index(lf, li, N1)];
+    }
+    hfs[dd * ns + d.x_to_shared(gi)] = sum;
+  }
+  // frame x board(b) blocks: sum over cameras
+  for (int e = threadIdx.x; e < d.B * DF * 6; e += blockDim.x) {
+    const int b = e / (DF * 6), dd = (e / 6) % DF, q = e % 6;
+    const int li = 6 * (d.NPB - 1) + q;
+    const int gi = local_to_x(d, f, 0, b, li);
+    if (gi < 0) continue;
+    const int lf = 6 + dd;
+    double sum = 0.0;
+    for (int c = 0; c < d.C; ++c) {
+      const int v = (fl * d.C + c) * d.B + b;
+      if (t.view_count[v] == 0) continue;
+      sum += rec[(size_t)v * d.rec_stride + tri_index(lf, li, N1)];
+    }
+    hfs[dd * ns + d.x_to_shared(gi)] = sum;
+  }
+  // frame x frame and gradient
+  for (int e = threadIdx.x; e < DF * (DF + 1); e += blockDim.x) {
+    const int dd = e / (DF + 1), d2 = e % (DF + 1);
+    const int la = 6 + dd, lb = d2 < DF ? 6 + d2 : NL;
+    double sum = 0.0;
+    for (int cb = 0; cb < d.C * d.B; ++cb) {
+      const int v = fl * d.C * d.B + cb;
+      if (t.view_count[v] == 0) continue;
+      sum += rec[(size_t)v * d.rec_stride + (la <= lb ? tri_index(la, lb, N1) : tri_index(lb, la, N1))];
+    }
+    if (d2 < DF) {
+      hff[dd * DF + d2] = sum;
+      if (d2 == dd) diag[d.frame_to_x(f, dd)] = sum;
+    } else {
+      g[d.frame_to_x(f, dd)] = sum;
+    }
+  }
+}
+
+// shared part, stage 1: partial[pair=(c,b)][chunk][rec_stride] = sum of the records over a chunk of frames
+__global__ void k_shared_partial(Dims d, Tables t, const double* __restrict__ rec, int nchunk,
+                                 double* __restrict__ partial) {
+  const int pair = blockIdx.x, ch = blockIdx.y;
+  const int c = pair / d.B, b = pair % d.B;
+  const int per = (d.Fl + nchunk - 1) / nchunk;
+  const int fa = ch * per, fb = min(d.Fl, fa + per);
+  double* out = partial + ((size_t)pair * nchunk + ch) * d.rec_stride;
+  for (int e = threadIdx.x; e < d.rec_stride; e += blockDim.x) {
+    double sum = 0.0;
+    for (int fl = fa; fl < fb; ++fl) {
+      const int v = (fl * d.C + c) * d.B + b;
+      if (t.view_count[v] == 0) continue;
+      sum += rec[(size_t)v * d.rec_stride + e];
+    }
+    out[e] = sum;
+  }
+}
+
+// shared part, stage 2 (single block): H_ss (dense ns x ns), g and diag of the shared parameters, total cost.
+// Pairs are folded in sequentially so that every H_ss entry is summed in a fixed order.
+__global__ void k_shared_final(Dims d, const double* __restrict__ partial, int nchunk, const uint16_t* __restrict__ tri,
+                               double* __restrict__ Hss, double* __restrict__ g, double* __restrict__ diag,
+                               double* __restrict__ cost_count) {
+  __shared__ double scratch[16];
+  const int ns = d.ns, NL = d.NL;
+  for (int e = threadIdx.x; e < ns * ns; e += blockDim.x) Hss[e] = 0.0;
+  for (int s = threadIdx.x; s < ns; s += blockDim.x) g[d.shared_to_x(s)] = 0.0;
+  __syncthreads();
+  double cost = 0.0, cnt = 0.0;
+  for (int pair = 0; pair < d.C * d.B; ++pair) {
+    const int c = pair / d.B, b = pair % d.B;
+    const double* base = partial + (size_t)pair * nchunk * d.rec_stride;
+    for (int e = threadIdx.x; e < d.rec_size + 2; e += blockDim.x) {
+      double val = 0.0;
+      for (int ch = 0; ch < nchunk; ++ch) val += base[(size_t)ch * d.rec_stride + e];
+      if (e >= d.rec_size) {
+        if (e == d.rec_size) cost += val; else cnt += val;
+        continue;
+      }
+      const int ij = tri[e];
+      const int i = ij >> 8, j = ij & 255;
+      if (i == NL) continue;                                   // (r, r) = sum f^2, the cost is carried separately
+      if (local_is_frame(d, i) || local_is_frame(d, j)) continue;
+      // frame index is irrelevant for shared parameters (hand-eye blocks do not depend on f either)
+      const int gi = local_to_x(d, 0, c, b, i);
+      if (gi < 0) continue;
+      const int si = d.x_to_shared(gi);
+      if (j == NL) {
+        g[gi] += val;
+        continue;
+      }
+      const int gj = local_to_x(d, 0, c, b, j);
+      if (gj < 0) continue;
+      const int sj = d.x_to_shared(gj);
+      Hss[si * ns + sj] += val;
+      if (si != sj) Hss[sj * ns + si] += val;
+    }
+    __syncthreads();
+  }
+  for (int s = threadIdx.x; s < ns; s += blockDim.x) diag[d.shared_to_x(s)] = Hss[s * ns + s];
+  const double ctot = block_reduce<false>(cost, scratch);
+  const double ntot = block_reduce<false>(cnt, scratch);
+  if (threadIdx.x == 0) {
+    cost_count[0] = ctot;
+    cost_count[1] = ntot;
+  }
+}
+
+// dense J^T J in x order from the block form (debug / parity tests)
+__global__ void k_dense_hessian(Dims d, const double* __restrict__ Hss, const double* __restrict__ Hfs,
+                                const double* __restrict__ Hff, double* __restrict__ H) {
+  const size_t n = d.n;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < n * n; e += (size_t)gridDim.x * blockDim.x) {
+    const int i = (int)(e / n), j = (int)(e % n);
+    const int si = d.x_to_shared(i), sj = d.x_to_shared(j);
+    double val = 0.0;
+    auto frame_of = [&](int xi, int& fl, int& dd) {
+      int o = xi - d.off_motion;
+      int half = 0;
+      if (o >= 6 * d.F) { o -= 6 * d.F; half = 1; }
+      fl = o / 6 - d.f0;
+      dd = o % 6 + 6 * half;
+    };
+    if (si >= 0 && sj >= 0) {
+      val = Hss[(size_t)si * d.ns + sj];
+    } else if (si < 0 && sj < 0) {
+      int fi, di, fj, dj;
+      frame_of(i, fi, di);
+      frame_of(j, fj, dj);
+      if (fi == fj && fi >= 0 && fi < d.Fl) val = Hff[((size_t)fi * d.DF + di) * d.DF + dj];
+    } else {
+      int fl, dd;
+      frame_of(si < 0 ? i : j, fl, dd);
+      const int s = si < 0 ? sj : si;
+      if (fl >= 0 && fl < d.Fl) val = Hfs[((size_t)fl * d.DF + dd) * d.ns + s];
+    }
+    H[e] = val;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// trust-region driver kernels.  Vectors of length n live on the device and are complete (replicated) on every
+// rank of a frame-sharded problem; only H-dependent partial sums are reduced across ranks.
+// ---------------------------------------------------------------------------------------------------------------
+// scipy compute_jac_scale (common.py:598-611) + g_h = d * g.   out = {|g|_inf, |g_h|^2, |x * scale_inv|^2}
+// (g and diag are complete on every rank: sharded handles all-reduce them before this kernel)
+__global__ void k_vec_scale(Dims d, const double* __restrict__ x, const double* __restrict__ g,
+                            const double* __restrict__ diag, double* __restrict__ scale_inv, double* __restrict__ dsc,
+                            double* __restrict__ gh, int first, double* __restrict__ out) {
+  __shared__ double scratch[16];
+  double mx = 0, gg = 0, xs = 0;
+  for (int i = threadIdx.x; i < d.n; i += blockDim.x) {
+    double si = sqrt(diag[i]);
+    if (first) { if (si == 0.0) si = 1.0; }
+    else si = fmax(si, scale_inv[i]);
+    scale_inv[i] = si;
+    const double di = 1.0 / si;
+    dsc[i] = di;
+    const double gi = g[i];
+    gh[i] = di * gi;
+    mx = fmax(mx, fabs(gi));
+    gg += di * gi * di * gi;
+    xs += x[i] * si * x[i] * si;
+  }
+  const double a = block_reduce<true>(mx, scratch);
+  const double b = block_reduce<false>(gg, scratch);
+  const double c = block_reduce<false>(xs, scratch);
+  if (threadIdx.x == 0) { out[0] = a; out[1] = b; out[2] = c; }
+}
+
+// quadratic forms of H_h = D H D for two vectors u0, u1 (scaled space):
+//   block fl < Fl : frame fl's contribution   q_ab += u_a,f^T D_f (H_fs D_s u_b,s + H_sf^T..)  (see below)
+//   block Fl      : shared part               q_ab += u_a,s^T D_s H_ss D_s u_b,s
+// partial[(blk)*3 + {0,1,2}] = {q00, q01, q11}
+__global__ void k_quadforms(Dims d, const double* __restrict__ Hss, const double* __restrict__ Hfs,
+                            const double* __restrict__ Hff, const double* __restrict__ dsc,
+                            const double* __restrict__ u0, const double* __restrict__ u1,
+                            double* __restrict__ partial) {
+  __shared__ double scratch[16];
+  __shared__ double tf[2][12];
+  const int ns = d.ns, DF = d.DF;
+  double q00 = 0, q01 = 0, q11 = 0;
+  if (blockIdx.x == gridDim.x - 1) {   // last block: shared part (grid = frames-with-DF + 1)
+    // y_a = H_ss (D u_a)_s ; q_ab = sum_i (D u_a)_i y_b,i
+    for (int i = threadIdx.x; i < ns; i += blockDim.x) {
+      const int xi = d.shared_to_x(i);
+      double y0 = 0, y1 = 0;
+      for (int j = 0; j < ns; ++j) {
+        const int xj = d.shared_to_x(j);
+        const double h = Hss[(size_t)i * ns + j], dj = dsc[xj];
+        y0 += h * dj * u0[xj];
+        y1 += h * dj * u1[xj];
+      }
+      const double a0 = dsc[xi] * u0[xi], a1 = dsc[xi] * u1[xi];
+      q00 += a0 * y0; q01 += a0 * y1; q11 += a1 * y1;
+    }
+  } else {
+    const int fl = blockIdx.x, f = d.f0 + fl;
+    const double* hfs = Hfs + (size_t)fl * DF * ns;
+    const double* hff = Hff + (size_t)fl * DF * DF;
+    // t_a[dd] = sum_s H_fs[dd][s] (D u_a)_s      (DF x ns mat-vec, threads over (dd, s-chunks))
+    for (int dd = 0; dd < DF; ++dd) {
+      double p0 = 0, p1 = 0;
+      for (int s = threadIdx.x; s < ns; s += blockDim.x) {
+        const int xs = d.shared_to_x(s);
+        const double h = hfs[dd * ns + s] * dsc[xs];
+        p0 += h * u0[xs];
+        p1 += h * u1[xs];
+      }
+      const double r0 = block_reduce<false>(p0, scratch);
+      const double r1 = block_reduce<false>(p1, scratch);
+      if (threadIdx.x == 0) { tf[0][dd] = r0; tf[1][dd] = r1; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int dd = 0; dd < DF; ++dd) {
+        const int xi = d.frame_to_x(f, dd);
+        const double a0 = dsc[xi] * u0[xi], a1 = dsc[xi] * u1[xi];
+        double h0 = 0, h1 = 0;
+        for (int d2 = 0; d2 < DF; ++d2) {
+          const int xj = d.frame_to_x(f, d2);
+          const double h = hff[dd * DF + d2] * dsc[xj];
+          h0 += h * u0[xj];
+          h1 += h * u1[xj];
+        }
+        // u^T H u over {s, f}: u_f^T H_ff u_f + 2 u_f^T H_fs u_s   (the s^T H_ss s part is block Fl)
+        q00 += a0 * (h0 + 2.0 * tf[0][dd]);
+        q11 += a1 * (h1 + 2.0 * tf[1][dd]);
+        q01 += a0 * (h1 + tf[1][dd]) + a1 * tf[0][dd];
+      }
+    }
+  }
+  const double r00 = block_reduce<false>(q00, scratch);
+  const double r01 = block_reduce<false>(q01, scratch);
+  const double r11 = block_reduce<false>(q11, scratch);
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x * 3 + 0] = r00;
+    partial[blockIdx.x * 3 + 1] = r01;
+    partial[blockIdx.x * 3 + 2] = r11;
+  }
+}
+
+// out[0..2] = {q00, q01, q11} summed over this rank's blocks (sharded handles all-reduce these three),
+// out[3..5] = dots {u0.u0, u0.u1, u1.u1} over the full vectors
+__global__ void k_quadforms_final(Dims d, const double* __restrict__ partial, int nblk,
+                                  const double* __restrict__ u0, const double* __restrict__ u1,
+                                  double* __restrict__ out) {
+  __shared__ double scratch[16];
+  double q[3] = {0, 0, 0};
+  for (int blk = threadIdx.x; blk < nblk; blk += blockDim.x)
+    for (int k = 0; k < 3; ++k) q[k] += partial[blk * 3 + k];
+  double dt[3] = {0, 0, 0};
+  for (int i = threadIdx.x; i < d.n; i += blockDim.x) {
+    dt[0] += u0[i] * u0[i];
+    dt[1] += u0[i] * u1[i];
+    dt[2] += u1[i] * u1[i];
+  }
+  for (int k = 0; k < 3; ++k) {
+    const double qs = block_reduce<false>(q[k], scratch);
+    const double ds = block_reduce<false>(dt[k], scratch);
+    if (threadIdx.x == 0) { out[k] = qs; out[3 + k] = ds; }
+  }
+}
+
+// Schur step 1, one block per frame:  A_ff = D_f H_ff D_f + reg I = L L^T,  W = L^-1 (D_f H_fs D_s)  [DF x ns],
+// y = L^-1 g_h,f.  L is kept for the back-substitution.
+__global__ void k_schur_frames(Dims d, const double* __restrict__ Hfs, const double* __restrict__ Hff,
+                               const double* __restrict__ dsc, const double* __restrict__ gh, double reg,
+                               double* __restrict__ Lf, double* __restrict__ W, double* __restrict__ yf) {
+  __shared__ double L[12 * 12];
+  __shared__ double y[12];
+  const int fl = blockIdx.x, f = d.f0 + fl, DF = d.DF, ns = d.ns;
+  const double* hff = Hff + (size_t)fl * DF * DF;
+  for (int e = threadIdx.x; e < DF * DF; e += blockDim.x) {
+    const int i = e / DF, j = e % DF;
+    L[i * 12 + j] = dsc[d.frame_to_x(f, i)] * hff[e] * dsc[d.frame_to_x(f, j)] + (i == j ? reg : 0.0);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    // dense Cholesky, lower triangle in place (DF <= 12)
+    for (int j = 0; j < DF; ++j) {
+      double s = L[j * 12 + j];
+      for (int k = 0; k < j; ++k) s -= L[j * 12 + k] * L[j * 12 + k];
+      const double dj = sqrt(fmax(s, 1e-300));
+      L[j * 12 + j] = dj;
+      for (int i = j + 1; i < DF; ++i) {
+        double v = L[i * 12 + j];
+        for (int k = 0; k < j; ++k) v -= L[i * 12 + k] * L[j * 12 + k];
+        L[i * 12 + j] = v / dj;
+      }
+    }
+    for (int i = 0; i < DF; ++i) {
+      double v = gh[d.frame_to_x(f, i)];
+      for (int k = 0; k < i; ++k) v -= L[i * 12 + k] * y[k];
+      y[i] = v / L[i * 12 + i];
+    }
+    for (int i = 0; i < DF; ++i) yf[fl * DF + i] = y[i];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < DF * DF; e += blockDim.x) Lf[(size_t)fl * DF * DF + e] = L[(e / DF) * 12 + (e % DF)];
+  const double* hfs = Hfs + (size_t)fl * DF * ns;
+  double* w = W + (size_t)fl * DF * ns;
+  for (int s = threadIdx.x; s < ns; s += blockDim.x) {
+    const double ds = dsc[d.shared_to_x(s)];
+    double col[12];
+    for (int i = 0; i < DF; ++i) {
+      double v = dsc[d.frame_to_x(f, i)] * hfs[i * ns + s] * ds;
+      for (int k = 0; k < i; ++k) v -= L[i * 12 + k] * col[k];
+      col[i] = v / L[i * 12 + i];
+      w[i * ns + s] = col[i];
+    }
+  }
+}
+
+// Schur step 2: partial SYRK  P[split][tile] = sum_{k in split} W[k][ti*16..]^T W[k][tj*16..]  over the stacked rows
+// k = (frame, dd) of W [K x ns].  One wavefront per (upper tile, K split); MFMA f64 16x16x4 reads its operands
+// straight from global memory (row-major W: 128-byte coalesced segments per 16 lanes).
+template <bool MFMA>
+__global__ __launch_bounds__(64) void k_schur_syrk(int K, int ns, int ntile, int ksplit, const double* __restrict__ W,
+                                                   double* __restrict__ P) {
+  const int tile = blockIdx.x, split = blockIdx.y, lane = threadIdx.x;
+  // decode upper-triangular tile index
+  int ti = 0, rem = tile;
+  while (rem >= ntile - ti) { rem -= ntile - ti; ++ti; }
+  const int tj = ti + rem;
+  const int per = ((K + ksplit - 1) / ksplit + 3) / 4 * 4;
+  const int k0 = split * per, k1 = min(K, k0 + per);
+  double* out = P + ((size_t)split * (ntile * (ntile + 1) / 2) + tile) * 256;
+  const int rsub = lane >> 4, csub = lane & 15;
+  const int ci = ti * 16 + csub, cj = tj * 16 + csub;
+  if constexpr (MFMA) {
+    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+    for (int k = k0; k < k1; k += 4) {
+      const int kk = k + rsub;
+      const double a = (kk < k1 && ci < ns) ? W[(size_t)kk * ns + ci] : 0.0;
+      const double b = (kk < k1 && cj < ns) ? W[(size_t)kk * ns + cj] : 0.0;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+    for (int r = 0; r < 4; ++r) out[(rsub + 4 * r) * 16 + csub] = acc[r];
+  } else {
+    // lane handles rows {rsub + 4 r} x column csub of the tile
+    double acc[4] = {0, 0, 0, 0};
+    for (int k = k0; k < k1; ++k) {
+      const double b = cj < ns ? W[(size_t)k * ns + cj] : 0.0;
+      for (int r = 0; r < 4; ++r) {
+        const int ri = ti * 16 + rsub + 4 * r;
+        acc[r] += (ri < ns ? W[(size_t)k * ns + ri] : 0.0) * b;
+      }
+    }
+    for (int r = 0; r < 4; ++r) out[(rsub + 4 * r) * 16 + csub] = acc[r];
+  }
+}
+
+// Schur step 3:  S = D_s H_ss D_s - sum_splits P  (reg I is added after the cross-rank reduction),
+//                rhs = [own shared gradient] - W^T y.   buf = [S (ns*ns) | rhs (ns)]
+__global__ void k_schur_reduce(Dims d, const double* __restrict__ Hss, const double* __restrict__ dsc,
+                               const double* __restrict__ gh, const double* __restrict__ P, int ntile, int ksplit,
+                               const double* __restrict__ W, const double* __restrict__ yf, int K, double g_weight,
+                               double* __restrict__ buf) {
+  const int ns = d.ns;
+  const int nt2 = ntile * (ntile + 1) / 2;
+  const int total = ns * ns + ns;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    if (e < ns * ns) {
+      const int i = e / ns, j = e % ns;
+      const int a = min(i, j), b = max(i, j);
+      const int ti = a / 16, tj = b / 16;
+      const int tile = ti * ntile - (ti * (ti - 1)) / 2 + (tj - ti);
+      double sum = 0.0;
+      if (K > 0)
+        for (int sp = 0; sp < ksplit; ++sp) sum += P[((size_t)sp * nt2 + tile) * 256 + (a % 16) * 16 + (b % 16)];
+      buf[e] = dsc[d.shared_to_x(i)] * Hss[e] * dsc[d.shared_to_x(j)] - sum;
+    } else {
+      const int s = e - ns * ns;
+      double sum = 0.0;
+      for (int k = 0; k < K; ++k) sum += W[(size_t)k * ns + s] * yf[k];
+      buf[e] = g_weight * gh[d.shared_to_x(s)] - sum;
+    }
+  }
+}
+
+// dense Cholesky solve of (S + reg I) p = rhs, single workgroup, right-looking on the global (L2-resident) matrix.
+// buf = [S (ns*ns) | rhs (ns)];  p_s is written to ps[ns].  S is overwritten by its factor.
+__global__ void k_chol_solve(int ns, double reg, double* __restrict__ buf, double* __restrict__ ps,
+                             int* __restrict__ info) {
+  double* S = buf;
+  double* rhs = buf + (size_t)ns * ns;
+  __shared__ double piv;
+  __shared__ int bad;
+  if (threadIdx.x == 0) bad = 0;
+  for (int i = threadIdx.x; i < ns; i += blockDim.x) S[(size_t)i * ns + i] += reg;
+  __syncthreads();
+  for (int j = 0; j < ns; ++j) {
+    if (threadIdx.x == 0) {
+      double s = S[(size_t)j * ns + j];
+      if (!(s > 0.0)) { bad = j + 1; s = 1e-300; }
+      piv = sqrt(s);
+      S[(size_t)j * ns + j] = piv;
+    }
+    __syncthreads();
+    const double pj = piv;
+    for (int i = j + 1 + threadIdx.x; i < ns; i += blockDim.x) S[(size_t)i * ns + j] /= pj;
+    __syncthreads();
+    // trailing update of the lower triangle: S[i][k] -= S[i][j] S[k][j], j < k <= i
+    const int m = ns - j - 1;
+    for (int e = threadIdx.x; e < m * m; e += blockDim.x) {
+      const int i = j + 1 + e / m, k = j + 1 + e % m;
+      if (k <= i) S[(size_t)i * ns + k] -= S[(size_t)i * ns + j] * S[(size_t)k * ns + j];
+    }
+    __syncthreads();
+  }
+  // forward / backward substitution (thread 0 drives, inner products in parallel)
+  __shared__ double scratch[16];
+  __shared__ double cur;
+  for (int i = 0; i < ns; ++i) {
+    double part = 0.0;
+    for (int k = threadIdx.x; k < i; k += blockDim.x) part += S[(size_t)i * ns + k] * rhs[k];
+    const double tot = block_reduce<false>(part, scratch);
+    if (threadIdx.x == 0) rhs[i] = (rhs[i] - tot) / S[(size_t)i * ns + i];
+    __syncthreads();
+  }
+  for (int i = ns - 1; i >= 0; --i) {
+    double part = 0.0;
+    for (int k = i + 1 + threadIdx.x; k < ns; k += blockDim.x) part += S[(size_t)k * ns + i] * rhs[k];
+    const double tot = block_reduce<false>(part, scratch);
+    if (threadIdx.x == 0) {
+      cur = (rhs[i] - tot) / S[(size_t)i * ns + i];
+      rhs[i] = cur;
+      ps[i] = cur;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) info[0] = bad;
+}
+
+// back-substitution: gn_s = p_s ; gn_f = L^-T (y_f - W p_s)  (one block per frame; block Fl copies the shared part)
+__global__ void k_schur_backsub(Dims d, const double* __restrict__ Lf, const double* __restrict__ W,
+                                const double* __restrict__ yf, const double* __restrict__ ps, double* __restrict__ gn) {
+  __shared__ double scratch[16];
+  __shared__ double z[12];
+  const int ns = d.ns, DF = d.DF;
+  if (blockIdx.x == gridDim.x - 1) {   // last block: shared part
+    for (int i = threadIdx.x; i < d.n; i += blockDim.x) {
+      const int s = d.x_to_shared(i);
+      if (s >= 0) gn[i] = ps[s];         // frame entries: written by their own blocks; other shards' stay 0 (memset)
+    }
+    return;
+  }
+  const int fl = blockIdx.x, f = d.f0 + fl;
+  const double* w = W + (size_t)fl * DF * ns;
+  for (int dd = 0; dd < DF; ++dd) {
+    double part = 0.0;
+    for (int s = threadIdx.x; s < ns; s += blockDim.x) part += w[dd * ns + s] * ps[s];
+    const double tot = block_reduce<false>(part, scratch);
+    if (threadIdx.x == 0) z[dd] = yf[fl * DF + dd] - tot;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double* L = Lf + (size_t)fl * DF * DF;
+    double p[12];
+    for (int i = DF - 1; i >= 0; --i) {
+      double v = z[i];
+      for (int k = i + 1; k < DF; ++k) v -= L[k * DF + i] * p[k];
+      p[i] = v / L[i * DF + i];
+    }
+    for (int i = 0; i < DF; ++i) gn[d.frame_to_x(f, i)] = p[i];
+  }
+}
+
+// step: p_h = alpha u0 + beta u1; step = d * p_h; x_new = x + step.   out = {|p_h|^2, |step|^2, |x|^2}
+__global__ void k_vec_step(Dims d, const double* __restrict__ x, const double* __restrict__ dsc,
+                           const double* __restrict__ u0, const double* __restrict__ u1, double alpha, double beta,
+                           double* __restrict__ xnew, double* __restrict__ out) {
+  __shared__ double scratch[16];
+  double ph = 0, st = 0, xx = 0;
+  for (int i = threadIdx.x; i < d.n; i += blockDim.x) {
+    const double p = alpha * u0[i] + beta * u1[i];
+    const double s = dsc[i] * p;
+    xnew[i] = x[i] + s;
+    ph += p * p;
+    st += s * s;
+    xx += x[i] * x[i];
+  }
+  const double a = block_reduce<false>(ph, scratch);
+  const double b = block_reduce<false>(st, scratch);
+  const double c = block_reduce<false>(xx, scratch);
+  if (threadIdx.x == 0) { out[0] = a; out[1] = b; out[2] = c; }
+}
+
+// MFMA layout self-test: D = A^T-style product with an asymmetric operand pair, checked on the host
+__global__ void k_mfma_probe(const double* __restrict__ V /*[4][32]*/, double* __restrict__ out /*[16][16]*/) {
+  const int lane = threadIdx.x, rsub = lane >> 4, csub = lane & 15;
+  double4_t acc = {0.0, 0.0, 0.0, 0.0};
+  const double a = V[rsub * 32 + csub], b = V[rsub * 32 + 16 + csub];
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  for (int r = 0; r < 4; ++r) out[(rsub + 4 * r) * 16 + csub] = acc[r];
+}
+
+}  // namespace mcba

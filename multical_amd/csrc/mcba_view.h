@@ -1,0 +1,242 @@
+// mcba_view.h -- per-slot / per-view device functions of the hot path (no thread indexing, no LDS):
+//   prep_item / view_item    x -> pose, camera, board-point and per-view chain tables
+//   slot_forward             forward model of one observation slot
+//   view_column / local_to_x pose-block structure of a view (column of That, x index of a local parameter)
+//   point_rows               the 2 x NV row pair V = [E | K | r] of one observation
+// They are __host__ __device__ so that tests/hostmath can run the SAME source serially with g++ on the CPU-only build
+// box and compare it with the oracle; the product only ever calls them from kernels.
+#pragma once
+#include "mcba_device.h"
+
+namespace mcba {
+
+MCBA_HD double param_value(const Tables& t, const double* x, int j) {
+  const int a = t.full2act[j];
+  return a >= 0 ? x[a] : t.xfull[j];
+}
+
+MCBA_HD int tri_index(int i, int j, int N1) {   // packed upper triangle, i <= j
+  return i * N1 - (i * (i - 1)) / 2 + (j - i);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward model of one table slot (motion/static_frames.py:16-25, motion/rolling_frames.py:15-41)
+// ---------------------------------------------------------------------------------------------------------------
+template <int ND, bool FISH, bool ROLL, bool JAC>
+MCBA_HD void slot_forward(const Dims& d, const Tables& t, int v, int c, int b, int p, double2 ob,
+                                             double* uv, double* A, double* Kc, double* Xs, double* Xe, double& tr) {
+  const double* X = t.board_points + 3 * (size_t)(b * d.P + p);
+  const double* V = t.view + (size_t)v * (VIEW_STRIDE * (ROLL ? 2 : 1));
+  const double* cam = t.cam + (size_t)c * CAM_STRIDE;
+  const double bx = X[0], by = X[1], bz = X[2];
+  double Xc[3];
+  for (int i = 0; i < 3; ++i) Xs[i] = V[3 * i] * bx + V[3 * i + 1] * by + V[3 * i + 2] * bz + V[9 + i];
+  if constexpr (ROLL) {
+    const double* W = V + VIEW_STRIDE;
+    for (int i = 0; i < 3; ++i) Xe[i] = W[3 * i] * bx + W[3 * i + 1] * by + W[3 * i + 2] * bz + W[9 + i];
+    tr = ob.y / cam[CAM_HEIGHT];                                  // rolling_frames.py:15-19 (observed row)
+    for (int i = 0; i < 3; ++i) Xc[i] = Xs[i] * (1.0 - tr) + Xe[i] * tr;   // interpolate.py:6-8
+  } else {
+    tr = 0.0;
+    for (int i = 0; i < 3; ++i) Xc[i] = Xs[i];
+  }
+  project_point<ND, FISH, JAC>(cam, Xc, uv, A, Kc);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// pose-block structure of a view: column j of That (DE rows) and the x index of every local parameter
+// ---------------------------------------------------------------------------------------------------------------
+MCBA_HD void view_column(const Dims& d, const Tables& t, int f, int c, int b, int j, double* col) {
+  const int k = j / 6, jj = j % 6;
+  const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  const double* Pc = t.pose + (size_t)(d.pose_cam + c) * POSE_STRIDE;
+  const double* Pb = t.pose + (size_t)(d.pose_board + b) * POSE_STRIDE;
+  const double* Rc = Pc + POSE_R;
+  const double* tc = Pc + POSE_T;
+  if (d.motion == MOTION_STATIC) {
+    const double* Pf = t.pose + (size_t)(d.pose_motion + f) * POSE_STRIDE;
+    if (k == 0) {
+      view_pose_column(I3, Pc + POSE_L, tc, jj, col);
+    } else {
+      double R1[9], t1[3];
+      se3_mul(Rc, tc, Pf + POSE_R, Pf + POSE_T, R1, t1);          // camera . frame
+      if (k == 1) {
+        view_pose_column(Rc, Pf + POSE_L, t1, jj, col);
+      } else {
+        double o[3], v3[3];
+        mat3_vec(R1, Pb + POSE_T, v3);
+        for (int i = 0; i < 3; ++i) o[i] = t1[i] + v3[i];
+        view_pose_column(R1, Pb + POSE_L, o, jj, col);
+      }
+    }
+  } else if (d.motion == MOTION_ROLLING) {
+    for (int i = 0; i < 12; ++i) col[i] = 0.0;
+    if (k == 0) {
+      view_pose_column(I3, Pc + POSE_L, tc, jj, col);
+      for (int i = 0; i < 6; ++i) col[6 + i] = col[i];
+    } else {
+      for (int ch = 0; ch < 2; ++ch) {
+        if ((k == 1 && ch == 1) || (k == 2 && ch == 0)) continue;
+        const double* Pf = t.pose + (size_t)(d.pose_motion + ch * d.F + f) * POSE_STRIDE;
+        double R1[9], t1[3];
+        se3_mul(Rc, tc, Pf + POSE_R, Pf + POSE_T, R1, t1);
+        if (k == 3) {
+          double o[3], v3[3];
+          mat3_vec(R1, Pb + POSE_T, v3);
+          for (int i = 0; i < 3; ++i) o[i] = t1[i] + v3[i];
+          view_pose_column(R1, Pb + POSE_L, o, jj, col + 6 * ch);
+        } else {
+          view_pose_column(Rc, Pf + POSE_L, t1, jj, col + 6 * ch);
+        }
+      }
+    }
+  } else {  // hand-eye: chain camera . G . B_f . Wb . board ; local blocks: cam | wb | gc | board
+    const double* Wb = t.pose + (size_t)(d.pose_motion + 0) * POSE_STRIDE;
+    const double* G = t.pose + (size_t)(d.pose_motion + 1) * POSE_STRIDE;
+    const double* Bf = t.bwg + 12 * (size_t)f;
+    if (k == 0) {
+      view_pose_column(I3, Pc + POSE_L, tc, jj, col);
+    } else {
+      double R1[9], t1[3];
+      se3_mul(Rc, tc, G + POSE_R, G + POSE_T, R1, t1);            // camera . G
+      if (k == 2) {
+        view_pose_column(Rc, G + POSE_L, t1, jj, col);
+      } else {
+        double R2[9], t2[3], R3[9], t3[3];
+        se3_mul(R1, t1, Bf, Bf + 9, R2, t2);                       // . B_f
+        se3_mul(R2, t2, Wb + POSE_R, Wb + POSE_T, R3, t3);         // . Wb
+        if (k == 1) {
+          view_pose_column(R2, Wb + POSE_L, t3, jj, col);
+        } else {
+          double o[3], v3[3];
+          mat3_vec(R3, Pb + POSE_T, v3);
+          for (int i = 0; i < 3; ++i) o[i] = t3[i] + v3[i];
+          view_pose_column(R3, Pb + POSE_L, o, jj, col);
+        }
+      }
+    }
+  }
+}
+
+// x index of local parameter i of view (f, c, b); -1 when its block is not optimised (or i is the residual column)
+MCBA_HD int local_to_x(const Dims& d, int f, int c, int b, int i) {
+  const int npose = 6 * d.NPB;
+  if (i < npose) {
+    const int k = i / 6, jj = i % 6;
+    if (k == 0) return d.off_campose < 0 ? -1 : d.off_campose + 6 * c + jj;
+    if (k == d.NPB - 1) return d.off_boardpose < 0 ? -1 : d.off_boardpose + 6 * b + jj;
+    if (d.off_motion < 0) return -1;
+    if (d.motion == MOTION_STATIC) return d.off_motion + 6 * f + jj;
+    if (d.motion == MOTION_ROLLING) return d.off_motion + (k == 2 ? 6 * d.F : 0) + 6 * f + jj;
+    return d.off_motion + 6 * (k - 1) + jj;
+  }
+  const int q = i - npose;
+  if (q >= d.KI || d.off_cameras < 0) return -1;
+  return d.off_cameras + c * (5 + d.ND) + (q < 4 ? q : q + 1);   // skip the skew slot (camera.py:153)
+}
+
+// is local parameter i an ELIMINATED per-frame parameter?
+MCBA_HD bool local_is_frame(const Dims& d, int i) {
+  if (d.DF == 0) return false;
+  return i >= 6 && i < 6 + d.DF;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// per-point row pair V = [E | K | r] (scaled for the robust loss); returns rho0_u + rho0_v
+// ---------------------------------------------------------------------------------------------------------------
+template <int ND, bool FISH, bool ROLL, bool OPTK>
+MCBA_HD double point_rows(const Dims& d, const Tables& t, int v, int c, int b, int p, double2 ob,
+                                             double* vr /*[2][NV]*/) {
+  constexpr int DE = ROLL ? 12 : 6, KI = OPTK ? 4 + ND : 0, NV = DE + KI + 1, KIA = 4 + ND;
+  double uv[2], A[6], Kc[2 * KIA], Xs[3], Xe[3], tr;
+  slot_forward<ND, FISH, ROLL, true>(d, t, v, c, b, p, ob, uv, A, Kc, Xs, Xe, tr);
+  const double e[2] = {uv[0] - ob.x, uv[1] - ob.y};
+  double rs[2], fs[2], rho = 0.0;
+  rho += robust_loss(d.loss, d.f_scale, e[0], &rs[0], &fs[0]);
+  rho += robust_loss(d.loss, d.f_scale, e[1], &rs[1], &fs[1]);
+  double E[12];
+  if constexpr (ROLL) {
+    double Es[12], Ee[12];
+    base_rows(A, Xs, Es);
+    base_rows(A, Xe, Ee);
+    for (int a = 0; a < 2; ++a)
+      for (int i = 0; i < 6; ++i) {
+        vr[a * NV + i] = rs[a] * (1.0 - tr) * Es[6 * a + i];
+        vr[a * NV + 6 + i] = rs[a] * tr * Ee[6 * a + i];
+      }
+  } else {
+    base_rows(A, Xs, E);
+    for (int a = 0; a < 2; ++a)
+      for (int i = 0; i < 6; ++i) vr[a * NV + i] = rs[a] * E[6 * a + i];
+  }
+  if constexpr (OPTK) {
+    for (int a = 0; a < 2; ++a)
+      for (int i = 0; i < KI; ++i) vr[a * NV + DE + i] = rs[a] * Kc[a * KIA + i];
+  }
+  vr[NV - 1] = e[0] * fs[0];
+  vr[2 * NV - 1] = e[1] * fs[1];
+  return rho;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// table preparation (bodies of k_prep / k_views)
+// ---------------------------------------------------------------------------------------------------------------
+MCBA_HD void prep_item(const Dims& d, const Tables& t, const double* x, int i) {
+  if (i < d.n_pose) {
+    int j;
+    if (i < d.pose_board) j = d.foff_campose + 6 * i;
+    else if (i < d.pose_motion) j = d.foff_boardpose + 6 * (i - d.pose_board);
+    else j = d.foff_motion + 6 * (i - d.pose_motion);
+    double rt[6];
+    for (int k = 0; k < 6; ++k) rt[k] = param_value(t, x, j + k);
+    double e[POSE_STRIDE];
+    pose_entry(rt, e);
+    for (int k = 0; k < POSE_STRIDE; ++k) t.pose[(size_t)i * POSE_STRIDE + k] = e[k];
+    return;
+  }
+  i -= d.n_pose;
+  if (i < d.C) {
+    double p[5 + MAX_DIST];
+    const int kc = 5 + d.ND;
+    for (int k = 0; k < kc; ++k) p[k] = param_value(t, x, d.foff_cameras + i * kc + k);
+    double e[CAM_STRIDE];
+    camera_entry(p, d.ND, t.img_h[i], t.fix_aspect[i] != 0, e);
+    for (int k = 0; k < CAM_STRIDE; ++k) t.cam[(size_t)i * CAM_STRIDE + k] = e[k];
+    return;
+  }
+  i -= d.C;
+  if (i < d.B * d.P) {
+    const int b = i / d.P, p = i % d.P;
+    const int nb = t.board_off[b + 1] - t.board_off[b];
+    for (int k = 0; k < 3; ++k)
+      t.board_points[3 * i + k] = (p < nb) ? param_value(t, x, d.foff_boards + 3 * (t.board_off[b] + p) + k) : 0.0;
+  }
+}
+
+MCBA_HD void view_item(const Dims& d, const Tables& t, int i) {
+  const int nch = d.motion == MOTION_ROLLING ? 2 : 1;
+  if (i >= d.views() * nch) return;
+  const int v = i / nch, ch = i % nch;
+  const int b = v % d.B, c = (v / d.B) % d.C, fl = v / (d.B * d.C), f = d.f0 + fl;
+  const double* Pc = t.pose + (size_t)(d.pose_cam + c) * POSE_STRIDE;
+  const double* Pb = t.pose + (size_t)(d.pose_board + b) * POSE_STRIDE;
+  double R1[9], t1[3], R2[9], t2[3];
+  if (d.motion == MOTION_HAND_EYE) {
+    const double* Wb = t.pose + (size_t)(d.pose_motion + 0) * POSE_STRIDE;
+    const double* G = t.pose + (size_t)(d.pose_motion + 1) * POSE_STRIDE;
+    const double* Bf = t.bwg + 12 * (size_t)f;
+    se3_mul(Pc + POSE_R, Pc + POSE_T, G + POSE_R, G + POSE_T, R1, t1);
+    se3_mul(R1, t1, Bf, Bf + 9, R2, t2);
+    se3_mul(R2, t2, Wb + POSE_R, Wb + POSE_T, R1, t1);
+    se3_mul(R1, t1, Pb + POSE_R, Pb + POSE_T, R2, t2);
+  } else {
+    const double* Pf = t.pose + (size_t)(d.pose_motion + ch * d.F + f) * POSE_STRIDE;
+    se3_mul(Pc + POSE_R, Pc + POSE_T, Pf + POSE_R, Pf + POSE_T, R1, t1);
+    se3_mul(R1, t1, Pb + POSE_R, Pb + POSE_T, R2, t2);
+  }
+  double* out = t.view + (size_t)v * d.view_stride() + ch * VIEW_STRIDE;
+  for (int k = 0; k < 9; ++k) out[k] = R2[k];
+  for (int k = 0; k < 3; ++k) out[9 + k] = t2[k];
+}
+
+}  // namespace mcba

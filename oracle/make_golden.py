@@ -42,6 +42,10 @@ def _edge(rig):
   rig.camera_valid[2] = False
   rig.init.camera_poses[2] = np.eye(4)
   rig.init.cameras[1].fix_aspect = True      # camera.py:147-148,159-160
+  # a camera calibrated with CALIB_FIX_ASPECT_RATIO has fx == fy; with fx != fy the reference's own
+  # `reprojection_error` (raw intrinsics) and `evaluate` (param_vec -> mean focal length) would disagree
+  rig.init.cameras[1].intrinsic = rig.init.cameras[1].intrinsic.copy()
+  rig.init.cameras[1].intrinsic[1, 1] = rig.init.cameras[1].intrinsic[0, 0]
   rig.init.cameras[0].has_skew = True        # camera.py:139-141 (skew is carried but cv2 ignores it)
   rig.init.cameras[0].intrinsic = rig.init.cameras[0].intrinsic.copy()
   rig.init.cameras[0].intrinsic[0, 1] = 0.7

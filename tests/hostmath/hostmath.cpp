@@ -1,0 +1,234 @@
+// TEST INFRASTRUCTURE -- serial CPU harness around the product's own device functions.
+//
+// Compiles multical_amd/csrc/mcba_view.h + mcba_math.h + mcba_lower.h with g++ (they are __host__ __device__ /
+// plain C++) and runs them in plain loops, so that the formulas and index maps the HIP kernels use can be checked
+// against the oracle on the GPU-less build box.  It mirrors the kernels' algebra (per-view S = V^T V, M = That^T S That,
+// scatter through local_to_x) but none of their parallel structure.  NEVER loaded by multical_amd: the product has
+// no CPU path.  Built by __graft_entry__.build() into tests/hostmath/_build/libmcba_hostmath.so.
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../multical_amd/csrc/mcba_lower.h"
+#include "../../multical_amd/csrc/mcba_view.h"
+
+using namespace mcba;
+
+namespace {
+thread_local std::string g_err;
+
+struct Host {
+  HostProblem hp;
+  Tables t{};
+  std::vector<double> board_points, pose, cam, view;
+  void init(const mcba_problem* p) {
+    lower_problem(p, hp);
+    const Dims& d = hp.d;
+    board_points.assign((size_t)d.B * d.P * 3, 0.0);
+    pose.assign((size_t)d.n_pose * POSE_STRIDE, 0.0);
+    cam.assign((size_t)d.C * CAM_STRIDE, 0.0);
+    view.assign((size_t)d.views() * d.view_stride(), 0.0);
+    t.obs = hp.obs.data(); t.inlier = hp.inlier.data(); t.evalid = hp.evalid.data(); t.obs_index = hp.obs_index.data();
+    t.view_count = hp.view_count.data(); t.board_off = hp.board_off.data(); t.full2act = hp.full2act.data();
+    t.xfull = hp.xfull.data(); t.bwg = hp.bwg.data(); t.img_h = hp.img_h.data(); t.fix_aspect = hp.fix_aspect.data();
+    t.board_points = board_points.data(); t.pose = pose.data(); t.cam = cam.data(); t.view = view.data();
+  }
+  void eval_tables(const double* x) {
+    const Dims& d = hp.d;
+    const int items = d.n_pose + d.C + d.B * d.P;
+    for (int i = 0; i < items; ++i) prep_item(d, t, x, i);
+    const int nv = d.views() * (d.motion == MOTION_ROLLING ? 2 : 1);
+    for (int i = 0; i < nv; ++i) view_item(d, t, i);
+  }
+};
+
+template <int ND, bool FISH, bool ROLL>
+void residuals_t(Host& h, double* r, double* err, uint8_t* valid) {
+  const Dims& d = h.hp.d;
+  for (int s = 0; s < d.slots(); ++s) {
+    const int p = s % d.P, v = s / d.P;
+    const int b = v % d.B, c = (v / d.B) % d.C, fl = v / (d.B * d.C), f = d.f0 + fl;
+    const double2 ob = h.t.obs[s];
+    double uv[2], Xs[3], Xe[3], tr;
+    slot_forward<ND, FISH, ROLL, false>(d, h.t, v, c, b, p, ob, uv, nullptr, nullptr, Xs, Xe, tr);
+    const double ex = uv[0] - ob.x, ey = uv[1] - ob.y;
+    const int idx = h.t.obs_index[s];
+    if (r && idx >= 0) { r[2 * idx] = ex; r[2 * idx + 1] = ey; }
+    if (err) {
+      const size_t ri = (((size_t)c * d.F + f) * d.B + b) * d.P + p;
+      const bool ok = h.t.evalid[s] != 0;
+      err[ri] = ok ? std::sqrt(ex * ex + ey * ey) : 0.0;
+      valid[ri] = ok;
+    }
+  }
+}
+
+template <int ND, bool FISH, bool ROLL>
+void jacobian_t(Host& h, int row_nnz, double* vals, int32_t* cols) {
+  const Dims& d = h.hp.d;
+  constexpr int DE = ROLL ? 12 : 6, KIA = 4 + ND, NV = DE + KIA + 1;
+  for (int s = 0; s < d.slots(); ++s) {
+    const int idx = h.t.obs_index[s];
+    if (idx < 0) continue;
+    const int p = s % d.P, v = s / d.P;
+    const int b = v % d.B, c = (v / d.B) % d.C, fl = v / (d.B * d.C), f = d.f0 + fl;
+    Dims dl = d;
+    dl.loss = 0;
+    double vr[2 * NV];
+    point_rows<ND, FISH, ROLL, true>(dl, h.t, v, c, b, p, h.t.obs[s], vr);
+    double* o0 = vals + (size_t)(2 * idx) * row_nnz;
+    double* o1 = o0 + row_nnz;
+    int32_t* oc = cols + (size_t)idx * row_nnz;
+    int pos = 0;
+    const int order[4] = {0, d.NPB - 1, 1, 2};
+    for (int oi = 0; oi < d.NPB; ++oi) {
+      const int k = order[oi];
+      if (local_to_x(d, f, c, b, 6 * k) < 0) continue;
+      for (int jj = 0; jj < 6; ++jj) {
+        double col[12];
+        view_column(d, h.t, f, c, b, 6 * k + jj, col);
+        double a0 = 0, a1 = 0;
+        for (int a = 0; a < DE; ++a) { a0 += vr[a] * col[a]; a1 += vr[NV + a] * col[a]; }
+        o0[pos] = a0; o1[pos] = a1; oc[pos] = local_to_x(d, f, c, b, 6 * k + jj);
+        ++pos;
+      }
+    }
+    if (d.off_cameras >= 0) {
+      const int base = d.off_cameras + c * (5 + ND);
+      for (int q = 0; q < 5 + ND; ++q) {
+        const int lq = q < 4 ? q : q - 1;
+        const bool skew = q == 4;
+        o0[pos] = skew ? 0.0 : vr[DE + lq];
+        o1[pos] = skew ? 0.0 : vr[NV + DE + lq];
+        oc[pos] = base + q;
+        ++pos;
+      }
+    }
+  }
+}
+
+// per-view S = V^T V, M = That^T S That, scattered into dense H / g  (the kernels' algebra, serial)
+template <int ND, bool FISH, bool ROLL, bool OPTK>
+void normal_t(Host& h, double* H, double* g, double* cost_out) {
+  const Dims& d = h.hp.d;
+  constexpr int DE = ROLL ? 12 : 6, KI = OPTK ? 4 + ND : 0, NV = DE + KI + 1;
+  const int NPC = 6 * d.NPB, NL = NPC + KI, N1 = NL + 1, n = d.n;
+  double cost = 0.0;
+  std::vector<double> S(NV * NV), That(NV * N1), Y(NV * N1), M(N1 * N1);
+  for (int v = 0; v < d.views(); ++v) {
+    if (h.t.view_count[v] == 0) continue;
+    const int b = v % d.B, c = (v / d.B) % d.C, fl = v / (d.B * d.C), f = d.f0 + fl;
+    std::fill(S.begin(), S.end(), 0.0);
+    for (int p = 0; p < d.P; ++p) {
+      const size_t s = (size_t)v * d.P + p;
+      if (!h.t.inlier[s]) continue;
+      double vr[2 * NV];
+      cost += point_rows<ND, FISH, ROLL, OPTK>(d, h.t, v, c, b, p, h.t.obs[s], vr);
+      for (int a = 0; a < 2; ++a)
+        for (int i = 0; i < NV; ++i)
+          for (int j = 0; j < NV; ++j) S[i * NV + j] += vr[a * NV + i] * vr[a * NV + j];
+    }
+    std::fill(That.begin(), That.end(), 0.0);
+    for (int j = 0; j < NPC; ++j) {
+      double col[12];
+      view_column(d, h.t, f, c, b, j, col);
+      for (int a = 0; a < DE; ++a) That[a * N1 + j] = col[a];
+    }
+    for (int q = 0; q < KI + 1; ++q) That[(DE + q) * N1 + NPC + q] = 1.0;
+    for (int a = 0; a < NV; ++a)
+      for (int j = 0; j < N1; ++j) {
+        double sum = 0;
+        for (int bb = 0; bb < NV; ++bb) sum += S[a * NV + bb] * That[bb * N1 + j];
+        Y[a * N1 + j] = sum;
+      }
+    for (int i = 0; i < N1; ++i)
+      for (int j = 0; j < N1; ++j) {
+        double sum = 0;
+        for (int a = 0; a < NV; ++a) sum += That[a * N1 + i] * Y[a * N1 + j];
+        M[i * N1 + j] = sum;
+      }
+    for (int i = 0; i < NL; ++i) {
+      const int gi = local_to_x(d, f, c, b, i);
+      if (gi < 0) continue;
+      g[gi] += M[i * N1 + NL];
+      for (int j = 0; j < NL; ++j) {
+        const int gj = local_to_x(d, f, c, b, j);
+        if (gj >= 0) H[(size_t)gi * n + gj] += M[i * N1 + j];
+      }
+    }
+  }
+  *cost_out = 0.5 * cost;
+}
+
+#define DISPATCH_CAM(FN, ...)                                                                  \
+  do {                                                                                         \
+    const Dims& dd_ = h.hp.d;                                                                  \
+    const bool roll_ = dd_.motion == MOTION_ROLLING;                                           \
+    if (dd_.fisheye) { if (roll_) FN<4, true, true>(__VA_ARGS__); else FN<4, true, false>(__VA_ARGS__); } \
+    else switch (dd_.ND) {                                                                     \
+      case 4: if (roll_) FN<4, false, true>(__VA_ARGS__); else FN<4, false, false>(__VA_ARGS__); break;   \
+      case 5: if (roll_) FN<5, false, true>(__VA_ARGS__); else FN<5, false, false>(__VA_ARGS__); break;   \
+      case 8: if (roll_) FN<8, false, true>(__VA_ARGS__); else FN<8, false, false>(__VA_ARGS__); break;   \
+      case 12: if (roll_) FN<12, false, true>(__VA_ARGS__); else FN<12, false, false>(__VA_ARGS__); break; \
+      default: if (roll_) FN<14, false, true>(__VA_ARGS__); else FN<14, false, false>(__VA_ARGS__); break; \
+    }                                                                                          \
+  } while (0)
+
+template <int ND, bool FISH, bool ROLL>
+void normal_k(Host& h, double* H, double* g, double* cost) {
+  if (h.hp.d.KI > 0) normal_t<ND, FISH, ROLL, true>(h, H, g, cost);
+  else normal_t<ND, FISH, ROLL, false>(h, H, g, cost);
+}
+
+}  // namespace
+
+#define HM_BEGIN try {
+#define HM_END return 0; } catch (const std::exception& e) { g_err = e.what(); return 1; }
+
+extern "C" {
+
+const char* hm_last_error() { return g_err.c_str(); }
+
+int32_t hm_sizes(const mcba_problem* p, int64_t* n_params, int64_t* n_residuals, int32_t* row_nnz) {
+  HM_BEGIN
+  Host h; h.init(p);
+  const Dims& d = h.hp.d;
+  *n_params = d.n;
+  *n_residuals = 2 * h.hp.n_inliers;
+  int nnz = 0;
+  if (d.off_campose >= 0) nnz += 6;
+  if (d.off_boardpose >= 0) nnz += 6;
+  if (d.off_motion >= 0) nnz += d.motion == MOTION_STATIC ? 6 : 12;
+  if (d.off_cameras >= 0) nnz += 5 + d.ND;
+  *row_nnz = nnz;
+  HM_END
+}
+
+int32_t hm_residuals(const mcba_problem* p, const double* x, double* r, double* err, uint8_t* valid) {
+  HM_BEGIN
+  Host h; h.init(p); h.eval_tables(x);
+  DISPATCH_CAM(residuals_t, h, r, err, valid);
+  HM_END
+}
+
+int32_t hm_jacobian(const mcba_problem* p, const double* x, int32_t row_nnz, double* vals, int32_t* cols) {
+  HM_BEGIN
+  Host h; h.init(p); h.eval_tables(x);
+  DISPATCH_CAM(jacobian_t, h, row_nnz, vals, cols);
+  HM_END
+}
+
+int32_t hm_normal_equations(const mcba_problem* p, const double* x, int32_t loss, double f_scale, double* H, double* g,
+                            double* cost) {
+  HM_BEGIN
+  Host h; h.init(p);
+  h.hp.d.loss = loss; h.hp.d.f_scale = f_scale;
+  h.eval_tables(x);
+  const size_t n = h.hp.d.n;
+  std::memset(H, 0, n * n * sizeof(double));
+  std::memset(g, 0, n * sizeof(double));
+  DISPATCH_CAM(normal_k, h, H, g, cost);
+  HM_END
+}
+
+}  // extern "C"

@@ -1,0 +1,143 @@
+"""CPU: host logic (parameter packing, lowering, C-ABI surface) and the product's device math compiled for the host
+(tests/hostmath) against the golden fixtures of the real reference."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from multical_amd import _lib, synthetic, calibration
+from multical_amd.backend import lower
+from hostmath_lib import HostMath
+from util import SMALL_CASES, ALL_CASES, load_golden, mirror, oracle, golden_jacobian, rel_col_error
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+  header = open(os.path.join(ROOT, "include", "mcba.h")).read()
+  declared = set(re.findall(r"\b(mcba_[a-z_0-9]+)\s*\(", header))
+  declared -= {"mcba_full_size()"}
+  lib = _lib.load()
+  bound = {name for name, _, _ in _lib.SYMBOLS}
+  missing = [s for s in declared if not hasattr(lib, s)]
+  assert not missing, f"libmcba.so lacks {missing}"
+  assert declared <= bound, f"ctypes table lacks {declared - bound}"
+
+
+def test_create_fails_loudly_without_gpu():
+  from util import gpu_available
+  if gpu_available():
+    pytest.skip("GPU present")
+  from multical_amd.backend import Handle
+  with pytest.raises(RuntimeError, match="no HIP device|GPU-only|hip"):
+    Handle(mirror(synthetic.make_rig("tiny")))
+
+
+@pytest.mark.parametrize("name", ALL_CASES)
+def test_parameter_packing_matches_reference(name):
+  g, rig = load_golden(name)
+  c = mirror(rig)
+  assert np.array_equal(c.param_vec, g["x0"])
+  assert np.array_equal(c.inliers, g["inliers0"])
+  # with_param_vec(param_vec) round trip and the canonicalised read-back of a solved vector (rtvec.py:29-32)
+  assert np.array_equal(c.with_param_vec(g["ba_x_raw"]).param_vec, g["ba_x"])
+
+
+def test_lowering_layout():
+  rig = synthetic.make_rig("tiny_rolling")
+  c = mirror(rig)
+  p = lower(c)
+  C_, F, B, P = p.shape
+  assert p.x_full.size == 6 * C_ + 6 * B + 12 * F + C_ * (5 + 5) + 3 * sum(p.board_sizes)
+  assert p.n_params == c.param_vec.size
+  n = ctypes.c_int64()
+  from multical_amd.backend import _to_struct
+  assert _lib.load().mcba_full_size(ctypes.byref(_to_struct(p)), ctypes.byref(n)) == 0
+  assert n.value == p.x_full.size
+  # enable flags follow `optimize[k] is True` (calibration.py:160)
+  assert lower(c.enable(cameras=False)).n_params == p.n_params - C_ * 10
+
+
+def test_pickle_holds_only_constructor_fields():
+  import pickle
+  c = mirror(synthetic.make_rig("tiny"))
+  c2 = pickle.loads(pickle.dumps(c))
+  assert sorted(c2.__dict__) == sorted(['cameras', 'boards', 'point_table', 'camera_poses', 'board_poses', 'motion',
+                                        'inlier_mask', 'optimize'])
+  assert np.array_equal(c2.param_vec, c.param_vec)
+
+
+@pytest.mark.parametrize("name", ALL_CASES)
+def test_device_math_residuals_match_reference(name):
+  """mcba_math.h / mcba_view.h (built for the host) reproduce evaluate() of the reference to 1e-9 px."""
+  g, rig = load_golden(name)
+  hm = HostMath(mirror(rig))
+  r = hm.residuals(g["x0"])
+  assert r.shape == g["r0"].shape
+  assert np.abs(r - g["r0"]).max() < 1e-9
+  err, valid = hm.reprojection_error(g["x0"])
+  assert np.abs(err[valid] - g["err0"]).max() < 1e-9
+  # ... and at the reference's solution
+  c = mirror(rig).with_param_vec(g["ba_x_raw"])
+  oc = oracle(rig)
+  assert np.abs(HostMath(c).residuals(g["ba_x_raw"]) - oc.evaluate(g["ba_x_raw"])).max() < 1e-9
+
+
+@pytest.mark.parametrize("name", SMALL_CASES)
+def test_device_math_jacobian_matches_reference_fd(name):
+  g, rig = load_golden(name)
+  hm = HostMath(mirror(rig))
+  J = hm.jacobian(g["x0"])
+  Jfd = golden_jacobian(g)
+  assert J.shape == Jfd.shape
+  assert rel_col_error(J, Jfd) < 5e-5          # forward differences with h = sqrt(eps)|x| are accurate to ~1e-6
+  # analytic non-zeros lie inside the reference's sparsity pattern
+  S = oracle(rig).sparsity_matrix.tocsr()
+  assert (abs(J) > 0).multiply(S == 0).nnz == 0
+
+
+def test_device_math_jacobian_against_central_differences():
+  """tighter check of the analytic derivatives: 3-point differences of the oracle (error ~1e-9)."""
+  from scipy.optimize._numdiff import approx_derivative, group_columns
+  from scipy.sparse import csr_matrix
+  for name in ["tiny_rolling", "tiny_fisheye", "tiny_tilted", "tiny_handeye"]:
+    g, rig = load_golden(name)
+    oc = oracle(rig)
+    S = csr_matrix(oc.sparsity_matrix)
+    J3 = csr_matrix(approx_derivative(oc.evaluate, g["x0"], method='3-point', sparsity=(S, group_columns(S))))
+    J = HostMath(mirror(rig)).jacobian(g["x0"])
+    assert rel_col_error(J, J3) < 2e-7, name
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_rolling", "tiny_handeye", "tiny_edge", "tiny_fixintr"])
+def test_device_math_normal_equations(name):
+  """per-view S = V^T V, M = That^T S That scattered through local_to_x == J^T J, J^T f."""
+  g, rig = load_golden(name)
+  hm = HostMath(mirror(rig))
+  J = hm.jacobian(g["x0"]).toarray()
+  r = hm.residuals(g["x0"])
+  H, grad, cost = hm.normal_equations(g["x0"])
+  assert np.abs(H - J.T @ J).max() <= 1e-12 * np.abs(H).max()
+  assert np.abs(grad - J.T @ r).max() <= 1e-12 * np.abs(grad).max()
+  assert cost == pytest.approx(0.5 * r @ r, rel=1e-13)
+
+
+@pytest.mark.parametrize("loss,f_scale", [("soft_l1", 1.5), ("huber", 2.0), ("cauchy", 1.0), ("arctan", 3.0)])
+def test_device_math_robust_loss_scaling(loss, f_scale):
+  """row / residual scaling == scipy's scale_for_robust_loss_function (common.py:720-731)."""
+  from scipy.optimize._lsq.least_squares import construct_loss_function
+  from scipy.optimize._lsq.common import scale_for_robust_loss_function
+  g, rig = load_golden("tiny")
+  hm = HostMath(mirror(rig))
+  J = hm.jacobian(g["x0"]).toarray()
+  f = hm.residuals(g["x0"])
+  lf = construct_loss_function(f.size, loss, f_scale)
+  rho = lf(f)
+  cost_ref = 0.5 * np.sum(rho[0])
+  Js, fs = scale_for_robust_loss_function(J.copy(), f.copy(), rho)
+  H, grad, cost = hm.normal_equations(g["x0"], loss=loss, f_scale=f_scale)
+  assert cost == pytest.approx(cost_ref, rel=1e-12)
+  assert np.abs(H - Js.T @ Js).max() <= 1e-11 * np.abs(H).max()
+  assert np.abs(grad - Js.T @ fs).max() <= 1e-11 * np.abs(grad).max()

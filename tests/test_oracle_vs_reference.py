@@ -1,0 +1,54 @@
+"""CPU, build box only: pin the oracle against the UNMODIFIED reference executed in-container (oracle/refload.py)."""
+import numpy as np
+import pytest
+
+from multical_amd import synthetic
+from oracle import restate
+
+pytestmark = pytest.mark.needs_reference
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_rolling", "tiny_fisheye", "tiny_handeye", "tiny_tilted"])
+def test_restatement_is_bit_identical_to_reference(name):
+  from oracle import build_reference
+  rig = synthetic.make_rig(name)
+  ref_calib, ref = build_reference.reference_calibration(rig)
+  oc = restate.from_rig(rig)
+  x = ref_calib.param_vec
+  assert np.array_equal(x, oc.param_vec)
+
+  def evaluate(v):
+    c = ref_calib.with_param_vec(v)
+    return (c.reprojected.points - c.point_table.points)[ref_calib.inliers].ravel()
+
+  rng = np.random.default_rng(0)
+  for _ in range(2):
+    assert np.array_equal(evaluate(x), oc.evaluate(x))
+    x = x + rng.normal(0, 1e-3, x.shape)
+  assert (ref_calib.sparsity_matrix.tocsr() != oc.sparsity_matrix.tocsr()).nnz == 0
+  assert np.array_equal(ref_calib.reprojection_error, oc.reprojection_error)
+
+
+def test_reference_bundle_adjust_equals_oracle():
+  from oracle import build_reference
+  rig = synthetic.make_rig("tiny_fisheye")
+  ref_calib, ref = build_reference.reference_calibration(rig)
+  a = ref_calib.bundle_adjust()
+  b = restate.from_rig(rig).bundle_adjust()
+  assert np.array_equal(a.param_vec, b.param_vec)
+
+
+def test_mirror_lowering_accepts_reference_objects():
+  """multical_amd.backend.lower() is duck-typed: the reference's own Calibration lowers to the same flat problem."""
+  from oracle import build_reference
+  from multical_amd import calibration
+  from multical_amd.backend import lower
+  for name in ["tiny_rolling", "tiny_handeye", "tiny_fisheye"]:
+    rig = synthetic.make_rig(name)
+    ref_calib, _ = build_reference.reference_calibration(rig)
+    pa, pb = lower(ref_calib), lower(calibration.from_rig(rig))
+    for k in ["points", "point_valid", "board_sizes", "camera_valid", "frame_valid", "board_valid", "x_full",
+              "image_heights", "fix_aspect"]:
+      assert np.array_equal(getattr(pa, k), getattr(pb, k)), k
+    assert (pa.motion, pa.camera_model, pa.n_dist, pa.optimize, pa.n_params) == \
+           (pb.motion, pb.camera_model, pb.n_dist, pb.optimize, pb.n_params)
