@@ -1,0 +1,199 @@
+#!/usr/bin/env python
+"""bench.py -- the hot path's headline metric on MI355X (contract: see the task statement / DESIGN.md section 6).
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+metric  : residual+Jacobian evaluations per second (BASELINE.json `metric`, first component); LM iterations/s and
+          the final reprojection RMS of a full solve are reported alongside in the same JSON line.
+step    : ONE fused residual+Jacobian evaluation reduced to the normal equations at one x -- table preparation,
+          k_linearize (MFMA), assembly into H_ss / H_fs / H_ff / g, and (N > 1) the all-reduce of [g | diag | cost]:
+          what one scipy `jac` call (1 + 34 finite-difference `evaluate` calls) plus J^T J / J^T f costs the reference.
+workload: BASELINE.json configs[2], the rig the north star quotes the metric on: 8 cameras x 500 frames x 2 boards
+          (charuco_16x22 + aprilgrid_9x9), rolling-shutter motion model, intrinsics + extrinsics optimised, synthetic
+          data (multical_amd.synthetic, seed 3).  Inputs are resident in HBM before the timed region.
+scaling : weak -- every rank owns a 500-frame shard of one 8 x (500 N) x 2 rig (frame sharding); `value`
+          counts shard evaluations (N per pass), so at N = 1 it is exactly evaluations/s of the north-star rig.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP64_PEAK_TFLOPS = 78.6    # MI355X FP64 vector = matrix peak (AMD spec; not in the guide's table)
+FRAMES_PER_SHARD = 500
+
+
+def cpu_baseline(n_frames_sample=25):
+  """Reference CPU path (oracle = numpy/scipy port of the reference, bit-identical to it in-container) on a bounded
+  sample of the same workload: the first `n_frames_sample` frames of the cfg3 rig.  One residual+Jacobian evaluation =
+  evaluate(x0) + scipy's grouped 2-point finite differences with the reference's sparsity (34 column groups)."""
+  from multical_amd import synthetic
+  from oracle import restate
+  from scipy.optimize._numdiff import approx_derivative, group_columns
+  from scipy.sparse import csr_matrix
+  rig = synthetic.make_rig("cfg3", frames=n_frames_sample)
+  oc = restate.from_rig(rig)
+  x0 = oc.param_vec
+  t0 = time.perf_counter()
+  S = csr_matrix(oc.sparsity_matrix)
+  groups = group_columns(S)
+  t_sparsity = time.perf_counter() - t0
+  n_eval = 0
+  t0 = time.perf_counter()
+  reps = 0
+  while True:
+    f0 = oc.evaluate(x0)
+    J = approx_derivative(oc.evaluate, x0, method='2-point', f0=f0, sparsity=(S, groups))
+    g = J.T @ f0                                    # the reduction the fused GPU pass also delivers
+    reps += 1
+    n_eval += 2 + int(groups.max())
+    if time.perf_counter() - t0 > 12.0 or reps >= 8:
+      break
+  dt = (time.perf_counter() - t0) / reps
+  evals_per_s_sample = 1.0 / dt
+  scale = n_frames_sample / FRAMES_PER_SHARD         # cost is linear in the number of frames
+  return dict(value=evals_per_s_sample * scale, unit="evals/s", cores=1, kind="port",
+              sample=(f"first {n_frames_sample} of {FRAMES_PER_SHARD} frames of the same rig (m={f0.size} residuals, "
+                      f"n={x0.size}); {reps} residual+Jacobian evaluations = {n_eval} evaluate() calls "
+                      f"({int(groups.max()) + 1} FD column groups), {dt:.2f} s each, sparsity build {t_sparsity:.1f} s "
+                      f"not counted; extrapolated linearly in frames to the 500-frame rig; host has "
+                      f"{os.cpu_count()} logical cores, numpy/scipy path is single-threaded"),
+              evals_per_s_on_sample=evals_per_s_sample)
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--gpus", type=int, default=1)
+  ap.add_argument("--steps", type=int, default=200)
+  ap.add_argument("--warmup", type=int, default=20)
+  ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--no-solve", action="store_true")
+  args = ap.parse_args()
+
+  import torch
+  import torch.distributed as dist
+  from multical_amd import synthetic, calibration
+  from multical_amd.backend import Handle, lower
+  from multical_amd import distributed as mdist
+
+  world = int(os.environ.get("WORLD_SIZE", "1"))
+  rank = int(os.environ.get("RANK", "0"))
+  local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+  assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+  torch.cuda.set_device(local_rank)
+  if world > 1:
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+  # ---- synthetic workload: this rank's 500-frame shard of the 8 x (500 N) x 2 rolling-shutter rig -------------
+  F_total = FRAMES_PER_SHARD * world
+  shard = (rank * FRAMES_PER_SHARD, (rank + 1) * FRAMES_PER_SHARD)
+  rig = synthetic.make_rig("cfg3", frames=F_total, obs_frames=shard)
+  calib = calibration.from_rig(rig)
+  x0 = calib.param_vec
+  stream = torch.cuda.current_stream().cuda_stream
+  h = Handle(lower(calib), frame_range=shard if world > 1 else None, stream=stream)
+  if world > 1:
+    h.set_allreduce(mdist.make_allreduce_hook())
+    h.set_shard_root(rank == 0)
+  n_slots = int(np.prod(rig.valid.shape[0:1] + (FRAMES_PER_SHARD,) + rig.valid.shape[2:]))
+  n_obs = h.n_residuals // 2
+
+  def barrier():
+    if world > 1:
+      dist.barrier()
+    torch.cuda.synchronize()
+
+  # ---- timed region: K fused residual+Jacobian evaluations ------------------------------------------------------
+  import ctypes as C
+  from multical_amd.backend import make_options, _ptr, check
+  xbuf = np.ascontiguousarray(x0)
+  opt = make_options()
+  cost = C.c_double()
+
+  def step():
+    # device-resident: x upload (49 KB) + tables + k_linearize + assembly (+ all-reduce); no result download
+    check(h.lib.mcba_normal_equations(h.h, _ptr(xbuf, C.c_double), C.byref(opt), C.byref(cost), None, None))
+
+  for _ in range(args.warmup):
+    step()
+  barrier()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    step()
+  barrier()
+  dt = time.perf_counter() - t0
+  if world > 1:
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+  ms_per_step = dt / args.steps * 1e3
+  value = world * args.steps / dt                       # shard evaluations per second, whole job
+
+  # ---- dominant kernel: k_linearize, HIP events on the handle's stream --------------------------------------------
+  lin_ms = h.time_linearize(x0, repeats=50)
+  res_ms = h.time_residuals(x0, repeats=50)
+  alg_bytes = 17 * n_slots + 16 * n_obs                  # observed xy + mask per slot, residual per obs
+  achieved = alg_bytes / (lin_ms * 1e-3) / 1e9
+  d = h.problem
+  NV = (12 if d.motion == 1 else 6) + (4 + d.n_dist if d.optimize & 8 else 0) + 1
+  alg_flops = n_obs * (2 * NV * (NV + 1) + 420 + (260 if d.motion == 1 else 0))
+  roofline = dict(bound="hbm", kernel="k_linearize", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                  frac=achieved / HBM_PEAK_GBS, traffic=None, launch_ms=lin_ms, algorithmic_bytes=alg_bytes,
+                  fp64=dict(achieved_tflops=alg_flops / (lin_ms * 1e-3) / 1e12, peak_tflops=FP64_PEAK_TFLOPS,
+                            frac=alg_flops / (lin_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, algorithmic_flops=alg_flops),
+                  residual_kernel=dict(launch_ms=res_ms, achieved=alg_bytes / (res_ms * 1e-3) / 1e9,
+                                       frac=alg_bytes / (res_ms * 1e-3) / 1e9 / HBM_PEAK_GBS))
+  traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+  if os.path.exists(traffic_file):
+    try:
+      roofline["traffic"] = json.load(open(traffic_file)).get("k_linearize_bytes_per_launch")
+    except Exception:
+      pass
+
+  # ---- LM iterations/s and final RMS: one full bundle adjustment of the same problem (not part of `value`) --------
+  extra = {}
+  if not args.no_solve:
+    barrier()
+    t0 = time.perf_counter()
+    res = h.solve(x0)
+    barrier()
+    t_solve = time.perf_counter() - t0
+    e, v = h.reprojection_error(res.x)
+    sq = torch.tensor([float((e[v] ** 2).sum()), float(v.sum())], dtype=torch.float64, device="cuda")
+    if world > 1:
+      dist.all_reduce(sq)
+    extra = dict(lm_iters_per_s=(res.nfev - 1) / t_solve, lm_trial_steps=res.nfev - 1, lm_linearizations=res.njev,
+                 solve_seconds=t_solve, solve_status=res.status,
+                 final_rms_px=float(torch.sqrt(sq[0] / sq[1]).item()), final_cost=res.cost,
+                 initial_cost=res.initial_cost)
+
+  out = None
+  if rank == 0:
+    out = dict(metric="residual+Jacobian evals/sec", value=value, unit="evals/s", n_gpus=world, steps=args.steps,
+               warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling="weak", vs_baseline=None,
+               dtype="f64", data="synthetic",
+               config=dict(workload=f"BASELINE configs[2]: 8 cameras x {FRAMES_PER_SHARD} frames x 2 boards per GPU "
+                                    f"(charuco_16x22 + aprilgrid_9x9), rolling-shutter motion, intrinsics+extrinsics; "
+                                    f"{world} frame shard(s) of one 8 x {F_total} x 2 rig",
+                           n_params=int(h.n_params), n_slots_per_gpu=n_slots, n_observations_per_gpu=int(n_obs),
+                           parallelism=f"frame-sharded x{world}" if world > 1 else "single GPU",
+                           device=h.device_info()),
+               roofline=roofline, **extra)
+    if world == 1 and not args.no_cpu_baseline:
+      out["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(out), flush=True)
+  h.close()
+  if world > 1:
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+  main()

@@ -94,8 +94,8 @@ typedef struct mcba_problem {
   uint32_t optimize;            /* OR of MCBA_OPT_*                                                    */
   const double* x_full;         /* all five blocks in reference order, length mcba_full_size();        */
                                 /* values of disabled blocks are taken from here                        */
-  int32_t frame_begin;          /* frame shard owned by this handle: [frame_begin, frame_end);          */
-  int32_t frame_end;            /* 0,0 = all frames.  Arrays above always describe ALL frames.          */
+  int32_t frame_begin;          /* frame shard owned by this handle: [frame_begin, frame_end) (may be empty);     */
+  int32_t frame_end;            /* frame_begin < 0 = all frames.  Arrays above always describe ALL frames.       */
 } mcba_problem;
 
 typedef struct mcba_options {          /* scipy.optimize.least_squares arguments used at calibration.py:209-210 */
@@ -156,6 +156,9 @@ int32_t mcba_num_residuals(mcba_handle h, int64_t* n_residuals);   /* 2 * #inlie
 int32_t mcba_set_inliers(mcba_handle h, const uint8_t* mask);
 
 int32_t mcba_set_allreduce(mcba_handle h, mcba_allreduce_fn fn, void* ctx);
+/* exactly one rank of a sharded problem is the root: it contributes the replicated (shared) right-hand side to the
+ * reduced system.  Default: root.  Ranks other than 0 call this with 0.                                          */
+int32_t mcba_set_shard_root(mcba_handle h, int32_t is_root);
 int32_t mcba_set_log(mcba_handle h, mcba_log_fn fn, void* ctx);
 
 /* --- evaluation -------------------------------------------------------------------------------------------- */

@@ -60,6 +60,7 @@ SYMBOLS = [
   ("mcba_num_residuals", C.c_int32, [H, C.POINTER(C.c_int64)]),
   ("mcba_set_inliers", C.c_int32, [H, c_uint8_p]),
   ("mcba_set_allreduce", C.c_int32, [H, ALLREDUCE_FN, C.c_void_p]),
+  ("mcba_set_shard_root", C.c_int32, [H, C.c_int32]),
   ("mcba_set_log", C.c_int32, [H, LOG_FN, C.c_void_p]),
   ("mcba_residuals", C.c_int32, [H, c_double_p, c_double_p]),
   ("mcba_jacobian", C.c_int32, [H, c_double_p, c_int32_p, c_double_p, c_int32_p]),

@@ -107,7 +107,7 @@ def _to_struct(p, frame_range=None):
   s.base_wrt_gripper = None if p.base_wrt_gripper is None else _ptr(p.base_wrt_gripper, C.c_double)
   s.optimize = p.optimize
   s.x_full = _ptr(p.x_full, C.c_double)
-  s.frame_begin, s.frame_end = (0, 0) if frame_range is None else frame_range
+  s.frame_begin, s.frame_end = (-1, -1) if frame_range is None else frame_range
   return s
 
 
@@ -263,6 +263,9 @@ class Handle(object):
       cb = _lib.LOG_FN(lambda ctx, it, nfev, cost, red, step, opt: fn(it, nfev, cost, red, step, opt))
     self._callbacks.append(cb)
     check(self.lib.mcba_set_log(self.h, cb, None))
+
+  def set_shard_root(self, is_root):
+    check(self.lib.mcba_set_shard_root(self.h, 1 if is_root else 0))
 
   def set_allreduce(self, fn):
     """fn(device_ptr:int, count:int, op:int, stream:int) -> int (0 = ok); see multical_amd.distributed."""

@@ -88,6 +88,8 @@ struct mcba_handle_s {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   bool use_mfma = true;
+  bool shard_root = true;
+  size_t chol_lds_set = 0;
 
   // host copies needed to rebuild the inlier tables
   std::vector<uint8_t> h_valid_ref;    // Calibration.valid, [C,F,B,P] reference order
@@ -210,8 +212,11 @@ void launch_assemble(mcba_handle_s* h) {
                        h->g(), h->diag());
   hipLaunchKernelGGL(k_shared_partial, dim3(d.C * d.B, h->nchunk), dim3(256), 0, h->stream, d, h->t, h->rec.p,
                      h->nchunk, h->partial.p);
-  hipLaunchKernelGGL(k_shared_final, dim3(1), dim3(1024), 0, h->stream, d, h->partial.p, h->nchunk, h->tri.p, h->Hss.p,
-                     h->g(), h->diag(), h->costcount());
+  HIP_OK(hipMemsetAsync(h->Hss.p, 0, (size_t)d.ns * d.ns * sizeof(double), h->stream));
+  hipLaunchKernelGGL(k_shared_zero_g, dim3((d.ns + 255) / 256), dim3(256), 0, h->stream, d, h->g());
+  hipLaunchKernelGGL(k_shared_final, dim3((d.rec_size + 2 + 63) / 64), dim3(64), 0, h->stream, d, h->partial.p, h->nchunk,
+                     h->tri.p, h->Hss.p, h->g(), h->costcount());
+  hipLaunchKernelGGL(k_shared_diag, dim3((d.ns + 255) / 256), dim3(256), 0, h->stream, d, h->Hss.p, h->diag());
   call_allreduce(h, h->gbuf.p, 2 * (size_t)d.n + 2, 0);
 }
 
@@ -242,18 +247,28 @@ void launch_gn_solve(mcba_handle_s* h, double reg, bool root_rank) {
                        h->Lf.p, h->W.p, h->yf.p);
     const int nt2 = h->ntile * (h->ntile + 1) / 2;
     if (h->use_mfma)
-      hipLaunchKernelGGL((k_schur_syrk<true>), dim3(nt2, h->ksplit), dim3(64), 0, h->stream, K, d.ns, h->ntile, h->ksplit,
-                         h->W.p, h->P.p);
+      hipLaunchKernelGGL((k_schur_syrk<true>), dim3(nt2, h->ksplit), dim3(64), 0, h->stream, K, d.ns + 1, h->ntile,
+                         h->ksplit, h->W.p, h->P.p);
     else
-      hipLaunchKernelGGL((k_schur_syrk<false>), dim3(nt2, h->ksplit), dim3(64), 0, h->stream, K, d.ns, h->ntile,
+      hipLaunchKernelGGL((k_schur_syrk<false>), dim3(nt2, h->ksplit), dim3(64), 0, h->stream, K, d.ns + 1, h->ntile,
                          h->ksplit, h->W.p, h->P.p);
   }
   const int total = d.ns * d.ns + d.ns;
   hipLaunchKernelGGL(k_schur_reduce, dim3(std::min(1024, (total + 255) / 256)), dim3(256), 0, h->stream, d, h->Hss.p,
-                     h->dsc.p, h->gh.p, h->P.p, h->ntile, h->ksplit, h->W.p, h->yf.p, K, root_rank ? 1.0 : 0.0,
-                     h->sbuf.p);
+                     h->dsc.p, h->gh.p, h->P.p, h->ntile, h->ksplit, K, root_rank ? 1.0 : 0.0, h->sbuf.p);
   call_allreduce(h, h->sbuf.p, (size_t)total, 0);
-  hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(1024), 0, h->stream, d.ns, reg, h->sbuf.p, h->ps.p, h->info.p);
+  {
+    const int max_rows = d.ns + 1;
+    const size_t lds = (size_t)(CHOL_NB + max_rows) * (CHOL_NB + 1) * sizeof(double) + 16;
+    REQUIRE(lds <= 160 * 1024 - 256, "reduced system too large for the single-workgroup Cholesky (ns = " +
+                                          std::to_string(d.ns) + ")");
+    if (lds > h->chol_lds_set) {
+      HIP_OK(hipFuncSetAttribute((const void*)k_chol_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      h->chol_lds_set = lds;
+    }
+    hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(1024), lds, h->stream, d.ns, reg, h->sbuf.p, h->ps.p, h->info.p,
+                       max_rows);
+  }
   const int nblk = (K > 0 ? d.Fl : 0) + 1;
   hipLaunchKernelGGL(k_schur_backsub, dim3(nblk), dim3(128), 0, h->stream, d, h->Lf.p, h->W.p, h->yf.p, h->ps.p, h->gn.p);
   if (h->allreduce && K > 0) {
@@ -460,7 +475,7 @@ int32_t mcba_create(const mcba_problem* p, void* hip_stream, mcba_handle* out) {
 
   // ---- work buffers -----------------------------------------------------------------------------------------
   h->rec.alloc((size_t)d.views() * d.rec_stride);
-  h->nchunk = std::max(1, std::min(64, d.Fl / 8));
+  h->nchunk = std::max(1, std::min(8, d.Fl / 48));
   h->partial.alloc((size_t)d.C * d.B * h->nchunk * d.rec_stride);
   h->Hss.alloc((size_t)d.ns * d.ns);
   h->Hfs.alloc((size_t)d.Fl * d.DF * d.ns);
@@ -472,9 +487,9 @@ int32_t mcba_create(const mcba_problem* p, void* hip_stream, mcba_handle* out) {
   h->cost_blocks = std::max(1, std::min(COST_BLOCKS_MAX, (int)((nslot + 255) / 256)));
   h->costpart.alloc((size_t)h->cost_blocks);
   h->Lf.alloc((size_t)d.Fl * d.DF * d.DF);
-  h->W.alloc((size_t)d.Fl * d.DF * d.ns);
+  h->W.alloc((size_t)d.Fl * d.DF * (d.ns + 1));
   h->yf.alloc((size_t)d.Fl * d.DF);
-  h->ntile = (d.ns + 15) / 16;
+  h->ntile = (d.ns + 1 + 15) / 16;   // tiles of W' = [W | y]
   {
     const int K = d.DF * d.Fl;
     const int nt2 = h->ntile * (h->ntile + 1) / 2;
@@ -540,6 +555,13 @@ int32_t mcba_set_allreduce(mcba_handle h, mcba_allreduce_fn fn, void* ctx) {
   REQUIRE(h, "null handle");
   h->allreduce = fn;
   h->allreduce_ctx = ctx;
+  API_END
+}
+
+int32_t mcba_set_shard_root(mcba_handle h, int32_t is_root) {
+  API_BEGIN
+  REQUIRE(h, "null handle");
+  h->shard_root = is_root != 0;
   API_END
 }
 
@@ -665,7 +687,7 @@ int32_t mcba_debug_gn_step(mcba_handle h, double reg, double* gn_h, double* g_h,
   const Dims& d = h->d;
   hipLaunchKernelGGL(k_vec_scale, dim3(1), dim3(1024), 0, h->stream, d, h->x.p, h->g(), h->diag(), h->scale_inv.p,
                      h->dsc.p, h->gh.p, 1, h->scal.p);
-  launch_gn_solve(h, reg, true);
+  launch_gn_solve(h, reg, h->shard_root);
   HIP_OK(hipMemcpyAsync(gn_h, h->gn.p, (size_t)d.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   if (g_h) HIP_OK(hipMemcpyAsync(g_h, h->gh.p, (size_t)d.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   if (scale_inv)
@@ -697,13 +719,7 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
   const double ftol = opt->ftol, xtol = opt->xtol, gtol = opt->gtol;
   const int max_nfev = opt->max_nfev > 0 ? opt->max_nfev : d.n * 100;
   const double NaN = std::numeric_limits<double>::quiet_NaN();
-  const bool root = true;   // rank weighting of replicated terms is handled by the hook (see launch_gn_solve)
-  bool is_root = true;
-  if (h->allreduce) {
-    // determine whether this rank is the root by reducing a one-hot marker: root = rank that owns frame 0
-    is_root = d.f0 == 0;
-  }
-  (void)root;
+  const bool is_root = h->shard_root;
 
   upload_x(h, x_inout, h->x.p);
   eval_tables(h, h->x.p);

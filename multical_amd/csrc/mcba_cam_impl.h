@@ -37,6 +37,7 @@ void jacobian(const Dims& d, const Tables& t, hipStream_t s, int row_nnz, double
 
 template <int MOTION, bool OPTK>
 void lin2(const Dims& d, const Tables& t, hipStream_t s, double* rec, const uint16_t* tri, bool mfma) {
+  if (d.views() == 0) return;   // empty frame shard
   const dim3 grid(d.views()), block(64);
   if (mfma)
     hipLaunchKernelGGL((k_linearize<ND_, FISH_, MOTION, OPTK, true>), grid, block, 0, s, d, t, rec, tri);

@@ -94,7 +94,7 @@ inline void lower_problem(const mcba_problem* p, HostProblem& hp) {
   Dims& d = hp.d;
   d.C = p->n_cameras; d.F = p->n_frames; d.B = p->n_boards; d.P = p->n_points;
   d.f0 = 0; d.Fl = d.F;
-  if (!(p->frame_begin == 0 && p->frame_end == 0)) {
+  if (p->frame_begin >= 0) {
     MCBA_REQUIRE(0 <= p->frame_begin && p->frame_begin <= p->frame_end && p->frame_end <= d.F, "bad frame shard");
     d.f0 = p->frame_begin;
     d.Fl = p->frame_end - p->frame_begin;

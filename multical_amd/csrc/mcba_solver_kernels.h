@@ -116,54 +116,53 @@ __global__ void k_shared_partial(Dims d, Tables t, const double* __restrict__ re
   }
 }
 
-// shared part, stage 2 (single block): H_ss (dense ns x ns), g and diag of the shared parameters, total cost.
-// Pairs are folded in sequentially so that every H_ss entry is summed in a fixed order.
+// shared part, stage 2: H_ss (dense ns x ns, zeroed by the caller), g and the total cost.
+// One THREAD per packed local entry e; it folds the pairs (c, b) in sequentially.  Two contributions can only meet in
+// the same H_ss element when they come from the same local entry e of different pairs (e.g. the camera block of
+// (c, b) and (c, b')), i.e. inside one thread -- so the sum order is fixed and no atomics are needed.
 __global__ void k_shared_final(Dims d, const double* __restrict__ partial, int nchunk, const uint16_t* __restrict__ tri,
-                               double* __restrict__ Hss, double* __restrict__ g, double* __restrict__ diag,
-                               double* __restrict__ cost_count) {
-  __shared__ double scratch[16];
+                               double* __restrict__ Hss, double* __restrict__ g, double* __restrict__ cost_count) {
   const int ns = d.ns, NL = d.NL;
-  for (int e = threadIdx.x; e < ns * ns; e += blockDim.x) Hss[e] = 0.0;
-  for (int s = threadIdx.x; s < ns; s += blockDim.x) g[d.shared_to_x(s)] = 0.0;
-  __syncthreads();
-  double cost = 0.0, cnt = 0.0;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= d.rec_size + 2) return;
+  if (e >= d.rec_size) {   // cost, count
+    double tot = 0.0;
+    for (int pair = 0; pair < d.C * d.B; ++pair)
+      for (int ch = 0; ch < nchunk; ++ch) tot += partial[((size_t)pair * nchunk + ch) * d.rec_stride + e];
+    cost_count[e - d.rec_size] = tot;
+    return;
+  }
+  const int ij = tri[e];
+  const int i = ij >> 8, j = ij & 255;
+  if (i == NL) return;                                   // (r, r) = sum f^2: the cost is carried separately
+  if (local_is_frame(d, i) || local_is_frame(d, j)) return;
   for (int pair = 0; pair < d.C * d.B; ++pair) {
     const int c = pair / d.B, b = pair % d.B;
-    const double* base = partial + (size_t)pair * nchunk * d.rec_stride;
-    for (int e = threadIdx.x; e < d.rec_size + 2; e += blockDim.x) {
-      double val = 0.0;
-      for (int ch = 0; ch < nchunk; ++ch) val += base[(size_t)ch * d.rec_stride + e];
-      if (e >= d.rec_size) {
-        if (e == d.rec_size) cost += val; else cnt += val;
-        continue;
-      }
-      const int ij = tri[e];
-      const int i = ij >> 8, j = ij & 255;
-      if (i == NL) continue;                                   // (r, r) = sum f^2, the cost is carried separately
-      if (local_is_frame(d, i) || local_is_frame(d, j)) continue;
-      // frame index is irrelevant for shared parameters (hand-eye blocks do not depend on f either)
-      const int gi = local_to_x(d, 0, c, b, i);
-      if (gi < 0) continue;
-      const int si = d.x_to_shared(gi);
-      if (j == NL) {
-        g[gi] += val;
-        continue;
-      }
-      const int gj = local_to_x(d, 0, c, b, j);
-      if (gj < 0) continue;
-      const int sj = d.x_to_shared(gj);
-      Hss[si * ns + sj] += val;
-      if (si != sj) Hss[sj * ns + si] += val;
+    // the frame index is irrelevant for shared parameters (hand-eye blocks do not depend on f either)
+    const int gi = local_to_x(d, 0, c, b, i);
+    if (gi < 0) continue;
+    const int gj = j == NL ? 0 : local_to_x(d, 0, c, b, j);
+    if (gj < 0) continue;
+    const double* base = partial + (size_t)pair * nchunk * d.rec_stride + e;
+    double val = 0.0;
+    for (int ch = 0; ch < nchunk; ++ch) val += base[(size_t)ch * d.rec_stride];
+    if (j == NL) {
+      g[gi] += val;
+    } else {
+      const int si = d.x_to_shared(gi), sj = d.x_to_shared(gj);
+      Hss[(size_t)si * ns + sj] += val;
+      if (si != sj) Hss[(size_t)sj * ns + si] += val;
     }
-    __syncthreads();
   }
-  for (int s = threadIdx.x; s < ns; s += blockDim.x) diag[d.shared_to_x(s)] = Hss[s * ns + s];
-  const double ctot = block_reduce<false>(cost, scratch);
-  const double ntot = block_reduce<false>(cnt, scratch);
-  if (threadIdx.x == 0) {
-    cost_count[0] = ctot;
-    cost_count[1] = ntot;
-  }
+}
+
+// diag(H) of the shared parameters and zeroing of their gradient entries (before k_shared_final accumulates)
+__global__ void k_shared_zero_g(Dims d, double* __restrict__ g) {
+  for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < d.ns; s += gridDim.x * blockDim.x) g[d.shared_to_x(s)] = 0.0;
+}
+__global__ void k_shared_diag(Dims d, const double* __restrict__ Hss, double* __restrict__ diag) {
+  for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < d.ns; s += gridDim.x * blockDim.x)
+    diag[d.shared_to_x(s)] = Hss[(size_t)s * d.ns + s];
 }
 
 // dense J^T J in x order from the block form (debug / parity tests)
@@ -323,19 +322,21 @@ __global__ void k_quadforms_final(Dims d, const double* __restrict__ partial, in
 }
 
 // Schur step 1, one block per frame:  A_ff = D_f H_ff D_f + reg I = L L^T,  W = L^-1 (D_f H_fs D_s)  [DF x ns],
-// y = L^-1 g_h,f.  L is kept for the back-substitution.
+// y = L^-1 g_h,f stored as the EXTRA COLUMN ns of W (row stride ns + 1), so that the SYRK below also delivers W^T y.
+// L is kept for the back-substitution.
 __global__ void k_schur_frames(Dims d, const double* __restrict__ Hfs, const double* __restrict__ Hff,
                                const double* __restrict__ dsc, const double* __restrict__ gh, double reg,
                                double* __restrict__ Lf, double* __restrict__ W, double* __restrict__ yf) {
   __shared__ double L[12 * 12];
   __shared__ double y[12];
-  const int fl = blockIdx.x, f = d.f0 + fl, DF = d.DF, ns = d.ns;
+  const int fl = blockIdx.x, f = d.f0 + fl, DF = d.DF, ns = d.ns, ldw = d.ns + 1;
   const double* hff = Hff + (size_t)fl * DF * DF;
   for (int e = threadIdx.x; e < DF * DF; e += blockDim.x) {
     const int i = e / DF, j = e % DF;
     L[i * 12 + j] = dsc[d.frame_to_x(f, i)] * hff[e] * dsc[d.frame_to_x(f, j)] + (i == j ? reg : 0.0);
   }
   __syncthreads();
+  double* w = W + (size_t)fl * DF * ldw;
   if (threadIdx.x == 0) {
     // dense Cholesky, lower triangle in place (DF <= 12)
     for (int j = 0; j < DF; ++j) {
@@ -354,12 +355,14 @@ __global__ void k_schur_frames(Dims d, const double* __restrict__ Hfs, const dou
       for (int k = 0; k < i; ++k) v -= L[i * 12 + k] * y[k];
       y[i] = v / L[i * 12 + i];
     }
-    for (int i = 0; i < DF; ++i) yf[fl * DF + i] = y[i];
+    for (int i = 0; i < DF; ++i) {
+      yf[fl * DF + i] = y[i];
+      w[i * ldw + ns] = y[i];
+    }
   }
   __syncthreads();
   for (int e = threadIdx.x; e < DF * DF; e += blockDim.x) Lf[(size_t)fl * DF * DF + e] = L[(e / DF) * 12 + (e % DF)];
   const double* hfs = Hfs + (size_t)fl * DF * ns;
-  double* w = W + (size_t)fl * DF * ns;
   for (int s = threadIdx.x; s < ns; s += blockDim.x) {
     const double ds = dsc[d.shared_to_x(s)];
     double col[12];
@@ -367,19 +370,18 @@ __global__ void k_schur_frames(Dims d, const double* __restrict__ Hfs, const dou
       double v = dsc[d.frame_to_x(f, i)] * hfs[i * ns + s] * ds;
       for (int k = 0; k < i; ++k) v -= L[i * 12 + k] * col[k];
       col[i] = v / L[i * 12 + i];
-      w[i * ns + s] = col[i];
+      w[i * ldw + s] = col[i];
     }
   }
 }
 
-// Schur step 2: partial SYRK  P[split][tile] = sum_{k in split} W[k][ti*16..]^T W[k][tj*16..]  over the stacked rows
-// k = (frame, dd) of W [K x ns].  One wavefront per (upper tile, K split); MFMA f64 16x16x4 reads its operands
-// straight from global memory (row-major W: 128-byte coalesced segments per 16 lanes).
+// Schur step 2: partial SYRK  P[split][tile] = sum_{k in split} W'[k][ti*16..]^T W'[k][tj*16..]  over the stacked rows
+// k = (frame, dd) of W' = [W | y]  [K x (ns+1)].  One wavefront per (upper tile, K split); MFMA f64 16x16x4 reads its
+// operands straight from global memory (row-major W': 128-byte coalesced segments per 16 lanes).
 template <bool MFMA>
-__global__ __launch_bounds__(64) void k_schur_syrk(int K, int ns, int ntile, int ksplit, const double* __restrict__ W,
+__global__ __launch_bounds__(64) void k_schur_syrk(int K, int ncol, int ntile, int ksplit, const double* __restrict__ W,
                                                    double* __restrict__ P) {
   const int tile = blockIdx.x, split = blockIdx.y, lane = threadIdx.x;
-  // decode upper-triangular tile index
   int ti = 0, rem = tile;
   while (rem >= ntile - ti) { rem -= ntile - ti; ++ti; }
   const int tj = ti + rem;
@@ -392,105 +394,166 @@ __global__ __launch_bounds__(64) void k_schur_syrk(int K, int ns, int ntile, int
     double4_t acc = {0.0, 0.0, 0.0, 0.0};
     for (int k = k0; k < k1; k += 4) {
       const int kk = k + rsub;
-      const double a = (kk < k1 && ci < ns) ? W[(size_t)kk * ns + ci] : 0.0;
-      const double b = (kk < k1 && cj < ns) ? W[(size_t)kk * ns + cj] : 0.0;
+      const double a = (kk < k1 && ci < ncol) ? W[(size_t)kk * ncol + ci] : 0.0;
+      const double b = (kk < k1 && cj < ncol) ? W[(size_t)kk * ncol + cj] : 0.0;
       acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
     }
     for (int r = 0; r < 4; ++r) out[(rsub + 4 * r) * 16 + csub] = acc[r];
   } else {
-    // lane handles rows {rsub + 4 r} x column csub of the tile
     double acc[4] = {0, 0, 0, 0};
     for (int k = k0; k < k1; ++k) {
-      const double b = cj < ns ? W[(size_t)k * ns + cj] : 0.0;
+      const double b = cj < ncol ? W[(size_t)k * ncol + cj] : 0.0;
       for (int r = 0; r < 4; ++r) {
         const int ri = ti * 16 + rsub + 4 * r;
-        acc[r] += (ri < ns ? W[(size_t)k * ns + ri] : 0.0) * b;
+        acc[r] += (ri < ncol ? W[(size_t)k * ncol + ri] : 0.0) * b;
       }
     }
     for (int r = 0; r < 4; ++r) out[(rsub + 4 * r) * 16 + csub] = acc[r];
   }
 }
 
-// Schur step 3:  S = D_s H_ss D_s - sum_splits P  (reg I is added after the cross-rank reduction),
-//                rhs = [own shared gradient] - W^T y.   buf = [S (ns*ns) | rhs (ns)]
+// Schur step 3:  S = D_s H_ss D_s - W^T W  (reg I is added after the cross-rank reduction),
+//                rhs = [own shared gradient] - W^T y.   buf = [S (ns*ns) | rhs (ns)]: rhs is "row ns" of the matrix.
 __global__ void k_schur_reduce(Dims d, const double* __restrict__ Hss, const double* __restrict__ dsc,
                                const double* __restrict__ gh, const double* __restrict__ P, int ntile, int ksplit,
-                               const double* __restrict__ W, const double* __restrict__ yf, int K, double g_weight,
-                               double* __restrict__ buf) {
+                               int K, double g_weight, double* __restrict__ buf) {
   const int ns = d.ns;
   const int nt2 = ntile * (ntile + 1) / 2;
   const int total = ns * ns + ns;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-    if (e < ns * ns) {
-      const int i = e / ns, j = e % ns;
-      const int a = min(i, j), b = max(i, j);
-      const int ti = a / 16, tj = b / 16;
-      const int tile = ti * ntile - (ti * (ti - 1)) / 2 + (tj - ti);
-      double sum = 0.0;
-      if (K > 0)
-        for (int sp = 0; sp < ksplit; ++sp) sum += P[((size_t)sp * nt2 + tile) * 256 + (a % 16) * 16 + (b % 16)];
-      buf[e] = dsc[d.shared_to_x(i)] * Hss[e] * dsc[d.shared_to_x(j)] - sum;
-    } else {
-      const int s = e - ns * ns;
-      double sum = 0.0;
-      for (int k = 0; k < K; ++k) sum += W[(size_t)k * ns + s] * yf[k];
-      buf[e] = g_weight * gh[d.shared_to_x(s)] - sum;
-    }
+    const int i = e / ns, j = e % ns;            // i == ns: the right-hand-side row
+    const int a = min(i, j), b = max(i, j);
+    const int ti = a / 16, tj = b / 16;
+    const int tile = ti * ntile - (ti * (ti - 1)) / 2 + (tj - ti);
+    double sum = 0.0;
+    if (K > 0)
+      for (int sp = 0; sp < ksplit; ++sp) sum += P[((size_t)sp * nt2 + tile) * 256 + (a % 16) * 16 + (b % 16)];
+    if (i < ns) buf[e] = dsc[d.shared_to_x(i)] * Hss[e] * dsc[d.shared_to_x(j)] - sum;
+    else buf[e] = g_weight * gh[d.shared_to_x(j)] - sum;
   }
 }
 
-// dense Cholesky solve of (S + reg I) p = rhs, single workgroup, right-looking on the global (L2-resident) matrix.
-// buf = [S (ns*ns) | rhs (ns)];  p_s is written to ps[ns].  S is overwritten by its factor.
-__global__ void k_chol_solve(int ns, double reg, double* __restrict__ buf, double* __restrict__ ps,
-                             int* __restrict__ info) {
-  double* S = buf;
-  double* rhs = buf + (size_t)ns * ns;
-  __shared__ double piv;
-  __shared__ int bad;
-  if (threadIdx.x == 0) bad = 0;
-  for (int i = threadIdx.x; i < ns; i += blockDim.x) S[(size_t)i * ns + i] += reg;
+// Blocked dense Cholesky solve of (S + reg I) p = rhs in ONE workgroup (the reduced system is small: ns = 18 ... ~300).
+// buf holds an (ns+1) x ns row-major matrix: rows 0..ns-1 = S (lower triangle used), row ns = rhs.  Treating the
+// right-hand side as an extra row makes the forward substitution part of the panel TRSM.  Per 32-column panel:
+//   wave 0 factors the diagonal block in LDS, every thread solves one row of the panel (L21 = A21 L11^-T, kept in LDS),
+//   all threads apply the symmetric rank-32 update to the trailing matrix (4x4 register tiles, global memory = L2).
+// Then a blocked backward substitution.  p is written to ps[ns]; info = first non-positive pivot (1-based) or 0.
+constexpr int CHOL_NB = 32;
+__global__ __launch_bounds__(1024) void k_chol_solve(int ns, double reg, double* __restrict__ buf, double* __restrict__ ps,
+                                                     int* __restrict__ info, int max_rows) {
+  extern __shared__ __attribute__((aligned(16))) double chol_lds[];
+  constexpr int NB = CHOL_NB, LD = NB + 1;
+  double* D = chol_lds;                 // [NB][LD] diagonal block
+  double* L21 = chol_lds + NB * LD;     // [max_rows][LD] panel rows below the diagonal block (+ the rhs row)
+  int& bad = *reinterpret_cast<int*>(L21 + (size_t)max_rows * LD);   // no static LDS in front of the dynamic region
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  double* A = buf;
+  if (tid == 0) bad = 0;
+  for (int i = tid; i < ns; i += nthr) A[(size_t)i * ns + i] += reg;
   __syncthreads();
-  for (int j = 0; j < ns; ++j) {
-    if (threadIdx.x == 0) {
-      double s = S[(size_t)j * ns + j];
-      if (!(s > 0.0)) { bad = j + 1; s = 1e-300; }
-      piv = sqrt(s);
-      S[(size_t)j * ns + j] = piv;
+
+  for (int k0 = 0; k0 < ns; k0 += NB) {
+    const int nb = min(NB, ns - k0);
+    const int m = ns - k0 - nb + 1;               // rows below the panel, including the rhs row
+    for (int e = tid; e < NB * NB; e += nthr) {   // pad a short last block with the identity
+      const int i = e / NB, j = e % NB;
+      D[i * LD + j] = (i < nb && j < nb) ? A[(size_t)(k0 + i) * ns + k0 + j] : (i == j ? 1.0 : 0.0);
     }
     __syncthreads();
-    const double pj = piv;
-    for (int i = j + 1 + threadIdx.x; i < ns; i += blockDim.x) S[(size_t)i * ns + j] /= pj;
+    if (tid < 64) {   // unblocked factorisation of the nb x nb diagonal block by one wavefront
+      for (int j = 0; j < nb; ++j) {
+        double dj = D[j * LD + j];
+        if (!(dj > 0.0)) { if (tid == 0 && bad == 0) bad = k0 + j + 1; dj = 1e-300; }
+        dj = sqrt(dj);
+        lds_fence();
+        if (tid == 0) D[j * LD + j] = dj;
+        for (int i = j + 1 + tid; i < nb; i += 64) D[i * LD + j] /= dj;
+        lds_fence();
+        const int mm = nb - j - 1;
+        for (int e = tid; e < mm * mm; e += 64) {
+          const int i = j + 1 + e / mm, k = j + 1 + e % mm;
+          if (k <= i) D[i * LD + k] -= D[i * LD + j] * D[k * LD + j];
+        }
+        lds_fence();
+      }
+    }
     __syncthreads();
-    // trailing update of the lower triangle: S[i][k] -= S[i][j] S[k][j], j < k <= i
-    const int m = ns - j - 1;
-    for (int e = threadIdx.x; e < m * m; e += blockDim.x) {
-      const int i = j + 1 + e / m, k = j + 1 + e % m;
-      if (k <= i) S[(size_t)i * ns + k] -= S[(size_t)i * ns + j] * S[(size_t)k * ns + j];
+    for (int e = tid; e < nb * nb; e += nthr) {
+      const int i = e / nb, j = e % nb;
+      if (j <= i) A[(size_t)(k0 + i) * ns + k0 + j] = D[i * LD + j];
+    }
+    // panel solve: one row per thread
+    for (int r = tid; r < m; r += nthr) {
+      double* arow = A + (size_t)(k0 + nb + r) * ns + k0;
+      double* xr = L21 + (size_t)r * LD;           // the row is private to this thread: no barrier inside the solve
+      for (int j = 0; j < NB; ++j) xr[j] = j < nb ? arow[j] : 0.0;
+      for (int j = 0; j < nb; ++j) {
+        double v = xr[j];
+        const double* dj = D + j * LD;
+        for (int k = 0; k < j; ++k) v -= xr[k] * dj[k];
+        v /= dj[j];
+        xr[j] = v;
+        arow[j] = v;
+      }
+    }
+    __syncthreads();
+    // trailing update (lower triangle + rhs row): A[r][c] -= L21[r] . L21[c], c <= r, c < m - 1
+    const int mt = (m + 3) / 4;
+    for (int tix = tid; tix < mt * mt; tix += nthr) {
+      const int tr = tix / mt, tc = tix % mt;
+      if (tc > tr) continue;
+      double acc[4][4] = {{0}};
+      for (int k = 0; k < NB; ++k) {   // padded columns of L21 are zero
+        double a[4], b[4];
+        for (int q = 0; q < 4; ++q) {
+          const int r = 4 * tr + q, c = 4 * tc + q;
+          a[q] = r < m ? L21[r * LD + k] : 0.0;
+          b[q] = c < m ? L21[c * LD + k] : 0.0;
+        }
+        for (int p = 0; p < 4; ++p)
+          for (int q = 0; q < 4; ++q) acc[p][q] += a[p] * b[q];
+      }
+      for (int p = 0; p < 4; ++p)
+        for (int q = 0; q < 4; ++q) {
+          const int r = 4 * tr + p, c = 4 * tc + q;
+          if (r < m && c < m - 1 && c <= r) A[(size_t)(k0 + nb + r) * ns + k0 + nb + c] -= acc[p][q];
+        }
     }
     __syncthreads();
   }
-  // forward / backward substitution (thread 0 drives, inner products in parallel)
-  __shared__ double scratch[16];
-  __shared__ double cur;
-  for (int i = 0; i < ns; ++i) {
-    double part = 0.0;
-    for (int k = threadIdx.x; k < i; k += blockDim.x) part += S[(size_t)i * ns + k] * rhs[k];
-    const double tot = block_reduce<false>(part, scratch);
-    if (threadIdx.x == 0) rhs[i] = (rhs[i] - tot) / S[(size_t)i * ns + i];
+
+  // backward substitution L^T p = y (y = row ns), blocked from the last panel to the first
+  double* y = A + (size_t)ns * ns;
+  const int npanel = (ns + NB - 1) / NB;
+  for (int pi = npanel - 1; pi >= 0; --pi) {
+    const int k0 = pi * NB, nb = min(NB, ns - k0);
+    for (int e = tid; e < nb * nb; e += nthr) {
+      const int i = e / nb, j = e % nb;
+      D[i * LD + j] = A[(size_t)(k0 + i) * ns + k0 + j];
+    }
     __syncthreads();
-  }
-  for (int i = ns - 1; i >= 0; --i) {
-    double part = 0.0;
-    for (int k = i + 1 + threadIdx.x; k < ns; k += blockDim.x) part += S[(size_t)k * ns + i] * rhs[k];
-    const double tot = block_reduce<false>(part, scratch);
-    if (threadIdx.x == 0) {
-      cur = (rhs[i] - tot) / S[(size_t)i * ns + i];
-      rhs[i] = cur;
-      ps[i] = cur;
+    if (tid < 64) {   // wave-parallel back substitution of the diagonal block: lane l carries y[k0 + l]
+      double yv = tid < nb ? y[k0 + tid] : 0.0;
+      for (int i = nb - 1; i >= 0; --i) {
+        const double pi = __shfl(yv, i, 64) / D[i * LD + i];
+        if (tid == i) yv = pi;
+        else if (tid < i) yv -= D[i * LD + tid] * pi;
+      }
+      if (tid < nb) {
+        y[k0 + tid] = yv;
+        ps[k0 + tid] = yv;
+      }
+    }
+    __syncthreads();
+    for (int j = tid; j < k0; j += nthr) {
+      double sum = 0.0;
+      for (int i = 0; i < nb; ++i) sum += A[(size_t)(k0 + i) * ns + j] * y[k0 + i];
+      y[j] -= sum;
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) info[0] = bad;
+  if (tid == 0) info[0] = bad;
 }
 
 // back-substitution: gn_s = p_s ; gn_f = L^-T (y_f - W p_s)  (one block per frame; block Fl copies the shared part)
@@ -506,11 +569,11 @@ __global__ void k_schur_backsub(Dims d, const double* __restrict__ Lf, const dou
     }
     return;
   }
-  const int fl = blockIdx.x, f = d.f0 + fl;
-  const double* w = W + (size_t)fl * DF * ns;
+  const int fl = blockIdx.x, f = d.f0 + fl, ldw = ns + 1;
+  const double* w = W + (size_t)fl * DF * ldw;
   for (int dd = 0; dd < DF; ++dd) {
     double part = 0.0;
-    for (int s = threadIdx.x; s < ns; s += blockDim.x) part += w[dd * ns + s] * ps[s];
+    for (int s = threadIdx.x; s < ns; s += blockDim.x) part += w[dd * ldw + s] * ps[s];
     const double tot = block_reduce<false>(part, scratch);
     if (threadIdx.x == 0) z[dd] = yf[fl * DF + dd] - tot;
   }

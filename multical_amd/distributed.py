@@ -1,0 +1,90 @@
+"""Frame sharding across GPUs: one process per GPU, torch.distributed for the cross-rank sums.
+
+Every observation belongs to exactly one frame, the per-frame pose blocks are private to the shard that owns the
+frame, and everything else is a sum -- so a rank keeps only its contiguous frame range of the observation table on
+its GPU and the solver exchanges just the reduced quantities per iteration:
+
+    [g | diag(J^T J) | cost]                 2 n + 2 doubles    after every linearisation
+    quadratic forms for the 2-D subspace     3 doubles          twice per iteration
+    Schur complement + right-hand side       n_s^2 + n_s        once per iteration
+    eliminated-frame part of the GN step     n_motion           once per iteration
+    trial cost                               1 double           once per trial step
+
+The C library calls back into `allreduce_hook` with DEVICE pointers (include/mcba.h: mcba_allreduce_fn); with the
+"nccl" backend (RCCL over xGMI on ROCm) the reduction runs in place on the handle's stream -- which is torch's
+current stream, so no host synchronisation is involved -- and with "gloo" (CPU-side tests) the buffer is staged
+through host memory.
+"""
+import numpy as np
+
+
+def frame_shards(n_frames, world_size, weights=None):
+  """Contiguous frame ranges [(f0, f1)] * world_size, balanced by `weights` (e.g. inlier count per frame)."""
+  if weights is None:
+    weights = np.ones(n_frames)
+  w = np.asarray(weights, dtype=np.float64)
+  assert w.shape == (n_frames,)
+  total = w.sum()
+  if total <= 0:
+    w = np.ones(n_frames)
+    total = float(n_frames)
+  cum = np.concatenate([[0.0], np.cumsum(w)])
+  bounds = [0]
+  for r in range(1, world_size):
+    target = total * r / world_size
+    f = int(np.searchsorted(cum, target, side='left'))
+    f = min(max(f, bounds[-1]), n_frames)
+    bounds.append(f)
+  bounds.append(n_frames)
+  return [(bounds[i], bounds[i + 1]) for i in range(world_size)]
+
+
+class _DevArray(object):
+  """Expose a raw device pointer of `count` doubles through __cuda_array_interface__ (zero-copy torch view)."""
+
+  def __init__(self, ptr, count):
+    self.__cuda_array_interface__ = dict(shape=(int(count),), typestr='<f8', data=(int(ptr), False), version=2,
+                                         strides=None)
+
+
+def make_allreduce_hook(group=None, device=None):
+  """Returns fn(ptr, count, op, stream) for Handle.set_allreduce, backed by torch.distributed."""
+  import torch
+  import torch.distributed as dist
+  backend = dist.get_backend(group)
+  dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+
+  def hook(ptr, count, op, stream):
+    t = torch.as_tensor(_DevArray(ptr, count), device=dev)
+    rop = dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX
+    if backend == "nccl":
+      dist.all_reduce(t, op=rop, group=group)          # RCCL, in place, ordered on torch's current stream
+    else:
+      host = t.cpu()                                   # gloo: stage through host memory
+      dist.all_reduce(host, op=rop, group=group)
+      t.copy_(host)
+    return 0
+
+  return hook
+
+
+def sharded_handle(calib, rank=None, world_size=None, group=None, balance=True):
+  """Handle owning this rank's frame shard, wired to torch.distributed.  Kernels run on torch's current stream."""
+  import torch
+  import torch.distributed as dist
+  from .backend import Handle, lower
+  rank = dist.get_rank(group) if rank is None else rank
+  world_size = dist.get_world_size(group) if world_size is None else world_size
+  prob = lower(calib)
+  weights = None
+  if balance:
+    inl = calib.inliers
+    weights = inl.sum(axis=(0, 2, 3)).astype(np.float64)
+  shards = frame_shards(prob.shape[1], world_size, weights)
+  stream = torch.cuda.current_stream().cuda_stream
+  h = Handle(prob, frame_range=shards[rank], stream=stream)
+  if world_size > 1:
+    h.set_allreduce(make_allreduce_hook(group))
+    h.set_shard_root(rank == 0)
+  h.frame_range = shards[rank]
+  return h

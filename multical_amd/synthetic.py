@@ -191,8 +191,10 @@ def _cube_board_poses(n, side):
   return np.stack(poses)
 
 
-def make_rig(name_or_cfg, frames=None, seed=None, noise=0.2, outlier_frac=0.01):
-  """Returns SimpleNamespace(truth=..., init=..., point_table=..., meta=...) of plain numpy data."""
+def make_rig(name_or_cfg, frames=None, seed=None, noise=0.2, outlier_frac=0.01, obs_frames=None):
+  """Returns SimpleNamespace(truth=..., init=..., points=..., valid=..., ...) of plain numpy data.
+
+  obs_frames=(f0, f1): synthesise observations only for that frame range (poses / parameters cover all frames)."""
   cfg = dict(CONFIGS[name_or_cfg]) if isinstance(name_or_cfg, str) else dict(name_or_cfg)
   if frames is not None:
     cfg["frames"] = frames
@@ -280,55 +282,61 @@ def make_rig(name_or_cfg, frames=None, seed=None, noise=0.2, outlier_frac=0.01):
   points = np.zeros((C, F, B, P, 2))
   valid = np.zeros((C, F, B, P), dtype=bool)
   w, h = IMAGE_SIZE
-  view_vis = rng.random((C, F, B)) < 0.7
-  point_vis = rng.random((C, F, B, P)) < 0.9
-  gauss = rng.normal(0, noise, (C, F, B, P, 2))
-  for c in range(C):
-    T0 = cam_poses[c] @ rig                             # [F,4,4]
-    X0 = np.einsum('fij,bpj->fbpi', T0[:, :3, :3], W) + T0[:, None, None, :3, 3]
-    if motion == "rolling":
-      T1 = cam_poses[c] @ rig_end
-      X1 = np.einsum('fij,bpj->fbpi', T1[:, :3, :3], W) + T1[:, None, None, :3, 3]
-      uv = _project(cameras[c], X0)
-      for _ in range(6):  # fixed point for the scan time of the *observed* row
-        t = np.clip(uv[..., 1] / h, 0.0, 1.0)[..., None]
+  fa, fb = (0, F) if obs_frames is None else obs_frames
+  # observations are drawn frame by frame from generators seeded with (seed, frame): a frame's data does not depend
+  # on which other frames are generated, so every rank of a frame-sharded run can synthesise just its own shard
+  for f in range(fa, fb):
+    frng = np.random.default_rng([cfg["seed"], 7919, f])
+    view_vis = frng.random((C, B)) < 0.7
+    point_vis = frng.random((C, B, P)) < 0.9
+    gauss = frng.normal(0, noise, (C, B, P, 2))
+    for c in range(C):
+      T0 = cam_poses[c] @ rig[f]
+      X0 = np.einsum('ij,bpj->bpi', T0[:3, :3], W) + T0[:3, 3]
+      if motion == "rolling":
+        T1 = cam_poses[c] @ rig_end[f]
+        X1 = np.einsum('ij,bpj->bpi', T1[:3, :3], W) + T1[:3, 3]
+        uv = _project(cameras[c], X0)
+        for _ in range(6):  # fixed point for the scan time of the observed row
+          t = np.clip(uv[..., 1] / h, 0.0, 1.0)[..., None]
+          Xc = X0 * (1 - t) + X1 * t
+          uv = _project(cameras[c], Xc)
+        # the reference derives t from the observed (noisy) y; make the data consistent with that model
+        obs = uv + gauss[c]
+        t = (obs[..., 1] / h)[..., None]
         Xc = X0 * (1 - t) + X1 * t
         uv = _project(cameras[c], Xc)
-      # the reference derives t from the observed (noisy) y; make the data consistent with that model
-      obs = uv + gauss[c]
-      t = (obs[..., 1] / h)[..., None]
-      Xc = X0 * (1 - t) + X1 * t
-      uv = _project(cameras[c], Xc)
-      obs_c = uv + gauss[c]
-    else:
-      Xc = X0
-      uv = _project(cameras[c], Xc)
+      else:
+        Xc = X0
+        uv = _project(cameras[c], Xc)
       obs_c = uv + gauss[c]
 
-    nz = np.einsum('fij,bj->fbi', T0[:, :3, :3], normals)          # board normal in camera frame
-    facing = np.einsum('fbi,fbpi->fbp', nz, Xc) > 0                # seen from the printed side
-    if not (ring or cfg.get("cube")):
-      facing = np.ones_like(facing)
-    ok = (Xc[..., 2] > 0.1) & (uv[..., 0] >= 0) & (uv[..., 0] < w) & (uv[..., 1] >= 0) & (uv[..., 1] < h)
-    ok &= np.isfinite(uv).all(axis=-1) & facing & pvalid[None]
-    if cfg["model"] == 'fisheye':
-      ok &= np.arctan2(np.hypot(Xc[..., 0], Xc[..., 1]), Xc[..., 2]) < np.deg2rad(75)
-    else:
-      ok &= np.hypot(Xc[..., 0], Xc[..., 1]) < 0.62 * Xc[..., 2]   # stay inside the monotone range of the radial model
-    v = ok & view_vis[c][..., None] & point_vis[c]
-    # a detector reports a board only when enough corners are found (charuco.py:99-101)
-    v &= (v.sum(axis=-1) >= 12)[..., None]
-    points[c] = np.where(v[..., None], obs_c, 0.0)
-    valid[c] = v
+      nz = np.einsum('ij,bj->bi', T0[:3, :3], normals)            # board normal in camera frame
+      facing = np.einsum('bi,bpi->bp', nz, Xc) > 0                  # seen from the printed side
+      if not (ring or cfg.get("cube")):
+        facing = np.ones_like(facing)
+      ok = (Xc[..., 2] > 0.1) & (uv[..., 0] >= 0) & (uv[..., 0] < w) & (uv[..., 1] >= 0) & (uv[..., 1] < h)
+      ok &= np.isfinite(uv).all(axis=-1) & facing & pvalid
+      if cfg["model"] == 'fisheye':
+        ok &= np.arctan2(np.hypot(Xc[..., 0], Xc[..., 1]), Xc[..., 2]) < np.deg2rad(75)
+      else:
+        ok &= np.hypot(Xc[..., 0], Xc[..., 1]) < 0.62 * Xc[..., 2]  # stay inside the monotone range of the radial model
+      v = ok & view_vis[c][..., None] & point_vis[c]
+      # a detector reports a board only when enough corners are found (charuco.py:99-101)
+      v &= (v.sum(axis=-1) >= 12)[..., None]
+      points[c, f] = np.where(v[..., None], obs_c, 0.0)
+      valid[c, f] = v
 
-  n_out = int(outlier_frac * valid.sum())
-  if n_out > 0:
-    idx = np.flatnonzero(valid.ravel())
-    pick = rng.choice(idx, size=n_out, replace=False)
-    ang = rng.uniform(0, 2 * np.pi, n_out)
-    mag = rng.uniform(5, 50, n_out)
-    flat = points.reshape(-1, 2)
-    flat[pick] += np.stack([mag * np.cos(ang), mag * np.sin(ang)], axis=1)
+    n_out = int(round(outlier_frac * valid[:, f].sum()))
+    if n_out > 0:
+      vf = valid[:, f]
+      idx = np.flatnonzero(vf.ravel())
+      pick = frng.choice(idx, size=n_out, replace=False)
+      ang = frng.uniform(0, 2 * np.pi, n_out)
+      mag = frng.uniform(5, 50, n_out)
+      pf = points[:, f].reshape(-1, 2).copy()
+      pf[pick] += np.stack([mag * np.cos(ang), mag * np.sin(ang)], axis=1)
+      points[:, f] = pf.reshape(points[:, f].shape)
 
   truth = SimpleNamespace(cameras=cameras, camera_poses=cam_poses, board_poses=board_poses, rig=rig,
                           rig_end=rig_end, hand_eye=hand_eye)
