@@ -207,6 +207,9 @@ void launch_linearize(mcba_handle_s* h) {
 
 void launch_assemble(mcba_handle_s* h) {
   const Dims& d = h->d;
+  // entries of frames owned by other ranks must be zero before the cross-rank sum (they hold the previous global
+  // values after an all-reduce)
+  HIP_OK(hipMemsetAsync(h->gbuf.p, 0, (2 * (size_t)d.n + 2) * sizeof(double), h->stream));
   if (d.DF > 0 && d.Fl > 0)
     hipLaunchKernelGGL(k_assemble_frames, dim3(d.Fl), dim3(256), 0, h->stream, d, h->t, h->rec.p, h->Hff.p, h->Hfs.p,
                        h->g(), h->diag());

@@ -1,0 +1,87 @@
+"""Drop-in for an installed multical: route Calibration.bundle_adjust (optimization/calibration.py:199-212) through
+the MI355X back-end while keeping every other line of multical untouched.
+
+    import multical_amd.dropin as dropin
+    dropin.install()              # or set MULTICAL_BACKEND=hip and call dropin.install_from_env()
+
+After `install()`, `Workspace.calibrate` (workspace.py:228-247), `Calibration.adjust_outliers` (calibration.py:254-268)
+and `HandEyeCalibration.bundle_adjust` (optimization/hand_eye.py:73-75) reach the GPU through the unchanged call chain.
+`bundle_adjust` keeps the reference's signature, returns `self.with_param_vec(res.x)` exactly like the reference, does
+not mutate `self`, stores nothing on the Calibration (pickling is unaffected, calibration.py:222-226) and writes the
+scipy-style iteration table to the same "calibration" logger.  See INTEGRATION.md.
+"""
+import os
+
+import numpy as np
+
+from .backend import Handle, lower
+
+_HEADER = "{:^15}{:^15}{:^15}{:^15}{:^15}{:^15}".format("Iteration", "Total nfev", "Cost", "Cost reduction", "Step norm",
+                                                        "Optimality")
+
+
+def _format_row(it, nfev, cost, red, step, opt):
+  red_s = " " * 15 if np.isnan(red) else f"{red:^15.2e}"
+  step_s = " " * 15 if np.isnan(step) else f"{step:^15.2e}"
+  return f"{it:^15}{nfev:^15}{cost:^15.4e}{red_s}{step_s}{opt:^15.2e}"
+
+
+def bundle_adjust(self, tolerance=1e-4, f_scale=1.0, max_iterations=100, loss='linear'):
+  """Replacement body of multical.optimization.calibration.Calibration.bundle_adjust (same signature)."""
+  import logging
+  log = logging.getLogger("calibration")        # multical/io/logging.py:11
+  rows = []
+  with Handle(lower(self)) as h:
+    h.set_log(lambda *a: rows.append(_format_row(*a)))
+    res = h.solve(self.param_vec, tolerance=tolerance, f_scale=f_scale, max_iterations=max_iterations, loss=loss)
+  log.info(_HEADER)
+  for r in rows:
+    log.info(r)
+  log.info(res.message)
+  log.info(f"Function evaluations {res.nfev}, initial cost {res.initial_cost:.4e}, final cost {res.cost:.4e}, "
+           f"first-order optimality {res.optimality:.2e}.")
+  return self.with_param_vec(res.x)
+
+
+def _reprojection_tables(self):
+  """(errors, mask) of tables.reprojection_error(self.reprojected, self.point_table) on the device (tables.py:244-249)."""
+  with Handle(lower(self)) as h:
+    return h.reprojection_error(self.param_vec)
+
+
+def install(calibration_module=None, patch_errors=False):
+  """Patch `Calibration.bundle_adjust` of multical (or of the given module object).  Returns the patched class.
+  patch_errors=True additionally evaluates `reprojection_error` / `reject_outliers` on the device."""
+  if calibration_module is None:
+    import multical.optimization.calibration as calibration_module
+  cls = calibration_module.Calibration
+  if not hasattr(cls, "_scipy_bundle_adjust"):
+    cls._scipy_bundle_adjust = cls.bundle_adjust
+  cls.bundle_adjust = bundle_adjust
+  if patch_errors:
+    from functools import cached_property
+
+    def reprojection_error(self):
+      err, mask = _reprojection_tables(self)
+      return err[mask]
+
+    prop = cached_property(reprojection_error)
+    prop.__set_name__(cls, "reprojection_error")
+    cls.reprojection_error = prop
+  return cls
+
+
+def uninstall(calibration_module=None):
+  if calibration_module is None:
+    import multical.optimization.calibration as calibration_module
+  cls = calibration_module.Calibration
+  if hasattr(cls, "_scipy_bundle_adjust"):
+    cls.bundle_adjust = cls._scipy_bundle_adjust
+    del cls._scipy_bundle_adjust
+
+
+def install_from_env():
+  """MULTICAL_BACKEND=hip -> install(); anything else keeps scipy."""
+  if os.environ.get("MULTICAL_BACKEND", "scipy").lower() == "hip":
+    return install()
+  return None

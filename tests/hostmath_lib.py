@@ -40,9 +40,9 @@ def _check(rc):
 
 
 class HostMath(object):
-  def __init__(self, calib):
+  def __init__(self, calib, frame_range=None):
     self.prob = lower(calib)
-    self.struct = _to_struct(self.prob)
+    self.struct = _to_struct(self.prob, frame_range)
     n, m, k = C.c_int64(), C.c_int64(), C.c_int32()
     _check(lib().hm_sizes(C.byref(self.struct), C.byref(n), C.byref(m), C.byref(k)))
     self.n, self.m, self.row_nnz = n.value, m.value, k.value

@@ -1,0 +1,118 @@
+"""Frame sharding.  CPU: shard planning + world_size-2 `gloo` reduction of per-shard normal equations
+(computed by the product's device functions compiled for the host) equals the unsharded result.  GPU: two ranks sharing
+one MI355X over gloo run the sharded HIP solve and reproduce the single-handle solve."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from multical_amd import distributed as mdist
+from util import load_golden, mirror
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+  s = socket.socket()
+  s.bind(("127.0.0.1", 0))
+  p = s.getsockname()[1]
+  s.close()
+  return p
+
+
+def test_frame_shards_cover_and_balance():
+  for F, W in [(500, 8), (20, 3), (5, 8), (1, 2)]:
+    sh = mdist.frame_shards(F, W)
+    assert len(sh) == W and sh[0][0] == 0 and sh[-1][1] == F
+    assert all(a[1] == b[0] for a, b in zip(sh, sh[1:]))
+    assert max(b - a for a, b in sh) - min(b - a for a, b in sh) <= 1 or F < W
+  w = np.zeros(100); w[:10] = 50; w[10:] = 1
+  sh = mdist.frame_shards(100, 4, w)
+  loads = [w[a:b].sum() for a, b in sh]
+  assert max(loads) <= 2.5 * w.sum() / 4
+  assert mdist.frame_shards(7, 2, np.zeros(7)) == [(0, 3), (3, 7)] or mdist.frame_shards(7, 2, np.zeros(7))[1][1] == 7
+
+
+def _cpu_worker(rank, world, port, name, out):
+  sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+  import torch
+  import torch.distributed as dist
+  from hostmath_lib import HostMath
+  os.environ["MASTER_ADDR"] = "127.0.0.1"
+  os.environ["MASTER_PORT"] = str(port)
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  g, rig = load_golden(name)
+  c = mirror(rig)
+  F = rig.valid.shape[1]
+  shard = mdist.frame_shards(F, world, c.inliers.sum(axis=(0, 2, 3)).astype(float))[rank]
+  hm = HostMath(c, frame_range=shard)
+  H, grad, cost = hm.normal_equations(g["x0"])
+  buf = torch.from_numpy(np.concatenate([H.ravel(), grad, [cost, hm.m]]))
+  dist.all_reduce(buf)                      # the same sum the GPU path performs through mcba_allreduce_fn
+  if rank == 0:
+    np.save(out, buf.numpy())
+  dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["tiny_rolling", "cfg1"])
+def test_sharded_normal_equations_sum_gloo(name, tmp_path):
+  import torch.multiprocessing as mp
+  from hostmath_lib import HostMath
+  out = str(tmp_path / "reduced.npy")
+  mp.spawn(_cpu_worker, args=(2, _free_port(), name, out), nprocs=2, join=True)
+  red = np.load(out)
+  g, rig = load_golden(name)
+  hm = HostMath(mirror(rig))
+  H, grad, cost = hm.normal_equations(g["x0"])
+  n = hm.n
+  assert np.abs(red[:n * n].reshape(n, n) - H).max() <= 1e-12 * np.abs(H).max()
+  assert np.abs(red[n * n:n * n + n] - grad).max() <= 1e-12 * np.abs(grad).max()
+  assert red[-2] == pytest.approx(cost, rel=1e-13)
+  assert red[-1] == hm.m                                           # shards partition the residual vector
+
+
+def _gpu_worker(rank, world, port, name, out):
+  sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+  import torch
+  import torch.distributed as dist
+  os.environ["MASTER_ADDR"] = "127.0.0.1"
+  os.environ["MASTER_PORT"] = str(port)
+  torch.cuda.set_device(0)                  # both ranks share the one GPU of the test box (gloo: host-staged sums)
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  g, rig = load_golden(name)
+  c = mirror(rig)
+  h = mdist.sharded_handle(c)
+  cost, grad, diag = h.normal_equations(g["x0"])
+  res = h.solve(g["x0"])
+  e, v = h.reprojection_error(res.x)
+  sq = torch.tensor([float((e[v] ** 2).sum()), float(v.sum())], dtype=torch.float64)
+  dist.all_reduce(sq)
+  if rank == 0:
+    np.savez(out, cost=cost, grad=grad, diag=diag, x=res.x, nfev=res.nfev, status=res.status, final_cost=res.cost,
+             rms=float(np.sqrt(sq[0] / sq[1])))
+  h.close()
+  dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["tiny_rolling", "tiny_handeye", "cfg1"])
+def test_sharded_solve_two_ranks_one_gpu(name, tmp_path):
+  import torch.multiprocessing as mp
+  from multical_amd.backend import Handle
+  out = str(tmp_path / "sharded.npz")
+  mp.spawn(_gpu_worker, args=(2, _free_port(), name, out), nprocs=2, join=True)
+  sh = np.load(out)
+  g, rig = load_golden(name)
+  with Handle(mirror(rig)) as h:
+    cost, grad, diag = h.normal_equations(g["x0"])
+    res = h.solve(g["x0"])
+    e, v = h.reprojection_error(res.x)
+  assert float(sh["cost"]) == pytest.approx(cost, rel=1e-13)
+  assert np.abs(sh["grad"] - grad).max() <= 1e-12 * np.abs(grad).max()
+  assert np.abs(sh["diag"] - diag).max() <= 1e-12 * np.abs(diag).max()
+  assert int(sh["nfev"]) == res.nfev and int(sh["status"]) == res.status
+  assert float(sh["final_cost"]) == pytest.approx(res.cost, rel=1e-10)
+  assert abs(float(sh["rms"]) - float(np.sqrt(np.mean(e[v] ** 2)))) < 1e-9
+  assert np.abs(sh["x"] - res.x).max() < 1e-8
