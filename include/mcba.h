@@ -206,6 +206,9 @@ int32_t mcba_set_mfma(mcba_handle h, int32_t on);
 /* regularised Gauss-Newton direction (H_h + reg I)^-1 g_h in the column-scaled space, computed by the Schur /
  * Cholesky kernels after a preceding mcba_normal_equations at the same x; g_h and scale_inv may be NULL.           */
 int32_t mcba_debug_gn_step(mcba_handle h, double reg, double* gn_h, double* g_h, double* scale_inv);
+/* per-view s_memtime stamps of the k_linearize phases: out[views][8] = {setup, rows, stage+mfma, epilogue, count,
+ * start, end, 0} in shader cycles (profiling aid for DESIGN.md section 5)                                             */
+int32_t mcba_debug_linearize_profile(mcba_handle h, const double* x, long long* out);
 /* one v_mfma_f64_16x16x4_f64 on V = [A | B] (4 x 32, row-major): out[16][16] = A^T B (operand-layout self-test)     */
 int32_t mcba_debug_mfma_probe(const double* V, double* out);
 

@@ -254,6 +254,13 @@ class Handle(object):
                                       _ptr(si, C.c_double)))
     return gn, gh, si
 
+  def linearize_profile(self, x):
+    x = self._x(x)
+    C_, F, B, P = self.shape
+    out = np.zeros((F * C_ * B, 8), dtype=np.int64)
+    check(self.lib.mcba_debug_linearize_profile(self.h, _ptr(x, C.c_double), out.ctypes.data_as(C.POINTER(C.c_longlong))))
+    return out
+
   # --- solve --------------------------------------------------------------------------------------------------
   def set_log(self, fn):
     """fn(iteration, nfev, cost, cost_reduction, step_norm, optimality) or None."""

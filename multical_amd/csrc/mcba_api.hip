@@ -101,6 +101,7 @@ struct mcba_handle_s {
   DevBuf<int32_t> obs_index, view_count, board_off, full2act;
   DevBuf<double> xfull, bwg, img_h, board_points, pose, cam, view;
   DevBuf<uint16_t> tri;
+  DevBuf<long long> dbg;
 
   // linearisation
   DevBuf<double> rec, partial, Hss, Hfs, Hff, gbuf;   // gbuf = [g (n) | diag (n) | cost, count]
@@ -474,7 +475,7 @@ int32_t mcba_create(const mcba_problem* p, void* hip_stream, mcba_handle* out) {
   t.obs = h->obs.p; t.inlier = h->inlier.p; t.evalid = h->evalid.p; t.obs_index = h->obs_index.p;
   t.view_count = h->view_count.p; t.board_off = h->board_off.p; t.full2act = h->full2act.p; t.xfull = h->xfull.p;
   t.bwg = h->bwg.p; t.img_h = h->img_h.p; t.fix_aspect = h->fix_aspect.p; t.board_points = h->board_points.p;
-  t.pose = h->pose.p; t.cam = h->cam.p; t.view = h->view.p;
+  t.pose = h->pose.p; t.cam = h->cam.p; t.view = h->view.p; t.dbg = nullptr;
 
   // ---- work buffers -----------------------------------------------------------------------------------------
   h->rec.alloc((size_t)d.views() * d.rec_stride);
@@ -699,6 +700,22 @@ int32_t mcba_debug_gn_step(mcba_handle h, double reg, double* gn_h, double* g_h,
   int info = 0;
   HIP_OK(hipMemcpy(&info, h->info.p, sizeof(int), hipMemcpyDeviceToHost));
   REQUIRE(info == 0, "Cholesky of the reduced system hit a non-positive pivot at column " + std::to_string(info));
+  API_END
+}
+
+// debug: per-view cycle stamps of the k_linearize phases [views][8] (setup, rows, stage+mfma, epilogue, count, t0, t1)
+int32_t mcba_debug_linearize_profile(mcba_handle h, const double* x, long long* out) {
+  API_BEGIN
+  REQUIRE(h && x && out, "null argument");
+  const size_t n = (size_t)h->d.views() * 8;
+  h->dbg.alloc(n, true);
+  h->t.dbg = h->dbg.p;
+  upload_x(h, x, h->x.p);
+  eval_tables(h, h->x.p);
+  launch_linearize(h);
+  h->t.dbg = nullptr;
+  HIP_OK(hipMemcpyAsync(out, h->dbg.p, n * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
+  sync(h);
   API_END
 }
 

@@ -179,14 +179,20 @@ __global__ void k_jacobian(Dims d, Tables t, int row_nnz, double* __restrict__ v
 // k_linearize: fused residual + Jacobian -> per-view local normal equations.
 //
 //   grid  = one 64-thread workgroup (one wavefront) per view (frame-major), empty views exit at once.
-//   loop  = chunks of 64 board points: lane = point.  Each lane evaluates the forward model and the 2 x NV row pair
-//           V = [E | K | r] in registers, the rows are transposed through an LDS staging buffer
+//   compaction: the inlier slots of the view are gathered into an index list in LDS (ballot + popcount), so that
+//           lanes and MFMA rows are only spent on real observations (about half of the slots of a visible view).
+//   loop  = chunks of 64 observations: lane = observation.  Each lane evaluates the forward model and the 2 x NV row
+//           pair V = [E | K | r] in registers, the rows are transposed through an LDS staging buffer
 //           (row stride NVP+1 doubles: conflict-free 128-byte row reads, 2-way write conflicts), and
 //           S += V^T V is accumulated by v_mfma_f64_16x16x4_f64: operand lane l holds V[4 s + (l>>4)][16 t + (l&15)],
 //           A and B operands are the SAME register for diagonal tiles.  NV <= 16 -> one tile, NV <= 32 -> three.
+//           Only the MFMA steps that contain observations are issued.
 //   epilogue: Y = S That, M = That^T Y (That = [T_cam | T_frame.. | T_board] (+) I) -> packed upper triangle record.
+//   LDS: one buffer is time-shared between the row staging and the epilogue matrices (S, Y) to keep >= 2 waves/SIMD.
 //   MFMA=false keeps the identical data flow with plain FMAs over the staged rows (validation / fallback build).
 // ---------------------------------------------------------------------------------------------------------------
+constexpr int LIN_MAX_POINTS = 512;    // points per board supported by the compaction list (mcba_create checks it)
+
 template <int ND, bool FISH, int MOTION, bool OPTK, bool MFMA>
 __global__ __launch_bounds__(64) void k_linearize(Dims d, Tables t, double* __restrict__ rec,
                                                   const uint16_t* __restrict__ tri) {
@@ -196,25 +202,45 @@ __global__ __launch_bounds__(64) void k_linearize(Dims d, Tables t, double* __re
   constexpr int NPC = 6 * NPB, NL = NPC + KI, N1 = NL + 1;
   constexpr int PTS = NT == 1 ? 64 : 32, RND = 64 / PTS, ROWS = 2 * PTS;
   constexpr int REC = N1 * (N1 + 1) / 2;
-  static_assert(NV * N1 <= ROWS * LDV, "Y does not fit in the staging buffer");
+  constexpr int STAGE = ROWS * LDV, EPI = NVP * NVP;
+  constexpr int BUF = STAGE > EPI ? STAGE : EPI;
 
-  __shared__ double Vbuf[ROWS * LDV];
-  __shared__ double Sbuf[NVP * NVP];
+  __shared__ double Buf[BUF];            // staging rows during the main loop; [S | Y] in the epilogue
   __shared__ double Tm[DE * NPC];
+  __shared__ uint16_t pidx[LIN_MAX_POINTS];
+  double* Vbuf = Buf;
 
   const int v = blockIdx.x, lane = threadIdx.x;
-  const int count = t.view_count[v];
-  if (count == 0) return;
+  if (t.view_count[v] == 0) return;
   const int b = v % d.B, c = (v / d.B) % d.C, fl = v / (d.B * d.C), f = d.f0 + fl;
+  long long stamp[6] = {0, 0, 0, 0, 0, 0};
+  const bool prof = t.dbg != nullptr;
+  if (prof) stamp[0] = clock64();
 
   if (lane < NPC) {
     double col[12];
     view_column(d, t, f, c, b, lane, col);
     for (int a = 0; a < DE; ++a) Tm[a * NPC + lane] = col[a];
   }
-  for (int e = lane; e < ROWS * LDV; e += 64) Vbuf[e] = 0.0;   // pad columns stay zero for the whole kernel
+  for (int e = lane; e < STAGE; e += 64) Vbuf[e] = 0.0;   // pad columns stay zero during the main loop
 
-  // accumulators
+  // gather the inlier slots of this view: all mask bytes are requested at once (one memory round trip)
+  constexpr int NPB64 = LIN_MAX_POINTS / 64;
+  uint8_t inb[NPB64];
+#pragma unroll
+  for (int k = 0; k < NPB64; ++k) {
+    const int p = k * 64 + lane;
+    inb[k] = p < d.P ? t.inlier[(size_t)v * d.P + p] : (uint8_t)0;
+  }
+  int count = 0;
+#pragma unroll
+  for (int k = 0; k < NPB64; ++k) {
+    const bool in = inb[k] != 0;
+    const unsigned long long m = __ballot(in);
+    if (in) pidx[count + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(k * 64 + lane);
+    count += __popcll(m);
+  }
+
   constexpr int NACC_V = NVP * NVP / 64;                  // plain-FMA variant: NVP*NVP entries over 64 lanes
   constexpr int NTILE = NT * (NT + 1) / 2;
   double accv[MFMA ? 1 : NACC_V];
@@ -226,45 +252,53 @@ __global__ __launch_bounds__(64) void k_linearize(Dims d, Tables t, double* __re
   }
   double cost = 0.0;
   lds_fence();
+  if (prof) stamp[1] = clock64();
 
-  const int nchunks = (d.P + 63) / 64;
-  for (int chunk = 0; chunk < nchunks; ++chunk) {
-    const int p = chunk * 64 + lane;
-    const size_t s = (size_t)v * d.P + p;
-    const bool in = p < d.P && t.inlier[s] != 0;
+  for (int base = 0; base < count; base += 64) {
+    const int i = base + lane;
+    const bool in = i < count;
     double vr[2 * NV];
+    long long t0 = 0;
+    if (prof) t0 = clock64();
     if (in) {
-      cost += point_rows<ND, FISH, ROLL, OPTK>(d, t, v, c, b, p, t.obs[s], vr);
+      const int p = pidx[i];
+      cost += point_rows<ND, FISH, ROLL, OPTK>(d, t, v, c, b, p, t.obs[(size_t)v * d.P + p], vr);
     } else {
-      for (int i = 0; i < 2 * NV; ++i) vr[i] = 0.0;
+      for (int k = 0; k < 2 * NV; ++k) vr[k] = 0.0;
     }
-    if (__ballot(in) == 0ull) continue;   // wave-uniform: nothing to add
-
+    if (prof) stamp[2] += clock64() - t0;
+    const int nchunk = min(64, count - base);              // observations in this chunk
     for (int q = 0; q < RND; ++q) {
+      const int npts = min(PTS, nchunk - q * PTS);          // observations staged in this round
+      if (npts <= 0) break;
       if (RND == 1 || (lane / PTS) == q) {
         const int row0 = 2 * (lane % PTS);
-        for (int i = 0; i < NV; ++i) {
-          Vbuf[row0 * LDV + i] = vr[i];
-          Vbuf[(row0 + 1) * LDV + i] = vr[NV + i];
+        for (int k = 0; k < NV; ++k) {
+          Vbuf[row0 * LDV + k] = vr[k];
+          Vbuf[(row0 + 1) * LDV + k] = vr[NV + k];
         }
       }
       lds_fence();
+      const int nsteps = (npts + 1) / 2;                    // 4 rows (2 observations) per MFMA step
       if constexpr (MFMA) {
         const int rsub = lane >> 4, csub = lane & 15;
-        for (int st = 0; st < ROWS / 4; ++st) {
-          double a[NT];
-          for (int tt = 0; tt < NT; ++tt) a[tt] = Vbuf[(4 * st + rsub) * LDV + 16 * tt + csub];
+        const double* vp = Vbuf + rsub * LDV + csub;
+        double a[NT], an[NT];
+        for (int tt = 0; tt < NT; ++tt) a[tt] = vp[16 * tt];
+        for (int st = 0; st < nsteps; ++st) {
+          if (st + 1 < nsteps)                                  // operands of the next step are in flight
+            for (int tt = 0; tt < NT; ++tt) an[tt] = vp[(4 * (st + 1)) * LDV + 16 * tt];
           int ti = 0;
           for (int t0 = 0; t0 < NT; ++t0)
             for (int t1 = t0; t1 < NT; ++t1, ++ti)
               accm[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t0], a[t1], accm[ti], 0, 0, 0);
+          for (int tt = 0; tt < NT; ++tt) a[tt] = an[tt];
         }
       } else {
-        constexpr int IW = NVP;                  // i index width
-        constexpr int JW = NACC_V;               // j entries per lane
-        const int i = lane % IW, j0 = (lane / IW) * JW;
-        for (int row = 0; row < ROWS; ++row) {
-          const double vi = Vbuf[row * LDV + i];
+        constexpr int IW = NVP, JW = NACC_V;
+        const int ii = lane % IW, j0 = (lane / IW) * JW;
+        for (int row = 0; row < 4 * nsteps; ++row) {
+          const double vi = Vbuf[row * LDV + ii];
           for (int jj = 0; jj < JW; ++jj) accv[jj] += vi * Vbuf[row * LDV + j0 + jj];
         }
       }
@@ -272,7 +306,9 @@ __global__ __launch_bounds__(64) void k_linearize(Dims d, Tables t, double* __re
     }
   }
 
-  // S -> LDS (full symmetric matrix)
+  if (prof) stamp[3] = clock64();
+  // S -> LDS (full symmetric matrix), time-sharing the staging buffer
+  double* Sbuf = Buf;
   if constexpr (MFMA) {
     const int rsub = lane >> 4, csub = lane & 15;
     int ti = 0;
@@ -285,42 +321,59 @@ __global__ __launch_bounds__(64) void k_linearize(Dims d, Tables t, double* __re
         }
   } else {
     constexpr int IW = NVP, JW = NACC_V;
-    const int i = lane % IW, j0 = (lane / IW) * JW;
-    for (int jj = 0; jj < JW; ++jj) Sbuf[i * NVP + j0 + jj] = accv[jj];
+    const int ii = lane % IW, j0 = (lane / IW) * JW;
+    for (int jj = 0; jj < JW; ++jj) Sbuf[ii * NVP + j0 + jj] = accv[jj];
   }
   lds_fence();
 
-  // epilogue: Y = S That  (NV x N1), staged in the (now free) row buffer
-  double* Y = Vbuf;
-  for (int e = lane; e < NV * N1; e += 64) {
-    const int a = e / N1, j = e % N1;
-    double sum;
-    if (j < NPC) {
-      sum = 0.0;
-      for (int bb = 0; bb < DE; ++bb) sum += Sbuf[a * NVP + bb] * Tm[bb * NPC + j];
-    } else {
-      sum = Sbuf[a * NVP + DE + (j - NPC)];
-    }
-    Y[e] = sum;
-  }
-  lds_fence();
+  // epilogue.  lane j < N1 owns column j of the local system:
+  //   y[a] = (S That)[a][j]  for the DE base rows  (That column j in registers, S rows are LDS broadcasts)
+  //   M[i][j] = sum_a That[a][i] y[a]  (i < NPC, i <= j),   M[i][j] = S[DE + i - NPC][.]-row entries otherwise
   double* out = rec + (size_t)v * d.rec_stride;
-  for (int e = lane; e < REC; e += 64) {
-    const int ij = tri[e];
-    const int i = ij >> 8, j = ij & 255;
-    double m;
-    if (i < NPC) {
-      m = 0.0;
-      for (int a = 0; a < DE; ++a) m += Tm[a * NPC + i] * Y[a * N1 + j];
-    } else {
-      m = Y[(DE + i - NPC) * N1 + j];
+  const int j = lane;
+  if (j < N1) {
+    double tcol[DE], y[DE];
+    const bool pose_col = j < NPC;
+#pragma unroll
+    for (int a = 0; a < DE; ++a) tcol[a] = pose_col ? Tm[a * NPC + j] : 0.0;
+#pragma unroll
+    for (int a = 0; a < DE; ++a) {
+      double sum;
+      if (pose_col) {
+        sum = 0.0;
+#pragma unroll
+        for (int bb = 0; bb < DE; ++bb) sum += Sbuf[a * NVP + bb] * tcol[bb];
+      } else {
+        sum = Sbuf[a * NVP + DE + (j - NPC)];
+      }
+      y[a] = sum;
     }
-    out[e] = m;
+    // rows i < NPC of column j
+    const int imax = pose_col ? j : NPC - 1;
+    for (int i = 0; i <= imax; ++i) {
+      double m = 0.0;
+#pragma unroll
+      for (int a = 0; a < DE; ++a) m += Tm[a * NPC + i] * y[a];
+      out[tri_index(i, j, N1)] = m;
+    }
+    // rows i >= NPC (intrinsics / residual rows): M[i][j] = S[DE + i - NPC][DE + j - NPC]
+    if (!pose_col)
+      for (int i = NPC; i <= j; ++i) out[tri_index(i, j, N1)] = Sbuf[(DE + i - NPC) * NVP + DE + (j - NPC)];
   }
   cost = wave_sum(cost);
   if (lane == 0) {
     out[REC] = 0.5 * cost;
     out[REC + 1] = (double)count;
+    if (prof) {
+      long long* o = t.dbg + (size_t)v * 8;
+      o[0] = stamp[1] - stamp[0];                 // setup: That columns, staging clear, compaction
+      o[1] = stamp[2];                            // forward model + Jacobian rows (all chunks)
+      o[2] = stamp[3] - stamp[1] - stamp[2];      // LDS staging + MFMA
+      o[3] = clock64() - stamp[3];                // epilogue
+      o[4] = count;
+      o[5] = stamp[0];
+      o[6] = clock64();
+    }
   }
 }
 
