@@ -193,8 +193,12 @@ __global__ void k_jacobian(Dims d, Tables t, int row_nnz, double* __restrict__ v
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int LIN_MAX_POINTS = 512;    // points per board supported by the compaction list (mcba_create checks it)
 
+// __launch_bounds__(64, 2): two waves per SIMD = a 256-register budget.  Besides fixing the occupancy the kernel is
+// designed for, this makes hipcc select the VGPR form of the MFMA: with the default 512-register budget it keeps the
+// loop-carried accumulators in VGPRs, issues AGPR-form MFMAs and brackets EVERY step with 24 v_accvgpr_write +
+// 24 v_accvgpr_read and a full-latency s_nop (196 instead of 64 cycles per MFMA, measured with s_memtime stamps).
 template <int ND, bool FISH, int MOTION, bool OPTK, bool MFMA>
-__global__ __launch_bounds__(64) void k_linearize(Dims d, Tables t, double* __restrict__ rec,
+__global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* __restrict__ rec,
                                                   const uint16_t* __restrict__ tri) {
   constexpr bool ROLL = MOTION == MOTION_ROLLING;
   constexpr int DE = ROLL ? 12 : 6, NPB = MOTION == MOTION_STATIC ? 3 : 4, KI = OPTK ? 4 + ND : 0;
@@ -217,11 +221,7 @@ __global__ __launch_bounds__(64) void k_linearize(Dims d, Tables t, double* __re
   const bool prof = t.dbg != nullptr;
   if (prof) stamp[0] = clock64();
 
-  if (lane < NPC) {
-    double col[12];
-    view_column(d, t, f, c, b, lane, col);
-    for (int a = 0; a < DE; ++a) Tm[a * NPC + lane] = col[a];
-  }
+  if (lane < NPC) view_column(d, t, f, c, b, lane, Tm + lane, NPC);   // column `lane` of That, written in place
   for (int e = lane; e < STAGE; e += 64) Vbuf[e] = 0.0;   // pad columns stay zero during the main loop
 
   // gather the inlier slots of this view: all mask bytes are requested at once (one memory round trip)
@@ -283,16 +283,30 @@ __global__ __launch_bounds__(64) void k_linearize(Dims d, Tables t, double* __re
       if constexpr (MFMA) {
         const int rsub = lane >> 4, csub = lane & 15;
         const double* vp = Vbuf + rsub * LDV + csub;
-        double a[NT], an[NT];
-        for (int tt = 0; tt < NT; ++tt) a[tt] = vp[16 * tt];
-        for (int st = 0; st < nsteps; ++st) {
-          if (st + 1 < nsteps)                                  // operands of the next step are in flight
-            for (int tt = 0; tt < NT; ++tt) an[tt] = vp[(4 * (st + 1)) * LDV + 16 * tt];
-          int ti = 0;
-          for (int t0 = 0; t0 < NT; ++t0)
-            for (int t1 = t0; t1 < NT; ++t1, ++ti)
-              accm[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t0], a[t1], accm[ti], 0, 0, 0);
-          for (int tt = 0; tt < NT; ++tt) a[tt] = an[tt];
+        // two steps per iteration with ping-pong operand registers: the LDS reads of the next step are in flight
+        // while the MFMAs of the current one issue, and no register copy forces an early s_waitcnt
+        // (every lane of the round stages its rows, zero rows for lanes without an observation, so the step count can
+        //  be rounded up to an even number and the loop body stays branch-free)
+        double a0[NT], a1[NT];
+        constexpr int MAXS = ROWS / 4;
+        const int nsteps2 = (nsteps + 1) & ~1;
+        for (int tt = 0; tt < NT; ++tt) a0[tt] = vp[16 * tt];
+        for (int st = 0; st < nsteps2; st += 2) {
+          for (int tt = 0; tt < NT; ++tt) a1[tt] = vp[(4 * (st + 1)) * LDV + 16 * tt];
+          {
+            int ti = 0;
+            for (int t0 = 0; t0 < NT; ++t0)
+              for (int t1 = t0; t1 < NT; ++t1, ++ti)
+                accm[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[t0], a0[t1], accm[ti], 0, 0, 0);
+          }
+          const int nx = min(st + 2, MAXS - 1);
+          for (int tt = 0; tt < NT; ++tt) a0[tt] = vp[(4 * nx) * LDV + 16 * tt];
+          {
+            int ti = 0;
+            for (int t0 = 0; t0 < NT; ++t0)
+              for (int t1 = t0; t1 < NT; ++t1, ++ti)
+                accm[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[t0], a1[t1], accm[ti], 0, 0, 0);
+          }
         }
       } else {
         constexpr int IW = NVP, JW = NACC_V;

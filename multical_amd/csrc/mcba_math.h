@@ -335,18 +335,26 @@ MCBA_HD void base_rows(const double* A, const double* X, double* E /*[2][6]*/) {
 
 // Column j (0..5) of T_k = [[Rpre L_k, 0], [[o_k]x Rpre L_k, Rpre]] for a pose with prefix rotation Rpre (product of
 // everything left of it in the chain), left Jacobian L_k and o_k = translation of (prefix . pose_k).
-MCBA_HD void view_pose_column(const double* Rpre, const double* Lk, const double* ok, int j, double* col /*[6]*/) {
+// Written without dynamic register indexing (unit-vector products, strided output) so that nothing spills to scratch.
+MCBA_HD void view_pose_column(const double* Rpre, const double* Lk, const double* ok, int j, double* col, int stride = 1) {
+  const int jj = j < 3 ? j : j - 3;
+  const double e0 = jj == 0 ? 1.0 : 0.0, e1 = jj == 1 ? 1.0 : 0.0, e2 = jj == 2 ? 1.0 : 0.0;
   if (j < 3) {
-    const double l[3] = {Lk[j], Lk[3 + j], Lk[6 + j]};
-    double top[3];
-    mat3_vec(Rpre, l, top);
-    col[0] = top[0]; col[1] = top[1]; col[2] = top[2];
-    cross3(ok, top, col + 3);
+    const double l0 = Lk[0] * e0 + Lk[1] * e1 + Lk[2] * e2;   // column jj of L_k
+    const double l1 = Lk[3] * e0 + Lk[4] * e1 + Lk[5] * e2;
+    const double l2 = Lk[6] * e0 + Lk[7] * e1 + Lk[8] * e2;
+    const double t0 = Rpre[0] * l0 + Rpre[1] * l1 + Rpre[2] * l2;
+    const double t1 = Rpre[3] * l0 + Rpre[4] * l1 + Rpre[5] * l2;
+    const double t2 = Rpre[6] * l0 + Rpre[7] * l1 + Rpre[8] * l2;
+    col[0] = t0; col[stride] = t1; col[2 * stride] = t2;
+    col[3 * stride] = ok[1] * t2 - ok[2] * t1;
+    col[4 * stride] = ok[2] * t0 - ok[0] * t2;
+    col[5 * stride] = ok[0] * t1 - ok[1] * t0;
   } else {
-    col[0] = col[1] = col[2] = 0.0;
-    col[3] = Rpre[j - 3];
-    col[4] = Rpre[3 + j - 3];
-    col[5] = Rpre[6 + j - 3];
+    col[0] = 0.0; col[stride] = 0.0; col[2 * stride] = 0.0;
+    col[3 * stride] = Rpre[0] * e0 + Rpre[1] * e1 + Rpre[2] * e2;   // column jj of R_pre
+    col[4 * stride] = Rpre[3] * e0 + Rpre[4] * e1 + Rpre[5] * e2;
+    col[5 * stride] = Rpre[6] * e0 + Rpre[7] * e1 + Rpre[8] * e2;
   }
 }
 

@@ -379,7 +379,7 @@ __global__ void k_schur_frames(Dims d, const double* __restrict__ Hfs, const dou
 // k = (frame, dd) of W' = [W | y]  [K x (ns+1)].  One wavefront per (upper tile, K split); MFMA f64 16x16x4 reads its
 // operands straight from global memory (row-major W': 128-byte coalesced segments per 16 lanes).
 template <bool MFMA>
-__global__ __launch_bounds__(64) void k_schur_syrk(int K, int ncol, int ntile, int ksplit, const double* __restrict__ W,
+__global__ __launch_bounds__(64, 2) void k_schur_syrk(int K, int ncol, int ntile, int ksplit, const double* __restrict__ W,
                                                    double* __restrict__ P) {
   const int tile = blockIdx.x, split = blockIdx.y, lane = threadIdx.x;
   int ti = 0, rem = tile;

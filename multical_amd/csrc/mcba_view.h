@@ -46,7 +46,7 @@ MCBA_HD void slot_forward(const Dims& d, const Tables& t, int v, int c, int b, i
 // ---------------------------------------------------------------------------------------------------------------
 // pose-block structure of a view: column j of That (DE rows) and the x index of every local parameter
 // ---------------------------------------------------------------------------------------------------------------
-MCBA_HD void view_column(const Dims& d, const Tables& t, int f, int c, int b, int j, double* col) {
+MCBA_HD void view_column(const Dims& d, const Tables& t, int f, int c, int b, int j, double* col, int stride = 1) {
   const int k = j / 6, jj = j % 6;
   const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   const double* Pc = t.pose + (size_t)(d.pose_cam + c) * POSE_STRIDE;
@@ -56,24 +56,24 @@ MCBA_HD void view_column(const Dims& d, const Tables& t, int f, int c, int b, in
   if (d.motion == MOTION_STATIC) {
     const double* Pf = t.pose + (size_t)(d.pose_motion + f) * POSE_STRIDE;
     if (k == 0) {
-      view_pose_column(I3, Pc + POSE_L, tc, jj, col);
+      view_pose_column(I3, Pc + POSE_L, tc, jj, col, stride);
     } else {
       double R1[9], t1[3];
       se3_mul(Rc, tc, Pf + POSE_R, Pf + POSE_T, R1, t1);          // camera . frame
       if (k == 1) {
-        view_pose_column(Rc, Pf + POSE_L, t1, jj, col);
+        view_pose_column(Rc, Pf + POSE_L, t1, jj, col, stride);
       } else {
         double o[3], v3[3];
         mat3_vec(R1, Pb + POSE_T, v3);
         for (int i = 0; i < 3; ++i) o[i] = t1[i] + v3[i];
-        view_pose_column(R1, Pb + POSE_L, o, jj, col);
+        view_pose_column(R1, Pb + POSE_L, o, jj, col, stride);
       }
     }
   } else if (d.motion == MOTION_ROLLING) {
-    for (int i = 0; i < 12; ++i) col[i] = 0.0;
+    for (int i = 0; i < 12; ++i) col[i * stride] = 0.0;
     if (k == 0) {
-      view_pose_column(I3, Pc + POSE_L, tc, jj, col);
-      for (int i = 0; i < 6; ++i) col[6 + i] = col[i];
+      view_pose_column(I3, Pc + POSE_L, tc, jj, col, stride);
+      for (int i = 0; i < 6; ++i) col[(6 + i) * stride] = col[i * stride];
     } else {
       for (int ch = 0; ch < 2; ++ch) {
         if ((k == 1 && ch == 1) || (k == 2 && ch == 0)) continue;
@@ -84,9 +84,9 @@ MCBA_HD void view_column(const Dims& d, const Tables& t, int f, int c, int b, in
           double o[3], v3[3];
           mat3_vec(R1, Pb + POSE_T, v3);
           for (int i = 0; i < 3; ++i) o[i] = t1[i] + v3[i];
-          view_pose_column(R1, Pb + POSE_L, o, jj, col + 6 * ch);
+          view_pose_column(R1, Pb + POSE_L, o, jj, col + 6 * ch * stride, stride);
         } else {
-          view_pose_column(Rc, Pf + POSE_L, t1, jj, col + 6 * ch);
+          view_pose_column(Rc, Pf + POSE_L, t1, jj, col + 6 * ch * stride, stride);
         }
       }
     }
@@ -95,23 +95,23 @@ MCBA_HD void view_column(const Dims& d, const Tables& t, int f, int c, int b, in
     const double* G = t.pose + (size_t)(d.pose_motion + 1) * POSE_STRIDE;
     const double* Bf = t.bwg + 12 * (size_t)f;
     if (k == 0) {
-      view_pose_column(I3, Pc + POSE_L, tc, jj, col);
+      view_pose_column(I3, Pc + POSE_L, tc, jj, col, stride);
     } else {
       double R1[9], t1[3];
       se3_mul(Rc, tc, G + POSE_R, G + POSE_T, R1, t1);            // camera . G
       if (k == 2) {
-        view_pose_column(Rc, G + POSE_L, t1, jj, col);
+        view_pose_column(Rc, G + POSE_L, t1, jj, col, stride);
       } else {
         double R2[9], t2[3], R3[9], t3[3];
         se3_mul(R1, t1, Bf, Bf + 9, R2, t2);                       // . B_f
         se3_mul(R2, t2, Wb + POSE_R, Wb + POSE_T, R3, t3);         // . Wb
         if (k == 1) {
-          view_pose_column(R2, Wb + POSE_L, t3, jj, col);
+          view_pose_column(R2, Wb + POSE_L, t3, jj, col, stride);
         } else {
           double o[3], v3[3];
           mat3_vec(R3, Pb + POSE_T, v3);
           for (int i = 0; i < 3; ++i) o[i] = t3[i] + v3[i];
-          view_pose_column(R3, Pb + POSE_L, o, jj, col);
+          view_pose_column(R3, Pb + POSE_L, o, jj, col, stride);
         }
       }
     }
