@@ -176,6 +176,18 @@ int32_t mcba_jacobian(mcba_handle h, const double* x, int32_t* row_nnz, double* 
  * report, calibration.py:134-141,240-252,290-310).  Arrays are in the reference's [C,F,B,P] order.             */
 int32_t mcba_reprojection_error(mcba_handle h, const double* x, double* err, uint8_t* valid);
 
+/* Errors reduced ON THE DEVICE (no [C,F,B,P] array crosses PCIe): n = number of masked points, sum_sq = sum of squared
+ * errors, values[i] = exact order statistic of (0-based, ascending) rank ranks[i] -- what error_stats / numpy.quantile
+ * need (calibration.py:37-40,304-310).  inliers_only = 0: mask of Calibration.reprojection_error; 1: of
+ * reprojection_inliers (calibration.py:138-141).  Sharded handles combine over all ranks.                         */
+int32_t mcba_error_stats(mcba_handle h, const double* x, int32_t inliers_only, int32_t n_ranks, const int64_t* ranks,
+                         double* values, int64_t* n, double* sum_sq);
+/* Calibration.reject_outliers on the device (calibration.py:240-252): inliers = (err < threshold) & valid at x;
+ * replaces the handle's inlier table.  n_inliers / n_valid (over all ranks) may be NULL.                            */
+int32_t mcba_reject_outliers(mcba_handle h, const double* x, double threshold, int64_t* n_inliers, int64_t* n_valid);
+/* current inlier table in the reference's [C,F,B,P] order                                                         */
+int32_t mcba_get_inliers(mcba_handle h, uint8_t* mask);
+
 /* Projected points [C,F,B,P,2] of Calibration.reprojected (calibration.py:124-130).                            */
 int32_t mcba_project(mcba_handle h, const double* x, double* projected);
 

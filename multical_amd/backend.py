@@ -254,6 +254,50 @@ class Handle(object):
                                       _ptr(si, C.c_double)))
     return gn, gh, si
 
+  # --- outlier loop on the device ---------------------------------------------------------------------------------
+  def error_stats(self, x, quantiles=(0, 0.25, 0.5, 0.75, 1), inliers_only=False):
+    """error_stats(Calibration.reprojection_error) of the reference (calibration.py:304-310) computed on the device:
+    returns (mse, rms, quantiles, n).  Quantiles follow numpy's default 'linear' method exactly: virtual index
+    (n-1) q, floor / ceil order statistics from the device radix select, numpy's _lerp on the host."""
+    x = self._x(x)
+    q = np.atleast_1d(np.asarray(quantiles, dtype=np.float64))
+    n = C.c_int64()
+    ssq = C.c_double()
+    # first call: n only (ranks depend on n)
+    check(self.lib.mcba_error_stats(self.h, _ptr(x, C.c_double), int(inliers_only), 0, None, None, C.byref(n),
+                                    C.byref(ssq)))
+    nv = n.value
+    if nv == 0:   # the reference substitutes a single zero (calibration.py:306-307)
+      return 0.0, 0.0, np.zeros(q.shape), 1
+    virt = (nv - 1) * q
+    lo = np.floor(virt).astype(np.int64)
+    hi = np.minimum(lo + 1, nv - 1)
+    lo = np.clip(lo, 0, nv - 1)
+    gamma = virt - np.floor(virt)
+    ranks = np.ascontiguousarray(np.stack([lo, hi], axis=1).ravel())
+    vals = np.empty(ranks.size)
+    check(self.lib.mcba_error_stats(self.h, _ptr(x, C.c_double), int(inliers_only), int(ranks.size),
+                                    ranks.ctypes.data_as(C.POINTER(C.c_int64)), _ptr(vals, C.c_double), C.byref(n),
+                                    C.byref(ssq)))
+    a, b = vals[0::2], vals[1::2]
+    diff = b - a
+    out = a + diff * gamma                                   # numpy.lib._function_base_impl._lerp
+    out = np.where(gamma >= 0.5, b - diff * (1 - gamma), out)
+    mse = ssq.value / nv
+    return mse, float(np.sqrt(mse)), out, nv
+
+  def reject_outliers(self, x, threshold):
+    """inliers = (err < threshold) & valid on the device; returns (n_inliers, n_valid)."""
+    x = self._x(x)
+    ni, nvv = C.c_int64(), C.c_int64()
+    check(self.lib.mcba_reject_outliers(self.h, _ptr(x, C.c_double), float(threshold), C.byref(ni), C.byref(nvv)))
+    return ni.value, nvv.value
+
+  def get_inliers(self):
+    m = np.zeros(self.shape, dtype=np.uint8)
+    check(self.lib.mcba_get_inliers(self.h, _ptr(m, C.c_uint8)))
+    return m.astype(bool)
+
   def linearize_profile(self, x):
     x = self._x(x)
     C_, F, B, P = self.shape

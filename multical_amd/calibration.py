@@ -32,9 +32,11 @@ default_optimize = struct(cameras=False, boards=False, camera_poses=True, board_
 
 
 def select_threshold(quantile=0.75, factor=5.0):
-  """calibration.py:37-40."""
+  """calibration.py:37-40.  The returned callable still works on an error array like the reference's; it is tagged with
+  its parameters so that adjust_outliers can evaluate the quantile on the device without downloading the errors."""
   def f(reprojection_error):
     return np.quantile(reprojection_error, quantile) * factor
+  f.quantile, f.factor = quantile, factor
   return f
 
 
@@ -86,6 +88,13 @@ class _HandleCache(object):
         out.append(x_full[pos:pos + n])
       pos += n
     return np.concatenate(out) if out else np.zeros(0)
+
+  def note_inliers(self, handle, mask):
+    """the device already holds `mask` (set by reject_outliers): remember its token so it is not uploaded again."""
+    tok = hash(np.asarray(mask).tobytes())
+    for i, (k, xf, h, _) in enumerate(self.entries):
+      if h is handle:
+        self.entries[i] = (k, xf, h, tok)
 
   def clear(self):
     for _, _, h, _ in self.entries:
@@ -237,31 +246,48 @@ class Calibration(parameters.Parameters):
     threshold = np.quantile(self.reprojection_error, quantile)
     return self.reject_outliers(threshold=threshold * factor)
 
+  def _select(self, selector):
+    """selector(self.reprojection_error); tagged select_threshold closures are evaluated on the device
+    (exact numpy 'linear' quantile from radix-selected order statistics), anything else gets the error array."""
+    if hasattr(selector, "quantile") and hasattr(selector, "factor"):
+      _, _, q, _ = self._handle().error_stats(self.param_vec, quantiles=[selector.quantile])
+      return float(q[0]) * selector.factor
+    return selector(self.reprojection_error)
+
   def reject_outliers(self, threshold):
-    errors, valid = self._errors()
-    inliers = (errors < threshold) & valid
-    num_outliers = valid.sum() - inliers.sum()
-    inlier_percent = 100.0 * inliers.sum() / max(valid.sum(), 1)
+    """calibration.py:240-252, evaluated on the device; only the new mask (uint8) comes back."""
+    h = self._handle()
+    n_in, n_valid = h.reject_outliers(self.param_vec, threshold)
+    inliers = h.get_inliers()
+    num_outliers = n_valid - n_in
+    inlier_percent = 100.0 * n_in / max(n_valid, 1)
     info(f"Rejecting {num_outliers} outliers with error > {threshold:.2f} pixels, "
-         f"keeping {inliers.sum()} / {valid.sum()} inliers, ({inlier_percent:.2f}%)")
-    return self.copy(inlier_mask=inliers)
+         f"keeping {n_in} / {n_valid} inliers, ({inlier_percent:.2f}%)")
+    out = self.copy(inlier_mask=inliers)
+    handle_cache.note_inliers(h, inliers)
+    return out
 
   def adjust_outliers(self, num_adjustments=3, select_scale=None, select_outliers=None, **kwargs):
     info(f"Beginning adjustments ({num_adjustments}) enabled: {dict(self.optimize)}, options: {kwargs}")
     for i in range(num_adjustments):
       self.report(f"Adjust_outliers {i}:")
-      f_scale = (None if select_scale is None else select_scale(self.reprojection_error)) or 1.0
+      f_scale = (None if select_scale is None else self._select(select_scale)) or 1.0
       if select_scale is not None:
         info(f"Auto scaling for outliers influence at {f_scale:.2f} pixels")
       if select_outliers is not None:
-        self = self.reject_outliers(select_outliers(self.reprojection_error))
+        self = self.reject_outliers(self._select(select_outliers))
       self = self.bundle_adjust(f_scale=f_scale, **kwargs)
     self.report("Adjust_outliers end:")
     return self
 
+  def error_statistics(self, inliers_only=False):
+    """error_stats(self.reprojection_error / reprojection_inliers) without downloading the error table."""
+    mse, rms, q, n = self._handle().error_stats(self.param_vec, inliers_only=inliers_only)
+    return struct(mse=mse, rms=rms, quantiles=q, n=n)
+
   def report(self, stage=""):
-    overall = error_stats(self.reprojection_error)
-    inliers = error_stats(self.reprojection_inliers)
+    overall = self.error_statistics(False)
+    inliers = self.error_statistics(True)
     if self.inlier_mask is not None:
       info(f"{stage} reprojection RMS={inliers.rms:.3f} ({overall.rms:.3f}), "
            f"n={inliers.n} ({overall.n}), quantiles={overall.quantiles}")

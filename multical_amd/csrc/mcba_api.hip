@@ -102,6 +102,10 @@ struct mcba_handle_s {
   DevBuf<double> xfull, bwg, img_h, board_points, pose, cam, view;
   DevBuf<uint16_t> tri;
   DevBuf<long long> dbg;
+  DevBuf<double> err_fm, sel_f64;
+  DevBuf<unsigned int> sel_hist;
+  DevBuf<unsigned long long> sel_state;   // SelState (2 words) + k_sel_next output (2 words)
+  bool obs_index_dirty = false;
 
   // linearisation
   DevBuf<double> rec, partial, Hss, Hfs, Hff, gbuf;   // gbuf = [g (n) | diag (n) | cost, count]
@@ -392,6 +396,83 @@ int check_termination(double dF, double F, double dx_norm, double x_norm, double
   return -100;   // None
 }
 
+
+// ---- device outlier loop -------------------------------------------------------------------------------------------
+void ensure_obs_index(mcba_handle_s* h) {
+  if (!h->obs_index_dirty) return;
+  // rebuild the residual ordering on the host from the device inlier table (needed by residuals / jacobian only)
+  const Dims& d = h->d;
+  const size_t nref = (size_t)d.C * d.F * d.B * d.P;
+  h->out_valid.alloc(nref, true);
+  hipLaunchKernelGGL(k_inliers_to_ref, dim3(std::max(1, std::min(4096, (d.slots() + 255) / 256))), dim3(256), 0, h->stream, d,
+                     h->inlier.p, h->out_valid.p);
+  std::vector<uint8_t> mask(nref);
+  HIP_OK(hipMemcpyAsync(mask.data(), h->out_valid.p, nref, hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  build_inliers(h, mask.data());
+  h->obs_index_dirty = false;
+}
+
+void compute_errors(mcba_handle_s* h, const double* x) {
+  const Dims& d = h->d;
+  if (h->err_fm.n < (size_t)std::max(d.slots(), 1)) h->err_fm.alloc((size_t)std::max(d.slots(), 1));
+  if (!h->sel_hist.p) {
+    h->sel_hist.alloc(2048);
+    h->sel_state.alloc(8);
+    h->sel_f64.alloc(2048);
+  }
+  upload_x(h, x, h->x.p);
+  eval_tables(h, h->x.p);
+  h->ops->residual(d, h->t, h->stream, nullptr, nullptr, h->err_fm.p, nullptr);   // frame-major errors
+}
+
+int sel_grid(const Dims& d) { return std::max(1, std::min(1024, (d.slots() + 255) / 256)); }
+
+void reduce_hist(mcba_handle_s* h) {
+  if (!h->allreduce) return;
+  hipLaunchKernelGGL(k_u32_to_f64, dim3(8), dim3(256), 0, h->stream, h->sel_hist.p, h->sel_f64.p, 2048);
+  call_allreduce(h, h->sel_f64.p, 2048, 0);
+  hipLaunchKernelGGL(k_f64_to_u32, dim3(8), dim3(256), 0, h->stream, h->sel_f64.p, h->sel_hist.p, 2048);
+}
+
+// exact k-th smallest (0-based, over all ranks of a sharded problem) of the masked errors; also the (k+1)-th
+void select_rank(mcba_handle_s* h, const uint8_t* m2, long long rank, double* v_k, double* v_k1) {
+  const Dims& d = h->d;
+  SelState* st = reinterpret_cast<SelState*>(h->sel_state.p);
+  const int n = d.slots(), grid = sel_grid(d);
+  hipLaunchKernelGGL(k_sel_init, dim3(1), dim3(256), 0, h->stream, st, rank, h->sel_hist.p);
+  const int shifts[6] = {53, 42, 31, 20, 9, 0};
+  const int bits[6] = {11, 11, 11, 11, 11, 9};
+  for (int p = 0; p < 6; ++p) {
+    hipLaunchKernelGGL(k_sel_hist, dim3(grid), dim3(256), 0, h->stream, h->err_fm.p, h->evalid.p, m2, n, st, shifts[p], bits[p],
+                       p == 0 ? 1 : 0, h->sel_hist.p);
+    reduce_hist(h);
+    hipLaunchKernelGGL(k_sel_pick, dim3(1), dim3(256), 0, h->stream, st, h->sel_hist.p, shifts[p], bits[p]);
+  }
+  unsigned long long init[2] = {0ull, 0x7FF0000000000000ull};
+  HIP_OK(hipMemcpyAsync(h->sel_state.p + 2, init, sizeof(init), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_sel_next, dim3(grid), dim3(256), 0, h->stream, h->err_fm.p, h->evalid.p, m2, n, st, h->sel_state.p + 2);
+  unsigned long long host[4];
+  HIP_OK(hipMemcpyAsync(host, h->sel_state.p, sizeof(host), hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  double vk, next;
+  memcpy(&vk, &host[0], 8);
+  memcpy(&next, &host[3], 8);
+  double cnt_le = (double)host[2];
+  if (h->allreduce) {   // combine (count, min) across ranks: sum and -max(-x)
+    double buf[2] = {cnt_le, -next};
+    HIP_OK(hipMemcpyAsync(h->sel_f64.p, buf, sizeof(buf), hipMemcpyHostToDevice, h->stream));
+    call_allreduce(h, h->sel_f64.p, 1, 0);
+    call_allreduce(h, h->sel_f64.p + 1, 1, 1);
+    HIP_OK(hipMemcpyAsync(buf, h->sel_f64.p, sizeof(buf), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    cnt_le = buf[0];
+    next = -buf[1];
+  }
+  *v_k = vk;
+  *v_k1 = (cnt_le > (double)(rank + 1)) ? vk : next;
+}
+
 double now_seconds() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -551,6 +632,7 @@ int32_t mcba_set_inliers(mcba_handle h, const uint8_t* mask) {
   REQUIRE(h, "null handle");
   sync(h);
   build_inliers(h, mask);
+  h->obs_index_dirty = false;
   API_END
 }
 
@@ -588,6 +670,7 @@ int32_t mcba_set_mfma(mcba_handle h, int32_t on) {
 int32_t mcba_residuals(mcba_handle h, const double* x, double* r) {
   API_BEGIN
   REQUIRE(h && x && r, "null argument");
+  ensure_obs_index(h);
   upload_x(h, x, h->x.p);
   eval_tables(h, h->x.p);
   h->ops->residual(h->d, h->t, h->stream, h->out_r.p, nullptr, nullptr, nullptr);
@@ -608,6 +691,7 @@ int32_t mcba_jacobian(mcba_handle h, const double* x, int32_t* row_nnz, double* 
   *row_nnz = nnz;
   if (!vals && !cols) return 0;
   REQUIRE(x && vals && cols, "null argument");
+  ensure_obs_index(h);
   const size_t nv = 2 * (size_t)h->n_inliers * nnz, nc = (size_t)h->n_inliers * nnz;
   h->out_big.alloc(std::max<size_t>(nv, 1), false);
   h->out_cols.alloc(std::max<size_t>(nc, 1), false);
@@ -879,6 +963,92 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
     result->solve_seconds = now_seconds() - t_start;
     result->linearize_seconds = lin_ms_total * 1e-3;
   }
+  API_END
+}
+
+
+/* errors of Calibration.reprojection_error (inliers_only = 0) / reprojection_inliers (1) reduced ON THE DEVICE:
+ * n = number of masked points, sum_sq = sum of squared errors, values[i] = exact order statistic of rank ranks[i]
+ * (0-based, ascending) found by radix select -- the inputs numpy.quantile needs (calibration.py:37-40,304-310).       */
+int32_t mcba_error_stats(mcba_handle h, const double* x, int32_t inliers_only, int32_t n_ranks, const int64_t* ranks,
+                         double* values, int64_t* n_out, double* sum_sq) {
+  API_BEGIN
+  REQUIRE(h && x && n_out && sum_sq, "null argument");
+  REQUIRE(n_ranks == 0 || (ranks && values), "null argument");
+  const Dims& d = h->d;
+  compute_errors(h, x);
+  const uint8_t* m2 = inliers_only ? h->inlier.p : nullptr;
+  const int grid = sel_grid(d);
+  if (h->costpart.n < (size_t)2 * grid) h->costpart.alloc((size_t)2 * std::max(grid, COST_BLOCKS_MAX));
+  hipLaunchKernelGGL(k_err_sums, dim3(grid), dim3(256), 0, h->stream, h->err_fm.p, h->evalid.p, m2, d.slots(), h->costpart.p);
+  hipLaunchKernelGGL(k_sum2, dim3(1), dim3(256), 0, h->stream, h->costpart.p, grid, h->scal.p);
+  call_allreduce(h, h->scal.p, 2, 0);
+  fetch_scalars(h, 2);
+  *sum_sq = h->h_scal[0];
+  const int64_t n = (int64_t)h->h_scal[1];
+  *n_out = n;
+  for (int i = 0; i < n_ranks; i += 2) {
+    // consecutive ranks (floor / ceil of a virtual index) share one selection
+    REQUIRE(n > 0 && ranks[i] >= 0 && ranks[i] < n, "order-statistic rank out of range");
+    double vk, vk1;
+    select_rank(h, m2, ranks[i], &vk, &vk1);
+    values[i] = vk;
+    if (i + 1 < n_ranks) {
+      REQUIRE(ranks[i + 1] >= 0 && ranks[i + 1] < n, "order-statistic rank out of range");
+      if (ranks[i + 1] == ranks[i]) values[i + 1] = vk;
+      else if (ranks[i + 1] == ranks[i] + 1) values[i + 1] = vk1;
+      else { double a, b; select_rank(h, m2, ranks[i + 1], &a, &b); values[i + 1] = a; }
+    }
+  }
+  API_END
+}
+
+/* Calibration.reject_outliers on the device (calibration.py:240-252): inliers = (err < threshold) & valid, evaluated
+ * at x; the handle's inlier table, per-view counts (and, lazily, the residual ordering) are replaced.               */
+int32_t mcba_reject_outliers(mcba_handle h, const double* x, double threshold, int64_t* n_inliers, int64_t* n_valid) {
+  API_BEGIN
+  REQUIRE(h && x, "null argument");
+  const Dims& d = h->d;
+  compute_errors(h, x);
+  if (d.views() > 0)
+    hipLaunchKernelGGL(k_reject, dim3(d.views()), dim3(64), 0, h->stream, d, h->err_fm.p, h->evalid.p, threshold, h->inlier.p,
+                       h->view_count.p);
+  const int grid = sel_grid(d);
+  if (h->costpart.n < (size_t)2 * grid) h->costpart.alloc((size_t)2 * std::max(grid, COST_BLOCKS_MAX));
+  hipLaunchKernelGGL(k_err_sums, dim3(grid), dim3(256), 0, h->stream, h->err_fm.p, h->evalid.p, h->inlier.p, d.slots(),
+                     h->costpart.p);
+  hipLaunchKernelGGL(k_sum2, dim3(1), dim3(256), 0, h->stream, h->costpart.p, grid, h->scal.p);
+  hipLaunchKernelGGL(k_err_sums, dim3(grid), dim3(256), 0, h->stream, h->err_fm.p, h->evalid.p, (const uint8_t*)nullptr,
+                     d.slots(), h->costpart.p);
+  hipLaunchKernelGGL(k_sum2, dim3(1), dim3(256), 0, h->stream, h->costpart.p, grid, h->scal.p + 2);
+  fetch_scalars(h, 4);
+  h->n_inliers = (int64_t)h->h_scal[1];      // this shard's inliers
+  h->obs_index_dirty = true;
+  h->out_r.alloc((size_t)std::max<int64_t>(2 * h->n_inliers, 1), false);
+  double tot[2] = {h->h_scal[1], h->h_scal[3]};
+  if (h->allreduce) {
+    HIP_OK(hipMemcpyAsync(h->scal.p, tot, sizeof(tot), hipMemcpyHostToDevice, h->stream));
+    call_allreduce(h, h->scal.p, 2, 0);
+    fetch_scalars(h, 2);
+    tot[0] = h->h_scal[0];
+    tot[1] = h->h_scal[1];
+  }
+  if (n_inliers) *n_inliers = (int64_t)tot[0];
+  if (n_valid) *n_valid = (int64_t)tot[1];
+  API_END
+}
+
+/* current inlier table in the reference's [C,F,B,P] order (frames of other shards are zero)                          */
+int32_t mcba_get_inliers(mcba_handle h, uint8_t* mask) {
+  API_BEGIN
+  REQUIRE(h && mask, "null argument");
+  const Dims& d = h->d;
+  const size_t nref = (size_t)d.C * d.F * d.B * d.P;
+  h->out_valid.alloc(nref, true);
+  hipLaunchKernelGGL(k_inliers_to_ref, dim3(std::max(1, std::min(4096, (d.slots() + 255) / 256))), dim3(256), 0, h->stream, d,
+                     h->inlier.p, h->out_valid.p);
+  HIP_OK(hipMemcpyAsync(mask, h->out_valid.p, nref, hipMemcpyDeviceToHost, h->stream));
+  sync(h);
   API_END
 }
 

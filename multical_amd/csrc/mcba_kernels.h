@@ -92,8 +92,13 @@ __global__ void k_residual(Dims d, Tables t, double* __restrict__ r, double* __r
     }
     if (err != nullptr) {
       const bool ok = t.evalid[s] != 0;
-      err[ri] = ok ? sqrt(ex * ex + ey * ey) : 0.0;
-      valid[ri] = ok ? 1 : 0;
+      const double e = ok ? sqrt(ex * ex + ey * ey) : 0.0;
+      if (valid != nullptr) {          // reference [C,F,B,P] order (host-facing)
+        err[ri] = e;
+        valid[ri] = ok ? 1 : 0;
+      } else {                         // frame-major, device-internal (outlier loop)
+        err[s] = e;
+      }
     }
   }
 }

@@ -610,6 +610,136 @@ __global__ void k_vec_step(Dims d, const double* __restrict__ x, const double* _
   if (threadIdx.x == 0) { out[0] = a; out[1] = b; out[2] = c; }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// outlier loop on the device (Calibration.reject_outliers / report, calibration.py:240-252,290-310):
+// exact order statistics of the per-point reprojection errors by radix select (6 passes over 11/9-bit digits of the
+// IEEE bit pattern -- errors are >= 0, so the unsigned bit pattern is monotone), error sums, threshold + mask update.
+// Integer atomics only: results are deterministic.  mask2 may be null (mask = evalid) or the inlier table.
+// ---------------------------------------------------------------------------------------------------------------
+struct SelState {
+  unsigned long long prefix;   // bits fixed so far (high bits), rest zero
+  long long rank;              // remaining rank inside the current prefix bucket
+};
+
+__global__ void k_sel_init(SelState* st, long long rank, unsigned int* hist) {
+  if (threadIdx.x == 0) { st->prefix = 0ull; st->rank = rank; }
+  for (int i = threadIdx.x; i < 2048; i += blockDim.x) hist[i] = 0u;
+}
+
+__global__ void k_sel_hist(const double* __restrict__ err, const uint8_t* __restrict__ m1, const uint8_t* __restrict__ m2,
+                           int n, const SelState* __restrict__ st, int shift, int bits, int first,
+                           unsigned int* __restrict__ hist) {
+  __shared__ unsigned int lh[2048];
+  for (int i = threadIdx.x; i < 2048; i += blockDim.x) lh[i] = 0u;
+  __syncthreads();
+  const unsigned long long prefix = st->prefix;
+  const unsigned int mask = (1u << bits) - 1u;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    if (!m1[i] || (m2 != nullptr && !m2[i])) continue;
+    const unsigned long long key = (unsigned long long)__double_as_longlong(err[i]);
+    if (!first && (key >> (shift + bits)) != (prefix >> (shift + bits))) continue;
+    atomicAdd(&lh[(unsigned int)(key >> shift) & mask], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2048; i += blockDim.x)
+    if (lh[i]) atomicAdd(&hist[i], lh[i]);
+}
+
+__global__ void k_sel_pick(SelState* st, unsigned int* hist, int shift, int bits) {
+  if (threadIdx.x == 0) {
+    long long rank = st->rank;
+    const int nb = 1 << bits;
+    int b = 0;
+    for (; b < nb - 1; ++b) {
+      const long long c = hist[b];
+      if (rank < c) break;
+      rank -= c;
+    }
+    st->prefix |= ((unsigned long long)b) << shift;
+    st->rank = rank;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2048; i += blockDim.x) hist[i] = 0u;
+}
+
+// out[0] = #elements <= v, out[1] = bit pattern of the smallest element > v (all ones if none)
+__global__ void k_sel_next(const double* __restrict__ err, const uint8_t* __restrict__ m1, const uint8_t* __restrict__ m2,
+                           int n, const SelState* __restrict__ st, unsigned long long* __restrict__ out) {
+  const unsigned long long v = st->prefix;
+  unsigned long long cnt = 0, mn = 0x7FF0000000000000ull;   // +inf
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    if (!m1[i] || (m2 != nullptr && !m2[i])) continue;
+    const unsigned long long key = (unsigned long long)__double_as_longlong(err[i]);
+    if (key <= v) ++cnt;
+    else if (key < mn) mn = key;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    cnt += __shfl_down(cnt, off, 64);
+    const unsigned long long o = __shfl_down(mn, off, 64);
+    mn = o < mn ? o : mn;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&out[0], cnt);
+    atomicMin(&out[1], mn);
+  }
+}
+
+__global__ void k_u32_to_f64(const unsigned int* __restrict__ in, double* __restrict__ out, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = (double)in[i];
+}
+__global__ void k_f64_to_u32(const double* __restrict__ in, unsigned int* __restrict__ out, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = (unsigned int)in[i];
+}
+
+// partial[blk*2 + {0,1}] = {sum err^2, count} over the mask
+__global__ void k_err_sums(const double* __restrict__ err, const uint8_t* __restrict__ m1, const uint8_t* __restrict__ m2,
+                           int n, double* __restrict__ partial) {
+  __shared__ double scratch[16];
+  double sq = 0.0, cnt = 0.0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    if (!m1[i] || (m2 != nullptr && !m2[i])) continue;
+    sq += err[i] * err[i];
+    cnt += 1.0;
+  }
+  const double a = block_reduce<false>(sq, scratch);
+  const double b = block_reduce<false>(cnt, scratch);
+  if (threadIdx.x == 0) { partial[2 * blockIdx.x] = a; partial[2 * blockIdx.x + 1] = b; }
+}
+__global__ void k_sum2(const double* __restrict__ partial, int nblk, double* __restrict__ out) {
+  __shared__ double scratch[16];
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += blockDim.x) { a += partial[2 * i]; b += partial[2 * i + 1]; }
+  const double ra = block_reduce<false>(a, scratch);
+  const double rb = block_reduce<false>(b, scratch);
+  if (threadIdx.x == 0) { out[0] = ra; out[1] = rb; }
+}
+
+// inliers = (err < threshold) & valid  (calibration.py:243-244); one block per view also refreshes view_count
+__global__ void k_reject(Dims d, const double* __restrict__ err, const uint8_t* __restrict__ evalid, double threshold,
+                         uint8_t* __restrict__ inlier, int32_t* __restrict__ view_count) {
+  __shared__ double scratch[16];
+  const int v = blockIdx.x;
+  double cnt = 0.0;
+  for (int p = threadIdx.x; p < d.P; p += blockDim.x) {
+    const size_t s = (size_t)v * d.P + p;
+    const bool in = evalid[s] && err[s] < threshold;
+    inlier[s] = in ? 1 : 0;
+    cnt += in ? 1.0 : 0.0;
+  }
+  const double tot = block_reduce<false>(cnt, scratch);
+  if (threadIdx.x == 0) view_count[v] = (int32_t)tot;
+}
+
+// frame-major inlier table -> reference [C,F,B,P] order (only this shard's frames are written)
+__global__ void k_inliers_to_ref(Dims d, const uint8_t* __restrict__ inlier, uint8_t* __restrict__ out) {
+  const int n = d.slots();
+  for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
+    const int p = s % d.P, v = s / d.P;
+    const int b = v % d.B, c = (v / d.B) % d.C, fl = v / (d.B * d.C), f = d.f0 + fl;
+    out[(((size_t)c * d.F + f) * d.B + b) * d.P + p] = inlier[s];
+  }
+}
+
 // MFMA layout self-test: D = A^T-style product with an asymmetric operand pair, checked on the host
 __global__ void k_mfma_probe(const double* __restrict__ V /*[4][32]*/, double* __restrict__ out /*[16][16]*/) {
   const int lane = threadIdx.x, rsub = lane >> 4, csub = lane & 15;

@@ -240,3 +240,34 @@ def test_empty_inlier_set_and_ragged_boards():
   g2, rig2 = load_golden("tiny_rolling")     # charuco_10x10 (81 pts) + aprilgrid (324 pts): ragged boards
   with Handle(mirror(rig2)) as h:
     assert np.abs(h.residuals(g2["x0"]) - g2["r0"]).max() < 1e-9
+
+
+@pytest.mark.parametrize("name", ["tiny_rolling", "tiny_edge", "cfg1"])
+def test_device_outlier_statistics_match_numpy(name):
+  """mcba_error_stats / mcba_reject_outliers (radix select on the device) == numpy on the downloaded error table:
+  quantiles bit-for-bit (numpy 'linear' method), RMS to 1e-12 relative, identical inlier masks and residual order."""
+  g, rig = load_golden(name)
+  c = mirror(rig)
+  x = g["ba_x_raw"]
+  with Handle(c) as h:
+    err, valid = h.reprojection_error(x)
+    e = err[valid]
+    qs = [0, 0.25, 0.5, 0.75, 1, 0.95, 0.123]
+    mse, rms, q, n = h.error_stats(x, quantiles=qs)
+    assert n == e.size
+    assert np.array_equal(q, np.array([np.quantile(e, v) for v in qs]))
+    assert mse == pytest.approx(np.square(e).mean(), rel=1e-12)
+    thr = np.quantile(e, 0.75) * 5.0
+    n_in, n_valid = h.reject_outliers(x, thr)
+    mask = h.get_inliers()
+    assert np.array_equal(mask, (err < thr) & valid)
+    assert (n_in, n_valid) == (int(mask.sum()), int(valid.sum()))
+    # inlier statistics and the residual ordering after a device-side rejection
+    _, rms_i, q_i, n_i = h.error_stats(x, inliers_only=True)
+    assert n_i == n_in and np.array_equal(q_i, np.array([np.quantile(err[mask], v) for v in [0, .25, .5, .75, 1]]))
+    oc = oracle(rig).copy(inlier_mask=mask)
+    assert np.abs(h.residuals(x) - oc.evaluate(x)).max() < 1e-9
+    # the fused pass honours the new mask
+    cost, _, _ = h.normal_equations(x)
+    r = oc.evaluate(x)
+    assert cost == pytest.approx(0.5 * r @ r, rel=1e-12)
