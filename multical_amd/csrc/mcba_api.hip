@@ -224,6 +224,8 @@ void launch_assemble(mcba_handle_s* h) {
   hipLaunchKernelGGL(k_shared_zero_g, dim3((d.ns + 255) / 256), dim3(256), 0, h->stream, d, h->g());
   hipLaunchKernelGGL(k_shared_final, dim3((d.rec_size + 2 + 63) / 64), dim3(64), 0, h->stream, d, h->partial.p, h->nchunk,
                      h->tri.p, h->Hss.p, h->g(), h->costcount());
+  if (d.off_boards >= 0)   // adjusted board points: their blocks of H_ss / H_fs / g (unique entries, plain stores)
+    h->ops->points(d, h->t, h->stream, (d.n - d.off_boards) / 3, h->Hss.p, h->Hfs.p, h->g());
   hipLaunchKernelGGL(k_shared_diag, dim3((d.ns + 255) / 256), dim3(256), 0, h->stream, d, h->Hss.p, h->diag());
   call_allreduce(h, h->gbuf.p, 2 * (size_t)d.n + 2, 0);
 }
@@ -688,6 +690,7 @@ int32_t mcba_jacobian(mcba_handle h, const double* x, int32_t* row_nnz, double* 
   if (d.off_boardpose >= 0) nnz += 6;
   if (d.off_motion >= 0) nnz += d.motion == MOTION_STATIC ? 6 : 12;
   if (d.off_cameras >= 0) nnz += 5 + d.ND;
+  if (d.off_boards >= 0) nnz += 3;
   *row_nnz = nnz;
   if (!vals && !cols) return 0;
   REQUIRE(x && vals && cols, "null argument");

@@ -57,7 +57,22 @@ void linearize(const Dims& d, const Tables& t, hipStream_t s, double* rec, const
   else lin1<MOTION_HAND_EYE>(d, t, s, rec, tri, mfma);
 }
 
-const CamOps OPS = {residual, cost, jacobian, linearize};
+template <int MOTION>
+void pts1(const Dims& d, const Tables& t, hipStream_t s, int nq, double* Hss, double* Hfs, double* g) {
+  if (d.KI > 0)
+    hipLaunchKernelGGL((k_points<ND_, FISH_, MOTION, true>), dim3(nq), dim3(256), 0, s, d, t, Hss, Hfs, g);
+  else
+    hipLaunchKernelGGL((k_points<ND_, FISH_, MOTION, false>), dim3(nq), dim3(256), 0, s, d, t, Hss, Hfs, g);
+}
+
+void points(const Dims& d, const Tables& t, hipStream_t s, int nq, double* Hss, double* Hfs, double* g) {
+  if (nq <= 0) return;
+  if (d.motion == MOTION_STATIC) pts1<MOTION_STATIC>(d, t, s, nq, Hss, Hfs, g);
+  else if (d.motion == MOTION_ROLLING) pts1<MOTION_ROLLING>(d, t, s, nq, Hss, Hfs, g);
+  else pts1<MOTION_HAND_EYE>(d, t, s, nq, Hss, Hfs, g);
+}
+
+const CamOps OPS = {residual, cost, jacobian, linearize, points};
 
 }  // namespace
 

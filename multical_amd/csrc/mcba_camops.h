@@ -14,6 +14,7 @@ struct CamOps {
   void (*cost)(const Dims&, const Tables&, hipStream_t, double* partial, int nblk);
   void (*jacobian)(const Dims&, const Tables&, hipStream_t, int row_nnz, double* vals, int32_t* cols);
   void (*linearize)(const Dims&, const Tables&, hipStream_t, double* rec, const uint16_t* tri, bool mfma);
+  void (*points)(const Dims&, const Tables&, hipStream_t, int n_points, double* Hss, double* Hfs, double* g);
 };
 
 const CamOps* cam_ops_pin4();

@@ -141,8 +141,8 @@ __global__ void k_jacobian(Dims d, Tables t, int row_nnz, double* __restrict__ v
     const int b = v % d.B, c = (v / d.B) % d.C, fl = v / (d.B * d.C), f = d.f0 + fl;
     Dims dl = d;
     dl.loss = 0;   // the Jacobian of evaluate() itself: no robust scaling
-    double vr[2 * NV];
-    point_rows<ND, FISH, ROLL, true>(dl, t, v, c, b, p, t.obs[s], vr);
+    double vr[2 * NV], jp[6];
+    point_rows<ND, FISH, ROLL, true>(dl, t, v, c, b, p, t.obs[s], vr, jp);
     double* o0 = vals + (size_t)(2 * idx) * row_nnz;
     double* o1 = o0 + row_nnz;
     int32_t* oc = cols + (size_t)idx * row_nnz;
@@ -175,6 +175,141 @@ __global__ void k_jacobian(Dims d, Tables t, int row_nnz, double* __restrict__ v
         o1[pos] = skew ? 0.0 : vr[NV + DE + lq];
         oc[pos] = base + q;
         ++pos;
+      }
+    }
+    if (d.off_boards >= 0) {   // adjusted board points (board/charuco.py:112-117): last block of x
+      const int base = d.off_boards + 3 * (t.board_off[b] + p);
+      for (int k = 0; k < 3; ++k) {
+        o0[pos] = jp[k];
+        o1[pos] = jp[3 + k];
+        oc[pos] = base + k;
+        ++pos;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_points: normal-equation blocks of the adjusted board points (optimize.boards, `adjust_board`).
+//   Board point q = (b, p) carries 3 shared parameters; its Jacobian per observation is jp = A R_view (2 x 3).  The
+//   blocks  H[q, q] (3x3),  H[q, camera c | intrinsics c] (sum over frames),  H[q, board b] / H[q, hand-eye] (sum over
+//   all views),  H[q, frame f] (sum over cameras -> H_fs columns)  and g[q] are gathered by ONE WORKGROUP PER POINT:
+//   threads own frames, cameras are walked in an outer loop, so every output element is produced by a fixed thread /
+//   a fixed reduction order (no atomics).  The local Jacobian columns come from the same view_column / point_rows
+//   functions as k_jacobian.  The remaining blocks come from k_linearize.
+// ---------------------------------------------------------------------------------------------------------------
+template <int ND, bool FISH, int MOTION, bool OPTK>
+__global__ __launch_bounds__(256) void k_points(Dims d, Tables t, double* __restrict__ Hss, double* __restrict__ Hfs,
+                                                double* __restrict__ g) {
+  constexpr bool ROLL = MOTION == MOTION_ROLLING;
+  constexpr int DE = ROLL ? 12 : 6, NPB = MOTION == MOTION_STATIC ? 3 : 4, KI = OPTK ? 4 + ND : 0;
+  constexpr int NV = DE + KI + 1, NPC = 6 * NPB, CW = 6 + KI;
+  constexpr int NMISC = 18 + 6 + 3 + (MOTION == MOTION_HAND_EYE ? 36 : 0);   // board | pt-pt | g | hand-eye
+  __shared__ double red[4][3 * CW > NMISC ? 3 * CW : NMISC];
+
+  const int q = blockIdx.x;                       // global point index over all boards
+  int b = 0;
+  while (q >= t.board_off[b + 1]) ++b;
+  const int p = q - t.board_off[b];
+  const int ns = d.ns, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int gq = d.off_boards + 3 * q;            // x index of the point's first coordinate
+  const int sq = d.x_to_shared(gq);
+
+  double misc[NMISC];
+  for (int i = 0; i < NMISC; ++i) misc[i] = 0.0;
+
+  for (int c = 0; c < d.C; ++c) {
+    double camacc[3 * CW];
+    for (int i = 0; i < 3 * CW; ++i) camacc[i] = 0.0;
+    for (int fl = threadIdx.x; fl < d.Fl; fl += blockDim.x) {
+      const int v = (fl * d.C + c) * d.B + b, f = d.f0 + fl;
+      const size_t s = (size_t)v * d.P + p;
+      if (!t.inlier[s]) continue;
+      double vr[2 * NV], jp[6];
+      point_rows<ND, FISH, ROLL, OPTK>(d, t, v, c, b, p, t.obs[s], vr, jp);
+      // pose columns of the local Jacobian, one at a time
+      for (int j = 0; j < NPC; ++j) {
+        const int k = j / 6, jj = j % 6;
+        const int gx = local_to_x(d, f, c, b, j);
+        if (gx < 0) continue;
+        double col[12];
+        view_column(d, t, f, c, b, j, col);
+        double a0 = 0.0, a1 = 0.0;
+        for (int a = 0; a < DE; ++a) {
+          a0 += vr[a] * col[a];
+          a1 += vr[NV + a] * col[a];
+        }
+        double h3[3];
+        for (int kk = 0; kk < 3; ++kk) h3[kk] = jp[kk] * a0 + jp[3 + kk] * a1;
+        if (k == 0) {
+          for (int kk = 0; kk < 3; ++kk) camacc[kk * CW + jj] += h3[kk];
+        } else if (k == NPB - 1) {
+          for (int kk = 0; kk < 3; ++kk) misc[kk * 6 + jj] += h3[kk];
+        } else if (local_is_frame(d, j)) {
+          const int dd = j - 6;
+          for (int kk = 0; kk < 3; ++kk) Hfs[((size_t)fl * d.DF + dd) * ns + sq + kk] += h3[kk];   // owned by this thread
+        } else if (MOTION == MOTION_HAND_EYE) {
+          for (int kk = 0; kk < 3; ++kk) misc[27 + kk * 12 + (j - 6)] += h3[kk];
+        }
+      }
+      if constexpr (OPTK) {
+        for (int qq = 0; qq < KI; ++qq)
+          for (int kk = 0; kk < 3; ++kk) camacc[kk * CW + 6 + qq] += jp[kk] * vr[DE + qq] + jp[3 + kk] * vr[NV + DE + qq];
+      }
+      // point x point (upper triangle) and gradient
+      int e = 18;
+      for (int k0 = 0; k0 < 3; ++k0)
+        for (int k1 = k0; k1 < 3; ++k1) misc[e++] += jp[k0] * jp[k1] + jp[3 + k0] * jp[3 + k1];
+      for (int kk = 0; kk < 3; ++kk) misc[24 + kk] += jp[kk] * vr[NV - 1] + jp[3 + kk] * vr[2 * NV - 1];
+    }
+    // reduce the camera block over the workgroup (fixed order: lanes by shuffle, then waves 0..3)
+    for (int i = 0; i < 3 * CW; ++i) {
+      const double w = wave_sum(camacc[i]);
+      if (lane == 0) red[wave][i] = w;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * CW; i += blockDim.x) {
+      const double val = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+      const int kk = i / CW, qq = i % CW;
+      const int li = qq < 6 ? qq : NPC + (qq - 6);
+      const int gx = local_to_x(d, 0, c, b, li);
+      if (gx >= 0) {
+        const int sx = d.x_to_shared(gx);
+        Hss[(size_t)(sq + kk) * ns + sx] = val;
+        Hss[(size_t)sx * ns + sq + kk] = val;
+      }
+    }
+    __syncthreads();
+  }
+  for (int i = 0; i < NMISC; ++i) {
+    const double w = wave_sum(misc[i]);
+    if (lane == 0) red[wave][i] = w;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NMISC; i += blockDim.x) {
+    const double val = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+    if (i < 18) {                                  // board pose block
+      const int kk = i / 6, jj = i % 6;
+      const int gx = local_to_x(d, 0, 0, b, 6 * (NPB - 1) + jj);
+      if (gx >= 0) {
+        const int sx = d.x_to_shared(gx);
+        Hss[(size_t)(sq + kk) * ns + sx] = val;
+        Hss[(size_t)sx * ns + sq + kk] = val;
+      }
+    } else if (i < 24) {                           // point x point
+      const int e = i - 18;
+      const int k0 = e < 3 ? 0 : (e < 5 ? 1 : 2), k1 = e < 3 ? e : (e < 5 ? e - 2 : 2);
+      Hss[(size_t)(sq + k0) * ns + sq + k1] = val;
+      Hss[(size_t)(sq + k1) * ns + sq + k0] = val;
+    } else if (i < 27) {
+      g[gq + (i - 24)] = val;
+    } else {                                       // hand-eye blocks (shared)
+      const int kk = (i - 27) / 12, jj = (i - 27) % 12;
+      const int gx = local_to_x(d, 0, 0, b, 6 + jj);
+      if (gx >= 0) {
+        const int sx = d.x_to_shared(gx);
+        Hss[(size_t)(sq + kk) * ns + sx] = val;
+        Hss[(size_t)sx * ns + sq + kk] = val;
       }
     }
   }

@@ -83,7 +83,6 @@ inline void lower_problem(const mcba_problem* p, HostProblem& hp) {
                "null array in mcba_problem");
   MCBA_REQUIRE(p->motion >= 0 && p->motion <= 2, "unknown motion model");
   MCBA_REQUIRE(p->motion != MCBA_MOTION_HAND_EYE || p->base_wrt_gripper, "hand-eye motion needs base_wrt_gripper");
-  MCBA_REQUIRE(!(p->optimize & MCBA_OPT_BOARDS), "adjust_board (optimize.boards) is not implemented in this build");
   MCBA_REQUIRE(p->optimize != 0, "no parameter block enabled");
   MCBA_REQUIRE(p->n_points <= 512, "boards with more than 512 points are not supported (k_linearize compaction list)");
   if (p->camera_model == MCBA_CAMERA_FISHEYE)

@@ -146,7 +146,7 @@ MCBA_HD bool local_is_frame(const Dims& d, int i) {
 // ---------------------------------------------------------------------------------------------------------------
 template <int ND, bool FISH, bool ROLL, bool OPTK>
 MCBA_HD double point_rows(const Dims& d, const Tables& t, int v, int c, int b, int p, double2 ob,
-                                             double* vr /*[2][NV]*/) {
+                                             double* vr /*[2][NV]*/, double* jp = nullptr /*[2][3]: d r / d X_board*/) {
   constexpr int DE = ROLL ? 12 : 6, KI = OPTK ? 4 + ND : 0, NV = DE + KI + 1, KIA = 4 + ND;
   double uv[2], A[6], Kc[2 * KIA], Xs[3], Xe[3], tr;
   slot_forward<ND, FISH, ROLL, true>(d, t, v, c, b, p, ob, uv, A, Kc, Xs, Xe, tr);
@@ -175,6 +175,20 @@ MCBA_HD double point_rows(const Dims& d, const Tables& t, int v, int c, int b, i
   }
   vr[NV - 1] = e[0] * fs[0];
   vr[2 * NV - 1] = e[1] * fs[1];
+  if (jp != nullptr) {
+    // d r / d X_board = A . R_view  (rolling: A ((1-t) R_start + t R_end)); board/charuco.py:112-117 `adjusted_points`
+    const double* V = t.view + (size_t)v * (VIEW_STRIDE * (ROLL ? 2 : 1));
+    for (int a = 0; a < 2; ++a)
+      for (int k = 0; k < 3; ++k) {
+        double sum = 0.0;
+        for (int i = 0; i < 3; ++i) {
+          double rik = V[3 * i + k];
+          if constexpr (ROLL) rik = (1.0 - tr) * rik + tr * V[VIEW_STRIDE + 3 * i + k];
+          sum += A[3 * a + i] * rik;
+        }
+        jp[3 * a + k] = rs[a] * sum;
+      }
+  }
   return rho;
 }
 

@@ -74,8 +74,8 @@ void jacobian_t(Host& h, int row_nnz, double* vals, int32_t* cols) {
     const int b = v % d.B, c = (v / d.B) % d.C, fl = v / (d.B * d.C), f = d.f0 + fl;
     Dims dl = d;
     dl.loss = 0;
-    double vr[2 * NV];
-    point_rows<ND, FISH, ROLL, true>(dl, h.t, v, c, b, p, h.t.obs[s], vr);
+    double vr[2 * NV], jp[6];
+    point_rows<ND, FISH, ROLL, true>(dl, h.t, v, c, b, p, h.t.obs[s], vr, jp);
     double* o0 = vals + (size_t)(2 * idx) * row_nnz;
     double* o1 = o0 + row_nnz;
     int32_t* oc = cols + (size_t)idx * row_nnz;
@@ -103,6 +103,10 @@ void jacobian_t(Host& h, int row_nnz, double* vals, int32_t* cols) {
         oc[pos] = base + q;
         ++pos;
       }
+    }
+    if (d.off_boards >= 0) {
+      const int base = d.off_boards + 3 * (h.t.board_off[b] + p);
+      for (int k = 0; k < 3; ++k) { o0[pos] = jp[k]; o1[pos] = jp[3 + k]; oc[pos] = base + k; ++pos; }
     }
   }
 }
@@ -200,6 +204,7 @@ int32_t hm_sizes(const mcba_problem* p, int64_t* n_params, int64_t* n_residuals,
   if (d.off_boardpose >= 0) nnz += 6;
   if (d.off_motion >= 0) nnz += d.motion == MOTION_STATIC ? 6 : 12;
   if (d.off_cameras >= 0) nnz += 5 + d.ND;
+  if (d.off_boards >= 0) nnz += 3;
   *row_nnz = nnz;
   HM_END
 }

@@ -271,3 +271,55 @@ def test_device_outlier_statistics_match_numpy(name):
     cost, _, _ = h.normal_equations(x)
     r = oc.evaluate(x)
     assert cost == pytest.approx(0.5 * r @ r, rel=1e-12)
+
+
+def test_adjust_board_block():
+  """optimize.boards=True (`adjust_board`, board/charuco.py:112-117): board-point columns of the Jacobian, their normal
+  equation blocks (k_points), and a solve that reaches the reference's cost."""
+  g, rig = load_golden("tiny_boards")
+  c = mirror(rig)
+  assert c.param_vec.size == g["x0"].size
+  hm = HostMath(c)
+  with Handle(c) as h:
+    assert np.abs(h.residuals(g["x0"]) - g["r0"]).max() < 1e-9
+    J = h.jacobian(g["x0"])
+    assert rel_col_error(J, golden_jacobian(g)) < 5e-5
+    assert np.abs((J - hm.jacobian(g["x0"]))).max() <= 1e-11 * abs(J).max()
+    Jd = J.toarray()
+    for mf in (1, 0):
+      h.set_mfma(mf)
+      cost, grad, diag = h.normal_equations(g["x0"])
+      H = h.dense_hessian()
+      assert np.abs(H - Jd.T @ Jd).max() <= 1e-12 * np.abs(H).max()
+      assert np.abs(grad - Jd.T @ g["r0"]).max() <= 1e-12 * np.abs(grad).max()
+      assert np.array_equal(H, H.T)
+    res = h.solve(g["x0"])
+    assert res.status in (2, 3, 4) and res.cost <= float(g["ba_cost"]) * (1 + 1e-9)
+    # the reference's own solution evaluates identically
+    oc = oracle(rig)
+    assert np.abs(h.residuals(g["ba_x_raw"]) - oc.evaluate(g["ba_x_raw"])).max() < 1e-9
+  out = c.bundle_adjust()
+  assert out.boards[0].adjusted_points.shape == c.boards[0].adjusted_points.shape
+  assert abs(calibration.error_stats(out.reprojection_error).rms - float(g["ba_rms"])) < 5e-2
+
+
+def test_adjust_board_rolling_and_handeye_blocks():
+  for name in ["tiny_rolling", "tiny_handeye", "tiny_fisheye"]:
+    g, rig = load_golden(name)
+    c = mirror(rig).enable(boards=True)
+    x0 = c.param_vec
+    with Handle(c) as h:
+      J = h.jacobian(x0).toarray()
+      r = h.residuals(x0)
+      cost, grad, diag = h.normal_equations(x0)
+      H = h.dense_hessian()
+      assert np.abs(H - J.T @ J).max() <= 1e-12 * np.abs(H).max(), name
+      assert np.abs(grad - J.T @ r).max() <= 1e-12 * np.abs(grad).max(), name
+    oc = oracle(rig).enable(boards=True)
+    assert np.abs(r - oc.evaluate(x0)).max() < 1e-9
+    from scipy.optimize._numdiff import approx_derivative
+    cols = np.arange(x0.size - 12, x0.size)          # spot-check the last board-point columns by finite differences
+    for j in cols[::5]:
+      e = np.zeros_like(x0); hstep = 1e-6; e[j] = hstep
+      fd = (oc.evaluate(x0 + e) - oc.evaluate(x0 - e)) / (2 * hstep)
+      assert np.abs(fd - J[:, j]).max() <= 1e-5 * max(np.abs(J[:, j]).max(), 1.0), (name, j)
