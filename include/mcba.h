@@ -221,6 +221,9 @@ int32_t mcba_debug_gn_step(mcba_handle h, double reg, double* gn_h, double* g_h,
 /* per-view s_memtime stamps of the k_linearize phases: out[views][8] = {setup, rows, stage+mfma, epilogue, count,
  * start, end, 0} in shader cycles (profiling aid for DESIGN.md section 5)                                             */
 int32_t mcba_debug_linearize_profile(mcba_handle h, const double* x, long long* out);
+/* (S + reg I) p = rhs with the device Cholesky kernels; blocked != 0 forces the multi-workgroup path              */
+int32_t mcba_debug_chol(mcba_handle h, int32_t ns, const double* S, const double* rhs, double reg, int32_t blocked,
+                        double* p_out);
 /* one v_mfma_f64_16x16x4_f64 on V = [A | B] (4 x 32, row-major): out[16][16] = A^T B (operand-layout self-test)     */
 int32_t mcba_debug_mfma_probe(const double* V, double* out);
 

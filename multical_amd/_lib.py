@@ -78,6 +78,7 @@ SYMBOLS = [
   ("mcba_set_mfma", C.c_int32, [H, C.c_int32]),
   ("mcba_debug_gn_step", C.c_int32, [H, C.c_double, c_double_p, c_double_p, c_double_p]),
   ("mcba_debug_mfma_probe", C.c_int32, [c_double_p, c_double_p]),
+  ("mcba_debug_chol", C.c_int32, [H, C.c_int32, c_double_p, c_double_p, C.c_double, C.c_int32, c_double_p]),
   ("mcba_debug_linearize_profile", C.c_int32, [H, c_double_p, C.POINTER(C.c_longlong)]),
 ]
 

@@ -254,6 +254,13 @@ class Handle(object):
                                       _ptr(si, C.c_double)))
     return gn, gh, si
 
+  def debug_chol(self, S, rhs, reg=0.0, blocked=False):
+    S, rhs = _f64(S), _f64(rhs)
+    out = np.empty(rhs.size)
+    check(self.lib.mcba_debug_chol(self.h, int(rhs.size), _ptr(S, C.c_double), _ptr(rhs, C.c_double), float(reg),
+                                   1 if blocked else 0, _ptr(out, C.c_double)))
+    return out
+
   # --- outlier loop on the device ---------------------------------------------------------------------------------
   def error_stats(self, x, quantiles=(0, 0.25, 0.5, 0.75, 1), inliers_only=False):
     """error_stats(Calibration.reprojection_error) of the reference (calibration.py:304-310) computed on the device:

@@ -247,6 +247,38 @@ void launch_quadforms(mcba_handle_s* h, const double* u0, const double* u1, int 
   call_allreduce(h, h->scal.p + off, 3, 0);
 }
 
+
+constexpr size_t CHOL_SINGLE_MAX_LDS = 96 * 1024;
+bool g_force_blocked_chol = false;   // test hook
+
+// (S + reg I) p = rhs for buf = [S (ns x ns) | rhs (ns)]; S is overwritten by its Cholesky factor
+void launch_chol(mcba_handle_s* h, int ns, double reg, double* buf, double* ps) {
+  const int max_rows = ns + 1;
+  const size_t lds = (size_t)(CHOL_NB + max_rows) * (CHOL_NB + 1) * sizeof(double) + 16;
+  if (lds <= CHOL_SINGLE_MAX_LDS && !g_force_blocked_chol) {
+    if (lds > h->chol_lds_set) {
+      HIP_OK(hipFuncSetAttribute((const void*)k_chol_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      h->chol_lds_set = lds;
+    }
+    hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(1024), lds, h->stream, ns, reg, buf, ps, h->info.p, max_rows);
+    return;
+  }
+  // large reduced system: multi-workgroup blocked factorisation
+  HIP_OK(hipMemsetAsync(h->info.p, 0, sizeof(int32_t), h->stream));
+  for (int k0 = 0; k0 < ns; k0 += CB) {
+    const int nb = std::min(CB, ns - k0);
+    hipLaunchKernelGGL(k_cholb_diag, dim3(1), dim3(64), 0, h->stream, ns, k0, reg, buf, h->info.p);
+    const int m = ns - k0 - nb + 1;   // rows below the panel incl. the rhs row
+    hipLaunchKernelGGL(k_cholb_trsm, dim3((m + 63) / 64), dim3(64), 0, h->stream, ns, k0, buf);
+    const int nblk = (m + CB - 1) / CB;
+    if (m > 1) hipLaunchKernelGGL(k_cholb_syrk, dim3(nblk, nblk), dim3(256), 0, h->stream, ns, k0, buf);
+  }
+  for (int k0 = ((ns - 1) / CB) * CB; k0 >= 0; k0 -= CB) {
+    hipLaunchKernelGGL(k_cholb_back_diag, dim3(1), dim3(64), 0, h->stream, ns, k0, buf, ps);
+    if (k0 > 0) hipLaunchKernelGGL(k_cholb_back_update, dim3((k0 + 255) / 256), dim3(256), 0, h->stream, ns, k0, buf);
+  }
+}
+
 // gn = (H_h + reg I)^-1 g_h  through the Schur complement of the per-frame blocks
 void launch_gn_solve(mcba_handle_s* h, double reg, bool root_rank) {
   const Dims& d = h->d;
@@ -267,18 +299,7 @@ void launch_gn_solve(mcba_handle_s* h, double reg, bool root_rank) {
   hipLaunchKernelGGL(k_schur_reduce, dim3(std::min(1024, (total + 255) / 256)), dim3(256), 0, h->stream, d, h->Hss.p,
                      h->dsc.p, h->gh.p, h->P.p, h->ntile, h->ksplit, K, root_rank ? 1.0 : 0.0, h->sbuf.p);
   call_allreduce(h, h->sbuf.p, (size_t)total, 0);
-  {
-    const int max_rows = d.ns + 1;
-    const size_t lds = (size_t)(CHOL_NB + max_rows) * (CHOL_NB + 1) * sizeof(double) + 16;
-    REQUIRE(lds <= 160 * 1024 - 256, "reduced system too large for the single-workgroup Cholesky (ns = " +
-                                          std::to_string(d.ns) + ")");
-    if (lds > h->chol_lds_set) {
-      HIP_OK(hipFuncSetAttribute((const void*)k_chol_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      h->chol_lds_set = lds;
-    }
-    hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(1024), lds, h->stream, d.ns, reg, h->sbuf.p, h->ps.p, h->info.p,
-                       max_rows);
-  }
+  launch_chol(h, d.ns, reg, h->sbuf.p, h->ps.p);
   const int nblk = (K > 0 ? d.Fl : 0) + 1;
   hipLaunchKernelGGL(k_schur_backsub, dim3(nblk), dim3(128), 0, h->stream, d, h->Lf.p, h->W.p, h->yf.p, h->ps.p, h->gn.p);
   if (h->allreduce && K > 0) {
@@ -803,6 +824,28 @@ int32_t mcba_debug_linearize_profile(mcba_handle h, const double* x, long long* 
   h->t.dbg = nullptr;
   HIP_OK(hipMemcpyAsync(out, h->dbg.p, n * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
   sync(h);
+  API_END
+}
+
+
+// debug: solve (S + reg I) p = rhs with the device Cholesky (blocked != 0 forces the multi-workgroup path)
+int32_t mcba_debug_chol(mcba_handle h, int32_t ns, const double* S, const double* rhs, double reg, int32_t blocked,
+                        double* p_out) {
+  API_BEGIN
+  REQUIRE(h && S && rhs && p_out && ns > 0, "bad argument");
+  DevBuf<double> buf, ps;
+  buf.alloc((size_t)ns * ns + ns, false);
+  ps.alloc((size_t)ns);
+  HIP_OK(hipMemcpyAsync(buf.p, S, (size_t)ns * ns * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_OK(hipMemcpyAsync(buf.p + (size_t)ns * ns, rhs, (size_t)ns * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  g_force_blocked_chol = blocked != 0;
+  try { launch_chol(h, ns, reg, buf.p, ps.p); } catch (...) { g_force_blocked_chol = false; throw; }
+  g_force_blocked_chol = false;
+  HIP_OK(hipMemcpyAsync(p_out, ps.p, (size_t)ns * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  sync(h);
+  int info = 0;
+  HIP_OK(hipMemcpy(&info, h->info.p, sizeof(int), hipMemcpyDeviceToHost));
+  REQUIRE(info == 0, "non-positive pivot at column " + std::to_string(info));
   API_END
 }
 

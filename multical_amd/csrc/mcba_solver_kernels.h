@@ -556,6 +556,138 @@ __global__ __launch_bounds__(1024) void k_chol_solve(int ns, double reg, double*
   if (tid == 0) info[0] = bad;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Multi-workgroup blocked Cholesky for large reduced systems (adjust_board: ns = shared + 3 x #board points, up to a
+// few thousand).  Same data layout as k_chol_solve ((ns+1) x ns, row ns = rhs), 64-column panels, three launches per
+// panel: diagonal block (one workgroup), panel solve (one row per thread), symmetric rank-64 trailing update with
+// v_mfma_f64_16x16x4_f64 on 64 x 64 tiles staged in LDS.  Then a blocked backward substitution (two launches / panel).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int CB = 64, CBL = CB + 1;
+
+__global__ __launch_bounds__(64) void k_cholb_diag(int ns, int k0, double reg, double* __restrict__ A, int* __restrict__ info) {
+  __shared__ double D[CB * CBL];
+  const int tid = threadIdx.x, nb = min(CB, ns - k0);
+  for (int e = tid; e < CB * CB; e += 64) {
+    const int i = e / CB, j = e % CB;
+    double v = (i == j) ? 1.0 : 0.0;
+    if (i < nb && j < nb) {
+      v = A[(size_t)(k0 + i) * ns + k0 + j];
+      if (i == j) v += reg;
+    }
+    D[i * CBL + j] = v;
+  }
+  lds_fence();
+  for (int j = 0; j < nb; ++j) {
+    double dj = D[j * CBL + j];
+    if (!(dj > 0.0)) { if (tid == 0 && info[0] == 0) info[0] = k0 + j + 1; dj = 1e-300; }
+    dj = sqrt(dj);
+    lds_fence();
+    if (tid == 0) D[j * CBL + j] = dj;
+    for (int i = j + 1 + tid; i < nb; i += 64) D[i * CBL + j] /= dj;
+    lds_fence();
+    const int mm = nb - j - 1;
+    for (int e = tid; e < mm * mm; e += 64) {
+      const int i = j + 1 + e / mm, k = j + 1 + e % mm;
+      if (k <= i) D[i * CBL + k] -= D[i * CBL + j] * D[k * CBL + j];
+    }
+    lds_fence();
+  }
+  for (int e = tid; e < nb * nb; e += 64) {
+    const int i = e / nb, j = e % nb;
+    if (j <= i) A[(size_t)(k0 + i) * ns + k0 + j] = D[i * CBL + j];
+  }
+}
+
+// rows k0+nb .. ns (the last one is the right-hand side):  row <- row L11^-T, one row per thread, row kept in LDS
+__global__ __launch_bounds__(64) void k_cholb_trsm(int ns, int k0, double* __restrict__ A) {
+  __shared__ double D[CB * CBL];
+  __shared__ double X[64 * CBL];
+  const int tid = threadIdx.x, nb = min(CB, ns - k0);
+  for (int e = tid; e < CB * CB; e += 64) {
+    const int i = e / CB, j = e % CB;
+    D[i * CBL + j] = (i < nb && j < nb && j <= i) ? A[(size_t)(k0 + i) * ns + k0 + j] : (i == j ? 1.0 : 0.0);
+  }
+  lds_fence();
+  const int r = k0 + nb + blockIdx.x * 64 + tid;
+  if (r > ns) return;
+  double* arow = A + (size_t)r * ns + k0;
+  double* xr = X + tid * CBL;
+  for (int j = 0; j < nb; ++j) xr[j] = arow[j];
+  for (int j = 0; j < nb; ++j) {
+    double v = xr[j];
+    const double* dj = D + j * CBL;
+    for (int k = 0; k < j; ++k) v -= xr[k] * dj[k];
+    v /= dj[j];
+    xr[j] = v;
+    arow[j] = v;
+  }
+}
+
+// trailing update: tile (br, bc), bc <= br, of rows/cols k0+nb+64*b .. ;  A[r][c] -= L[r][k0..k0+nb) . L[c][k0..k0+nb)
+__global__ __launch_bounds__(256) void k_cholb_syrk(int ns, int k0, double* __restrict__ A) {
+  __shared__ double Lr[CB * CBL];
+  __shared__ double Lc[CB * CBL];
+  const int br = blockIdx.x, bc = blockIdx.y;
+  if (bc > br) return;
+  const int nb = min(CB, ns - k0);
+  const int base = k0 + nb;
+  const int r0 = base + br * CB, c0 = base + bc * CB;
+  for (int e = threadIdx.x; e < CB * CB; e += 256) {
+    const int i = e / CB, k = e % CB;
+    const int r = r0 + i, c = c0 + i;
+    Lr[i * CBL + k] = (r <= ns && k < nb) ? A[(size_t)r * ns + k0 + k] : 0.0;
+    Lc[i * CBL + k] = (c < ns && k < nb) ? A[(size_t)c * ns + k0 + k] : 0.0;
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, rsub = lane >> 4, csub = lane & 15;
+  double4_t acc[4];
+  for (int ct = 0; ct < 4; ++ct) acc[ct] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  for (int st = 0; st < CB / 4; ++st) {
+    const double a = Lr[(16 * wave + csub) * CBL + 4 * st + rsub];
+    for (int ct = 0; ct < 4; ++ct) {
+      const double b = Lc[(16 * ct + csub) * CBL + 4 * st + rsub];
+      acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[ct], 0, 0, 0);
+    }
+  }
+  for (int ct = 0; ct < 4; ++ct)
+    for (int q = 0; q < 4; ++q) {
+      const int r = r0 + 16 * wave + rsub + 4 * q, c = c0 + 16 * ct + csub;
+      if (r <= ns && c < ns && c <= r) A[(size_t)r * ns + c] -= acc[ct][q];
+    }
+}
+
+// backward substitution, panel k0: solve L11^T p = y_panel (one wavefront)
+__global__ __launch_bounds__(64) void k_cholb_back_diag(int ns, int k0, double* __restrict__ A, double* __restrict__ ps) {
+  __shared__ double D[CB * CBL];
+  const int tid = threadIdx.x, nb = min(CB, ns - k0);
+  double* y = A + (size_t)ns * ns;
+  for (int e = tid; e < nb * nb; e += 64) {
+    const int i = e / nb, j = e % nb;
+    D[i * CBL + j] = A[(size_t)(k0 + i) * ns + k0 + j];
+  }
+  lds_fence();
+  double yv = tid < nb ? y[k0 + tid] : 0.0;
+  for (int i = nb - 1; i >= 0; --i) {
+    const double pi = __shfl(yv, i, 64) / D[i * CBL + i];
+    if (tid == i) yv = pi;
+    else if (tid < i) yv -= D[i * CBL + tid] * pi;
+  }
+  if (tid < nb) {
+    y[k0 + tid] = yv;
+    ps[k0 + tid] = yv;
+  }
+}
+// y[j] -= sum_i L[k0+i][j] p[k0+i]  for j < k0
+__global__ void k_cholb_back_update(int ns, int k0, double* __restrict__ A) {
+  const int nb = min(CB, ns - k0);
+  double* y = A + (size_t)ns * ns;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= k0) return;
+  double sum = 0.0;
+  for (int i = 0; i < nb; ++i) sum += A[(size_t)(k0 + i) * ns + j] * y[k0 + i];
+  y[j] -= sum;
+}
+
 // back-substitution: gn_s = p_s ; gn_f = L^-T (y_f - W p_s)  (one block per frame; block Fl copies the shared part)
 __global__ void k_schur_backsub(Dims d, const double* __restrict__ Lf, const double* __restrict__ W,
                                 const double* __restrict__ yf, const double* __restrict__ ps, double* __restrict__ gn) {

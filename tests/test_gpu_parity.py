@@ -323,3 +323,38 @@ def test_adjust_board_rolling_and_handeye_blocks():
       e = np.zeros_like(x0); hstep = 1e-6; e[j] = hstep
       fd = (oc.evaluate(x0 + e) - oc.evaluate(x0 - e)) / (2 * hstep)
       assert np.abs(fd - J[:, j]).max() <= 1e-5 * max(np.abs(J[:, j]).max(), 1.0), (name, j)
+
+
+@pytest.mark.parametrize("ns,blocked", [(40, False), (40, True), (200, False), (200, True), (333, True), (700, True),
+                                        (1500, True)])
+def test_device_cholesky_paths(ns, blocked):
+  """single-workgroup (LDS panels) and multi-workgroup (MFMA trailing update) Cholesky solves vs numpy."""
+  rng = np.random.default_rng(ns)
+  M = rng.normal(size=(ns + 20, ns))
+  S = M.T @ M / ns + 0.1 * np.eye(ns)
+  rhs = rng.normal(size=ns)
+  with Handle(mirror(synthetic.make_rig("tiny"))) as h:
+    p = h.debug_chol(S, rhs, reg=0.05, blocked=blocked)
+  ref = np.linalg.solve(S + 0.05 * np.eye(ns), rhs)
+  assert np.abs(p - ref).max() <= 1e-10 * np.abs(ref).max()
+
+
+def test_adjust_board_large_reduced_system():
+  """cfg1 with adjust_board: ns = 18 + 3 x 315 = 963 shared parameters -> multi-workgroup Cholesky inside the solve."""
+  g, rig = load_golden("cfg1")
+  c = mirror(rig).enable(boards=True)
+  x0 = c.param_vec
+  with Handle(c) as h:
+    J = h.jacobian(x0)
+    r = h.residuals(x0)
+    cost, grad, diag = h.normal_equations(x0)
+    assert np.abs(J.T @ r - grad).max() <= 1e-11 * np.abs(grad).max()
+    assert np.abs(np.asarray(J.multiply(J).sum(axis=0)).ravel() - diag).max() <= 1e-11 * diag.max()
+    reg = 1e-3
+    gn, gh, si = h.debug_gn_step(reg)
+    d = 1 / si
+    Hs = (J.T @ J).toarray() * d[:, None] * d[None, :]
+    ref = np.linalg.solve(Hs + reg * np.eye(x0.size), d * grad)
+    assert np.abs(gn - ref).max() <= 1e-8 * np.abs(ref).max()
+    res = h.solve(x0)
+    assert res.status in (2, 3, 4) and res.cost < float(g["ba_cost"])      # more freedom than the fixed-board fit
