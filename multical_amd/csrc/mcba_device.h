@@ -78,6 +78,7 @@ struct Tables {
   double* pose;                // [n_pose][POSE_STRIDE]
   double* cam;                 // [C][CAM_STRIDE]
   double* view;                // [Fl][C][B][view_stride]
+  double* tmat;                // [Fl][C][B][DE*NPC] That columns per view (k_tmat), consumed by k_linearize
   long long* dbg;              // optional [views][8] cycle stamps of k_linearize phases (profiling aid), else null
 };
 

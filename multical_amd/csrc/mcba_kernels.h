@@ -346,6 +346,11 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
   constexpr int NPC = 6 * NPB, NL = NPC + KI, N1 = NL + 1;
   constexpr int PTS = NT == 1 ? 64 : 32, RND = 64 / PTS, ROWS = 2 * PTS;
   constexpr int REC = N1 * (N1 + 1) / 2;
+  // NV in 17..23: the (NV-16)^2 corner of S is accumulated per lane on the VALU (same FP64 rate as the MFMA on gfx950,
+  // but only the <= 28 unique products instead of a 16x16x4 tile) and reduced across lanes once per view.
+  constexpr int TW = NV - 16;
+  constexpr bool TAILV = MFMA && NT == 2 && TW <= 7;
+  constexpr int NTAIL = TAILV ? TW * (TW + 1) / 2 : 1;
   constexpr int STAGE = ROWS * LDV, EPI = NVP * NVP;
   constexpr int BUF = STAGE > EPI ? STAGE : EPI;
 
@@ -361,10 +366,7 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
   const bool prof = t.dbg != nullptr;
   if (prof) stamp[0] = clock64();
 
-  if (lane < NPC) view_column(d, t, f, c, b, lane, Tm + lane, NPC);   // column `lane` of That, written in place
-  for (int e = lane; e < STAGE; e += 64) Vbuf[e] = 0.0;   // pad columns stay zero during the main loop
-
-  // gather the inlier slots of this view: all mask bytes are requested at once (one memory round trip)
+  // all global loads of the prologue are issued back to back (mask bytes, That): one memory round trip
   constexpr int NPB64 = LIN_MAX_POINTS / 64;
   uint8_t inb[NPB64];
 #pragma unroll
@@ -372,6 +374,15 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
     const int p = k * 64 + lane;
     inb[k] = p < d.P ? t.inlier[(size_t)v * d.P + p] : (uint8_t)0;
   }
+  {   // That of this view, precomputed by k_tmat
+    const double* tg = t.tmat + (size_t)v * (DE * NPC);
+    for (int e = lane; e < DE * NPC; e += 64) Tm[e] = tg[e];
+  }
+  if (prof) stamp[4] = clock64();
+  // only the pad columns need clearing: every staged row is fully rewritten (columns < NV) in every round
+  for (int e = lane; e < ROWS * (LDV - NV); e += 64) Vbuf[(e / (LDV - NV)) * LDV + NV + e % (LDV - NV)] = 0.0;
+
+  if (prof) stamp[5] = clock64();
   int count = 0;
 #pragma unroll
   for (int k = 0; k < NPB64; ++k) {
@@ -391,6 +402,8 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
     for (int i = 0; i < NACC_V; ++i) accv[i] = 0.0;
   }
   double cost = 0.0;
+  double tail[NTAIL];
+  for (int i = 0; i < NTAIL; ++i) tail[i] = 0.0;
   lds_fence();
   if (prof) stamp[1] = clock64();
 
@@ -405,6 +418,16 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
       cost += point_rows<ND, FISH, ROLL, OPTK>(d, t, v, c, b, p, t.obs[(size_t)v * d.P + p], vr);
     } else {
       for (int k = 0; k < 2 * NV; ++k) vr[k] = 0.0;
+    }
+    if constexpr (TAILV) {
+      if (in) {
+        int e = 0;
+#pragma unroll
+        for (int i0 = 0; i0 < TW; ++i0)
+#pragma unroll
+          for (int i1 = i0; i1 < TW; ++i1, ++e)
+            tail[e] += vr[16 + i0] * vr[16 + i1] + vr[NV + 16 + i0] * vr[NV + 16 + i1];
+      }
     }
     if (prof) stamp[2] += clock64() - t0;
     const int nchunk = min(64, count - base);              // observations in this chunk
@@ -437,7 +460,8 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
             int ti = 0;
             for (int t0 = 0; t0 < NT; ++t0)
               for (int t1 = t0; t1 < NT; ++t1, ++ti)
-                accm[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[t0], a0[t1], accm[ti], 0, 0, 0);
+                if (!(TAILV && t0 == 1))
+                  accm[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[t0], a0[t1], accm[ti], 0, 0, 0);
           }
           const int nx = min(st + 2, MAXS - 1);
           for (int tt = 0; tt < NT; ++tt) a0[tt] = vp[(4 * nx) * LDV + 16 * tt];
@@ -445,7 +469,8 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
             int ti = 0;
             for (int t0 = 0; t0 < NT; ++t0)
               for (int t1 = t0; t1 < NT; ++t1, ++ti)
-                accm[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[t0], a1[t1], accm[ti], 0, 0, 0);
+                if (!(TAILV && t0 == 1))
+                  accm[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[t0], a1[t1], accm[ti], 0, 0, 0);
           }
         }
       } else {
@@ -461,6 +486,20 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
   }
 
   if (prof) stamp[3] = clock64();
+  // cross-lane reduction of the VALU corner: transpose through the (now free) staging buffer, lane e sums row e
+  double tail_red = 0.0;
+  if constexpr (TAILV) {
+    static_assert(NTAIL * 65 <= BUF, "tail transpose does not fit");
+#pragma unroll
+    for (int e = 0; e < NTAIL; ++e) Buf[e * 65 + lane] = tail[e];
+    lds_fence();
+    if (lane < NTAIL) {
+      const double* row = Buf + lane * 65;
+#pragma unroll 16
+      for (int k = 0; k < 64; ++k) tail_red += row[k];
+    }
+    lds_fence();
+  }
   // S -> LDS (full symmetric matrix), time-sharing the staging buffer
   double* Sbuf = Buf;
   if constexpr (MFMA) {
@@ -477,6 +516,15 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
     constexpr int IW = NVP, JW = NACC_V;
     const int ii = lane % IW, j0 = (lane / IW) * JW;
     for (int jj = 0; jj < JW; ++jj) Sbuf[ii * NVP + j0 + jj] = accv[jj];
+  }
+  if constexpr (TAILV) {   // lanes e < NTAIL carry the reduced corner entries computed above
+    if (lane < NTAIL) {
+      int i0 = 0, rem = lane;
+      while (rem >= TW - i0) { rem -= TW - i0; ++i0; }
+      const int i1 = i0 + rem;
+      Sbuf[(16 + i0) * NVP + 16 + i1] = tail_red;
+      Sbuf[(16 + i1) * NVP + 16 + i0] = tail_red;
+    }
   }
   lds_fence();
 
@@ -525,8 +573,9 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
       o[2] = stamp[3] - stamp[1] - stamp[2];      // LDS staging + MFMA
       o[3] = clock64() - stamp[3];                // epilogue
       o[4] = count;
-      o[5] = stamp[0];
-      o[6] = clock64();
+      o[5] = stamp[4] - stamp[0];                 // setup part 1: That columns
+      o[6] = stamp[5] - stamp[4];                 // setup part 2: staging clear + inlier loads
+      o[7] = clock64() - stamp[0];                // lifetime
     }
   }
 }

@@ -34,6 +34,17 @@ __global__ void k_views(Dims d, Tables t) {
   view_item(d, t, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
+// That columns of every non-empty view (one thread per (view, column)): tmat[v][a][j], a < DE, j < 6*NPB
+__global__ void k_tmat(Dims d, Tables t) {
+  const int npc = 6 * d.NPB;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.views() * npc) return;
+  const int v = i / npc, j = i % npc;
+  if (t.view_count[v] == 0) return;
+  const int b = v % d.B, c = (v / d.B) % d.C, fl = v / (d.B * d.C), f = d.f0 + fl;
+  view_column(d, t, f, c, b, j, t.tmat + (size_t)v * d.DE * npc + j, npc);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // assembly of the records (deterministic gathers; no atomics)
 // ---------------------------------------------------------------------------------------------------------------
@@ -107,28 +118,41 @@ __global__ void k_shared_partial(Dims d, Tables t, const double* __restrict__ re
   double* out = partial + ((size_t)pair * nchunk + ch) * d.rec_stride;
   for (int e = threadIdx.x; e < d.rec_stride; e += blockDim.x) {
     double sum = 0.0;
+#pragma unroll 4
     for (int fl = fa; fl < fb; ++fl) {
       const int v = (fl * d.C + c) * d.B + b;
-      if (t.view_count[v] == 0) continue;
-      sum += rec[(size_t)v * d.rec_stride + e];
+      const double val = rec[(size_t)v * d.rec_stride + e];   // records of empty views are never written: mask them
+      sum += t.view_count[v] != 0 ? val : 0.0;
     }
     out[e] = sum;
   }
 }
 
-// shared part, stage 2: H_ss (dense ns x ns, zeroed by the caller), g and the total cost.
+// shared part, stage 2: pairsum[pair][e] = sum over the chunks (one thread per (pair, entry))
+__global__ void k_shared_pairsum(Dims d, const double* __restrict__ partial, int nchunk, double* __restrict__ pairsum) {
+  const int pair = blockIdx.y;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= d.rec_stride) return;
+  const double* base = partial + (size_t)pair * nchunk * d.rec_stride + e;
+  double sum = 0.0;
+#pragma unroll 8
+  for (int ch = 0; ch < nchunk; ++ch) sum += base[(size_t)ch * d.rec_stride];
+  pairsum[(size_t)pair * d.rec_stride + e] = sum;
+}
+
+// shared part, stage 3: H_ss (dense ns x ns, zeroed by the caller), g and the total cost.
 // One THREAD per packed local entry e; it folds the pairs (c, b) in sequentially.  Two contributions can only meet in
 // the same H_ss element when they come from the same local entry e of different pairs (e.g. the camera block of
 // (c, b) and (c, b')), i.e. inside one thread -- so the sum order is fixed and no atomics are needed.
-__global__ void k_shared_final(Dims d, const double* __restrict__ partial, int nchunk, const uint16_t* __restrict__ tri,
+__global__ void k_shared_final(Dims d, const double* __restrict__ pairsum, const uint16_t* __restrict__ tri,
                                double* __restrict__ Hss, double* __restrict__ g, double* __restrict__ cost_count) {
   const int ns = d.ns, NL = d.NL;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= d.rec_size + 2) return;
+  const int npair = d.C * d.B;
   if (e >= d.rec_size) {   // cost, count
     double tot = 0.0;
-    for (int pair = 0; pair < d.C * d.B; ++pair)
-      for (int ch = 0; ch < nchunk; ++ch) tot += partial[((size_t)pair * nchunk + ch) * d.rec_stride + e];
+    for (int pair = 0; pair < npair; ++pair) tot += pairsum[(size_t)pair * d.rec_stride + e];
     cost_count[e - d.rec_size] = tot;
     return;
   }
@@ -136,16 +160,14 @@ __global__ void k_shared_final(Dims d, const double* __restrict__ partial, int n
   const int i = ij >> 8, j = ij & 255;
   if (i == NL) return;                                   // (r, r) = sum f^2: the cost is carried separately
   if (local_is_frame(d, i) || local_is_frame(d, j)) return;
-  for (int pair = 0; pair < d.C * d.B; ++pair) {
+  for (int pair = 0; pair < npair; ++pair) {
     const int c = pair / d.B, b = pair % d.B;
     // the frame index is irrelevant for shared parameters (hand-eye blocks do not depend on f either)
     const int gi = local_to_x(d, 0, c, b, i);
     if (gi < 0) continue;
     const int gj = j == NL ? 0 : local_to_x(d, 0, c, b, j);
     if (gj < 0) continue;
-    const double* base = partial + (size_t)pair * nchunk * d.rec_stride + e;
-    double val = 0.0;
-    for (int ch = 0; ch < nchunk; ++ch) val += base[(size_t)ch * d.rec_stride];
+    const double val = pairsum[(size_t)pair * d.rec_stride + e];
     if (j == NL) {
       g[gi] += val;
     } else {

@@ -10,7 +10,7 @@ with Handle(c) as h:
     print("views active", len(act), "of", len(p), "mean count", act[:,4].mean())
     names = ["setup", "rows", "stage+mfma", "epilogue"]
     for i, n in enumerate(names): print(f"{n:12s} mean {act[:, i].mean():10.0f} cyc  median {np.median(act[:, i]):10.0f}  max {act[:, i].max()}")
-    life = act[:, 6] - act[:, 5]
-    print("lifetime mean", life.mean(), "kernel span", act[:, 6].max() - act[:, 5].min())
+    print("setup: That columns", act[:,5].mean(), " clear+mask loads", act[:,6].mean(), " compaction", (act[:,0]-act[:,5]-act[:,6]).mean())
+    print("lifetime mean", act[:, 7].mean())
     # clock rate of s_memtime: span vs measured time
     print("linearize ms", h.time_linearize(x0, 20))
