@@ -360,11 +360,11 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
   double* Vbuf = Buf;
 
   const int v = blockIdx.x, lane = threadIdx.x;
-  if (t.view_count[v] == 0) return;
   const int b = v % d.B, c = (v / d.B) % d.C, fl = v / (d.B * d.C), f = d.f0 + fl;
   long long stamp[6] = {0, 0, 0, 0, 0, 0};
   const bool prof = t.dbg != nullptr;
   if (prof) stamp[0] = clock64();
+  const int view_cnt = t.view_count[v];   // requested together with the other prologue loads; tested after them
 
   // all global loads of the prologue are issued back to back (mask bytes, That): one memory round trip
   constexpr int NPB64 = LIN_MAX_POINTS / 64;
@@ -374,9 +374,16 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
     const int p = k * 64 + lane;
     inb[k] = p < d.P ? t.inlier[(size_t)v * d.P + p] : (uint8_t)0;
   }
-  {   // That of this view, precomputed by k_tmat
+  {   // That of this view, precomputed by k_tmat (stale but harmless for empty views)
     const double* tg = t.tmat + (size_t)v * (DE * NPC);
-    for (int e = lane; e < DE * NPC; e += 64) Tm[e] = tg[e];
+    constexpr int NTL = (DE * NPC + 63) / 64;
+    double tl[NTL];
+#pragma unroll
+    for (int k = 0; k < NTL; ++k) tl[k] = (k * 64 + lane < DE * NPC) ? tg[k * 64 + lane] : 0.0;
+    if (view_cnt == 0) return;
+#pragma unroll
+    for (int k = 0; k < NTL; ++k)
+      if (k * 64 + lane < DE * NPC) Tm[k * 64 + lane] = tl[k];
   }
   if (prof) stamp[4] = clock64();
   // only the pad columns need clearing: every staged row is fully rewritten (columns < NV) in every round
@@ -407,18 +414,29 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
   lds_fence();
   if (prof) stamp[1] = clock64();
 
+  // software prefetch: observation + board point of the NEXT chunk are requested before the current one is processed
+  int p_cur = lane < count ? pidx[lane] : 0;
+  double2 ob_cur = t.obs[(size_t)v * d.P + p_cur];
+  double X_cur[3], X_nxt[3];
+  for (int k = 0; k < 3; ++k) X_cur[k] = t.board_points[3 * (size_t)(b * d.P + p_cur) + k];
   for (int base = 0; base < count; base += 64) {
     const int i = base + lane;
     const bool in = i < count;
+    const int inx = i + 64;
+    const int p_nxt = inx < count ? pidx[inx] : p_cur;
+    const double2 ob_nxt = t.obs[(size_t)v * d.P + p_nxt];
+    for (int k = 0; k < 3; ++k) X_nxt[k] = t.board_points[3 * (size_t)(b * d.P + p_nxt) + k];
     double vr[2 * NV];
     long long t0 = 0;
     if (prof) t0 = clock64();
     if (in) {
-      const int p = pidx[i];
-      cost += point_rows<ND, FISH, ROLL, OPTK>(d, t, v, c, b, p, t.obs[(size_t)v * d.P + p], vr);
+      cost += point_rows<ND, FISH, ROLL, OPTK>(d, t, v, c, b, p_cur, ob_cur, vr, nullptr, X_cur);
     } else {
       for (int k = 0; k < 2 * NV; ++k) vr[k] = 0.0;
     }
+    p_cur = p_nxt;
+    ob_cur = ob_nxt;
+    for (int k = 0; k < 3; ++k) X_cur[k] = X_nxt[k];
     if constexpr (TAILV) {
       if (in) {
         int e = 0;
@@ -528,39 +546,96 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
   }
   lds_fence();
 
-  // epilogue.  lane j < N1 owns column j of the local system:
-  //   y[a] = (S That)[a][j]  for the DE base rows  (That column j in registers, S rows are LDS broadcasts)
-  //   M[i][j] = sum_a That[a][i] y[a]  (i < NPC, i <= j),   M[i][j] = S[DE + i - NPC][.]-row entries otherwise
   double* out = rec + (size_t)v * d.rec_stride;
-  const int j = lane;
-  if (j < N1) {
-    double tcol[DE], y[DE];
-    const bool pose_col = j < NPC;
-#pragma unroll
-    for (int a = 0; a < DE; ++a) tcol[a] = pose_col ? Tm[a * NPC + j] : 0.0;
-#pragma unroll
-    for (int a = 0; a < DE; ++a) {
-      double sum;
-      if (pose_col) {
-        sum = 0.0;
-#pragma unroll
-        for (int bb = 0; bb < DE; ++bb) sum += Sbuf[a * NVP + bb] * tcol[bb];
-      } else {
-        sum = Sbuf[a * NVP + DE + (j - NPC)];
+  if constexpr (MFMA) {
+    // epilogue on the matrix pipe:  Y = S_EE That,  M_pp = That^T Y,  M_pK = That^T S_E,[K r]   (16x16x4 tiles, K = DE)
+    constexpr int NPCT = (NPC + 15) / 16, NPCP = 16 * NPCT, KR = KI + 1, KRT = (KR + 15) / 16, KS = (DE + 3) / 4;
+    static_assert(NVP * NVP + DE * NPCP <= BUF, "Y does not fit behind S");
+    double* Yb = Buf + NVP * NVP;                                   // [DE][NPCP]
+    const int rsub = lane >> 4, csub = lane & 15;
+    for (int tj = 0; tj < NPCT; ++tj) {                             // step 1: Y
+      double4_t acc = {0.0, 0.0, 0.0, 0.0};
+      for (int ks = 0; ks < KS; ++ks) {
+        const int k = 4 * ks + rsub, jc = 16 * tj + csub;
+        const double av = Sbuf[csub * NVP + k];
+        const double bv = (k < DE && jc < NPC) ? Tm[k * NPC + jc] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
       }
-      y[a] = sum;
+      for (int r = 0; r < 4; ++r) {
+        const int row = rsub + 4 * r;
+        if (row < DE) Yb[row * NPCP + 16 * tj + csub] = acc[r];
+      }
     }
-    // rows i < NPC of column j
-    const int imax = pose_col ? j : NPC - 1;
-    for (int i = 0; i <= imax; ++i) {
-      double m = 0.0;
-#pragma unroll
-      for (int a = 0; a < DE; ++a) m += Tm[a * NPC + i] * y[a];
-      out[tri_index(i, j, N1)] = m;
+    lds_fence();
+    for (int ti = 0; ti < NPCT; ++ti) {
+      double av[KS];
+      for (int ks = 0; ks < KS; ++ks) {
+        const int k = 4 * ks + rsub, ic = 16 * ti + csub;
+        av[ks] = (k < DE && ic < NPC) ? Tm[k * NPC + ic] : 0.0;
+      }
+      for (int tj = ti; tj < NPCT; ++tj) {                          // step 2: pose x pose
+        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+        for (int ks = 0; ks < KS; ++ks) {
+          const int k = 4 * ks + rsub;
+          const double bv = k < DE ? Yb[k * NPCP + 16 * tj + csub] : 0.0;
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], bv, acc, 0, 0, 0);
+        }
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * ti + rsub + 4 * r, j = 16 * tj + csub;
+          if (i <= j && j < NPC) out[tri_index(i, j, N1)] = acc[r];
+        }
+      }
+      for (int tk = 0; tk < KRT; ++tk) {                            // step 3: pose x (intrinsics | residual)
+        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+        for (int ks = 0; ks < KS; ++ks) {
+          const int k = 4 * ks + rsub, jc = 16 * tk + csub;
+          const double bv = (k < DE && jc < KR) ? Sbuf[k * NVP + DE + jc] : 0.0;
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], bv, acc, 0, 0, 0);
+        }
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * ti + rsub + 4 * r, jc = 16 * tk + csub;
+          if (i < NPC && jc < KR) out[tri_index(i, NPC + jc, N1)] = acc[r];
+        }
+      }
     }
-    // rows i >= NPC (intrinsics / residual rows): M[i][j] = S[DE + i - NPC][DE + j - NPC]
-    if (!pose_col)
-      for (int i = NPC; i <= j; ++i) out[tri_index(i, j, N1)] = Sbuf[(DE + i - NPC) * NVP + DE + (j - NPC)];
+    for (int e = lane; e < KR * KR; e += 64) {                      // step 4: (intrinsics | residual)^2 block = copy of S
+      const int i = e / KR, j = e % KR;
+      if (i <= j) out[tri_index(NPC + i, NPC + j, N1)] = Sbuf[(DE + i) * NVP + DE + j];
+    }
+  } else {
+    // epilogue.  lane j < N1 owns column j of the local system:
+    //   y[a] = (S That)[a][j]  for the DE base rows  (That column j in registers, S rows are LDS broadcasts)
+    //   M[i][j] = sum_a That[a][i] y[a]  (i < NPC, i <= j),   M[i][j] = S[DE + i - NPC][.]-row entries otherwise
+    const int j = lane;
+    if (j < N1) {
+      double tcol[DE], y[DE];
+      const bool pose_col = j < NPC;
+  #pragma unroll
+      for (int a = 0; a < DE; ++a) tcol[a] = pose_col ? Tm[a * NPC + j] : 0.0;
+  #pragma unroll
+      for (int a = 0; a < DE; ++a) {
+        double sum;
+        if (pose_col) {
+          sum = 0.0;
+  #pragma unroll
+          for (int bb = 0; bb < DE; ++bb) sum += Sbuf[a * NVP + bb] * tcol[bb];
+        } else {
+          sum = Sbuf[a * NVP + DE + (j - NPC)];
+        }
+        y[a] = sum;
+      }
+      // rows i < NPC of column j
+      const int imax = pose_col ? j : NPC - 1;
+      for (int i = 0; i <= imax; ++i) {
+        double m = 0.0;
+  #pragma unroll
+        for (int a = 0; a < DE; ++a) m += Tm[a * NPC + i] * y[a];
+        out[tri_index(i, j, N1)] = m;
+      }
+      // rows i >= NPC (intrinsics / residual rows): M[i][j] = S[DE + i - NPC][DE + j - NPC]
+      if (!pose_col)
+        for (int i = NPC; i <= j; ++i) out[tri_index(i, j, N1)] = Sbuf[(DE + i - NPC) * NVP + DE + (j - NPC)];
+    }
   }
   cost = wave_sum(cost);
   if (lane == 0) {

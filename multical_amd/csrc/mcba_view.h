@@ -24,8 +24,9 @@ MCBA_HD int tri_index(int i, int j, int N1) {   // packed upper triangle, i <= j
 // ---------------------------------------------------------------------------------------------------------------
 template <int ND, bool FISH, bool ROLL, bool JAC>
 MCBA_HD void slot_forward(const Dims& d, const Tables& t, int v, int c, int b, int p, double2 ob,
-                                             double* uv, double* A, double* Kc, double* Xs, double* Xe, double& tr) {
-  const double* X = t.board_points + 3 * (size_t)(b * d.P + p);
+                                             double* uv, double* A, double* Kc, double* Xs, double* Xe, double& tr,
+                                             const double* Xpre = nullptr /* prefetched board point */) {
+  const double* X = Xpre != nullptr ? Xpre : t.board_points + 3 * (size_t)(b * d.P + p);
   const double* V = t.view + (size_t)v * (VIEW_STRIDE * (ROLL ? 2 : 1));
   const double* cam = t.cam + (size_t)c * CAM_STRIDE;
   const double bx = X[0], by = X[1], bz = X[2];
@@ -146,10 +147,11 @@ MCBA_HD bool local_is_frame(const Dims& d, int i) {
 // ---------------------------------------------------------------------------------------------------------------
 template <int ND, bool FISH, bool ROLL, bool OPTK>
 MCBA_HD double point_rows(const Dims& d, const Tables& t, int v, int c, int b, int p, double2 ob,
-                                             double* vr /*[2][NV]*/, double* jp = nullptr /*[2][3]: d r / d X_board*/) {
+                                             double* vr /*[2][NV]*/, double* jp = nullptr /*[2][3]: d r / d X_board*/,
+                                             const double* Xpre = nullptr) {
   constexpr int DE = ROLL ? 12 : 6, KI = OPTK ? 4 + ND : 0, NV = DE + KI + 1, KIA = 4 + ND;
   double uv[2], A[6], Kc[2 * KIA], Xs[3], Xe[3], tr;
-  slot_forward<ND, FISH, ROLL, true>(d, t, v, c, b, p, ob, uv, A, Kc, Xs, Xe, tr);
+  slot_forward<ND, FISH, ROLL, true>(d, t, v, c, b, p, ob, uv, A, Kc, Xs, Xe, tr, Xpre);
   const double e[2] = {uv[0] - ob.x, uv[1] - ob.y};
   double rs[2], fs[2], rho = 0.0;
   rho += robust_loss(d.loss, d.f_scale, e[0], &rs[0], &fs[0]);
