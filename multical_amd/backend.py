@@ -258,7 +258,7 @@ class Handle(object):
     S, rhs = _f64(S), _f64(rhs)
     out = np.empty(rhs.size)
     check(self.lib.mcba_debug_chol(self.h, int(rhs.size), _ptr(S, C.c_double), _ptr(rhs, C.c_double), float(reg),
-                                   1 if blocked else 0, _ptr(out, C.c_double)))
+                                   int(blocked), _ptr(out, C.c_double)))
     return out
 
   # --- outlier loop on the device ---------------------------------------------------------------------------------

@@ -89,7 +89,8 @@ struct mcba_handle_s {
   bool own_stream = false;
   bool use_mfma = true;
   bool shard_root = true;
-  size_t chol_lds_set = 0;
+  size_t chol_lds_set = 0, chol_lds2_set = 0;
+  int lin_epoch = 0;
 
   // host copies needed to rebuild the inlier tables
   std::vector<uint8_t> h_valid_ref;    // Calibration.valid, [C,F,B,P] reference order
@@ -98,7 +99,7 @@ struct mcba_handle_s {
   // observation tables
   DevBuf<double2> obs;
   DevBuf<uint8_t> inlier, evalid, fix_aspect;
-  DevBuf<int32_t> obs_index, view_count, board_off, full2act;
+  DevBuf<int32_t> obs_index, view_count, active_views, work_counter, board_off, full2act;
   DevBuf<double> xfull, bwg, img_h, board_points, pose, cam, view, tmat;
   DevBuf<uint16_t> tri;
   DevBuf<long long> dbg;
@@ -156,6 +157,10 @@ const CamOps* pick_ops(int model, int nd) {
   throw Error("pinhole cameras carry 4, 5, 8, 12 or 14 distortion coefficients (cv2.projectPoints)");
 }
 
+void refresh_active_views(mcba_handle_s* h) {
+  hipLaunchKernelGGL(k_active_views, dim3(1), dim3(1024), 0, h->stream, h->d.views(), h->view_count.p, h->active_views.p);
+}
+
 // (re)build inlier table, residual ordering and per-view counts for the shard; mask in reference order or null
 void build_inliers(mcba_handle_s* h, const uint8_t* mask_ref) {
   HostProblem hp;
@@ -167,6 +172,7 @@ void build_inliers(mcba_handle_s* h, const uint8_t* mask_ref) {
   HIP_OK(hipMemcpy(h->inlier.p, hp.inlier.data(), nslot, hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(h->obs_index.p, hp.obs_index.data(), nslot * sizeof(int32_t), hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(h->view_count.p, hp.view_count.data(), hp.view_count.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  refresh_active_views(h);
   h->out_r.alloc((size_t)std::max<int64_t>(2 * hp.n_inliers, 1), false);
 }
 
@@ -209,7 +215,7 @@ void launch_linearize(mcba_handle_s* h) {
   const Dims& d = h->d;
   const int ncol = d.views() * 6 * d.NPB;
   if (ncol > 0) hipLaunchKernelGGL(k_tmat, dim3((ncol + 255) / 256), dim3(256), 0, h->stream, d, h->t);
-  h->ops->linearize(d, h->t, h->stream, h->rec.p, h->tri.p, h->use_mfma);
+  h->ops->linearize(d, h->t, h->stream, h->rec.p, h->tri.p, h->use_mfma, h->lin_epoch++);
 }
 
 void launch_assemble(mcba_handle_s* h) {
@@ -253,11 +259,21 @@ void launch_quadforms(mcba_handle_s* h, const double* u0, const double* u1, int 
 
 
 constexpr size_t CHOL_SINGLE_MAX_LDS = 96 * 1024;
-bool g_force_blocked_chol = false;   // test hook
+bool g_force_blocked_chol = false;   // test hooks
+bool g_force_panel_chol = false;
 
 // (S + reg I) p = rhs for buf = [S (ns x ns) | rhs (ns)]; S is overwritten by its Cholesky factor
 void launch_chol(mcba_handle_s* h, int ns, double reg, double* buf, double* ps) {
   const int max_rows = ns + 1;
+  const size_t lds_packed = ((size_t)(ns + 1) * (ns + 2) / 2 + (ns + 1) + 2) * sizeof(double);
+  if (lds_packed <= 150 * 1024 && !g_force_blocked_chol && !g_force_panel_chol) {
+    if (lds_packed > h->chol_lds2_set) {
+      HIP_OK(hipFuncSetAttribute((const void*)k_chol_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_packed));
+      h->chol_lds2_set = lds_packed;
+    }
+    hipLaunchKernelGGL(k_chol_lds, dim3(1), dim3(1024), lds_packed, h->stream, ns, reg, buf, ps, h->info.p);
+    return;
+  }
   const size_t lds = (size_t)(CHOL_NB + max_rows) * (CHOL_NB + 1) * sizeof(double) + 16;
   if (lds <= CHOL_SINGLE_MAX_LDS && !g_force_blocked_chol) {
     if (lds > h->chol_lds_set) {
@@ -565,6 +581,12 @@ int32_t mcba_create(const mcba_problem* p, void* hip_stream, mcba_handle* out) {
   h->inlier.upload(hp.inlier);
   h->obs_index.upload(hp.obs_index);
   h->view_count.upload(hp.view_count);
+  h->active_views.alloc((size_t)d.views() + 1);
+  h->work_counter.alloc(2);
+  {
+    const int32_t g0[2] = {LIN_GRID_MAX < d.views() ? LIN_GRID_MAX : d.views(), LIN_GRID_MAX < d.views() ? LIN_GRID_MAX : d.views()};
+    HIP_OK(hipMemcpy(h->work_counter.p, g0, sizeof(g0), hipMemcpyHostToDevice));
+  }
   h->n_inliers = hp.n_inliers;
   h->out_r.alloc((size_t)std::max<int64_t>(2 * hp.n_inliers, 1), false);
   h->full2act.upload(hp.full2act);
@@ -582,9 +604,10 @@ int32_t mcba_create(const mcba_problem* p, void* hip_stream, mcba_handle* out) {
 
   Tables& t = h->t;
   t.obs = h->obs.p; t.inlier = h->inlier.p; t.evalid = h->evalid.p; t.obs_index = h->obs_index.p;
-  t.view_count = h->view_count.p; t.board_off = h->board_off.p; t.full2act = h->full2act.p; t.xfull = h->xfull.p;
+  t.view_count = h->view_count.p; t.active_views = h->active_views.p; t.work_counter = h->work_counter.p; t.board_off = h->board_off.p; t.full2act = h->full2act.p; t.xfull = h->xfull.p;
   t.bwg = h->bwg.p; t.img_h = h->img_h.p; t.fix_aspect = h->fix_aspect.p; t.board_points = h->board_points.p;
   t.pose = h->pose.p; t.cam = h->cam.p; t.view = h->view.p; t.tmat = h->tmat.p; t.dbg = nullptr;
+  refresh_active_views(h.get());
 
   // ---- work buffers -----------------------------------------------------------------------------------------
   h->rec.alloc((size_t)d.views() * d.rec_stride);
@@ -844,9 +867,10 @@ int32_t mcba_debug_chol(mcba_handle h, int32_t ns, const double* S, const double
   ps.alloc((size_t)ns);
   HIP_OK(hipMemcpyAsync(buf.p, S, (size_t)ns * ns * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIP_OK(hipMemcpyAsync(buf.p + (size_t)ns * ns, rhs, (size_t)ns * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  g_force_blocked_chol = blocked != 0;
-  try { launch_chol(h, ns, reg, buf.p, ps.p); } catch (...) { g_force_blocked_chol = false; throw; }
-  g_force_blocked_chol = false;
+  g_force_blocked_chol = blocked == 1;   // 0: automatic, 1: multi-workgroup, 2: single-workgroup panel kernel
+  g_force_panel_chol = blocked == 2;
+  try { launch_chol(h, ns, reg, buf.p, ps.p); } catch (...) { g_force_blocked_chol = g_force_panel_chol = false; throw; }
+  g_force_blocked_chol = g_force_panel_chol = false;
   HIP_OK(hipMemcpyAsync(p_out, ps.p, (size_t)ns * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   sync(h);
   int info = 0;
@@ -1065,6 +1089,7 @@ int32_t mcba_reject_outliers(mcba_handle h, const double* x, double threshold, i
   if (d.views() > 0)
     hipLaunchKernelGGL(k_reject, dim3(d.views()), dim3(64), 0, h->stream, d, h->err_fm.p, h->evalid.p, threshold, h->inlier.p,
                        h->view_count.p);
+  refresh_active_views(h);
   const int grid = sel_grid(d);
   if (h->costpart.n < (size_t)2 * grid) h->costpart.alloc((size_t)2 * std::max(grid, COST_BLOCKS_MAX));
   hipLaunchKernelGGL(k_err_sums, dim3(grid), dim3(256), 0, h->stream, h->err_fm.p, h->evalid.p, h->inlier.p, d.slots(),
@@ -1114,7 +1139,7 @@ int32_t mcba_time_linearize(mcba_handle h, const double* x, const mcba_options* 
   sync(h);
   HIP_OK(hipEventRecord(h->ev0, h->stream));
   for (int i = 0; i < repeats; ++i)   // the dominant kernel alone (k_tmat ran in the warm-up), as rocprofv3 reports it
-    h->ops->linearize(h->d, h->t, h->stream, h->rec.p, h->tri.p, h->use_mfma);
+    h->ops->linearize(h->d, h->t, h->stream, h->rec.p, h->tri.p, h->use_mfma, h->lin_epoch++);
   HIP_OK(hipEventRecord(h->ev1, h->stream));
   sync(h);
   float ms = 0.f;

@@ -36,25 +36,26 @@ void jacobian(const Dims& d, const Tables& t, hipStream_t s, int row_nnz, double
 }
 
 template <int MOTION, bool OPTK>
-void lin2(const Dims& d, const Tables& t, hipStream_t s, double* rec, const uint16_t* tri, bool mfma) {
+void lin2(const Dims& d, const Tables& t, hipStream_t s, double* rec, const uint16_t* tri, bool mfma, int epoch) {
   if (d.views() == 0) return;   // empty frame shard
-  const dim3 grid(d.views()), block(64);
+  // persistent wavefronts: 8 single-wave workgroups per CU (2 per SIMD: 256-VGPR budget, 20 KB LDS each) x 256 CUs
+  const dim3 grid(d.views() < LIN_GRID_MAX ? d.views() : LIN_GRID_MAX), block(64);
   if (mfma)
-    hipLaunchKernelGGL((k_linearize<ND_, FISH_, MOTION, OPTK, true>), grid, block, 0, s, d, t, rec, tri);
+    hipLaunchKernelGGL((k_linearize<ND_, FISH_, MOTION, OPTK, true>), grid, block, 0, s, d, t, rec, tri, epoch);
   else
-    hipLaunchKernelGGL((k_linearize<ND_, FISH_, MOTION, OPTK, false>), grid, block, 0, s, d, t, rec, tri);
+    hipLaunchKernelGGL((k_linearize<ND_, FISH_, MOTION, OPTK, false>), grid, block, 0, s, d, t, rec, tri, epoch);
 }
 
 template <int MOTION>
-void lin1(const Dims& d, const Tables& t, hipStream_t s, double* rec, const uint16_t* tri, bool mfma) {
-  if (d.KI > 0) lin2<MOTION, true>(d, t, s, rec, tri, mfma);
-  else lin2<MOTION, false>(d, t, s, rec, tri, mfma);
+void lin1(const Dims& d, const Tables& t, hipStream_t s, double* rec, const uint16_t* tri, bool mfma, int epoch) {
+  if (d.KI > 0) lin2<MOTION, true>(d, t, s, rec, tri, mfma, epoch);
+  else lin2<MOTION, false>(d, t, s, rec, tri, mfma, epoch);
 }
 
-void linearize(const Dims& d, const Tables& t, hipStream_t s, double* rec, const uint16_t* tri, bool mfma) {
-  if (d.motion == MOTION_STATIC) lin1<MOTION_STATIC>(d, t, s, rec, tri, mfma);
-  else if (d.motion == MOTION_ROLLING) lin1<MOTION_ROLLING>(d, t, s, rec, tri, mfma);
-  else lin1<MOTION_HAND_EYE>(d, t, s, rec, tri, mfma);
+void linearize(const Dims& d, const Tables& t, hipStream_t s, double* rec, const uint16_t* tri, bool mfma, int epoch) {
+  if (d.motion == MOTION_STATIC) lin1<MOTION_STATIC>(d, t, s, rec, tri, mfma, epoch);
+  else if (d.motion == MOTION_ROLLING) lin1<MOTION_ROLLING>(d, t, s, rec, tri, mfma, epoch);
+  else lin1<MOTION_HAND_EYE>(d, t, s, rec, tri, mfma, epoch);
 }
 
 template <int MOTION>

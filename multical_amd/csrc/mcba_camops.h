@@ -13,7 +13,7 @@ struct CamOps {
   void (*residual)(const Dims&, const Tables&, hipStream_t, double* r, double* proj, double* err, uint8_t* valid);
   void (*cost)(const Dims&, const Tables&, hipStream_t, double* partial, int nblk);
   void (*jacobian)(const Dims&, const Tables&, hipStream_t, int row_nnz, double* vals, int32_t* cols);
-  void (*linearize)(const Dims&, const Tables&, hipStream_t, double* rec, const uint16_t* tri, bool mfma);
+  void (*linearize)(const Dims&, const Tables&, hipStream_t, double* rec, const uint16_t* tri, bool mfma, int epoch);
   void (*points)(const Dims&, const Tables&, hipStream_t, int n_points, double* Hss, double* Hfs, double* g);
 };
 

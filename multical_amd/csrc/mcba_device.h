@@ -9,6 +9,7 @@ struct double2 { double x, y; };   // host-only builds (tests/hostmath); hipcc p
 
 namespace mcba {
 
+constexpr int LIN_GRID_MAX = 2048;   // persistent k_linearize: 8 single-wave workgroups per CU x 256 CUs
 constexpr int MOTION_STATIC = 0, MOTION_ROLLING = 1, MOTION_HAND_EYE = 2;
 
 // Problem shape + index maps, passed BY VALUE to every kernel (fits the kernarg segment).
@@ -68,6 +69,7 @@ struct Tables {
   const uint8_t* evalid;       // proj.valid & obs.valid  (mask of tables.reprojection_error)
   const int32_t* obs_index;    // index of the observation in the reference's residual ordering, -1 if not an inlier
   const int32_t* view_count;   // [Fl][C][B] inliers per view
+  const int32_t* active_views; // [1 + views]: count, then the indices of the non-empty views (ascending)
   const int32_t* board_off;    // [B+1] prefix of board sizes (points)
   const int32_t* full2act;     // [nfull] full index -> active index or -1
   const double* xfull;         // [nfull] constants for disabled blocks
@@ -78,6 +80,7 @@ struct Tables {
   double* pose;                // [n_pose][POSE_STRIDE]
   double* cam;                 // [C][CAM_STRIDE]
   double* view;                // [Fl][C][B][view_stride]
+  int32_t* work_counter;       // [2] dynamic view hand-out of k_linearize (alternating between launches)
   double* tmat;                // [Fl][C][B][DE*NPC] That columns per view (k_tmat), consumed by k_linearize
   long long* dbg;              // optional [views][8] cycle stamps of k_linearize phases (profiling aid), else null
 };

@@ -339,7 +339,7 @@ constexpr int LIN_MAX_POINTS = 512;    // points per board supported by the comp
 // 24 v_accvgpr_read and a full-latency s_nop (196 instead of 64 cycles per MFMA, measured with s_memtime stamps).
 template <int ND, bool FISH, int MOTION, bool OPTK, bool MFMA>
 __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* __restrict__ rec,
-                                                  const uint16_t* __restrict__ tri) {
+                                                     const uint16_t* __restrict__ tri, int epoch) {
   constexpr bool ROLL = MOTION == MOTION_ROLLING;
   constexpr int DE = ROLL ? 12 : 6, NPB = MOTION == MOTION_STATIC ? 3 : 4, KI = OPTK ? 4 + ND : 0;
   constexpr int NV = DE + KI + 1, NT = (NV + 15) / 16, NVP = 16 * NT, LDV = NVP + 1;
@@ -359,8 +359,17 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
   __shared__ uint16_t pidx[LIN_MAX_POINTS];
   double* Vbuf = Buf;
 
-  const int v = blockIdx.x, lane = threadIdx.x;
+  // persistent wavefronts: the grid holds about as many workgroups as the chip keeps resident and each one walks the
+  // compact list of non-empty views (k_active_views).  One workgroup per view was DISPATCH-bound: ~42 cycles per
+  // launched workgroup x 8000 views = the whole kernel time, with the SIMD slots idle more than half of it.
+  const int lane = threadIdx.x;
+  // (a dynamic hand-out of the views through an atomic counter was measured slower at every size: static stride it is)
+  const int n_active = t.active_views[0];
+  (void)epoch;
+  for (int vi = blockIdx.x; vi < n_active; vi += gridDim.x) {
+  const int v = t.active_views[1 + vi];
   const int b = v % d.B, c = (v / d.B) % d.C, fl = v / (d.B * d.C), f = d.f0 + fl;
+  (void)f;
   long long stamp[6] = {0, 0, 0, 0, 0, 0};
   const bool prof = t.dbg != nullptr;
   if (prof) stamp[0] = clock64();
@@ -380,7 +389,7 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
     double tl[NTL];
 #pragma unroll
     for (int k = 0; k < NTL; ++k) tl[k] = (k * 64 + lane < DE * NPC) ? tg[k * 64 + lane] : 0.0;
-    if (view_cnt == 0) return;
+    if (view_cnt == 0) continue;   // cannot happen with the compact list; kept for safety
 #pragma unroll
     for (int k = 0; k < NTL; ++k)
       if (k * 64 + lane < DE * NPC) Tm[k * 64 + lane] = tl[k];
@@ -652,6 +661,8 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
       o[6] = stamp[5] - stamp[4];                 // setup part 2: staging clear + inlier loads
       o[7] = clock64() - stamp[0];                // lifetime
     }
+  }
+  lds_fence();   // the next view reuses the LDS buffers
   }
 }
 

@@ -579,6 +579,60 @@ __global__ __launch_bounds__(1024) void k_chol_solve(int ns, double reg, double*
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// LDS-resident Cholesky solve for the common small reduced systems (ns <= ~190: cameras + intrinsics + board poses).
+// The lower triangle of the (ns+1) x (ns+1) matrix [S rhs; rhs^T *] lives packed in LDS (80 KB at ns = 140); the
+// right-hand side is its last row, so the forward substitution is part of the factorisation.  Right-looking, one column
+// per step: phase 1 scales the column into a side vector, phase 2 is the rank-1 update of the trailing triangle by the
+// whole workgroup (32 x 32 thread tile), two barriers per column.  Then a barrier-per-row backward substitution.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int pk(int i, int j) { return i * (i + 1) / 2 + j; }   // j <= i
+
+__global__ __launch_bounds__(1024) void k_chol_lds(int ns, double reg, const double* __restrict__ buf,
+                                                   double* __restrict__ ps, int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) double chol_l[];
+  const int n1 = ns + 1;
+  double* L = chol_l;                          // packed lower triangle, n1 (n1 + 1) / 2
+  double* col = chol_l + n1 * (n1 + 1) / 2;    // scaled current column, n1
+  int* bad = reinterpret_cast<int*>(col + n1);
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  if (tid == 0) *bad = 0;
+  // rows of buf: S rows then the rhs row (row ns); flat loop so that many independent global loads are in flight
+#pragma unroll 4
+  for (int e = tid; e < n1 * ns; e += nthr) {
+    const int i = e / ns, j = e - i * ns;
+    if (j <= i) L[pk(i, j)] = buf[e] + ((i == j) ? reg : 0.0);
+  }
+  __syncthreads();
+  const int tx = tid & 31, ty = tid >> 5, nty = nthr >> 5;
+  for (int j = 0; j < ns; ++j) {
+    double dj = L[pk(j, j)];
+    if (!(dj > 0.0)) { if (tid == 0 && *bad == 0) *bad = j + 1; dj = 1e-300; }
+    const double inv = 1.0 / sqrt(dj);
+    for (int i = j + 1 + tid; i < n1; i += nthr) col[i] = L[pk(i, j)] * inv;
+    __syncthreads();
+    for (int i = j + 1 + tid; i < n1; i += nthr) L[pk(i, j)] = col[i];
+    if (tid == 0) L[pk(j, j)] = sqrt(dj);
+    for (int i = j + 1 + ty; i < n1; i += nty) {
+      const double ci = col[i];
+      double* Li = L + pk(i, 0);
+      for (int k = j + 1 + tx; k <= i && k < ns; k += 32) Li[k] -= ci * col[k];
+    }
+    __syncthreads();
+  }
+  // backward substitution  L^T p = y,  y = row ns
+  double* y = L + pk(ns, 0);
+  for (int i = ns - 1; i >= 0; --i) {
+    const double pi = y[i] / L[pk(i, i)];
+    __syncthreads();
+    if (tid == 0) { y[i] = pi; ps[i] = pi; }
+    const double* Li = L + pk(i, 0);
+    for (int k = tid; k < i; k += nthr) y[k] -= Li[k] * pi;
+    __syncthreads();
+  }
+  if (tid == 0) info[0] = *bad;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Multi-workgroup blocked Cholesky for large reduced systems (adjust_board: ns = shared + 3 x #board points, up to a
 // few thousand).  Same data layout as k_chol_solve ((ns+1) x ns, row ns = rhs), 64-column panels, three launches per
 // panel: diagonal block (one workgroup), panel solve (one row per thread), symmetric rank-64 trailing update with
@@ -882,6 +936,33 @@ __global__ void k_reject(Dims d, const double* __restrict__ err, const uint8_t* 
   }
   const double tot = block_reduce<false>(cnt, scratch);
   if (threadIdx.x == 0) view_count[v] = (int32_t)tot;
+}
+
+// compact list of the non-empty views: out[0] = count, out[1..] = view indices in ascending order (single workgroup)
+__global__ void k_active_views(int nviews, const int32_t* __restrict__ view_count, int32_t* __restrict__ out) {
+  __shared__ int wave_tot[16];
+  __shared__ int base;
+  if (threadIdx.x == 0) base = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int v0 = 0; v0 < nviews; v0 += blockDim.x) {
+    const int v = v0 + threadIdx.x;
+    const bool on = v < nviews && view_count[v] != 0;
+    const unsigned long long m = __ballot(on);
+    if (lane == 0) wave_tot[wave] = __popcll(m);
+    __syncthreads();
+    int off = base;
+    for (int w = 0; w < wave; ++w) off += wave_tot[w];
+    if (on) out[1 + off + __popcll(m & ((1ull << lane) - 1ull))] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int tot = 0;
+      for (int w = 0; w < nw; ++w) tot += wave_tot[w];
+      base += tot;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = base;
 }
 
 // frame-major inlier table -> reference [C,F,B,P] order (only this shard's frames are written)

@@ -325,10 +325,10 @@ def test_adjust_board_rolling_and_handeye_blocks():
       assert np.abs(fd - J[:, j]).max() <= 1e-5 * max(np.abs(J[:, j]).max(), 1.0), (name, j)
 
 
-@pytest.mark.parametrize("ns,blocked", [(40, False), (40, True), (200, False), (200, True), (333, True), (700, True),
-                                        (1500, True)])
+@pytest.mark.parametrize("ns,blocked", [(18, 0), (40, 0), (40, 1), (40, 2), (140, 0), (190, 0), (200, 0), (200, 1), (200, 2),
+                                        (333, 1), (700, 0), (1500, 1)])
 def test_device_cholesky_paths(ns, blocked):
-  """single-workgroup (LDS panels) and multi-workgroup (MFMA trailing update) Cholesky solves vs numpy."""
+  """LDS-resident (0, small ns), single-workgroup panel (2) and multi-workgroup MFMA (1) Cholesky solves vs numpy."""
   rng = np.random.default_rng(ns)
   M = rng.normal(size=(ns + 20, ns))
   S = M.T @ M / ns + 0.1 * np.eye(ns)
