@@ -321,6 +321,11 @@ def make_rig(name_or_cfg, frames=None, seed=None, noise=0.2, outlier_frac=0.01, 
         ok &= np.arctan2(np.hypot(Xc[..., 0], Xc[..., 1]), Xc[..., 2]) < np.deg2rad(75)
       else:
         ok &= np.hypot(Xc[..., 0], Xc[..., 1]) < 0.62 * Xc[..., 2]  # stay inside the monotone range of the radial model
+      if motion == "rolling":
+        # both ends of the scan must see the point too: otherwise the scan-time fixed point above can run away
+        # (t >> 1) and produce an observation that is inconsistent with t = y_observed / height
+        for Xq in (X0, X1):
+          ok &= (Xq[..., 2] > 0.1) & (np.hypot(Xq[..., 0], Xq[..., 1]) < 0.62 * Xq[..., 2])
       v = ok & view_vis[c][..., None] & point_vis[c]
       # a detector reports a board only when enough corners are found (charuco.py:99-101)
       v &= (v.sum(axis=-1) >= 12)[..., None]
