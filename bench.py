@@ -98,10 +98,10 @@ def main():
   rig = synthetic.make_rig("cfg3", frames=F_total, obs_frames=shard)
   calib = calibration.from_rig(rig)
   x0 = calib.param_vec
-  stream = torch.cuda.current_stream().cuda_stream
-  h = Handle(lower(calib), frame_range=shard if world > 1 else None, stream=stream)
+  tstream = torch.cuda.Stream()    # kernels and RCCL collectives share this (non-default) stream
+  h = Handle(lower(calib), frame_range=shard if world > 1 else None, stream=tstream.cuda_stream)
   if world > 1:
-    h.set_allreduce(mdist.make_allreduce_hook())
+    h.set_allreduce(mdist.make_allreduce_hook(stream=tstream))
     h.set_shard_root(rank == 0)
   n_slots = int(np.prod(rig.valid.shape[0:1] + (FRAMES_PER_SHARD,) + rig.valid.shape[2:]))
   n_obs = h.n_residuals // 2

@@ -66,7 +66,12 @@ struct DevBuf {
     n = count;
     const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
     HIP_OK(hipMalloc((void**)&p, bytes));
-    if (zero) HIP_OK(hipMemset(p, 0, bytes));
+    if (zero) {
+      // hipMemset runs on the NULL stream and is asynchronous w.r.t. the host; the handle's stream may be a
+      // non-blocking one (torch.cuda.Stream), which is not ordered against it -> wait here
+      HIP_OK(hipMemset(p, 0, bytes));
+      HIP_OK(hipStreamSynchronize(nullptr));
+    }
   }
   void upload(const std::vector<T>& h) {
     alloc(h.size(), h.empty());

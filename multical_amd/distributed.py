@@ -47,22 +47,29 @@ class _DevArray(object):
                                          strides=None)
 
 
-def make_allreduce_hook(group=None, device=None):
-  """Returns fn(ptr, count, op, stream) for Handle.set_allreduce, backed by torch.distributed."""
+def make_allreduce_hook(group=None, device=None, stream=None):
+  """Returns fn(ptr, count, op, stream) for Handle.set_allreduce, backed by torch.distributed.
+
+  `stream` is the torch.cuda.Stream the handle was created on: the collective is enqueued inside
+  `torch.cuda.stream(stream)`, i.e. ordered after the kernels that produced the buffer and before the ones that
+  consume it, without a host synchronisation (nccl) -- no reliance on legacy default-stream semantics."""
+  import contextlib
   import torch
   import torch.distributed as dist
   backend = dist.get_backend(group)
   dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
 
-  def hook(ptr, count, op, stream):
-    t = torch.as_tensor(_DevArray(ptr, count), device=dev)
-    rop = dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX
-    if backend == "nccl":
-      dist.all_reduce(t, op=rop, group=group)          # RCCL, in place, ordered on torch's current stream
-    else:
-      host = t.cpu()                                   # gloo: stage through host memory
-      dist.all_reduce(host, op=rop, group=group)
-      t.copy_(host)
+  def hook(ptr, count, op, raw_stream):
+    ctx = torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
+    with ctx:
+      t = torch.as_tensor(_DevArray(ptr, count), device=dev)
+      rop = dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX
+      if backend == "nccl":
+        dist.all_reduce(t, op=rop, group=group)        # RCCL over xGMI, in place
+      else:
+        host = t.cpu()                                 # gloo: stage through host memory
+        dist.all_reduce(host, op=rop, group=group)
+        t.copy_(host)
     return 0
 
   return hook
@@ -81,10 +88,11 @@ def sharded_handle(calib, rank=None, world_size=None, group=None, balance=True):
     inl = calib.inliers
     weights = inl.sum(axis=(0, 2, 3)).astype(np.float64)
   shards = frame_shards(prob.shape[1], world_size, weights)
-  stream = torch.cuda.current_stream().cuda_stream
-  h = Handle(prob, frame_range=shards[rank], stream=stream)
+  tstream = torch.cuda.Stream()                       # dedicated (non-default) stream shared by kernels and collectives
+  h = Handle(prob, frame_range=shards[rank], stream=tstream.cuda_stream)
+  h.torch_stream = tstream                            # keep it alive as long as the handle
   if world_size > 1:
-    h.set_allreduce(make_allreduce_hook(group))
+    h.set_allreduce(make_allreduce_hook(group, stream=tstream))
     h.set_shard_root(rank == 0)
   h.frame_range = shards[rank]
   return h
