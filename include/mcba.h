@@ -215,6 +215,8 @@ int32_t mcba_time_residuals(mcba_handle h, const double* x, int32_t repeats, dou
 /* 1 = accumulate V^T V and the Schur SYRK with v_mfma_f64_16x16x4_f64 (default); 0 = identical data flow with plain
  * FMAs (validation build of the same kernels).  The environment variable MCBA_NO_MFMA=1 sets the initial value.  */
 int32_t mcba_set_mfma(mcba_handle h, int32_t on);
+/* number of persistent k_linearize workgroups; 0 = automatic (profiling aid)                                        */
+int32_t mcba_debug_set_lin_grid(mcba_handle h, int32_t grid);
 /* regularised Gauss-Newton direction (H_h + reg I)^-1 g_h in the column-scaled space, computed by the Schur /
  * Cholesky kernels after a preceding mcba_normal_equations at the same x; g_h and scale_inv may be NULL.           */
 int32_t mcba_debug_gn_step(mcba_handle h, double reg, double* gn_h, double* g_h, double* scale_inv);

@@ -76,6 +76,7 @@ SYMBOLS = [
   ("mcba_time_linearize", C.c_int32, [H, c_double_p, C.POINTER(Options), C.c_int32, c_double_p]),
   ("mcba_time_residuals", C.c_int32, [H, c_double_p, C.c_int32, c_double_p]),
   ("mcba_set_mfma", C.c_int32, [H, C.c_int32]),
+  ("mcba_debug_set_lin_grid", C.c_int32, [H, C.c_int32]),
   ("mcba_debug_gn_step", C.c_int32, [H, C.c_double, c_double_p, c_double_p, c_double_p]),
   ("mcba_debug_mfma_probe", C.c_int32, [c_double_p, c_double_p]),
   ("mcba_debug_chol", C.c_int32, [H, C.c_int32, c_double_p, c_double_p, C.c_double, C.c_int32, c_double_p]),

@@ -182,6 +182,9 @@ class Handle(object):
   def set_mfma(self, on):
     check(self.lib.mcba_set_mfma(self.h, 1 if on else 0))
 
+  def set_lin_grid(self, grid):
+    check(self.lib.mcba_debug_set_lin_grid(self.h, int(grid)))
+
   def set_inliers(self, mask):
     if mask is None:
       check(self.lib.mcba_set_inliers(self.h, None))

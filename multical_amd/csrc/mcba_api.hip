@@ -94,8 +94,8 @@ struct mcba_handle_s {
   bool own_stream = false;
   bool use_mfma = true;
   bool shard_root = true;
-  size_t chol_lds_set = 0, chol_lds2_set = 0;
-  int lin_epoch = 0;
+  size_t chol_lds_set = 0, chol_lds2_set = 0, chol_lds3_set = 0;
+  int lin_grid = 0;          // 0 = automatic (see lin2), > 0 = forced number of persistent workgroups (debug)
 
   // host copies needed to rebuild the inlier tables
   std::vector<uint8_t> h_valid_ref;    // Calibration.valid, [C,F,B,P] reference order
@@ -220,7 +220,7 @@ void launch_linearize(mcba_handle_s* h) {
   const Dims& d = h->d;
   const int ncol = d.views() * 6 * d.NPB;
   if (ncol > 0) hipLaunchKernelGGL(k_tmat, dim3((ncol + 255) / 256), dim3(256), 0, h->stream, d, h->t);
-  h->ops->linearize(d, h->t, h->stream, h->rec.p, h->tri.p, h->use_mfma, h->lin_epoch++);
+  h->ops->linearize(d, h->t, h->stream, h->rec.p, h->tri.p, h->use_mfma, h->lin_grid);
 }
 
 void launch_assemble(mcba_handle_s* h) {
@@ -252,7 +252,17 @@ void fetch_scalars(mcba_handle_s* h, int count) {
   sync(h);
 }
 
-// quadratic forms + dots of (u0, u1) -> scal[off .. off+6)
+// Cauchy curvature g_h^T (D H D) g_h -> scal[off]
+constexpr int Q00_BLOCKS = 512;
+void launch_q00(mcba_handle_s* h, const double* u, int off) {
+  const Dims& d = h->d;
+  hipLaunchKernelGGL(k_q00, dim3(Q00_BLOCKS), dim3(256), 0, h->stream, d, h->Hss.p, h->Hfs.p, h->Hff.p, h->dsc.p, u,
+                     h->qpart.p);
+  hipLaunchKernelGGL(k_q00_final, dim3(1), dim3(256), 0, h->stream, h->qpart.p, Q00_BLOCKS, h->scal.p + off);
+  call_allreduce(h, h->scal.p + off, 1, 0);
+}
+
+// quadratic forms + dots of (u0, u1) -> scal[off .. off+6)   (two-vector version: debug / validation only)
 void launch_quadforms(mcba_handle_s* h, const double* u0, const double* u1, int off) {
   const Dims& d = h->d;
   const int nblk = (d.DF > 0 ? d.Fl : 0) + 1;
@@ -266,11 +276,22 @@ void launch_quadforms(mcba_handle_s* h, const double* u0, const double* u1, int 
 constexpr size_t CHOL_SINGLE_MAX_LDS = 96 * 1024;
 bool g_force_blocked_chol = false;   // test hooks
 bool g_force_panel_chol = false;
+bool g_force_column_chol = false;
+long long* g_chol_prof = nullptr;    // device buffer of 8 phase stamps (mcba_debug_chol, blocked == 4)
 
 // (S + reg I) p = rhs for buf = [S (ns x ns) | rhs (ns)]; S is overwritten by its Cholesky factor
 void launch_chol(mcba_handle_s* h, int ns, double reg, double* buf, double* ps) {
   const int max_rows = ns + 1;
   const size_t lds_packed = ((size_t)(ns + 1) * (ns + 2) / 2 + (ns + 1) + 2) * sizeof(double);
+  if (ns + 1 <= CHOL_BLK_MAX_N1 && !g_force_blocked_chol && !g_force_panel_chol && !g_force_column_chol) {
+    const size_t lds_blk = chol_blk_lds_bytes(ns);
+    if (lds_blk > h->chol_lds3_set) {
+      HIP_OK(hipFuncSetAttribute((const void*)k_chol_blk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_blk));
+      h->chol_lds3_set = lds_blk;
+    }
+    hipLaunchKernelGGL(k_chol_blk, dim3(1), dim3(CHOL_BLK_THREADS), lds_blk, h->stream, ns, reg, buf, ps, h->info.p, g_chol_prof);
+    return;
+  }
   if (lds_packed <= 150 * 1024 && !g_force_blocked_chol && !g_force_panel_chol) {
     if (lds_packed > h->chol_lds2_set) {
       HIP_OK(hipFuncSetAttribute((const void*)k_chol_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_packed));
@@ -625,7 +646,7 @@ int32_t mcba_create(const mcba_problem* p, void* hip_stream, mcba_handle* out) {
   h->gbuf.alloc(2 * (size_t)d.n + 2);
   for (DevBuf<double>* b : {&h->x, &h->xnew, &h->scale_inv, &h->dsc, &h->gh, &h->gn}) b->alloc((size_t)d.n);
   h->scal.alloc(N_SCALARS);
-  h->qpart.alloc(3 * (size_t)(d.Fl + 1));
+  h->qpart.alloc(std::max<size_t>(3 * (size_t)(d.Fl + 1), Q00_BLOCKS));
   h->cost_blocks = std::max(1, std::min(COST_BLOCKS_MAX, (int)((nslot + 255) / 256)));
   h->costpart.alloc((size_t)h->cost_blocks);
   h->Lf.alloc((size_t)d.Fl * d.DF * d.DF);
@@ -721,6 +742,14 @@ int32_t mcba_set_mfma(mcba_handle h, int32_t on) {
   API_BEGIN
   REQUIRE(h, "null handle");
   h->use_mfma = on != 0;
+  API_END
+}
+
+// debug knob: number of persistent k_linearize workgroups (0 = automatic)
+int32_t mcba_debug_set_lin_grid(mcba_handle h, int32_t grid) {
+  API_BEGIN
+  REQUIRE(h && grid >= 0, "bad argument");
+  h->lin_grid = grid;
   API_END
 }
 
@@ -874,8 +903,24 @@ int32_t mcba_debug_chol(mcba_handle h, int32_t ns, const double* S, const double
   HIP_OK(hipMemcpyAsync(buf.p + (size_t)ns * ns, rhs, (size_t)ns * sizeof(double), hipMemcpyHostToDevice, h->stream));
   g_force_blocked_chol = blocked == 1;   // 0: automatic, 1: multi-workgroup, 2: single-workgroup panel kernel
   g_force_panel_chol = blocked == 2;
-  try { launch_chol(h, ns, reg, buf.p, ps.p); } catch (...) { g_force_blocked_chol = g_force_panel_chol = false; throw; }
-  g_force_blocked_chol = g_force_panel_chol = false;
+  g_force_column_chol = blocked == 3;    // 3: column-by-column LDS kernel (the round-1 baseline of k_chol_blk)
+  DevBuf<long long> stamps;
+  if (blocked == 4) {                    // 4: k_chol_blk with phase stamps; p_out[0..7] receives the shader-clock totals
+    REQUIRE(ns >= 8 && ns + 1 <= CHOL_BLK_MAX_N1, "profiling needs 8 <= ns < 160");
+    stamps.alloc(8);
+    g_chol_prof = stamps.p;
+  }
+  try { launch_chol(h, ns, reg, buf.p, ps.p); }
+  catch (...) { g_force_blocked_chol = g_force_panel_chol = g_force_column_chol = false; g_chol_prof = nullptr; throw; }
+  g_force_blocked_chol = g_force_panel_chol = g_force_column_chol = false;
+  g_chol_prof = nullptr;
+  if (blocked == 4) {
+    long long st[8];
+    sync(h);
+    HIP_OK(hipMemcpy(st, stamps.p, sizeof(st), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 8; ++i) p_out[i] = (double)st[i];
+    return 0;
+  }
   HIP_OK(hipMemcpyAsync(p_out, ps.p, (size_t)ns * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   sync(h);
   int info = 0;
@@ -928,7 +973,7 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
     // ---- gradient scaling + Cauchy-step curvature (one sync) -------------------------------------------------
     hipLaunchKernelGGL(k_vec_scale, dim3(1), dim3(1024), 0, h->stream, d, h->x.p, h->g(), h->diag(), h->scale_inv.p,
                        h->dsc.p, h->gh.p, first ? 1 : 0, h->scal.p);
-    launch_quadforms(h, h->gh.p, h->gh.p, 4);
+    launch_q00(h, h->gh.p, 4);
     HIP_OK(hipMemcpyAsync(h->scal.p + 16, h->costcount(), 2 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     fetch_scalars(h, 18);
     if (fresh_lin) { collect_lin_time(); fresh_lin = false; }
@@ -956,7 +1001,7 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
 
     // ---- regularised Gauss-Newton step + 2-D subspace (one sync) ---------------------------------------------
     launch_gn_solve(h, reg, is_root);
-    launch_quadforms(h, h->gh.p, h->gn.p, 4);
+    hipLaunchKernelGGL(k_dots3, dim3(1), dim3(1024), 0, h->stream, d.n, h->gh.p, h->gn.p, h->scal.p + 7);
     HIP_OK(hipMemcpyAsync(h->scal.p + 12, h->info.p, sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
     fetch_scalars(h, 13);
     {
@@ -966,8 +1011,10 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
         throw Error("reduced normal equations are not positive definite (pivot " + std::to_string(chol_info) +
                     "); non-finite Jacobian?");
     }
-    const double Q00 = h->h_scal[4], Q01 = h->h_scal[5], Q11 = h->h_scal[6];
     const double d00 = h->h_scal[7], d01 = h->h_scal[8], d11 = h->h_scal[9];
+    // H_h gn = g_h - reg gn by construction of the step, so the forms with gn need no further pass over H:
+    //   g_h^T H_h gn = |g_h|^2 - reg g_h.gn,   gn^T H_h gn = g_h.gn - reg |gn|^2
+    const double Q00 = q00, Q01 = d00 - reg * d01, Q11 = d01 - reg * d11;
     // orthonormal basis [e0 e1] = [u0 u1] Cm of span{g_h, gn_h} (Gram-Schmidt on the 2x2 Gram matrix)
     const double n0 = std::sqrt(d00);
     const double proj = d01 / d00;
@@ -1144,7 +1191,7 @@ int32_t mcba_time_linearize(mcba_handle h, const double* x, const mcba_options* 
   sync(h);
   HIP_OK(hipEventRecord(h->ev0, h->stream));
   for (int i = 0; i < repeats; ++i)   // the dominant kernel alone (k_tmat ran in the warm-up), as rocprofv3 reports it
-    h->ops->linearize(h->d, h->t, h->stream, h->rec.p, h->tri.p, h->use_mfma, h->lin_epoch++);
+    h->ops->linearize(h->d, h->t, h->stream, h->rec.p, h->tri.p, h->use_mfma, h->lin_grid);
   HIP_OK(hipEventRecord(h->ev1, h->stream));
   sync(h);
   float ms = 0.f;

@@ -39,7 +39,8 @@ template <int MOTION, bool OPTK>
 void lin2(const Dims& d, const Tables& t, hipStream_t s, double* rec, const uint16_t* tri, bool mfma, int epoch) {
   if (d.views() == 0) return;   // empty frame shard
   // persistent wavefronts: 8 single-wave workgroups per CU (2 per SIMD: 256-VGPR budget, 20 KB LDS each) x 256 CUs
-  const dim3 grid(d.views() < LIN_GRID_MAX ? d.views() : LIN_GRID_MAX), block(64);
+  const int want = epoch > 0 ? epoch : LIN_GRID_MAX;   // the last argument carries the debug grid override
+  const dim3 grid(d.views() < want ? d.views() : want), block(64);
   if (mfma)
     hipLaunchKernelGGL((k_linearize<ND_, FISH_, MOTION, OPTK, true>), grid, block, 0, s, d, t, rec, tri, epoch);
   else

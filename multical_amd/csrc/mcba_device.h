@@ -9,7 +9,10 @@ struct double2 { double x, y; };   // host-only builds (tests/hostmath); hipcc p
 
 namespace mcba {
 
-constexpr int LIN_GRID_MAX = 2048;   // persistent k_linearize: 8 single-wave workgroups per CU x 256 CUs
+// persistent k_linearize: 2048 single-wave workgroups are resident (8 per CU x 256 CUs); launching 1.5x that many lets
+// the dispatcher hand the last third out as slots free up, which evens out the per-view cost spread (measured at the
+// north-star rig: 2048 -> 95.7 us, 2560..4096 -> 81.5..82 us, 1467 (exactly 3 views each) -> 112 us).
+constexpr int LIN_GRID_MAX = 3072;
 constexpr int MOTION_STATIC = 0, MOTION_ROLLING = 1, MOTION_HAND_EYE = 2;
 
 // Problem shape + index maps, passed BY VALUE to every kernel (fits the kernarg segment).

@@ -351,10 +351,12 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
   constexpr int TW = NV - 16;
   constexpr bool TAILV = MFMA && NT == 2 && TW <= 7;
   constexpr int NTAIL = TAILV ? TW * (TW + 1) / 2 : 1;
-  constexpr int STAGE = ROWS * LDV, EPI = NVP * NVP;
+  // epilogue footprint: S (NVP^2), Y (DE x 16 ceil(NPC/16)) and the packed record
+  constexpr int STAGE = ROWS * LDV;
+  constexpr int EPI = NVP * NVP + (MFMA ? DE * 16 * ((NPC + 15) / 16) + (REC + 2 + 1) / 2 * 2 : 0);
   constexpr int BUF = STAGE > EPI ? STAGE : EPI;
 
-  __shared__ double Buf[BUF];            // staging rows during the main loop; [S | Y] in the epilogue
+  __shared__ __attribute__((aligned(16))) double Buf[BUF];   // staging rows in the main loop; [S | Y | M] in the epilogue
   __shared__ double Tm[DE * NPC];
   __shared__ uint16_t pidx[LIN_MAX_POINTS];
   double* Vbuf = Buf;
@@ -513,55 +515,90 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
   }
 
   if (prof) stamp[3] = clock64();
-  // cross-lane reduction of the VALU corner: transpose through the (now free) staging buffer, lane e sums row e
+  // The epilogue indices only depend on the lane, so the compiler hoists them out of the view loop and then SPILLS them
+  // (the row evaluation needs the whole register budget): every store was preceded by a scratch reload and an
+  // s_waitcnt vmcnt(0), i.e. it waited for the previous global store to retire.  An opaque copy of the lane id keeps
+  // the index arithmetic (a handful of integer ops) inside the epilogue.
+  int el;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(el) : "v"(lane));
+  // cross-lane reduction of the VALU corner: transpose through the (now free) staging buffer; PARTS lanes share a row,
+  // each issues all its LDS reads before the first add, and lane (i0, i1) of a TW x TW layout gathers the partial sums
   double tail_red = 0.0;
   if constexpr (TAILV) {
-    static_assert(NTAIL * 65 <= BUF, "tail transpose does not fit");
+    constexpr int PARTS = (64 / NTAIL) > 4 ? 4 : (64 / NTAIL), SEG = (64 + PARTS - 1) / PARTS;
+    static_assert(NTAIL * 65 + 64 <= BUF, "tail transpose does not fit");
+    static_assert(PARTS >= 1 && TW * TW <= 64, "tail layout");
 #pragma unroll
-    for (int e = 0; e < NTAIL; ++e) Buf[e * 65 + lane] = tail[e];
+    for (int e = 0; e < NTAIL; ++e) Buf[e * 65 + el] = tail[e];
     lds_fence();
-    if (lane < NTAIL) {
-      const double* row = Buf + lane * 65;
-#pragma unroll 16
-      for (int k = 0; k < 64; ++k) tail_red += row[k];
+    double part = 0.0;
+    {
+      const int e = el % NTAIL, pt = el / NTAIL;
+      if (pt < PARTS) {
+        double vals[SEG];
+        const double* row = Buf + e * 65 + pt * SEG;
+#pragma unroll
+        for (int k = 0; k < SEG; ++k) vals[k] = row[k];
+#pragma unroll
+        for (int k = 0; k < SEG; ++k)
+          if (pt * SEG + k >= 64) vals[k] = 0.0;
+#pragma unroll
+        for (int w = 1; w < SEG; w *= 2)
+#pragma unroll
+          for (int k = 0; k + w < SEG; k += 2 * w) vals[k] += vals[k + w];
+        part = vals[0];
+      }
+    }
+    lds_fence();
+    Buf[NTAIL * 65 + el] = part;
+    lds_fence();
+    {
+      const int i0 = el / TW, i1 = el % TW;
+      if (el < TW * TW) {
+        const int lo = i0 < i1 ? i0 : i1, hi = i0 < i1 ? i1 : i0;
+        const int e = lo * TW - (lo * (lo - 1)) / 2 + (hi - lo);
+#pragma unroll
+        for (int pt = 0; pt < PARTS; ++pt) tail_red += Buf[NTAIL * 65 + pt * NTAIL + e];
+      }
     }
     lds_fence();
   }
   // S -> LDS (full symmetric matrix), time-sharing the staging buffer
   double* Sbuf = Buf;
   if constexpr (MFMA) {
-    const int rsub = lane >> 4, csub = lane & 15;
+    const int rsub = el >> 4, csub = el & 15;
     int ti = 0;
     for (int t0 = 0; t0 < NT; ++t0)
-      for (int t1 = t0; t1 < NT; ++t1, ++ti)
+      for (int t1 = t0; t1 < NT; ++t1, ++ti) {
+        if (TAILV && t0 == 1) continue;
         for (int r = 0; r < 4; ++r) {
           const int row = 16 * t0 + rsub + 4 * r, col = 16 * t1 + csub;
           Sbuf[row * NVP + col] = accm[ti][r];
           if (t0 != t1) Sbuf[col * NVP + row] = accm[ti][r];
         }
+      }
   } else {
     constexpr int IW = NVP, JW = NACC_V;
-    const int ii = lane % IW, j0 = (lane / IW) * JW;
+    const int ii = el % IW, j0 = (el / IW) * JW;
     for (int jj = 0; jj < JW; ++jj) Sbuf[ii * NVP + j0 + jj] = accv[jj];
   }
-  if constexpr (TAILV) {   // lanes e < NTAIL carry the reduced corner entries computed above
-    if (lane < NTAIL) {
-      int i0 = 0, rem = lane;
-      while (rem >= TW - i0) { rem -= TW - i0; ++i0; }
-      const int i1 = i0 + rem;
-      Sbuf[(16 + i0) * NVP + 16 + i1] = tail_red;
-      Sbuf[(16 + i1) * NVP + 16 + i0] = tail_red;
-    }
+  if constexpr (TAILV) {   // lane (i0, i1) carries the reduced corner entry computed above
+    if (el < TW * TW) Sbuf[(16 + el / TW) * NVP + 16 + el % TW] = tail_red;
   }
   lds_fence();
 
   double* out = rec + (size_t)v * d.rec_stride;
+  long long ep0 = 0, ep1 = 0;
+  if (prof) ep0 = clock64();
   if constexpr (MFMA) {
     // epilogue on the matrix pipe:  Y = S_EE That,  M_pp = That^T Y,  M_pK = That^T S_E,[K r]   (16x16x4 tiles, K = DE)
+    // M is assembled in LDS in the packed record order and leaves the CU with fully coalesced 16-byte stores.
     constexpr int NPCT = (NPC + 15) / 16, NPCP = 16 * NPCT, KR = KI + 1, KRT = (KR + 15) / 16, KS = (DE + 3) / 4;
-    static_assert(NVP * NVP + DE * NPCP <= BUF, "Y does not fit behind S");
+    constexpr int RECP = (REC + 2 + 1) / 2 * 2;                      // == d.rec_stride
+    static_assert(NVP * NVP + DE * NPCP + RECP <= BUF, "Y and the packed record do not fit behind S");
     double* Yb = Buf + NVP * NVP;                                   // [DE][NPCP]
-    const int rsub = lane >> 4, csub = lane & 15;
+    double* Mp = Yb + DE * NPCP;                                    // packed upper triangle + cost, count
+    const int rsub = el >> 4, csub = el & 15;
     for (int tj = 0; tj < NPCT; ++tj) {                             // step 1: Y
       double4_t acc = {0.0, 0.0, 0.0, 0.0};
       for (int ks = 0; ks < KS; ++ks) {
@@ -576,11 +613,17 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
       }
     }
     lds_fence();
+    if (prof) ep1 = clock64();
     for (int ti = 0; ti < NPCT; ++ti) {
       double av[KS];
       for (int ks = 0; ks < KS; ++ks) {
         const int k = 4 * ks + rsub, ic = 16 * ti + csub;
         av[ks] = (k < DE && ic < NPC) ? Tm[k * NPC + ic] : 0.0;
+      }
+      int rowoff[4];                                                // packed offset of row i:  i (2 N1 - 1 - i) / 2
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * ti + rsub + 4 * r;
+        rowoff[r] = (i * (2 * N1 - 1 - i)) / 2;
       }
       for (int tj = ti; tj < NPCT; ++tj) {                          // step 2: pose x pose
         double4_t acc = {0.0, 0.0, 0.0, 0.0};
@@ -591,7 +634,7 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
         }
         for (int r = 0; r < 4; ++r) {
           const int i = 16 * ti + rsub + 4 * r, j = 16 * tj + csub;
-          if (i <= j && j < NPC) out[tri_index(i, j, N1)] = acc[r];
+          if (i <= j && j < NPC) Mp[rowoff[r] + j] = acc[r];
         }
       }
       for (int tk = 0; tk < KRT; ++tk) {                            // step 3: pose x (intrinsics | residual)
@@ -603,14 +646,24 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
         }
         for (int r = 0; r < 4; ++r) {
           const int i = 16 * ti + rsub + 4 * r, jc = 16 * tk + csub;
-          if (i < NPC && jc < KR) out[tri_index(i, NPC + jc, N1)] = acc[r];
+          if (i < NPC && jc < KR) Mp[rowoff[r] + NPC + jc] = acc[r];
         }
       }
     }
-    for (int e = lane; e < KR * KR; e += 64) {                      // step 4: (intrinsics | residual)^2 block = copy of S
+    for (int e = el; e < KR * KR; e += 64) {                        // step 4: (intrinsics | residual)^2 block = copy of S
       const int i = e / KR, j = e % KR;
-      if (i <= j) out[tri_index(NPC + i, NPC + j, N1)] = Sbuf[(DE + i) * NVP + DE + j];
+      if (i <= j) Mp[((NPC + i) * (2 * N1 - 1 - (NPC + i))) / 2 + NPC + j] = Sbuf[(DE + i) * NVP + DE + j];
     }
+    cost = wave_sum(cost);
+    if (el == 0) {
+      Mp[REC] = 0.5 * cost;
+      Mp[REC + 1] = (double)count;
+      if (RECP > REC + 2) Mp[REC + 2] = 0.0;
+    }
+    lds_fence();
+    const double2* mp2 = reinterpret_cast<const double2*>(Mp);
+    double2* out2 = reinterpret_cast<double2*>(out);
+    for (int e = el; e < RECP / 2; e += 64) out2[e] = mp2[e];
   } else {
     // epilogue.  lane j < N1 owns column j of the local system:
     //   y[a] = (S That)[a][j]  for the DE base rows  (That column j in registers, S rows are LDS broadcasts)
@@ -646,10 +699,14 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
         for (int i = NPC; i <= j; ++i) out[tri_index(i, j, N1)] = Sbuf[(DE + i - NPC) * NVP + DE + (j - NPC)];
     }
   }
-  cost = wave_sum(cost);
+  if constexpr (!MFMA) {
+    cost = wave_sum(cost);
+    if (lane == 0) {
+      out[REC] = 0.5 * cost;
+      out[REC + 1] = (double)count;
+    }
+  }
   if (lane == 0) {
-    out[REC] = 0.5 * cost;
-    out[REC + 1] = (double)count;
     if (prof) {
       long long* o = t.dbg + (size_t)v * 8;
       o[0] = stamp[1] - stamp[0];                 // setup: That columns, staging clear, compaction
@@ -657,8 +714,8 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
       o[2] = stamp[3] - stamp[1] - stamp[2];      // LDS staging + MFMA
       o[3] = clock64() - stamp[3];                // epilogue
       o[4] = count;
-      o[5] = stamp[4] - stamp[0];                 // setup part 1: That columns
-      o[6] = stamp[5] - stamp[4];                 // setup part 2: staging clear + inlier loads
+      o[5] = ep0 - stamp[3];                      // epilogue part 1: corner reduction + S -> LDS
+      o[6] = ep1 - ep0;                           // epilogue part 2: Y = S_EE That
       o[7] = clock64() - stamp[0];                // lifetime
     }
   }

@@ -321,6 +321,63 @@ __global__ void k_quadforms(Dims d, const double* __restrict__ Hss, const double
   }
 }
 
+// q = u^T (D H D) u for ONE vector, as a plain streaming weighted sum over the stored blocks (grid-stride, coalesced):
+//   q = sum_{f,dd,s} 2 a_f[dd] H_fs[f][dd][s] a_s[s] + sum_{f,dd,d2} a_f[dd] H_ff[f][dd][d2] a_f[d2]
+//     + sum_{i,j} a_s[i] H_ss[i][j] a_s[j],            a = D u.
+// The trust-region driver only needs this for u = g_h (Cauchy curvature): the forms involving the Gauss-Newton step
+// follow from (D H D + reg I) gn = g_h without touching H again (mcba_solve).  partial[blockIdx.x] = block sum.
+__global__ __launch_bounds__(256) void k_q00(Dims d, const double* __restrict__ Hss, const double* __restrict__ Hfs,
+                                             const double* __restrict__ Hff, const double* __restrict__ dsc,
+                                             const double* __restrict__ u, double* __restrict__ partial) {
+  __shared__ double scratch[16];
+  const int ns = d.ns, DF = d.DF;
+  const int stride = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
+  double q = 0.0;
+  const int rows = DF > 0 ? d.Fl * DF : 0;
+  for (int e = t0; e < rows * ns; e += stride) {
+    const int row = e / ns, s = e - row * ns;
+    const int xi = d.frame_to_x(d.f0 + row / DF, row % DF), xs = d.shared_to_x(s);
+    q += 2.0 * (dsc[xi] * u[xi]) * Hfs[e] * (dsc[xs] * u[xs]);
+  }
+  for (int e = t0; e < rows * DF; e += stride) {
+    const int row = e / DF, d2 = e - row * DF, f = d.f0 + row / DF;
+    const int xi = d.frame_to_x(f, row % DF), xj = d.frame_to_x(f, d2);
+    q += (dsc[xi] * u[xi]) * Hff[e] * (dsc[xj] * u[xj]);
+  }
+  for (int e = t0; e < ns * ns; e += stride) {
+    const int i = e / ns, j = e - i * ns;
+    const int xi = d.shared_to_x(i), xj = d.shared_to_x(j);
+    q += (dsc[xi] * u[xi]) * Hss[e] * (dsc[xj] * u[xj]);
+  }
+  const double r = block_reduce<false>(q, scratch);
+  if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
+// out[0] = sum of the k_q00 partials (sharded handles all-reduce this one)
+__global__ void k_q00_final(const double* __restrict__ partial, int nblk, double* __restrict__ out) {
+  __shared__ double scratch[16];
+  double q = 0.0;
+  for (int blk = threadIdx.x; blk < nblk; blk += blockDim.x) q += partial[blk];
+  const double r = block_reduce<false>(q, scratch);
+  if (threadIdx.x == 0) out[0] = r;
+}
+
+// out[0..2] = {u0.u0, u0.u1, u1.u1} over the full (replicated) vectors
+__global__ void k_dots3(int n, const double* __restrict__ u0, const double* __restrict__ u1, double* __restrict__ out) {
+  __shared__ double scratch[16];
+  double dt[3] = {0, 0, 0};
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const double a = u0[i], b = u1[i];
+    dt[0] += a * a;
+    dt[1] += a * b;
+    dt[2] += b * b;
+  }
+  for (int k = 0; k < 3; ++k) {
+    const double ds = block_reduce<false>(dt[k], scratch);
+    if (threadIdx.x == 0) out[k] = ds;
+  }
+}
+
 // out[0..2] = {q00, q01, q11} summed over this rank's blocks (sharded handles all-reduce these three),
 // out[3..5] = dots {u0.u0, u0.u1, u1.u1} over the full vectors
 __global__ void k_quadforms_final(Dims d, const double* __restrict__ partial, int nblk,
@@ -630,6 +687,238 @@ __global__ __launch_bounds__(1024) void k_chol_lds(int ns, double reg, const dou
     __syncthreads();
   }
   if (tid == 0) info[0] = *bad;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_chol_blk: the reduced system of the usual calibration (ns <= 159: cameras x (pose + intrinsics) + boards) solved by
+// ONE workgroup of 8 wavefronts with the whole lower triangle resident in LDS as 16 x 16 tiles (row stride 17).
+// The column-by-column k_chol_lds above spends two 1024-thread barriers per column (234 us at ns = 140); here a block
+// column costs two barriers:
+//   (a) wave 0 factors the diagonal tile entirely in REGISTERS: lane i owns row i, the pivot and the scaled column
+//       entries travel through v_readlane (an LDS round trip costs ~250 cycles on this chip and there are ns of them
+//       on the critical path), then inverts it the same way, one column of L^-1 per lane,
+//   (b) all waves form the panel below as X = A L_kk^-T with v_mfma_f64_16x16x4_f64 (four steps per tile),
+//   (c) the symmetric rank-16 update of the trailing tiles, again on the matrix pipe -- with look-ahead: wave 0 updates
+//       the next diagonal tile first and runs (a) for it while waves 1-7 update the remaining tiles.
+// The right-hand side is row ns of the matrix, so (b)/(c) are also the forward substitution; the backward substitution
+// runs on wave 0 alone with the inverted diagonal tiles: p_k = L_kk^-T z_k, z_j -= L_kj^T p_k, no workgroup barrier.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int CT = 16, CTL = 17, CTS = CT * CTL;
+constexpr int CHOL_BLK_MAX_N1 = 160, CHOL_BLK_THREADS = 512;
+__host__ __device__ inline size_t chol_blk_lds_bytes(int ns) {
+  const int nb = (ns + 1 + CT - 1) / CT;
+  return ((size_t)(nb * (nb + 1) / 2 + nb) * CTS + 2 * nb * CT) * sizeof(double) + 16;
+}
+
+__device__ __forceinline__ double lane_bcast(double v, int src) {   // value of lane src (wave-uniform) in every lane
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
+// (a): Cholesky factor of the 16 x 16 tile D (first ncol columns; the rest is right-hand-side row / identity padding)
+// and its inverse Xi, by one wavefront.  col0 = global index of the tile's first column (for the pivot report).
+__device__ __forceinline__ void chol_tile_factor(double* __restrict__ D, double* __restrict__ Xi, int ncol, int col0,
+                                                 int lane, int& badcol) {
+  const int li = lane & 15;
+  double row[CT], dinv[CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c) row[c] = D[li * CTL + c];
+#pragma unroll
+  for (int j = 0; j < CT; ++j) {
+    dinv[j] = 1.0;
+    if (j < ncol) {                        // wave-uniform
+      double dj = lane_bcast(row[j], j);
+      badcol = (dj > 0.0 || badcol != 0) ? badcol : col0 + j + 1;
+      dj = fmax(dj, 1e-300);
+      const double inv = rsqrt(dj);
+      dinv[j] = inv;
+      const double l = (li == j) ? dj * inv : row[j] * inv;
+      row[j] = l;
+      // all broadcasts of the step first, then the FMAs: distinct SGPR pairs, no s_nop between readlane and use
+      double lk[CT];
+#pragma unroll
+      for (int k2 = j + 1; k2 < CT; ++k2) lk[k2] = lane_bcast(l, k2);
+#pragma unroll
+      for (int k2 = j + 1; k2 < CT; ++k2) row[k2] -= l * lk[k2];
+    }
+  }
+  if (lane < CT) {
+#pragma unroll
+    for (int c = 0; c < CT; ++c) D[li * CTL + c] = row[c];
+  }
+  // inverse: lane c solves L x = e_c (L_im is lane i's row[m]); the padding has a unit diagonal
+  double x[CT];
+#pragma unroll
+  for (int i = 0; i < CT; ++i) {
+    double s0 = (i == li) ? 1.0 : 0.0, s1 = 0.0;
+    double lr[CT];
+#pragma unroll
+    for (int m = 0; m < i; ++m) lr[m] = lane_bcast(row[m], i);
+#pragma unroll
+    for (int m = 0; m < i; ++m) {
+      if (m & 1) s1 -= lr[m] * x[m]; else s0 -= lr[m] * x[m];
+    }
+    x[i] = (i >= li) ? (s0 + s1) * dinv[i] : 0.0;
+  }
+  if (lane < CT) {
+#pragma unroll
+    for (int i = 0; i < CT; ++i) Xi[i * CTL + li] = x[i];
+  }
+}
+
+// C -= Xa Xb^T for one 16 x 16 tile (four MFMA steps), one wavefront
+__device__ __forceinline__ void chol_tile_syrk(const double* __restrict__ Xa, const double* __restrict__ Xb,
+                                               double* __restrict__ Cm, int li, int lg) {
+  double4_t acc;
+  double av[4], bv[4];
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) {
+    av[s4] = -Xa[li * CTL + 4 * s4 + lg];
+    bv[s4] = Xb[li * CTL + 4 * s4 + lg];
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = Cm[(lg + 4 * r) * CTL + li];
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s4], bv[s4], acc, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) Cm[(lg + 4 * r) * CTL + li] = acc[r];
+}
+
+__global__ __launch_bounds__(CHOL_BLK_THREADS) void k_chol_blk(int ns, double reg, const double* __restrict__ buf,
+                                                               double* __restrict__ ps, int* __restrict__ info,
+                                                               long long* __restrict__ prof) {
+  extern __shared__ __attribute__((aligned(16))) double chol_b[];
+  constexpr int NTHR = CHOL_BLK_THREADS, NW = NTHR / 64;
+  const int n1 = ns + 1, nb = (n1 + CT - 1) / CT, ntile = nb * (nb + 1) / 2;
+  double* Lb = chol_b;                         // tiles (bi, bj), bj <= bi, at (bi (bi + 1) / 2 + bj) * CTS
+  double* Li = Lb + (size_t)ntile * CTS;       // inverted diagonal tiles
+  double* yv = Li + (size_t)nb * CTS;          // forward-substituted right-hand side, updated by the back substitution
+  double* pv = yv + nb * CT;                   // solution
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int badcol = 0;                              // wave 0: first non-positive pivot (1-based)
+  long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tc = 0;   // phase stamps (prof != nullptr): load, a0, b, c + a, back
+  if (prof) tc = clock64();
+#define CHOL_STAMP(i) if (prof) { const long long now = clock64(); tp[i] += now - tc; tc = now; }
+  {   // load: two tiles per pass, thread (r, c) of each; padding rows / columns continue the matrix with the identity
+    const int r = (tid >> 4) & 15, c = tid & 15, half = tid >> 8;
+    constexpr int UN = 12;
+    for (int t0 = 0; t0 < ntile; t0 += 2 * UN) {
+      double v[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int tile = t0 + 2 * u + half;
+        int bi = (int)((sqrtf(8.0f * (float)tile + 1.0f) - 1.0f) * 0.5f);
+        bi += ((bi + 1) * (bi + 2) / 2 <= tile) ? 1 : 0;
+        bi -= (bi * (bi + 1) / 2 > tile) ? 1 : 0;
+        const int bj = tile - bi * (bi + 1) / 2;
+        const int gi = CT * bi + r, gj = CT * bj + c;
+        const bool in = tile < ntile && gi < n1 && gj < ns && gj <= gi;
+        const double g = buf[in ? (size_t)gi * ns + gj : 0];
+        v[u] = in ? g + ((gi == gj) ? reg : 0.0) : ((gi == gj) ? 1.0 : 0.0);
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int tile = t0 + 2 * u + half;
+        if (tile < ntile) Lb[(size_t)tile * CTS + r * CTL + c] = v[u];
+      }
+    }
+  }
+  __syncthreads();
+  CHOL_STAMP(0)
+  const int li = lane & 15, lg = lane >> 4;
+  if (wave == 0 && ns > 0) chol_tile_factor(Lb, Li, min(CT, ns), 0, lane, badcol);
+  __syncthreads();
+  CHOL_STAMP(1)
+  for (int k = 0; k < nb; ++k) {
+    if (ns - CT * k <= 0) break;               // no column of S in this block (right-hand-side row / padding only)
+    {
+      // (b) panel tiles below the diagonal:  X = A L_kk^-T   (D[i][j] = sum_m A[i][m] Linv[j][m])
+      const double* Xi = Li + (size_t)k * CTS;
+      double bv[4];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) bv[s4] = Xi[li * CTL + 4 * s4 + lg];
+      for (int bi = k + 1 + wave; bi < nb; bi += NW) {
+        double* A = Lb + (size_t)(bi * (bi + 1) / 2 + k) * CTS;
+        double av[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) av[s4] = A[li * CTL + 4 * s4 + lg];
+        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s4], bv[s4], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) A[(lg + 4 * r) * CTL + li] = acc[r];
+      }
+    }
+    __syncthreads();
+    CHOL_STAMP(2)
+    {
+      // (c) trailing tiles (bi, bj), k < bj <= bi:  C -= X_bi X_bj^T.  Tile 0 of the enumeration is the next diagonal
+      // tile: wave 0 updates it and factors it at once (look-ahead) while waves 1 .. 7 share the other tiles.
+      const int m = nb - k - 1, nt = m * (m + 1) / 2;
+      if (wave == 0) {
+        if (nt > 0) {
+          const int b1 = k + 1;
+          const double* X1 = Lb + (size_t)(b1 * (b1 + 1) / 2 + k) * CTS;
+          double* D1 = Lb + (size_t)(b1 * (b1 + 1) / 2 + b1) * CTS;
+          chol_tile_syrk(X1, X1, D1, li, lg);
+          lds_fence();
+          const int ncol1 = min(CT, ns - CT * b1);
+          if (ncol1 > 0) chol_tile_factor(D1, Li + (size_t)b1 * CTS, ncol1, CT * b1, lane, badcol);
+        }
+      } else {
+        for (int tt = wave; tt < nt; tt += NW - 1) {
+          int a = 0, rem = tt;
+          while (rem > a) { rem -= a + 1; ++a; }           // tt -> (a, rem), rem <= a
+          const int bi = k + 1 + a, bj = k + 1 + rem;
+          chol_tile_syrk(Lb + (size_t)(bi * (bi + 1) / 2 + k) * CTS, Lb + (size_t)(bj * (bj + 1) / 2 + k) * CTS,
+                         Lb + (size_t)(bi * (bi + 1) / 2 + bj) * CTS, li, lg);
+        }
+      }
+    }
+    __syncthreads();
+    CHOL_STAMP(3)
+  }
+  if (wave == 0) {
+    // forward-substituted right-hand side = row ns; then the blocked back substitution, wave 0 only
+    const int by = ns / CT, ry = ns % CT;
+    for (int e = lane; e < nb * CT; e += 64) {
+      const int bj = e / CT, c = e % CT;
+      yv[e] = (e < ns && bj <= by) ? Lb[(size_t)(by * (by + 1) / 2 + bj) * CTS + ry * CTL + c] : 0.0;
+    }
+    lds_fence();
+    const int nbc = (ns + CT - 1) / CT;
+    for (int kb = nbc - 1; kb >= 0; --kb) {
+      {   // p_k = L_kk^-T z_k   (the strict upper part of the stored inverse is zero)
+        const double* Xi = Li + (size_t)kb * CTS;
+        double sp[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < CT; ++i) sp[i & 3] += Xi[i * CTL + li] * yv[CT * kb + i];
+        const double sum = (sp[0] + sp[1]) + (sp[2] + sp[3]);
+        if (lane < CT) {
+          pv[CT * kb + li] = sum;
+          if (CT * kb + li < ns) ps[CT * kb + li] = sum;
+        }
+      }
+      lds_fence();
+      for (int e = lane; e < CT * kb; e += 64) {   // z_j -= L_kj^T p_k for the blocks above
+        const int bj = e / CT, c = e % CT;
+        const double* Lt = Lb + (size_t)(kb * (kb + 1) / 2 + bj) * CTS;
+        double sp[4] = {yv[e], 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < CT; ++r) sp[r & 3] -= Lt[r * CTL + c] * pv[CT * kb + r];
+        yv[e] = (sp[0] + sp[1]) + (sp[2] + sp[3]);
+      }
+      lds_fence();
+    }
+    CHOL_STAMP(4)
+    if (lane == 0) {
+      info[0] = badcol;
+      if (prof)
+        for (int i = 0; i < 8; ++i) prof[i] = tp[i];
+    }
+  }
+#undef CHOL_STAMP
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -10,7 +10,11 @@ with Handle(c) as h:
     print("views active", len(act), "of", len(p), "mean count", act[:,4].mean())
     names = ["setup", "rows", "stage+mfma", "epilogue"]
     for i, n in enumerate(names): print(f"{n:12s} mean {act[:, i].mean():10.0f} cyc  median {np.median(act[:, i]):10.0f}  max {act[:, i].max()}")
-    print("setup: That columns", act[:,5].mean(), " clear+mask loads", act[:,6].mean(), " compaction", (act[:,0]-act[:,5]-act[:,6]).mean())
+    print("epilogue: reduce + S store", act[:,5].mean(), " Y", act[:,6].mean(), " M + record stores", (act[:,3]-act[:,5]-act[:,6]).mean())
     print("lifetime mean", act[:, 7].mean())
     # clock rate of s_memtime: span vs measured time
     print("linearize ms", h.time_linearize(x0, 20))
+    for g in (1024, 1280, 1467, 1536, 1792, 2048, 2201, 2560, 3072, 4096, 4401):
+        h.set_lin_grid(g); h.time_linearize(x0, 3)
+        print("grid", g, "linearize ms", h.time_linearize(x0, 20))
+    h.set_lin_grid(0)

@@ -1,0 +1,21 @@
+"""Per-kernel timing of one full solve at the north-star rig (run under rocprofv3 --kernel-trace --stats)."""
+import sys, time, numpy as np
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+from multical_amd import synthetic, calibration
+from multical_amd.backend import Handle
+rig = synthetic.make_rig("cfg3"); c = calibration.from_rig(rig); x0 = c.param_vec
+with Handle(c) as h:
+    h.solve(x0)
+    t0 = time.perf_counter(); res = h.solve(x0); dt = time.perf_counter() - t0
+    print("solve s", dt, "nfev", res.nfev, "njev", res.njev, "status", res.status, "cost", res.cost, "iters/s", (res.nfev - 1) / dt)
+    print("linearize ms", h.time_linearize(x0, 50))
+    rng = np.random.default_rng(0)
+    for ns in (140,):
+        M = rng.normal(size=(ns + 20, ns)); S = M.T @ M / ns + 0.1 * np.eye(ns); rhs = rng.normal(size=ns)
+        st = h.debug_chol(S, rhs, reg=0.05, blocked=4)[:8]
+        print("k_chol_blk cycles: load %d  first diag %d  panel %d  syrk + next diag %d  back %d" % tuple(st[:5]))
+        for mode in (0, 3):
+            h.debug_chol(S, rhs, reg=0.05, blocked=mode)
+            t0 = time.perf_counter()
+            for _ in range(20): h.debug_chol(S, rhs, reg=0.05, blocked=mode)
+            print("chol mode", mode, "ms/call incl. copies", (time.perf_counter() - t0) / 20 * 1e3)

@@ -124,6 +124,12 @@ def test_schur_cholesky_step(name):
       ref = np.linalg.solve(Hh * d[:, None] * d[None, :] + reg * np.eye(h.n_params), d * gh)
       assert np.abs(si - si_ref).max() <= 1e-12 * si_ref.max()
       assert np.abs(gn - ref).max() <= 1e-8 * np.abs(ref).max()
+      # the trust-region driver takes the quadratic forms of the 2-D subspace from (H_h + reg I) gn = g_h instead of
+      # a second pass over H (mcba_solve): check the identities on the device step against the dense Hessian
+      Hs = Hh * d[:, None] * d[None, :]
+      q01, q11 = ghs @ Hs @ gn, gn @ Hs @ gn
+      assert abs((ghs @ ghs - reg * (ghs @ gn)) - q01) <= 1e-9 * abs(q01)
+      assert abs((ghs @ gn - reg * (gn @ gn)) - q11) <= 1e-9 * abs(q11)
 
 
 @pytest.mark.parametrize("name", ["cfg1", "tiny_handeye", "tiny_fixintr"])
@@ -325,7 +331,8 @@ def test_adjust_board_rolling_and_handeye_blocks():
       assert np.abs(fd - J[:, j]).max() <= 1e-5 * max(np.abs(J[:, j]).max(), 1.0), (name, j)
 
 
-@pytest.mark.parametrize("ns,blocked", [(18, 0), (40, 0), (40, 1), (40, 2), (140, 0), (190, 0), (200, 0), (200, 1), (200, 2),
+@pytest.mark.parametrize("ns,blocked", [(5, 0), (16, 0), (18, 0), (31, 0), (32, 0), (40, 0), (40, 1), (40, 2), (40, 3), (140, 0), (140, 3),
+                                        (159, 0), (160, 0), (190, 0), (200, 0), (200, 1), (200, 2),
                                         (333, 1), (700, 0), (1500, 1)])
 def test_device_cholesky_paths(ns, blocked):
   """LDS-resident (0, small ns), single-workgroup panel (2) and multi-workgroup MFMA (1) Cholesky solves vs numpy."""
