@@ -81,7 +81,15 @@ struct DevBuf {
 
 constexpr double REG_FLOOR = 1e-10;   // floor of the Levenberg-Marquardt damping in the scaled space (gauge null space)
 constexpr int COST_BLOCKS_MAX = 1024;
+// scalars fetched by the trust-region driver at its three synchronisation points; a single-GPU handle also fetches the
+// per-block partial sums that follow and adds them up on the host (fixed order), which saves the tiny final-sum
+// kernels and device-to-device copies of a latency-bound loop
 constexpr int N_SCALARS = 32;
+constexpr int Q00_BLOCKS = 512;
+constexpr int SC_Q00P = N_SCALARS;                 // [Q00_BLOCKS]      partials of k_q00              (sync 1)
+constexpr int SC_STEP = SC_Q00P + Q00_BLOCKS;      // [8]               k_vec_step norms               (sync 3)
+constexpr int SC_COSTP = SC_STEP + 8;              // [COST_BLOCKS_MAX] partials of k_cost             (sync 3)
+constexpr int SC_DOTP = SC_COSTP + COST_BLOCKS_MAX;   // [3 nblk + 1]   partial dots + pivot report    (sync 2)
 
 }  // namespace
 
@@ -114,7 +122,7 @@ struct mcba_handle_s {
   bool obs_index_dirty = false;
 
   // linearisation
-  DevBuf<double> rec, partial, pairsum, Hss, Hfs, Hff, gbuf;   // gbuf = [g (n) | diag (n) | cost, count]
+  DevBuf<double> rec, partial, Hss, Hfs, Hff, gbuf;   // gbuf = [g (n) | diag (n) | cost, count]
   int nchunk = 1;
   // solver state
   DevBuf<double> x, xnew, scale_inv, dsc, gh, gn, scal, qpart, costpart, Lf, W, yf, P, sbuf, ps;
@@ -228,32 +236,38 @@ void launch_assemble(mcba_handle_s* h) {
   // entries of frames owned by other ranks must be zero before the cross-rank sum (they hold the previous global
   // values after an all-reduce)
   HIP_OK(hipMemsetAsync(h->gbuf.p, 0, (2 * (size_t)d.n + 2) * sizeof(double), h->stream));
-  if (d.DF > 0 && d.Fl > 0)
-    hipLaunchKernelGGL(k_assemble_frames, dim3(d.Fl), dim3(256), 0, h->stream, d, h->t, h->rec.p, h->Hff.p, h->Hfs.p,
-                       h->g(), h->diag());
-  hipLaunchKernelGGL(k_shared_partial, dim3(d.C * d.B, h->nchunk), dim3(256), 0, h->stream, d, h->t, h->rec.p,
-                     h->nchunk, h->partial.p);
   HIP_OK(hipMemsetAsync(h->Hss.p, 0, (size_t)d.ns * d.ns * sizeof(double), h->stream));
-  hipLaunchKernelGGL(k_shared_zero_g, dim3((d.ns + 255) / 256), dim3(256), 0, h->stream, d, h->g());
-  hipLaunchKernelGGL(k_shared_pairsum, dim3((d.rec_stride + 127) / 128, d.C * d.B), dim3(128), 0, h->stream, d, h->partial.p,
-                     h->nchunk, h->pairsum.p);
-  hipLaunchKernelGGL(k_shared_final, dim3((d.rec_size + 2 + 63) / 64), dim3(64), 0, h->stream, d, h->pairsum.p, h->tri.p,
-                     h->Hss.p, h->g(), h->costcount());
-  if (d.off_boards >= 0)   // adjusted board points: their blocks of H_ss / H_fs / g (unique entries, plain stores)
+  const int nfb = (d.DF > 0) ? d.Fl : 0;
+  hipLaunchKernelGGL(k_assemble, dim3(nfb + d.C * d.B * h->nchunk), dim3(256), 0, h->stream, d, h->t, h->rec.p, nfb,
+                     h->nchunk, h->Hff.p, h->Hfs.p, h->g(), h->diag(), h->partial.p);
+  {
+    const int npair = d.C * d.B, pg = std::min(npair, 16);
+    REQUIRE((size_t)npair * 64 * sizeof(double) <= 64 * 1024, "too many (camera, board) pairs for the shared assembly");
+    hipLaunchKernelGGL(k_shared_final, dim3((d.rec_size + 2 + 63) / 64), dim3(64 * pg), (size_t)npair * 64 * sizeof(double),
+                       h->stream, d, h->partial.p, h->nchunk, h->tri.p, h->Hss.p, h->g(), h->diag(), h->costcount());
+  }
+  if (d.off_boards >= 0) {   // adjusted board points: their blocks of H_ss / H_fs / g (unique entries, plain stores)
     h->ops->points(d, h->t, h->stream, (d.n - d.off_boards) / 3, h->Hss.p, h->Hfs.p, h->g());
-  hipLaunchKernelGGL(k_shared_diag, dim3((d.ns + 255) / 256), dim3(256), 0, h->stream, d, h->Hss.p, h->diag());
+    hipLaunchKernelGGL(k_shared_diag, dim3((d.ns + 255) / 256), dim3(256), 0, h->stream, d, h->Hss.p, h->diag());
+  }
   call_allreduce(h, h->gbuf.p, 2 * (size_t)d.n + 2, 0);
 }
 
 void sync(mcba_handle_s* h) { HIP_OK(hipStreamSynchronize(h->stream)); }
 
-void fetch_scalars(mcba_handle_s* h, int count) {
-  HIP_OK(hipMemcpyAsync(h->h_scal, h->scal.p, count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+void fetch_scalars(mcba_handle_s* h, int count, int first = 0) {   // scal[first, first + count) -> h_scal (same offsets)
+  HIP_OK(hipMemcpyAsync(h->h_scal + first, h->scal.p + first, count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   sync(h);
+}
+double host_sum(const double* p, int n) {   // fixed order: the result does not depend on block scheduling
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  int i = 0;
+  for (; i + 4 <= n; i += 4) { s0 += p[i]; s1 += p[i + 1]; s2 += p[i + 2]; s3 += p[i + 3]; }
+  for (; i < n; ++i) s0 += p[i];
+  return (s0 + s1) + (s2 + s3);
 }
 
 // Cauchy curvature g_h^T (D H D) g_h -> scal[off]
-constexpr int Q00_BLOCKS = 512;
 void launch_q00(mcba_handle_s* h, const double* u, int off) {
   const Dims& d = h->d;
   hipLaunchKernelGGL(k_q00, dim3(Q00_BLOCKS), dim3(256), 0, h->stream, d, h->Hss.p, h->Hfs.p, h->Hff.p, h->dsc.p, u,
@@ -326,13 +340,30 @@ void launch_chol(mcba_handle_s* h, int ns, double reg, double* buf, double* ps) 
 }
 
 // gn = (H_h + reg I)^-1 g_h  through the Schur complement of the per-frame blocks
-void launch_gn_solve(mcba_handle_s* h, double reg, bool root_rank) {
+// dots_out (device, may be null): a single-GPU handle receives the per-block partial dots {g_h.g_h, g_h.gn, gn.gn} of
+// the back-substitution blocks, dots_out[3 blk + k], followed by the Cholesky pivot report (see gn_dot_blocks); a
+// frame-sharded handle receives the three complete dots (k_dots3 after the all-reduce of gn).
+int gn_dot_blocks(const Dims& d) {
+  const int K = d.DF * d.Fl;
+  return (K > 0 ? (d.DF == 12 ? (d.Fl + 15) / 16 : (d.Fl + 31) / 32) : 0) + 1;
+}
+void launch_gn_solve(mcba_handle_s* h, double reg, bool root_rank, double* dots_out = nullptr) {
   const Dims& d = h->d;
   const int K = d.DF * d.Fl;
-  HIP_OK(hipMemsetAsync(h->gn.p, 0, (size_t)d.n * sizeof(double), h->stream));
+  const bool sharded_frames = h->allreduce && K > 0;
+  // frame entries of other shards must be zero before the cross-rank sum; a single handle writes every entry of gn
+  if (h->allreduce) HIP_OK(hipMemsetAsync(h->gn.p, 0, (size_t)d.n * sizeof(double), h->stream));
+  double* fused_dots = sharded_frames ? nullptr : dots_out;
   if (K > 0) {
-    hipLaunchKernelGGL(k_schur_frames, dim3(d.Fl), dim3(128), 0, h->stream, d, h->Hfs.p, h->Hff.p, h->dsc.p, h->gh.p, reg,
-                       h->Lf.p, h->W.p, h->yf.p);
+    if (d.DF == 12) {
+      hipLaunchKernelGGL((k_frame_factor<12>), dim3((d.Fl + 63) / 64), dim3(64), 0, h->stream, d, h->Hff.p, h->dsc.p, h->gh.p,
+                         reg, h->Lf.p, h->W.p, h->yf.p);
+      hipLaunchKernelGGL((k_schur_w<12>), dim3(d.Fl), dim3(256), 0, h->stream, d, h->Hfs.p, h->dsc.p, h->Lf.p, h->W.p);
+    } else {
+      hipLaunchKernelGGL((k_frame_factor<6>), dim3((d.Fl + 63) / 64), dim3(64), 0, h->stream, d, h->Hff.p, h->dsc.p, h->gh.p,
+                         reg, h->Lf.p, h->W.p, h->yf.p);
+      hipLaunchKernelGGL((k_schur_w<6>), dim3(d.Fl), dim3(256), 0, h->stream, d, h->Hfs.p, h->dsc.p, h->Lf.p, h->W.p);
+    }
     const int nt2 = h->ntile * (h->ntile + 1) / 2;
     if (h->use_mfma)
       hipLaunchKernelGGL((k_schur_syrk<true>), dim3(nt2, h->ksplit), dim3(64), 0, h->stream, K, d.ns + 1, h->ntile,
@@ -346,12 +377,20 @@ void launch_gn_solve(mcba_handle_s* h, double reg, bool root_rank) {
                      h->dsc.p, h->gh.p, h->P.p, h->ntile, h->ksplit, K, root_rank ? 1.0 : 0.0, h->sbuf.p);
   call_allreduce(h, h->sbuf.p, (size_t)total, 0);
   launch_chol(h, d.ns, reg, h->sbuf.p, h->ps.p);
-  const int nblk = (K > 0 ? d.Fl : 0) + 1;
-  hipLaunchKernelGGL(k_schur_backsub, dim3(nblk), dim3(128), 0, h->stream, d, h->Lf.p, h->W.p, h->yf.p, h->ps.p, h->gn.p);
+  if (d.DF == 12) {
+    const int nblk = (K > 0 ? (d.Fl + 15) / 16 : 0) + 1;
+    hipLaunchKernelGGL((k_schur_backsub<12>), dim3(nblk), dim3(192), 0, h->stream, d, h->Lf.p, h->W.p, h->yf.p, h->ps.p,
+                       h->gn.p, h->gh.p, h->info.p, fused_dots);
+  } else {
+    const int nblk = (K > 0 ? (d.Fl + 31) / 32 : 0) + 1;
+    hipLaunchKernelGGL((k_schur_backsub<6>), dim3(nblk), dim3(192), 0, h->stream, d, h->Lf.p, h->W.p, h->yf.p, h->ps.p,
+                       h->gn.p, h->gh.p, h->info.p, fused_dots);
+  }
   if (h->allreduce && K > 0) {
     // frame entries of gn are known only to the owning rank: zero the (replicated) shared entries on non-root ranks
     // is not needed -- every rank holds identical p_s; sum only the frame block.
     call_allreduce(h, h->gn.p + d.off_motion, (size_t)d.n_motion, 0);
+    if (dots_out) hipLaunchKernelGGL(k_dots3, dim3(1), dim3(1024), 0, h->stream, d.n, h->gh.p, h->gn.p, dots_out);
   }
 }
 
@@ -638,14 +677,13 @@ int32_t mcba_create(const mcba_problem* p, void* hip_stream, mcba_handle* out) {
   // ---- work buffers -----------------------------------------------------------------------------------------
   h->rec.alloc((size_t)d.views() * d.rec_stride);
   h->nchunk = std::max(1, std::min(64, (d.Fl + 7) / 8));
-  h->pairsum.alloc((size_t)d.C * d.B * d.rec_stride);
   h->partial.alloc((size_t)d.C * d.B * h->nchunk * d.rec_stride);
   h->Hss.alloc((size_t)d.ns * d.ns);
   h->Hfs.alloc((size_t)d.Fl * d.DF * d.ns);
   h->Hff.alloc((size_t)d.Fl * d.DF * d.DF);
   h->gbuf.alloc(2 * (size_t)d.n + 2);
   for (DevBuf<double>* b : {&h->x, &h->xnew, &h->scale_inv, &h->dsc, &h->gh, &h->gn}) b->alloc((size_t)d.n);
-  h->scal.alloc(N_SCALARS);
+  h->scal.alloc((size_t)SC_DOTP + 3 * (size_t)(d.Fl + 2) + 8);
   h->qpart.alloc(std::max<size_t>(3 * (size_t)(d.Fl + 1), Q00_BLOCKS));
   h->cost_blocks = std::max(1, std::min(COST_BLOCKS_MAX, (int)((nslot + 255) / 256)));
   h->costpart.alloc((size_t)h->cost_blocks);
@@ -657,14 +695,14 @@ int32_t mcba_create(const mcba_problem* p, void* hip_stream, mcba_handle* out) {
     const int K = d.DF * d.Fl;
     const int nt2 = h->ntile * (h->ntile + 1) / 2;
     int ks = 1;
-    while (ks < 64 && nt2 * ks < 2048 && K / (ks * 2) >= 32) ks *= 2;
+    while (ks < 64 && nt2 * ks < 1024 && K / (ks * 2) >= 32) ks *= 2;
     h->ksplit = ks;
     h->P.alloc((size_t)ks * nt2 * 256);
   }
   h->sbuf.alloc((size_t)d.ns * d.ns + d.ns);
   h->ps.alloc((size_t)d.ns);
   h->info.alloc(4);
-  HIP_OK(hipHostMalloc((void**)&h->h_scal, N_SCALARS * sizeof(double)));
+  HIP_OK(hipHostMalloc((void**)&h->h_scal, h->scal.n * sizeof(double)));
   HIP_OK(hipEventCreate(&h->ev0));
   HIP_OK(hipEventCreate(&h->ev1));
   HIP_OK(hipDeviceSynchronize());
@@ -950,6 +988,7 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
   const int max_nfev = opt->max_nfev > 0 ? opt->max_nfev : d.n * 100;
   const double NaN = std::numeric_limits<double>::quiet_NaN();
   const bool is_root = h->shard_root;
+  const bool host_sums = h->allreduce == nullptr;   // single GPU: per-block partials are added up on the host
 
   upload_x(h, x_inout, h->x.p);
   eval_tables(h, h->x.p);
@@ -971,11 +1010,18 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
 
   while (true) {
     // ---- gradient scaling + Cauchy-step curvature (one sync) -------------------------------------------------
+    // k_vec_scale also forwards {cost, count} of the linearisation into scal[16..17]
     hipLaunchKernelGGL(k_vec_scale, dim3(1), dim3(1024), 0, h->stream, d, h->x.p, h->g(), h->diag(), h->scale_inv.p,
-                       h->dsc.p, h->gh.p, first ? 1 : 0, h->scal.p);
-    launch_q00(h, h->gh.p, 4);
-    HIP_OK(hipMemcpyAsync(h->scal.p + 16, h->costcount(), 2 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    fetch_scalars(h, 18);
+                       h->dsc.p, h->gh.p, first ? 1 : 0, h->scal.p, h->costcount());
+    if (host_sums) {
+      hipLaunchKernelGGL(k_q00, dim3(Q00_BLOCKS), dim3(256), 0, h->stream, d, h->Hss.p, h->Hfs.p, h->Hff.p, h->dsc.p,
+                         h->gh.p, h->scal.p + SC_Q00P);
+      fetch_scalars(h, SC_Q00P + Q00_BLOCKS);
+      h->h_scal[4] = host_sum(h->h_scal + SC_Q00P, Q00_BLOCKS);
+    } else {
+      launch_q00(h, h->gh.p, 4);
+      fetch_scalars(h, 18);
+    }
     if (fresh_lin) { collect_lin_time(); fresh_lin = false; }
     g_norm = h->h_scal[0];
     const double gh2 = h->h_scal[1];
@@ -1000,13 +1046,23 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
     const double reg = std::max(reg_term, REG_FLOOR);
 
     // ---- regularised Gauss-Newton step + 2-D subspace (one sync) ---------------------------------------------
-    launch_gn_solve(h, reg, is_root);
-    hipLaunchKernelGGL(k_dots3, dim3(1), dim3(1024), 0, h->stream, d.n, h->gh.p, h->gn.p, h->scal.p + 7);
-    HIP_OK(hipMemcpyAsync(h->scal.p + 12, h->info.p, sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
-    fetch_scalars(h, 13);
-    {
-      int32_t chol_info = 0;
+    int32_t chol_info = 0;
+    if (host_sums) {
+      const int nblk = gn_dot_blocks(d);
+      launch_gn_solve(h, reg, is_root, h->scal.p + SC_DOTP);
+      fetch_scalars(h, 3 * nblk + 1, SC_DOTP);
+      double dsum[3] = {0, 0, 0};
+      for (int blk = 0; blk < nblk; ++blk)
+        for (int k = 0; k < 3; ++k) dsum[k] += h->h_scal[SC_DOTP + 3 * blk + k];
+      for (int k = 0; k < 3; ++k) h->h_scal[7 + k] = dsum[k];
+      chol_info = (int32_t)h->h_scal[SC_DOTP + 3 * nblk];
+    } else {
+      launch_gn_solve(h, reg, is_root, h->scal.p + 7);
+      HIP_OK(hipMemcpyAsync(h->scal.p + 12, h->info.p, sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
+      fetch_scalars(h, 13);
       memcpy(&chol_info, &h->h_scal[12], sizeof(int32_t));
+    }
+    {
       if (chol_info != 0)
         throw Error("reduced normal equations are not positive definite (pivot " + std::to_string(chol_info) +
                     "); non-finite Jacobian?");
@@ -1042,11 +1098,21 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
           -(0.5 * (pS[0] * (BS[0] * pS[0] + BS[1] * pS[1]) + pS[1] * (BS[1] * pS[0] + BS[2] * pS[1])) + gS[0] * pS[0] +
             gS[1] * pS[1]);
       const double alpha = Cm[0] * pS[0] + Cm[1] * pS[1], beta = Cm[2] * pS[0] + Cm[3] * pS[1];
-      hipLaunchKernelGGL(k_vec_step, dim3(1), dim3(1024), 0, h->stream, d, h->x.p, h->dsc.p, h->gh.p, h->gn.p, alpha, beta,
-                         h->xnew.p, h->scal.p);
-      eval_tables(h, h->xnew.p);
-      launch_cost(h, h->scal.p + 3);
-      fetch_scalars(h, 4);
+      if (host_sums) {
+        hipLaunchKernelGGL(k_vec_step, dim3(1), dim3(1024), 0, h->stream, d, h->x.p, h->dsc.p, h->gh.p, h->gn.p, alpha,
+                           beta, h->xnew.p, h->scal.p + SC_STEP);
+        eval_tables(h, h->xnew.p);
+        h->ops->cost(d, h->t, h->stream, h->scal.p + SC_COSTP, h->cost_blocks);
+        fetch_scalars(h, 8 + h->cost_blocks, SC_STEP);
+        for (int k = 0; k < 3; ++k) h->h_scal[k] = h->h_scal[SC_STEP + k];
+        h->h_scal[3] = host_sum(h->h_scal + SC_COSTP, h->cost_blocks);
+      } else {
+        hipLaunchKernelGGL(k_vec_step, dim3(1), dim3(1024), 0, h->stream, d, h->x.p, h->dsc.p, h->gh.p, h->gn.p, alpha,
+                           beta, h->xnew.p, h->scal.p);
+        eval_tables(h, h->xnew.p);
+        launch_cost(h, h->scal.p + 3);
+        fetch_scalars(h, 4);
+      }
       ++nfev;
       const double step_h_norm = std::sqrt(h->h_scal[0]);
       cost_new = h->h_scal[3];

@@ -62,6 +62,11 @@ __device__ __forceinline__ double block_reduce(double v, double* scratch /*[16]*
   return r;
 }
 
+// (Fusing the "sum the per-block partials" launch into the producing kernel with the threadfence + ticket-counter idiom
+//  was measured and rejected on this chip: an agent-scope release is an L2 write-back on a multi-XCD part and ~75 ns per
+//  same-address atomic serialises 500-1000 tickets into 40-90 us.  Single-GPU solves copy the partials to the host with
+//  the scalars they already fetch instead; sharded solves keep the small final-sum kernels.)
+
 // ---------------------------------------------------------------------------------------------------------------
 // k_residual: evaluate() of optimization/calibration.py:204-206 (+ projections and per-slot errors of
 //             tables.reprojection_error, tables.py:244-249).  One thread per slot, frame-major coalesced loads of the

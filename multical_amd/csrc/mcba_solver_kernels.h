@@ -49,9 +49,11 @@ __global__ void k_tmat(Dims d, Tables t) {
 // assembly of the records (deterministic gathers; no atomics)
 // ---------------------------------------------------------------------------------------------------------------
 // per-frame blocks: H_ff [Fl][DF][DF], H_fs [Fl][DF][ns], g / diag entries of the frame's parameters.
-__global__ void k_assemble_frames(Dims d, Tables t, const double* __restrict__ rec, double* __restrict__ Hff,
-                                  double* __restrict__ Hfs, double* __restrict__ g, double* __restrict__ diag) {
-  const int fl = blockIdx.x, f = d.f0 + fl;
+__device__ __forceinline__ void assemble_frame_block(const Dims& d, const Tables& t, int fl,
+                                                     const double* __restrict__ rec, double* __restrict__ Hff,
+                                                     double* __restrict__ Hfs, double* __restrict__ g,
+                                                     double* __restrict__ diag) {
+  const int f = d.f0 + fl;
   const int DF = d.DF, ns = d.ns, N1 = d.N1, NL = d.NL;
   double* hfs = Hfs + (size_t)fl * DF * ns;
   double* hff = Hff + (size_t)fl * DF * DF;
@@ -109,9 +111,9 @@ __global__ void k_assemble_frames(Dims d, Tables t, const double* __restrict__ r
 }
 
 // shared part, stage 1: partial[pair=(c,b)][chunk][rec_stride] = sum of the records over a chunk of frames
-__global__ void k_shared_partial(Dims d, Tables t, const double* __restrict__ rec, int nchunk,
-                                 double* __restrict__ partial) {
-  const int pair = blockIdx.x, ch = blockIdx.y;
+__device__ __forceinline__ void shared_partial_block(const Dims& d, const Tables& t, int pair, int ch,
+                                                     const double* __restrict__ rec, int nchunk,
+                                                     double* __restrict__ partial) {
   const int c = pair / d.B, b = pair % d.B;
   const int per = (d.Fl + nchunk - 1) / nchunk;
   const int fa = ch * per, fb = min(d.Fl, fa + per);
@@ -128,60 +130,95 @@ __global__ void k_shared_partial(Dims d, Tables t, const double* __restrict__ re
   }
 }
 
-// shared part, stage 2: pairsum[pair][e] = sum over the chunks (one thread per (pair, entry))
-__global__ void k_shared_pairsum(Dims d, const double* __restrict__ partial, int nchunk, double* __restrict__ pairsum) {
-  const int pair = blockIdx.y;
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= d.rec_stride) return;
-  const double* base = partial + (size_t)pair * nchunk * d.rec_stride + e;
-  double sum = 0.0;
-#pragma unroll 8
-  for (int ch = 0; ch < nchunk; ++ch) sum += base[(size_t)ch * d.rec_stride];
-  pairsum[(size_t)pair * d.rec_stride + e] = sum;
+// ONE launch for both gathers (they are independent and each is too small to fill the chip):
+//   blocks [0, nfb)                 frame blocks (nfb = Fl when per-frame parameters are eliminated, else 0)
+//   blocks [nfb, nfb + C B nchunk)  chunk sums of the shared part
+__global__ __launch_bounds__(256) void k_assemble(Dims d, Tables t, const double* __restrict__ rec, int nfb, int nchunk,
+                                                  double* __restrict__ Hff, double* __restrict__ Hfs,
+                                                  double* __restrict__ g, double* __restrict__ diag,
+                                                  double* __restrict__ partial) {
+  if ((int)blockIdx.x < nfb) {
+    assemble_frame_block(d, t, blockIdx.x, rec, Hff, Hfs, g, diag);
+  } else {
+    const int q = blockIdx.x - nfb;
+    shared_partial_block(d, t, q / nchunk, q % nchunk, rec, nchunk, partial);
+  }
 }
 
-// shared part, stage 3: H_ss (dense ns x ns, zeroed by the caller), g and the total cost.
-// One THREAD per packed local entry e; it folds the pairs (c, b) in sequentially.  Two contributions can only meet in
-// the same H_ss element when they come from the same local entry e of different pairs (e.g. the camera block of
-// (c, b) and (c, b')), i.e. inside one thread -- so the sum order is fixed and no atomics are needed.
-__global__ void k_shared_final(Dims d, const double* __restrict__ pairsum, const uint16_t* __restrict__ tri,
-                               double* __restrict__ Hss, double* __restrict__ g, double* __restrict__ cost_count) {
-  const int ns = d.ns, NL = d.NL;
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= d.rec_size + 2) return;
-  const int npair = d.C * d.B;
-  if (e >= d.rec_size) {   // cost, count
-    double tot = 0.0;
-    for (int pair = 0; pair < npair; ++pair) tot += pairsum[(size_t)pair * d.rec_stride + e];
-    cost_count[e - d.rec_size] = tot;
-    return;
+// shared part, stage 2: H_ss (dense ns x ns, zeroed by the caller), g, diag and the total cost from the chunk sums.
+// A block covers 64 packed local entries e x ALL pairs (c, b): thread (e, pair lane) first adds the chunk sums of its
+// pairs (independent loads, 8 in flight) into LDS.  A local entry maps to an element of H_ss that depends on the camera
+// only (camera pose / intrinsics columns), on the board only (board pose), on both, or on neither (hand-eye blocks):
+// the thread of the FIRST pair of each equivalence class owns the element, adds the pair sums of its class from LDS in
+// a fixed order and stores -- no atomics, no read-modify-write chains, every element written once.
+__global__ __launch_bounds__(1024) void k_shared_final(Dims d, const double* __restrict__ partial, int nchunk,
+                                                       const uint16_t* __restrict__ tri, double* __restrict__ Hss,
+                                                       double* __restrict__ g, double* __restrict__ diag,
+                                                       double* __restrict__ cost_count) {
+  extern __shared__ double pair_sum[];   // [C B][64]
+  const int ns = d.ns, NL = d.NL, npose = 6 * d.NPB, npair = d.C * d.B;
+  const int el = threadIdx.x & 63, pg = threadIdx.x >> 6, PG = blockDim.x >> 6;
+  const int e = blockIdx.x * 64 + el;
+  const bool in = e < d.rec_size + 2;
+  const size_t rs = d.rec_stride;
+  for (int pair = pg; pair < npair; pair += PG) {
+    double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (in) {
+      const double* base = partial + (size_t)pair * nchunk * rs + e;
+      int ch = 0;
+      for (; ch + 8 <= nchunk; ch += 8)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] += base[(size_t)(ch + u) * rs];
+      for (; ch < nchunk; ++ch) a[0] += base[(size_t)ch * rs];
+    }
+    pair_sum[pair * 64 + el] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   }
-  const int ij = tri[e];
-  const int i = ij >> 8, j = ij & 255;
-  if (i == NL) return;                                   // (r, r) = sum f^2: the cost is carried separately
-  if (local_is_frame(d, i) || local_is_frame(d, j)) return;
-  for (int pair = 0; pair < npair; ++pair) {
+  __syncthreads();
+  if (!in) return;
+  bool depc = false, depb = false;
+  int i = 0, j = 0;
+  if (e < d.rec_size) {
+    const int ij = tri[e];
+    i = ij >> 8;
+    j = ij & 255;
+    if (i == NL) return;                                   // (r, r) = sum f^2: the cost is carried separately
+    if (local_is_frame(d, i) || local_is_frame(d, j)) return;
+    auto dep_c = [&](int l) { return l < 6 || l >= npose; };
+    auto dep_b = [&](int l) { return l >= npose - 6 && l < npose; };
+    depc = dep_c(i) || (j < NL && dep_c(j));
+    depb = dep_b(i) || (j < NL && dep_b(j));
+  }
+  for (int pair = pg; pair < npair; pair += PG) {
     const int c = pair / d.B, b = pair % d.B;
-    // the frame index is irrelevant for shared parameters (hand-eye blocks do not depend on f either)
-    const int gi = local_to_x(d, 0, c, b, i);
-    if (gi < 0) continue;
-    const int gj = j == NL ? 0 : local_to_x(d, 0, c, b, j);
-    if (gj < 0) continue;
-    const double val = pairsum[(size_t)pair * d.rec_stride + e];
-    if (j == NL) {
-      g[gi] += val;
+    if ((!depc && c != 0) || (!depb && b != 0)) continue;    // not the first pair of its class
+    int gi = -1, gj = -1;
+    if (e < d.rec_size) {
+      // the frame index is irrelevant for shared parameters (hand-eye blocks do not depend on f either)
+      gi = local_to_x(d, 0, c, b, i);
+      if (gi < 0) continue;
+      if (j < NL) {
+        gj = local_to_x(d, 0, c, b, j);
+        if (gj < 0) continue;
+      }
+    }
+    const int c0 = depc ? c : 0, c1 = depc ? c + 1 : d.C, b0 = depb ? b : 0, b1 = depb ? b + 1 : d.B;
+    double val = 0.0;
+    for (int cc = c0; cc < c1; ++cc)
+      for (int bb = b0; bb < b1; ++bb) val += pair_sum[(cc * d.B + bb) * 64 + el];
+    if (e >= d.rec_size) {
+      cost_count[e - d.rec_size] = val;
+    } else if (j == NL) {
+      g[gi] = val;
     } else {
       const int si = d.x_to_shared(gi), sj = d.x_to_shared(gj);
-      Hss[(size_t)si * ns + sj] += val;
-      if (si != sj) Hss[(size_t)sj * ns + si] += val;
+      Hss[(size_t)si * ns + sj] = val;
+      if (si != sj) Hss[(size_t)sj * ns + si] = val;
+      else diag[gi] = val;
     }
   }
 }
 
-// diag(H) of the shared parameters and zeroing of their gradient entries (before k_shared_final accumulates)
-__global__ void k_shared_zero_g(Dims d, double* __restrict__ g) {
-  for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < d.ns; s += gridDim.x * blockDim.x) g[d.shared_to_x(s)] = 0.0;
-}
+// diag(H) of the shared parameters from H_ss (only needed after k_points added the board-point blocks)
 __global__ void k_shared_diag(Dims d, const double* __restrict__ Hss, double* __restrict__ diag) {
   for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < d.ns; s += gridDim.x * blockDim.x)
     diag[d.shared_to_x(s)] = Hss[(size_t)s * d.ns + s];
@@ -227,7 +264,8 @@ __global__ void k_dense_hessian(Dims d, const double* __restrict__ Hss, const do
 // (g and diag are complete on every rank: sharded handles all-reduce them before this kernel)
 __global__ void k_vec_scale(Dims d, const double* __restrict__ x, const double* __restrict__ g,
                             const double* __restrict__ diag, double* __restrict__ scale_inv, double* __restrict__ dsc,
-                            double* __restrict__ gh, int first, double* __restrict__ out) {
+                            double* __restrict__ gh, int first, double* __restrict__ out,
+                            const double* __restrict__ cost_count = nullptr) {
   __shared__ double scratch[16];
   double mx = 0, gg = 0, xs = 0;
   for (int i = threadIdx.x; i < d.n; i += blockDim.x) {
@@ -246,7 +284,10 @@ __global__ void k_vec_scale(Dims d, const double* __restrict__ x, const double* 
   const double a = block_reduce<true>(mx, scratch);
   const double b = block_reduce<false>(gg, scratch);
   const double c = block_reduce<false>(xs, scratch);
-  if (threadIdx.x == 0) { out[0] = a; out[1] = b; out[2] = c; }
+  if (threadIdx.x == 0) {
+    out[0] = a; out[1] = b; out[2] = c;
+    if (cost_count) { out[16] = cost_count[0]; out[17] = cost_count[1]; }
+  }
 }
 
 // quadratic forms of H_h = D H D for two vectors u0, u1 (scaled space):
@@ -325,7 +366,8 @@ __global__ void k_quadforms(Dims d, const double* __restrict__ Hss, const double
 //   q = sum_{f,dd,s} 2 a_f[dd] H_fs[f][dd][s] a_s[s] + sum_{f,dd,d2} a_f[dd] H_ff[f][dd][d2] a_f[d2]
 //     + sum_{i,j} a_s[i] H_ss[i][j] a_s[j],            a = D u.
 // The trust-region driver only needs this for u = g_h (Cauchy curvature): the forms involving the Gauss-Newton step
-// follow from (D H D + reg I) gn = g_h without touching H again (mcba_solve).  partial[blockIdx.x] = block sum.
+// follow from (D H D + reg I) gn = g_h without touching H again (mcba_solve).  partial[blockIdx.x] = block sum
+// (added up in index order by the host of a single-GPU solve, by k_sum + all-reduce on a sharded one).
 __global__ __launch_bounds__(256) void k_q00(Dims d, const double* __restrict__ Hss, const double* __restrict__ Hfs,
                                              const double* __restrict__ Hff, const double* __restrict__ dsc,
                                              const double* __restrict__ u, double* __restrict__ partial) {
@@ -400,56 +442,95 @@ __global__ void k_quadforms_final(Dims d, const double* __restrict__ partial, in
   }
 }
 
-// Schur step 1, one block per frame:  A_ff = D_f H_ff D_f + reg I = L L^T,  W = L^-1 (D_f H_fs D_s)  [DF x ns],
-// y = L^-1 g_h,f stored as the EXTRA COLUMN ns of W (row stride ns + 1), so that the SYRK below also delivers W^T y.
-// L is kept for the back-substitution.
-__global__ void k_schur_frames(Dims d, const double* __restrict__ Hfs, const double* __restrict__ Hff,
-                               const double* __restrict__ dsc, const double* __restrict__ gh, double reg,
-                               double* __restrict__ Lf, double* __restrict__ W, double* __restrict__ yf) {
-  __shared__ double L[12 * 12];
-  __shared__ double y[12];
-  const int fl = blockIdx.x, f = d.f0 + fl, DF = d.DF, ns = d.ns, ldw = d.ns + 1;
+// Schur step 1a, one THREAD per frame:  A_ff = D_f H_ff D_f + reg I = L L^T entirely in registers (DF = 6 or 12: 21 / 78
+// doubles), then L^-1 by forward substitution and y = L^-1 g_h,f.  The per-frame systems are tiny and there are
+// hundreds of them: a lane per system needs no cross-lane traffic at all (the block-per-frame version spent 39 us of
+// LDS latency in a single thread of each block).  Linv is stored dense [DF][DF] (zeros above the diagonal); y goes to
+// yf and to the EXTRA COLUMN ns of W (row stride ns + 1), so that the SYRK below also delivers W^T y.
+template <int DF>
+__global__ __launch_bounds__(64) void k_frame_factor(Dims d, const double* __restrict__ Hff, const double* __restrict__ dsc,
+                                                     const double* __restrict__ gh, double reg, double* __restrict__ Linv,
+                                                     double* __restrict__ W, double* __restrict__ yf) {
+  const int fl = blockIdx.x * blockDim.x + threadIdx.x;
+  if (fl >= d.Fl) return;
+  const int f = d.f0 + fl, ldw = d.ns + 1;
   const double* hff = Hff + (size_t)fl * DF * DF;
-  for (int e = threadIdx.x; e < DF * DF; e += blockDim.x) {
-    const int i = e / DF, j = e % DF;
-    L[i * 12 + j] = dsc[d.frame_to_x(f, i)] * hff[e] * dsc[d.frame_to_x(f, j)] + (i == j ? reg : 0.0);
+  double ds[DF], L[DF][DF], X[DF][DF];
+#pragma unroll
+  for (int i = 0; i < DF; ++i) ds[i] = dsc[d.frame_to_x(f, i)];
+#pragma unroll
+  for (int i = 0; i < DF; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) L[i][j] = ds[i] * hff[i * DF + j] * ds[j] + (i == j ? reg : 0.0);
+  double dinv[DF];
+#pragma unroll
+  for (int j = 0; j < DF; ++j) {
+    double sj = L[j][j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) sj -= L[j][k] * L[j][k];
+    const double inv = rsqrt(fmax(sj, 1e-300));
+    dinv[j] = inv;
+#pragma unroll
+    for (int i = j + 1; i < DF; ++i) {
+      double v = L[i][j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k];
+      L[i][j] = v * inv;
+    }
   }
-  __syncthreads();
+  // X = L^-1 (lower triangular), column c by forward substitution
+#pragma unroll
+  for (int c = 0; c < DF; ++c) {
+#pragma unroll
+    for (int i = c; i < DF; ++i) {
+      double v = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+      for (int m = c; m < i; ++m) v -= L[i][m] * X[m][c];
+      X[i][c] = v * dinv[i];
+    }
+  }
+  double* xo = Linv + (size_t)fl * DF * DF;
+#pragma unroll
+  for (int i = 0; i < DF; ++i)
+#pragma unroll
+    for (int j = 0; j < DF; ++j) xo[i * DF + j] = (j <= i) ? X[i][j] : 0.0;
+  double gf[DF];
+#pragma unroll
+  for (int i = 0; i < DF; ++i) gf[i] = gh[d.frame_to_x(f, i)];
   double* w = W + (size_t)fl * DF * ldw;
-  if (threadIdx.x == 0) {
-    // dense Cholesky, lower triangle in place (DF <= 12)
-    for (int j = 0; j < DF; ++j) {
-      double s = L[j * 12 + j];
-      for (int k = 0; k < j; ++k) s -= L[j * 12 + k] * L[j * 12 + k];
-      const double dj = sqrt(fmax(s, 1e-300));
-      L[j * 12 + j] = dj;
-      for (int i = j + 1; i < DF; ++i) {
-        double v = L[i * 12 + j];
-        for (int k = 0; k < j; ++k) v -= L[i * 12 + k] * L[j * 12 + k];
-        L[i * 12 + j] = v / dj;
-      }
-    }
-    for (int i = 0; i < DF; ++i) {
-      double v = gh[d.frame_to_x(f, i)];
-      for (int k = 0; k < i; ++k) v -= L[i * 12 + k] * y[k];
-      y[i] = v / L[i * 12 + i];
-    }
-    for (int i = 0; i < DF; ++i) {
-      yf[fl * DF + i] = y[i];
-      w[i * ldw + ns] = y[i];
-    }
+#pragma unroll
+  for (int i = 0; i < DF; ++i) {
+    double y = 0.0;
+#pragma unroll
+    for (int k = 0; k <= i; ++k) y += X[i][k] * gf[k];
+    yf[fl * DF + i] = y;
+    w[i * ldw + d.ns] = y;
   }
-  __syncthreads();
-  for (int e = threadIdx.x; e < DF * DF; e += blockDim.x) Lf[(size_t)fl * DF * DF + e] = L[(e / DF) * 12 + (e % DF)];
+}
+
+// Schur step 1b, one block per frame, one thread per shared column s:  W[:, s] = L^-1 (D_f H_fs D_s)[:, s]  as a plain
+// triangular product with the inverse from step 1a (wave-uniform operand: scalar loads, no dependent chain).
+template <int DF>
+__global__ __launch_bounds__(256) void k_schur_w(Dims d, const double* __restrict__ Hfs, const double* __restrict__ dsc,
+                                                 const double* __restrict__ Linv, double* __restrict__ W) {
+  const int fl = blockIdx.x, f = d.f0 + fl, ns = d.ns, ldw = d.ns + 1;
+  const double* X = Linv + (size_t)fl * DF * DF;
   const double* hfs = Hfs + (size_t)fl * DF * ns;
+  double* w = W + (size_t)fl * DF * ldw;
+  double df[DF];
+#pragma unroll
+  for (int i = 0; i < DF; ++i) df[i] = dsc[d.frame_to_x(f, i)];
   for (int s = threadIdx.x; s < ns; s += blockDim.x) {
-    const double ds = dsc[d.shared_to_x(s)];
-    double col[12];
+    const double dsv = dsc[d.shared_to_x(s)];
+    double bcol[DF];
+#pragma unroll
+    for (int i = 0; i < DF; ++i) bcol[i] = df[i] * hfs[i * ns + s] * dsv;
+#pragma unroll
     for (int i = 0; i < DF; ++i) {
-      double v = dsc[d.frame_to_x(f, i)] * hfs[i * ns + s] * ds;
-      for (int k = 0; k < i; ++k) v -= L[i * 12 + k] * col[k];
-      col[i] = v / L[i * 12 + i];
-      w[i * ldw + s] = col[i];
+      double v = 0.0;
+#pragma unroll
+      for (int k = 0; k <= i; ++k) v += X[i * DF + k] * bcol[k];
+      w[i * ldw + s] = v;
     }
   }
 }
@@ -471,11 +552,17 @@ __global__ __launch_bounds__(64, 2) void k_schur_syrk(int K, int ncol, int ntile
   const int ci = ti * 16 + csub, cj = tj * 16 + csub;
   if constexpr (MFMA) {
     double4_t acc = {0.0, 0.0, 0.0, 0.0};
-    for (int k = k0; k < k1; k += 4) {
-      const int kk = k + rsub;
-      const double a = (kk < k1 && ci < ncol) ? W[(size_t)kk * ncol + ci] : 0.0;
-      const double b = (kk < k1 && cj < ncol) ? W[(size_t)kk * ncol + cj] : 0.0;
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    constexpr int UB = 8;                           // operand loads of 8 MFMA steps in flight at once
+    for (int k = k0; k < k1; k += 4 * UB) {
+      double av[UB], bv[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int kk = k + 4 * u + rsub;
+        av[u] = (kk < k1 && ci < ncol) ? W[(size_t)kk * ncol + ci] : 0.0;
+        bv[u] = (kk < k1 && cj < ncol) ? W[(size_t)kk * ncol + cj] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
     }
     for (int r = 0; r < 4; ++r) out[(rsub + 4 * r) * 16 + csub] = acc[r];
   } else {
@@ -505,8 +592,20 @@ __global__ void k_schur_reduce(Dims d, const double* __restrict__ Hss, const dou
     const int ti = a / 16, tj = b / 16;
     const int tile = ti * ntile - (ti * (ti - 1)) / 2 + (tj - ti);
     double sum = 0.0;
-    if (K > 0)
-      for (int sp = 0; sp < ksplit; ++sp) sum += P[((size_t)sp * nt2 + tile) * 256 + (a % 16) * 16 + (b % 16)];
+    if (K > 0) {
+      const double* pp = P + (size_t)tile * 256 + (a % 16) * 16 + (b % 16);
+      const size_t st = (size_t)nt2 * 256;
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      int sp = 0;
+      for (; sp + 4 <= ksplit; sp += 4) {          // four independent loads in flight, fixed summation order
+        s0 += pp[(size_t)sp * st];
+        s1 += pp[(size_t)(sp + 1) * st];
+        s2 += pp[(size_t)(sp + 2) * st];
+        s3 += pp[(size_t)(sp + 3) * st];
+      }
+      for (; sp < ksplit; ++sp) s0 += pp[(size_t)sp * st];
+      sum = (s0 + s1) + (s2 + s3);
+    }
     if (i < ns) buf[e] = dsc[d.shared_to_x(i)] * Hss[e] * dsc[d.shared_to_x(j)] - sum;
     else buf[e] = g_weight * gh[d.shared_to_x(j)] - sum;
   }
@@ -1053,37 +1152,68 @@ __global__ void k_cholb_back_update(int ns, int k0, double* __restrict__ A) {
   y[j] -= sum;
 }
 
-// back-substitution: gn_s = p_s ; gn_f = L^-T (y_f - W p_s)  (one block per frame; block Fl copies the shared part)
-__global__ void k_schur_backsub(Dims d, const double* __restrict__ Lf, const double* __restrict__ W,
-                                const double* __restrict__ yf, const double* __restrict__ ps, double* __restrict__ gn) {
+// back-substitution: gn_s = p_s ; gn_f = L^-T (y_f - W p_s).  FPB frames per block, one thread per eliminated row
+// (frame, dd): the row of W is streamed by its own lane (p_s is wave-uniform), z goes through LDS and the same
+// thread applies column dd of L^-1.  The last block copies the shared part.
+template <int DF>
+__global__ __launch_bounds__(192) void k_schur_backsub(Dims d, const double* __restrict__ Linv, const double* __restrict__ W,
+                                                       const double* __restrict__ yf, const double* __restrict__ ps,
+                                                       double* __restrict__ gn, const double* __restrict__ gh,
+                                                       const int* __restrict__ info, double* __restrict__ dots) {
+  constexpr int FPB = 192 / DF;
+  __shared__ double z[192];
   __shared__ double scratch[16];
-  __shared__ double z[12];
-  const int ns = d.ns, DF = d.DF;
-  if (blockIdx.x == gridDim.x - 1) {   // last block: shared part
+  const int ns = d.ns;
+  const bool shared_blk = blockIdx.x == gridDim.x - 1;
+  if (shared_blk) {   // last block of the grid: shared part
     for (int i = threadIdx.x; i < d.n; i += blockDim.x) {
       const int s = d.x_to_shared(i);
       if (s >= 0) gn[i] = ps[s];         // frame entries: written by their own blocks; other shards' stay 0 (memset)
     }
-    return;
   }
-  const int fl = blockIdx.x, f = d.f0 + fl, ldw = ns + 1;
-  const double* w = W + (size_t)fl * DF * ldw;
-  for (int dd = 0; dd < DF; ++dd) {
-    double part = 0.0;
-    for (int s = threadIdx.x; s < ns; s += blockDim.x) part += w[dd * ldw + s] * ps[s];
-    const double tot = block_reduce<false>(part, scratch);
-    if (threadIdx.x == 0) z[dd] = yf[fl * DF + dd] - tot;
+  const int fq = threadIdx.x / DF, dd = threadIdx.x % DF, fl = blockIdx.x * FPB + fq;
+  const bool live = !shared_blk && fq < FPB && fl < d.Fl;
+  if (live) {
+    const double* w = W + ((size_t)fl * DF + dd) * (ns + 1);
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int s = 0;
+    for (; s + 4 <= ns; s += 4) {
+      a0 += w[s] * ps[s];
+      a1 += w[s + 1] * ps[s + 1];
+      a2 += w[s + 2] * ps[s + 2];
+      a3 += w[s + 3] * ps[s + 3];
+    }
+    for (; s < ns; ++s) a0 += w[s] * ps[s];
+    z[threadIdx.x] = yf[fl * DF + dd] - ((a0 + a1) + (a2 + a3));
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const double* L = Lf + (size_t)fl * DF * DF;
-    double p[12];
-    for (int i = DF - 1; i >= 0; --i) {
-      double v = z[i];
-      for (int k = i + 1; k < DF; ++k) v -= L[k * DF + i] * p[k];
-      p[i] = v / L[i * DF + i];
-    }
-    for (int i = 0; i < DF; ++i) gn[d.frame_to_x(f, i)] = p[i];
+  if (live) {
+    const double* X = Linv + (size_t)fl * DF * DF;
+    double v = 0.0;
+#pragma unroll
+    for (int k = 0; k < DF; ++k) v += (k >= dd) ? X[k * DF + dd] * z[fq * DF + k] : 0.0;
+    gn[d.frame_to_x(d.f0 + fl, dd)] = v;
+  }
+  // partial dots {g_h.g_h, g_h.gn, gn.gn} over the entries this block has just written: dots[3 blk + k], plus the
+  // Cholesky pivot report as dots[3 gridDim.x] -- the single-GPU driver sums them on the host with the scalars it
+  // fetches anyway (sharded handles pass dots == nullptr: they need the all-reduced gn first, k_dots3).
+  if (dots == nullptr) return;
+  double dt[3] = {0, 0, 0};
+  if (shared_blk) {
+    for (int i = threadIdx.x; i < d.n; i += blockDim.x)
+      if (d.x_to_shared(i) >= 0) {
+        const double a = gh[i], b = gn[i];     // written by this very thread above
+        dt[0] += a * a; dt[1] += a * b; dt[2] += b * b;
+      }
+    if (threadIdx.x == 0) dots[3 * gridDim.x] = (double)info[0];
+  } else if (live) {
+    const int xi = d.frame_to_x(d.f0 + fl, dd);
+    const double a = gh[xi], b = gn[xi];
+    dt[0] = a * a; dt[1] = a * b; dt[2] = b * b;
+  }
+  for (int k = 0; k < 3; ++k) {
+    const double ds = block_reduce<false>(dt[k], scratch);
+    if (threadIdx.x == 0) dots[3 * blockIdx.x + k] = ds;
   }
 }
 

@@ -9,6 +9,12 @@ with Handle(c) as h:
     t0 = time.perf_counter(); res = h.solve(x0); dt = time.perf_counter() - t0
     print("solve s", dt, "nfev", res.nfev, "njev", res.njev, "status", res.status, "cost", res.cost, "iters/s", (res.nfev - 1) / dt)
     print("linearize ms", h.time_linearize(x0, 50))
+    rng = np.random.default_rng(1)
+    x1 = x0 + 1e-3 * rng.normal(size=x0.size)
+    h.solve(x1)
+    t0 = time.perf_counter(); res = h.solve(x1); dt = time.perf_counter() - t0
+    print("perturbed solve s", dt, "nfev", res.nfev, "njev", res.njev, "status", res.status, "cost", res.cost,
+          "ms/iter", dt / max(res.nfev - 1, 1) * 1e3)
     rng = np.random.default_rng(0)
     for ns in (140,):
         M = rng.normal(size=(ns + 20, ns)); S = M.T @ M / ns + 0.1 * np.eye(ns); rhs = rng.normal(size=ns)
