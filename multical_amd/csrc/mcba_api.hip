@@ -80,16 +80,33 @@ struct DevBuf {
 };
 
 constexpr double REG_FLOOR = 1e-10;   // floor of the Levenberg-Marquardt damping in the scaled space (gauge null space)
-constexpr int COST_BLOCKS_MAX = 1024;
-// scalars fetched by the trust-region driver at its three synchronisation points; a single-GPU handle also fetches the
-// per-block partial sums that follow and adds them up on the host (fixed order), which saves the tiny final-sum
-// kernels and device-to-device copies of a latency-bound loop
+constexpr int COST_BLOCKS_MAX = 3072;   // persistent single-wave workgroups of k_cost (see LIN_GRID_MAX)
+// Scalars fetched by the trust-region driver at its three synchronisation points.  Each fetch is ONE contiguous
+// device-to-host copy that also carries per-block partial sums, which the host folds in a fixed order: that saves the
+// tiny final-sum kernels and device-to-device copies of a latency-bound loop (every launch costs ~5 us of GPU timeline).
+// Frame-sharded handles reduce the H-dependent partials on the device and all-reduce them instead.
 constexpr int N_SCALARS = 32;
 constexpr int Q00_BLOCKS = 512;
-constexpr int SC_Q00P = N_SCALARS;                 // [Q00_BLOCKS]      partials of k_q00              (sync 1)
-constexpr int SC_STEP = SC_Q00P + Q00_BLOCKS;      // [8]               k_vec_step norms               (sync 3)
-constexpr int SC_COSTP = SC_STEP + 8;              // [COST_BLOCKS_MAX] partials of k_cost             (sync 3)
-constexpr int SC_DOTP = SC_COSTP + COST_BLOCKS_MAX;   // [3 nblk + 1]   partial dots + pivot report    (sync 2)
+struct ScalLayout {
+  int nvb = 0;        // blocks of the element-wise vector kernels, ceil(n / 256)
+  int vs = 0;         // [3 nvb]           k_vec_scale partials                       (sync 1)
+  int q00p = 0;       // [Q00_BLOCKS]      k_q00 partials (single GPU)                (sync 1)
+  int step = 0;       // [3 nvb]           k_vec_step partials                        (sync 3)
+  int cost1 = 0;      // [2]               reduced cost (sharded)                     (sync 3)
+  int costp = 0;      // [COST_BLOCKS_MAX] k_cost partials (single GPU)               (sync 3)
+  int dotp = 0;       // [3 nblk + 1]      partial dots + pivot report (single GPU)   (sync 2)
+  int total = 0;
+  void init(int n, int dot_blocks) {
+    nvb = (n + 255) / 256;
+    vs = N_SCALARS;
+    q00p = vs + (3 * nvb + 1) / 2 * 2;
+    step = q00p + Q00_BLOCKS;
+    cost1 = step + (3 * nvb + 1) / 2 * 2;
+    costp = cost1 + 2;
+    dotp = costp + COST_BLOCKS_MAX;
+    total = dotp + 3 * dot_blocks + 8;
+  }
+};
 
 }  // namespace
 
@@ -102,6 +119,7 @@ struct mcba_handle_s {
   bool own_stream = false;
   bool use_mfma = true;
   bool shard_root = true;
+  ScalLayout sl;
   size_t chol_lds_set = 0, chol_lds2_set = 0, chol_lds3_set = 0;
   int lin_grid = 0;          // 0 = automatic (see lin2), > 0 = forced number of persistent workgroups (debug)
 
@@ -345,7 +363,7 @@ void launch_chol(mcba_handle_s* h, int ns, double reg, double* buf, double* ps) 
 // frame-sharded handle receives the three complete dots (k_dots3 after the all-reduce of gn).
 int gn_dot_blocks(const Dims& d) {
   const int K = d.DF * d.Fl;
-  return (K > 0 ? (d.DF == 12 ? (d.Fl + 15) / 16 : (d.Fl + 31) / 32) : 0) + 1;
+  return (K > 0 ? d.Fl : 0) + 1;
 }
 void launch_gn_solve(mcba_handle_s* h, double reg, bool root_rank, double* dots_out = nullptr) {
   const Dims& d = h->d;
@@ -378,12 +396,12 @@ void launch_gn_solve(mcba_handle_s* h, double reg, bool root_rank, double* dots_
   call_allreduce(h, h->sbuf.p, (size_t)total, 0);
   launch_chol(h, d.ns, reg, h->sbuf.p, h->ps.p);
   if (d.DF == 12) {
-    const int nblk = (K > 0 ? (d.Fl + 15) / 16 : 0) + 1;
-    hipLaunchKernelGGL((k_schur_backsub<12>), dim3(nblk), dim3(192), 0, h->stream, d, h->Lf.p, h->W.p, h->yf.p, h->ps.p,
+    const int nblk = gn_dot_blocks(d);
+    hipLaunchKernelGGL((k_schur_backsub<12>), dim3(nblk), dim3(64), 0, h->stream, d, h->Lf.p, h->W.p, h->yf.p, h->ps.p,
                        h->gn.p, h->gh.p, h->info.p, fused_dots);
   } else {
-    const int nblk = (K > 0 ? (d.Fl + 31) / 32 : 0) + 1;
-    hipLaunchKernelGGL((k_schur_backsub<6>), dim3(nblk), dim3(192), 0, h->stream, d, h->Lf.p, h->W.p, h->yf.p, h->ps.p,
+    const int nblk = gn_dot_blocks(d);
+    hipLaunchKernelGGL((k_schur_backsub<6>), dim3(nblk), dim3(64), 0, h->stream, d, h->Lf.p, h->W.p, h->yf.p, h->ps.p,
                        h->gn.p, h->gh.p, h->info.p, fused_dots);
   }
   if (h->allreduce && K > 0) {
@@ -640,7 +658,6 @@ int32_t mcba_create(const mcba_problem* p, void* hip_stream, mcba_handle* out) {
   h->d = hp.d;
   Dims& d = h->d;
   h->h_valid_ref = hp.valid_ref;
-  const size_t nslot = (size_t)d.slots();
   h->obs.upload(hp.obs);
   h->evalid.upload(hp.evalid);
   h->inlier.upload(hp.inlier);
@@ -683,9 +700,10 @@ int32_t mcba_create(const mcba_problem* p, void* hip_stream, mcba_handle* out) {
   h->Hff.alloc((size_t)d.Fl * d.DF * d.DF);
   h->gbuf.alloc(2 * (size_t)d.n + 2);
   for (DevBuf<double>* b : {&h->x, &h->xnew, &h->scale_inv, &h->dsc, &h->gh, &h->gn}) b->alloc((size_t)d.n);
-  h->scal.alloc((size_t)SC_DOTP + 3 * (size_t)(d.Fl + 2) + 8);
+  h->sl.init(d.n, d.Fl + 2);
+  h->scal.alloc((size_t)h->sl.total);
   h->qpart.alloc(std::max<size_t>(3 * (size_t)(d.Fl + 1), Q00_BLOCKS));
-  h->cost_blocks = std::max(1, std::min(COST_BLOCKS_MAX, (int)((nslot + 255) / 256)));
+  h->cost_blocks = std::max(1, std::min(COST_BLOCKS_MAX, d.views()));
   h->costpart.alloc((size_t)h->cost_blocks);
   h->Lf.alloc((size_t)d.Fl * d.DF * d.DF);
   h->W.alloc((size_t)d.Fl * d.DF * (d.ns + 1));
@@ -898,8 +916,8 @@ int32_t mcba_debug_gn_step(mcba_handle h, double reg, double* gn_h, double* g_h,
   API_BEGIN
   REQUIRE(h && gn_h, "null argument");
   const Dims& d = h->d;
-  hipLaunchKernelGGL(k_vec_scale, dim3(1), dim3(1024), 0, h->stream, d, h->x.p, h->g(), h->diag(), h->scale_inv.p,
-                     h->dsc.p, h->gh.p, 1, h->scal.p);
+  hipLaunchKernelGGL(k_vec_scale, dim3(h->sl.nvb), dim3(256), 0, h->stream, d, h->x.p, h->g(), h->diag(), h->scale_inv.p,
+                     h->dsc.p, h->gh.p, 1, h->scal.p + h->sl.vs, (const double*)nullptr, (double*)nullptr);
   launch_gn_solve(h, reg, h->shard_root);
   HIP_OK(hipMemcpyAsync(gn_h, h->gn.p, (size_t)d.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   if (g_h) HIP_OK(hipMemcpyAsync(g_h, h->gh.p, (size_t)d.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -1011,16 +1029,26 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
   while (true) {
     // ---- gradient scaling + Cauchy-step curvature (one sync) -------------------------------------------------
     // k_vec_scale also forwards {cost, count} of the linearisation into scal[16..17]
-    hipLaunchKernelGGL(k_vec_scale, dim3(1), dim3(1024), 0, h->stream, d, h->x.p, h->g(), h->diag(), h->scale_inv.p,
-                       h->dsc.p, h->gh.p, first ? 1 : 0, h->scal.p, h->costcount());
+    const ScalLayout& sl = h->sl;
+    hipLaunchKernelGGL(k_vec_scale, dim3(sl.nvb), dim3(256), 0, h->stream, d, h->x.p, h->g(), h->diag(), h->scale_inv.p,
+                       h->dsc.p, h->gh.p, first ? 1 : 0, h->scal.p + sl.vs, h->costcount(), h->scal.p + 16);
     if (host_sums) {
       hipLaunchKernelGGL(k_q00, dim3(Q00_BLOCKS), dim3(256), 0, h->stream, d, h->Hss.p, h->Hfs.p, h->Hff.p, h->dsc.p,
-                         h->gh.p, h->scal.p + SC_Q00P);
-      fetch_scalars(h, SC_Q00P + Q00_BLOCKS);
-      h->h_scal[4] = host_sum(h->h_scal + SC_Q00P, Q00_BLOCKS);
+                         h->gh.p, h->scal.p + sl.q00p);
+      fetch_scalars(h, sl.q00p + Q00_BLOCKS);
+      h->h_scal[4] = host_sum(h->h_scal + sl.q00p, Q00_BLOCKS);
     } else {
       launch_q00(h, h->gh.p, 4);
-      fetch_scalars(h, 18);
+      fetch_scalars(h, sl.q00p);
+    }
+    {
+      double mx = 0, gg = 0, xs = 0;
+      for (int blk = 0; blk < sl.nvb; ++blk) {
+        mx = std::max(mx, h->h_scal[sl.vs + 3 * blk]);
+        gg += h->h_scal[sl.vs + 3 * blk + 1];
+        xs += h->h_scal[sl.vs + 3 * blk + 2];
+      }
+      h->h_scal[0] = mx; h->h_scal[1] = gg; h->h_scal[2] = xs;
     }
     if (fresh_lin) { collect_lin_time(); fresh_lin = false; }
     g_norm = h->h_scal[0];
@@ -1049,13 +1077,13 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
     int32_t chol_info = 0;
     if (host_sums) {
       const int nblk = gn_dot_blocks(d);
-      launch_gn_solve(h, reg, is_root, h->scal.p + SC_DOTP);
-      fetch_scalars(h, 3 * nblk + 1, SC_DOTP);
+      launch_gn_solve(h, reg, is_root, h->scal.p + sl.dotp);
+      fetch_scalars(h, 3 * nblk + 1, sl.dotp);
       double dsum[3] = {0, 0, 0};
       for (int blk = 0; blk < nblk; ++blk)
-        for (int k = 0; k < 3; ++k) dsum[k] += h->h_scal[SC_DOTP + 3 * blk + k];
+        for (int k = 0; k < 3; ++k) dsum[k] += h->h_scal[sl.dotp + 3 * blk + k];
       for (int k = 0; k < 3; ++k) h->h_scal[7 + k] = dsum[k];
-      chol_info = (int32_t)h->h_scal[SC_DOTP + 3 * nblk];
+      chol_info = (int32_t)h->h_scal[sl.dotp + 3 * nblk];
     } else {
       launch_gn_solve(h, reg, is_root, h->scal.p + 7);
       HIP_OK(hipMemcpyAsync(h->scal.p + 12, h->info.p, sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
@@ -1098,20 +1126,23 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
           -(0.5 * (pS[0] * (BS[0] * pS[0] + BS[1] * pS[1]) + pS[1] * (BS[1] * pS[0] + BS[2] * pS[1])) + gS[0] * pS[0] +
             gS[1] * pS[1]);
       const double alpha = Cm[0] * pS[0] + Cm[1] * pS[1], beta = Cm[2] * pS[0] + Cm[3] * pS[1];
+      hipLaunchKernelGGL(k_vec_step, dim3(sl.nvb), dim3(256), 0, h->stream, d, h->x.p, h->dsc.p, h->gh.p, h->gn.p, alpha,
+                         beta, h->xnew.p, h->scal.p + sl.step);
+      eval_tables(h, h->xnew.p);
       if (host_sums) {
-        hipLaunchKernelGGL(k_vec_step, dim3(1), dim3(1024), 0, h->stream, d, h->x.p, h->dsc.p, h->gh.p, h->gn.p, alpha,
-                           beta, h->xnew.p, h->scal.p + SC_STEP);
-        eval_tables(h, h->xnew.p);
-        h->ops->cost(d, h->t, h->stream, h->scal.p + SC_COSTP, h->cost_blocks);
-        fetch_scalars(h, 8 + h->cost_blocks, SC_STEP);
-        for (int k = 0; k < 3; ++k) h->h_scal[k] = h->h_scal[SC_STEP + k];
-        h->h_scal[3] = host_sum(h->h_scal + SC_COSTP, h->cost_blocks);
+        h->ops->cost(d, h->t, h->stream, h->scal.p + sl.costp, h->cost_blocks);
+        fetch_scalars(h, sl.costp + h->cost_blocks - sl.step, sl.step);
+        h->h_scal[3] = host_sum(h->h_scal + sl.costp, h->cost_blocks);
       } else {
-        hipLaunchKernelGGL(k_vec_step, dim3(1), dim3(1024), 0, h->stream, d, h->x.p, h->dsc.p, h->gh.p, h->gn.p, alpha,
-                           beta, h->xnew.p, h->scal.p);
-        eval_tables(h, h->xnew.p);
-        launch_cost(h, h->scal.p + 3);
-        fetch_scalars(h, 4);
+        launch_cost(h, h->scal.p + sl.cost1);
+        fetch_scalars(h, sl.cost1 + 1 - sl.step, sl.step);
+        h->h_scal[3] = h->h_scal[sl.cost1];
+      }
+      {
+        double s3[3] = {0, 0, 0};
+        for (int blk = 0; blk < sl.nvb; ++blk)
+          for (int k = 0; k < 3; ++k) s3[k] += h->h_scal[sl.step + 3 * blk + k];
+        for (int k = 0; k < 3; ++k) h->h_scal[k] = s3[k];
       }
       ++nfev;
       const double step_h_norm = std::sqrt(h->h_scal[0]);

@@ -23,9 +23,9 @@ void residual(const Dims& d, const Tables& t, hipStream_t s, double* r, double* 
 
 void cost(const Dims& d, const Tables& t, hipStream_t s, double* partial, int nblk) {
   if (d.motion == MOTION_ROLLING)
-    hipLaunchKernelGGL((k_cost<ND_, FISH_, true>), dim3(nblk), dim3(256), 0, s, d, t, partial);
+    hipLaunchKernelGGL((k_cost<ND_, FISH_, true>), dim3(nblk), dim3(64), 0, s, d, t, partial);
   else
-    hipLaunchKernelGGL((k_cost<ND_, FISH_, false>), dim3(nblk), dim3(256), 0, s, d, t, partial);
+    hipLaunchKernelGGL((k_cost<ND_, FISH_, false>), dim3(nblk), dim3(64), 0, s, d, t, partial);
 }
 
 void jacobian(const Dims& d, const Tables& t, hipStream_t s, int row_nnz, double* vals, int32_t* cols) {

@@ -109,26 +109,54 @@ __global__ void k_residual(Dims d, Tables t, double* __restrict__ r, double* __r
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// k_cost: 0.5 * sum rho(f^2) over the inliers of the shard; partial sums per block (fixed grid -> deterministic)
+// k_cost: 0.5 * sum rho(f^2) over the inliers of the shard; partial sums per workgroup (fixed grid -> deterministic).
+// Persistent single-wave workgroups walk the compact list of non-empty views like k_linearize does: the inlier bytes of
+// a view are ballot-compacted into a point list first, so the projections run on dense 64-lane chunks (about a quarter
+// of the table slots of a real rig hold an inlier; a thread-per-slot loop idles three lanes out of four).
 // ---------------------------------------------------------------------------------------------------------------
+constexpr int LIN_MAX_POINTS = 512;    // points per board supported by the compaction lists (mcba_create checks it)
+
 template <int ND, bool FISH, bool ROLL>
-__global__ void k_cost(Dims d, Tables t, double* __restrict__ partial) {
-  __shared__ double scratch[16];
-  const int n = d.slots();
+__global__ __launch_bounds__(64) void k_cost(Dims d, Tables t, double* __restrict__ partial) {
+  __shared__ uint16_t pidx[LIN_MAX_POINTS];
+  const int lane = threadIdx.x;
+  const int n_active = t.active_views[0];
   double acc = 0.0;
-  for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
-    if (!t.inlier[s]) continue;
-    const int p = s % d.P, v = s / d.P;
+  for (int vi = blockIdx.x; vi < n_active; vi += gridDim.x) {
+    const int v = t.active_views[1 + vi];
     const int b = v % d.B, c = (v / d.B) % d.C;
-    const double2 ob = t.obs[s];
-    double uv[2], Xs[3], Xe[3], tr;
-    slot_forward<ND, FISH, ROLL, false>(d, t, v, c, b, p, ob, uv, nullptr, nullptr, Xs, Xe, tr);
-    double rs, fs;
-    acc += robust_loss(d.loss, d.f_scale, uv[0] - ob.x, &rs, &fs);
-    acc += robust_loss(d.loss, d.f_scale, uv[1] - ob.y, &rs, &fs);
+    constexpr int NPB64 = LIN_MAX_POINTS / 64;
+    uint8_t inb[NPB64];
+#pragma unroll
+    for (int k = 0; k < NPB64; ++k) {
+      const int p = k * 64 + lane;
+      inb[k] = p < d.P ? t.inlier[(size_t)v * d.P + p] : (uint8_t)0;
+    }
+    int count = 0;
+#pragma unroll
+    for (int k = 0; k < NPB64; ++k) {
+      const bool in = inb[k] != 0;
+      const unsigned long long m = __ballot(in);
+      if (in) pidx[count + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(k * 64 + lane);
+      count += __popcll(m);
+    }
+    lds_fence();
+    for (int base = 0; base < count; base += 64) {
+      const int i = base + lane;
+      if (i < count) {
+        const int p = pidx[i];
+        const double2 ob = t.obs[(size_t)v * d.P + p];
+        double uv[2], Xs[3], Xe[3], tr;
+        slot_forward<ND, FISH, ROLL, false>(d, t, v, c, b, p, ob, uv, nullptr, nullptr, Xs, Xe, tr);
+        double rs, fs;
+        acc += robust_loss(d.loss, d.f_scale, uv[0] - ob.x, &rs, &fs);
+        acc += robust_loss(d.loss, d.f_scale, uv[1] - ob.y, &rs, &fs);
+      }
+    }
+    lds_fence();   // the next view rewrites the list
   }
-  const double tot = block_reduce<false>(acc, scratch);
-  if (threadIdx.x == 0) partial[blockIdx.x] = 0.5 * tot;
+  const double tot = wave_sum(acc);
+  if (lane == 0) partial[blockIdx.x] = 0.5 * tot;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -336,7 +364,6 @@ __global__ __launch_bounds__(256) void k_points(Dims d, Tables t, double* __rest
 //   LDS: one buffer is time-shared between the row staging and the epilogue matrices (S, Y) to keep >= 2 waves/SIMD.
 //   MFMA=false keeps the identical data flow with plain FMAs over the staged rows (validation / fallback build).
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int LIN_MAX_POINTS = 512;    // points per board supported by the compaction list (mcba_create checks it)
 
 // __launch_bounds__(64, 2): two waves per SIMD = a 256-register budget.  Besides fixing the occupancy the kernel is
 // designed for, this makes hipcc select the VGPR form of the MFMA: with the default 512-register budget it keeps the

@@ -260,15 +260,18 @@ __global__ void k_dense_hessian(Dims d, const double* __restrict__ Hss, const do
 // trust-region driver kernels.  Vectors of length n live on the device and are complete (replicated) on every
 // rank of a frame-sharded problem; only H-dependent partial sums are reduced across ranks.
 // ---------------------------------------------------------------------------------------------------------------
-// scipy compute_jac_scale (common.py:598-611) + g_h = d * g.   out = {|g|_inf, |g_h|^2, |x * scale_inv|^2}
-// (g and diag are complete on every rank: sharded handles all-reduce them before this kernel)
-__global__ void k_vec_scale(Dims d, const double* __restrict__ x, const double* __restrict__ g,
-                            const double* __restrict__ diag, double* __restrict__ scale_inv, double* __restrict__ dsc,
-                            double* __restrict__ gh, int first, double* __restrict__ out,
-                            const double* __restrict__ cost_count = nullptr) {
+// scipy compute_jac_scale (common.py:598-611) + g_h = d * g, one element per thread.
+// part[3 blk + {0,1,2}] = {|g|_inf, |g_h|^2, |x * scale_inv|^2} of the block (the host folds the blocks: the vectors are
+// complete on every rank, so there is nothing to all-reduce); block 0 forwards {cost, count} of the linearisation.
+__global__ __launch_bounds__(256) void k_vec_scale(Dims d, const double* __restrict__ x, const double* __restrict__ g,
+                                                   const double* __restrict__ diag, double* __restrict__ scale_inv,
+                                                   double* __restrict__ dsc, double* __restrict__ gh, int first,
+                                                   double* __restrict__ part, const double* __restrict__ cost_count,
+                                                   double* __restrict__ cost_out) {
   __shared__ double scratch[16];
   double mx = 0, gg = 0, xs = 0;
-  for (int i = threadIdx.x; i < d.n; i += blockDim.x) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < d.n) {
     double si = sqrt(diag[i]);
     if (first) { if (si == 0.0) si = 1.0; }
     else si = fmax(si, scale_inv[i]);
@@ -277,16 +280,18 @@ __global__ void k_vec_scale(Dims d, const double* __restrict__ x, const double* 
     dsc[i] = di;
     const double gi = g[i];
     gh[i] = di * gi;
-    mx = fmax(mx, fabs(gi));
-    gg += di * gi * di * gi;
-    xs += x[i] * si * x[i] * si;
+    mx = fabs(gi);
+    gg = di * gi * di * gi;
+    xs = x[i] * si * x[i] * si;
   }
   const double a = block_reduce<true>(mx, scratch);
   const double b = block_reduce<false>(gg, scratch);
   const double c = block_reduce<false>(xs, scratch);
   if (threadIdx.x == 0) {
-    out[0] = a; out[1] = b; out[2] = c;
-    if (cost_count) { out[16] = cost_count[0]; out[17] = cost_count[1]; }
+    part[3 * blockIdx.x + 0] = a;
+    part[3 * blockIdx.x + 1] = b;
+    part[3 * blockIdx.x + 2] = c;
+    if (blockIdx.x == 0 && cost_count) { cost_out[0] = cost_count[0]; cost_out[1] = cost_count[1]; }
   }
 }
 
@@ -1152,89 +1157,107 @@ __global__ void k_cholb_back_update(int ns, int k0, double* __restrict__ A) {
   y[j] -= sum;
 }
 
-// back-substitution: gn_s = p_s ; gn_f = L^-T (y_f - W p_s).  FPB frames per block, one thread per eliminated row
-// (frame, dd): the row of W is streamed by its own lane (p_s is wave-uniform), z goes through LDS and the same
-// thread applies column dd of L^-1.  The last block copies the shared part.
+// back-substitution: gn_s = p_s ; gn_f = L^-T (y_f - W p_s).  One wavefront per frame: W p_s (DF x ns, rows padded to
+// 16) runs on the matrix pipe with p_s broadcast over the 16 output columns -- the MFMA does the cross-lane reduction
+// that a lane-per-column dot product would need 12 shuffles trees for; z goes through LDS and lane dd < DF applies
+// column dd of L^-1.  The last block copies the shared part.  dots (may be null): partial dots over the entries the
+// block has written, dots[3 blk + {0,1,2}] = {g_h.g_h, g_h.gn, gn.gn}, and the Cholesky pivot report in
+// dots[3 gridDim.x] -- summed on the host by the single-GPU driver (sharded handles need the all-reduced gn: k_dots3).
 template <int DF>
-__global__ __launch_bounds__(192) void k_schur_backsub(Dims d, const double* __restrict__ Linv, const double* __restrict__ W,
-                                                       const double* __restrict__ yf, const double* __restrict__ ps,
-                                                       double* __restrict__ gn, const double* __restrict__ gh,
-                                                       const int* __restrict__ info, double* __restrict__ dots) {
-  constexpr int FPB = 192 / DF;
-  __shared__ double z[192];
-  __shared__ double scratch[16];
-  const int ns = d.ns;
-  const bool shared_blk = blockIdx.x == gridDim.x - 1;
-  if (shared_blk) {   // last block of the grid: shared part
-    for (int i = threadIdx.x; i < d.n; i += blockDim.x) {
-      const int s = d.x_to_shared(i);
-      if (s >= 0) gn[i] = ps[s];         // frame entries: written by their own blocks; other shards' stay 0 (memset)
+__global__ __launch_bounds__(64) void k_schur_backsub(Dims d, const double* __restrict__ Linv, const double* __restrict__ W,
+                                                      const double* __restrict__ yf, const double* __restrict__ ps,
+                                                      double* __restrict__ gn, const double* __restrict__ gh,
+                                                      const int* __restrict__ info, double* __restrict__ dots) {
+  __shared__ double zs[16];
+  __shared__ double dl[3][16];
+  const int ns = d.ns, lane = threadIdx.x;
+  if (blockIdx.x == gridDim.x - 1) {   // last block: shared part (frame entries of other shards stay 0: memset)
+    double dt[3] = {0, 0, 0};
+    for (int s = lane; s < ns; s += 64) {
+      const int xi = d.shared_to_x(s);
+      const double a = gh[xi], b = ps[s];
+      gn[xi] = b;
+      dt[0] += a * a; dt[1] += a * b; dt[2] += b * b;
     }
-  }
-  const int fq = threadIdx.x / DF, dd = threadIdx.x % DF, fl = blockIdx.x * FPB + fq;
-  const bool live = !shared_blk && fq < FPB && fl < d.Fl;
-  if (live) {
-    const double* w = W + ((size_t)fl * DF + dd) * (ns + 1);
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    int s = 0;
-    for (; s + 4 <= ns; s += 4) {
-      a0 += w[s] * ps[s];
-      a1 += w[s + 1] * ps[s + 1];
-      a2 += w[s + 2] * ps[s + 2];
-      a3 += w[s + 3] * ps[s + 3];
+    if (dots == nullptr) return;
+    for (int k = 0; k < 3; ++k) {
+      const double ds = wave_sum(dt[k]);
+      if (lane == 0) dots[3 * blockIdx.x + k] = ds;
     }
-    for (; s < ns; ++s) a0 += w[s] * ps[s];
-    z[threadIdx.x] = yf[fl * DF + dd] - ((a0 + a1) + (a2 + a3));
+    if (lane == 0) dots[3 * gridDim.x] = (double)info[0];
+    return;
   }
-  __syncthreads();
-  if (live) {
-    const double* X = Linv + (size_t)fl * DF * DF;
-    double v = 0.0;
+  const int fl = blockIdx.x, ldw = ns + 1;
+  const double* w = W + (size_t)fl * DF * ldw;
+  const int ri = lane & 15, kq = lane >> 4;
+  double4_t acc = {0.0, 0.0, 0.0, 0.0};
+  constexpr int UB = 8;
+  for (int k0 = 0; k0 < ns; k0 += 4 * UB) {
+    double av[UB], bv[UB];
 #pragma unroll
-    for (int k = 0; k < DF; ++k) v += (k >= dd) ? X[k * DF + dd] * z[fq * DF + k] : 0.0;
-    gn[d.frame_to_x(d.f0 + fl, dd)] = v;
+    for (int u = 0; u < UB; ++u) {
+      const int kk = k0 + 4 * u + kq;
+      av[u] = (ri < DF && kk < ns) ? w[ri * ldw + kk] : 0.0;
+      bv[u] = kk < ns ? ps[kk] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
   }
-  // partial dots {g_h.g_h, g_h.gn, gn.gn} over the entries this block has just written: dots[3 blk + k], plus the
-  // Cholesky pivot report as dots[3 gridDim.x] -- the single-GPU driver sums them on the host with the scalars it
-  // fetches anyway (sharded handles pass dots == nullptr: they need the all-reduced gn first, k_dots3).
+  if (ri == 0) {   // output column 0 (all 16 columns are equal): rows kq + 4 r
+#pragma unroll
+    for (int r = 0; r < 4; ++r) zs[kq + 4 * r] = acc[r];
+  }
+  lds_fence();
+  double a = 0.0, v = 0.0;
+  if (lane < DF) {
+    const double* X = Linv + (size_t)fl * DF * DF;
+#pragma unroll
+    for (int k = 0; k < DF; ++k) v += (k >= lane) ? X[k * DF + lane] * (yf[fl * DF + k] - zs[k]) : 0.0;
+    const int xi = d.frame_to_x(d.f0 + fl, lane);
+    gn[xi] = v;
+    a = gh[xi];
+  }
   if (dots == nullptr) return;
-  double dt[3] = {0, 0, 0};
-  if (shared_blk) {
-    for (int i = threadIdx.x; i < d.n; i += blockDim.x)
-      if (d.x_to_shared(i) >= 0) {
-        const double a = gh[i], b = gn[i];     // written by this very thread above
-        dt[0] += a * a; dt[1] += a * b; dt[2] += b * b;
-      }
-    if (threadIdx.x == 0) dots[3 * gridDim.x] = (double)info[0];
-  } else if (live) {
-    const int xi = d.frame_to_x(d.f0 + fl, dd);
-    const double a = gh[xi], b = gn[xi];
-    dt[0] = a * a; dt[1] = a * b; dt[2] = b * b;
+  if (lane < 16) {
+    dl[0][lane] = a * a;
+    dl[1][lane] = a * v;
+    dl[2][lane] = v * v;
   }
-  for (int k = 0; k < 3; ++k) {
-    const double ds = block_reduce<false>(dt[k], scratch);
-    if (threadIdx.x == 0) dots[3 * blockIdx.x + k] = ds;
+  lds_fence();
+  if (lane < 3) {
+    double sum = 0.0;
+#pragma unroll
+    for (int k = 0; k < DF; ++k) sum += dl[lane][k];
+    dots[3 * blockIdx.x + lane] = sum;
   }
 }
 
-// step: p_h = alpha u0 + beta u1; step = d * p_h; x_new = x + step.   out = {|p_h|^2, |step|^2, |x|^2}
-__global__ void k_vec_step(Dims d, const double* __restrict__ x, const double* __restrict__ dsc,
-                           const double* __restrict__ u0, const double* __restrict__ u1, double alpha, double beta,
-                           double* __restrict__ xnew, double* __restrict__ out) {
+// step: p_h = alpha u0 + beta u1; step = d * p_h; x_new = x + step, one element per thread.
+// part[3 blk + {0,1,2}] = {|p_h|^2, |step|^2, |x|^2} of the block (folded by the host)
+__global__ __launch_bounds__(256) void k_vec_step(Dims d, const double* __restrict__ x, const double* __restrict__ dsc,
+                                                  const double* __restrict__ u0, const double* __restrict__ u1,
+                                                  double alpha, double beta, double* __restrict__ xnew,
+                                                  double* __restrict__ part) {
   __shared__ double scratch[16];
   double ph = 0, st = 0, xx = 0;
-  for (int i = threadIdx.x; i < d.n; i += blockDim.x) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < d.n) {
     const double p = alpha * u0[i] + beta * u1[i];
     const double s = dsc[i] * p;
-    xnew[i] = x[i] + s;
-    ph += p * p;
-    st += s * s;
-    xx += x[i] * x[i];
+    const double xi = x[i];
+    xnew[i] = xi + s;
+    ph = p * p;
+    st = s * s;
+    xx = xi * xi;
   }
   const double a = block_reduce<false>(ph, scratch);
   const double b = block_reduce<false>(st, scratch);
   const double c = block_reduce<false>(xx, scratch);
-  if (threadIdx.x == 0) { out[0] = a; out[1] = b; out[2] = c; }
+  if (threadIdx.x == 0) {
+    part[3 * blockIdx.x + 0] = a;
+    part[3 * blockIdx.x + 1] = b;
+    part[3 * blockIdx.x + 2] = c;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -16,6 +16,9 @@ with Handle(c) as h:
     print("perturbed solve s", dt, "nfev", res.nfev, "njev", res.njev, "status", res.status, "cost", res.cost,
           "ms/iter", dt / max(res.nfev - 1, 1) * 1e3)
     rng = np.random.default_rng(0)
+    for _ in range(3):
+        t0 = time.perf_counter(); res = h.solve(x1); dt = time.perf_counter() - t0
+        print("  repeat: ms/iter", dt / max(res.nfev - 1, 1) * 1e3, "total ms", dt * 1e3)
     for ns in (140,):
         M = rng.normal(size=(ns + 20, ns)); S = M.T @ M / ns + 0.1 * np.eye(ns); rhs = rng.normal(size=ns)
         st = h.debug_chol(S, rhs, reg=0.05, blocked=4)[:8]
