@@ -219,10 +219,16 @@ void upload_x(mcba_handle_s* h, const double* x, double* dst) {
 }
 
 // x (device) -> pose / camera / view tables
-void eval_tables(mcba_handle_s* h, const double* dx) {
+// pose / camera / board-point tables only (enough for k_cost and for launch_linearize, whose k_tmat rebuilds the view table)
+void eval_pose_tables(mcba_handle_s* h, const double* dx) {
   const Dims& d = h->d;
   const int items = d.n_pose + d.C + d.B * d.P;
   hipLaunchKernelGGL(k_prep, dim3((items + 127) / 128), dim3(128), 0, h->stream, d, h->t, dx);
+}
+
+void eval_tables(mcba_handle_s* h, const double* dx) {
+  const Dims& d = h->d;
+  eval_pose_tables(h, dx);
   const int nv = d.views() * (d.motion == MOTION_ROLLING ? 2 : 1);
   if (nv > 0) hipLaunchKernelGGL(k_views, dim3((nv + 127) / 128), dim3(128), 0, h->stream, d, h->t);
 }
@@ -244,17 +250,17 @@ void launch_cost(mcba_handle_s* h, double* out_dev) {
 // fused residual+Jacobian -> block normal equations at the current tables
 void launch_linearize(mcba_handle_s* h) {
   const Dims& d = h->d;
-  const int ncol = d.views() * 6 * d.NPB;
-  if (ncol > 0) hipLaunchKernelGGL(k_tmat, dim3((ncol + 255) / 256), dim3(256), 0, h->stream, d, h->t);
+  // k_tmat also zeroes [g | diag | cost] and H_ss for the assembly that follows (entries of frames owned by other ranks
+  // must be zero before the cross-rank sum: they hold the previous global values after an all-reduce)
+  static_assert(TMV * 4 <= 64, "k_tmat: (view, pose block) threads of a workgroup");
+  hipLaunchKernelGGL(k_tmat, dim3(std::max((d.views() + TMV - 1) / TMV, 1)), dim3(64), 0, h->stream, d, h->t, h->gbuf.p,
+                     2 * d.n + 2, h->Hss.p, d.ns * d.ns);
   h->ops->linearize(d, h->t, h->stream, h->rec.p, h->tri.p, h->use_mfma, h->lin_grid);
 }
 
 void launch_assemble(mcba_handle_s* h) {
   const Dims& d = h->d;
-  // entries of frames owned by other ranks must be zero before the cross-rank sum (they hold the previous global
-  // values after an all-reduce)
-  HIP_OK(hipMemsetAsync(h->gbuf.p, 0, (2 * (size_t)d.n + 2) * sizeof(double), h->stream));
-  HIP_OK(hipMemsetAsync(h->Hss.p, 0, (size_t)d.ns * d.ns * sizeof(double), h->stream));
+  // ([g | diag | cost] and H_ss were zeroed by k_tmat at the start of this linearisation)
   const int nfb = (d.DF > 0) ? d.Fl : 0;
   hipLaunchKernelGGL(k_assemble, dim3(nfb + d.C * d.B * h->nchunk), dim3(256), 0, h->stream, d, h->t, h->rec.p, nfb,
                      h->nchunk, h->Hff.p, h->Hfs.p, h->g(), h->diag(), h->partial.p);
@@ -1128,7 +1134,7 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
       const double alpha = Cm[0] * pS[0] + Cm[1] * pS[1], beta = Cm[2] * pS[0] + Cm[3] * pS[1];
       hipLaunchKernelGGL(k_vec_step, dim3(sl.nvb), dim3(256), 0, h->stream, d, h->x.p, h->dsc.p, h->gh.p, h->gn.p, alpha,
                          beta, h->xnew.p, h->scal.p + sl.step);
-      eval_tables(h, h->xnew.p);
+      eval_pose_tables(h, h->xnew.p);
       if (host_sums) {
         h->ops->cost(d, h->t, h->stream, h->scal.p + sl.costp, h->cost_blocks);
         fetch_scalars(h, sl.costp + h->cost_blocks - sl.step, sl.step);

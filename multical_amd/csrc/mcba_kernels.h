@@ -124,7 +124,12 @@ __global__ __launch_bounds__(64) void k_cost(Dims d, Tables t, double* __restric
   double acc = 0.0;
   for (int vi = blockIdx.x; vi < n_active; vi += gridDim.x) {
     const int v = t.active_views[1 + vi];
-    const int b = v % d.B, c = (v / d.B) % d.C;
+    const int b = v % d.B, c = (v / d.B) % d.C, f = d.f0 + v / (d.B * d.C);
+    // the chain matrices of the view straight from the pose table (wave-uniform work, done by every lane): a trial step
+    // then needs k_prep only, not the per-view table pass k_views
+    double Vc[ROLL ? 2 * VIEW_STRIDE : VIEW_STRIDE];
+    view_chain(d, t, f, c, b, 0, Vc);
+    if constexpr (ROLL) view_chain(d, t, f, c, b, 1, Vc + VIEW_STRIDE);
     constexpr int NPB64 = LIN_MAX_POINTS / 64;
     uint8_t inb[NPB64];
 #pragma unroll
@@ -147,7 +152,7 @@ __global__ __launch_bounds__(64) void k_cost(Dims d, Tables t, double* __restric
         const int p = pidx[i];
         const double2 ob = t.obs[(size_t)v * d.P + p];
         double uv[2], Xs[3], Xe[3], tr;
-        slot_forward<ND, FISH, ROLL, false>(d, t, v, c, b, p, ob, uv, nullptr, nullptr, Xs, Xe, tr);
+        slot_forward<ND, FISH, ROLL, false>(d, t, v, c, b, p, ob, uv, nullptr, nullptr, Xs, Xe, tr, nullptr, Vc);
         double rs, fs;
         acc += robust_loss(d.loss, d.f_scale, uv[0] - ob.x, &rs, &fs);
         acc += robust_loss(d.loss, d.f_scale, uv[1] - ob.y, &rs, &fs);

@@ -34,15 +34,34 @@ __global__ void k_views(Dims d, Tables t) {
   view_item(d, t, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
-// That columns of every non-empty view (one thread per (view, column)): tmat[v][a][j], a < DE, j < 6*NPB
-__global__ void k_tmat(Dims d, Tables t) {
-  const int npc = 6 * d.NPB;
+// That of every non-empty view: tmat[v][a][j], a < DE, j < 6 NPB.  One thread per (view, pose block): the chain prefix
+// of the block is computed once and shared by its six columns (a thread per column re-read the three pose entries and
+// redid the chain 24 times per view); the columns of TMV views are transposed through LDS so that the table is written
+// with coalesced stores (writing 48-byte pieces straight from the (view, block) threads was 2x slower than the
+// thread-per-column kernel).  The kernel opens every linearisation, so it also zeroes the two accumulation targets of
+// the assembly that follows ([g | diag | cost] and H_ss) -- two fill launches less.
+constexpr int TMV = 16;   // views per workgroup
+__global__ __launch_bounds__(64) void k_tmat(Dims d, Tables t, double* __restrict__ zero_a, int na,
+                                             double* __restrict__ zero_b, int nb) {
+  __shared__ double tile[TMV * 12 * 24];
+  const int NPB = d.NPB, npc = 6 * NPB, DE = d.DE, vsz = DE * npc;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= d.views() * npc) return;
-  const int v = i / npc, j = i % npc;
-  if (t.view_count[v] == 0) return;
-  const int b = v % d.B, c = (v / d.B) % d.C, fl = v / (d.B * d.C), f = d.f0 + fl;
-  view_column(d, t, f, c, b, j, t.tmat + (size_t)v * d.DE * npc + j, npc);
+  for (int e = i; e < na; e += gridDim.x * blockDim.x) zero_a[e] = 0.0;
+  for (int e = i; e < nb; e += gridDim.x * blockDim.x) zero_b[e] = 0.0;
+  const int v0 = blockIdx.x * TMV, nv = min(TMV, d.views() - v0);
+  if (nv <= 0) return;
+  const int vl = threadIdx.x / NPB, k = threadIdx.x % NPB, v = v0 + vl;
+  if (vl < nv && t.view_count[v] != 0) {
+    const int b = v % d.B, c = (v / d.B) % d.C, fl = v / (d.B * d.C), f = d.f0 + fl;
+    view_block_columns(d, t, f, c, b, k, tile + vl * vsz + 6 * k, npc);
+    if (k == NPB - 1) {   // the view table too: the trial step that led here only ran k_prep (k_cost forms its own chains)
+      const int nch = d.motion == MOTION_ROLLING ? 2 : 1;
+      for (int ch = 0; ch < nch; ++ch) view_chain(d, t, f, c, b, ch, t.view + (size_t)v * d.view_stride() + ch * VIEW_STRIDE);
+    }
+  }
+  __syncthreads();
+  double* tg = t.tmat + (size_t)v0 * vsz;   // views of a workgroup are contiguous; empty views get stale LDS (never read)
+  for (int e = threadIdx.x; e < nv * vsz; e += blockDim.x) tg[e] = tile[e];
 }
 
 // ---------------------------------------------------------------------------------------------------------------

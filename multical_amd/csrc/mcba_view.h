@@ -25,9 +25,10 @@ MCBA_HD int tri_index(int i, int j, int N1) {   // packed upper triangle, i <= j
 template <int ND, bool FISH, bool ROLL, bool JAC>
 MCBA_HD void slot_forward(const Dims& d, const Tables& t, int v, int c, int b, int p, double2 ob,
                                              double* uv, double* A, double* Kc, double* Xs, double* Xe, double& tr,
-                                             const double* Xpre = nullptr /* prefetched board point */) {
+                                             const double* Xpre = nullptr /* prefetched board point */,
+                                             const double* Vpre = nullptr /* chain matrices of the view in registers */) {
   const double* X = Xpre != nullptr ? Xpre : t.board_points + 3 * (size_t)(b * d.P + p);
-  const double* V = t.view + (size_t)v * (VIEW_STRIDE * (ROLL ? 2 : 1));
+  const double* V = Vpre != nullptr ? Vpre : t.view + (size_t)v * (VIEW_STRIDE * (ROLL ? 2 : 1));
   const double* cam = t.cam + (size_t)c * CAM_STRIDE;
   const double bx = X[0], by = X[1], bz = X[2];
   double Xc[3];
@@ -115,6 +116,69 @@ MCBA_HD void view_column(const Dims& d, const Tables& t, int f, int c, int b, in
           view_pose_column(R3, Pb + POSE_L, o, jj, col, stride);
         }
       }
+    }
+  }
+}
+
+// All six columns of pose block k of That at once: out[a * stride + jj], a < DE, jj < 6 (same values as six calls of
+// view_column, but the chain prefix of the block is formed once).  Rows a block does not touch are written as zero.
+MCBA_HD void view_block_columns(const Dims& d, const Tables& t, int f, int c, int b, int k, double* out, int stride) {
+  const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  const double* Pc = t.pose + (size_t)(d.pose_cam + c) * POSE_STRIDE;
+  const double* Pb = t.pose + (size_t)(d.pose_board + b) * POSE_STRIDE;
+  const double* Rc = Pc + POSE_R;
+  const double* tc = Pc + POSE_T;
+  const int last = d.NPB - 1;
+  if (k == 0) {   // camera pose: identity prefix; rolling shutter: the same block acts on both chains
+    for (int jj = 0; jj < 6; ++jj) view_pose_column(I3, Pc + POSE_L, tc, jj, out + jj, stride);
+    if (d.motion == MOTION_ROLLING)
+      for (int a = 0; a < 6; ++a)
+        for (int jj = 0; jj < 6; ++jj) out[(6 + a) * stride + jj] = out[a * stride + jj];
+    return;
+  }
+  if (d.motion == MOTION_HAND_EYE) {   // chain camera . G . B_f . Wb . board ; local blocks: cam | wb | gc | board
+    const double* Wb = t.pose + (size_t)(d.pose_motion + 0) * POSE_STRIDE;
+    const double* G = t.pose + (size_t)(d.pose_motion + 1) * POSE_STRIDE;
+    const double* Bf = t.bwg + 12 * (size_t)f;
+    double R1[9], t1[3];
+    se3_mul(Rc, tc, G + POSE_R, G + POSE_T, R1, t1);            // camera . G
+    if (k == 2) {
+      for (int jj = 0; jj < 6; ++jj) view_pose_column(Rc, G + POSE_L, t1, jj, out + jj, stride);
+      return;
+    }
+    double R2[9], t2[3], R3[9], t3[3];
+    se3_mul(R1, t1, Bf, Bf + 9, R2, t2);                         // . B_f
+    se3_mul(R2, t2, Wb + POSE_R, Wb + POSE_T, R3, t3);           // . Wb
+    if (k == 1) {
+      for (int jj = 0; jj < 6; ++jj) view_pose_column(R2, Wb + POSE_L, t3, jj, out + jj, stride);
+    } else {
+      double o[3], v3[3];
+      mat3_vec(R3, Pb + POSE_T, v3);
+      for (int i = 0; i < 3; ++i) o[i] = t3[i] + v3[i];
+      for (int jj = 0; jj < 6; ++jj) view_pose_column(R3, Pb + POSE_L, o, jj, out + jj, stride);
+    }
+    return;
+  }
+  const int nch = d.motion == MOTION_ROLLING ? 2 : 1;
+  for (int ch = 0; ch < nch; ++ch) {
+    double* o6 = out + 6 * ch * stride;
+    // rolling shutter: block 1 = start pose (chain 0 only), block 2 = end pose (chain 1 only), block 3 = board (both)
+    const bool touches = k == last || nch == 1 || k == 1 + ch;
+    if (!touches) {
+      for (int a = 0; a < 6; ++a)
+        for (int jj = 0; jj < 6; ++jj) o6[a * stride + jj] = 0.0;
+      continue;
+    }
+    const double* Pf = t.pose + (size_t)(d.pose_motion + ch * d.F + f) * POSE_STRIDE;
+    double R1[9], t1[3];
+    se3_mul(Rc, tc, Pf + POSE_R, Pf + POSE_T, R1, t1);            // camera . frame
+    if (k == last) {
+      double o[3], v3[3];
+      mat3_vec(R1, Pb + POSE_T, v3);
+      for (int i = 0; i < 3; ++i) o[i] = t1[i] + v3[i];
+      for (int jj = 0; jj < 6; ++jj) view_pose_column(R1, Pb + POSE_L, o, jj, o6 + jj, stride);
+    } else {
+      for (int jj = 0; jj < 6; ++jj) view_pose_column(Rc, Pf + POSE_L, t1, jj, o6 + jj, stride);
     }
   }
 }
@@ -229,11 +293,8 @@ MCBA_HD void prep_item(const Dims& d, const Tables& t, const double* x, int i) {
   }
 }
 
-MCBA_HD void view_item(const Dims& d, const Tables& t, int i) {
-  const int nch = d.motion == MOTION_ROLLING ? 2 : 1;
-  if (i >= d.views() * nch) return;
-  const int v = i / nch, ch = i % nch;
-  const int b = v % d.B, c = (v / d.B) % d.C, fl = v / (d.B * d.C), f = d.f0 + fl;
+// chain matrix board -> camera of view (f, c, b), chain ch (rolling shutter: 0 = start pose, 1 = end pose): out[12] = R | t
+MCBA_HD void view_chain(const Dims& d, const Tables& t, int f, int c, int b, int ch, double* out) {
   const double* Pc = t.pose + (size_t)(d.pose_cam + c) * POSE_STRIDE;
   const double* Pb = t.pose + (size_t)(d.pose_board + b) * POSE_STRIDE;
   double R1[9], t1[3], R2[9], t2[3];
@@ -250,9 +311,16 @@ MCBA_HD void view_item(const Dims& d, const Tables& t, int i) {
     se3_mul(Pc + POSE_R, Pc + POSE_T, Pf + POSE_R, Pf + POSE_T, R1, t1);
     se3_mul(R1, t1, Pb + POSE_R, Pb + POSE_T, R2, t2);
   }
-  double* out = t.view + (size_t)v * d.view_stride() + ch * VIEW_STRIDE;
   for (int k = 0; k < 9; ++k) out[k] = R2[k];
   for (int k = 0; k < 3; ++k) out[9 + k] = t2[k];
+}
+
+MCBA_HD void view_item(const Dims& d, const Tables& t, int i) {
+  const int nch = d.motion == MOTION_ROLLING ? 2 : 1;
+  if (i >= d.views() * nch) return;
+  const int v = i / nch, ch = i % nch;
+  const int b = v % d.B, c = (v / d.B) % d.C, fl = v / (d.B * d.C), f = d.f0 + fl;
+  view_chain(d, t, f, c, b, ch, t.view + (size_t)v * d.view_stride() + ch * VIEW_STRIDE);
 }
 
 }  // namespace mcba
