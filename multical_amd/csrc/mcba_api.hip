@@ -79,7 +79,6 @@ struct DevBuf {
   }
 };
 
-constexpr double REG_FLOOR = 1e-10;   // floor of the Levenberg-Marquardt damping in the scaled space (gauge null space)
 constexpr int COST_BLOCKS_MAX = 3072;   // persistent single-wave workgroups of k_cost (see LIN_GRID_MAX)
 // Scalars fetched by the trust-region driver at its three synchronisation points.  Each fetch is ONE contiguous
 // device-to-host copy that also carries per-block partial sums, which the host folds in a fixed order: that saves the
@@ -300,15 +299,6 @@ void launch_q00(mcba_handle_s* h, const double* u, int off) {
   call_allreduce(h, h->scal.p + off, 1, 0);
 }
 
-// quadratic forms + dots of (u0, u1) -> scal[off .. off+6)   (two-vector version: debug / validation only)
-void launch_quadforms(mcba_handle_s* h, const double* u0, const double* u1, int off) {
-  const Dims& d = h->d;
-  const int nblk = (d.DF > 0 ? d.Fl : 0) + 1;
-  hipLaunchKernelGGL(k_quadforms, dim3(nblk), dim3(256), 0, h->stream, d, h->Hss.p, h->Hfs.p, h->Hff.p, h->dsc.p, u0, u1,
-                     h->qpart.p);
-  hipLaunchKernelGGL(k_quadforms_final, dim3(1), dim3(256), 0, h->stream, d, h->qpart.p, nblk, u0, u1, h->scal.p + off);
-  call_allreduce(h, h->scal.p + off, 3, 0);
-}
 
 
 constexpr size_t CHOL_SINGLE_MAX_LDS = 96 * 1024;
@@ -371,7 +361,10 @@ int gn_dot_blocks(const Dims& d) {
   const int K = d.DF * d.Fl;
   return (K > 0 ? d.Fl : 0) + 1;
 }
-void launch_gn_solve(mcba_handle_s* h, double reg, bool root_rank, double* dots_out = nullptr) {
+// tr_dev (device, may be null): the scalar block of the single-GPU driver; the damping is then read from tr_dev[TR_REG]
+// on the device (`reg` is ignored) and added to the reduced system by k_schur_reduce.
+void launch_gn_solve(mcba_handle_s* h, double reg, bool root_rank, double* dots_out = nullptr,
+                     const double* tr_dev = nullptr) {
   const Dims& d = h->d;
   const int K = d.DF * d.Fl;
   const bool sharded_frames = h->allreduce && K > 0;
@@ -381,11 +374,11 @@ void launch_gn_solve(mcba_handle_s* h, double reg, bool root_rank, double* dots_
   if (K > 0) {
     if (d.DF == 12) {
       hipLaunchKernelGGL((k_frame_factor<12>), dim3((d.Fl + 63) / 64), dim3(64), 0, h->stream, d, h->Hff.p, h->dsc.p, h->gh.p,
-                         reg, h->Lf.p, h->W.p, h->yf.p);
+                         reg, h->Lf.p, h->W.p, h->yf.p, tr_dev);
       hipLaunchKernelGGL((k_schur_w<12>), dim3(d.Fl), dim3(256), 0, h->stream, d, h->Hfs.p, h->dsc.p, h->Lf.p, h->W.p);
     } else {
       hipLaunchKernelGGL((k_frame_factor<6>), dim3((d.Fl + 63) / 64), dim3(64), 0, h->stream, d, h->Hff.p, h->dsc.p, h->gh.p,
-                         reg, h->Lf.p, h->W.p, h->yf.p);
+                         reg, h->Lf.p, h->W.p, h->yf.p, tr_dev);
       hipLaunchKernelGGL((k_schur_w<6>), dim3(d.Fl), dim3(256), 0, h->stream, d, h->Hfs.p, h->dsc.p, h->Lf.p, h->W.p);
     }
     const int nt2 = h->ntile * (h->ntile + 1) / 2;
@@ -398,9 +391,9 @@ void launch_gn_solve(mcba_handle_s* h, double reg, bool root_rank, double* dots_
   }
   const int total = d.ns * d.ns + d.ns;
   hipLaunchKernelGGL(k_schur_reduce, dim3(std::min(1024, (total + 255) / 256)), dim3(256), 0, h->stream, d, h->Hss.p,
-                     h->dsc.p, h->gh.p, h->P.p, h->ntile, h->ksplit, K, root_rank ? 1.0 : 0.0, h->sbuf.p);
+                     h->dsc.p, h->gh.p, h->P.p, h->ntile, h->ksplit, K, root_rank ? 1.0 : 0.0, h->sbuf.p, tr_dev);
   call_allreduce(h, h->sbuf.p, (size_t)total, 0);
-  launch_chol(h, d.ns, reg, h->sbuf.p, h->ps.p);
+  launch_chol(h, d.ns, tr_dev ? 0.0 : reg, h->sbuf.p, h->ps.p);
   if (d.DF == 12) {
     const int nblk = gn_dot_blocks(d);
     hipLaunchKernelGGL((k_schur_backsub<12>), dim3(nblk), dim3(64), 0, h->stream, d, h->Lf.p, h->W.p, h->yf.p, h->ps.p,
@@ -417,117 +410,6 @@ void launch_gn_solve(mcba_handle_s* h, double reg, bool root_rank, double* dots_
     if (dots_out) hipLaunchKernelGGL(k_dots3, dim3(1), dim3(1024), 0, h->stream, d.n, h->gh.p, h->gn.p, dots_out);
   }
 }
-
-// ---- host-side 2-D trust-region algebra (scipy/optimize/_lsq/common.py) ---------------------------------------
-void minimize_quadratic_1d(double a, double b, double lb, double ub, double* t_out, double* y_out) {
-  double t[3] = {lb, ub, 0};
-  int n = 2;
-  if (a != 0) {
-    const double ext = -0.5 * b / a;
-    if (lb < ext && ext < ub) t[n++] = ext;
-  }
-  double best = std::numeric_limits<double>::infinity();
-  for (int i = 0; i < n; ++i) {
-    const double y = t[i] * (a * t[i] + b);
-    if (y < best) { best = y; *t_out = t[i]; }
-  }
-  *y_out = best;
-}
-
-// real roots of a polynomial of degree <= 4 (coefficients highest power first); Durand-Kerner + Newton polish
-int real_roots(const double* coeffs_in, int ncoef, double* roots) {
-  int start = 0;
-  while (start < ncoef && coeffs_in[start] == 0.0) ++start;   // numpy.roots strips leading zeros
-  int deg = ncoef - start - 1;
-  if (deg <= 0) return 0;
-  std::vector<double> c(coeffs_in + start, coeffs_in + ncoef);
-  // strip trailing zeros -> roots at 0
-  int nroots = 0;
-  while (deg > 0 && c[deg] == 0.0) { roots[nroots++] = 0.0; --deg; }
-  if (deg == 0) return nroots;
-  std::vector<std::complex<double>> z(deg);
-  const double lead = c[0];
-  double bound = 0;
-  for (int i = 1; i <= deg; ++i) bound = std::max(bound, std::fabs(c[i] / lead));
-  bound = 1.0 + bound;
-  for (int i = 0; i < deg; ++i) z[i] = std::polar(bound * 0.7, 0.4 + 2.0 * M_PI * i / deg);
-  auto eval = [&](std::complex<double> x) {
-    std::complex<double> v = c[0];
-    for (int i = 1; i <= deg; ++i) v = v * x + c[i];
-    return v;
-  };
-  for (int it = 0; it < 500; ++it) {
-    double change = 0;
-    for (int i = 0; i < deg; ++i) {
-      std::complex<double> den = lead;
-      for (int j = 0; j < deg; ++j)
-        if (j != i) den *= (z[i] - z[j]);
-      if (std::abs(den) == 0) den = 1e-300;
-      const std::complex<double> dz = eval(z[i]) / den;
-      z[i] -= dz;
-      change = std::max(change, std::abs(dz) / (1.0 + std::abs(z[i])));
-    }
-    if (change < 1e-15) break;
-  }
-  for (int i = 0; i < deg; ++i) {
-    if (std::fabs(z[i].imag()) > 1e-7 * (1.0 + std::fabs(z[i].real()))) continue;
-    double x = z[i].real();
-    for (int it = 0; it < 4; ++it) {   // Newton polish on the real axis
-      double v = c[0], dv = 0;
-      for (int k = 1; k <= deg; ++k) { dv = dv * x + v; v = v * x + c[k]; }
-      if (dv == 0) break;
-      const double nx = x - v / dv;
-      if (!std::isfinite(nx)) break;
-      x = nx;
-    }
-    roots[nroots++] = x;
-  }
-  return nroots;
-}
-
-// scipy solve_trust_region_2d
-void solve_trust_region_2d(const double B[3] /*b00,b01,b11*/, const double g[2], double Delta, double p[2]) {
-  const double b00 = B[0], b01 = B[1], b11 = B[2];
-  const double det = b00 * b11 - b01 * b01;
-  if (b00 > 0 && det > 0) {   // Cholesky succeeds <=> positive definite
-    const double p0 = -(b11 * g[0] - b01 * g[1]) / det, p1 = -(-b01 * g[0] + b00 * g[1]) / det;
-    if (p0 * p0 + p1 * p1 <= Delta * Delta) { p[0] = p0; p[1] = p1; return; }
-  }
-  const double a = b00 * Delta * Delta, b = b01 * Delta * Delta, c = b11 * Delta * Delta;
-  const double dd = g[0] * Delta, f = g[1] * Delta;
-  const double coeffs[5] = {-b + dd, 2 * (a - c + f), 6 * b, 2 * (-a + c + f), -b - dd};
-  double roots[8];
-  const int nr = real_roots(coeffs, 5, roots);
-  double best = std::numeric_limits<double>::infinity();
-  p[0] = 0; p[1] = -Delta;   // t -> infinity limit of the parametrisation, as a safe fallback candidate
-  auto consider = [&](double p0, double p1) {
-    const double val = 0.5 * (p0 * (b00 * p0 + b01 * p1) + p1 * (b01 * p0 + b11 * p1)) + g[0] * p0 + g[1] * p1;
-    if (val < best) { best = val; p[0] = p0; p[1] = p1; }
-  };
-  consider(0.0, -Delta);
-  for (int i = 0; i < nr; ++i) {
-    const double t = roots[i], q = 1 + t * t;
-    consider(Delta * 2 * t / q, Delta * (1 - t * t) / q);
-  }
-}
-
-void update_tr_radius(double& Delta, double actual, double predicted, double step_norm, bool bound_hit, double& ratio) {
-  if (predicted > 0) ratio = actual / predicted;
-  else if (predicted == 0 && actual == 0) ratio = 1;
-  else ratio = 0;
-  if (ratio < 0.25) Delta = 0.25 * step_norm;
-  else if (ratio > 0.75 && bound_hit) Delta *= 2.0;
-}
-
-int check_termination(double dF, double F, double dx_norm, double x_norm, double ratio, double ftol, double xtol) {
-  const bool f_ok = dF < ftol * F && ratio > 0.25;
-  const bool x_ok = dx_norm < xtol * (xtol + x_norm);
-  if (f_ok && x_ok) return 4;
-  if (f_ok) return 2;
-  if (x_ok) return 3;
-  return -100;   // None
-}
-
 
 // ---- device outlier loop -------------------------------------------------------------------------------------------
 void ensure_obs_index(mcba_handle_s* h) {
@@ -1008,11 +890,17 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
   const double t_start = now_seconds();
   set_loss(h, opt);
   const Dims& d = h->d;
+  const ScalLayout& sl = h->sl;
   const double ftol = opt->ftol, xtol = opt->xtol, gtol = opt->gtol;
   const int max_nfev = opt->max_nfev > 0 ? opt->max_nfev : d.n * 100;
   const double NaN = std::numeric_limits<double>::quiet_NaN();
   const bool is_root = h->shard_root;
-  const bool host_sums = h->allreduce == nullptr;   // single GPU: per-block partials are added up on the host
+  // Single GPU: the scalar trust-region algebra runs in one-wave kernels between the vector kernels (k_tr_reg, k_tr_step),
+  // so that a whole iteration -- scaling, Cauchy curvature, damped Gauss-Newton solve, 2-D subspace step, trial cost -- is
+  // enqueued at once and the host synchronises ONCE per iteration.  Frame-sharded handles run the same algebra
+  // (mcba_trmath.h) on the host between their all-reduces: three synchronisations per iteration.
+  const bool dev_tr = h->allreduce == nullptr;
+  double* S = h->h_scal;   // host copy of the scalar block scal[0 .. TR_NSLOTS)
 
   upload_x(h, x_inout, h->x.p);
   eval_tables(h, h->x.p);
@@ -1027,142 +915,120 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) lin_ms_total += ms;
   };
+  // trial step for coefficients given by the host (retries, sharded handles) or by k_tr_step (tr_dev)
+  auto enqueue_trial = [&](double alpha, double beta, const double* tr_dev) {
+    hipLaunchKernelGGL(k_vec_step, dim3(sl.nvb), dim3(256), 0, h->stream, d, h->x.p, h->dsc.p, h->gh.p, h->gn.p, alpha, beta,
+                       h->xnew.p, h->scal.p + sl.step, tr_dev);
+    eval_pose_tables(h, h->xnew.p);   // k_cost forms the view chains itself; k_tmat rebuilds the view table if accepted
+    if (dev_tr) h->ops->cost(d, h->t, h->stream, h->scal.p + sl.costp, h->cost_blocks);
+    else launch_cost(h, h->scal.p + sl.cost1);
+  };
+  auto fold_trial = [&](double* step_h2, double* step2, double* x2) {   // after a fetch that covers [sl.step, ...)
+    double s3[3] = {0, 0, 0};
+    for (int blk = 0; blk < sl.nvb; ++blk)
+      for (int k = 0; k < 3; ++k) s3[k] += S[sl.step + 3 * blk + k];
+    *step_h2 = s3[0]; *step2 = s3[1]; *x2 = s3[2];
+    return dev_tr ? host_sum(S + sl.costp, h->cost_blocks) : S[sl.cost1];
+  };
+  const int trial_fetch_end = dev_tr ? sl.costp + h->cost_blocks : sl.cost1 + 1;
+
   timed_linearize();
   int nfev = 1, njev = 1, iteration = 0, status = -100;
   bool first = true, fresh_lin = true;
   double cost = 0, Delta = 0, step_norm = NaN, actual_reduction = NaN, g_norm = 0, initial_cost = 0;
 
   while (true) {
-    // ---- gradient scaling + Cauchy-step curvature (one sync) -------------------------------------------------
-    // k_vec_scale also forwards {cost, count} of the linearisation into scal[16..17]
-    const ScalLayout& sl = h->sl;
+    // a terminated / exhausted solve only needs the gradient norm of the final iterate (scipy reports it as optimality)
+    const bool finishing = status != -100 || nfev >= max_nfev;
+    // ---- enqueue: gradient scaling, Cauchy curvature (+ on a single GPU the whole step and its trial evaluation) ----
+    // k_vec_scale also forwards {cost, count} of the linearisation into scal[TR_COST, TR_COUNT]
     hipLaunchKernelGGL(k_vec_scale, dim3(sl.nvb), dim3(256), 0, h->stream, d, h->x.p, h->g(), h->diag(), h->scale_inv.p,
-                       h->dsc.p, h->gh.p, first ? 1 : 0, h->scal.p + sl.vs, h->costcount(), h->scal.p + 16);
-    if (host_sums) {
+                       h->dsc.p, h->gh.p, first ? 1 : 0, h->scal.p + sl.vs, h->costcount(), h->scal.p + TR_COST);
+    bool have_trial = false;
+    if (finishing) {
+      fetch_scalars(h, sl.q00p);
+    } else if (dev_tr) {
       hipLaunchKernelGGL(k_q00, dim3(Q00_BLOCKS), dim3(256), 0, h->stream, d, h->Hss.p, h->Hfs.p, h->Hff.p, h->dsc.p,
                          h->gh.p, h->scal.p + sl.q00p);
-      fetch_scalars(h, sl.q00p + Q00_BLOCKS);
-      h->h_scal[4] = host_sum(h->h_scal + sl.q00p, Q00_BLOCKS);
+      hipLaunchKernelGGL(k_tr_reg, dim3(1), dim3(64), 0, h->stream, h->scal.p, h->scal.p + sl.vs, sl.nvb,
+                         h->scal.p + sl.q00p, Q00_BLOCKS, first ? 1 : 0, Delta);
+      launch_gn_solve(h, 0.0, is_root, h->scal.p + sl.dotp, h->scal.p);
+      hipLaunchKernelGGL(k_tr_step, dim3(1), dim3(64), 0, h->stream, h->scal.p, h->scal.p + sl.dotp, gn_dot_blocks(d));
+      enqueue_trial(0.0, 0.0, h->scal.p);
+      fetch_scalars(h, trial_fetch_end);
+      have_trial = true;
     } else {
-      launch_q00(h, h->gh.p, 4);
+      launch_q00(h, h->gh.p, TR_Q00);
       fetch_scalars(h, sl.q00p);
     }
-    {
+    if (fresh_lin) { collect_lin_time(); fresh_lin = false; }
+    if (!have_trial) {   // fold the k_vec_scale partials on the host (the vectors are complete on every rank)
       double mx = 0, gg = 0, xs = 0;
       for (int blk = 0; blk < sl.nvb; ++blk) {
-        mx = std::max(mx, h->h_scal[sl.vs + 3 * blk]);
-        gg += h->h_scal[sl.vs + 3 * blk + 1];
-        xs += h->h_scal[sl.vs + 3 * blk + 2];
+        mx = std::max(mx, S[sl.vs + 3 * blk]);
+        gg += S[sl.vs + 3 * blk + 1];
+        xs += S[sl.vs + 3 * blk + 2];
       }
-      h->h_scal[0] = mx; h->h_scal[1] = gg; h->h_scal[2] = xs;
+      S[TR_GNORM] = mx; S[TR_GH2] = gg; S[TR_XS2] = xs;
     }
-    if (fresh_lin) { collect_lin_time(); fresh_lin = false; }
-    g_norm = h->h_scal[0];
-    const double gh2 = h->h_scal[1];
+    g_norm = S[TR_GNORM];
     if (first) {
-      cost = h->h_scal[16];
+      cost = S[TR_COST];
       initial_cost = cost;
       if (!std::isfinite(cost))
         throw Error("Residuals are not finite in the initial point.");   // scipy least_squares.py:844-845
-      Delta = std::sqrt(h->h_scal[2]);
-      if (Delta == 0) Delta = 1.0;
+      if (have_trial) {
+        Delta = S[TR_DELTA];                       // trf.py:428-430, evaluated by k_tr_reg
+      } else {
+        Delta = std::sqrt(S[TR_XS2]);
+        if (Delta == 0) Delta = 1.0;
+      }
       first = false;
     }
     if (g_norm < gtol) status = 1;
     if (h->log && opt->verbose >= 2) h->log(h->log_ctx, iteration, nfev, cost, actual_reduction, step_norm, g_norm);
-    if (status != -100 || nfev >= max_nfev) break;
+    if (status != -100 || nfev >= max_nfev) break;   // (a step the device has already evaluated is simply dropped)
 
-    const double q00 = h->h_scal[4];
-    const double gh_norm = std::sqrt(gh2);
-    double tmin, ag_value;
-    minimize_quadratic_1d(0.5 * q00, -gh2, 0.0, Delta / gh_norm, &tmin, &ag_value);
-    const double reg_term = -ag_value / (Delta * Delta);
-    const double reg = std::max(reg_term, REG_FLOOR);
-
-    // ---- regularised Gauss-Newton step + 2-D subspace (one sync) ---------------------------------------------
+    // ---- regularised Gauss-Newton step + 2-D subspace ------------------------------------------------------------
     int32_t chol_info = 0;
-    if (host_sums) {
-      const int nblk = gn_dot_blocks(d);
-      launch_gn_solve(h, reg, is_root, h->scal.p + sl.dotp);
-      fetch_scalars(h, 3 * nblk + 1, sl.dotp);
-      double dsum[3] = {0, 0, 0};
-      for (int blk = 0; blk < nblk; ++blk)
-        for (int k = 0; k < 3; ++k) dsum[k] += h->h_scal[sl.dotp + 3 * blk + k];
-      for (int k = 0; k < 3; ++k) h->h_scal[7 + k] = dsum[k];
-      chol_info = (int32_t)h->h_scal[sl.dotp + 3 * nblk];
+    if (dev_tr) {
+      chol_info = (int32_t)S[TR_INFO];
     } else {
-      launch_gn_solve(h, reg, is_root, h->scal.p + 7);
-      HIP_OK(hipMemcpyAsync(h->scal.p + 12, h->info.p, sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
-      fetch_scalars(h, 13);
-      memcpy(&chol_info, &h->h_scal[12], sizeof(int32_t));
+      S[TR_REG] = S[TR_GH2] > 0 ? tr_reg_term(S[TR_Q00], S[TR_GH2], Delta) : TR_REG_FLOOR;
+      launch_gn_solve(h, S[TR_REG], is_root, h->scal.p + TR_D00);
+      HIP_OK(hipMemcpyAsync(h->scal.p + TR_INFO, h->info.p, sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
+      fetch_scalars(h, TR_INFO + 1 - TR_D00, TR_D00);
+      memcpy(&chol_info, &S[TR_INFO], sizeof(int32_t));
+      tr_subspace(S);
     }
-    {
-      if (chol_info != 0)
-        throw Error("reduced normal equations are not positive definite (pivot " + std::to_string(chol_info) +
-                    "); non-finite Jacobian?");
-    }
-    const double d00 = h->h_scal[7], d01 = h->h_scal[8], d11 = h->h_scal[9];
-    // H_h gn = g_h - reg gn by construction of the step, so the forms with gn need no further pass over H:
-    //   g_h^T H_h gn = |g_h|^2 - reg g_h.gn,   gn^T H_h gn = g_h.gn - reg |gn|^2
-    const double Q00 = q00, Q01 = d00 - reg * d01, Q11 = d01 - reg * d11;
-    // orthonormal basis [e0 e1] = [u0 u1] Cm of span{g_h, gn_h} (Gram-Schmidt on the 2x2 Gram matrix)
-    const double n0 = std::sqrt(d00);
-    const double proj = d01 / d00;
-    double nw2 = d11 - proj * d01;
-    double Cm[4];   // row-major 2x2: [alpha; beta] = Cm p_S
-    double BS[3], gS[2] = {n0, 0.0};
-    if (nw2 > 1e-28 * d11 && std::isfinite(nw2)) {
-      const double nw = std::sqrt(nw2);
-      Cm[0] = 1.0 / n0; Cm[1] = -proj / nw;
-      Cm[2] = 0.0;      Cm[3] = 1.0 / nw;
-      BS[0] = Q00 / d00;
-      BS[1] = (Q01 - proj * Q00) / (n0 * nw);
-      BS[2] = (Q11 - 2 * proj * Q01 + proj * proj * Q00) / nw2;
-    } else {   // gn parallel to the gradient: 1-D subspace
-      Cm[0] = 1.0 / n0; Cm[1] = 0; Cm[2] = 0; Cm[3] = 0;
-      BS[0] = Q00 / d00; BS[1] = 0; BS[2] = 1.0;
-    }
+    if (chol_info != 0)
+      throw Error("reduced normal equations are not positive definite (pivot " + std::to_string(chol_info) +
+                  "); non-finite Jacobian?");
 
     actual_reduction = -1;
     double cost_new = cost, ratio = 0;
     while (actual_reduction <= 0 && nfev < max_nfev) {
-      double pS[2];
-      solve_trust_region_2d(BS, gS, Delta, pS);
-      const double predicted =
-          -(0.5 * (pS[0] * (BS[0] * pS[0] + BS[1] * pS[1]) + pS[1] * (BS[1] * pS[0] + BS[2] * pS[1])) + gS[0] * pS[0] +
-            gS[1] * pS[1]);
-      const double alpha = Cm[0] * pS[0] + Cm[1] * pS[1], beta = Cm[2] * pS[0] + Cm[3] * pS[1];
-      hipLaunchKernelGGL(k_vec_step, dim3(sl.nvb), dim3(256), 0, h->stream, d, h->x.p, h->dsc.p, h->gh.p, h->gn.p, alpha,
-                         beta, h->xnew.p, h->scal.p + sl.step);
-      eval_pose_tables(h, h->xnew.p);
-      if (host_sums) {
-        h->ops->cost(d, h->t, h->stream, h->scal.p + sl.costp, h->cost_blocks);
-        fetch_scalars(h, sl.costp + h->cost_blocks - sl.step, sl.step);
-        h->h_scal[3] = host_sum(h->h_scal + sl.costp, h->cost_blocks);
-      } else {
-        launch_cost(h, h->scal.p + sl.cost1);
-        fetch_scalars(h, sl.cost1 + 1 - sl.step, sl.step);
-        h->h_scal[3] = h->h_scal[sl.cost1];
+      if (!have_trial) {
+        tr_trial(S, Delta);
+        enqueue_trial(S[TR_ALPHA], S[TR_BETA], nullptr);
+        fetch_scalars(h, trial_fetch_end - sl.step, sl.step);
       }
-      {
-        double s3[3] = {0, 0, 0};
-        for (int blk = 0; blk < sl.nvb; ++blk)
-          for (int k = 0; k < 3; ++k) s3[k] += h->h_scal[sl.step + 3 * blk + k];
-        for (int k = 0; k < 3; ++k) h->h_scal[k] = s3[k];
-      }
+      have_trial = false;
+      double step_h2, step2, x2;
+      cost_new = fold_trial(&step_h2, &step2, &x2);
+      const double predicted = S[TR_PRED];
       ++nfev;
-      const double step_h_norm = std::sqrt(h->h_scal[0]);
-      cost_new = h->h_scal[3];
+      const double step_h_norm = std::sqrt(step_h2);
       if (!std::isfinite(cost_new)) {
         Delta = 0.25 * step_h_norm;
         continue;
       }
       actual_reduction = cost - cost_new;
       double Delta_new = Delta;
-      update_tr_radius(Delta_new, actual_reduction, predicted, step_h_norm, step_h_norm > 0.95 * Delta, ratio);
-      step_norm = std::sqrt(h->h_scal[1]);
-      const double x_norm = std::sqrt(h->h_scal[2]);
-      status = check_termination(actual_reduction, cost, step_norm, x_norm, ratio, ftol, xtol);
+      tr_update_radius(Delta_new, actual_reduction, predicted, step_h_norm, step_h_norm > 0.95 * Delta, ratio);
+      step_norm = std::sqrt(step2);
+      const double x_norm = std::sqrt(x2);
+      status = tr_check_termination(actual_reduction, cost, step_norm, x_norm, ratio, ftol, xtol);
       if (status != -100) break;
       Delta = Delta_new;
     }
@@ -1170,7 +1036,7 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
     if (actual_reduction > 0) {
       std::swap(h->x.p, h->xnew.p);
       cost = cost_new;
-      timed_linearize();   // tables already hold x_new
+      timed_linearize();   // pose tables already hold x_new
       fresh_lin = true;
       ++njev;
     } else {

@@ -3,6 +3,7 @@
 // driver (Schur elimination of the per-frame blocks, dense Cholesky, vector updates).  Included only by mcba_api.hip.
 #pragma once
 #include "mcba_kernels.h"
+#include "mcba_trmath.h"
 
 namespace mcba {
 
@@ -314,78 +315,6 @@ __global__ __launch_bounds__(256) void k_vec_scale(Dims d, const double* __restr
   }
 }
 
-// quadratic forms of H_h = D H D for two vectors u0, u1 (scaled space):
-//   block fl < Fl : frame fl's contribution   q_ab += u_a,f^T D_f (H_fs D_s u_b,s + H_sf^T..)  (see below)
-//   block Fl      : shared part               q_ab += u_a,s^T D_s H_ss D_s u_b,s
-// partial[(blk)*3 + {0,1,2}] = {q00, q01, q11}
-__global__ void k_quadforms(Dims d, const double* __restrict__ Hss, const double* __restrict__ Hfs,
-                            const double* __restrict__ Hff, const double* __restrict__ dsc,
-                            const double* __restrict__ u0, const double* __restrict__ u1,
-                            double* __restrict__ partial) {
-  __shared__ double scratch[16];
-  __shared__ double tf[2][12];
-  const int ns = d.ns, DF = d.DF;
-  double q00 = 0, q01 = 0, q11 = 0;
-  if (blockIdx.x == gridDim.x - 1) {   // last block: shared part (grid = frames-with-DF + 1)
-    // y_a = H_ss (D u_a)_s ; q_ab = sum_i (D u_a)_i y_b,i
-    for (int i = threadIdx.x; i < ns; i += blockDim.x) {
-      const int xi = d.shared_to_x(i);
-      double y0 = 0, y1 = 0;
-      for (int j = 0; j < ns; ++j) {
-        const int xj = d.shared_to_x(j);
-        const double h = Hss[(size_t)i * ns + j], dj = dsc[xj];
-        y0 += h * dj * u0[xj];
-        y1 += h * dj * u1[xj];
-      }
-      const double a0 = dsc[xi] * u0[xi], a1 = dsc[xi] * u1[xi];
-      q00 += a0 * y0; q01 += a0 * y1; q11 += a1 * y1;
-    }
-  } else {
-    const int fl = blockIdx.x, f = d.f0 + fl;
-    const double* hfs = Hfs + (size_t)fl * DF * ns;
-    const double* hff = Hff + (size_t)fl * DF * DF;
-    // t_a[dd] = sum_s H_fs[dd][s] (D u_a)_s      (DF x ns mat-vec, threads over (dd, s-chunks))
-    for (int dd = 0; dd < DF; ++dd) {
-      double p0 = 0, p1 = 0;
-      for (int s = threadIdx.x; s < ns; s += blockDim.x) {
-        const int xs = d.shared_to_x(s);
-        const double h = hfs[dd * ns + s] * dsc[xs];
-        p0 += h * u0[xs];
-        p1 += h * u1[xs];
-      }
-      const double r0 = block_reduce<false>(p0, scratch);
-      const double r1 = block_reduce<false>(p1, scratch);
-      if (threadIdx.x == 0) { tf[0][dd] = r0; tf[1][dd] = r1; }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      for (int dd = 0; dd < DF; ++dd) {
-        const int xi = d.frame_to_x(f, dd);
-        const double a0 = dsc[xi] * u0[xi], a1 = dsc[xi] * u1[xi];
-        double h0 = 0, h1 = 0;
-        for (int d2 = 0; d2 < DF; ++d2) {
-          const int xj = d.frame_to_x(f, d2);
-          const double h = hff[dd * DF + d2] * dsc[xj];
-          h0 += h * u0[xj];
-          h1 += h * u1[xj];
-        }
-        // u^T H u over {s, f}: u_f^T H_ff u_f + 2 u_f^T H_fs u_s   (the s^T H_ss s part is block Fl)
-        q00 += a0 * (h0 + 2.0 * tf[0][dd]);
-        q11 += a1 * (h1 + 2.0 * tf[1][dd]);
-        q01 += a0 * (h1 + tf[1][dd]) + a1 * tf[0][dd];
-      }
-    }
-  }
-  const double r00 = block_reduce<false>(q00, scratch);
-  const double r01 = block_reduce<false>(q01, scratch);
-  const double r11 = block_reduce<false>(q11, scratch);
-  if (threadIdx.x == 0) {
-    partial[blockIdx.x * 3 + 0] = r00;
-    partial[blockIdx.x * 3 + 1] = r01;
-    partial[blockIdx.x * 3 + 2] = r11;
-  }
-}
-
 // q = u^T (D H D) u for ONE vector, as a plain streaming weighted sum over the stored blocks (grid-stride, coalesced):
 //   q = sum_{f,dd,s} 2 a_f[dd] H_fs[f][dd][s] a_s[s] + sum_{f,dd,d2} a_f[dd] H_ff[f][dd][d2] a_f[d2]
 //     + sum_{i,j} a_s[i] H_ss[i][j] a_s[j],            a = D u.
@@ -444,28 +373,6 @@ __global__ void k_dots3(int n, const double* __restrict__ u0, const double* __re
   }
 }
 
-// out[0..2] = {q00, q01, q11} summed over this rank's blocks (sharded handles all-reduce these three),
-// out[3..5] = dots {u0.u0, u0.u1, u1.u1} over the full vectors
-__global__ void k_quadforms_final(Dims d, const double* __restrict__ partial, int nblk,
-                                  const double* __restrict__ u0, const double* __restrict__ u1,
-                                  double* __restrict__ out) {
-  __shared__ double scratch[16];
-  double q[3] = {0, 0, 0};
-  for (int blk = threadIdx.x; blk < nblk; blk += blockDim.x)
-    for (int k = 0; k < 3; ++k) q[k] += partial[blk * 3 + k];
-  double dt[3] = {0, 0, 0};
-  for (int i = threadIdx.x; i < d.n; i += blockDim.x) {
-    dt[0] += u0[i] * u0[i];
-    dt[1] += u0[i] * u1[i];
-    dt[2] += u1[i] * u1[i];
-  }
-  for (int k = 0; k < 3; ++k) {
-    const double qs = block_reduce<false>(q[k], scratch);
-    const double ds = block_reduce<false>(dt[k], scratch);
-    if (threadIdx.x == 0) { out[k] = qs; out[3 + k] = ds; }
-  }
-}
-
 // Schur step 1a, one THREAD per frame:  A_ff = D_f H_ff D_f + reg I = L L^T entirely in registers (DF = 6 or 12: 21 / 78
 // doubles), then L^-1 by forward substitution and y = L^-1 g_h,f.  The per-frame systems are tiny and there are
 // hundreds of them: a lane per system needs no cross-lane traffic at all (the block-per-frame version spent 39 us of
@@ -474,9 +381,11 @@ __global__ void k_quadforms_final(Dims d, const double* __restrict__ partial, in
 template <int DF>
 __global__ __launch_bounds__(64) void k_frame_factor(Dims d, const double* __restrict__ Hff, const double* __restrict__ dsc,
                                                      const double* __restrict__ gh, double reg, double* __restrict__ Linv,
-                                                     double* __restrict__ W, double* __restrict__ yf) {
+                                                     double* __restrict__ W, double* __restrict__ yf,
+                                                     const double* __restrict__ tr = nullptr) {
   const int fl = blockIdx.x * blockDim.x + threadIdx.x;
   if (fl >= d.Fl) return;
+  if (tr != nullptr) reg = tr[TR_REG];   // damping computed on the device by k_tr_reg
   const int f = d.f0 + fl, ldw = d.ns + 1;
   const double* hff = Hff + (size_t)fl * DF * DF;
   double ds[DF], L[DF][DF], X[DF][DF];
@@ -606,7 +515,7 @@ __global__ __launch_bounds__(64, 2) void k_schur_syrk(int K, int ncol, int ntile
 //                rhs = [own shared gradient] - W^T y.   buf = [S (ns*ns) | rhs (ns)]: rhs is "row ns" of the matrix.
 __global__ void k_schur_reduce(Dims d, const double* __restrict__ Hss, const double* __restrict__ dsc,
                                const double* __restrict__ gh, const double* __restrict__ P, int ntile, int ksplit,
-                               int K, double g_weight, double* __restrict__ buf) {
+                               int K, double g_weight, double* __restrict__ buf, const double* __restrict__ tr = nullptr) {
   const int ns = d.ns;
   const int nt2 = ntile * (ntile + 1) / 2;
   const int total = ns * ns + ns;
@@ -630,7 +539,9 @@ __global__ void k_schur_reduce(Dims d, const double* __restrict__ Hss, const dou
       for (; sp < ksplit; ++sp) s0 += pp[(size_t)sp * st];
       sum = (s0 + s1) + (s2 + s3);
     }
-    if (i < ns) buf[e] = dsc[d.shared_to_x(i)] * Hss[e] * dsc[d.shared_to_x(j)] - sum;
+    // (single-GPU driver: the damping lives on the device and is added here; otherwise the Cholesky kernel adds it
+    //  after the cross-rank reduction)
+    if (i < ns) buf[e] = dsc[d.shared_to_x(i)] * Hss[e] * dsc[d.shared_to_x(j)] - sum + ((tr != nullptr && i == j) ? tr[TR_REG] : 0.0);
     else buf[e] = g_weight * gh[d.shared_to_x(j)] - sum;
   }
 }
@@ -1256,8 +1167,12 @@ __global__ __launch_bounds__(64) void k_schur_backsub(Dims d, const double* __re
 __global__ __launch_bounds__(256) void k_vec_step(Dims d, const double* __restrict__ x, const double* __restrict__ dsc,
                                                   const double* __restrict__ u0, const double* __restrict__ u1,
                                                   double alpha, double beta, double* __restrict__ xnew,
-                                                  double* __restrict__ part) {
+                                                  double* __restrict__ part, const double* __restrict__ tr = nullptr) {
   __shared__ double scratch[16];
+  if (tr != nullptr) {   // coefficients computed on the device by k_tr_step
+    alpha = tr[TR_ALPHA];
+    beta = tr[TR_BETA];
+  }
   double ph = 0, st = 0, xx = 0;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < d.n) {
@@ -1276,6 +1191,57 @@ __global__ __launch_bounds__(256) void k_vec_step(Dims d, const double* __restri
     part[3 * blockIdx.x + 0] = a;
     part[3 * blockIdx.x + 1] = b;
     part[3 * blockIdx.x + 2] = c;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// one-wave kernels that keep the scalar trust-region algebra on the device between the vector kernels (single-GPU
+// driver: one host synchronisation per iteration).  S = scal[0 .. TR_NSLOTS), see mcba_trmath.h.
+// ---------------------------------------------------------------------------------------------------------------
+// folds the k_vec_scale / k_q00 partials, fixes the trust radius of the first iteration and computes the damping
+__global__ __launch_bounds__(64) void k_tr_reg(double* __restrict__ S, const double* __restrict__ vs_part, int nvb,
+                                               const double* __restrict__ q_part, int nq, int first, double Delta_in) {
+  const int lane = threadIdx.x;
+  double mx = 0, gg = 0, xs = 0, q = 0;
+  for (int b = lane; b < nvb; b += 64) {
+    mx = fmax(mx, vs_part[3 * b]);
+    gg += vs_part[3 * b + 1];
+    xs += vs_part[3 * b + 2];
+  }
+  for (int b = lane; b < nq; b += 64) q += q_part[b];
+  mx = wave_max(mx);
+  gg = wave_sum(gg);
+  xs = wave_sum(xs);
+  q = wave_sum(q);
+  if (lane == 0) {
+    double Delta = Delta_in;
+    if (first) {   // trf.py:428-430
+      Delta = sqrt(xs);
+      if (Delta == 0) Delta = 1.0;
+    }
+    S[TR_GNORM] = mx;
+    S[TR_GH2] = gg;
+    S[TR_XS2] = xs;
+    S[TR_Q00] = q;
+    S[TR_DELTA] = Delta;
+    S[TR_REG] = gg > 0 ? tr_reg_term(q, gg, Delta) : TR_REG_FLOOR;
+  }
+}
+
+// folds the partial dots of the back-substitution, builds the 2-D subspace model and solves it for the current radius
+__global__ __launch_bounds__(64) void k_tr_step(double* __restrict__ S, const double* __restrict__ dot_part, int nblk) {
+  const int lane = threadIdx.x;
+  double dt[3] = {0, 0, 0};
+  for (int b = lane; b < nblk; b += 64)
+    for (int k = 0; k < 3; ++k) dt[k] += dot_part[3 * b + k];
+  for (int k = 0; k < 3; ++k) dt[k] = wave_sum(dt[k]);
+  if (lane == 0) {
+    S[TR_D00] = dt[0];
+    S[TR_D01] = dt[1];
+    S[TR_D11] = dt[2];
+    S[TR_INFO] = dot_part[3 * nblk];
+    tr_subspace(S);
+    tr_trial(S, S[TR_DELTA]);
   }
 }
 

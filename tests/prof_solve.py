@@ -19,6 +19,9 @@ with Handle(c) as h:
     for _ in range(3):
         t0 = time.perf_counter(); res = h.solve(x1); dt = time.perf_counter() - t0
         print("  repeat: ms/iter", dt / max(res.nfev - 1, 1) * 1e3, "total ms", dt * 1e3)
+    res = h.solve(x1, tolerance=1e-15, xtol=1e-15, gtol=1e-15, max_iterations=41)
+    t0 = time.perf_counter(); res = h.solve(x1, tolerance=1e-15, xtol=1e-15, gtol=1e-15, max_iterations=41); dt = time.perf_counter() - t0
+    print("long solve: nfev", res.nfev, "njev", res.njev, "status", res.status, "ms per trial step", dt / max(res.nfev - 1, 1) * 1e3)
     for ns in (140,):
         M = rng.normal(size=(ns + 20, ns)); S = M.T @ M / ns + 0.1 * np.eye(ns); rhs = rng.normal(size=ns)
         st = h.debug_chol(S, rhs, reg=0.05, blocked=4)[:8]

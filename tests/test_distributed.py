@@ -115,4 +115,6 @@ def test_sharded_solve_two_ranks_one_gpu(name, tmp_path):
   assert int(sh["nfev"]) == res.nfev and int(sh["status"]) == res.status
   assert float(sh["final_cost"]) == pytest.approx(res.cost, rel=1e-10)
   assert abs(float(sh["rms"]) - float(np.sqrt(np.mean(e[v] ** 2)))) < 1e-9
-  assert np.abs(sh["x"] - res.x).max() < 1e-8
+  # (the sharded handle runs the scalar trust-region algebra on the host, the single handle in device kernels: libm and
+  #  ocml differ in the last bits of sqrt / hypot / sin / cos, which weakly determined gauge directions amplify)
+  assert np.abs(sh["x"] - res.x).max() < 1e-7
