@@ -157,12 +157,13 @@ struct mcba_handle_s {
   mcba_log_fn log = nullptr;
   void* log_ctx = nullptr;
 
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fetch = nullptr;
 
   ~mcba_handle_s() {
     if (h_scal) (void)hipHostFree(h_scal);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
+    if (ev_fetch) (void)hipEventDestroy(ev_fetch);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
   }
   double* g() { return gbuf.p; }
@@ -282,6 +283,12 @@ void fetch_scalars(mcba_handle_s* h, int count, int first = 0) {   // scal[first
   HIP_OK(hipMemcpyAsync(h->h_scal + first, h->scal.p + first, count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   sync(h);
 }
+// split form: the copy is followed by an event, more work may be enqueued behind it, the host waits for the event only
+void fetch_scalars_begin(mcba_handle_s* h, int count, int first = 0) {
+  HIP_OK(hipMemcpyAsync(h->h_scal + first, h->scal.p + first, count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipEventRecord(h->ev_fetch, h->stream));
+}
+void fetch_scalars_end(mcba_handle_s* h) { HIP_OK(hipEventSynchronize(h->ev_fetch)); }
 double host_sum(const double* p, int n) {   // fixed order: the result does not depend on block scheduling
   double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
   int i = 0;
@@ -611,6 +618,7 @@ int32_t mcba_create(const mcba_problem* p, void* hip_stream, mcba_handle* out) {
   HIP_OK(hipHostMalloc((void**)&h->h_scal, h->scal.n * sizeof(double)));
   HIP_OK(hipEventCreate(&h->ev0));
   HIP_OK(hipEventCreate(&h->ev1));
+  HIP_OK(hipEventCreateWithFlags(&h->ev_fetch, hipEventDisableTiming));
   HIP_OK(hipDeviceSynchronize());
   *out = h.release();
   API_END
@@ -934,12 +942,18 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
 
   timed_linearize();
   int nfev = 1, njev = 1, iteration = 0, status = -100;
-  bool first = true, fresh_lin = true;
+  bool first = true, fresh_lin = true, lin_stale = false;
   double cost = 0, Delta = 0, step_norm = NaN, actual_reduction = NaN, g_norm = 0, initial_cost = 0;
 
   while (true) {
     // a terminated / exhausted solve only needs the gradient norm of the final iterate (scipy reports it as optimality)
     const bool finishing = status != -100 || nfev >= max_nfev;
+    if (lin_stale) {   // the last speculative linearisation was for a rejected point: rebuild g, H at x
+      eval_pose_tables(h, h->x.p);
+      timed_linearize();
+      lin_stale = false;
+    }
+    bool spec_lin = false;
     // ---- enqueue: gradient scaling, Cauchy curvature (+ on a single GPU the whole step and its trial evaluation) ----
     // k_vec_scale also forwards {cost, count} of the linearisation into scal[TR_COST, TR_COUNT]
     hipLaunchKernelGGL(k_vec_scale, dim3(sl.nvb), dim3(256), 0, h->stream, d, h->x.p, h->g(), h->diag(), h->scale_inv.p,
@@ -955,7 +969,14 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
       launch_gn_solve(h, 0.0, is_root, h->scal.p + sl.dotp, h->scal.p);
       hipLaunchKernelGGL(k_tr_step, dim3(1), dim3(64), 0, h->stream, h->scal.p, h->scal.p + sl.dotp, gn_dot_blocks(d));
       enqueue_trial(0.0, 0.0, h->scal.p);
-      fetch_scalars(h, trial_fetch_end);
+      fetch_scalars_begin(h, trial_fetch_end);
+      // Speculation: most trial steps are accepted, so the linearisation at x_new is enqueued right behind the copy and
+      // runs while the host looks at the trial cost and prepares the next iteration.  A rejected step leaves the
+      // records / H / g of x_new behind (lin_stale): they are not needed by the retries with a smaller radius, and
+      // are rebuilt before anything reads them again.
+      timed_linearize();
+      spec_lin = true;
+      fetch_scalars_end(h);
       have_trial = true;
     } else {
       launch_q00(h, h->gh.p, TR_Q00);
@@ -1007,8 +1028,10 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
 
     actual_reduction = -1;
     double cost_new = cost, ratio = 0;
+    bool spec_valid = spec_lin;   // true while the trial under evaluation is the one the speculation was made for
     while (actual_reduction <= 0 && nfev < max_nfev) {
       if (!have_trial) {
+        spec_valid = false;
         tr_trial(S, Delta);
         enqueue_trial(S[TR_ALPHA], S[TR_BETA], nullptr);
         fetch_scalars(h, trial_fetch_end - sl.step, sl.step);
@@ -1036,13 +1059,15 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
     if (actual_reduction > 0) {
       std::swap(h->x.p, h->xnew.p);
       cost = cost_new;
-      timed_linearize();   // pose tables already hold x_new
+      if (!spec_valid) timed_linearize();   // pose tables already hold x_new
       fresh_lin = true;
       ++njev;
     } else {
       step_norm = 0;
       actual_reduction = 0;
+      if (spec_lin) lin_stale = true;
     }
+    if (spec_lin && !spec_valid && actual_reduction > 0) lin_stale = false;   // re-linearised at the accepted retry
     ++iteration;
   }
   if (status == -100) status = 0;
