@@ -145,6 +145,8 @@ struct mcba_handle_s {
   DevBuf<double> x, xnew, scale_inv, dsc, gh, gn, scal, qpart, costpart, Lf, W, yf, P, sbuf, ps;
   DevBuf<int32_t> info;
   double* h_scal = nullptr;   // pinned
+  double* h_x = nullptr;      // pinned staging of x uploads [n]
+  double* h_gbuf = nullptr;   // pinned landing zone of [g | diag | cost, count]
   int ntile = 0, ksplit = 1, cost_blocks = 1;
 
   // outputs staging
@@ -161,6 +163,8 @@ struct mcba_handle_s {
 
   ~mcba_handle_s() {
     if (h_scal) (void)hipHostFree(h_scal);
+    if (h_x) (void)hipHostFree(h_x);
+    if (h_gbuf) (void)hipHostFree(h_gbuf);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     if (ev_fetch) (void)hipEventDestroy(ev_fetch);
@@ -214,8 +218,11 @@ void set_loss(mcba_handle_s* h, const mcba_options* opt) {
   REQUIRE(h->d.loss == 0 || h->d.f_scale > 0, "f_scale must be positive");
 }
 
+// x goes up through a pinned staging buffer (a pageable source makes the runtime stage and synchronise internally).
+// The previous upload from the buffer has completed: every API entry synchronises the stream before it returns.
 void upload_x(mcba_handle_s* h, const double* x, double* dst) {
-  HIP_OK(hipMemcpyAsync(dst, x, (size_t)h->d.n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  memcpy(h->h_x, x, (size_t)h->d.n * sizeof(double));
+  HIP_OK(hipMemcpyAsync(dst, h->h_x, (size_t)h->d.n * sizeof(double), hipMemcpyHostToDevice, h->stream));
 }
 
 // x (device) -> pose / camera / view tables
@@ -616,6 +623,8 @@ int32_t mcba_create(const mcba_problem* p, void* hip_stream, mcba_handle* out) {
   h->ps.alloc((size_t)d.ns);
   h->info.alloc(4);
   HIP_OK(hipHostMalloc((void**)&h->h_scal, h->scal.n * sizeof(double)));
+  HIP_OK(hipHostMalloc((void**)&h->h_x, std::max<size_t>(d.n, 1) * sizeof(double)));
+  HIP_OK(hipHostMalloc((void**)&h->h_gbuf, (2 * (size_t)d.n + 2) * sizeof(double)));
   HIP_OK(hipEventCreate(&h->ev0));
   HIP_OK(hipEventCreate(&h->ev1));
   HIP_OK(hipEventCreateWithFlags(&h->ev_fetch, hipEventDisableTiming));
@@ -783,12 +792,13 @@ int32_t mcba_normal_equations(mcba_handle h, const double* x, const mcba_options
   launch_linearize(h);
   launch_assemble(h);
   const Dims& d = h->d;
-  std::vector<double> host(2 * (size_t)d.n + 2);
-  HIP_OK(hipMemcpyAsync(host.data(), h->gbuf.p, host.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  // [g | diag | cost, count] comes down into pinned memory; only the two scalars when the vectors are not asked for
+  const size_t first = (g || diag) ? 0 : 2 * (size_t)d.n, count = 2 * (size_t)d.n + 2 - first;
+  HIP_OK(hipMemcpyAsync(h->h_gbuf + first, h->gbuf.p + first, count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   sync(h);
-  if (g) memcpy(g, host.data(), (size_t)d.n * sizeof(double));
-  if (diag) memcpy(diag, host.data() + d.n, (size_t)d.n * sizeof(double));
-  if (cost) *cost = host[2 * (size_t)d.n];
+  if (g) memcpy(g, h->h_gbuf, (size_t)d.n * sizeof(double));
+  if (diag) memcpy(diag, h->h_gbuf + d.n, (size_t)d.n * sizeof(double));
+  if (cost) *cost = h->h_gbuf[2 * (size_t)d.n];
   API_END
 }
 

@@ -35,6 +35,23 @@ __device__ __forceinline__ void lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// p[i] where ok, else 0 -- as an UNCONDITIONAL load from a clamped address whose value always enters the arithmetic.
+// Written as `ok ? p[i] : 0`, hipcc branches around every such load and waits for it (s_waitcnt vmcnt(0)) before the
+// join, which turns a batch of independent loads into one serial memory round trip each (found in the ISA of the
+// k_linearize prologue and of the k_chol_blk load loop: 8 and 12 dependent round trips).  No fast-math: the multiply by
+// 0 / 1 cannot be folded back into a select.  (An empty asm on the mask is worse: hipcc drains vmcnt before inline asm.)
+__device__ __forceinline__ double masked_load(const double* __restrict__ p, size_t i, bool ok) {
+  return p[ok ? i : 0] * (ok ? 1.0 : 0.0);
+}
+// row[i] for i < n, else 0; row is wave-uniform and the lane offset stays a 32-bit value (no 64-bit per-lane index that
+// the register allocator would hoist out of the view loop and spill)
+__device__ __forceinline__ double masked_load_row(const double* __restrict__ row, int i, int n) {
+  return row[min(i, n - 1)] * (i < n ? 1.0 : 0.0);
+}
+__device__ __forceinline__ uint8_t masked_load_row(const uint8_t* __restrict__ row, int i, int n) {
+  return (uint8_t)(row[min(i, n - 1)] & (i < n ? 0xFFu : 0u));
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -135,7 +152,7 @@ __global__ __launch_bounds__(64) void k_cost(Dims d, Tables t, double* __restric
 #pragma unroll
     for (int k = 0; k < NPB64; ++k) {
       const int p = k * 64 + lane;
-      inb[k] = p < d.P ? t.inlier[(size_t)v * d.P + p] : (uint8_t)0;
+      inb[k] = masked_load_row(t.inlier + (size_t)v * d.P, p, d.P);
     }
     int count = 0;
 #pragma unroll
@@ -390,7 +407,7 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
   constexpr int NTAIL = TAILV ? TW * (TW + 1) / 2 : 1;
   // epilogue footprint: S (NVP^2), Y (DE x 16 ceil(NPC/16)) and the packed record
   constexpr int STAGE = ROWS * LDV;
-  constexpr int EPI = NVP * NVP + (MFMA ? DE * 16 * ((NPC + 15) / 16) + (REC + 2 + 1) / 2 * 2 : 0);
+  constexpr int EPI = NVP * NVP + (MFMA ? DE * 16 * ((NPC + 15) / 16) + (REC + 2 + 1) / 2 * 2 + 64 : 0);
   constexpr int BUF = STAGE > EPI ? STAGE : EPI;
 
   __shared__ __attribute__((aligned(16))) double Buf[BUF];   // staging rows in the main loop; [S | Y | M] in the epilogue
@@ -412,26 +429,29 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
   long long stamp[6] = {0, 0, 0, 0, 0, 0};
   const bool prof = t.dbg != nullptr;
   if (prof) stamp[0] = clock64();
-  const int view_cnt = t.view_count[v];   // requested together with the other prologue loads; tested after them
+  // Opaque copy of the lane id: the prologue offsets depend on the lane only, so hipcc hoists their 64-bit forms out of
+  // the view loop and SPILLS them (256 registers are taken) -- every load was then preceded by a scratch reload and a
+  // vmcnt(0) wait.  Recomputing a 32-bit offset per view is two integer instructions.
+  int pl;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(pl) : "v"(lane));
 
   // all global loads of the prologue are issued back to back (mask bytes, That): one memory round trip
   constexpr int NPB64 = LIN_MAX_POINTS / 64;
   uint8_t inb[NPB64];
+  {
+    const uint8_t* mrow = t.inlier + (size_t)v * d.P;
 #pragma unroll
-  for (int k = 0; k < NPB64; ++k) {
-    const int p = k * 64 + lane;
-    inb[k] = p < d.P ? t.inlier[(size_t)v * d.P + p] : (uint8_t)0;
+    for (int k = 0; k < NPB64; ++k) inb[k] = masked_load_row(mrow, k * 64 + pl, d.P);
   }
-  {   // That of this view, precomputed by k_tmat (stale but harmless for empty views)
+  {   // That of this view, precomputed by k_tmat
     const double* tg = t.tmat + (size_t)v * (DE * NPC);
     constexpr int NTL = (DE * NPC + 63) / 64;
     double tl[NTL];
 #pragma unroll
-    for (int k = 0; k < NTL; ++k) tl[k] = (k * 64 + lane < DE * NPC) ? tg[k * 64 + lane] : 0.0;
-    if (view_cnt == 0) continue;   // cannot happen with the compact list; kept for safety
+    for (int k = 0; k < NTL; ++k) tl[k] = masked_load_row(tg, k * 64 + pl, DE * NPC);
 #pragma unroll
     for (int k = 0; k < NTL; ++k)
-      if (k * 64 + lane < DE * NPC) Tm[k * 64 + lane] = tl[k];
+      if (k * 64 + pl < DE * NPC) Tm[k * 64 + pl] = tl[k];
   }
   if (prof) stamp[4] = clock64();
   // only the pad columns need clearing: every staged row is fully rewritten (columns < NV) in every round
@@ -632,55 +652,80 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
     // M is assembled in LDS in the packed record order and leaves the CU with fully coalesced 16-byte stores.
     constexpr int NPCT = (NPC + 15) / 16, NPCP = 16 * NPCT, KR = KI + 1, KRT = (KR + 15) / 16, KS = (DE + 3) / 4;
     constexpr int RECP = (REC + 2 + 1) / 2 * 2;                      // == d.rec_stride
-    static_assert(NVP * NVP + DE * NPCP + RECP <= BUF, "Y and the packed record do not fit behind S");
+    static_assert(NVP * NVP + DE * NPCP + RECP + 64 <= BUF, "Y, the packed record and the cost slots do not fit behind S");
     double* Yb = Buf + NVP * NVP;                                   // [DE][NPCP]
     double* Mp = Yb + DE * NPCP;                                    // packed upper triangle + cost, count
-    const int rsub = el >> 4, csub = el & 15;
-    for (int tj = 0; tj < NPCT; ++tj) {                             // step 1: Y
-      double4_t acc = {0.0, 0.0, 0.0, 0.0};
-      for (int ks = 0; ks < KS; ++ks) {
-        const int k = 4 * ks + rsub, jc = 16 * tj + csub;
-        const double av = Sbuf[csub * NVP + k];
-        const double bv = (k < DE && jc < NPC) ? Tm[k * NPC + jc] : 0.0;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-      }
-      for (int r = 0; r < 4; ++r) {
-        const int row = rsub + 4 * r;
-        if (row < DE) Yb[row * NPCP + 16 * tj + csub] = acc[r];
+    double* Cb = Mp + RECP;                                         // [64] per-lane costs
+    // (& 3: el is opaque to the optimiser, the mask tells it that 4 ks + rsub < 4 KS)
+    const int rsub = (el >> 4) & 3, csub = el & 15;
+    // LDS operand loads are written as unconditional reads of a clamped index times a 0/1 mask and issued in batches
+    // ahead of the MFMAs that use them: `cond ? lds[i] : 0` compiles to a branch + ds_read + lgkmcnt(0) per MFMA, i.e. one
+    // LDS round trip (~130 cycles) for each of the 21 matrix instructions.
+    auto lmask = [](const double* p, int i, bool ok) { return p[ok ? i : 0] * (ok ? 1.0 : 0.0); };
+    Cb[el] = cost;
+    {                                                               // step 1: Y = S_EE That
+      double a1[KS], b1[NPCT][KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) a1[ks] = Sbuf[csub * NVP + 4 * ks + rsub];
+#pragma unroll
+      for (int tj = 0; tj < NPCT; ++tj)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const int k = 4 * ks + rsub, jc = 16 * tj + csub;
+          b1[tj][ks] = lmask(Tm, k * NPC + jc, k < DE && jc < NPC);
+        }
+#pragma unroll
+      for (int tj = 0; tj < NPCT; ++tj) {
+        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[ks], b1[tj][ks], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = rsub + 4 * r;
+          if (row < DE) Yb[row * NPCP + 16 * tj + csub] = acc[r];
+        }
       }
     }
     lds_fence();
     if (prof) ep1 = clock64();
+#pragma unroll
     for (int ti = 0; ti < NPCT; ++ti) {
-      double av[KS];
+      double av[KS], b2[NPCT][KS], b3[KRT][KS];
+#pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const int k = 4 * ks + rsub, ic = 16 * ti + csub;
-        av[ks] = (k < DE && ic < NPC) ? Tm[k * NPC + ic] : 0.0;
+        av[ks] = lmask(Tm, k * NPC + ic, k < DE && ic < NPC);
+#pragma unroll
+        for (int tj = ti; tj < NPCT; ++tj) b2[tj][ks] = lmask(Yb, k * NPCP + 16 * tj + csub, k < DE);
+#pragma unroll
+        for (int tk = 0; tk < KRT; ++tk) {
+          const int jc = 16 * tk + csub;
+          b3[tk][ks] = lmask(Sbuf, k * NVP + DE + jc, k < DE && jc < KR);
+        }
       }
       int rowoff[4];                                                // packed offset of row i:  i (2 N1 - 1 - i) / 2
+#pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = 16 * ti + rsub + 4 * r;
         rowoff[r] = (i * (2 * N1 - 1 - i)) / 2;
       }
+#pragma unroll
       for (int tj = ti; tj < NPCT; ++tj) {                          // step 2: pose x pose
         double4_t acc = {0.0, 0.0, 0.0, 0.0};
-        for (int ks = 0; ks < KS; ++ks) {
-          const int k = 4 * ks + rsub;
-          const double bv = k < DE ? Yb[k * NPCP + 16 * tj + csub] : 0.0;
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], bv, acc, 0, 0, 0);
-        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], b2[tj][ks], acc, 0, 0, 0);
+#pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = 16 * ti + rsub + 4 * r, j = 16 * tj + csub;
           if (i <= j && j < NPC) Mp[rowoff[r] + j] = acc[r];
         }
       }
+#pragma unroll
       for (int tk = 0; tk < KRT; ++tk) {                            // step 3: pose x (intrinsics | residual)
         double4_t acc = {0.0, 0.0, 0.0, 0.0};
-        for (int ks = 0; ks < KS; ++ks) {
-          const int k = 4 * ks + rsub, jc = 16 * tk + csub;
-          const double bv = (k < DE && jc < KR) ? Sbuf[k * NVP + DE + jc] : 0.0;
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], bv, acc, 0, 0, 0);
-        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], b3[tk][ks], acc, 0, 0, 0);
+#pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = 16 * ti + rsub + 4 * r, jc = 16 * tk + csub;
           if (i < NPC && jc < KR) Mp[rowoff[r] + NPC + jc] = acc[r];
@@ -691,9 +736,16 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
       const int i = e / KR, j = e % KR;
       if (i <= j) Mp[((NPC + i) * (2 * N1 - 1 - (NPC + i))) / 2 + NPC + j] = Sbuf[(DE + i) * NVP + DE + j];
     }
-    cost = wave_sum(cost);
-    if (el == 0) {
-      Mp[REC] = 0.5 * cost;
+    if (el == 0) {   // cost of the view: the 64 per-lane sums in one LDS round trip (a shuffle tree is six of them)
+      double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        c0 += Cb[4 * q];
+        c1 += Cb[4 * q + 1];
+        c2 += Cb[4 * q + 2];
+        c3 += Cb[4 * q + 3];
+      }
+      Mp[REC] = 0.5 * ((c0 + c1) + (c2 + c3));
       Mp[REC + 1] = (double)count;
       if (RECP > REC + 2) Mp[REC + 2] = 0.0;
     }

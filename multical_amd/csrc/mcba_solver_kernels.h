@@ -73,12 +73,18 @@ __device__ __forceinline__ void assemble_frame_block(const Dims& d, const Tables
                                                      const double* __restrict__ rec, double* __restrict__ Hff,
                                                      double* __restrict__ Hfs, double* __restrict__ g,
                                                      double* __restrict__ diag) {
+  // activity flags of the frame's C B views, read once: with `if (view_count[v] == 0) continue;` inside the sums every
+  // record load waited for its own flag load (two dependent memory round trips per view, 16 views in a row).  The
+  // record loads below are unconditional (records of empty views hold stale numbers) and are masked after the load.
+  __shared__ double act[128];   // C B <= 128 (checked by launch_assemble)
   const int f = d.f0 + fl;
-  const int DF = d.DF, ns = d.ns, N1 = d.N1, NL = d.NL;
+  const int DF = d.DF, ns = d.ns, N1 = d.N1, NL = d.NL, CB = d.C * d.B;
   double* hfs = Hfs + (size_t)fl * DF * ns;
   double* hff = Hff + (size_t)fl * DF * DF;
+  for (int e = threadIdx.x; e < CB; e += blockDim.x) act[e] = t.view_count[fl * CB + e] != 0 ? 1.0 : 0.0;
   for (int e = threadIdx.x; e < DF * ns; e += blockDim.x) hfs[e] = 0.0;
   __syncthreads();
+  const double* rf = rec + (size_t)fl * CB * d.rec_stride;   // records of this frame: view (c, b) at (c B + b) rec_stride
   const int CW = 6 + d.KI;   // camera pose + intrinsics columns
   // frame x camera(c) blocks: sum over boards
   for (int e = threadIdx.x; e < d.C * DF * CW; e += blockDim.x) {
@@ -87,12 +93,11 @@ __device__ __forceinline__ void assemble_frame_block(const Dims& d, const Tables
     const int gi = local_to_x(d, f, c, 0, li);
     if (gi < 0) continue;
     const int lf = 6 + dd;
+    const int off = li < lf ? tri_index(li, lf, N1) : tri_index(lf, li, N1);
     double sum = 0.0;
     for (int b = 0; b < d.B; ++b) {
-      const int v = (fl * d.C + c) * d.B + b;
-      if (t.view_count[v] == 0) continue;
-      const double* r = rec + (size_t)v * d.rec_stride;
-      sum += r[li < lf ? tri_index(li, lf, N1) : tri_index(lf, li, N1)];
+      const double val = rf[(size_t)(c * d.B + b) * d.rec_stride + off];
+      sum += act[c * d.B + b] != 0.0 ? val : 0.0;
     }
     hfs[dd * ns + d.x_to_shared(gi)] = sum;
   }
@@ -102,25 +107,43 @@ __device__ __forceinline__ void assemble_frame_block(const Dims& d, const Tables
     const int li = 6 * (d.NPB - 1) + q;
     const int gi = local_to_x(d, f, 0, b, li);
     if (gi < 0) continue;
-    const int lf = 6 + dd;
-    double sum = 0.0;
-    for (int c = 0; c < d.C; ++c) {
-      const int v = (fl * d.C + c) * d.B + b;
-      if (t.view_count[v] == 0) continue;
-      sum += rec[(size_t)v * d.rec_stride + tri_index(lf, li, N1)];
+    const int off = tri_index(6 + dd, li, N1);
+    double s0 = 0.0, s1 = 0.0;
+    int c = 0;
+    for (; c + 2 <= d.C; c += 2) {
+      const double v0 = rf[(size_t)(c * d.B + b) * d.rec_stride + off];
+      const double v1 = rf[(size_t)((c + 1) * d.B + b) * d.rec_stride + off];
+      s0 += act[c * d.B + b] != 0.0 ? v0 : 0.0;
+      s1 += act[(c + 1) * d.B + b] != 0.0 ? v1 : 0.0;
     }
-    hfs[dd * ns + d.x_to_shared(gi)] = sum;
+    for (; c < d.C; ++c) {
+      const double v0 = rf[(size_t)(c * d.B + b) * d.rec_stride + off];
+      s0 += act[c * d.B + b] != 0.0 ? v0 : 0.0;
+    }
+    hfs[dd * ns + d.x_to_shared(gi)] = s0 + s1;
   }
   // frame x frame and gradient
   for (int e = threadIdx.x; e < DF * (DF + 1); e += blockDim.x) {
     const int dd = e / (DF + 1), d2 = e % (DF + 1);
     const int la = 6 + dd, lb = d2 < DF ? 6 + d2 : NL;
-    double sum = 0.0;
-    for (int cb = 0; cb < d.C * d.B; ++cb) {
-      const int v = fl * d.C * d.B + cb;
-      if (t.view_count[v] == 0) continue;
-      sum += rec[(size_t)v * d.rec_stride + (la <= lb ? tri_index(la, lb, N1) : tri_index(lb, la, N1))];
+    const int off = la <= lb ? tri_index(la, lb, N1) : tri_index(lb, la, N1);
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int cb = 0;
+    for (; cb + 4 <= CB; cb += 4) {      // four independent loads in flight, fixed summation order
+      const double v0 = rf[(size_t)cb * d.rec_stride + off];
+      const double v1 = rf[(size_t)(cb + 1) * d.rec_stride + off];
+      const double v2 = rf[(size_t)(cb + 2) * d.rec_stride + off];
+      const double v3 = rf[(size_t)(cb + 3) * d.rec_stride + off];
+      s0 += act[cb] != 0.0 ? v0 : 0.0;
+      s1 += act[cb + 1] != 0.0 ? v1 : 0.0;
+      s2 += act[cb + 2] != 0.0 ? v2 : 0.0;
+      s3 += act[cb + 3] != 0.0 ? v3 : 0.0;
     }
+    for (; cb < CB; ++cb) {
+      const double v0 = rf[(size_t)cb * d.rec_stride + off];
+      s0 += act[cb] != 0.0 ? v0 : 0.0;
+    }
+    const double sum = (s0 + s1) + (s2 + s3);
     if (d2 < DF) {
       hff[dd * DF + d2] = sum;
       if (d2 == dd) diag[d.frame_to_x(f, dd)] = sum;
@@ -491,8 +514,8 @@ __global__ __launch_bounds__(64, 2) void k_schur_syrk(int K, int ncol, int ntile
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
         const int kk = k + 4 * u + rsub;
-        av[u] = (kk < k1 && ci < ncol) ? W[(size_t)kk * ncol + ci] : 0.0;
-        bv[u] = (kk < k1 && cj < ncol) ? W[(size_t)kk * ncol + cj] : 0.0;
+        av[u] = masked_load(W, (size_t)kk * ncol + ci, kk < k1 && ci < ncol);
+        bv[u] = masked_load(W, (size_t)kk * ncol + cj, kk < k1 && cj < ncol);
       }
 #pragma unroll
       for (int u = 0; u < UB; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
@@ -848,14 +871,14 @@ __global__ __launch_bounds__(CHOL_BLK_THREADS) void k_chol_blk(int ns, double re
         const int bj = tile - bi * (bi + 1) / 2;
         const int gi = CT * bi + r, gj = CT * bj + c;
         const bool in = tile < ntile && gi < n1 && gj < ns && gj <= gi;
-        const double g = buf[in ? (size_t)gi * ns + gj : 0];
-        v[u] = in ? g + ((gi == gj) ? reg : 0.0) : ((gi == gj) ? 1.0 : 0.0);
+        v[u] = masked_load(buf, (size_t)gi * ns + gj, in) + (in ? ((gi == gj) ? reg : 0.0) : ((gi == gj) ? 1.0 : 0.0));
       }
 #pragma unroll
       for (int u = 0; u < UN; ++u) {
         const int tile = t0 + 2 * u + half;
         if (tile < ntile) Lb[(size_t)tile * CTS + r * CTL + c] = v[u];
       }
+      if (t0 == 0) { CHOL_STAMP(5) } else { CHOL_STAMP(6) }
     }
   }
   __syncthreads();
@@ -1127,8 +1150,8 @@ __global__ __launch_bounds__(64) void k_schur_backsub(Dims d, const double* __re
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
       const int kk = k0 + 4 * u + kq;
-      av[u] = (ri < DF && kk < ns) ? w[ri * ldw + kk] : 0.0;
-      bv[u] = kk < ns ? ps[kk] : 0.0;
+      av[u] = masked_load(w, (size_t)(ri * ldw + kk), ri < DF && kk < ns);
+      bv[u] = masked_load(ps, (size_t)kk, kk < ns);
     }
 #pragma unroll
     for (int u = 0; u < UB; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);

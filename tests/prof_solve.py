@@ -25,7 +25,7 @@ with Handle(c) as h:
     for ns in (140,):
         M = rng.normal(size=(ns + 20, ns)); S = M.T @ M / ns + 0.1 * np.eye(ns); rhs = rng.normal(size=ns)
         st = h.debug_chol(S, rhs, reg=0.05, blocked=4)[:8]
-        print("k_chol_blk cycles: load %d  first diag %d  panel %d  syrk + next diag %d  back %d" % tuple(st[:5]))
+        print("k_chol_blk cycles: load(barrier) %d  first diag %d  panel %d  syrk + next diag %d  back %d | load batch 1 %d  batch 2 %d" % tuple(st[:7]))
         for mode in (0, 3):
             h.debug_chol(S, rhs, reg=0.05, blocked=mode)
             t0 = time.perf_counter()
