@@ -119,7 +119,8 @@ struct mcba_handle_s {
   bool use_mfma = true;
   bool shard_root = true;
   ScalLayout sl;
-  size_t chol_lds_set = 0, chol_lds2_set = 0, chol_lds3_set = 0;
+  size_t chol_lds_set = 0, chol_lds2_set = 0, chol_lds3_set = 0, chol_lds4_set = 0;
+  DevBuf<double> chol_linv;   // inverted diagonal tiles of k_chol_glb
   int lin_grid = 0;          // 0 = automatic (see lin2), > 0 = forced number of persistent workgroups (debug)
 
   // host copies needed to rebuild the inlier tables
@@ -319,19 +320,34 @@ constexpr size_t CHOL_SINGLE_MAX_LDS = 96 * 1024;
 bool g_force_blocked_chol = false;   // test hooks
 bool g_force_panel_chol = false;
 bool g_force_column_chol = false;
+bool g_force_glb_chol = false;
 long long* g_chol_prof = nullptr;    // device buffer of 8 phase stamps (mcba_debug_chol, blocked == 4)
 
 // (S + reg I) p = rhs for buf = [S (ns x ns) | rhs (ns)]; S is overwritten by its Cholesky factor
 void launch_chol(mcba_handle_s* h, int ns, double reg, double* buf, double* ps) {
   const int max_rows = ns + 1;
   const size_t lds_packed = ((size_t)(ns + 1) * (ns + 2) / 2 + (ns + 1) + 2) * sizeof(double);
-  if (ns + 1 <= CHOL_BLK_MAX_N1 && !g_force_blocked_chol && !g_force_panel_chol && !g_force_column_chol) {
+  if (ns + 1 <= CHOL_BLK_MAX_N1 && !g_force_blocked_chol && !g_force_panel_chol && !g_force_column_chol && !g_force_glb_chol) {
     const size_t lds_blk = chol_blk_lds_bytes(ns);
     if (lds_blk > h->chol_lds3_set) {
       HIP_OK(hipFuncSetAttribute((const void*)k_chol_blk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_blk));
       h->chol_lds3_set = lds_blk;
     }
     hipLaunchKernelGGL(k_chol_blk, dim3(1), dim3(CHOL_BLK_THREADS), lds_blk, h->stream, ns, reg, buf, ps, h->info.p, g_chol_prof);
+    return;
+  }
+  if (ns + 1 <= (g_force_glb_chol ? CHOL_GLB_MAX_N1 : CHOL_GLB_AUTO_N1) && !g_force_blocked_chol && !g_force_panel_chol &&
+      !g_force_column_chol) {
+    // 160 <= ns + 1 <= 1024: one workgroup, matrix in L2, panel in LDS
+    const size_t lds_glb = chol_glb_lds_bytes(ns);
+    if (lds_glb > h->chol_lds4_set) {
+      HIP_OK(hipFuncSetAttribute((const void*)k_chol_glb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_glb));
+      h->chol_lds4_set = lds_glb;
+    }
+    const size_t nlinv = (size_t)((ns + 1 + CT - 1) / CT) * CT * CT;
+    if (h->chol_linv.n < nlinv) h->chol_linv.alloc(nlinv, false);
+    hipLaunchKernelGGL(k_chol_glb, dim3(1), dim3(CHOL_BLK_THREADS), lds_glb, h->stream, ns, reg, buf, h->chol_linv.p, ps,
+                       h->info.p);
     return;
   }
   if (lds_packed <= 150 * 1024 && !g_force_blocked_chol && !g_force_panel_chol) {
@@ -595,7 +611,9 @@ int32_t mcba_create(const mcba_problem* p, void* hip_stream, mcba_handle* out) {
 
   // ---- work buffers -----------------------------------------------------------------------------------------
   h->rec.alloc((size_t)d.views() * d.rec_stride);
-  h->nchunk = std::max(1, std::min(64, (d.Fl + 7) / 8));
+  // chunk sums of the shared part: about 1024 (pair, chunk) workgroups in k_assemble; k_shared_final reads C B nchunk
+  // partial records per entry, so many pairs get fewer chunks
+  h->nchunk = std::max(1, std::min(std::min(64, (d.Fl + 7) / 8), std::max(4, 1024 / std::max(1, d.C * d.B))));
   h->partial.alloc((size_t)d.C * d.B * h->nchunk * d.rec_stride);
   h->Hss.alloc((size_t)d.ns * d.ns);
   h->Hfs.alloc((size_t)d.Fl * d.DF * d.ns);
@@ -866,6 +884,7 @@ int32_t mcba_debug_chol(mcba_handle h, int32_t ns, const double* S, const double
   g_force_blocked_chol = blocked == 1;   // 0: automatic, 1: multi-workgroup, 2: single-workgroup panel kernel
   g_force_panel_chol = blocked == 2;
   g_force_column_chol = blocked == 3;    // 3: column-by-column LDS kernel (the round-1 baseline of k_chol_blk)
+  g_force_glb_chol = blocked == 5;       // 5: one-workgroup kernel with the matrix in global memory
   DevBuf<long long> stamps;
   if (blocked == 4) {                    // 4: k_chol_blk with phase stamps; p_out[0..7] receives the shader-clock totals
     REQUIRE(ns >= 8 && ns + 1 <= CHOL_BLK_MAX_N1, "profiling needs 8 <= ns < 160");
@@ -873,8 +892,8 @@ int32_t mcba_debug_chol(mcba_handle h, int32_t ns, const double* S, const double
     g_chol_prof = stamps.p;
   }
   try { launch_chol(h, ns, reg, buf.p, ps.p); }
-  catch (...) { g_force_blocked_chol = g_force_panel_chol = g_force_column_chol = false; g_chol_prof = nullptr; throw; }
-  g_force_blocked_chol = g_force_panel_chol = g_force_column_chol = false;
+  catch (...) { g_force_blocked_chol = g_force_panel_chol = g_force_column_chol = g_force_glb_chol = false; g_chol_prof = nullptr; throw; }
+  g_force_blocked_chol = g_force_panel_chol = g_force_column_chol = g_force_glb_chol = false;
   g_chol_prof = nullptr;
   if (blocked == 4) {
     long long st[8];

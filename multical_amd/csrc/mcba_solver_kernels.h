@@ -979,6 +979,201 @@ __global__ __launch_bounds__(CHOL_BLK_THREADS) void k_chol_blk(int ns, double re
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// k_chol_glb: the same tile algorithm as k_chol_blk for reduced systems that do not fit LDS (ns = 160 ... 1023: many
+// cameras, or adjust_board).  ONE workgroup; the matrix stays in global memory (it is L2-resident: <= 8 MB) and is
+// factored in place, only the current panel (the X tiles of one block column), the current diagonal tile and its inverse
+// live in LDS.  Per block column: wave 0 factors + inverts the diagonal tile in registers (chol_tile_factor), every wave
+// forms panel tiles X = A L_kk^-T on the matrix pipe (A from global, X to LDS and to global), then the trailing tiles
+// C -= X_i X_j^T are updated in global memory with X from LDS; the next diagonal tile is updated first and factored by
+// wave 0 while the other waves finish the update (look-ahead).  The inverted diagonal tiles are kept (Linv, global) for
+// the backward substitution, which runs on wave 0.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int CHOL_GLB_MAX_N1 = 1024;    // LDS limit of the kernel (measured: 4.8 ms at ns = 963 against 5.8 ms multi-workgroup)
+constexpr int CHOL_GLB_AUTO_N1 = CHOL_GLB_MAX_N1;
+__host__ __device__ inline size_t chol_glb_lds_bytes(int ns) {
+  const int nb = (ns + 1 + CT - 1) / CT;
+  return ((size_t)(nb + 2) * CTS + 2 * nb * CT) * sizeof(double) + 16;
+}
+
+__global__ __launch_bounds__(CHOL_BLK_THREADS) void k_chol_glb(int ns, double reg, double* __restrict__ buf,
+                                                               double* __restrict__ Linv, double* __restrict__ ps,
+                                                               int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) double chol_g[];
+  constexpr int NW = CHOL_BLK_THREADS / 64;
+  const int n1 = ns + 1, nb = (n1 + CT - 1) / CT, nbc = (ns + CT - 1) / CT;
+  double* Dt = chol_g;                          // current diagonal tile
+  double* Li = Dt + CTS;                        // its inverse
+  double* Xp = Li + CTS;                        // panel: X tiles of block rows k+1 .. nb-1 (tile bi at (bi - k - 1) CTS)
+  double* yv = Xp + (size_t)nb * CTS;
+  double* pv = yv + nb * CT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+  int badcol = 0;
+  // entry (gi, gj) of the augmented matrix; identity outside (padding rows / columns), reg on the diagonal of S
+  auto load_entry = [&](int gi, int gj) {
+    const bool in = gi < n1 && gj < ns;
+    return masked_load(buf, (size_t)gi * ns + gj, in) + (gi == gj ? (in ? reg : 1.0) : 0.0);
+  };
+  if (wave == 0) {   // first diagonal tile
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Dt[(lg + 4 * r) * CTL + li] = load_entry(lg + 4 * r, li);
+    lds_fence();
+    chol_tile_factor(Dt, Li, min(CT, ns), 0, lane, badcol);
+    lds_fence();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int gi = lg + 4 * r;
+      if (gi < n1 && li < ns) buf[(size_t)gi * ns + li] = Dt[gi * CTL + li];
+      Linv[(lg + 4 * r) * CT + li] = Li[(lg + 4 * r) * CTL + li];
+    }
+  }
+  __syncthreads();
+  for (int k = 0; k < nbc; ++k) {
+    const int c0 = CT * k;
+    {
+      // panel: X = A L_kk^-T for the tiles below the diagonal (rows may run into the rhs row / padding)
+      double bv[4];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) bv[s4] = Li[li * CTL + 4 * s4 + lg];
+      for (int bi = k + 1 + wave; bi < nb; bi += NW) {
+        const int gi = CT * bi + li;
+        double av[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const int gj = c0 + 4 * s4 + lg;
+          av[s4] = masked_load(buf, (size_t)gi * ns + gj, gi < n1 && gj < ns);
+        }
+        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s4], bv[s4], acc, 0, 0, 0);
+        double* X = Xp + (size_t)(bi - k - 1) * CTS;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ro = lg + 4 * r, gr = CT * bi + ro, gc = c0 + li;
+          X[ro * CTL + li] = acc[r];
+          if (gr < n1 && gc < ns) buf[(size_t)gr * ns + gc] = acc[r];
+        }
+      }
+    }
+    __syncthreads();
+    {
+      // trailing tiles (bi, bj), k < bj <= bi:  C -= X_bi X_bj^T in global memory.  Tile 0 of the enumeration is the next
+      // diagonal tile: wave 0 updates it into LDS and factors it (look-ahead) while waves 1 .. 7 share the others.
+      const int m = nb - k - 1, nt = m * (m + 1) / 2;
+      if (wave == 0) {
+        const int b1 = k + 1;
+        if (nt > 0 && ns - CT * b1 > 0) {
+          const double* X1 = Xp;   // tile b1 is the first of the panel
+          double4_t acc;
+          double av[4], bw[4];
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) {
+            av[s4] = -X1[li * CTL + 4 * s4 + lg];
+            bw[s4] = X1[li * CTL + 4 * s4 + lg];
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[r] = load_entry(CT * b1 + lg + 4 * r, CT * b1 + li);
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s4], bw[s4], acc, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Dt[(lg + 4 * r) * CTL + li] = acc[r];
+          lds_fence();
+          // (the panel of column k still needs the inverse of tile k: the new inverse goes to a scratch tile first)
+          double* Ln = Xp + (size_t)(nb - 1) * CTS;   // free: the panel of column k has nb - k - 1 <= nb - 1 tiles
+          chol_tile_factor(Dt, Ln, min(CT, ns - CT * b1), CT * b1, lane, badcol);
+          lds_fence();
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int ro = lg + 4 * r, gi = CT * b1 + ro, gj = CT * b1 + li;
+            if (gi < n1 && gj < ns) buf[(size_t)gi * ns + gj] = Dt[ro * CTL + li];
+            Linv[(size_t)b1 * CT * CT + ro * CT + li] = Ln[ro * CTL + li];
+          }
+        }
+      } else {
+        // TB tiles at a time: the C tiles come from L2 (~1 us per round trip), so the loads of a batch are all issued
+        // before the first MFMA
+        constexpr int TB = 4;
+        for (int t0 = wave; t0 < nt; t0 += TB * (NW - 1)) {
+          double4_t acc[TB];
+          int tbi[TB], tbj[TB], ta[TB], tr[TB];
+#pragma unroll
+          for (int u = 0; u < TB; ++u) {
+            const int tt = t0 + u * (NW - 1);
+            const int tc = tt < nt ? tt : 0;               // tt -> (a, rem), rem <= a: row a of the lower-triangular enumeration
+            int a = (int)((sqrtf(8.0f * (float)tc + 1.0f) - 1.0f) * 0.5f);
+            a += ((a + 1) * (a + 2) / 2 <= tc) ? 1 : 0;
+            a -= (a * (a + 1) / 2 > tc) ? 1 : 0;
+            const int rem = tc - a * (a + 1) / 2;
+            ta[u] = a; tr[u] = rem;
+            tbi[u] = k + 1 + a; tbj[u] = k + 1 + rem;
+            const int gj = CT * tbj[u] + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int gi = CT * tbi[u] + lg + 4 * r;
+              acc[u][r] = masked_load(buf, (size_t)gi * ns + gj, tt < nt && gi < n1 && gj < ns);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < TB; ++u) {
+            const double* Xa = Xp + (size_t)ta[u] * CTS;
+            const double* Xb = Xp + (size_t)tr[u] * CTS;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+              acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Xa[li * CTL + 4 * s4 + lg], Xb[li * CTL + 4 * s4 + lg], acc[u], 0, 0, 0);
+          }
+#pragma unroll
+          for (int u = 0; u < TB; ++u) {
+            const int tt = t0 + u * (NW - 1);
+            const int gj = CT * tbj[u] + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int gi = CT * tbi[u] + lg + 4 * r;
+              if (tt < nt && gi < n1 && gj < ns) buf[(size_t)gi * ns + gj] = acc[u][r];
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (wave == 0 && k + 1 < nbc) {   // the inverse of the next diagonal tile becomes the current one
+      const double* Ln = Xp + (size_t)(nb - 1) * CTS;
+      for (int e = lane; e < CTS; e += 64) Li[e] = Ln[e];
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+  if (wave == 0) {
+    // forward-substituted right-hand side = row ns of the factor; blocked back substitution with the stored inverses
+    for (int e = lane; e < nb * CT; e += 64) yv[e] = e < ns ? buf[(size_t)ns * ns + e] : 0.0;
+    lds_fence();
+    for (int kb = nbc - 1; kb >= 0; --kb) {
+      {   // p_k = L_kk^-T z_k   (the strict upper part of the stored inverse is zero)
+        const double* Xi = Linv + (size_t)kb * CT * CT;
+        double sp[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < CT; ++i) sp[i & 3] += Xi[i * CT + li] * yv[CT * kb + i];
+        const double sum = (sp[0] + sp[1]) + (sp[2] + sp[3]);
+        if (lane < CT) {
+          pv[CT * kb + li] = sum;
+          if (CT * kb + li < ns) ps[CT * kb + li] = sum;
+        }
+      }
+      lds_fence();
+      for (int e = lane; e < CT * kb; e += 64) {   // z_j -= L_kj^T p_k for the blocks above (L_kj from global)
+        double sp[4] = {yv[e], 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < CT; ++r) {
+          const int gi = CT * kb + r;
+          sp[r & 3] -= masked_load(buf, (size_t)gi * ns + e, gi < ns) * pv[gi];
+        }
+        yv[e] = (sp[0] + sp[1]) + (sp[2] + sp[3]);
+      }
+      lds_fence();
+    }
+    if (lane == 0) info[0] = badcol;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Multi-workgroup blocked Cholesky for large reduced systems (adjust_board: ns = shared + 3 x #board points, up to a
 // few thousand).  Same data layout as k_chol_solve ((ns+1) x ns, row ns = rhs), 64-column panels, three launches per
 // panel: diagonal block (one workgroup), panel solve (one row per thread), symmetric rank-64 trailing update with

@@ -332,7 +332,7 @@ def test_adjust_board_rolling_and_handeye_blocks():
 
 
 @pytest.mark.parametrize("ns,blocked", [(5, 0), (16, 0), (18, 0), (31, 0), (32, 0), (40, 0), (40, 1), (40, 2), (40, 3), (140, 0), (140, 3),
-                                        (159, 0), (160, 0), (190, 0), (200, 0), (200, 1), (200, 2),
+                                        (159, 0), (160, 0), (190, 0), (40, 5), (144, 5), (160, 5), (286, 0), (286, 3), (700, 0), (1022, 5), (1023, 1), (200, 0), (200, 1), (200, 2),
                                         (333, 1), (700, 0), (1500, 1)])
 def test_device_cholesky_paths(ns, blocked):
   """LDS-resident (0, small ns), single-workgroup panel (2) and multi-workgroup MFMA (1) Cholesky solves vs numpy."""
