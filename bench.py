@@ -88,10 +88,17 @@ def main():
   rank = int(os.environ.get("RANK", "0"))
   local_rank = int(os.environ.get("LOCAL_RANK", "0"))
   assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-  torch.cuda.set_device(local_rank)
+  # MCBA_BENCH_BACKEND=gloo is a test hook: it lets the N > 1 code path run with several ranks on ONE GPU (all-reduces
+  # staged through the host); the measured configuration is always nccl (= RCCL over xGMI), one GPU per rank
+  backend = os.environ.get("MCBA_BENCH_BACKEND", "nccl")
+  device_index = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
+  torch.cuda.set_device(device_index)
   if world > 1:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if backend == "nccl":
+      dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+    else:
+      dist.init_process_group(backend)
 
   # ---- synthetic workload: this rank's 500-frame shard of the 8 x (500 N) x 2 rolling-shutter rig -------------
   F_total = FRAMES_PER_SHARD * world
@@ -101,8 +108,14 @@ def main():
   x0 = calib.param_vec
   tstream = torch.cuda.Stream()    # kernels and RCCL collectives share this (non-default) stream
   h = Handle(lower(calib), frame_range=shard if world > 1 else None, stream=tstream.cuda_stream)
+  native = False
   if world > 1:
-    h.set_allreduce(mdist.make_allreduce_hook(stream=tstream))
+    # reductions: the library's own RCCL communicator (in-place ncclAllReduce on the handle's stream); the
+    # torch.distributed hook is the fallback (gloo test hook, or if the native initialisation fails on any rank)
+    if backend == "nccl" and os.environ.get("MCBA_NO_NATIVE_RCCL", "0") != "1":
+      native = mdist.init_native_allreduce(h, rank, world)
+    if not native:
+      h.set_allreduce(mdist.make_allreduce_hook(stream=tstream))
     h.set_shard_root(rank == 0)
   n_slots = int(np.prod(rig.valid.shape[0:1] + (FRAMES_PER_SHARD,) + rig.valid.shape[2:]))
   n_obs = h.n_residuals // 2
@@ -188,7 +201,8 @@ def main():
                                     f"(charuco_16x22 + aprilgrid_9x9), rolling-shutter motion, intrinsics+extrinsics; "
                                     f"{world} frame shard(s) of one 8 x {F_total} x 2 rig",
                            n_params=int(h.n_params), n_slots_per_gpu=n_slots, n_observations_per_gpu=int(n_obs),
-                           parallelism=f"frame-sharded x{world}" if world > 1 else "single GPU",
+                           parallelism=(f"frame-sharded x{world}, " + ("native RCCL all-reduce" if native else
+                                        f"torch.distributed ({backend}) all-reduce hook")) if world > 1 else "single GPU",
                            device=h.device_info()),
                roofline=roofline, **extra)
     if world == 1 and not args.no_cpu_baseline:

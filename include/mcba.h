@@ -156,6 +156,13 @@ int32_t mcba_num_residuals(mcba_handle h, int64_t* n_residuals);   /* 2 * #inlie
 int32_t mcba_set_inliers(mcba_handle h, const uint8_t* mask);
 
 int32_t mcba_set_allreduce(mcba_handle h, mcba_allreduce_fn fn, void* ctx);
+/* Native alternative to the callback: RCCL over xGMI driven from inside the library (librccl is loaded at run time).
+ * One rank calls mcba_rccl_unique_id and hands the 128 bytes to all ranks (multical_amd.distributed broadcasts them with
+ * torch.distributed); then EVERY rank calls mcba_rccl_init (collective).  From then on all reductions of the handle are
+ * in-place ncclAllReduce calls on the handle's stream.  mcba_rccl_shutdown leaves the native path again.            */
+int32_t mcba_rccl_unique_id(uint8_t* id_out /*[128]*/);
+int32_t mcba_rccl_init(mcba_handle h, const uint8_t* id /*[128]*/, int32_t rank, int32_t world);
+int32_t mcba_rccl_shutdown(mcba_handle h);
 /* exactly one rank of a sharded problem is the root: it contributes the replicated (shared) right-hand side to the
  * reduced system.  Default: root.  Ranks other than 0 call this with 0.                                          */
 int32_t mcba_set_shard_root(mcba_handle h, int32_t is_root);

@@ -344,6 +344,24 @@ class Handle(object):
     self._callbacks.append(cb)
     check(self.lib.mcba_set_allreduce(self.h, cb, None))
 
+  # --- native RCCL all-reduce (multical_amd.distributed.init_native_allreduce drives these) ----------------------
+  @staticmethod
+  def rccl_unique_id():
+    """128 opaque bytes from ncclGetUniqueId (call on ONE rank, hand to all)."""
+    buf = (C.c_uint8 * 128)()
+    check(_lib.load().mcba_rccl_unique_id(buf))
+    return bytes(buf)
+
+  def rccl_init(self, unique_id, rank, world):
+    """Collective: builds this handle's RCCL communicator; afterwards every reduction is an in-place ncclAllReduce on
+    the handle's stream."""
+    assert len(unique_id) == 128
+    buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+    check(self.lib.mcba_rccl_init(self.h, buf, int(rank), int(world)))
+
+  def rccl_shutdown(self):
+    check(self.lib.mcba_rccl_shutdown(self.h))
+
   def solve(self, x0, tolerance=1e-4, f_scale=1.0, max_iterations=100, loss='linear', xtol=1e-8, gtol=1e-8,
             verbose=2):
     x = self._x(x0).copy()

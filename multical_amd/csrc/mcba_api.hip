@@ -11,6 +11,7 @@
 //     + dense Cholesky of the reduced system), all on the GPU.  Only 2x2 algebra and control flow run on the host.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <dlfcn.h>
 #include <chrono>
 #include <cmath>
 #include <complex>
@@ -109,6 +110,8 @@ struct ScalLayout {
 
 }  // namespace
 
+namespace { void destroy_rccl_comm(void* comm); }
+
 struct mcba_handle_s {
   Dims d{};
   Tables t{};
@@ -157,6 +160,7 @@ struct mcba_handle_s {
 
   mcba_allreduce_fn allreduce = nullptr;
   void* allreduce_ctx = nullptr;
+  void* rccl_comm = nullptr;   // ncclComm_t of the native all-reduce path (mcba_rccl_init)
   mcba_log_fn log = nullptr;
   void* log_ctx = nullptr;
 
@@ -169,6 +173,7 @@ struct mcba_handle_s {
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     if (ev_fetch) (void)hipEventDestroy(ev_fetch);
+    if (rccl_comm) destroy_rccl_comm(rccl_comm);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
   }
   double* g() { return gbuf.p; }
@@ -239,6 +244,44 @@ void eval_tables(mcba_handle_s* h, const double* dx) {
   eval_pose_tables(h, dx);
   const int nv = d.views() * (d.motion == MOTION_ROLLING ? 2 : 1);
   if (nv > 0) hipLaunchKernelGGL(k_views, dim3((nv + 127) / 128), dim3(128), 0, h->stream, d, h->t);
+}
+
+// ---- native RCCL all-reduce (one process per GPU over xGMI): librccl is loaded at run time, so the library has no link-
+// time dependency on it and single-GPU users never touch it.  Enumerators from rccl.h (ABI-stable): ncclSum = 0,
+// ncclMax = 2, ncclFloat64 = 8, ncclSuccess = 0; the unique id is 128 opaque bytes.
+struct RcclApi {
+  typedef struct { char internal[128]; } UniqueId;
+  int (*GetUniqueId)(UniqueId*) = nullptr;
+  int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  bool ok = false;
+};
+const RcclApi& rccl_api() {
+  static const RcclApi api = [] {
+    RcclApi a;
+    void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) return a;
+    a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+    a.CommInitRank = (decltype(a.CommInitRank))dlsym(lib, "ncclCommInitRank");
+    a.AllReduce = (decltype(a.AllReduce))dlsym(lib, "ncclAllReduce");
+    a.CommDestroy = (decltype(a.CommDestroy))dlsym(lib, "ncclCommDestroy");
+    a.GetErrorString = (decltype(a.GetErrorString))dlsym(lib, "ncclGetErrorString");
+    a.ok = a.GetUniqueId && a.CommInitRank && a.AllReduce && a.CommDestroy;
+    return a;
+  }();
+  return api;
+}
+void destroy_rccl_comm(void* comm) {
+  if (comm && rccl_api().ok) (void)rccl_api().CommDestroy(comm);
+}
+int32_t rccl_allreduce_native(void* ctx, void* device_buf, size_t count, int32_t op, void* stream) {
+  mcba_handle_s* h = static_cast<mcba_handle_s*>(ctx);
+  const int rc = rccl_api().AllReduce(device_buf, device_buf, count, /*ncclFloat64*/ 8, op == 0 ? /*ncclSum*/ 0 : /*ncclMax*/ 2,
+                                      h->rccl_comm, (hipStream_t)stream);
+  return rc;
 }
 
 int call_allreduce(mcba_handle_s* h, double* buf, size_t count, int op) {
@@ -698,6 +741,51 @@ int32_t mcba_set_allreduce(mcba_handle h, mcba_allreduce_fn fn, void* ctx) {
   REQUIRE(h, "null handle");
   h->allreduce = fn;
   h->allreduce_ctx = ctx;
+  API_END
+}
+
+// native path: 128-byte RCCL unique id, created by ONE rank and distributed by the caller
+int32_t mcba_rccl_unique_id(uint8_t* id_out) {
+  API_BEGIN
+  REQUIRE(id_out, "null argument");
+  const RcclApi& api = rccl_api();
+  REQUIRE(api.ok, "librccl could not be loaded");
+  RcclApi::UniqueId id;
+  const int rc = api.GetUniqueId(&id);
+  REQUIRE(rc == 0, std::string("ncclGetUniqueId failed: ") + (api.GetErrorString ? api.GetErrorString(rc) : "?"));
+  memcpy(id_out, id.internal, 128);
+  API_END
+}
+
+// collective over all `world` ranks: creates the communicator of this handle; from then on every reduction of the handle
+// is an in-place ncclAllReduce on the handle's stream -- no Python, no host synchronisation
+int32_t mcba_rccl_init(mcba_handle h, const uint8_t* id_in, int32_t rank, int32_t world) {
+  API_BEGIN
+  REQUIRE(h && id_in && world >= 1 && rank >= 0 && rank < world, "bad argument");
+  const RcclApi& api = rccl_api();
+  REQUIRE(api.ok, "librccl could not be loaded");
+  REQUIRE(h->rccl_comm == nullptr, "communicator already initialised");
+  HIP_OK(hipSetDevice(h->device));
+  RcclApi::UniqueId id;
+  memcpy(id.internal, id_in, 128);
+  void* comm = nullptr;
+  const int rc = api.CommInitRank(&comm, world, id, rank);
+  REQUIRE(rc == 0 && comm, std::string("ncclCommInitRank failed: ") + (api.GetErrorString ? api.GetErrorString(rc) : "?"));
+  h->rccl_comm = comm;
+  h->allreduce = rccl_allreduce_native;
+  h->allreduce_ctx = h;
+  API_END
+}
+
+// leaves the native path again (used when the caller's consistency check across ranks fails)
+int32_t mcba_rccl_shutdown(mcba_handle h) {
+  API_BEGIN
+  REQUIRE(h, "null handle");
+  if (h->rccl_comm) {
+    destroy_rccl_comm(h->rccl_comm);
+    h->rccl_comm = nullptr;
+    if (h->allreduce == rccl_allreduce_native) { h->allreduce = nullptr; h->allreduce_ctx = nullptr; }
+  }
   API_END
 }
 

@@ -15,6 +15,8 @@ The C library calls back into `allreduce_hook` with DEVICE pointers (include/mcb
 current stream, so no host synchronisation is involved -- and with "gloo" (CPU-side tests) the buffer is staged
 through host memory.
 """
+import os
+
 import numpy as np
 
 
@@ -75,8 +77,42 @@ def make_allreduce_hook(group=None, device=None, stream=None):
   return hook
 
 
-def sharded_handle(calib, rank=None, world_size=None, group=None, balance=True):
-  """Handle owning this rank's frame shard, wired to torch.distributed.  Kernels run on torch's current stream."""
+def init_native_allreduce(h, rank, world_size, group=None):
+  """Switches handle `h` to the library's own RCCL communicator (collective over the group).
+
+  torch.distributed only carries the 128-byte unique id and the success flags; the reductions themselves are
+  ncclAllReduce calls issued by the C library on the handle's stream (no Python callback, no torch dispatch in the
+  inner loop -- the callback path costs ~50 us of host time per reduction).  Returns True when EVERY rank succeeded;
+  otherwise all ranks leave the native path again and the caller falls back to the torch.distributed hook."""
+  import torch
+  import torch.distributed as dist
+  from .backend import Handle
+  ok = 1
+  payload = [None]
+  if rank == 0:
+    try:
+      payload[0] = Handle.rccl_unique_id()
+    except Exception:
+      payload[0] = None
+  dist.broadcast_object_list(payload, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+  if payload[0] is None:
+    ok = 0
+  else:
+    try:
+      h.rccl_init(payload[0], rank, world_size)
+    except Exception:
+      ok = 0
+  flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if dist.get_backend(group) == "nccl" else "cpu")
+  dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+  if int(flag.item()) != 1:
+    h.rccl_shutdown()
+    return False
+  return True
+
+
+def sharded_handle(calib, rank=None, world_size=None, group=None, balance=True, native=None):
+  """Handle owning this rank's frame shard.  Reductions: the library's own RCCL communicator (`native`, default when the
+  group's backend is nccl, i.e. one GPU per rank) or a torch.distributed hook (gloo tests, fallback)."""
   import torch
   import torch.distributed as dist
   from .backend import Handle, lower
@@ -92,7 +128,11 @@ def sharded_handle(calib, rank=None, world_size=None, group=None, balance=True):
   h = Handle(prob, frame_range=shards[rank], stream=tstream.cuda_stream)
   h.torch_stream = tstream                            # keep it alive as long as the handle
   if world_size > 1:
-    h.set_allreduce(make_allreduce_hook(group, stream=tstream))
+    if native is None:
+      native = dist.get_backend(group) == "nccl" and os.environ.get("MCBA_NO_NATIVE_RCCL", "0") != "1"
+    h.native_allreduce = bool(native) and init_native_allreduce(h, rank, world_size, group)
+    if not h.native_allreduce:
+      h.set_allreduce(make_allreduce_hook(group, stream=tstream))
     h.set_shard_root(rank == 0)
   h.frame_range = shards[rank]
   return h

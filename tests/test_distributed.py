@@ -118,3 +118,26 @@ def test_sharded_solve_two_ranks_one_gpu(name, tmp_path):
   # (the sharded handle runs the scalar trust-region algebra on the host, the single handle in device kernels: libm and
   #  ocml differ in the last bits of sqrt / hypot / sin / cos, which weakly determined gauge directions amplify)
   assert np.abs(sh["x"] - res.x).max() < 1e-7
+
+
+@pytest.mark.gpu
+def test_native_rccl_single_rank_communicator():
+  """The library's own RCCL path (mcba_rccl_*): a one-rank communicator on this GPU; every reduction of the sharded
+  driver then goes through ncclAllReduce on the handle's stream and the solve must equal the plain single-GPU solve
+  (host trust-region algebra vs device kernels: same tolerance as the two-rank test)."""
+  from multical_amd.backend import Handle
+  g, rig = load_golden("tiny_rolling")
+  c = mirror(rig)
+  with Handle(c) as h0:
+    ref = h0.solve(g["x0"])
+  with Handle(c) as h:
+    uid = Handle.rccl_unique_id()
+    assert len(uid) == 128
+    h.rccl_init(uid, 0, 1)
+    h.set_shard_root(True)
+    cost, grad, diag = h.normal_equations(g["x0"])
+    res = h.solve(g["x0"])
+    h.rccl_shutdown()
+  assert res.nfev == ref.nfev and res.status == ref.status
+  assert res.cost == pytest.approx(ref.cost, rel=1e-10)
+  assert np.abs(res.x - ref.x).max() < 1e-7
