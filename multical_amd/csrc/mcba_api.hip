@@ -81,28 +81,26 @@ struct DevBuf {
 };
 
 constexpr int COST_BLOCKS_MAX = 3072;   // persistent single-wave workgroups of k_cost (see LIN_GRID_MAX)
-// Scalars fetched by the trust-region driver at its three synchronisation points.  Each fetch is ONE contiguous
-// device-to-host copy that also carries per-block partial sums, which the host folds in a fixed order: that saves the
-// tiny final-sum kernels and device-to-device copies of a latency-bound loop (every launch costs ~5 us of GPU timeline).
-// Frame-sharded handles reduce the H-dependent partials on the device and all-reduce them instead.
+// Scalars and per-block partial sums fetched by the trust-region driver: ONE contiguous device-to-host copy per
+// iteration.  Partials are folded in a fixed order by the one-wave driver kernels or by the host, which saves the tiny
+// final-sum kernels and device-to-device copies of a latency-bound loop (every launch costs ~5 us of GPU timeline).
+// Frame-sharded handles all-reduce the H-dependent partial arrays element-wise before they are folded.
 constexpr int N_SCALARS = 32;
 constexpr int Q00_BLOCKS = 512;
 struct ScalLayout {
   int nvb = 0;        // blocks of the element-wise vector kernels, ceil(n / 256)
-  int vs = 0;         // [3 nvb]           k_vec_scale partials                       (sync 1)
-  int q00p = 0;       // [Q00_BLOCKS]      k_q00 partials (single GPU)                (sync 1)
-  int step = 0;       // [3 nvb]           k_vec_step partials                        (sync 3)
-  int cost1 = 0;      // [2]               reduced cost (sharded)                     (sync 3)
-  int costp = 0;      // [COST_BLOCKS_MAX] k_cost partials (single GPU)               (sync 3)
-  int dotp = 0;       // [3 nblk + 1]      partial dots + pivot report (single GPU)   (sync 2)
+  int vs = 0;         // [3 nvb]           k_vec_scale partials
+  int q00p = 0;       // [Q00_BLOCKS]      k_q00 partials (all-reduced element-wise when sharded)
+  int step = 0;       // [3 nvb]           k_vec_step partials
+  int costp = 0;      // [COST_BLOCKS_MAX] k_cost partials (all-reduced element-wise when sharded)
+  int dotp = 0;       // [3 nblk + 1]      partial dots + pivot report (folded by k_tr_step)
   int total = 0;
   void init(int n, int dot_blocks) {
     nvb = (n + 255) / 256;
     vs = N_SCALARS;
     q00p = vs + (3 * nvb + 1) / 2 * 2;
     step = q00p + Q00_BLOCKS;
-    cost1 = step + (3 * nvb + 1) / 2 * 2;
-    costp = cost1 + 2;
+    costp = step + (3 * nvb + 1) / 2 * 2;
     dotp = costp + COST_BLOCKS_MAX;
     total = dotp + 3 * dot_blocks + 8;
   }
@@ -146,7 +144,7 @@ struct mcba_handle_s {
   DevBuf<double> rec, partial, Hss, Hfs, Hff, gbuf;   // gbuf = [g (n) | diag (n) | cost, count]
   int nchunk = 1;
   // solver state
-  DevBuf<double> x, xnew, scale_inv, dsc, gh, gn, scal, qpart, costpart, Lf, W, yf, P, sbuf, ps;
+  DevBuf<double> x, xnew, scale_inv, dsc, gh, gn, scal, costpart, Lf, W, yf, P, sbuf, ps;
   DevBuf<int32_t> info;
   double* h_scal = nullptr;   // pinned
   double* h_x = nullptr;      // pinned staging of x uploads [n]
@@ -291,12 +289,6 @@ int call_allreduce(mcba_handle_s* h, double* buf, size_t count, int op) {
   return 0;
 }
 
-// cost at the current tables -> costpart[0] on the device (reduced across ranks)
-void launch_cost(mcba_handle_s* h, double* out_dev) {
-  h->ops->cost(h->d, h->t, h->stream, h->costpart.p, h->cost_blocks);
-  hipLaunchKernelGGL(k_sum, dim3(1), dim3(256), 0, h->stream, h->costpart.p, h->cost_blocks, out_dev);
-  call_allreduce(h, out_dev, 1, 0);
-}
 
 // fused residual+Jacobian -> block normal equations at the current tables
 void launch_linearize(mcba_handle_s* h) {
@@ -348,14 +340,6 @@ double host_sum(const double* p, int n) {   // fixed order: the result does not 
   return (s0 + s1) + (s2 + s3);
 }
 
-// Cauchy curvature g_h^T (D H D) g_h -> scal[off]
-void launch_q00(mcba_handle_s* h, const double* u, int off) {
-  const Dims& d = h->d;
-  hipLaunchKernelGGL(k_q00, dim3(Q00_BLOCKS), dim3(256), 0, h->stream, d, h->Hss.p, h->Hfs.p, h->Hff.p, h->dsc.p, u,
-                     h->qpart.p);
-  hipLaunchKernelGGL(k_q00_final, dim3(1), dim3(256), 0, h->stream, h->qpart.p, Q00_BLOCKS, h->scal.p + off);
-  call_allreduce(h, h->scal.p + off, 1, 0);
-}
 
 
 
@@ -480,7 +464,8 @@ void launch_gn_solve(mcba_handle_s* h, double reg, bool root_rank, double* dots_
     // frame entries of gn are known only to the owning rank: zero the (replicated) shared entries on non-root ranks
     // is not needed -- every rank holds identical p_s; sum only the frame block.
     call_allreduce(h, h->gn.p + d.off_motion, (size_t)d.n_motion, 0);
-    if (dots_out) hipLaunchKernelGGL(k_dots3, dim3(1), dim3(1024), 0, h->stream, d.n, h->gh.p, h->gn.p, dots_out);
+    if (dots_out)   // complete dots + pivot report in the layout of ONE back-substitution block: [d00 d01 d11 | info]
+      hipLaunchKernelGGL(k_dots3, dim3(1), dim3(1024), 0, h->stream, d.n, h->gh.p, h->gn.p, dots_out, h->info.p);
   }
 }
 
@@ -665,7 +650,6 @@ int32_t mcba_create(const mcba_problem* p, void* hip_stream, mcba_handle* out) {
   for (DevBuf<double>* b : {&h->x, &h->xnew, &h->scale_inv, &h->dsc, &h->gh, &h->gn}) b->alloc((size_t)d.n);
   h->sl.init(d.n, d.Fl + 2);
   h->scal.alloc((size_t)h->sl.total);
-  h->qpart.alloc(std::max<size_t>(3 * (size_t)(d.Fl + 1), Q00_BLOCKS));
   h->cost_blocks = std::max(1, std::min(COST_BLOCKS_MAX, d.views()));
   h->costpart.alloc((size_t)h->cost_blocks);
   h->Lf.alloc((size_t)d.Fl * d.DF * d.DF);
@@ -1020,11 +1004,12 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
   const int max_nfev = opt->max_nfev > 0 ? opt->max_nfev : d.n * 100;
   const double NaN = std::numeric_limits<double>::quiet_NaN();
   const bool is_root = h->shard_root;
-  // Single GPU: the scalar trust-region algebra runs in one-wave kernels between the vector kernels (k_tr_reg, k_tr_step),
-  // so that a whole iteration -- scaling, Cauchy curvature, damped Gauss-Newton solve, 2-D subspace step, trial cost -- is
-  // enqueued at once and the host synchronises ONCE per iteration.  Frame-sharded handles run the same algebra
-  // (mcba_trmath.h) on the host between their all-reduces: three synchronisations per iteration.
-  const bool dev_tr = h->allreduce == nullptr;
+  // The scalar trust-region algebra runs in one-wave kernels between the vector kernels (k_tr_reg, k_tr_step), so that a
+  // whole iteration -- scaling, Cauchy curvature, damped Gauss-Newton solve, 2-D subspace step, trial cost -- is enqueued
+  // at once and the host synchronises ONCE per iteration.  Frame-sharded handles insert their all-reduces into the same
+  // chain (stream-ordered: native RCCL or the torch.distributed hook): H-dependent per-block partials are reduced element-
+  // wise across ranks before the device (k_q00 partials) or the host (k_cost partials) folds them.  The host runs the
+  // same algebra (mcba_trmath.h) only for the retries after a rejected step.
   double* S = h->h_scal;   // host copy of the scalar block scal[0 .. TR_NSLOTS)
 
   upload_x(h, x_inout, h->x.p);
@@ -1040,22 +1025,24 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) lin_ms_total += ms;
   };
-  // trial step for coefficients given by the host (retries, sharded handles) or by k_tr_step (tr_dev)
+  // the element-wise all-reduce of the k_cost partials needs the same count on every rank: shards differ in size
+  const int cost_grid = h->allreduce ? COST_BLOCKS_MAX : h->cost_blocks;
+  // trial step for coefficients given by the host (retries) or by k_tr_step (tr_dev)
   auto enqueue_trial = [&](double alpha, double beta, const double* tr_dev) {
     hipLaunchKernelGGL(k_vec_step, dim3(sl.nvb), dim3(256), 0, h->stream, d, h->x.p, h->dsc.p, h->gh.p, h->gn.p, alpha, beta,
                        h->xnew.p, h->scal.p + sl.step, tr_dev);
     eval_pose_tables(h, h->xnew.p);   // k_cost forms the view chains itself; k_tmat rebuilds the view table if accepted
-    if (dev_tr) h->ops->cost(d, h->t, h->stream, h->scal.p + sl.costp, h->cost_blocks);
-    else launch_cost(h, h->scal.p + sl.cost1);
+    h->ops->cost(d, h->t, h->stream, h->scal.p + sl.costp, cost_grid);
+    call_allreduce(h, h->scal.p + sl.costp, (size_t)cost_grid, 0);
   };
   auto fold_trial = [&](double* step_h2, double* step2, double* x2) {   // after a fetch that covers [sl.step, ...)
     double s3[3] = {0, 0, 0};
     for (int blk = 0; blk < sl.nvb; ++blk)
       for (int k = 0; k < 3; ++k) s3[k] += S[sl.step + 3 * blk + k];
     *step_h2 = s3[0]; *step2 = s3[1]; *x2 = s3[2];
-    return dev_tr ? host_sum(S + sl.costp, h->cost_blocks) : S[sl.cost1];
+    return host_sum(S + sl.costp, cost_grid);
   };
-  const int trial_fetch_end = dev_tr ? sl.costp + h->cost_blocks : sl.cost1 + 1;
+  const int trial_fetch_end = sl.costp + cost_grid;
 
   timed_linearize();
   int nfev = 1, njev = 1, iteration = 0, status = -100;
@@ -1078,13 +1065,16 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
     bool have_trial = false;
     if (finishing) {
       fetch_scalars(h, sl.q00p);
-    } else if (dev_tr) {
+    } else {
       hipLaunchKernelGGL(k_q00, dim3(Q00_BLOCKS), dim3(256), 0, h->stream, d, h->Hss.p, h->Hfs.p, h->Hff.p, h->dsc.p,
                          h->gh.p, h->scal.p + sl.q00p);
+      call_allreduce(h, h->scal.p + sl.q00p, Q00_BLOCKS, 0);
       hipLaunchKernelGGL(k_tr_reg, dim3(1), dim3(64), 0, h->stream, h->scal.p, h->scal.p + sl.vs, sl.nvb,
                          h->scal.p + sl.q00p, Q00_BLOCKS, first ? 1 : 0, Delta);
       launch_gn_solve(h, 0.0, is_root, h->scal.p + sl.dotp, h->scal.p);
-      hipLaunchKernelGGL(k_tr_step, dim3(1), dim3(64), 0, h->stream, h->scal.p, h->scal.p + sl.dotp, gn_dot_blocks(d));
+      // (a handle that owns only a shard of the frames gets the three complete dots + the pivot report: one "block")
+      hipLaunchKernelGGL(k_tr_step, dim3(1), dim3(64), 0, h->stream, h->scal.p, h->scal.p + sl.dotp,
+                         (h->allreduce && d.DF * d.Fl > 0) ? 1 : gn_dot_blocks(d));
       enqueue_trial(0.0, 0.0, h->scal.p);
       fetch_scalars_begin(h, trial_fetch_end);
       // Speculation: most trial steps are accepted, so the linearisation at x_new is enqueued right behind the copy and
@@ -1095,9 +1085,6 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
       spec_lin = true;
       fetch_scalars_end(h);
       have_trial = true;
-    } else {
-      launch_q00(h, h->gh.p, TR_Q00);
-      fetch_scalars(h, sl.q00p);
     }
     if (fresh_lin) { collect_lin_time(); fresh_lin = false; }
     if (!have_trial) {   // fold the k_vec_scale partials on the host (the vectors are complete on every rank)
@@ -1128,17 +1115,7 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
     if (status != -100 || nfev >= max_nfev) break;   // (a step the device has already evaluated is simply dropped)
 
     // ---- regularised Gauss-Newton step + 2-D subspace ------------------------------------------------------------
-    int32_t chol_info = 0;
-    if (dev_tr) {
-      chol_info = (int32_t)S[TR_INFO];
-    } else {
-      S[TR_REG] = S[TR_GH2] > 0 ? tr_reg_term(S[TR_Q00], S[TR_GH2], Delta) : TR_REG_FLOOR;
-      launch_gn_solve(h, S[TR_REG], is_root, h->scal.p + TR_D00);
-      HIP_OK(hipMemcpyAsync(h->scal.p + TR_INFO, h->info.p, sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
-      fetch_scalars(h, TR_INFO + 1 - TR_D00, TR_D00);
-      memcpy(&chol_info, &S[TR_INFO], sizeof(int32_t));
-      tr_subspace(S);
-    }
+    const int32_t chol_info = (int32_t)S[TR_INFO];
     if (chol_info != 0)
       throw Error("reduced normal equations are not positive definite (pivot " + std::to_string(chol_info) +
                   "); non-finite Jacobian?");

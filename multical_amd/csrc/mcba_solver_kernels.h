@@ -8,18 +8,6 @@
 namespace mcba {
 
 // ---------------------------------------------------------------------------------------------------------------
-// deterministic sum of per-block partials
-// ---------------------------------------------------------------------------------------------------------------
-// out[0] = sum(partial[0..n))  (single block, fixed order)
-__global__ void k_sum(const double* __restrict__ partial, int n, double* __restrict__ out) {
-  __shared__ double scratch[16];
-  double acc = 0.0;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) acc += partial[i];
-  const double tot = block_reduce<false>(acc, scratch);
-  if (threadIdx.x == 0) out[0] = tot;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
 // k_prep: x -> device tables (replaces the object re-construction of Calibration.with_param_vec,
 //         optimization/calibration.py:164-171 -> pose_set.py:55-57, camera.py:157-171, board/charuco.py:116-117)
 // ---------------------------------------------------------------------------------------------------------------
@@ -343,7 +331,7 @@ __global__ __launch_bounds__(256) void k_vec_scale(Dims d, const double* __restr
 //     + sum_{i,j} a_s[i] H_ss[i][j] a_s[j],            a = D u.
 // The trust-region driver only needs this for u = g_h (Cauchy curvature): the forms involving the Gauss-Newton step
 // follow from (D H D + reg I) gn = g_h without touching H again (mcba_solve).  partial[blockIdx.x] = block sum
-// (added up in index order by the host of a single-GPU solve, by k_sum + all-reduce on a sharded one).
+// (folded by k_tr_reg; a frame-sharded handle all-reduces the partial array element-wise first).
 __global__ __launch_bounds__(256) void k_q00(Dims d, const double* __restrict__ Hss, const double* __restrict__ Hfs,
                                              const double* __restrict__ Hff, const double* __restrict__ dsc,
                                              const double* __restrict__ u, double* __restrict__ partial) {
@@ -371,17 +359,9 @@ __global__ __launch_bounds__(256) void k_q00(Dims d, const double* __restrict__ 
   if (threadIdx.x == 0) partial[blockIdx.x] = r;
 }
 
-// out[0] = sum of the k_q00 partials (sharded handles all-reduce this one)
-__global__ void k_q00_final(const double* __restrict__ partial, int nblk, double* __restrict__ out) {
-  __shared__ double scratch[16];
-  double q = 0.0;
-  for (int blk = threadIdx.x; blk < nblk; blk += blockDim.x) q += partial[blk];
-  const double r = block_reduce<false>(q, scratch);
-  if (threadIdx.x == 0) out[0] = r;
-}
-
 // out[0..2] = {u0.u0, u0.u1, u1.u1} over the full (replicated) vectors
-__global__ void k_dots3(int n, const double* __restrict__ u0, const double* __restrict__ u1, double* __restrict__ out) {
+__global__ void k_dots3(int n, const double* __restrict__ u0, const double* __restrict__ u1, double* __restrict__ out,
+                        const int* __restrict__ info = nullptr) {
   __shared__ double scratch[16];
   double dt[3] = {0, 0, 0};
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
@@ -394,6 +374,7 @@ __global__ void k_dots3(int n, const double* __restrict__ u0, const double* __re
     const double ds = block_reduce<false>(dt[k], scratch);
     if (threadIdx.x == 0) out[k] = ds;
   }
+  if (info != nullptr && threadIdx.x == 0) out[3] = (double)info[0];   // pivot report of the reduced Cholesky
 }
 
 // Schur step 1a, one THREAD per frame:  A_ff = D_f H_ff D_f + reg I = L L^T entirely in registers (DF = 6 or 12: 21 / 78
@@ -562,9 +543,8 @@ __global__ void k_schur_reduce(Dims d, const double* __restrict__ Hss, const dou
       for (; sp < ksplit; ++sp) s0 += pp[(size_t)sp * st];
       sum = (s0 + s1) + (s2 + s3);
     }
-    // (single-GPU driver: the damping lives on the device and is added here; otherwise the Cholesky kernel adds it
-    //  after the cross-rank reduction)
-    if (i < ns) buf[e] = dsc[d.shared_to_x(i)] * Hss[e] * dsc[d.shared_to_x(j)] - sum + ((tr != nullptr && i == j) ? tr[TR_REG] : 0.0);
+    // (the damping lives on the device, tr[TR_REG]; only the root rank adds it: the buffer is summed over the ranks next)
+    if (i < ns) buf[e] = dsc[d.shared_to_x(i)] * Hss[e] * dsc[d.shared_to_x(j)] - sum + ((tr != nullptr && i == j) ? g_weight * tr[TR_REG] : 0.0);
     else buf[e] = g_weight * gh[d.shared_to_x(j)] - sum;
   }
 }
