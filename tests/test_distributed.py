@@ -115,8 +115,8 @@ def test_sharded_solve_two_ranks_one_gpu(name, tmp_path):
   assert int(sh["nfev"]) == res.nfev and int(sh["status"]) == res.status
   assert float(sh["final_cost"]) == pytest.approx(res.cost, rel=1e-10)
   assert abs(float(sh["rms"]) - float(np.sqrt(np.mean(e[v] ** 2)))) < 1e-9
-  # (the sharded handle runs the scalar trust-region algebra on the host, the single handle in device kernels: libm and
-  #  ocml differ in the last bits of sqrt / hypot / sin / cos, which weakly determined gauge directions amplify)
+  # (two shards sum H and the partial arrays in a different order than one handle; weakly determined gauge directions
+  #  amplify the last-bit differences)
   assert np.abs(sh["x"] - res.x).max() < 1e-7
 
 
@@ -124,7 +124,7 @@ def test_sharded_solve_two_ranks_one_gpu(name, tmp_path):
 def test_native_rccl_single_rank_communicator():
   """The library's own RCCL path (mcba_rccl_*): a one-rank communicator on this GPU; every reduction of the sharded
   driver then goes through ncclAllReduce on the handle's stream and the solve must equal the plain single-GPU solve
-  (host trust-region algebra vs device kernels: same tolerance as the two-rank test)."""
+  (same tolerance as the two-rank test)."""
   from multical_amd.backend import Handle
   g, rig = load_golden("tiny_rolling")
   c = mirror(rig)
