@@ -9,10 +9,12 @@ struct double2 { double x, y; };   // host-only builds (tests/hostmath); hipcc p
 
 namespace mcba {
 
-// persistent k_linearize: 2048 single-wave workgroups are resident (8 per CU x 256 CUs); launching 1.5x that many lets
-// the dispatcher hand the last third out as slots free up, which evens out the per-view cost spread (measured at the
-// north-star rig: 2048 -> 95.7 us, 2560..4096 -> 81.5..82 us, 1467 (exactly 3 views each) -> 112 us).
-constexpr int LIN_GRID_MAX = 3072;
+// persistent k_linearize: 2048 single-wave workgroups are resident (8 per CU x 256 CUs); launching twice that many lets
+// the dispatcher hand the rest out as slots free up.  Together with the largest-first order of the active-view list
+// (k_active_views) this is longest-processing-time-first list scheduling: the short views fill the tail of the launch.
+// Measured at the north-star rig (4401 active views): ascending order 2048 -> 95.7 us, 3072 -> 81.5 us; largest-first
+// 2048 -> 74.9, 3072 -> 72.4, 4096 -> 65.7, 4401 (one view each) -> 67.6, exactly 3 views each (1467, ascending) -> 112 us.
+constexpr int LIN_GRID_MAX = 4096;
 constexpr int MOTION_STATIC = 0, MOTION_ROLLING = 1, MOTION_HAND_EYE = 2;
 
 // Problem shape + index maps, passed BY VALUE to every kernel (fits the kernarg segment).

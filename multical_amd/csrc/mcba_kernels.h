@@ -421,7 +421,7 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
   const int lane = threadIdx.x;
   // (a dynamic hand-out of the views through an atomic counter was measured slower at every size: static stride it is)
   const int n_active = t.active_views[0];
-  (void)epoch;
+  (void)epoch;   // (de-phasing the workgroups with a start-up delay per blockIdx & 3 was measured: only slower)
   for (int vi = blockIdx.x; vi < n_active; vi += gridDim.x) {
   const int v = t.active_views[1 + vi];
   const int b = v % d.B, c = (v / d.B) % d.C, fl = v / (d.B * d.C), f = d.f0 + fl;

@@ -1563,29 +1563,36 @@ __global__ void k_reject(Dims d, const double* __restrict__ err, const uint8_t* 
   if (threadIdx.x == 0) view_count[v] = (int32_t)tot;
 }
 
-// compact list of the non-empty views: out[0] = count, out[1..] = view indices in ascending order (single workgroup)
+// compact list of the non-empty views: out[0] = count, out[1..] = view indices, LARGEST views first (by the number of
+// 64-observation chunks; ascending index within a class, so the list is deterministic).  The persistent kernels hand
+// the list out front to back: the long views start first and the short ones fill the tail of the launch (longest-
+// processing-time-first list scheduling).  Single workgroup; runs only when the inlier set changes.
 __global__ void k_active_views(int nviews, const int32_t* __restrict__ view_count, int32_t* __restrict__ out) {
   __shared__ int wave_tot[16];
   __shared__ int base;
   if (threadIdx.x == 0) base = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  for (int v0 = 0; v0 < nviews; v0 += blockDim.x) {
-    const int v = v0 + threadIdx.x;
-    const bool on = v < nviews && view_count[v] != 0;
-    const unsigned long long m = __ballot(on);
-    if (lane == 0) wave_tot[wave] = __popcll(m);
-    __syncthreads();
-    int off = base;
-    for (int w = 0; w < wave; ++w) off += wave_tot[w];
-    if (on) out[1 + off + __popcll(m & ((1ull << lane) - 1ull))] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      int tot = 0;
-      for (int w = 0; w < nw; ++w) tot += wave_tot[w];
-      base += tot;
+  constexpr int NCLASS = LIN_MAX_POINTS / 64;
+  for (int cls = NCLASS; cls >= 1; --cls) {
+    for (int v0 = 0; v0 < nviews; v0 += blockDim.x) {
+      const int v = v0 + threadIdx.x;
+      const int cnt = v < nviews ? view_count[v] : 0;
+      const bool on = cnt != 0 && min((cnt + 63) / 64, NCLASS) == cls;
+      const unsigned long long m = __ballot(on);
+      if (lane == 0) wave_tot[wave] = __popcll(m);
+      __syncthreads();
+      int off = base;
+      for (int w = 0; w < wave; ++w) off += wave_tot[w];
+      if (on) out[1 + off + __popcll(m & ((1ull << lane) - 1ull))] = v;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int w = 0; w < nw; ++w) tot += wave_tot[w];
+        base += tot;
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
   if (threadIdx.x == 0) out[0] = base;
 }

@@ -14,7 +14,7 @@ with Handle(c) as h:
     print("lifetime mean", act[:, 7].mean())
     # clock rate of s_memtime: span vs measured time
     print("linearize ms", h.time_linearize(x0, 20))
-    for g in (1024, 1280, 1467, 1536, 1792, 2048, 2201, 2560, 3072, 4096, 4401):
+    for g in (2048, 3072, 4096, 4401, 6000):
         h.set_lin_grid(g); h.time_linearize(x0, 3)
         print("grid", g, "linearize ms", h.time_linearize(x0, 20))
     h.set_lin_grid(0)
