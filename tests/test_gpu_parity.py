@@ -216,6 +216,41 @@ def test_full_size_properties_cfg2():
     assert np.abs(g2 / si).max() < 1e-3 * np.sqrt(2 * res.cost)
 
 
+@pytest.mark.parametrize("name", ["cfg3", "cfg4", "cfg5"])
+def test_full_size_properties(name):
+  """BASELINE configs[2..4] at full size (rolling shutter 8x500x2, 16x1000x5, fisheye 6x400x5): size-independent
+  properties of the HIP path plus the oracle on the first frames of the same rig (the oracle needs minutes to hours for
+  the whole rig)."""
+  from util import sub_rig
+  rig = synthetic.make_rig(name)
+  c = mirror(rig)
+  x0 = c.param_vec
+  with Handle(c) as h:
+    r = h.residuals(x0)
+    cost, grad, diag = h.normal_equations(x0)
+    assert cost == pytest.approx(0.5 * r @ r, rel=1e-12)                       # fused pass == residual pass
+    J = h.jacobian(x0)
+    assert np.abs(J.T @ r - grad).max() <= 1e-10 * np.abs(grad).max()          # J^T f
+    assert np.abs(np.asarray(J.multiply(J).sum(axis=0)).ravel() - diag).max() <= 1e-10 * diag.max()
+    err, valid = h.reprojection_error(x0)
+    # oracle on the first frames: same reprojection errors, slot by slot (bit-identical indexing, <= 1e-9 px)
+    K = 4
+    oc = restate.from_rig(sub_rig(rig, K))
+    eo, vo = oc.reprojection_error_table()
+    assert np.array_equal(valid[:, :K].astype(bool), vo)
+    assert np.abs(err[:, :K][vo] - eo[vo]).max() < 1e-9
+    res = h.solve(x0)
+    assert res.status in (1, 2, 3, 4) and res.cost < 0.02 * res.initial_cost
+    # gradient vanishes at the solution (first-order optimality in the scaled norm)
+    _, g2, d2 = h.normal_equations(res.x)
+    si = np.sqrt(d2); si[si == 0] = 1
+    assert np.abs(g2 / si).max() < 1e-3 * np.sqrt(2 * res.cost)
+  # the whole Workspace.calibrate sequence (outlier loop on the device): the inlier RMS ends at the noise level
+  from multical_amd import Workspace
+  out = Workspace(c).calibrate(cameras=rig.optimize["cameras"], camera_poses=rig.optimize["camera_poses"])
+  assert 0.27 < out.error_statistics(True).rms < 0.30                          # synthetic noise: 0.2 px per axis
+
+
 def test_non_finite_start_raises_value_error():
   rig = synthetic.make_rig("tiny")
   c = mirror(rig)

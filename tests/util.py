@@ -44,3 +44,18 @@ def gpu_available():
     return torch.cuda.is_available()
   except Exception:
     return False
+
+
+def sub_rig(rig, frames):
+  """The first `frames` frames of a synthetic rig as a rig of its own (same cameras, boards, initial guess): lets the
+  CPU oracle check a slice of a full-size BASELINE configuration in seconds."""
+  from multical_amd import synthetic
+  arrs = dict(synthetic.rig_to_arrays(rig))
+  for k in ("points", "valid"):
+    arrs[k] = arrs[k][:, :frames]
+  arrs["frame_valid"] = arrs["frame_valid"][:frames]
+  for prefix in ("init_", "truth_"):
+    for k in ("rig", "rig_end", "he_base_wrt_gripper"):
+      if prefix + k in arrs:
+        arrs[prefix + k] = arrs[prefix + k][:frames]
+  return synthetic.rig_from_arrays(arrs)
