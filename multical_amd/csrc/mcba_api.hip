@@ -878,7 +878,7 @@ int32_t mcba_normal_equations(mcba_handle h, const double* x, const mcba_options
   REQUIRE(h && x, "null argument");
   set_loss(h, opt);
   upload_x(h, x, h->x.p);
-  eval_tables(h, h->x.p);
+  eval_pose_tables(h, h->x.p);   // (k_tmat, the first kernel of the linearisation, writes the view table)
   launch_linearize(h);
   launch_assemble(h);
   const Dims& d = h->d;
@@ -934,7 +934,7 @@ int32_t mcba_debug_linearize_profile(mcba_handle h, const double* x, long long* 
   h->dbg.alloc(n, true);
   h->t.dbg = h->dbg.p;
   upload_x(h, x, h->x.p);
-  eval_tables(h, h->x.p);
+  eval_pose_tables(h, h->x.p);   // (k_tmat, the first kernel of the linearisation, writes the view table)
   launch_linearize(h);
   h->t.dbg = nullptr;
   HIP_OK(hipMemcpyAsync(out, h->dbg.p, n * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
@@ -1013,7 +1013,7 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
   double* S = h->h_scal;   // host copy of the scalar block scal[0 .. TR_NSLOTS)
 
   upload_x(h, x_inout, h->x.p);
-  eval_tables(h, h->x.p);
+  eval_pose_tables(h, h->x.p);   // (k_tmat, the first kernel of every linearisation, writes the view table)
   float lin_ms_total = 0.f;
   auto timed_linearize = [&]() {
     HIP_OK(hipEventRecord(h->ev0, h->stream));
@@ -1274,7 +1274,7 @@ int32_t mcba_time_linearize(mcba_handle h, const double* x, const mcba_options* 
   REQUIRE(h && x && avg_ms && repeats > 0, "bad argument");
   set_loss(h, opt);
   upload_x(h, x, h->x.p);
-  eval_tables(h, h->x.p);
+  eval_pose_tables(h, h->x.p);   // (k_tmat, the first kernel of the linearisation, writes the view table)
   launch_linearize(h);   // warm-up
   sync(h);
   HIP_OK(hipEventRecord(h->ev0, h->stream));
