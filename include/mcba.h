@@ -224,6 +224,8 @@ int32_t mcba_time_residuals(mcba_handle h, const double* x, int32_t repeats, dou
 int32_t mcba_set_mfma(mcba_handle h, int32_t on);
 /* number of persistent k_linearize workgroups; 0 = automatic (profiling aid)                                        */
 int32_t mcba_debug_set_lin_grid(mcba_handle h, int32_t grid);
+/* FP64 VALU vs FP64 MFMA pipe-sharing probe: ms_out[3] = all-FMA, all-MFMA, half / half        */
+int32_t mcba_debug_pipe_probe(int32_t iters, double* ms_out);
 /* regularised Gauss-Newton direction (H_h + reg I)^-1 g_h in the column-scaled space, computed by the Schur /
  * Cholesky kernels after a preceding mcba_normal_equations at the same x; g_h and scale_inv may be NULL.           */
 int32_t mcba_debug_gn_step(mcba_handle h, double reg, double* gn_h, double* g_h, double* scale_inv);

@@ -993,6 +993,30 @@ int32_t mcba_debug_mfma_probe(const double* V, double* out) {
   API_END
 }
 
+// debug: FP64 VALU / FP64 MFMA pipe-sharing probe (k_pipe_probe); ms_out[3] = milliseconds of modes 0, 1, 2
+int32_t mcba_debug_pipe_probe(int32_t iters, double* ms_out) {
+  API_BEGIN
+  REQUIRE(ms_out && iters > 0, "bad argument");
+  DevBuf<double> sink;
+  sink.alloc(8);
+  hipEvent_t e0, e1;
+  HIP_OK(hipEventCreate(&e0));
+  HIP_OK(hipEventCreate(&e1));
+  for (int mode = 0; mode < 3; ++mode) {
+    hipLaunchKernelGGL(k_pipe_probe, dim3(256), dim3(512), 0, 0, mode, 16, sink.p);   // warm-up
+    HIP_OK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(k_pipe_probe, dim3(256), dim3(512), 0, 0, mode, iters, sink.p);
+    HIP_OK(hipEventRecord(e1, 0));
+    HIP_OK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+    ms_out[mode] = ms;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  API_END
+}
+
 int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba_result* result) {
   API_BEGIN
   REQUIRE(h && x_inout && opt, "null argument");

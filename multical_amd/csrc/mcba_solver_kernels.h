@@ -1616,4 +1616,42 @@ __global__ void k_mfma_probe(const double* __restrict__ V /*[4][32]*/, double* _
   for (int r = 0; r < 4; ++r) out[(rsub + 4 * r) * 16 + csub] = acc[r];
 }
 
+
+// Pipe probe: does a wave's FP64 VALU work overlap with another wave's FP64 MFMAs on the same SIMD?
+// One workgroup of 512 threads per CU = two waves per SIMD.  mode 0: every wave runs `iters` rounds of 16 independent FP64
+// FMAs (64 instructions of 4 issue cycles each = 256 pipe cycles per round... x 4 unrolled); mode 1: every wave runs `iters`
+// rounds of 4 independent MFMA f64 16x16x4 (4 x 64 cycles); mode 2: waves 0-3 (one per SIMD) do the FMA loop, waves 4-7 the
+// MFMA loop.  If the two kinds of work shared nothing, mode 2 would take as long as one wave alone per SIMD (half of
+// modes 0 / 1); if FP64 MFMA and FP64 VALU share the pipe, mode 2 takes the sum.
+__global__ __launch_bounds__(512) void k_pipe_probe(int mode, int iters, double* __restrict__ sink) {
+  const int wave = threadIdx.x >> 6;
+  const bool do_mfma = mode == 1 || (mode == 2 && wave >= 4);
+  double acc = 0.0;
+  if (do_mfma) {
+    double4_t a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
+    const double x = 1.0 + threadIdx.x * 1e-9, y = 1.0 - threadIdx.x * 1e-9;
+    for (int it = 0; it < iters; ++it) {
+      a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, x, a1, 0, 0, 0);
+      a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, a2, 0, 0, 0);
+      a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, y, a3, 0, 0, 0);
+    }
+    acc = a0[0] + a1[1] + a2[2] + a3[3];
+  } else {
+    double f[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) f[k] = 1.0 + k * 1e-3 + threadIdx.x * 1e-9;
+    const double m = 1.0 - 1e-12, c = 1e-13;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int rep = 0; rep < 4; ++rep)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) f[k] = f[k] * m + c;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc += f[k];
+  }
+  if (acc == 12345.678) sink[0] = acc;   // keep the work alive
+}
+
 }  // namespace mcba
