@@ -80,6 +80,7 @@ struct DevBuf {
   }
 };
 
+constexpr int SEL_NEXT_BLOCKS = 256;    // workgroups (= per-block partials) of k_selm_next
 constexpr int COST_BLOCKS_MAX = 3072;   // persistent single-wave workgroups of k_cost (see LIN_GRID_MAX)
 // Scalars and per-block partial sums fetched by the trust-region driver: ONE contiguous device-to-host copy per
 // iteration.  Partials are folded in a fixed order by the one-wave driver kernels or by the host, which saves the tiny
@@ -137,7 +138,7 @@ struct mcba_handle_s {
   DevBuf<long long> dbg;
   DevBuf<double> err_fm, sel_f64;
   DevBuf<unsigned int> sel_hist;
-  DevBuf<unsigned long long> sel_state;   // SelState (2 words) + k_sel_next output (2 words)
+  DevBuf<unsigned long long> sel_state;   // SelState x SEL_MAX | ranks | per-block (count, next) of k_selm_next
   bool obs_index_dirty = false;
 
   // linearisation
@@ -489,9 +490,9 @@ void compute_errors(mcba_handle_s* h, const double* x) {
   const Dims& d = h->d;
   if (h->err_fm.n < (size_t)std::max(d.slots(), 1)) h->err_fm.alloc((size_t)std::max(d.slots(), 1));
   if (!h->sel_hist.p) {
-    h->sel_hist.alloc(2048);
-    h->sel_state.alloc(8);
-    h->sel_f64.alloc(2048);
+    h->sel_hist.alloc((size_t)SEL_MAX * 2048);
+    h->sel_state.alloc(3 * SEL_MAX + (size_t)SEL_NEXT_BLOCKS * SEL_MAX * 2);   // SelState | ranks | per-block (count, next)
+    h->sel_f64.alloc((size_t)SEL_MAX * 2048);
   }
   upload_x(h, x, h->x.p);
   eval_tables(h, h->x.p);
@@ -500,49 +501,62 @@ void compute_errors(mcba_handle_s* h, const double* x) {
 
 int sel_grid(const Dims& d) { return std::max(1, std::min(1024, (d.slots() + 255) / 256)); }
 
-void reduce_hist(mcba_handle_s* h) {
+void reduce_hist(mcba_handle_s* h, int nh = 1) {
   if (!h->allreduce) return;
-  hipLaunchKernelGGL(k_u32_to_f64, dim3(8), dim3(256), 0, h->stream, h->sel_hist.p, h->sel_f64.p, 2048);
-  call_allreduce(h, h->sel_f64.p, 2048, 0);
-  hipLaunchKernelGGL(k_f64_to_u32, dim3(8), dim3(256), 0, h->stream, h->sel_f64.p, h->sel_hist.p, 2048);
+  hipLaunchKernelGGL(k_u32_to_f64, dim3(8 * nh), dim3(256), 0, h->stream, h->sel_hist.p, h->sel_f64.p, 2048 * nh);
+  call_allreduce(h, h->sel_f64.p, (size_t)2048 * nh, 0);
+  hipLaunchKernelGGL(k_f64_to_u32, dim3(8 * nh), dim3(256), 0, h->stream, h->sel_f64.p, h->sel_hist.p, 2048 * nh);
 }
 
-// exact k-th smallest (0-based, over all ranks of a sharded problem) of the masked errors; also the (k+1)-th
-void select_rank(mcba_handle_s* h, const uint8_t* m2, long long rank, double* v_k, double* v_k1) {
+// exact k-th smallest (0-based, over all ranks of a sharded problem) of the masked errors, and the (k+1)-th, for
+// several order statistics at once (nsel <= SEL_MAX): the same six passes over the errors serve all of them
+void select_ranks_multi(mcba_handle_s* h, const uint8_t* m2, int nsel, const long long* ranks, double* v_k, double* v_k1) {
   const Dims& d = h->d;
   SelState* st = reinterpret_cast<SelState*>(h->sel_state.p);
+  long long* dranks = reinterpret_cast<long long*>(h->sel_state.p + 2 * SEL_MAX);
+  unsigned long long* dout = h->sel_state.p + 3 * SEL_MAX;
   const int n = d.slots(), grid = sel_grid(d);
-  hipLaunchKernelGGL(k_sel_init, dim3(1), dim3(256), 0, h->stream, st, rank, h->sel_hist.p);
+  HIP_OK(hipMemcpyAsync(dranks, ranks, nsel * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_selm_init, dim3(1), dim3(256), 0, h->stream, st, nsel, dranks, h->sel_hist.p);
   const int shifts[6] = {53, 42, 31, 20, 9, 0};
   const int bits[6] = {11, 11, 11, 11, 11, 9};
   for (int p = 0; p < 6; ++p) {
-    hipLaunchKernelGGL(k_sel_hist, dim3(grid), dim3(256), 0, h->stream, h->err_fm.p, h->evalid.p, m2, n, st, shifts[p], bits[p],
-                       p == 0 ? 1 : 0, h->sel_hist.p);
-    reduce_hist(h);
-    hipLaunchKernelGGL(k_sel_pick, dim3(1), dim3(256), 0, h->stream, st, h->sel_hist.p, shifts[p], bits[p]);
+    hipLaunchKernelGGL(k_selm_hist, dim3(grid), dim3(256), 0, h->stream, h->err_fm.p, h->evalid.p, m2, n, st, nsel, shifts[p],
+                       bits[p], p == 0 ? 1 : 0, h->sel_hist.p);
+    reduce_hist(h, p == 0 ? 1 : nsel);
+    hipLaunchKernelGGL(k_selm_pick, dim3(1), dim3(64 * SEL_MAX), 0, h->stream, st, nsel, h->sel_hist.p, shifts[p], bits[p],
+                       p == 0 ? 1 : 0);
   }
-  unsigned long long init[2] = {0ull, 0x7FF0000000000000ull};
-  HIP_OK(hipMemcpyAsync(h->sel_state.p + 2, init, sizeof(init), hipMemcpyHostToDevice, h->stream));
-  hipLaunchKernelGGL(k_sel_next, dim3(grid), dim3(256), 0, h->stream, h->err_fm.p, h->evalid.p, m2, n, st, h->sel_state.p + 2);
-  unsigned long long host[4];
-  HIP_OK(hipMemcpyAsync(host, h->sel_state.p, sizeof(host), hipMemcpyDeviceToHost, h->stream));
+  hipLaunchKernelGGL(k_selm_next, dim3(SEL_NEXT_BLOCKS), dim3(256), 0, h->stream, h->err_fm.p, h->evalid.p, m2, n, st, nsel,
+                     dout);
+  std::vector<unsigned long long> host(3 * SEL_MAX + (size_t)SEL_NEXT_BLOCKS * SEL_MAX * 2);
+  HIP_OK(hipMemcpyAsync(host.data(), h->sel_state.p, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                        h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
-  double vk, next;
-  memcpy(&vk, &host[0], 8);
-  memcpy(&next, &host[3], 8);
-  double cnt_le = (double)host[2];
-  if (h->allreduce) {   // combine (count, min) across ranks: sum and -max(-x)
-    double buf[2] = {cnt_le, -next};
-    HIP_OK(hipMemcpyAsync(h->sel_f64.p, buf, sizeof(buf), hipMemcpyHostToDevice, h->stream));
-    call_allreduce(h, h->sel_f64.p, 1, 0);
-    call_allreduce(h, h->sel_f64.p + 1, 1, 1);
-    HIP_OK(hipMemcpyAsync(buf, h->sel_f64.p, sizeof(buf), hipMemcpyDeviceToHost, h->stream));
-    HIP_OK(hipStreamSynchronize(h->stream));
-    cnt_le = buf[0];
-    next = -buf[1];
+  for (int r = 0; r < nsel; ++r) {
+    double vk, next;
+    memcpy(&vk, &host[2 * r], 8);                       // SelState r: prefix = bit pattern of the order statistic
+    unsigned long long cnt = 0, mn = 0x7FF0000000000000ull;
+    for (int blk = 0; blk < SEL_NEXT_BLOCKS; ++blk) {
+      const unsigned long long* pp = &host[3 * SEL_MAX + ((size_t)blk * SEL_MAX + r) * 2];
+      cnt += pp[0];
+      mn = pp[1] < mn ? pp[1] : mn;
+    }
+    memcpy(&next, &mn, 8);
+    double cnt_le = (double)cnt;
+    if (h->allreduce) {   // combine (count, min) across ranks: sum and -max(-x)
+      double buf[2] = {cnt_le, -next};
+      HIP_OK(hipMemcpyAsync(h->sel_f64.p, buf, sizeof(buf), hipMemcpyHostToDevice, h->stream));
+      call_allreduce(h, h->sel_f64.p, 1, 0);
+      call_allreduce(h, h->sel_f64.p + 1, 1, 1);
+      HIP_OK(hipMemcpyAsync(buf, h->sel_f64.p, sizeof(buf), hipMemcpyDeviceToHost, h->stream));
+      HIP_OK(hipStreamSynchronize(h->stream));
+      cnt_le = buf[0];
+      next = -buf[1];
+    }
+    v_k[r] = vk;
+    v_k1[r] = (cnt_le > (double)(ranks[r] + 1)) ? vk : next;
   }
-  *v_k = vk;
-  *v_k1 = (cnt_le > (double)(rank + 1)) ? vk : next;
 }
 
 double now_seconds() {
@@ -1227,19 +1241,26 @@ int32_t mcba_error_stats(mcba_handle h, const double* x, int32_t inliers_only, i
   *sum_sq = h->h_scal[0];
   const int64_t n = (int64_t)h->h_scal[1];
   *n_out = n;
-  for (int i = 0; i < n_ranks; i += 2) {
-    // consecutive ranks (floor / ceil of a virtual index) share one selection
+  // consecutive ranks (floor / ceil of a virtual index) share one selection; all selections of a batch share the six
+  // passes over the errors
+  std::vector<long long> sel;          // distinct selections
+  std::vector<int> which(n_ranks, -1), use_next(n_ranks, 0);
+  for (int i = 0; i < n_ranks; ++i) {
     REQUIRE(n > 0 && ranks[i] >= 0 && ranks[i] < n, "order-statistic rank out of range");
-    double vk, vk1;
-    select_rank(h, m2, ranks[i], &vk, &vk1);
-    values[i] = vk;
-    if (i + 1 < n_ranks) {
-      REQUIRE(ranks[i + 1] >= 0 && ranks[i + 1] < n, "order-statistic rank out of range");
-      if (ranks[i + 1] == ranks[i]) values[i + 1] = vk;
-      else if (ranks[i + 1] == ranks[i] + 1) values[i + 1] = vk1;
-      else { double a, b; select_rank(h, m2, ranks[i + 1], &a, &b); values[i + 1] = a; }
+    int found = -1;
+    for (size_t k = 0; k < sel.size(); ++k) {
+      if (sel[k] == ranks[i]) { found = (int)k; use_next[i] = 0; break; }
+      if (sel[k] + 1 == ranks[i]) { found = (int)k; use_next[i] = 1; break; }
     }
+    if (found < 0) { sel.push_back(ranks[i]); found = (int)sel.size() - 1; }
+    which[i] = found;
   }
+  std::vector<double> vk(sel.size()), vk1(sel.size());
+  for (size_t k0 = 0; k0 < sel.size(); k0 += SEL_MAX) {
+    const int nsel = (int)std::min<size_t>(SEL_MAX, sel.size() - k0);
+    select_ranks_multi(h, m2, nsel, sel.data() + k0, vk.data() + k0, vk1.data() + k0);
+  }
+  for (int i = 0; i < n_ranks; ++i) values[i] = use_next[i] ? vk1[which[i]] : vk[which[i]];
   API_END
 }
 

@@ -1454,66 +1454,133 @@ struct SelState {
   long long rank;              // remaining rank inside the current prefix bucket
 };
 
-__global__ void k_sel_init(SelState* st, long long rank, unsigned int* hist) {
-  if (threadIdx.x == 0) { st->prefix = 0ull; st->rank = rank; }
-  for (int i = threadIdx.x; i < 2048; i += blockDim.x) hist[i] = 0u;
+// ---- several order statistics in the same six data passes (report: five quantiles = five selections) ----------------
+constexpr int SEL_MAX = 6;   // selections per batch: SEL_MAX x 2048 privatised bins = 48 KB of LDS
+
+__global__ void k_selm_init(SelState* st, int nsel, const long long* __restrict__ ranks, unsigned int* hist) {
+  if (threadIdx.x < nsel) { st[threadIdx.x].prefix = 0ull; st[threadIdx.x].rank = ranks[threadIdx.x]; }
+  for (int i = threadIdx.x; i < SEL_MAX * 2048; i += blockDim.x) hist[i] = 0u;
 }
 
-__global__ void k_sel_hist(const double* __restrict__ err, const uint8_t* __restrict__ m1, const uint8_t* __restrict__ m2,
-                           int n, const SelState* __restrict__ st, int shift, int bits, int first,
-                           unsigned int* __restrict__ hist) {
-  __shared__ unsigned int lh[2048];
-  for (int i = threadIdx.x; i < 2048; i += blockDim.x) lh[i] = 0u;
+// pass `first`: nothing is fixed yet, one histogram (hist[0]) serves every selection; later passes: selection r counts the
+// elements that share its prefix into hist[r]
+__global__ __launch_bounds__(256) void k_selm_hist(const double* __restrict__ err, const uint8_t* __restrict__ m1,
+                                                   const uint8_t* __restrict__ m2, int n, const SelState* __restrict__ st,
+                                                   int nsel, int shift, int bits, int first,
+                                                   unsigned int* __restrict__ hist) {
+  __shared__ unsigned int lh[SEL_MAX * 2048];
+  const int nh = first ? 1 : nsel;
+  for (int i = threadIdx.x; i < nh * 2048; i += blockDim.x) lh[i] = 0u;
   __syncthreads();
-  const unsigned long long prefix = st->prefix;
+  unsigned long long pre[SEL_MAX];
+#pragma unroll
+  for (int r = 0; r < SEL_MAX; ++r) pre[r] = r < nsel ? st[r].prefix >> (shift + bits) : ~0ull;
   const unsigned int mask = (1u << bits) - 1u;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     if (!m1[i] || (m2 != nullptr && !m2[i])) continue;
     const unsigned long long key = (unsigned long long)__double_as_longlong(err[i]);
-    if (!first && (key >> (shift + bits)) != (prefix >> (shift + bits))) continue;
-    atomicAdd(&lh[(unsigned int)(key >> shift) & mask], 1u);
+    const unsigned int digit = (unsigned int)(key >> shift) & mask;
+    if (first) {
+      atomicAdd(&lh[digit], 1u);
+    } else {
+      const unsigned long long top = key >> (shift + bits);
+#pragma unroll
+      for (int r = 0; r < SEL_MAX; ++r)
+        if (r < nsel && top == pre[r]) atomicAdd(&lh[r * 2048 + digit], 1u);
+    }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2048; i += blockDim.x)
+  for (int i = threadIdx.x; i < nh * 2048; i += blockDim.x)
     if (lh[i]) atomicAdd(&hist[i], lh[i]);
 }
 
-__global__ void k_sel_pick(SelState* st, unsigned int* hist, int shift, int bits) {
-  if (threadIdx.x == 0) {
-    long long rank = st->rank;
-    const int nb = 1 << bits;
-    int b = 0;
-    for (; b < nb - 1; ++b) {
-      const long long c = hist[b];
-      if (rank < c) break;
-      rank -= c;
+// one wavefront per selection: lane l owns bins [32 l, 32 l + 32); wave-level exclusive scan of the lane totals finds the
+// lane whose range holds the rank, that lane walks its 32 bins (a single thread walking 2048 bins in global memory with
+// an early exit cost 134 us per pass)
+__global__ __launch_bounds__(64 * SEL_MAX) void k_selm_pick(SelState* st, int nsel, unsigned int* hist, int shift, int bits,
+                                                            int first) {
+  __shared__ unsigned int lh[SEL_MAX * 2048];
+  const int nh = first ? 1 : nsel;
+  for (int i = threadIdx.x; i < nh * 2048; i += blockDim.x) lh[i] = hist[i];
+  __syncthreads();
+  const int r = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (r < nsel) {
+    const unsigned int* hr = lh + (first ? 0 : r * 2048);
+    const int nb = 1 << bits, per = 32;
+    long long tot = 0;
+    for (int k = 0; k < per; ++k) {
+      const int bin = lane * per + k;
+      tot += bin < nb ? hr[bin] : 0u;
     }
-    st->prefix |= ((unsigned long long)b) << shift;
-    st->rank = rank;
+    long long incl = tot;                                  // inclusive scan over the lanes
+    for (int off = 1; off < 64; off <<= 1) {
+      const long long o = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += o;
+    }
+    const long long excl = incl - tot, rank = st[r].rank;
+    // the owner: first lane whose inclusive count exceeds the rank (the last non-empty range if the rank is past the end)
+    const bool mine = rank >= excl && rank < incl;
+    const unsigned long long m = __ballot(mine);
+    const int owner = m ? __ffsll((long long)m) - 1 : min(63, (nb - 1) / per);
+    if (lane == owner) {
+      long long rem = rank - excl;
+      int bb = lane * per;
+      const int last = min(nb - 1, lane * per + per - 1);
+      for (; bb < last; ++bb) {
+        const long long c = hr[bb];
+        if (rem < c) break;
+        rem -= c;
+      }
+      st[r].prefix |= ((unsigned long long)bb) << shift;
+      st[r].rank = rem;
+    }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2048; i += blockDim.x) hist[i] = 0u;
+  for (int i = threadIdx.x; i < SEL_MAX * 2048; i += blockDim.x) hist[i] = 0u;
 }
 
-// out[0] = #elements <= v, out[1] = bit pattern of the smallest element > v (all ones if none)
-__global__ void k_sel_next(const double* __restrict__ err, const uint8_t* __restrict__ m1, const uint8_t* __restrict__ m2,
-                           int n, const SelState* __restrict__ st, unsigned long long* __restrict__ out) {
-  const unsigned long long v = st->prefix;
-  unsigned long long cnt = 0, mn = 0x7FF0000000000000ull;   // +inf
+// part[(blk * SEL_MAX + r) * 2 + {0, 1}] = {#elements <= v_r, bit pattern of the smallest element > v_r (+inf if none)}
+// of the block; folded by the host (atomics on 2 nsel addresses from 4096 waves serialise at ~75 ns each: 200 us)
+__global__ __launch_bounds__(256) void k_selm_next(const double* __restrict__ err, const uint8_t* __restrict__ m1,
+                                                   const uint8_t* __restrict__ m2, int n, const SelState* __restrict__ st,
+                                                   int nsel, unsigned long long* __restrict__ part) {
+  __shared__ unsigned long long red[4][2 * SEL_MAX];
+  unsigned long long v[SEL_MAX], cnt[SEL_MAX], mn[SEL_MAX];
+#pragma unroll
+  for (int r = 0; r < SEL_MAX; ++r) {
+    v[r] = r < nsel ? st[r].prefix : 0ull;
+    cnt[r] = 0;
+    mn[r] = 0x7FF0000000000000ull;   // +inf
+  }
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     if (!m1[i] || (m2 != nullptr && !m2[i])) continue;
     const unsigned long long key = (unsigned long long)__double_as_longlong(err[i]);
-    if (key <= v) ++cnt;
-    else if (key < mn) mn = key;
+#pragma unroll
+    for (int r = 0; r < SEL_MAX; ++r) {
+      if (key <= v[r]) ++cnt[r];
+      else if (key < mn[r]) mn[r] = key;
+    }
   }
-  for (int off = 32; off > 0; off >>= 1) {
-    cnt += __shfl_down(cnt, off, 64);
-    const unsigned long long o = __shfl_down(mn, off, 64);
-    mn = o < mn ? o : mn;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int r = 0; r < SEL_MAX; ++r) {
+    for (int off = 32; off > 0; off >>= 1) {
+      cnt[r] += __shfl_down(cnt[r], off, 64);
+      const unsigned long long o = __shfl_down(mn[r], off, 64);
+      mn[r] = o < mn[r] ? o : mn[r];
+    }
+    if (lane == 0) { red[wave][2 * r] = cnt[r]; red[wave][2 * r + 1] = mn[r]; }
   }
-  if ((threadIdx.x & 63) == 0) {
-    atomicAdd(&out[0], cnt);
-    atomicMin(&out[1], mn);
+  __syncthreads();
+  if (threadIdx.x < SEL_MAX) {
+    const int r = threadIdx.x;
+    unsigned long long c = 0, m = 0x7FF0000000000000ull;
+    for (int w = 0; w < 4; ++w) {
+      c += red[w][2 * r];
+      m = red[w][2 * r + 1] < m ? red[w][2 * r + 1] : m;
+    }
+    part[((size_t)blockIdx.x * SEL_MAX + r) * 2] = c;
+    part[((size_t)blockIdx.x * SEL_MAX + r) * 2 + 1] = m;
   }
 }
 
