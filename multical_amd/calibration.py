@@ -174,6 +174,17 @@ class Calibration(parameters.Parameters):
     d.update(k)
     return Calibration(**d)
 
+  def with_master(self, camera):
+    """calibration.py:99-104: re-gauge so that `camera` (name or index) sits at the origin."""
+    if isinstance(camera, str):
+      camera = self.camera_poses.names.index(camera)
+    return self.transform_views(self.camera_poses.poses[int(camera)])
+
+  def transform_views(self, t):
+    """calibration.py:107-112: cameras by t^-1, time poses by t -- the reprojections do not change."""
+    return self.copy(camera_poses=self.camera_poses.post_transform(np.linalg.inv(t)),
+                     motion=self.motion.pre_transform(t))
+
   # --- device evaluation ------------------------------------------------------------------------------------
   def _handle(self):
     return handle_cache.get(self)[0]

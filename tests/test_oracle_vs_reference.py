@@ -52,3 +52,26 @@ def test_mirror_lowering_accepts_reference_objects():
       assert np.array_equal(getattr(pa, k), getattr(pb, k)), k
     assert (pa.motion, pa.camera_model, pa.n_dist, pa.optimize, pa.n_params) == \
            (pb.motion, pb.camera_model, pb.n_dist, pb.optimize, pb.n_params)
+
+
+@pytest.mark.parametrize("name,master", [("cfg1", None), ("cfg1", "cam1"), ("tiny_rolling", "cam0"), ("tiny_handeye", None)])
+def test_export_json_equals_reference_export(name, master):
+  """SURVEY 8(f) result formats: multical_amd.export.export_json on the mirror Calibration == the reference's
+  export_json (io/export_calib.py:81-97) on the reference Calibration of the same rig, with and without a master
+  camera (with_master / transform_views, calibration.py:99-112).  Lists of floats are compared exactly."""
+  import json
+  from types import SimpleNamespace
+  from oracle import build_reference
+  from multical_amd import calibration as mcal, export as mexport
+  rig = synthetic.make_rig(name)
+  ref_calib, ref = build_reference.reference_calibration(rig)
+  from multical.io.export_calib import export_json as ref_export_json
+  from structs.struct import to_dicts
+  C = rig.valid.shape[0]
+  names = SimpleNamespace(camera=[f"cam{i}" for i in range(C)])
+  filenames = [[f"cam{c}/img{f}.png" for f in range(3)] for c in range(C)]
+  want = to_dicts(ref_export_json(ref_calib, names, filenames, master=master))
+  mine = mcal.from_rig(rig)
+  mine.camera_poses.names = list(names.camera)
+  got = mexport.export_json(mine, names, filenames, master=master)
+  assert json.loads(json.dumps(got)) == json.loads(json.dumps(want))
