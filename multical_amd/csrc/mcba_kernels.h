@@ -3,15 +3,17 @@
 // Evaluation pipeline at a parameter vector x (all FP64):
 //   k_prep        x -> pose table (R, t, left Jacobian per pose), camera table, board points
 //   k_views       pose table -> one board->camera chain matrix per view (camera, frame, board)
+//   k_tmat        pose table -> That (pose-block structure) and chain matrix of every non-empty view; opens a linearisation
 //   k_residual    one thread per table slot: residuals / projections / reprojection errors         (evaluate())
-//   k_cost        one thread per slot + block reduction: robust cost of a trial step
+//   k_cost        persistent wavefronts over the non-empty views (largest first): robust cost of a trial step
 //   k_jacobian    analytic Jacobian rows in the reference's sparsity pattern                        (parity / scipy-driven mode)
-//   k_linearize   ONE WAVEFRONT PER VIEW: per-point row pairs V = [E | K | r] are staged through LDS and
-//                 accumulated into S = V^T V with v_mfma_f64_16x16x4_f64 (the MFMA does the cross-lane
+//   k_linearize   persistent wavefronts, ONE WAVEFRONT PER VIEW at a time: per-point row pairs V = [E | K | r] are staged
+//                 through LDS and accumulated into S = V^T V with v_mfma_f64_16x16x4_f64 (the MFMA does the cross-lane
 //                 reduction); the view's local normal equations M = That^T S That are written as one record.
-//   k_assemble_*  deterministic reductions of the records into H_ss (dense, shared parameters),
-//                 H_fs / H_ff (per-frame blocks), g and diag(H)
-//   k_schur_* / k_chol_* / k_vec_*   the damped normal-equation solve of the trust-region driver
+//   k_assemble, k_shared_final   deterministic reductions of the records into H_ss (dense, shared parameters),
+//                 H_fs / H_ff (per-frame blocks), g and diag(H)                                    (mcba_solver_kernels.h)
+//   k_frame_factor / k_schur_* / k_chol_* / k_vec_* / k_tr_*   the damped normal-equation solve and the scalar algebra of
+//                 the trust-region driver                                                           (mcba_solver_kernels.h)
 //
 // There is no reference counterpart for the normal-equation kernels (the reference hands a finite-difference
 // sparse Jacobian to scipy's LSMR, optimization/calibration.py:209-210); their specification is J^T J, J^T f of the
