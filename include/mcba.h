@@ -203,6 +203,11 @@ int32_t mcba_project(mcba_handle h, const double* x, double* projected);
  * diag = diag(J^T J) [n_params].  Any output pointer may be NULL.  Sharded handles all-reduce through the hook. */
 int32_t mcba_normal_equations(mcba_handle h, const double* x, const mcba_options* opt,
                               double* cost, double* g, double* diag);
+/* The same evaluation at the x already resident on the device (from the last mcba_normal_equations / mcba_solve),
+ * enqueued on the handle's stream without host transfer or synchronisation -- the way the solver itself evaluates.
+ * Results stay in HBM; mcba_synchronize waits for the stream.                                                    */
+int32_t mcba_normal_equations_device(mcba_handle h, const mcba_options* opt);
+int32_t mcba_synchronize(mcba_handle h);
 /* dense J^T J [n_params x n_params] assembled from the block form (debug / parity tests; small problems only)  */
 int32_t mcba_dense_hessian(mcba_handle h, double* H);
 

@@ -71,6 +71,8 @@ SYMBOLS = [
   ("mcba_reject_outliers", C.c_int32, [H, c_double_p, C.c_double, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
   ("mcba_get_inliers", C.c_int32, [H, c_uint8_p]),
   ("mcba_normal_equations", C.c_int32, [H, c_double_p, C.POINTER(Options), c_double_p, c_double_p, c_double_p]),
+  ("mcba_normal_equations_device", C.c_int32, [H, C.POINTER(Options)]),
+  ("mcba_synchronize", C.c_int32, [H]),
   ("mcba_dense_hessian", C.c_int32, [H, c_double_p]),
   ("mcba_solve", C.c_int32, [H, c_double_p, C.POINTER(Options), C.POINTER(Result)]),
   ("mcba_time_linearize", C.c_int32, [H, c_double_p, C.POINTER(Options), C.c_int32, c_double_p]),

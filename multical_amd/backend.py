@@ -244,6 +244,15 @@ class Handle(object):
                                          _ptr(g, C.c_double), _ptr(diag, C.c_double)))
     return cost.value, g, diag
 
+  def normal_equations_device(self, loss='linear', f_scale=1.0):
+    """The same evaluation at the x already on the device, enqueued without host transfer or synchronisation (results
+    stay in HBM: read them with dense_hessian / debug_gn_step, or continue with a solve)."""
+    opt = make_options(loss=loss, f_scale=f_scale)
+    check(self.lib.mcba_normal_equations_device(self.h, C.byref(opt)))
+
+  def synchronize(self):
+    check(self.lib.mcba_synchronize(self.h))
+
   def dense_hessian(self):
     H = np.empty((self.n_params, self.n_params))
     check(self.lib.mcba_dense_hessian(self.h, _ptr(H, C.c_double)))

@@ -906,6 +906,26 @@ int32_t mcba_normal_equations(mcba_handle h, const double* x, const mcba_options
   API_END
 }
 
+// The same evaluation at the x that is already on the device (last mcba_normal_equations / mcba_solve), enqueued without
+// any host transfer or synchronisation: this is how the trust-region driver itself evaluates (x, tables and the normal
+// equations never leave HBM).  mcba_synchronize waits for the handle's stream.
+int32_t mcba_normal_equations_device(mcba_handle h, const mcba_options* opt) {
+  API_BEGIN
+  REQUIRE(h, "null handle");
+  set_loss(h, opt);
+  eval_pose_tables(h, h->x.p);
+  launch_linearize(h);
+  launch_assemble(h);
+  API_END
+}
+
+int32_t mcba_synchronize(mcba_handle h) {
+  API_BEGIN
+  REQUIRE(h, "null handle");
+  sync(h);
+  API_END
+}
+
 int32_t mcba_dense_hessian(mcba_handle h, double* H) {
   API_BEGIN
   REQUIRE(h && H, "null argument");

@@ -89,6 +89,23 @@ def test_fused_normal_equations(name, mfma):
   assert np.array_equal(H, H.T)
 
 
+def test_device_resident_evaluation_equals_host_boundary_evaluation():
+  """mcba_normal_equations_device (x, tables and results stay in HBM: the bench step and the solver's own evaluations)
+  reproduces mcba_normal_equations bit for bit."""
+  g, rig = load_golden("tiny_rolling")
+  with Handle(mirror(rig)) as h:
+    cost, grad, diag = h.normal_equations(g["x0"])
+    H0 = h.dense_hessian()
+    for _ in range(3):
+      h.normal_equations_device()
+    h.synchronize()
+    H1 = h.dense_hessian()
+    assert np.array_equal(H0, H1)
+    gn0, gh0, _ = h.debug_gn_step(1e-3)
+    cost2, grad2, diag2 = h.normal_equations(g["x0"])
+    assert cost2 == cost and np.array_equal(grad2, grad) and np.array_equal(diag2, diag)
+
+
 @pytest.mark.parametrize("loss,f_scale", [("soft_l1", 1.5), ("huber", 2.0), ("cauchy", 1.0), ("arctan", 3.0)])
 def test_robust_loss_normal_equations(loss, f_scale):
   from scipy.optimize._lsq.least_squares import construct_loss_function
