@@ -653,9 +653,13 @@ int32_t mcba_create(const mcba_problem* p, void* hip_stream, mcba_handle* out) {
 
   // ---- work buffers -----------------------------------------------------------------------------------------
   h->rec.alloc((size_t)d.views() * d.rec_stride);
-  // chunk sums of the shared part: about 1024 (pair, chunk) workgroups in k_assemble; k_shared_final reads C B nchunk
+  // chunk sums of the shared part: about 512 (pair, chunk) workgroups in k_assemble; k_shared_final reads C B nchunk
   // partial records per entry, so many pairs get fewer chunks
-  h->nchunk = std::max(1, std::min(std::min(64, (d.Fl + 7) / 8), std::max(4, 1024 / std::max(1, d.C * d.B))));
+  {
+    const char* e = getenv("MCBA_NCHUNK_TARGET");   // tuning knob: (pair, chunk) workgroups aimed at
+    const int target = e ? std::max(1, atoi(e)) : 512;   // measured at cfg3: 256 -> 114.4 us / step, 512 -> 113.1, 1024 -> 119.3
+    h->nchunk = std::max(1, std::min(std::min(64, (d.Fl + 7) / 8), std::max(4, target / std::max(1, d.C * d.B))));
+  }
   h->partial.alloc((size_t)d.C * d.B * h->nchunk * d.rec_stride);
   h->Hss.alloc((size_t)d.ns * d.ns);
   h->Hfs.alloc((size_t)d.Fl * d.DF * d.ns);
