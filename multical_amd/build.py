@@ -65,7 +65,7 @@ def build(force=False, verbose=True):
           sys.stderr.write(r.stderr)
   objs = [os.path.join(OUT, src.replace(".hip", ".o")) for src in SOURCES]
   if force or jobs or _newer(LIB, objs):
-    cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
+    cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl", "-lpthread"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
       sys.stderr.write(r.stdout + r.stderr)

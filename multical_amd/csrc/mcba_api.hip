@@ -74,7 +74,8 @@ struct DevBuf {
       HIP_OK(hipStreamSynchronize(nullptr));
     }
   }
-  void upload(const std::vector<T>& h) {
+  template <typename V>
+  void upload(const V& h) {   // std::vector<T> or SlotVec<T>
     alloc(h.size(), h.empty());
     if (!h.empty()) HIP_OK(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
   }
@@ -126,7 +127,7 @@ struct mcba_handle_s {
   int lin_grid = 0;          // 0 = automatic (see lin2), > 0 = forced number of persistent workgroups (debug)
 
   // host copies needed to rebuild the inlier tables
-  std::vector<uint8_t> h_valid_ref;    // Calibration.valid, [C,F,B,P] reference order
+  SlotVec<uint8_t> h_valid_ref;        // Calibration.valid, [C,F,B,P] reference order
   int64_t n_inliers = 0;
 
   // observation tables
@@ -613,16 +614,20 @@ int32_t mcba_create(const mcba_problem* p, void* hip_stream, mcba_handle* out) {
   if (const char* env = getenv("MCBA_NO_MFMA")) h->use_mfma = !(env[0] == '1');
   h->ops = pick_ops(p->camera_model, p->n_dist);
 
+  const bool timing = getenv("MCBA_TIMING") != nullptr;
+  const double tc0 = now_seconds();
   HostProblem hp;
   lower_problem(p, hp);
+  const double tc1 = now_seconds();
   h->d = hp.d;
   Dims& d = h->d;
-  h->h_valid_ref = hp.valid_ref;
+  h->h_valid_ref = std::move(hp.valid_ref);   // (kept for mcba_set_inliers(NULL); hp is not used for it again)
   h->obs.upload(hp.obs);
   h->evalid.upload(hp.evalid);
   h->inlier.upload(hp.inlier);
   h->obs_index.upload(hp.obs_index);
   h->view_count.upload(hp.view_count);
+  const double tc2 = now_seconds();
   h->active_views.alloc((size_t)d.views() + 1);
   h->work_counter.alloc(2);
   {
@@ -692,6 +697,9 @@ int32_t mcba_create(const mcba_problem* p, void* hip_stream, mcba_handle* out) {
   HIP_OK(hipEventCreate(&h->ev1));
   HIP_OK(hipEventCreateWithFlags(&h->ev_fetch, hipEventDisableTiming));
   HIP_OK(hipDeviceSynchronize());
+  if (timing)
+    fprintf(stderr, "[mcba_create] lowering %.2f ms, observation tables up %.2f ms, remaining buffers %.2f ms\n",
+            (tc1 - tc0) * 1e3, (tc2 - tc1) * 1e3, (now_seconds() - tc2) * 1e3);
   *out = h.release();
   API_END
 }

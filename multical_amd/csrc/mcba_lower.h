@@ -7,13 +7,38 @@
 //   residual ordering of `evaluate`                   calibration.py:204-206 (C-order over the inlier mask)
 //   parameter block order / enable flags              calibration.py:146-161
 #pragma once
+#include <algorithm>
 #include <stdexcept>
 #include <string>
+#include <memory>
+#include <thread>
+#include <utility>
 #include <vector>
 #include "../../include/mcba.h"
 #include "mcba_device.h"
 
 namespace mcba {
+
+// The lowering walks every table slot three times (masks, frame-major re-layout, inlier tables): 2.6 M slots at the
+// north-star rig, 6.5 M at BASELINE configs[3].  The outer loops are independent, so they are spread over a few host
+// threads (the handle is created once per Calibration; this is the PCIe-inclusive part of the boundary).
+template <typename F>
+inline void lower_parallel_for(int n, F&& fn) {
+  const unsigned hw = std::thread::hardware_concurrency();
+  const int nt = std::max(1, std::min({n, 16, (int)(hw ? hw : 1)}));
+  if (nt == 1) {
+    for (int i = 0; i < n; ++i) fn(i);
+    return;
+  }
+  std::vector<std::thread> pool;
+  pool.reserve(nt);
+  for (int t = 0; t < nt; ++t)
+    pool.emplace_back([=, &fn]() {
+      for (int i = t; i < n; i += nt) fn(i);
+    });
+  for (auto& th : pool) th.join();
+}
+
 
 struct LowerError : std::runtime_error {
   using std::runtime_error::runtime_error;
@@ -23,13 +48,28 @@ struct LowerError : std::runtime_error {
     if (!(cond)) throw ::mcba::LowerError(msg);  \
   } while (0)
 
+// vector whose resize() leaves new elements uninitialised: the slot tables are tens of MB and every element is written by
+// the (threaded) lowering loops anyway -- value-initialising them first cost a serial memset plus all the page faults
+template <typename T>
+struct NoInitAlloc : std::allocator<T> {
+  template <typename U> struct rebind { using other = NoInitAlloc<U>; };
+  template <typename U, typename... A>
+  void construct(U* ptr, A&&... a) {
+    if constexpr (sizeof...(A) == 0) ::new ((void*)ptr) U;
+    else ::new ((void*)ptr) U(std::forward<A>(a)...);
+  }
+};
+template <typename T> using SlotVec = std::vector<T, NoInitAlloc<T>>;
+
 struct HostProblem {
   Dims d{};
-  std::vector<uint8_t> valid_ref;    // Calibration.valid, [C,F,B,P] reference order, all frames
-  std::vector<uint8_t> evalid_ref;   // proj.valid & obs.valid
-  std::vector<double2> obs;          // frame-major shard tables ...
-  std::vector<uint8_t> evalid, inlier, fix_aspect;
-  std::vector<int32_t> obs_index, view_count, board_off, full2act;
+  SlotVec<uint8_t> valid_ref;        // Calibration.valid, [C,F,B,P] reference order, all frames
+  SlotVec<uint8_t> evalid_ref;       // proj.valid & obs.valid
+  SlotVec<double2> obs;              // frame-major shard tables ...
+  SlotVec<uint8_t> evalid, inlier;
+  SlotVec<int32_t> obs_index;
+  std::vector<uint8_t> fix_aspect;
+  std::vector<int32_t> view_count, board_off, full2act;
   std::vector<double> xfull, bwg, img_h;
   std::vector<uint16_t> tri;
   int64_t n_inliers = 0;
@@ -47,29 +87,39 @@ inline int64_t full_size_of(const mcba_problem* p) {
 inline void lower_inliers(HostProblem& hp, const uint8_t* mask_ref) {
   const Dims& d = hp.d;
   const size_t nslot = (size_t)d.slots();
-  hp.inlier.assign(nslot, 0);
-  hp.obs_index.assign(nslot, -1);
+  hp.inlier.resize(nslot);       // every element is written below
+  hp.obs_index.resize(nslot);
   hp.view_count.assign((size_t)d.views(), 0);
-  int64_t count = 0;
-  // residual order = reference C-order over (c, f, b, p) restricted to the shard's frames
-  for (int c = 0; c < d.C; ++c)
-    for (int fl = 0; fl < d.Fl; ++fl) {
-      const int f = d.f0 + fl;
-      for (int b = 0; b < d.B; ++b) {
-        const size_t ref0 = (((size_t)c * d.F + f) * d.B + b) * d.P;
-        const size_t v = ((size_t)fl * d.C + c) * d.B + b;
-        int vc = 0;
-        for (int p = 0; p < d.P; ++p) {
-          const uint8_t in = mask_ref ? mask_ref[ref0 + p] : hp.valid_ref[ref0 + p];
-          hp.inlier[v * d.P + p] = in ? 1 : 0;
-          if (in) {
-            hp.obs_index[v * d.P + p] = (int32_t)count++;
-            ++vc;
-          }
-        }
-        hp.view_count[v] = vc;
+  // residual order = reference C-order over (c, f, b, p) restricted to the shard's frames.  Pass 1 (parallel over
+  // (c, f)): inlier bytes and per-view counts; the exclusive prefix of the counts in C-order gives every view its first
+  // residual index; pass 2 (parallel) numbers the observations.
+  const int nv = d.C * d.Fl;
+  std::vector<int64_t> first((size_t)nv * d.B + 1, 0);     // [c][fl][b] view offsets in reference order
+  lower_parallel_for(nv, [&](int cf) {
+    const int c = cf / d.Fl, fl = cf % d.Fl, f = d.f0 + fl;
+    for (int b = 0; b < d.B; ++b) {
+      const size_t ref0 = (((size_t)c * d.F + f) * d.B + b) * d.P;
+      const size_t v = ((size_t)fl * d.C + c) * d.B + b;
+      int vc = 0;
+      for (int p = 0; p < d.P; ++p) {
+        const uint8_t in = mask_ref ? mask_ref[ref0 + p] : hp.valid_ref[ref0 + p];
+        hp.inlier[v * d.P + p] = in ? 1 : 0;
+        vc += in ? 1 : 0;
       }
+      hp.view_count[v] = vc;
+      first[(size_t)cf * d.B + b + 1] = vc;
     }
+  });
+  for (size_t i = 1; i < first.size(); ++i) first[i] += first[i - 1];
+  const int64_t count = first.back();
+  lower_parallel_for(nv, [&](int cf) {
+    const int c = cf / d.Fl, fl = cf % d.Fl;
+    for (int b = 0; b < d.B; ++b) {
+      const size_t v = ((size_t)fl * d.C + c) * d.B + b;
+      int64_t idx = first[(size_t)cf * d.B + b];
+      for (int p = 0; p < d.P; ++p) hp.obs_index[v * d.P + p] = hp.inlier[v * d.P + p] ? (int32_t)idx++ : -1;
+    }
+  });
   MCBA_REQUIRE(count < (1LL << 30), "too many observations for 32-bit residual indices");
   hp.n_inliers = count;
 }
@@ -141,26 +191,27 @@ inline void lower_problem(const mcba_problem* p, HostProblem& hp) {
   const size_t nref = (size_t)d.C * d.F * d.B * d.P;
   hp.valid_ref.resize(nref);
   hp.evalid_ref.resize(nref);
-  for (int c = 0; c < d.C; ++c)
-    for (int f = 0; f < d.F; ++f)
-      for (int b = 0; b < d.B; ++b) {
-        const bool pv = p->camera_valid[c] && p->frame_valid[f] && p->board_valid[b];
-        const size_t r0 = (((size_t)c * d.F + f) * d.B + b) * d.P;
-        for (int q = 0; q < d.P; ++q) {
-          const bool v = pv && p->point_valid[r0 + q];
-          hp.valid_ref[r0 + q] = v;
-          hp.evalid_ref[r0 + q] = v && q < p->board_sizes[b];
-        }
+  lower_parallel_for(d.C * d.F, [&](int cf) {
+    const int c = cf / d.F, f = cf % d.F;
+    for (int b = 0; b < d.B; ++b) {
+      const bool pv = p->camera_valid[c] && p->frame_valid[f] && p->board_valid[b];
+      const size_t r0 = (((size_t)c * d.F + f) * d.B + b) * d.P;
+      for (int q = 0; q < d.P; ++q) {
+        const bool v = pv && p->point_valid[r0 + q];
+        hp.valid_ref[r0 + q] = v;
+        hp.evalid_ref[r0 + q] = v && q < p->board_sizes[b];
       }
+    }
+  });
 
   // ---- frame-major observation tables of the shard ----------------------------------------------------------
   const size_t nslot = (size_t)d.slots();
   {
-    std::vector<double2>& obs = hp.obs;
-    std::vector<uint8_t>& ev = hp.evalid;
+    SlotVec<double2>& obs = hp.obs;
+    SlotVec<uint8_t>& ev = hp.evalid;
     obs.resize(nslot);
     ev.resize(nslot);
-    for (int fl = 0; fl < d.Fl; ++fl)
+    lower_parallel_for(d.Fl, [&](int fl) {
       for (int c = 0; c < d.C; ++c)
         for (int b = 0; b < d.B; ++b) {
           const size_t r0 = (((size_t)c * d.F + d.f0 + fl) * d.B + b) * d.P;
@@ -171,6 +222,7 @@ inline void lower_problem(const mcba_problem* p, HostProblem& hp) {
             ev[s0 + q] = hp.evalid_ref[r0 + q];
           }
         }
+    });
   }
   lower_inliers(hp, p->inlier_mask);
 

@@ -19,7 +19,7 @@ def build(force=False):
   csrc = os.path.join(os.path.dirname(HERE), "multical_amd", "csrc")
   deps = [SRC] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".h")]
   if force or not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", LIB, SRC])
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", LIB, SRC])
   return LIB
 
 
