@@ -176,6 +176,38 @@ def test_bundle_adjust_reaches_lower_or_equal_cost(name):
     assert abs(calibration.error_stats(out.reprojection_error).rms - float(g["ba_rms"])) < 5e-3
 
 
+@pytest.mark.parametrize("name,noise,outliers,seed", [
+    ("tiny", 0.5, 0.0, 11), ("tiny", 0.5, 0.0, 12), ("tiny", 0.1, 0.05, 13), ("tiny_rolling", 0.2, 0.03, 11),
+    ("tiny_fisheye", 0.1, 0.01, 11), ("tiny_fisheye", 0.4, 0.0, 12), ("tiny_handeye", 0.3, 0.02, 11),
+    ("tiny_handeye", 0.3, 0.02, 12), ("tiny_handeye", 1.0, 0.0, 13)])
+def test_randomised_rigs_against_the_oracle(name, noise, outliers, seed):
+  """Fresh synthetic rigs (seeds, noise levels and outlier fractions that no fixture uses): residuals at the start point
+  within 1e-9 px of the oracle, analytic gradient == J^T r of the oracle's finite-difference-free check (3-point), and
+  the HIP solve ends at a cost not above the oracle's (= the reference's) bundle_adjust on the same rig."""
+  rig = synthetic.make_rig(name, seed=seed, noise=noise, outlier_frac=outliers)
+  c = mirror(rig)
+  oc = restate.from_rig(rig)
+  x0 = c.param_vec
+  assert np.array_equal(x0, oc.param_vec)
+  with Handle(c) as h:
+    r = h.residuals(x0)
+    r_ref = oc.evaluate(x0)
+    assert r.shape == r_ref.shape and np.abs(r - r_ref).max() < 1e-9
+    cost, grad, _ = h.normal_equations(x0)
+    assert cost == pytest.approx(0.5 * r_ref @ r_ref, rel=1e-12)
+    # directional derivative of the oracle's cost along a random direction == grad . direction (central differences)
+    rng = np.random.default_rng(seed)
+    dvec = rng.normal(size=x0.size) * 1e-6
+    f = lambda x: 0.5 * np.sum(oc.evaluate(x) ** 2)
+    num = (f(x0 + dvec) - f(x0 - dvec)) / 2
+    assert num == pytest.approx(grad @ dvec, rel=2e-5, abs=1e-9 * abs(cost))
+    res = h.solve(x0)
+  ref = oc.bundle_adjust()
+  ref_cost = 0.5 * np.sum(ref.evaluate(ref.param_vec) ** 2)
+  assert res.status in (0, 1, 2, 3, 4)   # 0: the reference exhausts its 100 evaluations on the same rig too (rolling, 3 % outliers)
+  assert res.cost <= ref_cost * (1 + 1e-9)
+
+
 @pytest.mark.parametrize("name", ["tiny", "tiny_rolling", "tiny_handeye", "tiny_fisheye", "tiny_edge", "cfg1"])
 def test_outlier_loop_matches_reference(name):
   """Workspace.calibrate's sequence (3 x {reject at 5 x q75, bundle_adjust}, workspace.py:228-247):
