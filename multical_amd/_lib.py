@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "_build", "libmcba.so")
+LIB_PATH = os.environ.get("MCBA_LIB_PATH") or os.path.join(HERE, "_build", "libmcba.so")   # (override: kernel experiments)
 
 MCBA_VERSION = 1
 MOTION_STATIC, MOTION_ROLLING, MOTION_HAND_EYE = 0, 1, 2

@@ -14,13 +14,17 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OUT = os.path.join(HERE, "_build")
+# MCBA_BUILD_VARIANT=name + MCBA_EXTRA_FLAGS="-DX=1 ..." build an experimental variant into _build_name/ (profiling aid:
+# several variants of the kernels can then be compared in one GPU session, selected with MCBA_LIB_PATH)
+VARIANT = os.environ.get("MCBA_BUILD_VARIANT", "")
+OUT = os.path.join(HERE, "_build" + ("_" + VARIANT if VARIANT else ""))
 LIB = os.path.join(OUT, "libmcba.so")
 ARCH = "gfx950"
 SOURCES = ["mcba_api.hip", "mcba_cam_pin4.hip", "mcba_cam_pin5.hip", "mcba_cam_pin8.hip", "mcba_cam_pin12.hip",
            "mcba_cam_pin14.hip", "mcba_cam_fish4.hip"]
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "mcba.h")]
-FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-Wall", "-Wno-unused-function"]
+FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-Wall", "-Wno-unused-function"] + \
+        os.environ.get("MCBA_EXTRA_FLAGS", "").split()
 
 
 def hipcc():

@@ -41,10 +41,14 @@ void lin2(const Dims& d, const Tables& t, hipStream_t s, double* rec, const uint
   // persistent wavefronts: 8 single-wave workgroups per CU (2 per SIMD: 256-VGPR budget, 20 KB LDS each) x 256 CUs
   const int want = epoch > 0 ? epoch : LIN_GRID_MAX;   // the last argument carries the debug grid override
   const dim3 grid(d.views() < want ? d.views() : want), block(64);
-  if (mfma)
-    hipLaunchKernelGGL((k_linearize<ND_, FISH_, MOTION, OPTK, true>), grid, block, 0, s, d, t, rec, tri, epoch);
+  // the linear loss (the reference's default, calibration.py:199) has its own instantiation of the MFMA kernel: no loss
+  // switch and no robust-scale constants in the hot loop; the plain-FMA validation build keeps the generic form
+  if (mfma && d.loss == 0)
+    hipLaunchKernelGGL((k_linearize<ND_, FISH_, MOTION, OPTK, true, false>), grid, block, 0, s, d, t, rec, tri, epoch);
+  else if (mfma)
+    hipLaunchKernelGGL((k_linearize<ND_, FISH_, MOTION, OPTK, true, true>), grid, block, 0, s, d, t, rec, tri, epoch);
   else
-    hipLaunchKernelGGL((k_linearize<ND_, FISH_, MOTION, OPTK, false>), grid, block, 0, s, d, t, rec, tri, epoch);
+    hipLaunchKernelGGL((k_linearize<ND_, FISH_, MOTION, OPTK, false, true>), grid, block, 0, s, d, t, rec, tri, epoch);
 }
 
 template <int MOTION>

@@ -65,6 +65,24 @@ __device__ __forceinline__ double wave_max(double v) {
   return v;
 }
 
+// Pairwise in-register folding of per-lane partial sums with the gfx950 lane-swap instructions (VALU, no LDS traffic):
+//   fold32(a, b): lanes  0..31 return a[l] + a[l + 32],  lanes 32..63 return b[l - 32] + b[l]
+//                 (v_permlane32_swap: lanes 32..63 of the first operand <-> lanes 0..31 of the second)
+//   fold16(a, b): with rows of 16 lanes a = [a0 a1 a2 a3], b = [b0 b1 b2 b3]:  [a0 + a1, b0 + b1, a2 + a3, b2 + b3]
+//                 (v_permlane16_swap: odd rows of the first operand <-> even rows of the second)
+__device__ __forceinline__ double fold32(double a, double b) {
+  const unsigned alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
+  const auto lo = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+  return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ double fold16(double a, double b) {
+  const unsigned alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
+  const auto lo = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+  return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+
 // deterministic block reduction (blockDim.x multiple of 64, <= 1024); result valid in thread 0
 template <bool MAX>
 __device__ __forceinline__ double block_reduce(double v, double* scratch /*[16]*/) {
@@ -393,17 +411,25 @@ __global__ __launch_bounds__(256) void k_points(Dims d, Tables t, double* __rest
 // designed for, this makes hipcc select the VGPR form of the MFMA: with the default 512-register budget it keeps the
 // loop-carried accumulators in VGPRs, issues AGPR-form MFMAs and brackets EVERY step with 24 v_accvgpr_write +
 // 24 v_accvgpr_read and a full-latency s_nop (196 instead of 64 cycles per MFMA, measured with s_memtime stamps).
-template <int ND, bool FISH, int MOTION, bool OPTK, bool MFMA>
+template <int ND, bool FISH, int MOTION, bool OPTK, bool MFMA, bool ROBUST>
 __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* __restrict__ rec,
                                                      const uint16_t* __restrict__ tri, int epoch) {
   constexpr bool ROLL = MOTION == MOTION_ROLLING;
   constexpr int DE = ROLL ? 12 : 6, NPB = MOTION == MOTION_STATIC ? 3 : 4, KI = OPTK ? 4 + ND : 0;
   constexpr int NV = DE + KI + 1, NT = (NV + 15) / 16, NVP = 16 * NT, LDV = NVP + 1;
   constexpr int NPC = 6 * NPB, NL = NPC + KI, N1 = NL + 1;
-  constexpr int PTS = NT == 1 ? 64 : 32, RND = 64 / PTS, ROWS = 2 * PTS;
+  // staging: one LDS row per lane; a chunk of 64 observations is accumulated in TWO rounds, first the u-rows of all 64
+  // lanes, then the v-rows (S = sum of the outer products of all rows: the order is free).  Compared with staging the
+  // row pairs of 32 lanes per round this issues half as many ds_write instructions (every lane is active in every store)
+  // and the registers of a row die as soon as it is staged.
+  constexpr int ROWS = 64;
   constexpr int REC = N1 * (N1 + 1) / 2;
-  // NV in 17..23: the (NV-16)^2 corner of S is accumulated per lane on the VALU (same FP64 rate as the MFMA on gfx950,
-  // but only the <= 28 unique products instead of a 16x16x4 tile) and reduced across lanes once per view.
+  // NV in 17..23 (rolling shutter + intrinsics: 22): ONE shifted MFMA tile per step instead of three.  With A = columns
+  // [0, 16) and B = columns [TW, TW + 16), TW = NV - 16, the 16 x 16 product covers S[0:16][TW:NV], i.e. every pair
+  // {i, j} except the pairs inside the first TW and inside the last TW columns.  Those 2 * TW (TW + 1) / 2 (= 42) products
+  // per row are accumulated per lane on the VALU (same FP64 pipe and rate as the MFMA on gfx950, but only the unique
+  // products) and reduced across lanes once per view.  211 of the 256 products of the tile are distinct entries of the
+  // symmetric S (the tiles (0,0) + (0,1) of the straightforward blocking delivered 232 distinct entries for 512 products).
   constexpr int TW = NV - 16;
   constexpr bool TAILV = MFMA && NT == 2 && TW <= 7;
   constexpr int NTAIL = TAILV ? TW * (TW + 1) / 2 : 1;
@@ -457,7 +483,9 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
   }
   if (prof) stamp[4] = clock64();
   // only the pad columns need clearing: every staged row is fully rewritten (columns < NV) in every round
-  for (int e = lane; e < ROWS * (LDV - NV); e += 64) Vbuf[(e / (LDV - NV)) * LDV + NV + e % (LDV - NV)] = 0.0;
+  // (the shifted tile reads columns < NV only: nothing to clear)
+  if constexpr (!TAILV)
+    for (int e = lane; e < ROWS * (LDV - NV); e += 64) Vbuf[(e / (LDV - NV)) * LDV + NV + e % (LDV - NV)] = 0.0;
 
   if (prof) stamp[5] = clock64();
   int count = 0;
@@ -470,7 +498,7 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
   }
 
   constexpr int NACC_V = NVP * NVP / 64;                  // plain-FMA variant: NVP*NVP entries over 64 lanes
-  constexpr int NTILE = NT * (NT + 1) / 2;
+  constexpr int NTILE = TAILV ? 2 : NT * (NT + 1) / 2;   // shifted tile: two accumulators (even / odd steps), no dependent MFMAs
   double accv[MFMA ? 1 : NACC_V];
   double4_t accm[MFMA ? NTILE : 1];
   if constexpr (MFMA) {
@@ -479,8 +507,8 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
     for (int i = 0; i < NACC_V; ++i) accv[i] = 0.0;
   }
   double cost = 0.0;
-  double tail[NTAIL];
-  for (int i = 0; i < NTAIL; ++i) tail[i] = 0.0;
+  double tail[NTAIL], head[NTAIL];
+  for (int i = 0; i < NTAIL; ++i) tail[i] = head[i] = 0.0;
   lds_fence();
   if (prof) stamp[1] = clock64();
 
@@ -496,69 +524,69 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
     const int p_nxt = inx < count ? pidx[inx] : p_cur;
     const double2 ob_nxt = t.obs[(size_t)v * d.P + p_nxt];
     for (int k = 0; k < 3; ++k) X_nxt[k] = t.board_points[3 * (size_t)(b * d.P + p_nxt) + k];
-    double vr[2 * NV];
+    PointState<ND, ROLL> ps;
     long long t0 = 0;
     if (prof) t0 = clock64();
     if (in) {
-      cost += point_rows<ND, FISH, ROLL, OPTK>(d, t, v, c, b, p_cur, ob_cur, vr, nullptr, X_cur);
-    } else {
-      for (int k = 0; k < 2 * NV; ++k) vr[k] = 0.0;
+      cost += point_state<ND, FISH, ROLL, ROBUST>(d, t, v, c, b, p_cur, ob_cur, ps, X_cur);
+    } else {   // lanes past the end of the list stage zero rows
+      ps = PointState<ND, ROLL>{};
     }
     p_cur = p_nxt;
     ob_cur = ob_nxt;
     for (int k = 0; k < 3; ++k) X_cur[k] = X_nxt[k];
-    if constexpr (TAILV) {
-      if (in) {
+    if (prof) stamp[2] += clock64() - t0;
+    const int nchunk = min(64, count - base);              // observations in this chunk
+    const int nsteps = (nchunk + 3) / 4;                   // 4 rows (4 observations, one image axis) per MFMA step
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {                          // q = 0: u-rows, q = 1: v-rows
+      double row[NV];
+      point_row<ND, ROLL, OPTK>(ps, q, row);
+      if constexpr (TAILV) {                               // the two VALU blocks of this row (zero rows add zeros)
         int e = 0;
 #pragma unroll
         for (int i0 = 0; i0 < TW; ++i0)
 #pragma unroll
-          for (int i1 = i0; i1 < TW; ++i1, ++e)
-            tail[e] += vr[16 + i0] * vr[16 + i1] + vr[NV + 16 + i0] * vr[NV + 16 + i1];
+          for (int i1 = i0; i1 < TW; ++i1, ++e) {
+            head[e] += row[i0] * row[i1];
+            tail[e] += row[16 + i0] * row[16 + i1];
+          }
       }
-    }
-    if (prof) stamp[2] += clock64() - t0;
-    const int nchunk = min(64, count - base);              // observations in this chunk
-    for (int q = 0; q < RND; ++q) {
-      const int npts = min(PTS, nchunk - q * PTS);          // observations staged in this round
-      if (npts <= 0) break;
-      if (RND == 1 || (lane / PTS) == q) {
-        const int row0 = 2 * (lane % PTS);
-        for (int k = 0; k < NV; ++k) {
-          Vbuf[row0 * LDV + k] = vr[k];
-          Vbuf[(row0 + 1) * LDV + k] = vr[NV + k];
-        }
-      }
+#pragma unroll
+      for (int k = 0; k < NV; ++k) Vbuf[lane * LDV + k] = row[k];
       lds_fence();
-      const int nsteps = (npts + 1) / 2;                    // 4 rows (2 observations) per MFMA step
       if constexpr (MFMA) {
         const int rsub = lane >> 4, csub = lane & 15;
         const double* vp = Vbuf + rsub * LDV + csub;
         // two steps per iteration with ping-pong operand registers: the LDS reads of the next step are in flight
         // while the MFMAs of the current one issue, and no register copy forces an early s_waitcnt
-        // (every lane of the round stages its rows, zero rows for lanes without an observation, so the step count can
-        //  be rounded up to an even number and the loop body stays branch-free)
+        // (every lane stages its row, a zero row for lanes without an observation, so the step count can be rounded
+        //  up to an even number and the loop body stays branch-free)
+        // operand column offsets: plain blocking = tile t at column 16 t; shifted tile = A at column 0, B at column TW
+        constexpr int COFF1 = TAILV ? TW : 16;
         double a0[NT], a1[NT];
         constexpr int MAXS = ROWS / 4;
         const int nsteps2 = (nsteps + 1) & ~1;
-        for (int tt = 0; tt < NT; ++tt) a0[tt] = vp[16 * tt];
+        for (int tt = 0; tt < NT; ++tt) a0[tt] = vp[COFF1 * tt];
         for (int st = 0; st < nsteps2; st += 2) {
-          for (int tt = 0; tt < NT; ++tt) a1[tt] = vp[(4 * (st + 1)) * LDV + 16 * tt];
-          {
+          for (int tt = 0; tt < NT; ++tt) a1[tt] = vp[(4 * (st + 1)) * LDV + COFF1 * tt];
+          if constexpr (TAILV) {
+            accm[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[0], a0[1], accm[0], 0, 0, 0);
+          } else {
             int ti = 0;
             for (int t0 = 0; t0 < NT; ++t0)
               for (int t1 = t0; t1 < NT; ++t1, ++ti)
-                if (!(TAILV && t0 == 1))
-                  accm[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[t0], a0[t1], accm[ti], 0, 0, 0);
+                accm[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[t0], a0[t1], accm[ti], 0, 0, 0);
           }
           const int nx = min(st + 2, MAXS - 1);
-          for (int tt = 0; tt < NT; ++tt) a0[tt] = vp[(4 * nx) * LDV + 16 * tt];
-          {
+          for (int tt = 0; tt < NT; ++tt) a0[tt] = vp[(4 * nx) * LDV + COFF1 * tt];
+          if constexpr (TAILV) {
+            accm[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[0], a1[1], accm[1], 0, 0, 0);
+          } else {
             int ti = 0;
             for (int t0 = 0; t0 < NT; ++t0)
               for (int t1 = t0; t1 < NT; ++t1, ++ti)
-                if (!(TAILV && t0 == 1))
-                  accm[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[t0], a1[t1], accm[ti], 0, 0, 0);
+                accm[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[t0], a1[t1], accm[ti], 0, 0, 0);
           }
         }
       } else {
@@ -574,51 +602,44 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
   }
 
   if (prof) stamp[3] = clock64();
+#if defined(MCBA_EXP_PRIO)
+  __builtin_amdgcn_s_setprio(MCBA_EXP_PRIO);   // latency-bound epilogue: ask for the issue slots, the partner wave keeps the pipe busy
+#endif
   // The epilogue indices only depend on the lane, so the compiler hoists them out of the view loop and then SPILLS them
   // (the row evaluation needs the whole register budget): every store was preceded by a scratch reload and an
   // s_waitcnt vmcnt(0), i.e. it waited for the previous global store to retire.  An opaque copy of the lane id keeps
   // the index arithmetic (a handful of integer ops) inside the epilogue.
   int el;
   asm volatile("v_mov_b32 %0, %1" : "=v"(el) : "v"(lane));
-  // cross-lane reduction of the VALU corner: transpose through the (now free) staging buffer; PARTS lanes share a row,
-  // each issues all its LDS reads before the first add, and lane (i0, i1) of a TW x TW layout gathers the partial sums
-  double tail_red = 0.0;
+  // cross-lane reduction of the two VALU blocks (first TW and last TW columns): the 2 NTAIL values per lane are folded in
+  // registers, two values per fold32 (64 -> 32 partials each) and two of those per fold16 (-> 16 partials), so that a
+  // quarter of the vectors goes through LDS: row g of vector j carries 16 partials of value 4 j + {0, 2, 1, 3}[g].  Lane
+  // e < 2 NTAIL then adds the 16 partials of value e (all reads issued before the first add).  Value e < NTAIL belongs to
+  // the first block, the others to the last block.
+  double corner_red = 0.0;
   if constexpr (TAILV) {
-    constexpr int PARTS = (64 / NTAIL) > 4 ? 4 : (64 / NTAIL), SEG = (64 + PARTS - 1) / PARTS;
-    static_assert(NTAIL * 65 + 64 <= BUF, "tail transpose does not fit");
-    static_assert(PARTS >= 1 && TW * TW <= 64, "tail layout");
+    constexpr int NC = 2 * NTAIL, NZ = (NC + 1) / 2, NW = (NZ + 1) / 2;
+    static_assert(NC <= 64 && 4 * NW * 17 <= BUF, "corner transpose does not fit");
+    double cv[2 * NZ], z[2 * NW];
 #pragma unroll
-    for (int e = 0; e < NTAIL; ++e) Buf[e * 65 + el] = tail[e];
-    lds_fence();
-    double part = 0.0;
-    {
-      const int e = el % NTAIL, pt = el / NTAIL;
-      if (pt < PARTS) {
-        double vals[SEG];
-        const double* row = Buf + e * 65 + pt * SEG;
+    for (int e = 0; e < 2 * NZ; ++e) cv[e] = e < NTAIL ? head[e < NTAIL ? e : 0] : (e < NC ? tail[e < NC ? e - NTAIL : 0] : 0.0);
 #pragma unroll
-        for (int k = 0; k < SEG; ++k) vals[k] = row[k];
+    for (int i = 0; i < 2 * NW; ++i) z[i] = i < NZ ? fold32(cv[2 * (i < NZ ? i : 0)], cv[2 * (i < NZ ? i : 0) + 1]) : 0.0;
+    const int grow = (el >> 4) & 3, gperm = ((grow & 1) << 1) | (grow >> 1);   // row -> value offset {0, 2, 1, 3}
 #pragma unroll
-        for (int k = 0; k < SEG; ++k)
-          if (pt * SEG + k >= 64) vals[k] = 0.0;
-#pragma unroll
-        for (int w = 1; w < SEG; w *= 2)
-#pragma unroll
-          for (int k = 0; k + w < SEG; k += 2 * w) vals[k] += vals[k + w];
-        part = vals[0];
-      }
-    }
-    lds_fence();
-    Buf[NTAIL * 65 + el] = part;
+    for (int j = 0; j < NW; ++j) Buf[(4 * j + gperm) * 17 + (el & 15)] = fold16(z[2 * j], z[2 * j + 1]);
     lds_fence();
     {
-      const int i0 = el / TW, i1 = el % TW;
-      if (el < TW * TW) {
-        const int lo = i0 < i1 ? i0 : i1, hi = i0 < i1 ? i1 : i0;
-        const int e = lo * TW - (lo * (lo - 1)) / 2 + (hi - lo);
+      const int e = el < NC ? el : 0;
+      double vals[16];
+      const double* row = Buf + e * 17;
 #pragma unroll
-        for (int pt = 0; pt < PARTS; ++pt) tail_red += Buf[NTAIL * 65 + pt * NTAIL + e];
-      }
+      for (int k = 0; k < 16; ++k) vals[k] = row[k];
+#pragma unroll
+      for (int w = 1; w < 16; w *= 2)
+#pragma unroll
+        for (int k = 0; k + w < 16; k += 2 * w) vals[k] += vals[k + w];
+      corner_red = vals[0];
     }
     lds_fence();
   }
@@ -626,23 +647,40 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
   double* Sbuf = Buf;
   if constexpr (MFMA) {
     const int rsub = el >> 4, csub = el & 15;
-    int ti = 0;
-    for (int t0 = 0; t0 < NT; ++t0)
-      for (int t1 = t0; t1 < NT; ++t1, ++ti) {
-        if (TAILV && t0 == 1) continue;
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * t0 + rsub + 4 * r, col = 16 * t1 + csub;
-          Sbuf[row * NVP + col] = accm[ti][r];
-          if (t0 != t1) Sbuf[col * NVP + row] = accm[ti][r];
-        }
+    if constexpr (TAILV) {
+      // shifted tile: accumulator entry (row, csub) is S[row][TW + csub]; entries below the diagonal duplicate their
+      // mirror image bit for bit (same products, same order), so both lanes store the same value
+      for (int r = 0; r < 4; ++r) {
+        const int row = rsub + 4 * r, col = TW + csub;
+        const double val = accm[0][r] + accm[1][r];
+        Sbuf[row * NVP + col] = val;
+        Sbuf[col * NVP + row] = val;
       }
+    } else {
+      int ti = 0;
+      for (int t0 = 0; t0 < NT; ++t0)
+        for (int t1 = t0; t1 < NT; ++t1, ++ti) {
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * t0 + rsub + 4 * r, col = 16 * t1 + csub;
+            Sbuf[row * NVP + col] = accm[ti][r];
+            if (t0 != t1) Sbuf[col * NVP + row] = accm[ti][r];
+          }
+        }
+    }
   } else {
     constexpr int IW = NVP, JW = NACC_V;
     const int ii = el % IW, j0 = (el / IW) * JW;
     for (int jj = 0; jj < JW; ++jj) Sbuf[ii * NVP + j0 + jj] = accv[jj];
   }
-  if constexpr (TAILV) {   // lane (i0, i1) carries the reduced corner entry computed above
-    if (el < TW * TW) Sbuf[(16 + el / TW) * NVP + 16 + el % TW] = tail_red;
+  if constexpr (TAILV) {   // lane e carries packed entry e = (i0 <= i1) of the first (e < NTAIL) or of the last block
+    if (el < 2 * NTAIL) {
+      const int blk = el < NTAIL ? 0 : 1, e = el - blk * NTAIL;
+      int i0 = 0, rem = e;
+      while (rem >= TW - i0) { rem -= TW - i0; ++i0; }
+      const int i1 = i0 + rem, o = 16 * blk;
+      Sbuf[(o + i0) * NVP + o + i1] = corner_red;
+      Sbuf[(o + i1) * NVP + o + i0] = corner_red;
+    }
   }
   lds_fence();
 
@@ -811,6 +849,9 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
     }
   }
   lds_fence();   // the next view reuses the LDS buffers
+#if defined(MCBA_EXP_PRIO)
+  __builtin_amdgcn_s_setprio(0);
+#endif
   }
 }
 

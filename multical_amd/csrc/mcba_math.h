@@ -320,17 +320,18 @@ MCBA_HD void project_point(const double* cam, const double* X, double* uv, doubl
 // Every pose block k of the chain has d r / d(pose k) = E . T_k with a view-constant 6x6 matrix T_k
 // (see view_pose_column below), so only E is accumulated per point.
 // ---------------------------------------------------------------------------------------------------------
+MCBA_HD void base_row(const double* a, const double* X, double* E /*[6]*/) {
+  // a^T (-[X]x) = (X x a)^T
+  E[0] = X[1] * a[2] - X[2] * a[1];
+  E[1] = X[2] * a[0] - X[0] * a[2];
+  E[2] = X[0] * a[1] - X[1] * a[0];
+  E[3] = a[0];
+  E[4] = a[1];
+  E[5] = a[2];
+}
 MCBA_HD void base_rows(const double* A, const double* X, double* E /*[2][6]*/) {
-  for (int r = 0; r < 2; ++r) {
-    const double* a = A + 3 * r;
-    // a^T (-[X]x) = (X x a)^T
-    E[6 * r + 0] = X[1] * a[2] - X[2] * a[1];
-    E[6 * r + 1] = X[2] * a[0] - X[0] * a[2];
-    E[6 * r + 2] = X[0] * a[1] - X[1] * a[0];
-    E[6 * r + 3] = a[0];
-    E[6 * r + 4] = a[1];
-    E[6 * r + 5] = a[2];
-  }
+  base_row(A, X, E);
+  base_row(A + 3, X, E + 6);
 }
 
 // Column j (0..5) of T_k = [[Rpre L_k, 0], [[o_k]x Rpre L_k, Rpre]] for a pose with prefix rotation Rpre (product of

@@ -207,40 +207,70 @@ MCBA_HD bool local_is_frame(const Dims& d, int i) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// per-point row pair V = [E | K | r] (scaled for the robust loss); returns rho0_u + rho0_v
+// per-point row pair V = [E | K | r] (scaled for the robust loss), in two phases:
+//   point_state   forward model + analytic derivatives of one observation (everything both rows share)
+//   point_row     row a (0 = u, 1 = v) of V from the state
+// k_linearize builds, consumes and stages one row at a time (the registers of the u-row are free before the v-row is
+// formed); point_rows = state + both rows is what every other caller uses -- the arithmetic is the same.
 // ---------------------------------------------------------------------------------------------------------------
+template <int ND, bool ROLL>
+struct PointState {
+  double A[6];              // d(u,v)/d X_cam
+  double Kc[2 * (4 + ND)];  // d(u,v)/d intrinsics (skew column omitted)
+  double Xs[3], Xe[3];      // camera-frame point of the start / end chain
+  double tr;                // scan time of the observed row (rolling shutter)
+  double e[2];              // reprojection residual
+  double rs[2], fs[2];      // robust-loss row scale / residual scale
+};
+
+// returns rho0_u + rho0_v
+// ROBUST = false compiles the linear loss in (no loss switch, no row scaling: the hot kernel's default instantiation)
+template <int ND, bool FISH, bool ROLL, bool ROBUST = true>
+MCBA_HD double point_state(const Dims& d, const Tables& t, int v, int c, int b, int p, double2 ob,
+                           PointState<ND, ROLL>& st, const double* Xpre = nullptr) {
+  double uv[2];
+  slot_forward<ND, FISH, ROLL, true>(d, t, v, c, b, p, ob, uv, st.A, st.Kc, st.Xs, st.Xe, st.tr, Xpre);
+  st.e[0] = uv[0] - ob.x;
+  st.e[1] = uv[1] - ob.y;
+  double rho = 0.0;
+  const int loss = ROBUST ? d.loss : 0;
+  rho += robust_loss(loss, d.f_scale, st.e[0], &st.rs[0], &st.fs[0]);
+  rho += robust_loss(loss, d.f_scale, st.e[1], &st.rs[1], &st.fs[1]);
+  return rho;
+}
+
+template <int ND, bool ROLL, bool OPTK>
+MCBA_HD void point_row(const PointState<ND, ROLL>& st, int a, double* row /*[NV]*/) {
+  constexpr int DE = ROLL ? 12 : 6, KI = OPTK ? 4 + ND : 0, NV = DE + KI + 1, KIA = 4 + ND;
+  const double* ar = st.A + 3 * a;
+  if constexpr (ROLL) {
+    double Es[6], Ee[6];
+    base_row(ar, st.Xs, Es);
+    base_row(ar, st.Xe, Ee);
+    for (int i = 0; i < 6; ++i) {
+      row[i] = st.rs[a] * (1.0 - st.tr) * Es[i];
+      row[6 + i] = st.rs[a] * st.tr * Ee[i];
+    }
+  } else {
+    double E[6];
+    base_row(ar, st.Xs, E);
+    for (int i = 0; i < 6; ++i) row[i] = st.rs[a] * E[i];
+  }
+  if constexpr (OPTK) {
+    for (int i = 0; i < KI; ++i) row[DE + i] = st.rs[a] * st.Kc[a * KIA + i];
+  }
+  row[NV - 1] = st.e[a] * st.fs[a];
+}
+
 template <int ND, bool FISH, bool ROLL, bool OPTK>
 MCBA_HD double point_rows(const Dims& d, const Tables& t, int v, int c, int b, int p, double2 ob,
                                              double* vr /*[2][NV]*/, double* jp = nullptr /*[2][3]: d r / d X_board*/,
                                              const double* Xpre = nullptr) {
-  constexpr int DE = ROLL ? 12 : 6, KI = OPTK ? 4 + ND : 0, NV = DE + KI + 1, KIA = 4 + ND;
-  double uv[2], A[6], Kc[2 * KIA], Xs[3], Xe[3], tr;
-  slot_forward<ND, FISH, ROLL, true>(d, t, v, c, b, p, ob, uv, A, Kc, Xs, Xe, tr, Xpre);
-  const double e[2] = {uv[0] - ob.x, uv[1] - ob.y};
-  double rs[2], fs[2], rho = 0.0;
-  rho += robust_loss(d.loss, d.f_scale, e[0], &rs[0], &fs[0]);
-  rho += robust_loss(d.loss, d.f_scale, e[1], &rs[1], &fs[1]);
-  double E[12];
-  if constexpr (ROLL) {
-    double Es[12], Ee[12];
-    base_rows(A, Xs, Es);
-    base_rows(A, Xe, Ee);
-    for (int a = 0; a < 2; ++a)
-      for (int i = 0; i < 6; ++i) {
-        vr[a * NV + i] = rs[a] * (1.0 - tr) * Es[6 * a + i];
-        vr[a * NV + 6 + i] = rs[a] * tr * Ee[6 * a + i];
-      }
-  } else {
-    base_rows(A, Xs, E);
-    for (int a = 0; a < 2; ++a)
-      for (int i = 0; i < 6; ++i) vr[a * NV + i] = rs[a] * E[6 * a + i];
-  }
-  if constexpr (OPTK) {
-    for (int a = 0; a < 2; ++a)
-      for (int i = 0; i < KI; ++i) vr[a * NV + DE + i] = rs[a] * Kc[a * KIA + i];
-  }
-  vr[NV - 1] = e[0] * fs[0];
-  vr[2 * NV - 1] = e[1] * fs[1];
+  constexpr int DE = ROLL ? 12 : 6, KI = OPTK ? 4 + ND : 0, NV = DE + KI + 1;
+  PointState<ND, ROLL> st;
+  const double rho = point_state<ND, FISH, ROLL>(d, t, v, c, b, p, ob, st, Xpre);
+  point_row<ND, ROLL, OPTK>(st, 0, vr);
+  point_row<ND, ROLL, OPTK>(st, 1, vr + NV);
   if (jp != nullptr) {
     // d r / d X_board = A . R_view  (rolling: A ((1-t) R_start + t R_end)); board/charuco.py:112-117 `adjusted_points`
     const double* V = t.view + (size_t)v * (VIEW_STRIDE * (ROLL ? 2 : 1));
@@ -249,10 +279,10 @@ MCBA_HD double point_rows(const Dims& d, const Tables& t, int v, int c, int b, i
         double sum = 0.0;
         for (int i = 0; i < 3; ++i) {
           double rik = V[3 * i + k];
-          if constexpr (ROLL) rik = (1.0 - tr) * rik + tr * V[VIEW_STRIDE + 3 * i + k];
-          sum += A[3 * a + i] * rik;
+          if constexpr (ROLL) rik = (1.0 - st.tr) * rik + st.tr * V[VIEW_STRIDE + 3 * i + k];
+          sum += st.A[3 * a + i] * rik;
         }
-        jp[3 * a + k] = rs[a] * sum;
+        jp[3 * a + k] = st.rs[a] * sum;
       }
   }
   return rho;

@@ -138,9 +138,20 @@ CONFIGS = {
                         optimize_cameras=True, layout="stereo", seed=15),
   "tiny_tilted": dict(cameras=2, frames=8, boards=["charuco_10x10"], motion="static", model="tilted",
                       optimize_cameras=True, layout="stereo", seed=16),
+  # four distortion coefficients (k1 k2 p1 p2): a `standard` reference Camera whose dist array has 4 entries, as loaded
+  # from a calibration file written by OpenCV with CALIB_FIX_K3 (cv2.projectPoints accepts 4, 5, 8, 12 or 14)
+  "tiny_pin4": dict(cameras=2, frames=8, boards=["charuco_10x10"], motion="static", model="pin4",
+                    optimize_cameras=True, layout="stereo", seed=18),
+  # reduced-frame variants of BASELINE configs[2..4] whose complete reference run (adjust_outliers) finishes in minutes
+  "cfg3_40": dict(cameras=8, frames=40, boards=["charuco_16x22", "aprilgrid_9x9"], motion="rolling",
+                  model="standard", optimize_cameras=True, layout="stereo", seed=3),
+  "cfg4_40": dict(cameras=16, frames=40, boards=["charuco_10x10"] * 5, motion="static", model="standard",
+                  optimize_cameras=True, layout="stereo", cube=True, seed=4),
+  "cfg5_40": dict(cameras=6, frames=40, boards=["charuco_10x10"] * 5, motion="static", model="fisheye",
+                  optimize_cameras=True, layout="ring", seed=5),
 }
 
-DIST_SIZE = dict(standard=5, rational=8, thin_prism=12, tilted=14, fisheye=4)
+DIST_SIZE = dict(standard=5, rational=8, thin_prism=12, tilted=14, fisheye=4, pin4=4)
 
 
 def _make_camera(model, rng, focal=2250.0):
@@ -151,14 +162,16 @@ def _make_camera(model, rng, focal=2250.0):
     dist = np.array([0.05, 0.01, -0.005, 0.001]) * rng.uniform(0.8, 1.2, 4)
   else:
     dist = np.zeros(DIST_SIZE[model])
-    dist[:5] = np.array([-0.12, 0.3, 1e-3, -1e-3, -0.2]) * rng.uniform(0.8, 1.2, 5)
+    n5 = min(5, dist.size)
+    dist[:n5] = (np.array([-0.12, 0.3, 1e-3, -1e-3, -0.2]) * rng.uniform(0.8, 1.2, 5))[:n5]
     if model in ('rational', 'thin_prism', 'tilted'):
       dist[5:8] = np.array([0.02, -0.01, 0.005]) * rng.uniform(0.8, 1.2, 3)
     if model in ('thin_prism', 'tilted'):
       dist[8:12] = np.array([1e-3, -5e-4, 8e-4, 3e-4]) * rng.uniform(0.8, 1.2, 4)
     if model == 'tilted':
       dist[12:14] = np.array([0.01, -0.008]) * rng.uniform(0.8, 1.2, 2)
-  return SimpleNamespace(model=model, image_size=IMAGE_SIZE, intrinsic=K, dist=dist,
+  # (the reference's Camera.model enumerates OpenCV calibration flags; a 4-coefficient camera is a `standard` one)
+  return SimpleNamespace(model='standard' if model == 'pin4' else model, image_size=IMAGE_SIZE, intrinsic=K, dist=dist,
                          fix_aspect=False, has_skew=False)
 
 

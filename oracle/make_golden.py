@@ -14,7 +14,17 @@ Per case the fixture holds the inputs (synthetic rig arrays, multical_amd.synthe
   err0 / rms0   reprojection_error / error_stats at x0                 (calibration.py:134-136,304-310)
   ba_*          Calibration.bundle_adjust(**ba_kwargs) result          (calibration.py:199-212)
   ao_*          Calibration.adjust_outliers(num_adjustments=3, select_outliers=select_threshold(.75, 5))
-                as Workspace.calibrate drives it                       (workspace.py:228-247)
+                as Workspace.calibrate drives it                       (workspace.py:228-247); `ao_kwargs_json` holds the
+                Workspace.calibrate arguments (loss, auto_scale) of the case
+  *_tight_*     the CONVERGED optimum of the reference's own residual function (scipy's exact trust-region solver /
+                a dense Gauss-Newton polish on 3-point differences of the reference's `evaluate`)
+  *_pert_*      SELF-SENSITIVITY of the reference: the same reference call repeated with N(0, 1e-12 px) noise added to
+                its residual function (a few ulp of a 2000 px coordinate).  scipy's forward differences (h ~ 1.5e-8)
+                amplify that noise 1e8-fold into the Jacobian, and LSMR-truncated steps + ftol=1e-4 stop the run before
+                convergence, so the reference's default-tolerance end point is only defined up to this spread.
+
+Big configurations (cfg2, cfg3_40, cfg4_40, cfg5_40) are stored RESULT-ONLY: the rig is regenerated from its seed by
+multical_amd.synthetic.make_rig (checksums of the observation table are kept in the fixture).
 """
 import io
 import os
@@ -74,7 +84,26 @@ CASES = {
   "tiny_arctan": ("tiny", None, dict(loss='arctan', f_scale=3.0), False, False),
   "tiny_boards": ("tiny", _adjust_board, {}, False, True),
   "cfg1": ("cfg1", None, {}, True, False),
+  "tiny_pin4": ("tiny_pin4", None, {}, True, True),
+  # Workspace.calibrate(loss=..., auto_scale=...) (workspace.py:239-244): f_scale = quantile_0.75(errors) * auto_scale
+  "tiny_autoscale": ("tiny", None, dict(loss='soft_l1', f_scale=1.5), True, False),
+  "tiny_autoscale_huber": ("tiny_rolling", None, dict(loss='huber', f_scale=2.0), True, False),
 }
+
+AO_KWARGS = {   # Workspace.calibrate arguments of the adjust_outliers run (default: loss='linear', no auto_scale)
+  "tiny_autoscale": dict(loss='soft_l1', auto_scale=2.0),
+  "tiny_autoscale_huber": dict(loss='huber', auto_scale=1.0),
+}
+
+# result-only goldens of the BASELINE configurations: (config name, frames or None = as configured)
+BIG_CASES = {
+  "cfg2": ("cfg2", None),
+  "cfg3_40": ("cfg3_40", None),
+  "cfg4_40": ("cfg4_40", None),
+  "cfg5_40": ("cfg5_40", None),
+}
+N_PERT = 3            # perturbed re-runs per reference call
+PERT_SIGMA = 1e-12    # px
 
 
 def fd_jacobian(calib, x0, f0):
@@ -94,6 +123,164 @@ def fd_jacobian(calib, x0, f0):
   return csr_matrix(J), int(groups.max()) + 1
 
 
+class _Spy(object):
+  """Wraps scipy.optimize.least_squares (the call at calibration.py:209-210): records the OptimizeResults and, when
+  `sigma` > 0, adds N(0, sigma) noise to the reference's residual function (self-sensitivity runs)."""
+
+  def __init__(self, sigma=0.0, seed=0):
+    from scipy import optimize
+    self.optimize = optimize
+    self.real = optimize.least_squares
+    self.results = []
+    self.sigma = sigma
+    self.rng = np.random.default_rng(seed)
+
+  def __enter__(self):
+    def spy(fun, x0, *a, **k):
+      f = fun
+      if self.sigma > 0:
+        f = lambda x: (lambda r: r + self.rng.normal(size=r.size) * self.sigma)(fun(x))
+      res = self.real(f, x0, *a, **k)
+      self.results.append(res)
+      return res
+    self.optimize.least_squares = spy
+    return self
+
+  def __exit__(self, *a):
+    self.optimize.least_squares = self.real
+
+
+def _evaluate(c0, x):
+  c = c0.with_param_vec(x)
+  return (c.reprojected.points - c.point_table.points)[c0.inliers].ravel()
+
+
+def _dense_polish(calib, x, iters=12):
+  """Converged optimum of the reference's residual function on the inlier set of `calib`, for problems too large for
+  scipy's exact (SVD) trust-region solver: damped Gauss-Newton on the DENSE normal equations of the reference's own
+  `evaluate`, Jacobian by scipy's 3-point differences with the reference's sparsity (column scaling like x_scale='jac',
+  damping 1e-10 in the scaled space: the 12 gauge directions have zero gradient).  Independent of the HIP code."""
+  from scipy.optimize._numdiff import approx_derivative, group_columns
+  from scipy.sparse import csr_matrix
+  S = csr_matrix(calib.sparsity_matrix)
+  groups = group_columns(S)
+  fun = lambda v: _evaluate(calib, v)
+  f = fun(x)
+  cost = 0.5 * f @ f
+  for it in range(iters):
+    J = csr_matrix(approx_derivative(fun, x, method='3-point', f0=f, sparsity=(S, groups)))
+    H = (J.T @ J).toarray()
+    g = J.T @ f
+    d = np.sqrt(np.diag(H))
+    d[d == 0] = 1
+    Hs = H / d[:, None] / d[None, :]
+    step = -np.linalg.solve(Hs + 1e-10 * np.eye(x.size), g / d) / d
+    lam = 1.0
+    while lam > 1e-4:
+      fn = fun(x + lam * step)
+      cn = 0.5 * fn @ fn
+      if cn <= cost:
+        break
+      lam *= 0.5
+    if not cn <= cost:
+      break
+    rel = (cost - cn) / cost
+    x, f, cost = x + lam * step, fn, cn
+    if rel < 1e-15:
+      break
+  return x, cost
+
+
+def _reference_runs(calib, ref, out, ba_kwargs, ao_kwargs, run_ao, exact_polish):
+  """bundle_adjust / adjust_outliers through the reference entry points + tight optima + self-sensitivity."""
+  error_stats = ref.optimization_calibration.error_stats
+  select_threshold = ref.optimization_calibration.select_threshold
+  log = io.StringIO()
+  import logging
+  handler = logging.StreamHandler(log)
+  logger = logging.getLogger("calibration")
+  logger.addHandler(handler)
+  logger.setLevel(logging.INFO)
+  logger.propagate = False
+
+  def polish(c, x, loss='linear', f_scale=1.0):
+    if exact_polish:
+      res_t = _Spy().real(lambda v: _evaluate(c, v), x, jac='3-point', x_scale='jac', tr_solver='exact', loss=loss,
+                          f_scale=f_scale, ftol=1e-15, xtol=1e-15, gtol=1e-15, max_nfev=400, method='trf')
+      return res_t.x, res_t.cost, res_t.status, res_t.optimality
+    assert loss == 'linear'
+    xt, cost = _dense_polish(c, x)
+    return xt, cost, -1, np.nan
+
+  def ao_args():
+    kw = dict(ao_kwargs)
+    auto_scale = kw.pop("auto_scale", None)
+    return dict(num_adjustments=3, select_outliers=select_threshold(quantile=0.75, factor=5.0),
+                select_scale=select_threshold(quantile=0.75, factor=auto_scale) if auto_scale is not None else None,
+                loss=kw.get("loss", 'linear'), tolerance=1e-4)
+
+  try:
+    with _Spy() as spy:
+      ba = calib.bundle_adjust(**ba_kwargs)
+      res = spy.results[-1]
+    out["ba_kwargs_json"] = np.array(json.dumps(ba_kwargs))
+    out["ba_x"] = ba.param_vec          # canonicalised by with_param_vec -> from_matrix (rtvec.py:29-32)
+    out["ba_x_raw"] = res.x             # scipy's res.x (raw rotation vectors)
+    out["ba_cost"], out["ba_optimality"] = res.cost, res.optimality
+    out["ba_nfev"], out["ba_njev"], out["ba_status"] = res.nfev, res.njev, res.status
+    out["ba_rms"] = error_stats(ba.reprojection_error).rms
+    out["ba_log"] = np.array(log.getvalue())
+    xt, cost_t, status_t, opt_t = polish(calib, res.x, ba_kwargs.get("loss", "linear"), ba_kwargs.get("f_scale", 1.0))
+    out["ba_tight_x"], out["ba_tight_cost"], out["ba_tight_status"] = xt, cost_t, status_t
+    out["ba_tight_rms"] = error_stats(calib.with_param_vec(xt).reprojection_error).rms
+    pert = []
+    for k in range(N_PERT):
+      with _Spy(PERT_SIGMA, seed=100 + k) as spy:
+        bp = calib.bundle_adjust(**ba_kwargs)
+        pert.append((error_stats(bp.reprojection_error).rms, spy.results[-1].nfev, spy.results[-1].cost))
+    out["ba_pert_rms"] = np.array([p[0] for p in pert])
+    out["ba_pert_nfev"] = np.array([p[1] for p in pert])
+    out["ba_pert_cost"] = np.array([p[2] for p in pert])
+
+    if run_ao:
+      with _Spy() as spy:
+        ao = calib.adjust_outliers(**ao_args())
+        results = list(spy.results)
+      out["ao_kwargs_json"] = np.array(json.dumps(ao_kwargs))
+      out["ao_x"] = ao.param_vec
+      out["ao_x_raw"] = results[-1].x
+      out["ao_inliers"] = ao.inliers
+      out["ao_rms"] = error_stats(ao.reprojection_error).rms
+      out["ao_rms_inliers"] = error_stats(ao.reprojection_inliers).rms
+      out["ao_nfev"] = np.array([r.nfev for r in results])
+      out["ao_cost"] = np.array([r.cost for r in results])
+      out["ao_log"] = np.array(log.getvalue())
+      if ao_kwargs.get("loss", "linear") == "linear":
+        # converged optimum of the reference's residual function on the final inlier set: the value any converged
+        # solver must reach (SURVEY.md 7, hard part 1).  scipy's default LSMR trust-region solver does not converge
+        # tightly on these problems (hundreds of evaluations, status 0), so the polish uses scipy's exact (SVD)
+        # trust-region solver with 3-point differences of the reference's own `evaluate` (dense Gauss-Newton on the
+        # same differences for the big configurations).
+        xt, cost_t, status_t, opt_t = polish(ao, results[-1].x)
+        tight = ao.with_param_vec(xt)
+        out["ao_tight_rms"] = error_stats(tight.reprojection_error).rms
+        out["ao_tight_rms_inliers"] = error_stats(tight.reprojection_inliers).rms
+        out["ao_tight_cost"] = cost_t
+        out["ao_tight_status"] = status_t
+        out["ao_tight_optimality"] = opt_t
+      pert = []
+      for k in range(N_PERT):
+        with _Spy(PERT_SIGMA, seed=200 + k):
+          ap = calib.adjust_outliers(**ao_args())
+        pert.append((error_stats(ap.reprojection_error).rms, error_stats(ap.reprojection_inliers).rms,
+                     int(np.sum(ap.inliers != ao.inliers))))
+      out["ao_pert_rms"] = np.array([p[0] for p in pert])
+      out["ao_pert_rms_inliers"] = np.array([p[1] for p in pert])
+      out["ao_pert_mask_diff"] = np.array([p[2] for p in pert])
+  finally:
+    logger.removeHandler(handler)
+
+
 def run_case(name):
   cfg, mutate, ba_kwargs, run_ao, store_j = CASES[name]
   rig = synthetic.make_rig(cfg)
@@ -102,16 +289,10 @@ def run_case(name):
     rig = mutate(rig)
   calib, ref = build_reference.reference_calibration(rig)
   error_stats = ref.optimization_calibration.error_stats
-  select_threshold = ref.optimization_calibration.select_threshold
 
   out = synthetic.rig_to_arrays(rig)
   x0 = calib.param_vec
-
-  def evaluate(c0, x):
-    c = c0.with_param_vec(x)
-    return (c.reprojected.points - c.point_table.points)[c0.inliers].ravel()
-
-  r0 = evaluate(calib, x0)
+  r0 = _evaluate(calib, x0)
   out["x0"], out["r0"] = x0, r0
   out["inliers0"] = calib.inliers
   err0 = calib.reprojection_error
@@ -131,74 +312,57 @@ def run_case(name):
     out["JTr"] = J.T @ r0
     out["J_groups"] = n_groups
 
-  # --- bundle_adjust through the reference entry point, scipy's table captured via the logger ------
-  log = io.StringIO()
-  import logging
-  handler = logging.StreamHandler(log)
-  logger = logging.getLogger("calibration")
-  logger.addHandler(handler)
-  logger.setLevel(logging.INFO)
-  logger.propagate = False
-
-  # the reference returns only the new Calibration; recover scipy's counters by wrapping least_squares
-  from scipy import optimize
-  results = []
-  real_lsq = optimize.least_squares
-
-  def spy(*a, **k):
-    res = real_lsq(*a, **k)
-    results.append(res)
-    return res
-
-  optimize.least_squares = spy
-  try:
-    ba = calib.bundle_adjust(**ba_kwargs)
-    res = results[-1]
-    out["ba_kwargs_json"] = np.array(json.dumps(ba_kwargs))
-    out["ba_x"] = ba.param_vec          # canonicalised by with_param_vec -> from_matrix (rtvec.py:29-32)
-    out["ba_x_raw"] = res.x             # scipy's res.x (raw rotation vectors)
-    out["ba_cost"], out["ba_optimality"] = res.cost, res.optimality
-    out["ba_nfev"], out["ba_njev"], out["ba_status"] = res.nfev, res.njev, res.status
-    out["ba_rms"] = error_stats(ba.reprojection_error).rms
-    out["ba_log"] = np.array(log.getvalue())
-
-    if run_ao:
-      results.clear()
-      ao = calib.adjust_outliers(num_adjustments=3, select_outliers=select_threshold(quantile=0.75, factor=5.0),
-                                 loss='linear', tolerance=1e-4)
-      out["ao_x"] = ao.param_vec
-      out["ao_inliers"] = ao.inliers
-      out["ao_rms"] = error_stats(ao.reprojection_error).rms
-      out["ao_rms_inliers"] = error_stats(ao.reprojection_inliers).rms
-      out["ao_nfev"] = np.array([r.nfev for r in results])
-      out["ao_cost"] = np.array([r.cost for r in results])
-      # converged optimum of the reference's residual function on the final inlier set: the value any converged
-      # solver must reach (hard part 1).  scipy's default LSMR trust-region solver does not converge
-      # tightly on these problems (hundreds of evaluations, status 0), so the polish uses scipy's exact (SVD)
-      # trust-region solver with 3-point differences of the reference's own `evaluate`.
-      res_t = real_lsq(lambda x: evaluate(ao, x), ao.param_vec, jac='3-point', x_scale='jac', tr_solver='exact',
-                       ftol=1e-15, xtol=1e-15, gtol=1e-15, max_nfev=400, method='trf')
-      tight = ao.with_param_vec(res_t.x)
-      out["ao_tight_rms"] = error_stats(tight.reprojection_error).rms
-      out["ao_tight_rms_inliers"] = error_stats(tight.reprojection_inliers).rms
-      out["ao_tight_cost"] = res_t.cost
-      out["ao_tight_status"] = res_t.status
-      out["ao_tight_optimality"] = res_t.optimality
-  finally:
-    optimize.least_squares = real_lsq
-    logger.removeHandler(handler)
+  _reference_runs(calib, ref, out, ba_kwargs, AO_KWARGS.get(name, {}), run_ao, exact_polish=True)
 
   os.makedirs(GOLDEN_DIR, exist_ok=True)
   path = os.path.join(GOLDEN_DIR, f"{name}.npz")
   np.savez_compressed(path, **out)
   print(f"{name}: n={x0.size} m={r0.size} rms0={float(out['rms0']):.4f} ba_rms={float(out['ba_rms']):.6f} "
-        f"nfev={int(out['ba_nfev'])} -> {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+        f"nfev={int(out['ba_nfev'])} pert spread {np.abs(out['ba_pert_rms'] - out['ba_rms']).max():.1e} "
+        f"-> {path} ({os.path.getsize(path) / 1024:.0f} KiB)", flush=True)
+
+
+def run_big_case(name):
+  """Result-only golden of a BASELINE configuration: the rig is regenerated from its seed on the test side."""
+  import time
+  cfg, frames = BIG_CASES[name]
+  rig = synthetic.make_rig(cfg, frames=frames)
+  rig.name = name
+  calib, ref = build_reference.reference_calibration(rig)
+  error_stats = ref.optimization_calibration.error_stats
+  out = dict(config=np.array(cfg), frames=np.array(rig.valid.shape[1]),
+             points_sum=np.array(rig.points.sum()), points_abs_sum=np.array(np.abs(rig.points).sum()),
+             valid_count=np.array(int(rig.valid.sum())), shape=np.array(rig.valid.shape))
+  x0 = calib.param_vec
+  t0 = time.time()
+  r0 = _evaluate(calib, x0)
+  out["x0"] = x0
+  out["r0_sum"], out["r0_sq"], out["r0_size"] = r0.sum(), r0 @ r0, r0.size
+  out["r0_head"] = r0[:64]
+  out["rms0"] = error_stats(calib.reprojection_error).rms
+  full = {}
+  _reference_runs(calib, ref, full, {}, {}, True, exact_polish=False)
+  for k, v in full.items():
+    if k == "ao_inliers":
+      out["ao_inliers_packed"] = np.packbits(v.ravel())
+    else:
+      out[k] = v
+  out["seconds"] = time.time() - t0
+  path = os.path.join(GOLDEN_DIR, f"{name}.npz")
+  np.savez_compressed(path, **out)
+  print(f"{name}: n={x0.size} m={r0.size} ba_rms={float(out['ba_rms']):.6f} ao_rms_inliers={float(out['ao_rms_inliers']):.6f} "
+        f"tight {float(out['ao_tight_rms_inliers']):.6f} pert spread ba {np.abs(out['ba_pert_rms'] - out['ba_rms']).max():.1e} "
+        f"ao {np.abs(out['ao_pert_rms_inliers'] - out['ao_rms_inliers']).max():.1e} mask diffs {out['ao_pert_mask_diff']} "
+        f"in {out['seconds']:.0f} s -> {path} ({os.path.getsize(path) / 1024:.0f} KiB)", flush=True)
 
 
 def main(argv):
   names = argv or list(CASES)
   for n in names:
-    run_case(n)
+    if n in BIG_CASES:
+      run_big_case(n)
+    else:
+      run_case(n)
 
 
 if __name__ == "__main__":

@@ -148,8 +148,8 @@ class _Fisheye(object):
   @staticmethod
   def projectPoints(objectPoints, rvec, tvec, K, D, alpha=0, *args, **kwargs):
     """Kannala-Brandt (cv::fisheye::projectPoints): theta_d = theta(1+k1 th^2+k2 th^4+k3 th^6+k4 th^8),
-    u = fx (x' + alpha y') + cx with alpha = K[0,1]/fx when called with the camera matrix (the python
-    binding's `alpha` argument defaults to 0 and the skew is taken from K), v = fy y' + cy."""
+    u = fx (x' + alpha y') + cx, v = fy y' + cy, where the skew is the separate `alpha` ARGUMENT (default 0);
+    K[0,1] is never read (see the comment below; the reference calls it without alpha, camera_fisheye.py:115-117)."""
     wrapped = isinstance(objectPoints, UMat)
     pts = _unwrap(objectPoints).astype(np.float64).reshape(-1, 3)
     R = _rodrigues(_unwrap(rvec))
