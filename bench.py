@@ -13,8 +13,12 @@ step    : ONE fused residual+Jacobian evaluation reduced to the normal equations
 workload: BASELINE.json configs[2], the rig the north star quotes the metric on: 8 cameras x 500 frames x 2 boards
           (charuco_16x22 + aprilgrid_9x9), rolling-shutter motion model, intrinsics + extrinsics optimised, synthetic
           data (multical_amd.synthetic, seed 3).  Inputs are resident in HBM before the timed region.
-scaling : weak -- every rank owns a 500-frame shard of one 8 x (500 N) x 2 rig (frame sharding); `value`
-          counts shard evaluations (N per pass), so at N = 1 it is exactly evaluations/s of the north-star rig.
+scaling : `value` is WEAK scaling -- every rank owns a 500-frame shard of one 8 x (500 N) x 2 rig (frame sharding, SURVEY
+          8(e)) and `value` counts shard evaluations (N per pass), so at N = 1 it is exactly evaluations/s of the
+          north-star rig.  For N > 1 the same line also carries `strong_scaling`: the FIXED 8 x 500 x 2 rig of the north
+          star split over the N ranks (500 / N frames each), evaluations/s of that one rig -- the wording of
+          BASELINE.json's north star.  At 62 frames per GPU k_linearize is latency-bound, so the strong number is the
+          harder one; both are measured in the same run with the same timing protocol.
 """
 import argparse
 import json
@@ -61,6 +65,20 @@ def cpu_baseline(n_frames_sample=25):
       break
   dt = (time.perf_counter() - t0) / reps
   evals_per_s_sample = 1.0 / dt
+  # one LSMR iteration of the reference's linear solve = one J v and one J^T u (scipy lsmr: 2 sparse mat-vecs + O(m + n)
+  # vector work); a TRF iteration runs up to min(m, n) of them (74 % of the reference's wall time)
+  v = np.ones(x0.size)
+  t1 = time.perf_counter()
+  for _ in range(20):
+    u = J @ v
+    w = J.T @ u
+  t_lsmr_iter = (time.perf_counter() - t1) / 20
+  # one complete TRF iteration of the reference on the sample (Jacobian + LSMR solve + trial evaluations): two iterations
+  # of the reference's own bundle_adjust, timed as a whole
+  t1 = time.perf_counter()
+  ba = oc.bundle_adjust(max_iterations=3, return_result=True)[1]
+  t_ba = time.perf_counter() - t1
+  lm_iters_per_s_sample = max(ba.nfev - 1, 1) / t_ba
   scale = n_frames_sample / FRAMES_PER_SHARD         # cost is linear in the number of frames
   return dict(value=evals_per_s_sample * scale, unit="evals/s", cores=1, kind="port",
               sample=(f"first {n_frames_sample} of {FRAMES_PER_SHARD} frames of the same rig (m={f0.size} residuals, "
@@ -68,7 +86,11 @@ def cpu_baseline(n_frames_sample=25):
                       f"({int(groups.max()) + 1} FD column groups), {dt:.2f} s each, sparsity build {t_sparsity:.1f} s "
                       f"not counted; extrapolated linearly in frames to the 500-frame rig; host has "
                       f"{os.cpu_count()} logical cores, numpy/scipy path is single-threaded"),
-              evals_per_s_on_sample=evals_per_s_sample)
+              evals_per_s_on_sample=evals_per_s_sample,
+              lm_iters_per_s=lm_iters_per_s_sample * scale, lm_iters_per_s_on_sample=lm_iters_per_s_sample,
+              lsmr_iteration_ms_on_sample=t_lsmr_iter * 1e3,
+              lm_note=(f"reference TRF on the same sample: {ba.nfev - 1} trial steps (max_nfev = 3) in {t_ba:.1f} s incl. "
+                       f"finite-difference Jacobians and LSMR; one LSMR iteration (J v + J^T u) = {t_lsmr_iter * 1e3:.1f} ms"))
 
 
 def main():
@@ -146,20 +168,46 @@ def main():
     # the same evaluation through the host boundary: x upload (49 KB), cost download, one synchronisation per call
     check(h.lib.mcba_normal_equations(h.h, _ptr(xbuf, C.c_double), C.byref(opt), C.byref(cost), None, None))
 
-  for _ in range(args.warmup):
-    step()
-  barrier()
-  t0 = time.perf_counter()
-  for _ in range(args.steps):
-    step()
-  barrier()
-  dt = time.perf_counter() - t0
-  if world > 1:
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+  def timed(fn):
+    """W untimed warm-up steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks."""
+    for _ in range(args.warmup):
+      fn()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+      fn()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+      tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+      dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+      dt = float(tmax.item())
+    return dt
+
+  dt = timed(step)
   ms_per_step = dt / args.steps * 1e3
   value = world * args.steps / dt                       # shard evaluations per second, whole job
+
+  # ---- strong scaling (N > 1): the FIXED 8 x 500 x 2 rig of the north star, 500 / N frames per rank ---------------
+  strong = None
+  if world > 1:
+    sshards = mdist.frame_shards(FRAMES_PER_SHARD, world)
+    srig = synthetic.make_rig("cfg3", frames=FRAMES_PER_SHARD, obs_frames=sshards[rank])
+    scalib = calibration.from_rig(srig)
+    hs = Handle(lower(scalib), frame_range=sshards[rank], stream=tstream.cuda_stream)
+    snative = False
+    if backend == "nccl" and os.environ.get("MCBA_NO_NATIVE_RCCL", "0") != "1":
+      snative = mdist.init_native_allreduce(hs, rank, world)
+    if not snative:
+      hs.set_allreduce(mdist.make_allreduce_hook(stream=tstream))
+    hs.set_shard_root(rank == 0)
+    sx = np.ascontiguousarray(scalib.param_vec)
+    check(hs.lib.mcba_normal_equations(hs.h, _ptr(sx, C.c_double), C.byref(opt), C.byref(cost), None, None))
+    sdt = timed(lambda: check(hs.lib.mcba_normal_equations_device(hs.h, C.byref(opt))))
+    strong = dict(value=args.steps / sdt, unit="evals/s of the fixed 8 x 500 x 2 rig", ms_per_step=sdt / args.steps * 1e3,
+                  frames_per_gpu=[b - a for a, b in sshards], scaling="strong",
+                  note="one rig, frame-sharded over all ranks; every evaluation ends with the all-reduce of [g | diag | cost]")
+    hs.close()
   # PCIe-inclusive variant (never `value`): every evaluation enters and leaves through the host boundary
   barrier()
   t0 = time.perf_counter()
@@ -185,10 +233,15 @@ def main():
                   hbm=dict(achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS),
                   residual_kernel=dict(bound="hbm", launch_ms=res_ms, achieved=alg_bytes / (res_ms * 1e-3) / 1e9,
                                        frac=alg_bytes / (res_ms * 1e-3) / 1e9 / HBM_PEAK_GBS))
+  # HBM bytes per launch from the PMC counters: they cannot be read inside an un-profiled run, so the figure of the
+  # committed rocprofv3 passes of the same command is quoted and labelled as such (profiles/hbm_traffic.json: separate
+  # --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction)
   traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic.json")
   if os.path.exists(traffic_file):
     try:
-      roofline["traffic"] = json.load(open(traffic_file)).get("k_linearize_bytes_per_launch")
+      tj = json.load(open(traffic_file))
+      roofline["traffic"] = tj.get("k_linearize_bytes_per_launch")
+      roofline["traffic_source"] = "profiles/hbm_traffic.json (" + str(tj.get("source", "rocprofv3 --pmc passes")) + "), not measured in this run"
     except Exception:
       pass
 
@@ -218,12 +271,15 @@ def main():
                                     f"(charuco_16x22 + aprilgrid_9x9), rolling-shutter motion, intrinsics+extrinsics; "
                                     f"{world} frame shard(s) of one 8 x {F_total} x 2 rig",
                            n_params=int(h.n_params), n_slots_per_gpu=n_slots, n_observations_per_gpu=int(n_obs),
+                           observation_fill=float(n_obs) / n_slots,   # evals/s is linear in observations, not in slots
                            parallelism=(f"frame-sharded x{world}, " + ("native RCCL all-reduce" if native else
                                         f"torch.distributed ({backend}) all-reduce hook")) if world > 1 else "single GPU",
                            device=h.device_info()),
                host_boundary=dict(ms_per_step=host_ms_per_step, evals_per_s=world * 1e3 / host_ms_per_step,
                                   note="same evaluation with x uploaded and the cost downloaded on every call"),
                roofline=roofline, **extra)
+    if strong is not None:
+      out["strong_scaling"] = strong
     if world == 1 and not args.no_cpu_baseline:
       out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out), flush=True)

@@ -147,7 +147,7 @@ class Handle(object):
     n = C.c_int64()
     check(self.lib.mcba_num_params(self.h, C.byref(n)))
     self.n_params = n.value
-    self._callbacks = []
+    self._log_cb = self._allreduce_cb = None    # the currently installed ctypes thunks (kept alive, one per kind)
     self.shape = self.problem.shape
 
   def close(self):
@@ -331,8 +331,8 @@ class Handle(object):
       cb = C.cast(None, _lib.LOG_FN)
     else:
       cb = _lib.LOG_FN(lambda ctx, it, nfev, cost, red, step, opt: fn(it, nfev, cost, red, step, opt))
-    self._callbacks.append(cb)
     check(self.lib.mcba_set_log(self.h, cb, None))
+    self._log_cb = cb        # replaces (and releases) the previous thunk
 
   def set_shard_root(self, is_root):
     check(self.lib.mcba_set_shard_root(self.h, 1 if is_root else 0))
@@ -350,8 +350,8 @@ class Handle(object):
           traceback.print_exc()
           return 1
       cb = _lib.ALLREDUCE_FN(tramp)
-    self._callbacks.append(cb)
     check(self.lib.mcba_set_allreduce(self.h, cb, None))
+    self._allreduce_cb = cb
 
   # --- native RCCL all-reduce (multical_amd.distributed.init_native_allreduce drives these) ----------------------
   @staticmethod

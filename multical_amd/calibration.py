@@ -55,30 +55,46 @@ def error_stats(errors):
 class _HandleCache(object):
   def __init__(self, capacity=2):
     self.capacity = capacity
-    # (key, x_full, handle, inlier mask object).  The mask OBJECT is the token (compared with `is`): Calibration objects
-    # are immutable, and holding the reference keeps the id from being recycled; hashing 2.6 MB of mask bytes on every
-    # lookup cost 0.6 ms x 16 lookups per Workspace.calibrate.
+    # entries: dict(key, points, valid, x_full, handle, mask).  `points` / `valid` are the ORIGINAL arrays of the point
+    # table the handle was built from, held strongly: identity (`is`) is the fast test, and holding the reference keeps
+    # an id from being recycled by a later table of the same shape (float32 detections are widened into a copy, so the
+    # handle itself would not keep the original alive).  A table with equal content but another identity (e.g.
+    # `point_table._extend(valid=...)` keeps `points`, replaces `valid`) is compared by value.  The inlier mask OBJECT is
+    # a token compared with `is` first: hashing 2.6 MB of mask bytes on every lookup cost 0.6 ms x 16 lookups per
+    # Workspace.calibrate.
     self.entries = []
 
+  @staticmethod
+  def _same_array(a, b):
+    return a is b or (a.shape == b.shape and a.dtype == b.dtype and np.array_equal(a, b))
+
   def get(self, calib):
-    prob = lower(calib)
-    key = (id(calib.point_table.points), prob.shape, prob.optimize, prob.motion, prob.camera_model, prob.n_dist,
-           prob.fix_aspect.tobytes(), prob.camera_valid.tobytes(), prob.frame_valid.tobytes(),
-           prob.board_valid.tobytes(), prob.board_sizes.tobytes())
-    for i, (k, xf, h, tok) in enumerate(self.entries):
-      if k == key and h.h and np.array_equal(self._constants(calib, prob, xf), self._constants(calib, prob, prob.x_full)) \
+    prob = getattr(calib, "_mcba_problem", None)     # Calibration objects are immutable: lower once per object
+    if prob is None:
+      prob = lower(calib)
+      try:
+        calib._mcba_problem = prob                   # (not part of __getstate__: never pickled)
+      except AttributeError:
+        pass
+    key = (prob.shape, prob.optimize, prob.motion, prob.camera_model, prob.n_dist, prob.fix_aspect.tobytes(),
+           prob.camera_valid.tobytes(), prob.frame_valid.tobytes(), prob.board_valid.tobytes(),
+           prob.board_sizes.tobytes(), prob.image_heights.tobytes())
+    points, valid = calib.point_table.points, calib.point_table.valid
+    for i, e in enumerate(self.entries):
+      h = e["handle"]
+      if e["key"] == key and h.h and self._same_array(e["points"], points) and self._same_array(e["valid"], valid) \
+          and np.array_equal(self._constants(calib, prob, e["x_full"]), self._constants(calib, prob, prob.x_full)) \
           and (prob.base_wrt_gripper is None or np.array_equal(prob.base_wrt_gripper, h.problem.base_wrt_gripper)):
-        mask = calib.inlier_mask
+        mask, tok = calib.inlier_mask, e["mask"]
         if mask is not tok:
           if mask is None or tok is None or not np.array_equal(mask, tok):
             h.set_inliers(mask)
-          self.entries[i] = (k, xf, h, mask)
+          e["mask"] = mask
         return h, prob
     h = Handle(prob)
-    self.entries.append((key, prob.x_full, h, calib.inlier_mask))
+    self.entries.append(dict(key=key, points=points, valid=valid, x_full=prob.x_full, handle=h, mask=calib.inlier_mask))
     while len(self.entries) > self.capacity:
-      _, _, old, _ = self.entries.pop(0)
-      old.close()
+      self.entries.pop(0)["handle"].close()
     return h, prob
 
   @staticmethod
@@ -93,13 +109,13 @@ class _HandleCache(object):
 
   def note_inliers(self, handle, mask):
     """the device already holds `mask` (set by reject_outliers): remember its token so it is not uploaded again."""
-    for i, (k, xf, h, _) in enumerate(self.entries):
-      if h is handle:
-        self.entries[i] = (k, xf, h, mask)
+    for e in self.entries:
+      if e["handle"] is handle:
+        e["mask"] = mask
 
   def clear(self):
-    for _, _, h, _ in self.entries:
-      h.close()
+    for e in self.entries:
+      e["handle"].close()
     self.entries = []
 
 
@@ -243,8 +259,11 @@ class Calibration(parameters.Parameters):
     h.set_log(log_row)
     info("{:^15}{:^15}{:^15}{:^15}{:^15}{:^15}".format("Iteration", "Total nfev", "Cost", "Cost reduction",
                                                        "Step norm", "Optimality"))
-    res = h.solve(self.param_vec, tolerance=tolerance, f_scale=f_scale, max_iterations=max_iterations, loss=loss,
-                  xtol=xtol, gtol=gtol, verbose=2)
+    try:
+      res = h.solve(self.param_vec, tolerance=tolerance, f_scale=f_scale, max_iterations=max_iterations, loss=loss,
+                    xtol=xtol, gtol=gtol, verbose=2)
+    finally:
+      h.set_log(None)        # cached handles outlive the call: do not keep the closure over `rows` installed
     for r in rows:
       info(r)
     info(res.message)

@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "../../include/mcba.h"
+#include "mcba_debug.h"
 #include "mcba_camops.h"
 #include "mcba_lower.h"
 #include "mcba_solver_kernels.h"
@@ -256,6 +257,8 @@ struct RcclApi {
   int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
+  int (*GetVersion)(int*) = nullptr;
+  int version = 0;
   bool ok = false;
 };
 const RcclApi& rccl_api() {
@@ -269,7 +272,13 @@ const RcclApi& rccl_api() {
     a.AllReduce = (decltype(a.AllReduce))dlsym(lib, "ncclAllReduce");
     a.CommDestroy = (decltype(a.CommDestroy))dlsym(lib, "ncclCommDestroy");
     a.GetErrorString = (decltype(a.GetErrorString))dlsym(lib, "ncclGetErrorString");
-    a.ok = a.GetUniqueId && a.CommInitRank && a.AllReduce && a.CommDestroy;
+    a.GetVersion = (decltype(a.GetVersion))dlsym(lib, "ncclGetVersion");
+    // The enumerator values hard-coded above (ncclSum = 0, ncclMax = 2, ncclFloat64 = 8) and the by-value 128-byte
+    // ncclUniqueId are those of the NCCL 2.x ABI that RCCL ships (2.26 in this image); refuse anything else rather than
+    // reduce with the wrong operator.  ncclGetVersion reports major * 10000 + minor * 100 + patch.
+    if (a.GetVersion && a.GetVersion(&a.version) != 0) a.version = 0;
+    const bool abi_ok = a.version >= 20000 && a.version < 30000;
+    a.ok = a.GetUniqueId && a.CommInitRank && a.AllReduce && a.CommDestroy && abi_ok;
     return a;
   }();
   return api;
@@ -292,14 +301,22 @@ int call_allreduce(mcba_handle_s* h, double* buf, size_t count, int op) {
 }
 
 
-// fused residual+Jacobian -> block normal equations at the current tables
-void launch_linearize(mcba_handle_s* h) {
+// fused residual+Jacobian -> block normal equations.  dx != nullptr: at the parameter vector dx (device); k_tmat then also
+// prepares the pose / camera / board-point tables (no k_prep launch).  dx == nullptr: at the tables already prepared
+// (the trial step that was just accepted ran k_prep for its cost evaluation).
+void launch_linearize(mcba_handle_s* h, const double* dx) {
   const Dims& d = h->d;
   // k_tmat also zeroes [g | diag | cost] and H_ss for the assembly that follows (entries of frames owned by other ranks
   // must be zero before the cross-rank sum: they hold the previous global values after an all-reduce)
   static_assert(TMV * 4 <= 64, "k_tmat: (view, pose block) threads of a workgroup");
-  hipLaunchKernelGGL(k_tmat, dim3(std::max((d.views() + TMV - 1) / TMV, 1)), dim3(64), 0, h->stream, d, h->t, h->gbuf.p,
-                     2 * d.n + 2, h->Hss.p, d.ns * d.ns);
+  const int nb_views = std::max((d.views() + TMV - 1) / TMV, 1);
+  if (dx != nullptr && tmat_local_poses(d) > TM_LOCAL_POSES) {   // unusual shape: separate table pass
+    eval_pose_tables(h, dx);
+    dx = nullptr;
+  }
+  const int nb_prep = dx ? (d.n_pose + d.C + d.B * d.P + 63) / 64 : 0;
+  hipLaunchKernelGGL(k_tmat, dim3(nb_views + nb_prep), dim3(64), 0, h->stream, d, h->t, h->gbuf.p, 2 * d.n + 2, h->Hss.p,
+                     d.ns * d.ns, dx, nb_views);
   h->ops->linearize(d, h->t, h->stream, h->rec.p, h->tri.p, h->use_mfma, h->lin_grid);
 }
 
@@ -426,7 +443,10 @@ void launch_gn_solve(mcba_handle_s* h, double reg, bool root_rank, double* dots_
                      const double* tr_dev = nullptr) {
   const Dims& d = h->d;
   const int K = d.DF * d.Fl;
-  const bool sharded_frames = h->allreduce && K > 0;
+  // Whether the frame part of the step is reduced across ranks must not depend on THIS rank's shard size (an empty shard,
+  // K == 0, is legal: frame_shards produces them when there are fewer frames than ranks): every rank of a problem with
+  // eliminated frame parameters (DF > 0) joins the same sequence of collectives and contributes zeros where it owns nothing.
+  const bool sharded_frames = h->allreduce && d.DF > 0;
   // frame entries of other shards must be zero before the cross-rank sum; a single handle writes every entry of gn
   if (h->allreduce) HIP_OK(hipMemsetAsync(h->gn.p, 0, (size_t)d.n * sizeof(double), h->stream));
   double* fused_dots = sharded_frames ? nullptr : dots_out;
@@ -462,7 +482,7 @@ void launch_gn_solve(mcba_handle_s* h, double reg, bool root_rank, double* dots_
     hipLaunchKernelGGL((k_schur_backsub<6>), dim3(nblk), dim3(64), 0, h->stream, d, h->Lf.p, h->W.p, h->yf.p, h->ps.p,
                        h->gn.p, h->gh.p, h->info.p, fused_dots);
   }
-  if (h->allreduce && K > 0) {
+  if (sharded_frames) {
     // frame entries of gn are known only to the owning rank: zero the (replicated) shared entries on non-root ranks
     // is not needed -- every rank holds identical p_s; sum only the frame block.
     call_allreduce(h, h->gn.p + d.off_motion, (size_t)d.n_motion, 0);
@@ -904,8 +924,7 @@ int32_t mcba_normal_equations(mcba_handle h, const double* x, const mcba_options
   REQUIRE(h && x, "null argument");
   set_loss(h, opt);
   upload_x(h, x, h->x.p);
-  eval_pose_tables(h, h->x.p);   // (k_tmat, the first kernel of the linearisation, writes the view table)
-  launch_linearize(h);
+  launch_linearize(h, h->x.p);   // (k_tmat, the first kernel of the linearisation, prepares every table from x)
   launch_assemble(h);
   const Dims& d = h->d;
   // [g | diag | cost, count] comes down into pinned memory; only the two scalars when the vectors are not asked for
@@ -925,8 +944,7 @@ int32_t mcba_normal_equations_device(mcba_handle h, const mcba_options* opt) {
   API_BEGIN
   REQUIRE(h, "null handle");
   set_loss(h, opt);
-  eval_pose_tables(h, h->x.p);
-  launch_linearize(h);
+  launch_linearize(h, h->x.p);
   launch_assemble(h);
   API_END
 }
@@ -980,8 +998,7 @@ int32_t mcba_debug_linearize_profile(mcba_handle h, const double* x, long long* 
   h->dbg.alloc(n, true);
   h->t.dbg = h->dbg.p;
   upload_x(h, x, h->x.p);
-  eval_pose_tables(h, h->x.p);   // (k_tmat, the first kernel of the linearisation, writes the view table)
-  launch_linearize(h);
+  launch_linearize(h, h->x.p);
   h->t.dbg = nullptr;
   HIP_OK(hipMemcpyAsync(out, h->dbg.p, n * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
   sync(h);
@@ -1083,11 +1100,12 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
   double* S = h->h_scal;   // host copy of the scalar block scal[0 .. TR_NSLOTS)
 
   upload_x(h, x_inout, h->x.p);
-  eval_pose_tables(h, h->x.p);   // (k_tmat, the first kernel of every linearisation, writes the view table)
   float lin_ms_total = 0.f;
-  auto timed_linearize = [&]() {
+  // dx: linearise at that parameter vector (tables prepared by k_tmat itself); nullptr: the pose tables already hold the
+  // point (the trial step's k_prep)
+  auto timed_linearize = [&](const double* dx) {
     HIP_OK(hipEventRecord(h->ev0, h->stream));
-    launch_linearize(h);
+    launch_linearize(h, dx);
     HIP_OK(hipEventRecord(h->ev1, h->stream));
     launch_assemble(h);
   };
@@ -1095,26 +1113,31 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) lin_ms_total += ms;
   };
-  // the element-wise all-reduce of the k_cost partials needs the same count on every rank: shards differ in size
-  const int cost_grid = h->allreduce ? COST_BLOCKS_MAX : h->cost_blocks;
+  // k_cost partials: a single GPU copies them to the host with the other scalars (no extra launch); a sharded handle folds
+  // them on the device first, so that the trial cost crosses the ranks as ONE double
+  const int cost_grid = h->cost_blocks;
+  const int cost_fetch = h->allreduce ? 1 : cost_grid;
   // trial step for coefficients given by the host (retries) or by k_tr_step (tr_dev)
   auto enqueue_trial = [&](double alpha, double beta, const double* tr_dev) {
     hipLaunchKernelGGL(k_vec_step, dim3(sl.nvb), dim3(256), 0, h->stream, d, h->x.p, h->dsc.p, h->gh.p, h->gn.p, alpha, beta,
                        h->xnew.p, h->scal.p + sl.step, tr_dev);
     eval_pose_tables(h, h->xnew.p);   // k_cost forms the view chains itself; k_tmat rebuilds the view table if accepted
-    h->ops->cost(d, h->t, h->stream, h->scal.p + sl.costp, cost_grid);
-    call_allreduce(h, h->scal.p + sl.costp, (size_t)cost_grid, 0);
+    h->ops->cost(d, h->t, h->stream, h->scal.p + sl.costp, cost_grid);   // (an empty shard writes partial[0] = 0)
+    if (h->allreduce) {
+      hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(64), 0, h->stream, h->scal.p + sl.costp, cost_grid);
+      call_allreduce(h, h->scal.p + sl.costp, 1, 0);
+    }
   };
   auto fold_trial = [&](double* step_h2, double* step2, double* x2) {   // after a fetch that covers [sl.step, ...)
     double s3[3] = {0, 0, 0};
     for (int blk = 0; blk < sl.nvb; ++blk)
       for (int k = 0; k < 3; ++k) s3[k] += S[sl.step + 3 * blk + k];
     *step_h2 = s3[0]; *step2 = s3[1]; *x2 = s3[2];
-    return host_sum(S + sl.costp, cost_grid);
+    return host_sum(S + sl.costp, cost_fetch);
   };
-  const int trial_fetch_end = sl.costp + cost_grid;
+  const int trial_fetch_end = sl.costp + cost_fetch;
 
-  timed_linearize();
+  timed_linearize(h->x.p);
   int nfev = 1, njev = 1, iteration = 0, status = -100;
   bool first = true, fresh_lin = true, lin_stale = false;
   double cost = 0, Delta = 0, step_norm = NaN, actual_reduction = NaN, g_norm = 0, initial_cost = 0;
@@ -1123,8 +1146,7 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
     // a terminated / exhausted solve only needs the gradient norm of the final iterate (scipy reports it as optimality)
     const bool finishing = status != -100 || nfev >= max_nfev;
     if (lin_stale) {   // the last speculative linearisation was for a rejected point: rebuild g, H at x
-      eval_pose_tables(h, h->x.p);
-      timed_linearize();
+      timed_linearize(h->x.p);
       lin_stale = false;
     }
     bool spec_lin = false;
@@ -1138,20 +1160,23 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
     } else {
       hipLaunchKernelGGL(k_q00, dim3(Q00_BLOCKS), dim3(256), 0, h->stream, d, h->Hss.p, h->Hfs.p, h->Hff.p, h->dsc.p,
                          h->gh.p, h->scal.p + sl.q00p);
-      call_allreduce(h, h->scal.p + sl.q00p, Q00_BLOCKS, 0);
+      if (h->allreduce) {   // one double crosses the ranks, not the 512 per-block partials
+        hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(64), 0, h->stream, h->scal.p + sl.q00p, Q00_BLOCKS);
+        call_allreduce(h, h->scal.p + sl.q00p, 1, 0);
+      }
       hipLaunchKernelGGL(k_tr_reg, dim3(1), dim3(64), 0, h->stream, h->scal.p, h->scal.p + sl.vs, sl.nvb,
-                         h->scal.p + sl.q00p, Q00_BLOCKS, first ? 1 : 0, Delta);
+                         h->scal.p + sl.q00p, h->allreduce ? 1 : Q00_BLOCKS, first ? 1 : 0, Delta);
       launch_gn_solve(h, 0.0, is_root, h->scal.p + sl.dotp, h->scal.p);
       // (a handle that owns only a shard of the frames gets the three complete dots + the pivot report: one "block")
       hipLaunchKernelGGL(k_tr_step, dim3(1), dim3(64), 0, h->stream, h->scal.p, h->scal.p + sl.dotp,
-                         (h->allreduce && d.DF * d.Fl > 0) ? 1 : gn_dot_blocks(d));
+                         (h->allreduce && d.DF > 0) ? 1 : gn_dot_blocks(d));
       enqueue_trial(0.0, 0.0, h->scal.p);
       fetch_scalars_begin(h, trial_fetch_end);
       // Speculation: most trial steps are accepted, so the linearisation at x_new is enqueued right behind the copy and
       // runs while the host looks at the trial cost and prepares the next iteration.  A rejected step leaves the
       // records / H / g of x_new behind (lin_stale): they are not needed by the retries with a smaller radius, and
       // are rebuilt before anything reads them again.
-      timed_linearize();
+      timed_linearize(nullptr);   // (the pose tables hold x_new: enqueue_trial ran k_prep for k_cost)
       spec_lin = true;
       fetch_scalars_end(h);
       have_trial = true;
@@ -1223,7 +1248,7 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
     if (actual_reduction > 0) {
       std::swap(h->x.p, h->xnew.p);
       cost = cost_new;
-      if (!spec_valid) timed_linearize();   // pose tables already hold x_new
+      if (!spec_valid) timed_linearize(nullptr);   // pose tables already hold x_new
       fresh_lin = true;
       ++njev;
     } else {
@@ -1351,8 +1376,7 @@ int32_t mcba_time_linearize(mcba_handle h, const double* x, const mcba_options* 
   REQUIRE(h && x && avg_ms && repeats > 0, "bad argument");
   set_loss(h, opt);
   upload_x(h, x, h->x.p);
-  eval_pose_tables(h, h->x.p);   // (k_tmat, the first kernel of the linearisation, writes the view table)
-  launch_linearize(h);   // warm-up
+  launch_linearize(h, h->x.p);   // warm-up (k_tmat prepares every table the dominant kernel reads)
   sync(h);
   HIP_OK(hipEventRecord(h->ev0, h->stream));
   for (int i = 0; i < repeats; ++i)   // the dominant kernel alone (k_tmat ran in the warm-up), as rocprofv3 reports it

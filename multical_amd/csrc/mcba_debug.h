@@ -1,0 +1,32 @@
+/* mcba_debug.h -- test / profiling entry points of libmcba.so.  NOT part of the drop-in boundary (include/mcba.h): nothing
+ * in multical binds these; tests/ and the profiling scripts use them to validate and time individual kernels.          */
+#ifndef MCBA_DEBUG_H
+#define MCBA_DEBUG_H
+#include "../../include/mcba.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* 1 = accumulate V^T V and the Schur SYRK with v_mfma_f64_16x16x4_f64 (default); 0 = identical data flow with plain
+ * FMAs (validation build of the same kernels).  The environment variable MCBA_NO_MFMA=1 sets the initial value.  */
+int32_t mcba_set_mfma(mcba_handle h, int32_t on);
+/* number of persistent k_linearize workgroups; 0 = automatic (profiling aid)                                        */
+int32_t mcba_debug_set_lin_grid(mcba_handle h, int32_t grid);
+/* FP64 VALU vs FP64 MFMA pipe-sharing probe: ms_out[3] = all-FMA, all-MFMA, half / half        */
+int32_t mcba_debug_pipe_probe(int32_t iters, double* ms_out);
+/* regularised Gauss-Newton direction (H_h + reg I)^-1 g_h in the column-scaled space, computed by the Schur /
+ * Cholesky kernels after a preceding mcba_normal_equations at the same x; g_h and scale_inv may be NULL.           */
+int32_t mcba_debug_gn_step(mcba_handle h, double reg, double* gn_h, double* g_h, double* scale_inv);
+/* per-view s_memtime stamps of the k_linearize phases: out[views][8] = {setup, rows, stage+mfma, epilogue, count,
+ * start, end, 0} in shader cycles (profiling aid for DESIGN.md section 5)                                             */
+int32_t mcba_debug_linearize_profile(mcba_handle h, const double* x, long long* out);
+/* (S + reg I) p = rhs with the device Cholesky kernels; blocked != 0 forces the multi-workgroup path              */
+int32_t mcba_debug_chol(mcba_handle h, int32_t ns, const double* S, const double* rhs, double reg, int32_t blocked,
+                        double* p_out);
+/* one v_mfma_f64_16x16x4_f64 on V = [A | B] (4 x 32, row-major): out[16][16] = A^T B (operand-layout self-test)     */
+int32_t mcba_debug_mfma_probe(const double* V, double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCBA_DEBUG_H */

@@ -135,6 +135,8 @@ inline void lower_problem(const mcba_problem* p, HostProblem& hp) {
   MCBA_REQUIRE(p->motion != MCBA_MOTION_HAND_EYE || p->base_wrt_gripper, "hand-eye motion needs base_wrt_gripper");
   MCBA_REQUIRE(p->optimize != 0, "no parameter block enabled");
   MCBA_REQUIRE(p->n_points <= 512, "boards with more than 512 points are not supported (k_linearize compaction list)");
+  MCBA_REQUIRE((int64_t)p->n_cameras * p->n_boards <= 128,
+               "more than 128 (camera, board) pairs are not supported (pair sums of the shared assembly live in LDS)");
   if (p->camera_model == MCBA_CAMERA_FISHEYE)
     MCBA_REQUIRE(p->n_dist == 4, "fisheye cameras carry 4 distortion coefficients (camera_fisheye.py:113-117)");
   else

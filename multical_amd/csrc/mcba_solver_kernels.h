@@ -29,23 +29,66 @@ __global__ void k_views(Dims d, Tables t) {
 // with coalesced stores (writing 48-byte pieces straight from the (view, block) threads was 2x slower than the
 // thread-per-column kernel).  The kernel opens every linearisation, so it also zeroes the two accumulation targets of
 // the assembly that follows ([g | diag | cost] and H_ss) -- two fill launches less.
-constexpr int TMV = 16;   // views per workgroup
+//
+// x != nullptr: the kernel ALSO replaces k_prep.  Every workgroup forms the pose entries its views need (all cameras,
+// all boards, the frames it touches) in LDS straight from x -- a handful of Rodrigues evaluations instead of a kernel
+// boundary and a dependent read of the pose table -- and the blocks behind the view blocks (blockIdx >= nb_views) write
+// the global pose / camera / board-point tables for the kernels that follow (k_linearize reads the camera and board-point
+// tables, k_cost / k_points the pose table).  TM_LOCAL_POSES bounds the local table (the host checks the shape).
+constexpr int TMV = 16;              // views per workgroup
+constexpr int TM_LOCAL_POSES = 64;   // pose entries of the workgroup-local table
+__host__ __device__ inline int tmat_local_poses(const Dims& d) {   // upper bound of the entries one workgroup needs
+  const int CB = d.C * d.B;
+  const int nfl = (TMV - 1) / (CB > 0 ? CB : 1) + 2;
+  return d.C + d.B + (d.motion == MOTION_HAND_EYE ? 2 : (d.motion == MOTION_ROLLING ? 2 : 1) * nfl);
+}
 __global__ __launch_bounds__(64) void k_tmat(Dims d, Tables t, double* __restrict__ zero_a, int na,
-                                             double* __restrict__ zero_b, int nb) {
+                                             double* __restrict__ zero_b, int nb, const double* __restrict__ x,
+                                             int nb_views) {
   __shared__ double tile[TMV * 12 * 24];
+  __shared__ double lpose[TM_LOCAL_POSES * POSE_STRIDE];
   const int NPB = d.NPB, npc = 6 * NPB, DE = d.DE, vsz = DE * npc;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   for (int e = i; e < na; e += gridDim.x * blockDim.x) zero_a[e] = 0.0;
   for (int e = i; e < nb; e += gridDim.x * blockDim.x) zero_b[e] = 0.0;
+  if ((int)blockIdx.x >= nb_views) {   // table blocks (only launched with x): the body of k_prep
+    prep_item(d, t, x, ((int)blockIdx.x - nb_views) * blockDim.x + threadIdx.x);
+    return;
+  }
   const int v0 = blockIdx.x * TMV, nv = min(TMV, d.views() - v0);
   if (nv <= 0) return;
+  PoseSrc ps = global_pose_src(d, t);
+  if (x != nullptr) {
+    const int CB = d.C * d.B, nch = d.motion == MOTION_ROLLING ? 2 : 1;
+    const int f_lo = d.f0 + v0 / CB, nfl = (d.f0 + (v0 + nv - 1) / CB) - f_lo + 1;
+    const int nmot = d.motion == MOTION_HAND_EYE ? 2 : nch * nfl, np = d.C + d.B + nmot;
+    for (int e = threadIdx.x; e < np; e += blockDim.x) {
+      int j;
+      if (e < d.C) j = d.foff_campose + 6 * e;
+      else if (e < d.C + d.B) j = d.foff_boardpose + 6 * (e - d.C);
+      else {
+        const int li = e - d.C - d.B;
+        j = d.motion == MOTION_HAND_EYE ? d.foff_motion + 6 * li : d.foff_motion + 6 * ((li / nfl) * d.F + f_lo + li % nfl);
+      }
+      double rt[6];
+      for (int k = 0; k < 6; ++k) rt[k] = param_value(t, x, j + k);
+      pose_entry(rt, lpose + (size_t)e * POSE_STRIDE);
+    }
+    __syncthreads();
+    ps.cam = lpose;
+    ps.board = lpose + (size_t)d.C * POSE_STRIDE;
+    ps.mot = lpose + (size_t)(d.C + d.B) * POSE_STRIDE;
+    ps.chain = nfl;
+    ps.f0 = f_lo;
+  }
   const int vl = threadIdx.x / NPB, k = threadIdx.x % NPB, v = v0 + vl;
   if (vl < nv && t.view_count[v] != 0) {
     const int b = v % d.B, c = (v / d.B) % d.C, fl = v / (d.B * d.C), f = d.f0 + fl;
-    view_block_columns(d, t, f, c, b, k, tile + vl * vsz + 6 * k, npc);
+    view_block_columns(d, ps, t.bwg, f, c, b, k, tile + vl * vsz + 6 * k, npc);
     if (k == NPB - 1) {   // the view table too: the trial step that led here only ran k_prep (k_cost forms its own chains)
       const int nch = d.motion == MOTION_ROLLING ? 2 : 1;
-      for (int ch = 0; ch < nch; ++ch) view_chain(d, t, f, c, b, ch, t.view + (size_t)v * d.view_stride() + ch * VIEW_STRIDE);
+      for (int ch = 0; ch < nch; ++ch)
+        view_chain(d, ps, t.bwg, f, c, b, ch, t.view + (size_t)v * d.view_stride() + ch * VIEW_STRIDE);
     }
   }
   __syncthreads();
@@ -1390,6 +1433,15 @@ __global__ __launch_bounds__(256) void k_vec_step(Dims d, const double* __restri
     part[3 * blockIdx.x + 1] = b;
     part[3 * blockIdx.x + 2] = c;
   }
+}
+
+// frame-sharded handles: fold a per-block partial array into its first element BEFORE the cross-rank sum, so that the
+// collective carries one double instead of the whole array (fixed order: deterministic)
+__global__ __launch_bounds__(64) void k_fold_partials(double* __restrict__ part, int n) {
+  double s = 0.0;
+  for (int b = threadIdx.x; b < n; b += 64) s += part[b];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) part[0] = s;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

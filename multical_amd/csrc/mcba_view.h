@@ -120,12 +120,34 @@ MCBA_HD void view_column(const Dims& d, const Tables& t, int f, int c, int b, in
   }
 }
 
+// Where the pose entries (R, t, L) of a view come from: the global pose table written by k_prep, or a workgroup-local
+// table in LDS that k_tmat fills straight from x (the same pose_entry function: identical bits).  Motion entries are
+// addressed as mot + (ch * chain + (f - f0)) * POSE_STRIDE (rolling shutter: ch = 0 start, 1 end); hand-eye: mot[0] =
+// world_wrt_base, mot[1] = gripper_wrt_camera.
+struct PoseSrc {
+  const double* cam;     // entry of camera c at cam + c * POSE_STRIDE
+  const double* board;   // entry of board b
+  const double* mot;     // motion entries
+  int chain;             // entries per chain
+  int f0;                // global frame of motion entry 0
+};
+MCBA_HD PoseSrc global_pose_src(const Dims& d, const Tables& t) {
+  PoseSrc s;
+  s.cam = t.pose + (size_t)d.pose_cam * POSE_STRIDE;
+  s.board = t.pose + (size_t)d.pose_board * POSE_STRIDE;
+  s.mot = t.pose + (size_t)d.pose_motion * POSE_STRIDE;
+  s.chain = d.F;
+  s.f0 = 0;
+  return s;
+}
+
 // All six columns of pose block k of That at once: out[a * stride + jj], a < DE, jj < 6 (same values as six calls of
 // view_column, but the chain prefix of the block is formed once).  Rows a block does not touch are written as zero.
-MCBA_HD void view_block_columns(const Dims& d, const Tables& t, int f, int c, int b, int k, double* out, int stride) {
+MCBA_HD void view_block_columns(const Dims& d, const PoseSrc& ps, const double* bwg, int f, int c, int b, int k,
+                                double* out, int stride) {
   const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-  const double* Pc = t.pose + (size_t)(d.pose_cam + c) * POSE_STRIDE;
-  const double* Pb = t.pose + (size_t)(d.pose_board + b) * POSE_STRIDE;
+  const double* Pc = ps.cam + (size_t)c * POSE_STRIDE;
+  const double* Pb = ps.board + (size_t)b * POSE_STRIDE;
   const double* Rc = Pc + POSE_R;
   const double* tc = Pc + POSE_T;
   const int last = d.NPB - 1;
@@ -137,9 +159,9 @@ MCBA_HD void view_block_columns(const Dims& d, const Tables& t, int f, int c, in
     return;
   }
   if (d.motion == MOTION_HAND_EYE) {   // chain camera . G . B_f . Wb . board ; local blocks: cam | wb | gc | board
-    const double* Wb = t.pose + (size_t)(d.pose_motion + 0) * POSE_STRIDE;
-    const double* G = t.pose + (size_t)(d.pose_motion + 1) * POSE_STRIDE;
-    const double* Bf = t.bwg + 12 * (size_t)f;
+    const double* Wb = ps.mot;
+    const double* G = ps.mot + POSE_STRIDE;
+    const double* Bf = bwg + 12 * (size_t)f;
     double R1[9], t1[3];
     se3_mul(Rc, tc, G + POSE_R, G + POSE_T, R1, t1);            // camera . G
     if (k == 2) {
@@ -169,7 +191,7 @@ MCBA_HD void view_block_columns(const Dims& d, const Tables& t, int f, int c, in
         for (int jj = 0; jj < 6; ++jj) o6[a * stride + jj] = 0.0;
       continue;
     }
-    const double* Pf = t.pose + (size_t)(d.pose_motion + ch * d.F + f) * POSE_STRIDE;
+    const double* Pf = ps.mot + (size_t)(ch * ps.chain + (f - ps.f0)) * POSE_STRIDE;
     double R1[9], t1[3];
     se3_mul(Rc, tc, Pf + POSE_R, Pf + POSE_T, R1, t1);            // camera . frame
     if (k == last) {
@@ -181,6 +203,9 @@ MCBA_HD void view_block_columns(const Dims& d, const Tables& t, int f, int c, in
       for (int jj = 0; jj < 6; ++jj) view_pose_column(Rc, Pf + POSE_L, t1, jj, o6 + jj, stride);
     }
   }
+}
+MCBA_HD void view_block_columns(const Dims& d, const Tables& t, int f, int c, int b, int k, double* out, int stride) {
+  view_block_columns(d, global_pose_src(d, t), t.bwg, f, c, b, k, out, stride);
 }
 
 // x index of local parameter i of view (f, c, b); -1 when its block is not optimised (or i is the residual column)
@@ -324,25 +349,28 @@ MCBA_HD void prep_item(const Dims& d, const Tables& t, const double* x, int i) {
 }
 
 // chain matrix board -> camera of view (f, c, b), chain ch (rolling shutter: 0 = start pose, 1 = end pose): out[12] = R | t
-MCBA_HD void view_chain(const Dims& d, const Tables& t, int f, int c, int b, int ch, double* out) {
-  const double* Pc = t.pose + (size_t)(d.pose_cam + c) * POSE_STRIDE;
-  const double* Pb = t.pose + (size_t)(d.pose_board + b) * POSE_STRIDE;
+MCBA_HD void view_chain(const Dims& d, const PoseSrc& ps, const double* bwg, int f, int c, int b, int ch, double* out) {
+  const double* Pc = ps.cam + (size_t)c * POSE_STRIDE;
+  const double* Pb = ps.board + (size_t)b * POSE_STRIDE;
   double R1[9], t1[3], R2[9], t2[3];
   if (d.motion == MOTION_HAND_EYE) {
-    const double* Wb = t.pose + (size_t)(d.pose_motion + 0) * POSE_STRIDE;
-    const double* G = t.pose + (size_t)(d.pose_motion + 1) * POSE_STRIDE;
-    const double* Bf = t.bwg + 12 * (size_t)f;
+    const double* Wb = ps.mot;
+    const double* G = ps.mot + POSE_STRIDE;
+    const double* Bf = bwg + 12 * (size_t)f;
     se3_mul(Pc + POSE_R, Pc + POSE_T, G + POSE_R, G + POSE_T, R1, t1);
     se3_mul(R1, t1, Bf, Bf + 9, R2, t2);
     se3_mul(R2, t2, Wb + POSE_R, Wb + POSE_T, R1, t1);
     se3_mul(R1, t1, Pb + POSE_R, Pb + POSE_T, R2, t2);
   } else {
-    const double* Pf = t.pose + (size_t)(d.pose_motion + ch * d.F + f) * POSE_STRIDE;
+    const double* Pf = ps.mot + (size_t)(ch * ps.chain + (f - ps.f0)) * POSE_STRIDE;
     se3_mul(Pc + POSE_R, Pc + POSE_T, Pf + POSE_R, Pf + POSE_T, R1, t1);
     se3_mul(R1, t1, Pb + POSE_R, Pb + POSE_T, R2, t2);
   }
   for (int k = 0; k < 9; ++k) out[k] = R2[k];
   for (int k = 0; k < 3; ++k) out[9 + k] = t2[k];
+}
+MCBA_HD void view_chain(const Dims& d, const Tables& t, int f, int c, int b, int ch, double* out) {
+  view_chain(d, global_pose_src(d, t), t.bwg, f, c, b, ch, out);
 }
 
 MCBA_HD void view_item(const Dims& d, const Tables& t, int i) {

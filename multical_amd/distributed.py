@@ -110,9 +110,10 @@ def init_native_allreduce(h, rank, world_size, group=None):
   return True
 
 
-def sharded_handle(calib, rank=None, world_size=None, group=None, balance=True, native=None):
+def sharded_handle(calib, rank=None, world_size=None, group=None, balance=True, native=None, shards=None):
   """Handle owning this rank's frame shard.  Reductions: the library's own RCCL communicator (`native`, default when the
-  group's backend is nccl, i.e. one GPU per rank) or a torch.distributed hook (gloo tests, fallback)."""
+  group's backend is nccl, i.e. one GPU per rank) or a torch.distributed hook (gloo tests, fallback).
+  `shards`: explicit [(f0, f1)] * world_size instead of the balanced plan (empty ranges are legal)."""
   import torch
   import torch.distributed as dist
   from .backend import Handle, lower
@@ -123,7 +124,9 @@ def sharded_handle(calib, rank=None, world_size=None, group=None, balance=True, 
   if balance:
     inl = calib.inliers
     weights = inl.sum(axis=(0, 2, 3)).astype(np.float64)
-  shards = frame_shards(prob.shape[1], world_size, weights)
+  if shards is None:
+    shards = frame_shards(prob.shape[1], world_size, weights)
+  assert len(shards) == world_size and shards[0][0] == 0 and shards[-1][1] == prob.shape[1]
   tstream = torch.cuda.Stream()                       # dedicated (non-default) stream shared by kernels and collectives
   h = Handle(prob, frame_range=shards[rank], stream=tstream.cuda_stream)
   h.torch_stream = tstream                            # keep it alive as long as the handle

@@ -449,3 +449,30 @@ def test_adjust_board_large_reduced_system():
     assert np.abs(gn - ref).max() <= 1e-8 * np.abs(ref).max()
     res = h.solve(x0)
     assert res.status in (2, 3, 4) and res.cost < float(g["ba_cost"])      # more freedom than the fixed-board fit
+
+
+def test_handle_cache_sees_a_changed_validity_mask_and_float32_tables():
+  """the device-handle cache is keyed on the point table by identity AND content: a copy of the Calibration whose point
+  table has another `valid` mask (same `points` object) must not hit the tables built for the old mask, and float32
+  detection tables (widened into a copy on lowering) keep their identity alive inside the cache entry."""
+  from multical_amd.structs import Table
+  g, rig = load_golden("tiny")
+  c = mirror(rig)
+  calibration.handle_cache.clear()
+  r_all = c.residuals()
+  valid2 = c.point_table.valid.copy()
+  valid2[0, 0] = False                                  # drop camera 0 / frame 0
+  c2 = c.copy(point_table=Table.create(points=c.point_table.points, valid=valid2))
+  r2 = c2.residuals()
+  assert r2.size == 2 * int((c2.valid).sum()) and r2.size < r_all.size
+  oc = oracle(rig)
+  oc2 = oc.copy(valid=valid2)
+  assert np.abs(r2 - oc2.evaluate(c2.param_vec)).max() < 1e-9
+  assert np.abs(c.residuals() - r_all).max() == 0.0     # and back again
+  # float32 detections: two different tables of the same shape in a loop never alias
+  for seed in (31, 32, 33):
+    rg = synthetic.make_rig("tiny", seed=seed)
+    rg.points = rg.points.astype(np.float32)
+    cm = mirror(rg)
+    ocm = restate.from_rig(rg)
+    assert np.abs(cm.residuals() - ocm.evaluate(cm.param_vec)).max() < 1e-9
