@@ -193,6 +193,9 @@ int32_t mcba_reprojection_error(mcba_handle h, const double* x, double* err, uin
  * reprojection_inliers (calibration.py:138-141).  Sharded handles combine over all ranks.                         */
 int32_t mcba_error_stats(mcba_handle h, const double* x, int32_t inliers_only, int32_t n_ranks, const int64_t* ranks,
                          double* values, int64_t* n, double* sum_sq);
+/* n of mcba_error_stats known without a device pass (single-GPU handles; -1 for a frame-sharded handle): the caller can
+ * derive the quantile ranks first and make ONE mcba_error_stats call                                                  */
+int32_t mcba_error_count(mcba_handle h, int32_t inliers_only, int64_t* n);
 /* Calibration.reject_outliers on the device (calibration.py:240-252): inliers = (err < threshold) & valid at x;
  * replaces the handle's inlier table.  n_inliers / n_valid (over all ranks) may be NULL.                            */
 int32_t mcba_reject_outliers(mcba_handle h, const double* x, double threshold, int64_t* n_inliers, int64_t* n_valid);
@@ -201,6 +204,12 @@ int32_t mcba_get_inliers(mcba_handle h, uint8_t* mask);
 
 /* Projected points [C,F,B,P,2] of Calibration.reprojected (calibration.py:124-130).                            */
 int32_t mcba_project(mcba_handle h, const double* x, double* projected);
+
+/* Projected points [C,F,B,P,2] of Calibration.projected (calibration.py:113-119): the projection WITHOUT the measured
+ * points, consumed by the GUI / reprojection tables (interface/view_table.py:43-52).  Rolling shutter iterates the scan
+ * time from the projected row: 0.5 first, then max_iterations fixed-point passes (motion/rolling_frames.py:115-133,
+ * RollingFrames.max_iterations, default 4); the other motion models ignore max_iterations.                           */
+int32_t mcba_project_model(mcba_handle h, const double* x, int32_t max_iterations, double* projected);
 
 /* One fused residual+Jacobian evaluation reduced to the normal equations at x (what one scipy `jac` call plus
  * J^T J / J^T f would produce): cost = 0.5 |f|^2 (robust-loss scaled), g = J^T f [n_params],

@@ -66,8 +66,10 @@ SYMBOLS = [
   ("mcba_jacobian", C.c_int32, [H, c_double_p, c_int32_p, c_double_p, c_int32_p]),
   ("mcba_reprojection_error", C.c_int32, [H, c_double_p, c_double_p, c_uint8_p]),
   ("mcba_project", C.c_int32, [H, c_double_p, c_double_p]),
+  ("mcba_project_model", C.c_int32, [H, c_double_p, C.c_int32, c_double_p]),
   ("mcba_error_stats", C.c_int32, [H, c_double_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), c_double_p,
                                    C.POINTER(C.c_int64), c_double_p]),
+  ("mcba_error_count", C.c_int32, [H, C.c_int32, C.POINTER(C.c_int64)]),
   ("mcba_reject_outliers", C.c_int32, [H, c_double_p, C.c_double, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
   ("mcba_get_inliers", C.c_int32, [H, c_uint8_p]),
   ("mcba_normal_equations", C.c_int32, [H, c_double_p, C.POINTER(Options), c_double_p, c_double_p, c_double_p]),

@@ -22,7 +22,12 @@ def _ptr(a, ctype):
 
 
 def _u8(a):
-  return np.ascontiguousarray(np.asarray(a).astype(np.uint8))
+  a = np.asarray(a)
+  if a.dtype == np.bool_ and a.flags.c_contiguous:
+    return a.view(np.uint8)          # masks are bool tables of millions of slots: reinterpret, do not copy
+  if a.dtype == np.uint8 and a.flags.c_contiguous:
+    return a
+  return np.ascontiguousarray(a.astype(np.uint8))
 
 
 def _f64(a):
@@ -81,10 +86,12 @@ def lower(calib):
   p.fix_aspect = _u8([bool(c.fix_aspect) for c in cams])
 
   p.optimize = _optimize_bits(calib.optimize)
-  # all five parameter blocks in reference order (calibration.py:146-153), enabled or not
+  # all five parameter blocks in reference order (calibration.py:146-153), enabled or not.  (`param_vec` is a cached
+  # property of every block object: the vectors are shared with Calibration.param_vec, nothing is converted twice.)
   objs = calib.param_objects
-  p.x_full = _f64(np.concatenate([np.asarray(objs[k].param_vec, dtype=np.float64).ravel() for k in PARAM_ORDER]))
-  p.block_sizes = [int(np.asarray(objs[k].param_vec).size) for k in PARAM_ORDER]
+  vecs = [np.asarray(objs[k].param_vec, dtype=np.float64).ravel() for k in PARAM_ORDER]
+  p.x_full = _f64(np.concatenate(vecs))
+  p.block_sizes = [int(v.size) for v in vecs]
   p.n_params = sum(n for k, n in zip(PARAM_ORDER, p.block_sizes) if calib.optimize[k] is True)
   return p
 
@@ -234,6 +241,14 @@ class Handle(object):
     check(self.lib.mcba_project(self.h, _ptr(x, C.c_double), _ptr(out, C.c_double)))
     return out
 
+  def project_model(self, x, max_iterations=4):
+    """Calibration.projected (calibration.py:113-119): projection without the measured points (rolling shutter: scan
+    time iterated from the projected row, motion/rolling_frames.py:125-133)."""
+    x = self._x(x)
+    out = np.empty(tuple(self.shape) + (2,))
+    check(self.lib.mcba_project_model(self.h, _ptr(x, C.c_double), int(max_iterations), _ptr(out, C.c_double)))
+    return out
+
   def normal_equations(self, x, loss='linear', f_scale=1.0):
     x = self._x(x)
     opt = make_options(loss=loss, f_scale=f_scale)
@@ -279,15 +294,20 @@ class Handle(object):
     returns (mse, rms, quantiles, n).  Quantiles follow numpy's default 'linear' method exactly: virtual index
     (n-1) q, floor / ceil order statistics from the device radix select, numpy's _lerp on the host."""
     x = self._x(x)
-    q = np.atleast_1d(np.asarray(quantiles, dtype=np.float64))
+    q = np.asarray(quantiles, dtype=np.float64).reshape(-1)
     n = C.c_int64()
     ssq = C.c_double()
-    # first call: n only (ranks depend on n)
-    check(self.lib.mcba_error_stats(self.h, _ptr(x, C.c_double), int(inliers_only), 0, None, None, C.byref(n),
-                                    C.byref(ssq)))
+    # the ranks depend on n: known on the host for a single-GPU handle; a sharded handle needs a first pass for it
+    check(self.lib.mcba_error_count(self.h, int(inliers_only), C.byref(n)))
+    if n.value < 0 or q.size == 0:
+      check(self.lib.mcba_error_stats(self.h, _ptr(x, C.c_double), int(inliers_only), 0, None, None, C.byref(n),
+                                      C.byref(ssq)))
     nv = n.value
     if nv == 0:   # the reference substitutes a single zero (calibration.py:306-307)
       return 0.0, 0.0, np.zeros(q.shape), 1
+    if q.size == 0:
+      mse = ssq.value / nv
+      return mse, float(np.sqrt(mse)), q, nv
     virt = (nv - 1) * q
     lo = np.floor(virt).astype(np.int64)
     hi = np.minimum(lo + 1, nv - 1)
@@ -313,9 +333,9 @@ class Handle(object):
     return ni.value, nvv.value
 
   def get_inliers(self):
-    m = np.zeros(self.shape, dtype=np.uint8)
-    check(self.lib.mcba_get_inliers(self.h, _ptr(m, C.c_uint8)))
-    return m.astype(bool)
+    m = np.empty(self.shape, dtype=np.bool_)      # the device writes 0 / 1 bytes: a bool array without a second copy
+    check(self.lib.mcba_get_inliers(self.h, _ptr(m.view(np.uint8), C.c_uint8)))
+    return m
 
   def linearize_profile(self, x):
     x = self._x(x)

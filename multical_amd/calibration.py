@@ -219,6 +219,14 @@ class Calibration(parameters.Parameters):
     board_valid = np.arange(P)[None, :] < sizes[:, None]
     return Table.create(points=points, valid=pose_valid & board_valid[None, None])
 
+  @cached_property
+  def projected(self):
+    """calibration.py:113-119: projected points to each image WITHOUT the measured points (rolling shutter: the scan
+    time is iterated from the projected row, RollingFrames.max_iterations passes) -- the table the GUI draws."""
+    h = self._handle()
+    points = h.project_model(self.param_vec, getattr(self.motion, "max_iterations", 4))
+    return Table.create(points=points, valid=self.reprojected.valid)
+
   def _errors(self):
     """tables.reprojection_error (tables.py:244-249) of (reprojected, point_table) on the device."""
     return self._handle().reprojection_error(self.param_vec)
@@ -311,14 +319,15 @@ class Calibration(parameters.Parameters):
     self.report("Adjust_outliers end:")
     return self
 
-  def error_statistics(self, inliers_only=False):
+  def error_statistics(self, inliers_only=False, quantiles=(0, 0.25, 0.5, 0.75, 1)):
     """error_stats(self.reprojection_error / reprojection_inliers) without downloading the error table."""
-    mse, rms, q, n = self._handle().error_stats(self.param_vec, inliers_only=inliers_only)
+    mse, rms, q, n = self._handle().error_stats(self.param_vec, quantiles=quantiles, inliers_only=inliers_only)
     return struct(mse=mse, rms=rms, quantiles=q, n=n)
 
   def report(self, stage=""):
     overall = self.error_statistics(False)
-    inliers = self.error_statistics(True)
+    # (the reference's report prints RMS and n of the inliers, never their quantiles: calibration.py:296-300)
+    inliers = self.error_statistics(True, quantiles=()) if self.inlier_mask is not None else overall
     if self.inlier_mask is not None:
       info(f"{stage} reprojection RMS={inliers.rms:.3f} ({overall.rms:.3f}), "
            f"n={inliers.n} ({overall.n}), quantiles={overall.quantiles}")

@@ -50,6 +50,8 @@ struct Error : std::runtime_error {
     if (!(cond)) throw Error(msg);         \
   } while (0)
 
+thread_local hipStream_t g_fill_stream = nullptr;   // stream of the running API call (see DevBuf::alloc)
+
 template <class T>
 struct DevBuf {
   T* p = nullptr;
@@ -64,15 +66,23 @@ struct DevBuf {
     n = 0;
   }
   void alloc(size_t count, bool zero = true) {
-    release();
-    n = count;
     const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
-    HIP_OK(hipMalloc((void**)&p, bytes));
+    if (p == nullptr || n < count) {   // (a buffer that is large enough is reused: hipFree / hipMalloc cost ~100 us each)
+      release();
+      n = count;
+      HIP_OK(hipMalloc((void**)&p, bytes));
+    }
     if (zero) {
-      // hipMemset runs on the NULL stream and is asynchronous w.r.t. the host; the handle's stream may be a
-      // non-blocking one (torch.cuda.Stream), which is not ordered against it -> wait here
-      HIP_OK(hipMemset(p, 0, bytes));
-      HIP_OK(hipStreamSynchronize(nullptr));
+      // zero-fill ON THE HANDLE'S STREAM (g_fill_stream is set by every API entry that allocates): ordered against the
+      // kernels that use the buffer, no host synchronisation per buffer (mcba_create makes ~40 of them).  Without a
+      // stream: hipMemset on the NULL stream is asynchronous w.r.t. the host and not ordered against a non-blocking
+      // stream (torch.cuda.Stream) -> wait.
+      if (g_fill_stream != nullptr) {
+        HIP_OK(hipMemsetAsync(p, 0, bytes, g_fill_stream));
+      } else {
+        HIP_OK(hipMemset(p, 0, bytes));
+        HIP_OK(hipStreamSynchronize(nullptr));
+      }
     }
   }
   template <typename V>
@@ -127,18 +137,23 @@ struct mcba_handle_s {
   DevBuf<double> chol_linv;   // inverted diagonal tiles of k_chol_glb
   int lin_grid = 0;          // 0 = automatic (see lin2), > 0 = forced number of persistent workgroups (debug)
 
-  // host copies needed to rebuild the inlier tables
-  SlotVec<uint8_t> h_valid_ref;        // Calibration.valid, [C,F,B,P] reference order
-  int64_t n_inliers = 0;
+  int64_t n_inliers = 0;               // inliers of this shard
+  int64_t n_evalid = 0;                // points in the mask of tables.reprojection_error (this shard)
 
   // observation tables
   DevBuf<double2> obs;
   DevBuf<uint8_t> inlier, evalid, fix_aspect;
+  DevBuf<uint8_t> valid_fm, raw_mask, cam_valid, frame_valid, board_valid;   // Calibration.valid (frame-major), mask slabs
+  DevBuf<int32_t> view_first;            // first residual pair of every view (k_view_scan)
+  DevBuf<long long> totals;              // {inliers, evalid points} of the shard
+  long long* h_totals = nullptr;         // pinned
   DevBuf<int32_t> obs_index, view_count, active_views, work_counter, board_off, full2act;
   DevBuf<double> xfull, bwg, img_h, board_points, pose, cam, view, tmat;
   DevBuf<uint16_t> tri;
   DevBuf<long long> dbg;
   DevBuf<double> err_fm, sel_f64;
+  std::vector<double> err_x;           // parameter vector the frame-major error table err_fm was evaluated at
+  bool err_valid = false;
   DevBuf<unsigned int> sel_hist;
   DevBuf<unsigned long long> sel_state;   // SelState x SEL_MAX | ranks | per-block (count, next) of k_selm_next
   bool obs_index_dirty = false;
@@ -171,6 +186,7 @@ struct mcba_handle_s {
     if (h_scal) (void)hipHostFree(h_scal);
     if (h_x) (void)hipHostFree(h_x);
     if (h_gbuf) (void)hipHostFree(h_gbuf);
+    if (h_totals) (void)hipHostFree(h_totals);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     if (ev_fetch) (void)hipEventDestroy(ev_fetch);
@@ -203,19 +219,51 @@ void refresh_active_views(mcba_handle_s* h) {
   hipLaunchKernelGGL(k_active_views, dim3(1), dim3(1024), 0, h->stream, h->d.views(), h->view_count.p, h->active_views.p);
 }
 
-// (re)build inlier table, residual ordering and per-view counts for the shard; mask in reference order or null
+// upload the shard's frames of a [C,F,B,P] host array (element size esz bytes) as C contiguous slabs [C][Fl][B][P]
+void upload_shard_slabs(mcba_handle_s* h, void* dst, const void* src, size_t esz) {
+  const Dims& d = h->d;
+  const size_t slab = (size_t)d.Fl * d.B * d.P * esz, cam = (size_t)d.F * d.B * d.P * esz, off = (size_t)d.f0 * d.B * d.P * esz;
+  if (slab == 0) return;
+  if (d.Fl == d.F) {
+    HIP_OK(hipMemcpyAsync(dst, src, slab * d.C, hipMemcpyHostToDevice, h->stream));
+    return;
+  }
+  for (int c = 0; c < d.C; ++c)
+    HIP_OK(hipMemcpyAsync((char*)dst + c * slab, (const char*)src + c * cam + off, slab, hipMemcpyHostToDevice, h->stream));
+}
+
+// per-view first residual index + shard totals (inliers, evalid points) -> host copies; one synchronisation
+void scan_views(mcba_handle_s* h) {
+  const Dims& d = h->d;
+  hipLaunchKernelGGL(k_view_scan, dim3(1), dim3(1024), 0, h->stream, d, h->view_count.p, (const int32_t*)nullptr,
+                     h->view_first.p, h->totals.p);
+  HIP_OK(hipMemcpyAsync(h->h_totals, h->totals.p, sizeof(long long), hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  REQUIRE(h->h_totals[0] < (1LL << 30), "too many observations for 32-bit residual indices");
+  h->n_inliers = h->h_totals[0];
+}
+
+// (re)build inlier table and per-view counts of the shard ON THE DEVICE; mask in reference order or null (= valid).
+// The residual ordering (obs_index) is rebuilt lazily by ensure_obs_index.
 void build_inliers(mcba_handle_s* h, const uint8_t* mask_ref) {
-  HostProblem hp;
-  hp.d = h->d;
-  hp.valid_ref = h->h_valid_ref;
-  lower_inliers(hp, mask_ref);
-  const size_t nslot = (size_t)h->d.slots();
-  h->n_inliers = hp.n_inliers;
-  HIP_OK(hipMemcpy(h->inlier.p, hp.inlier.data(), nslot, hipMemcpyHostToDevice));
-  HIP_OK(hipMemcpy(h->obs_index.p, hp.obs_index.data(), nslot * sizeof(int32_t), hipMemcpyHostToDevice));
-  HIP_OK(hipMemcpy(h->view_count.p, hp.view_count.data(), hp.view_count.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  const Dims& d = h->d;
+  if (d.views() > 0) {
+    if (mask_ref != nullptr) {
+      if (h->raw_mask.n < (size_t)d.slots()) h->raw_mask.alloc((size_t)d.slots(), false);
+      upload_shard_slabs(h, h->raw_mask.p, mask_ref, 1);
+      hipLaunchKernelGGL(k_lower_view, dim3(d.views()), dim3(64), 0, h->stream, d, (const double2*)nullptr,
+                         (const uint8_t*)h->raw_mask.p, (const uint8_t*)h->raw_mask.p, h->cam_valid.p, h->frame_valid.p,
+                         h->board_valid.p, h->board_off.p, (double2*)nullptr, (uint8_t*)nullptr, (uint8_t*)nullptr,
+                         h->inlier.p, h->view_count.p, (int32_t*)nullptr);
+    } else {
+      hipLaunchKernelGGL(k_inliers_from_valid, dim3(d.views()), dim3(64), 0, h->stream, d, h->valid_fm.p, h->inlier.p,
+                         h->view_count.p);
+    }
+  }
   refresh_active_views(h);
-  h->out_r.alloc((size_t)std::max<int64_t>(2 * hp.n_inliers, 1), false);
+  scan_views(h);
+  h->out_r.alloc((size_t)std::max<int64_t>(2 * h->n_inliers, 1), false);
+  h->obs_index_dirty = true;
 }
 
 void set_loss(mcba_handle_s* h, const mcba_options* opt) {
@@ -309,6 +357,19 @@ void launch_linearize(mcba_handle_s* h, const double* dx) {
   // k_tmat also zeroes [g | diag | cost] and H_ss for the assembly that follows (entries of frames owned by other ranks
   // must be zero before the cross-rank sum: they hold the previous global values after an all-reduce)
   static_assert(TMV * 4 <= 64, "k_tmat: (view, pose block) threads of a workgroup");
+  // Fused form (opt-in, MCBA_FUSED=1): k_linearize itself forms That / the chain matrices from dx, reads the intrinsics
+  // from dx and zeroes the assembly targets -- one launch instead of two.  Conditions: the MFMA build, no tilted model
+  // (its tilt matrices come from the camera table, which only k_prep refreshes), board points not optimised (the
+  // board-point table is then constant: written once by mcba_create).  Measured at the north-star rig: the evaluation
+  // drops from 88.8 to 86.6 us, but the per-view prologue (Rodrigues of four poses on four lanes, divergent column code)
+  // grows from 3.8 k to 14 k cycles and k_linearize from 49.5 to 62 us -- the table form stays the default until the
+  // in-kernel prologue is lane-uniform.
+  static const bool fused_on = getenv("MCBA_FUSED") != nullptr && getenv("MCBA_FUSED")[0] == '1';
+  if (dx != nullptr && h->use_mfma && d.ND != 14 && d.off_boards < 0 && fused_on) {
+    h->ops->linearize(d, h->t, h->stream, h->rec.p, h->tri.p, true, h->lin_grid, dx, h->gbuf.p, 2 * d.n + 2, h->Hss.p,
+                      d.ns * d.ns);
+    return;
+  }
   const int nb_views = std::max((d.views() + TMV - 1) / TMV, 1);
   if (dx != nullptr && tmat_local_poses(d) > TM_LOCAL_POSES) {   // unusual shape: separate table pass
     eval_pose_tables(h, dx);
@@ -317,7 +378,7 @@ void launch_linearize(mcba_handle_s* h, const double* dx) {
   const int nb_prep = dx ? (d.n_pose + d.C + d.B * d.P + 63) / 64 : 0;
   hipLaunchKernelGGL(k_tmat, dim3(nb_views + nb_prep), dim3(64), 0, h->stream, d, h->t, h->gbuf.p, 2 * d.n + 2, h->Hss.p,
                      d.ns * d.ns, dx, nb_views);
-  h->ops->linearize(d, h->t, h->stream, h->rec.p, h->tri.p, h->use_mfma, h->lin_grid);
+  h->ops->linearize(d, h->t, h->stream, h->rec.p, h->tri.p, h->use_mfma, h->lin_grid, nullptr, nullptr, 0, nullptr, 0);
 }
 
 void launch_assemble(mcba_handle_s* h) {
@@ -494,16 +555,13 @@ void launch_gn_solve(mcba_handle_s* h, double reg, bool root_rank, double* dots_
 // ---- device outlier loop -------------------------------------------------------------------------------------------
 void ensure_obs_index(mcba_handle_s* h) {
   if (!h->obs_index_dirty) return;
-  // rebuild the residual ordering on the host from the device inlier table (needed by residuals / jacobian only)
+  // residual ordering of the current inlier table (needed by residuals / jacobian only): prefix sums on the device
   const Dims& d = h->d;
-  const size_t nref = (size_t)d.C * d.F * d.B * d.P;
-  h->out_valid.alloc(nref, true);
-  hipLaunchKernelGGL(k_inliers_to_ref, dim3(std::max(1, std::min(4096, (d.slots() + 255) / 256))), dim3(256), 0, h->stream, d,
-                     h->inlier.p, h->out_valid.p);
-  std::vector<uint8_t> mask(nref);
-  HIP_OK(hipMemcpyAsync(mask.data(), h->out_valid.p, nref, hipMemcpyDeviceToHost, h->stream));
-  HIP_OK(hipStreamSynchronize(h->stream));
-  build_inliers(h, mask.data());
+  if (d.views() > 0) {
+    hipLaunchKernelGGL(k_view_scan, dim3(1), dim3(1024), 0, h->stream, d, h->view_count.p, (const int32_t*)nullptr,
+                       h->view_first.p, h->totals.p);
+    hipLaunchKernelGGL(k_obs_index, dim3(d.views()), dim3(64), 0, h->stream, d, h->inlier.p, h->view_first.p, h->obs_index.p);
+  }
   h->obs_index_dirty = false;
 }
 
@@ -515,9 +573,14 @@ void compute_errors(mcba_handle_s* h, const double* x) {
     h->sel_state.alloc(3 * SEL_MAX + (size_t)SEL_NEXT_BLOCKS * SEL_MAX * 2);   // SelState | ranks | per-block (count, next)
     h->sel_f64.alloc((size_t)SEL_MAX * 2048);
   }
+  // the per-slot errors depend on x only (the observation tables of a handle are fixed): report() asks for the statistics
+  // of the same point several times (all valid points, inliers, the rejection threshold) -- evaluate once
+  if (h->err_valid && h->err_x.size() == (size_t)d.n && memcmp(h->err_x.data(), x, (size_t)d.n * sizeof(double)) == 0) return;
   upload_x(h, x, h->x.p);
   eval_tables(h, h->x.p);
   h->ops->residual(d, h->t, h->stream, nullptr, nullptr, h->err_fm.p, nullptr);   // frame-major errors
+  h->err_x.assign(x, x + d.n);
+  h->err_valid = true;
 }
 
 int sel_grid(const Dims& d) { return std::max(1, std::min(1024, (d.slots() + 255) / 256)); }
@@ -589,15 +652,19 @@ double now_seconds() {
 // =================================================================================================================
 // C ABI
 // =================================================================================================================
+// (g_fill_stream is valid for the duration of ONE API call: the entry points that allocate set it, every exit clears it)
 #define API_BEGIN try {
 #define API_END                                 \
+  g_fill_stream = nullptr;                      \
   return 0;                                     \
   }                                             \
   catch (const std::exception& e) {             \
+    g_fill_stream = nullptr;                    \
     g_error = e.what();                         \
     return 1;                                   \
   }                                             \
   catch (...) {                                 \
+    g_fill_stream = nullptr;                    \
     g_error = "unknown error";                  \
     return 1;                                   \
   }
@@ -621,10 +688,20 @@ int32_t mcba_create(const mcba_problem* p, void* hip_stream, mcba_handle* out) {
     throw Error("no HIP device: the mcba back-end is GPU-only (there is no CPU fallback)");
   auto h = std::make_unique<mcba_handle_s>();
   HIP_OK(hipGetDevice(&h->device));
-  hipDeviceProp_t prop;
-  HIP_OK(hipGetDeviceProperties(&prop, h->device));
-  REQUIRE(std::string(prop.gcnArchName).rfind("gfx950", 0) == 0,
-          std::string("mcba kernels are built for gfx950 only, found ") + prop.gcnArchName);
+  {   // the architecture check costs a hipGetDeviceProperties (milliseconds): once per device and process
+    static std::string arch_of[64];
+    static bool arch_known[64] = {false};
+    const int di = h->device;
+    if (di < 0 || di >= 64 || !arch_known[di]) {
+      hipDeviceProp_t prop;
+      HIP_OK(hipGetDeviceProperties(&prop, h->device));
+      if (di >= 0 && di < 64) { arch_of[di] = prop.gcnArchName; arch_known[di] = true; }
+      REQUIRE(std::string(prop.gcnArchName).rfind("gfx950", 0) == 0,
+              std::string("mcba kernels are built for gfx950 only, found ") + prop.gcnArchName);
+    } else {
+      REQUIRE(arch_of[di].rfind("gfx950", 0) == 0, std::string("mcba kernels are built for gfx950 only, found ") + arch_of[di]);
+    }
+  }
   if (hip_stream) {
     h->stream = (hipStream_t)hip_stream;
   } else {
@@ -636,29 +713,66 @@ int32_t mcba_create(const mcba_problem* p, void* hip_stream, mcba_handle* out) {
 
   const bool timing = getenv("MCBA_TIMING") != nullptr;
   const double tc0 = now_seconds();
+  g_fill_stream = h->stream;      // buffers are zero-filled on the handle's stream (no synchronisation per buffer)
   HostProblem hp;
-  lower_problem(p, hp);
+  lower_dims(p, hp);              // shape, index maps, small parameter tables; the slot tables are built on the device
   const double tc1 = now_seconds();
   h->d = hp.d;
   Dims& d = h->d;
-  h->h_valid_ref = std::move(hp.valid_ref);   // (kept for mcba_set_inliers(NULL); hp is not used for it again)
-  h->obs.upload(hp.obs);
-  h->evalid.upload(hp.evalid);
-  h->inlier.upload(hp.inlier);
-  h->obs_index.upload(hp.obs_index);
-  h->view_count.upload(hp.view_count);
+  // ---- raw upload + device lowering (k_lower_view): the caller's [C,F,B,P] arrays go up as they are ------------------
+  const size_t nslot = (size_t)d.slots();
+  h->obs.alloc(nslot, false);
+  h->evalid.alloc(nslot, false);
+  h->valid_fm.alloc(nslot, false);
+  h->inlier.alloc(nslot, false);
+  h->obs_index.alloc(nslot, false);
+  h->view_count.alloc((size_t)d.views(), false);
+  h->view_first.alloc((size_t)d.views(), false);
+  h->totals.alloc(2);
+  HIP_OK(hipHostMalloc((void**)&h->h_totals, 2 * sizeof(long long)));
+  h->board_off.upload(hp.board_off);
+  h->cam_valid.upload(std::vector<uint8_t>(p->camera_valid, p->camera_valid + d.C));
+  h->frame_valid.upload(std::vector<uint8_t>(p->frame_valid, p->frame_valid + d.F));
+  h->board_valid.upload(std::vector<uint8_t>(p->board_valid, p->board_valid + d.B));
+  {
+    DevBuf<double2> raw_pts;
+    DevBuf<uint8_t> raw_valid, view_e_unused;
+    DevBuf<int32_t> view_ecount;
+    raw_pts.alloc(nslot, false);
+    raw_valid.alloc(nslot, false);
+    view_ecount.alloc((size_t)d.views(), false);
+    upload_shard_slabs(h.get(), raw_pts.p, p->points, sizeof(double2));
+    upload_shard_slabs(h.get(), raw_valid.p, p->point_valid, 1);
+    if (p->inlier_mask) {
+      h->raw_mask.alloc(nslot, false);
+      upload_shard_slabs(h.get(), h->raw_mask.p, p->inlier_mask, 1);
+    }
+    if (d.views() > 0) {
+      hipLaunchKernelGGL(k_lower_view, dim3(d.views()), dim3(64), 0, h->stream, d, (const double2*)raw_pts.p,
+                         (const uint8_t*)raw_valid.p, (const uint8_t*)(p->inlier_mask ? h->raw_mask.p : nullptr),
+                         h->cam_valid.p, h->frame_valid.p, h->board_valid.p, h->board_off.p, h->obs.p, h->valid_fm.p,
+                         h->evalid.p, h->inlier.p, h->view_count.p, view_ecount.p);
+    }
+    hipLaunchKernelGGL(k_view_scan, dim3(1), dim3(1024), 0, h->stream, d, h->view_count.p, (const int32_t*)view_ecount.p,
+                       h->view_first.p, h->totals.p);
+    HIP_OK(hipMemcpyAsync(h->h_totals, h->totals.p, 2 * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));   // (the raw slabs are freed at the end of this scope)
+    REQUIRE(h->h_totals[0] < (1LL << 30), "too many observations for 32-bit residual indices");
+    h->n_inliers = h->h_totals[0];
+    h->n_evalid = h->h_totals[1];
+  }
+  h->obs_index_dirty = true;      // the residual ordering is built on first use (mcba_residuals / mcba_jacobian)
   const double tc2 = now_seconds();
   h->active_views.alloc((size_t)d.views() + 1);
   h->work_counter.alloc(2);
   {
     const int32_t g0[2] = {LIN_GRID_MAX < d.views() ? LIN_GRID_MAX : d.views(), LIN_GRID_MAX < d.views() ? LIN_GRID_MAX : d.views()};
-    HIP_OK(hipMemcpy(h->work_counter.p, g0, sizeof(g0), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpyAsync(h->work_counter.p, g0, sizeof(g0), hipMemcpyHostToDevice, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));   // (g0 lives on the stack)
   }
-  h->n_inliers = hp.n_inliers;
-  h->out_r.alloc((size_t)std::max<int64_t>(2 * hp.n_inliers, 1), false);
+  h->out_r.alloc((size_t)std::max<int64_t>(2 * h->n_inliers, 1), false);
   h->full2act.upload(hp.full2act);
   h->xfull.upload(hp.xfull);
-  h->board_off.upload(hp.board_off);
   h->img_h.upload(hp.img_h);
   h->fix_aspect.upload(hp.fix_aspect);
   h->bwg.upload(hp.bwg);
@@ -716,6 +830,13 @@ int32_t mcba_create(const mcba_problem* p, void* hip_stream, mcba_handle* out) {
   HIP_OK(hipEventCreate(&h->ev0));
   HIP_OK(hipEventCreate(&h->ev1));
   HIP_OK(hipEventCreateWithFlags(&h->ev_fetch, hipEventDisableTiming));
+  {   // the tables of the initial point: the camera table's constant part (image height, fix_aspect) and the board points
+      // when they are not optimised are only ever written here (the fused k_linearize reads them, nothing refreshes them)
+    for (int j = 0; j < d.nfull; ++j)
+      if (hp.full2act[j] >= 0) h->h_x[hp.full2act[j]] = hp.xfull[j];
+    HIP_OK(hipMemcpyAsync(h->x.p, h->h_x, (size_t)d.n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    eval_pose_tables(h.get(), h->x.p);
+  }
   HIP_OK(hipDeviceSynchronize());
   if (timing)
     fprintf(stderr, "[mcba_create] lowering %.2f ms, observation tables up %.2f ms, remaining buffers %.2f ms\n",
@@ -760,9 +881,8 @@ int32_t mcba_num_residuals(mcba_handle h, int64_t* n) {
 int32_t mcba_set_inliers(mcba_handle h, const uint8_t* mask) {
   API_BEGIN
   REQUIRE(h, "null handle");
-  sync(h);
+  g_fill_stream = h->stream;
   build_inliers(h, mask);
-  h->obs_index_dirty = false;
   API_END
 }
 
@@ -891,6 +1011,7 @@ int32_t mcba_jacobian(mcba_handle h, const double* x, int32_t* row_nnz, double* 
 int32_t mcba_reprojection_error(mcba_handle h, const double* x, double* err, uint8_t* valid) {
   API_BEGIN
   REQUIRE(h && x && err && valid, "null argument");
+  g_fill_stream = h->stream;
   const Dims& d = h->d;
   const size_t nref = (size_t)d.C * d.F * d.B * d.P;
   h->out_big.alloc(nref, true);
@@ -907,12 +1028,28 @@ int32_t mcba_reprojection_error(mcba_handle h, const double* x, double* err, uin
 int32_t mcba_project(mcba_handle h, const double* x, double* projected) {
   API_BEGIN
   REQUIRE(h && x && projected, "null argument");
+  g_fill_stream = h->stream;
   const Dims& d = h->d;
   const size_t nref = (size_t)d.C * d.F * d.B * d.P;
   h->out_big.alloc(2 * nref, true);
   upload_x(h, x, h->x.p);
   eval_tables(h, h->x.p);
   h->ops->residual(d, h->t, h->stream, nullptr, h->out_big.p, nullptr, nullptr);
+  HIP_OK(hipMemcpyAsync(projected, h->out_big.p, 2 * nref * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  sync(h);
+  API_END
+}
+
+int32_t mcba_project_model(mcba_handle h, const double* x, int32_t max_iterations, double* projected) {
+  API_BEGIN
+  REQUIRE(h && x && projected && max_iterations >= 0, "bad argument");
+  g_fill_stream = h->stream;
+  const Dims& d = h->d;
+  const size_t nref = (size_t)d.C * d.F * d.B * d.P;
+  h->out_big.alloc(2 * nref, true);
+  upload_x(h, x, h->x.p);
+  eval_tables(h, h->x.p);
+  h->ops->project_model(d, h->t, h->stream, max_iterations, h->out_big.p);
   HIP_OK(hipMemcpyAsync(projected, h->out_big.p, 2 * nref * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   sync(h);
   API_END
@@ -1176,7 +1313,7 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
       // runs while the host looks at the trial cost and prepares the next iteration.  A rejected step leaves the
       // records / H / g of x_new behind (lin_stale): they are not needed by the retries with a smaller radius, and
       // are rebuilt before anything reads them again.
-      timed_linearize(nullptr);   // (the pose tables hold x_new: enqueue_trial ran k_prep for k_cost)
+      timed_linearize(h->xnew.p);   // (fused form: straight from x_new; table form: k_tmat re-derives its entries)
       spec_lin = true;
       fetch_scalars_end(h);
       have_trial = true;
@@ -1248,7 +1385,7 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
     if (actual_reduction > 0) {
       std::swap(h->x.p, h->xnew.p);
       cost = cost_new;
-      if (!spec_valid) timed_linearize(nullptr);   // pose tables already hold x_new
+      if (!spec_valid) timed_linearize(h->x.p);   // (x now points at the accepted x_new)
       fresh_lin = true;
       ++njev;
     } else {
@@ -1286,6 +1423,7 @@ int32_t mcba_error_stats(mcba_handle h, const double* x, int32_t inliers_only, i
   API_BEGIN
   REQUIRE(h && x && n_out && sum_sq, "null argument");
   REQUIRE(n_ranks == 0 || (ranks && values), "null argument");
+  g_fill_stream = h->stream;
   const Dims& d = h->d;
   compute_errors(h, x);
   const uint8_t* m2 = inliers_only ? h->inlier.p : nullptr;
@@ -1294,10 +1432,16 @@ int32_t mcba_error_stats(mcba_handle h, const double* x, int32_t inliers_only, i
   hipLaunchKernelGGL(k_err_sums, dim3(grid), dim3(256), 0, h->stream, h->err_fm.p, h->evalid.p, m2, d.slots(), h->costpart.p);
   hipLaunchKernelGGL(k_sum2, dim3(1), dim3(256), 0, h->stream, h->costpart.p, grid, h->scal.p);
   call_allreduce(h, h->scal.p, 2, 0);
-  fetch_scalars(h, 2);
-  *sum_sq = h->h_scal[0];
-  const int64_t n = (int64_t)h->h_scal[1];
-  *n_out = n;
+  int64_t n;
+  const bool count_known = !h->allreduce;   // single handle: the counts are host-side facts (mcba_error_count)
+  if (count_known && n_ranks > 0) {
+    // one synchronisation for the whole call: the sums come down behind the selection passes
+    n = inliers_only ? h->n_inliers : h->n_evalid;
+    HIP_OK(hipMemcpyAsync(h->h_scal, h->scal.p, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  } else {
+    fetch_scalars(h, 2);
+    n = (int64_t)h->h_scal[1];
+  }
   // consecutive ranks (floor / ceil of a virtual index) share one selection; all selections of a batch share the six
   // passes over the errors
   std::vector<long long> sel;          // distinct selections
@@ -1318,6 +1462,18 @@ int32_t mcba_error_stats(mcba_handle h, const double* x, int32_t inliers_only, i
     select_ranks_multi(h, m2, nsel, sel.data() + k0, vk.data() + k0, vk1.data() + k0);
   }
   for (int i = 0; i < n_ranks; ++i) values[i] = use_next[i] ? vk1[which[i]] : vk[which[i]];
+  *sum_sq = h->h_scal[0];                     // (select_ranks_multi synchronised the stream)
+  REQUIRE(!count_known || n_ranks == 0 || (int64_t)h->h_scal[1] == n, "inlier count out of sync with the device table");
+  *n_out = n;
+  API_END
+}
+
+/* number of points behind mcba_error_stats WITHOUT touching the device: lets the caller compute numpy's quantile ranks
+ * first and make a single mcba_error_stats call.  -1 for a frame-sharded handle (the global count needs a reduction).  */
+int32_t mcba_error_count(mcba_handle h, int32_t inliers_only, int64_t* n) {
+  API_BEGIN
+  REQUIRE(h && n, "null argument");
+  *n = h->allreduce ? -1 : (inliers_only ? h->n_inliers : h->n_evalid);
   API_END
 }
 
@@ -1326,6 +1482,7 @@ int32_t mcba_error_stats(mcba_handle h, const double* x, int32_t inliers_only, i
 int32_t mcba_reject_outliers(mcba_handle h, const double* x, double threshold, int64_t* n_inliers, int64_t* n_valid) {
   API_BEGIN
   REQUIRE(h && x, "null argument");
+  g_fill_stream = h->stream;
   const Dims& d = h->d;
   compute_errors(h, x);
   if (d.views() > 0)
@@ -1361,6 +1518,7 @@ int32_t mcba_reject_outliers(mcba_handle h, const double* x, double threshold, i
 int32_t mcba_get_inliers(mcba_handle h, uint8_t* mask) {
   API_BEGIN
   REQUIRE(h && mask, "null argument");
+  g_fill_stream = h->stream;
   const Dims& d = h->d;
   const size_t nref = (size_t)d.C * d.F * d.B * d.P;
   h->out_valid.alloc(nref, true);
@@ -1376,11 +1534,18 @@ int32_t mcba_time_linearize(mcba_handle h, const double* x, const mcba_options* 
   REQUIRE(h && x && avg_ms && repeats > 0, "bad argument");
   set_loss(h, opt);
   upload_x(h, x, h->x.p);
-  launch_linearize(h, h->x.p);   // warm-up (k_tmat prepares every table the dominant kernel reads)
+  launch_linearize(h, h->x.p);   // warm-up (the table form: k_tmat prepares every table the dominant kernel reads)
   sync(h);
   HIP_OK(hipEventRecord(h->ev0, h->stream));
-  for (int i = 0; i < repeats; ++i)   // the dominant kernel alone (k_tmat ran in the warm-up), as rocprofv3 reports it
-    h->ops->linearize(h->d, h->t, h->stream, h->rec.p, h->tri.p, h->use_mfma, h->lin_grid);
+  for (int i = 0; i < repeats; ++i) {   // the dominant kernel alone, as rocprofv3 reports it (table form: k_tmat ran above)
+    const Dims& d = h->d;
+    static const bool fused_on = getenv("MCBA_FUSED") != nullptr && getenv("MCBA_FUSED")[0] == '1';
+    if (h->use_mfma && d.ND != 14 && d.off_boards < 0 && fused_on)
+      h->ops->linearize(d, h->t, h->stream, h->rec.p, h->tri.p, true, h->lin_grid, h->x.p, h->gbuf.p, 2 * d.n + 2, h->Hss.p,
+                        d.ns * d.ns);
+    else
+      h->ops->linearize(d, h->t, h->stream, h->rec.p, h->tri.p, h->use_mfma, h->lin_grid, nullptr, nullptr, 0, nullptr, 0);
+  }
   HIP_OK(hipEventRecord(h->ev1, h->stream));
   sync(h);
   float ms = 0.f;

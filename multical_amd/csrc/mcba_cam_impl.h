@@ -1,4 +1,5 @@
 // mcba_cam_impl.h -- body of one camera-model translation unit: define MCBA_ND, MCBA_FISH, MCBA_CAM_FN, include.
+#include <algorithm>
 #include "mcba_kernels.h"
 #include "mcba_camops.h"
 
@@ -21,6 +22,13 @@ void residual(const Dims& d, const Tables& t, hipStream_t s, double* r, double* 
     hipLaunchKernelGGL((k_residual<ND_, FISH_, false>), dim3(slot_grid(d)), dim3(256), 0, s, d, t, r, proj, err, valid);
 }
 
+void project_model(const Dims& d, const Tables& t, hipStream_t s, int iterations, double* proj) {
+  if (d.motion == MOTION_ROLLING)
+    hipLaunchKernelGGL((k_project_model<ND_, FISH_, true>), dim3(slot_grid(d)), dim3(256), 0, s, d, t, iterations, proj);
+  else
+    hipLaunchKernelGGL((k_project_model<ND_, FISH_, false>), dim3(slot_grid(d)), dim3(256), 0, s, d, t, iterations, proj);
+}
+
 void cost(const Dims& d, const Tables& t, hipStream_t s, double* partial, int nblk) {
   if (d.motion == MOTION_ROLLING)
     hipLaunchKernelGGL((k_cost<ND_, FISH_, true>), dim3(nblk), dim3(64), 0, s, d, t, partial);
@@ -36,31 +44,38 @@ void jacobian(const Dims& d, const Tables& t, hipStream_t s, int row_nnz, double
 }
 
 template <int MOTION, bool OPTK>
-void lin2(const Dims& d, const Tables& t, hipStream_t s, double* rec, const uint16_t* tri, bool mfma, int epoch) {
-  if (d.views() == 0) return;   // empty frame shard
+void lin2(const Dims& d, const Tables& t, hipStream_t s, double* rec, const uint16_t* tri, bool mfma, int epoch,
+          const double* x, double* za, int na, double* zb, int nb) {
+  if (d.views() == 0 && x == nullptr) return;   // empty frame shard (the fused form still zeroes the assembly targets)
   // persistent wavefronts: 8 single-wave workgroups per CU (2 per SIMD: 256-VGPR budget, 20 KB LDS each) x 256 CUs
   const int want = epoch > 0 ? epoch : LIN_GRID_MAX;   // the last argument carries the debug grid override
-  const dim3 grid(d.views() < want ? d.views() : want), block(64);
+  const dim3 grid(std::max(1, d.views() < want ? d.views() : want)), block(64);
   // the linear loss (the reference's default, calibration.py:199) has its own instantiation of the MFMA kernel: no loss
   // switch and no robust-scale constants in the hot loop; the plain-FMA validation build keeps the generic form
-  if (mfma && d.loss == 0)
-    hipLaunchKernelGGL((k_linearize<ND_, FISH_, MOTION, OPTK, true, false>), grid, block, 0, s, d, t, rec, tri, epoch);
+  if (x != nullptr && mfma && d.loss == 0)
+    hipLaunchKernelGGL((k_linearize<ND_, FISH_, MOTION, OPTK, true, false, true>), grid, block, 0, s, d, t, rec, tri, epoch, x, za, na, zb, nb);
+  else if (x != nullptr && mfma)
+    hipLaunchKernelGGL((k_linearize<ND_, FISH_, MOTION, OPTK, true, true, true>), grid, block, 0, s, d, t, rec, tri, epoch, x, za, na, zb, nb);
+  else if (mfma && d.loss == 0)
+    hipLaunchKernelGGL((k_linearize<ND_, FISH_, MOTION, OPTK, true, false, false>), grid, block, 0, s, d, t, rec, tri, epoch, x, za, na, zb, nb);
   else if (mfma)
-    hipLaunchKernelGGL((k_linearize<ND_, FISH_, MOTION, OPTK, true, true>), grid, block, 0, s, d, t, rec, tri, epoch);
+    hipLaunchKernelGGL((k_linearize<ND_, FISH_, MOTION, OPTK, true, true, false>), grid, block, 0, s, d, t, rec, tri, epoch, x, za, na, zb, nb);
   else
-    hipLaunchKernelGGL((k_linearize<ND_, FISH_, MOTION, OPTK, false, true>), grid, block, 0, s, d, t, rec, tri, epoch);
+    hipLaunchKernelGGL((k_linearize<ND_, FISH_, MOTION, OPTK, false, true, false>), grid, block, 0, s, d, t, rec, tri, epoch, x, za, na, zb, nb);
 }
 
 template <int MOTION>
-void lin1(const Dims& d, const Tables& t, hipStream_t s, double* rec, const uint16_t* tri, bool mfma, int epoch) {
-  if (d.KI > 0) lin2<MOTION, true>(d, t, s, rec, tri, mfma, epoch);
-  else lin2<MOTION, false>(d, t, s, rec, tri, mfma, epoch);
+void lin1(const Dims& d, const Tables& t, hipStream_t s, double* rec, const uint16_t* tri, bool mfma, int epoch,
+          const double* x, double* za, int na, double* zb, int nb) {
+  if (d.KI > 0) lin2<MOTION, true>(d, t, s, rec, tri, mfma, epoch, x, za, na, zb, nb);
+  else lin2<MOTION, false>(d, t, s, rec, tri, mfma, epoch, x, za, na, zb, nb);
 }
 
-void linearize(const Dims& d, const Tables& t, hipStream_t s, double* rec, const uint16_t* tri, bool mfma, int epoch) {
-  if (d.motion == MOTION_STATIC) lin1<MOTION_STATIC>(d, t, s, rec, tri, mfma, epoch);
-  else if (d.motion == MOTION_ROLLING) lin1<MOTION_ROLLING>(d, t, s, rec, tri, mfma, epoch);
-  else lin1<MOTION_HAND_EYE>(d, t, s, rec, tri, mfma, epoch);
+void linearize(const Dims& d, const Tables& t, hipStream_t s, double* rec, const uint16_t* tri, bool mfma, int epoch,
+               const double* x, double* za, int na, double* zb, int nb) {
+  if (d.motion == MOTION_STATIC) lin1<MOTION_STATIC>(d, t, s, rec, tri, mfma, epoch, x, za, na, zb, nb);
+  else if (d.motion == MOTION_ROLLING) lin1<MOTION_ROLLING>(d, t, s, rec, tri, mfma, epoch, x, za, na, zb, nb);
+  else lin1<MOTION_HAND_EYE>(d, t, s, rec, tri, mfma, epoch, x, za, na, zb, nb);
 }
 
 template <int MOTION>
@@ -78,7 +93,7 @@ void points(const Dims& d, const Tables& t, hipStream_t s, int nq, double* Hss, 
   else pts1<MOTION_HAND_EYE>(d, t, s, nq, Hss, Hfs, g);
 }
 
-const CamOps OPS = {residual, cost, jacobian, linearize, points};
+const CamOps OPS = {residual, project_model, cost, jacobian, linearize, points};
 
 }  // namespace
 

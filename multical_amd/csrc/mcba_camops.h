@@ -11,9 +11,12 @@ namespace mcba {
 
 struct CamOps {
   void (*residual)(const Dims&, const Tables&, hipStream_t, double* r, double* proj, double* err, uint8_t* valid);
+  void (*project_model)(const Dims&, const Tables&, hipStream_t, int iterations, double* proj);
   void (*cost)(const Dims&, const Tables&, hipStream_t, double* partial, int nblk);
   void (*jacobian)(const Dims&, const Tables&, hipStream_t, int row_nnz, double* vals, int32_t* cols);
-  void (*linearize)(const Dims&, const Tables&, hipStream_t, double* rec, const uint16_t* tri, bool mfma, int epoch);
+  // x != nullptr: the fused form (k_linearize builds That / the chains from x itself and zeroes za[na], zb[nb])
+  void (*linearize)(const Dims&, const Tables&, hipStream_t, double* rec, const uint16_t* tri, bool mfma, int epoch,
+                    const double* x, double* za, int na, double* zb, int nb);
   void (*points)(const Dims&, const Tables&, hipStream_t, int n_points, double* Hss, double* Hfs, double* g);
 };
 

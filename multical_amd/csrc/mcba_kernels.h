@@ -146,6 +146,36 @@ __global__ void k_residual(Dims d, Tables t, double* __restrict__ r, double* __r
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// k_project_model: Calibration.projected (optimization/calibration.py:113-119): the projection of every table slot WITHOUT
+// the measured points.  Rolling shutter (motion/rolling_frames.py:115-133): scan time 0.5 in the first pass, then
+// `iterations` fixed-point passes with the scan time taken from the projected row of the previous pass; the other motion
+// models project once.  Output in the reference's [C,F,B,P,2] order (host-facing: GUI / reprojection tables).
+// ---------------------------------------------------------------------------------------------------------------
+template <int ND, bool FISH, bool ROLL>
+__global__ void k_project_model(Dims d, Tables t, int iterations, double* __restrict__ proj) {
+  const int n = d.slots();
+  for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
+    const int p = s % d.P, v = s / d.P;
+    const int b = v % d.B, c = (v / d.B) % d.C, fl = v / (d.B * d.C), f = d.f0 + fl;
+    const double height = t.cam[(size_t)c * CAM_STRIDE + CAM_HEIGHT];
+    double uv[2], Xs[3], Xe[3], tr;
+    double2 ob;
+    ob.x = 0.0;
+    ob.y = 0.5 * height;             // scan time 0.5 exactly ((0.5 h) / h)
+    slot_forward<ND, FISH, ROLL, false>(d, t, v, c, b, p, ob, uv, nullptr, nullptr, Xs, Xe, tr);
+    if constexpr (ROLL) {
+      for (int it = 0; it < iterations; ++it) {
+        ob.y = uv[1];                // rolling_times of the projected points: t = y / image height
+        slot_forward<ND, FISH, ROLL, false>(d, t, v, c, b, p, ob, uv, nullptr, nullptr, Xs, Xe, tr);
+      }
+    }
+    const size_t ri = (((size_t)c * d.F + f) * d.B + b) * d.P + p;
+    proj[2 * ri] = uv[0];
+    proj[2 * ri + 1] = uv[1];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // k_cost: 0.5 * sum rho(f^2) over the inliers of the shard; partial sums per workgroup (fixed grid -> deterministic).
 // Persistent single-wave workgroups walk the compact list of non-empty views like k_linearize does: the inlier bytes of
 // a view are ballot-compacted into a point list first, so the projections run on dense 64-lane chunks (about a quarter
@@ -411,9 +441,17 @@ __global__ __launch_bounds__(256) void k_points(Dims d, Tables t, double* __rest
 // designed for, this makes hipcc select the VGPR form of the MFMA: with the default 512-register budget it keeps the
 // loop-carried accumulators in VGPRs, issues AGPR-form MFMAs and brackets EVERY step with 24 v_accvgpr_write +
 // 24 v_accvgpr_read and a full-latency s_nop (196 instead of 64 cycles per MFMA, measured with s_memtime stamps).
-template <int ND, bool FISH, int MOTION, bool OPTK, bool MFMA, bool ROBUST>
+// FUSED: the kernel forms That and the chain matrices of every view ITSELF, straight from x (lanes 0..NPB-1 evaluate the
+// view's pose entries -- Rodrigues + left Jacobian -- into LDS, lanes 0..6 NPB - 1 one column of That each, two more lanes
+// the chain matrices), reads the intrinsics from the camera's block inside x and zeroes the accumulation targets of the
+// assembly: no k_prep / k_tmat launch, no That table (18 MB written + 10 MB read per evaluation at the north-star rig),
+// one kernel boundary less.  Not used for the tilted model (its tilt matrices live in the camera table) and when the
+// board points are optimised (the board-point table must be refreshed): those keep the k_tmat path.
+template <int ND, bool FISH, int MOTION, bool OPTK, bool MFMA, bool ROBUST, bool FUSED>
 __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* __restrict__ rec,
-                                                     const uint16_t* __restrict__ tri, int epoch) {
+                                                     const uint16_t* __restrict__ tri, int epoch,
+                                                     const double* __restrict__ x, double* __restrict__ zero_a, int na,
+                                                     double* __restrict__ zero_b, int nb) {
   constexpr bool ROLL = MOTION == MOTION_ROLLING;
   constexpr int DE = ROLL ? 12 : 6, NPB = MOTION == MOTION_STATIC ? 3 : 4, KI = OPTK ? 4 + ND : 0;
   constexpr int NV = DE + KI + 1, NT = (NV + 15) / 16, NVP = 16 * NT, LDV = NVP + 1;
@@ -441,7 +479,12 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
   __shared__ __attribute__((aligned(16))) double Buf[BUF];   // staging rows in the main loop; [S | Y | M] in the epilogue
   __shared__ double Tm[DE * NPC];
   __shared__ uint16_t pidx[LIN_MAX_POINTS];
+  __shared__ double Vm[FUSED ? (ROLL ? 2 : 1) * VIEW_STRIDE : 1];   // chain matrices of the view (FUSED)
   double* Vbuf = Buf;
+  if constexpr (FUSED) {   // the assembly that follows accumulates into [g | diag | cost] and H_ss
+    for (int e = blockIdx.x * 64 + threadIdx.x; e < na; e += gridDim.x * 64) zero_a[e] = 0.0;
+    for (int e = blockIdx.x * 64 + threadIdx.x; e < nb; e += gridDim.x * 64) zero_b[e] = 0.0;
+  }
 
   // persistent wavefronts: the grid holds about as many workgroups as the chip keeps resident and each one walks the
   // compact list of non-empty views (k_active_views).  One workgroup per view was DISPATCH-bound: ~42 cycles per
@@ -471,7 +514,47 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
 #pragma unroll
     for (int k = 0; k < NPB64; ++k) inb[k] = masked_load_row(mrow, k * 64 + pl, d.P);
   }
-  {   // That of this view, precomputed by k_tmat
+  const double* camp = nullptr;   // FUSED: the camera's parameter block [fx fy cx cy skew k...] inside x (or the constants)
+  if constexpr (FUSED) {
+    camp = d.off_cameras >= 0 ? x + d.off_cameras + c * (5 + ND) : t.xfull + d.foff_cameras + c * (5 + ND);
+    // pose entries of the view from x: lane 0 camera, lane NPB - 1 board, the lanes between the motion poses
+    static_assert(NPB * POSE_STRIDE <= BUF, "pose entries do not fit the staging buffer");
+    double* Pl = Buf;                      // (the staging buffer is free until the first chunk)
+    if (pl < NPB) {
+      int jf;
+      if (pl == 0) jf = d.foff_campose + 6 * c;
+      else if (pl == NPB - 1) jf = d.foff_boardpose + 6 * b;
+      else if (MOTION == MOTION_STATIC) jf = d.foff_motion + 6 * f;
+      else if (MOTION == MOTION_ROLLING) jf = d.foff_motion + 6 * ((pl - 1) * d.F + f);
+      else jf = d.foff_motion + 6 * (pl - 1);
+      double rt[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) rt[k] = param_value(t, x, jf + k);
+      double pe[POSE_STRIDE];
+      pose_entry(rt, pe);
+#pragma unroll
+      for (int k = 0; k < POSE_STRIDE; ++k) Pl[pl * POSE_STRIDE + k] = pe[k];
+    }
+    lds_fence();
+    const double* Pc = Pl;
+    const double* Pb = Pl + (NPB - 1) * POSE_STRIDE;
+    const double* Pm0 = Pl + POSE_STRIDE;
+    const double* Pm1 = Pl + (NPB > 3 ? 2 : 1) * POSE_STRIDE;
+    const double* Bf = t.bwg + 12 * (size_t)f;
+    if (pl < NPC) {                        // one column of That per lane
+      double col[DE];
+      view_column_p(d, Pc, Pb, Pm0, Pm1, Bf, pl, col);
+#pragma unroll
+      for (int a = 0; a < DE; ++a) Tm[a * NPC + pl] = col[a];
+    } else if (pl < NPC + (ROLL ? 2 : 1)) {   // the chain matrices board -> camera (start / end pose)
+      const int ch = pl - NPC;
+      double Vc[VIEW_STRIDE];
+      view_chain_p(d, Pc, Pb, (ROLL && ch == 1) ? Pm1 : Pm0, Pm1, Bf, Vc);
+#pragma unroll
+      for (int k = 0; k < VIEW_STRIDE; ++k) Vm[ch * VIEW_STRIDE + k] = Vc[k];
+    }
+    lds_fence();                           // Pl is dead: the staging buffer may be written again
+  } else {   // That of this view, precomputed by k_tmat
     const double* tg = t.tmat + (size_t)v * (DE * NPC);
     constexpr int NTL = (DE * NPC + 63) / 64;
     double tl[NTL];
@@ -528,7 +611,7 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
     long long t0 = 0;
     if (prof) t0 = clock64();
     if (in) {
-      cost += point_state<ND, FISH, ROLL, ROBUST>(d, t, v, c, b, p_cur, ob_cur, ps, X_cur);
+      cost += point_state<ND, FISH, ROLL, ROBUST>(d, t, v, c, b, p_cur, ob_cur, ps, X_cur, FUSED ? Vm : nullptr, camp);
     } else {   // lanes past the end of the list stage zero rows
       ps = PointState<ND, ROLL>{};
     }

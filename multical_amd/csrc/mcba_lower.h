@@ -124,7 +124,9 @@ inline void lower_inliers(HostProblem& hp, const uint8_t* mask_ref) {
   hp.n_inliers = count;
 }
 
-inline void lower_problem(const mcba_problem* p, HostProblem& hp) {
+// shape, index maps and the small parameter tables (everything but the per-slot tables): what mcba_create needs on the
+// host -- the slot tables are built on the device (k_lower_view)
+inline void lower_dims(const mcba_problem* p, HostProblem& hp) {
   MCBA_REQUIRE(p != nullptr, "null problem");
   MCBA_REQUIRE(p->version == MCBA_VERSION, "mcba_problem.version mismatch");
   MCBA_REQUIRE(p->n_cameras > 0 && p->n_frames > 0 && p->n_boards > 0 && p->n_points > 0, "empty problem");
@@ -189,6 +191,43 @@ inline void lower_problem(const mcba_problem* p, HostProblem& hp) {
   d.n_pose = d.C + d.B + d.n_motion / 6;
   MCBA_REQUIRE((int64_t)d.slots() < (1LL << 31), "observation table too large for 32-bit slot indices");
 
+  // ---- parameter tables -------------------------------------------------------------------------------------
+  {
+    std::vector<int32_t> f2a((size_t)d.nfull, -1);
+    for (int k = 0; k < 5; ++k)
+      if (aoff[k] >= 0)
+        for (int i = 0; i < sizes[k]; ++i) f2a[foff[k] + i] = aoff[k] + i;
+    hp.full2act = f2a;
+    hp.xfull.assign(p->x_full, p->x_full + d.nfull);
+    hp.board_off = board_off;
+    hp.img_h.assign(p->image_heights, p->image_heights + d.C);
+    hp.fix_aspect.assign(p->fix_aspect, p->fix_aspect + d.C);
+    std::vector<double> bwg;
+    if (d.motion == MOTION_HAND_EYE) {
+      bwg.resize((size_t)12 * d.F);
+      for (int f = 0; f < d.F; ++f) {
+        const double* m = p->base_wrt_gripper + 16 * (size_t)f;
+        for (int i = 0; i < 3; ++i) {
+          for (int j = 0; j < 3; ++j) bwg[12 * f + 3 * i + j] = m[4 * i + j];
+          bwg[12 * f + 9 + i] = m[4 * i + 3];
+        }
+      }
+    }
+    hp.bwg = bwg;
+    std::vector<uint16_t> tri((size_t)d.rec_size);
+    size_t e = 0;
+    for (int i = 0; i < d.N1; ++i)
+      for (int j = i; j < d.N1; ++j) tri[e++] = (uint16_t)((i << 8) | j);
+    hp.tri = tri;
+  }
+}
+
+// the complete host lowering incl. the per-slot tables: used by tests/hostmath (the CPU build of the device functions);
+// the product builds the slot tables on the device
+inline void lower_problem(const mcba_problem* p, HostProblem& hp) {
+  lower_dims(p, hp);
+  const Dims& d = hp.d;
+
   // ---- masks (Calibration.valid, calibration.py:69-76; tables.reprojection_error mask, tables.py:244-249) ----
   const size_t nref = (size_t)d.C * d.F * d.B * d.P;
   hp.valid_ref.resize(nref);
@@ -227,36 +266,6 @@ inline void lower_problem(const mcba_problem* p, HostProblem& hp) {
     });
   }
   lower_inliers(hp, p->inlier_mask);
-
-  // ---- parameter tables -------------------------------------------------------------------------------------
-  {
-    std::vector<int32_t> f2a((size_t)d.nfull, -1);
-    for (int k = 0; k < 5; ++k)
-      if (aoff[k] >= 0)
-        for (int i = 0; i < sizes[k]; ++i) f2a[foff[k] + i] = aoff[k] + i;
-    hp.full2act = f2a;
-    hp.xfull.assign(p->x_full, p->x_full + d.nfull);
-    hp.board_off = board_off;
-    hp.img_h.assign(p->image_heights, p->image_heights + d.C);
-    hp.fix_aspect.assign(p->fix_aspect, p->fix_aspect + d.C);
-    std::vector<double> bwg;
-    if (d.motion == MOTION_HAND_EYE) {
-      bwg.resize((size_t)12 * d.F);
-      for (int f = 0; f < d.F; ++f) {
-        const double* m = p->base_wrt_gripper + 16 * (size_t)f;
-        for (int i = 0; i < 3; ++i) {
-          for (int j = 0; j < 3; ++j) bwg[12 * f + 3 * i + j] = m[4 * i + j];
-          bwg[12 * f + 9 + i] = m[4 * i + 3];
-        }
-      }
-    }
-    hp.bwg = bwg;
-    std::vector<uint16_t> tri((size_t)d.rec_size);
-    size_t e = 0;
-    for (int i = 0; i < d.N1; ++i)
-      for (int j = i; j < d.N1; ++j) tri[e++] = (uint16_t)((i << 8) | j);
-    hp.tri = tri;
-  }
 }
 
 }  // namespace mcba

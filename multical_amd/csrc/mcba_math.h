@@ -172,10 +172,14 @@ MCBA_HD void camera_entry(const double* p, int n_dist, double image_height, bool
 //   Kc[2*(4+ND)]     d(u,v)/d(fx, fy, cx, cy, k_0..k_{ND-1}), row-major 2 x (4+ND); skew column omitted (== 0).
 //                    Under fix_aspect column 0 is d/df of the single focal parameter and column 1 is zero.
 // ---------------------------------------------------------------------------------------------------------
+// `cam` points at the parameter block [fx fy cx cy skew k...] -- the head of a camera-table entry, or the camera's block
+// inside x itself (same order, camera.py:150-155) -- and `ext` at the table entry's tail [T dTx dTy height fix_aspect]
+// (CAM_TILT onwards).  Under fix_aspect the second focal entry is ignored (camera.py:159-160).
 template <int ND, bool FISHEYE, bool JAC>
-MCBA_HD void project_point(const double* cam, const double* X, double* uv, double* A, double* Kc) {
+MCBA_HD void project_point(const double* cam, const double* ext, const double* X, double* uv, double* A, double* Kc) {
   constexpr int KI = 4 + ND;
-  const double fx = cam[CAM_FX], fy = cam[CAM_FY], cx = cam[CAM_CX], cy = cam[CAM_CY];
+  const bool fa = ext[CAM_FIXASPECT - CAM_TILT] != 0.0;
+  const double fx = cam[CAM_FX], fy = fa ? cam[CAM_FX] : cam[CAM_FY], cx = cam[CAM_CX], cy = cam[CAM_CY];
   const double* k = cam + CAM_K;
   const double Z = X[2];
   const double iz = (Z != 0.0) ? 1.0 / Z : 1.0;   // cvProjectPoints2Internal: z = z ? 1/z : 1
@@ -259,7 +263,7 @@ MCBA_HD void project_point(const double* cam, const double* X, double* uv, doubl
       }
     }
     if constexpr (ND >= 14) {
-      const double* T = cam + CAM_TILT;
+      const double* T = ext;
       const double vx = T[0] * xd0 + T[1] * yd0 + T[2];
       const double vy = T[3] * xd0 + T[4] * yd0 + T[5];
       const double vz = T[6] * xd0 + T[7] * yd0 + T[8];
@@ -277,7 +281,7 @@ MCBA_HD void project_point(const double* cam, const double* X, double* uv, doubl
           dk[i] = t00 * ax + t01 * ay;
           dk[ND + i] = t10 * ax + t11 * ay;
         }
-        const double* D[2] = {cam + CAM_DTX, cam + CAM_DTY};
+        const double* D[2] = {ext + (CAM_DTX - CAM_TILT), ext + (CAM_DTY - CAM_TILT)};
         for (int q = 0; q < 2; ++q) {
           const double* d = D[q];
           const double wx = d[0] * xd0 + d[1] * yd0 + d[2];
@@ -302,7 +306,6 @@ MCBA_HD void project_point(const double* cam, const double* X, double* uv, doubl
     const double ux = fx * dxx, uy = fx * dxy, vx_ = fy * dyx, vy_ = fy * dyy;
     A[0] = ux * iz; A[1] = uy * iz; A[2] = -(ux * x + uy * y) * iz;
     A[3] = vx_ * iz; A[4] = vy_ * iz; A[5] = -(vx_ * x + vy_ * y) * iz;
-    const bool fa = cam[CAM_FIXASPECT] != 0.0;
     // row 0 (u)                           row 1 (v)
     Kc[0] = xd;                            Kc[KI + 0] = fa ? yd : 0.0;
     Kc[1] = 0.0;                           Kc[KI + 1] = fa ? 0.0 : yd;

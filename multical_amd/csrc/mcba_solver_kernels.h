@@ -92,8 +92,13 @@ __global__ __launch_bounds__(64) void k_tmat(Dims d, Tables t, double* __restric
     }
   }
   __syncthreads();
-  double* tg = t.tmat + (size_t)v0 * vsz;   // views of a workgroup are contiguous; empty views get stale LDS (never read)
-  for (int e = threadIdx.x; e < nv * vsz; e += blockDim.x) tg[e] = tile[e];
+  // views of a workgroup are contiguous: coalesced stores; empty views (45 % of the north-star rig) are skipped -- nobody
+  // reads their That, and the table is the largest thing this kernel writes (18 MB for all views)
+  double* tg = t.tmat + (size_t)v0 * vsz;
+  for (int vv = 0; vv < nv; ++vv) {
+    if (t.view_count[v0 + vv] == 0) continue;
+    for (int e = threadIdx.x; e < vsz; e += blockDim.x) tg[vv * vsz + e] = tile[vv * vsz + e];
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1714,6 +1719,121 @@ __global__ void k_active_views(int nviews, const int32_t* __restrict__ view_coun
     }
   }
   if (threadIdx.x == 0) out[0] = base;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// lowering ON THE DEVICE (mcba_create / mcba_set_inliers): the caller's arrays are uploaded as they are -- the shard's
+// frames of point_table.points / .valid / inlier_mask in the reference's [C][F][B][P] order, one contiguous slab per
+// camera -- and these kernels build the frame-major tables from them.  (The host loops they replace cost 7 ms per
+// Calibration at the north-star rig: three passes over 2.6 M slots.)
+//   Calibration.valid / inliers                      optimization/calibration.py:69-81
+//   mask of tables.reprojection_error                 tables.py:244-249 (reprojected.valid & point_table.valid)
+//   residual ordering of `evaluate`                   calibration.py:204-206 (C-order over the inlier mask)
+// ---------------------------------------------------------------------------------------------------------------
+// one wavefront per view v (frame-major) of the shard; raw slabs are [C][Fl][B][P]
+__global__ __launch_bounds__(64) void k_lower_view(Dims d, const double2* __restrict__ pts_raw,
+                                                   const uint8_t* __restrict__ pvalid_raw,
+                                                   const uint8_t* __restrict__ mask_raw /* or null: inliers = valid */,
+                                                   const uint8_t* __restrict__ cam_valid, const uint8_t* __restrict__ frame_valid,
+                                                   const uint8_t* __restrict__ board_valid, const int32_t* __restrict__ board_off,
+                                                   double2* __restrict__ obs, uint8_t* __restrict__ valid_fm,
+                                                   uint8_t* __restrict__ evalid, uint8_t* __restrict__ inlier,
+                                                   int32_t* __restrict__ view_count, int32_t* __restrict__ view_ecount) {
+  const int v = blockIdx.x, lane = threadIdx.x;
+  const int b = v % d.B, c = (v / d.B) % d.C, fl = v / (d.B * d.C), f = d.f0 + fl;
+  const bool pv = cam_valid[c] && frame_valid[f] && board_valid[b];
+  const int nb = board_off[b + 1] - board_off[b];
+  const size_t r0 = (((size_t)c * d.Fl + fl) * d.B + b) * d.P, s0 = (size_t)v * d.P;
+  int cnt = 0, ecnt = 0;
+  for (int q0 = 0; q0 < d.P; q0 += 64) {
+    const int q = q0 + lane;
+    bool in = false, ev = false;
+    if (q < d.P) {
+      const bool vv = pv && pvalid_raw[r0 + q] != 0;
+      ev = vv && q < nb;
+      in = mask_raw != nullptr ? mask_raw[r0 + q] != 0 : vv;
+      if (pts_raw != nullptr) obs[s0 + q] = pts_raw[r0 + q];
+      if (valid_fm != nullptr) { valid_fm[s0 + q] = vv ? 1 : 0; evalid[s0 + q] = ev ? 1 : 0; }
+      inlier[s0 + q] = in ? 1 : 0;
+    }
+    cnt += __popcll(__ballot(in));
+    ecnt += __popcll(__ballot(ev));
+  }
+  if (lane == 0) {
+    view_count[v] = cnt;
+    if (view_ecount != nullptr) view_ecount[v] = ecnt;
+  }
+}
+
+// inliers = valid (mcba_set_inliers(NULL)): from the frame-major validity table kept on the device
+__global__ __launch_bounds__(64) void k_inliers_from_valid(Dims d, const uint8_t* __restrict__ valid_fm,
+                                                           uint8_t* __restrict__ inlier, int32_t* __restrict__ view_count) {
+  const int v = blockIdx.x, lane = threadIdx.x;
+  const size_t s0 = (size_t)v * d.P;
+  int cnt = 0;
+  for (int q0 = 0; q0 < d.P; q0 += 64) {
+    const int q = q0 + lane;
+    const bool in = q < d.P && valid_fm[s0 + q] != 0;
+    if (q < d.P) inlier[s0 + q] = in ? 1 : 0;
+    cnt += __popcll(__ballot(in));
+  }
+  if (lane == 0) view_count[v] = cnt;
+}
+
+// exclusive prefix of the per-view inlier counts in the REFERENCE order of the views (camera, frame, board) -- the order
+// of the residual vector -- written back per frame-major view: first[v] = index of the view's first residual pair;
+// totals[0] = number of inliers, totals[1] = sum of the second count array (may be null).  One workgroup.
+__global__ __launch_bounds__(1024) void k_view_scan(Dims d, const int32_t* __restrict__ view_count,
+                                                    const int32_t* __restrict__ view_ecount, int32_t* __restrict__ first,
+                                                    long long* __restrict__ totals) {
+  __shared__ long long wsum[16], wsum_e[16];
+  const int nv = d.views(), tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = (nv + 1023) / 1024, r0 = tid * per, r1 = min(nv, r0 + per);
+  auto fm_of = [&](int r) {   // reference-order view index r = (c Fl + fl) B + b  ->  frame-major index
+    const int b = r % d.B, fl = (r / d.B) % d.Fl, c = r / (d.B * d.Fl);
+    return (fl * d.C + c) * d.B + b;
+  };
+  long long mine = 0, mine_e = 0;
+  for (int r = r0; r < r1; ++r) {
+    const int v = fm_of(r);
+    mine += view_count[v];
+    if (view_ecount != nullptr) mine_e += view_ecount[v];
+  }
+  long long incl = mine, incl_e = mine_e;
+  for (int off = 1; off < 64; off <<= 1) {
+    const long long o = __shfl_up(incl, off, 64), oe = __shfl_up(incl_e, off, 64);
+    if (lane >= off) { incl += o; incl_e += oe; }
+  }
+  if (lane == 63) { wsum[wave] = incl; wsum_e[wave] = incl_e; }
+  __syncthreads();
+  long long base = 0, tot = 0, tot_e = 0;
+  for (int w = 0; w < 16; ++w) {
+    if (w < wave) base += wsum[w];
+    tot += wsum[w];
+    tot_e += wsum_e[w];
+  }
+  long long run = base + incl - mine;
+  for (int r = r0; r < r1; ++r) {
+    const int v = fm_of(r);
+    first[v] = (int32_t)run;
+    run += view_count[v];
+  }
+  if (tid == 0) { totals[0] = tot; totals[1] = tot_e; }
+}
+
+// residual index of every slot: obs_index[s] = first[v] + (number of inliers before p in the view), -1 if not an inlier
+__global__ __launch_bounds__(64) void k_obs_index(Dims d, const uint8_t* __restrict__ inlier, const int32_t* __restrict__ first,
+                                                  int32_t* __restrict__ obs_index) {
+  const int v = blockIdx.x, lane = threadIdx.x;
+  const size_t s0 = (size_t)v * d.P;
+  int base = first[v];
+  for (int q0 = 0; q0 < d.P; q0 += 64) {
+    const int q = q0 + lane;
+    const bool in = q < d.P && inlier[s0 + q] != 0;
+    const unsigned long long m = __ballot(in);
+    if (q < d.P) obs_index[s0 + q] = in ? base + __popcll(m & ((1ull << lane) - 1ull)) : -1;
+    base += __popcll(m);
+  }
 }
 
 // frame-major inlier table -> reference [C,F,B,P] order (only this shard's frames are written)

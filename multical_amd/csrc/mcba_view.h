@@ -26,37 +26,41 @@ template <int ND, bool FISH, bool ROLL, bool JAC>
 MCBA_HD void slot_forward(const Dims& d, const Tables& t, int v, int c, int b, int p, double2 ob,
                                              double* uv, double* A, double* Kc, double* Xs, double* Xe, double& tr,
                                              const double* Xpre = nullptr /* prefetched board point */,
-                                             const double* Vpre = nullptr /* chain matrices of the view in registers */) {
+                                             const double* Vpre = nullptr /* chain matrices of the view (registers / LDS) */,
+                                             const double* camp = nullptr /* the camera's parameter block inside x */) {
   const double* X = Xpre != nullptr ? Xpre : t.board_points + 3 * (size_t)(b * d.P + p);
   const double* V = Vpre != nullptr ? Vpre : t.view + (size_t)v * (VIEW_STRIDE * (ROLL ? 2 : 1));
   const double* cam = t.cam + (size_t)c * CAM_STRIDE;
+  const double* ext = cam + CAM_TILT;
+  if (camp != nullptr) cam = camp;
   const double bx = X[0], by = X[1], bz = X[2];
   double Xc[3];
   for (int i = 0; i < 3; ++i) Xs[i] = V[3 * i] * bx + V[3 * i + 1] * by + V[3 * i + 2] * bz + V[9 + i];
   if constexpr (ROLL) {
     const double* W = V + VIEW_STRIDE;
     for (int i = 0; i < 3; ++i) Xe[i] = W[3 * i] * bx + W[3 * i + 1] * by + W[3 * i + 2] * bz + W[9 + i];
-    tr = ob.y / cam[CAM_HEIGHT];                                  // rolling_frames.py:15-19 (observed row)
+    tr = ob.y / ext[CAM_HEIGHT - CAM_TILT];                       // rolling_frames.py:15-19 (observed row)
     for (int i = 0; i < 3; ++i) Xc[i] = Xs[i] * (1.0 - tr) + Xe[i] * tr;   // interpolate.py:6-8
   } else {
     tr = 0.0;
     for (int i = 0; i < 3; ++i) Xc[i] = Xs[i];
   }
-  project_point<ND, FISH, JAC>(cam, Xc, uv, A, Kc);
+  project_point<ND, FISH, JAC>(cam, ext, Xc, uv, A, Kc);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // pose-block structure of a view: column j of That (DE rows) and the x index of every local parameter
 // ---------------------------------------------------------------------------------------------------------------
-MCBA_HD void view_column(const Dims& d, const Tables& t, int f, int c, int b, int j, double* col, int stride = 1) {
+// column j of That from explicit pose entries: Pc camera, Pb board, Pm0 / Pm1 the motion entries (static: Pm0 = frame;
+// rolling: start / end pose of the frame; hand-eye: world_wrt_base / gripper_wrt_camera), Bf = base_wrt_gripper[f] (R | t)
+MCBA_HD void view_column_p(const Dims& d, const double* Pc, const double* Pb, const double* Pm0, const double* Pm1,
+                           const double* Bf, int j, double* col, int stride = 1) {
   const int k = j / 6, jj = j % 6;
   const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-  const double* Pc = t.pose + (size_t)(d.pose_cam + c) * POSE_STRIDE;
-  const double* Pb = t.pose + (size_t)(d.pose_board + b) * POSE_STRIDE;
   const double* Rc = Pc + POSE_R;
   const double* tc = Pc + POSE_T;
   if (d.motion == MOTION_STATIC) {
-    const double* Pf = t.pose + (size_t)(d.pose_motion + f) * POSE_STRIDE;
+    const double* Pf = Pm0;
     if (k == 0) {
       view_pose_column(I3, Pc + POSE_L, tc, jj, col, stride);
     } else {
@@ -79,7 +83,7 @@ MCBA_HD void view_column(const Dims& d, const Tables& t, int f, int c, int b, in
     } else {
       for (int ch = 0; ch < 2; ++ch) {
         if ((k == 1 && ch == 1) || (k == 2 && ch == 0)) continue;
-        const double* Pf = t.pose + (size_t)(d.pose_motion + ch * d.F + f) * POSE_STRIDE;
+        const double* Pf = ch == 0 ? Pm0 : Pm1;
         double R1[9], t1[3];
         se3_mul(Rc, tc, Pf + POSE_R, Pf + POSE_T, R1, t1);
         if (k == 3) {
@@ -93,9 +97,8 @@ MCBA_HD void view_column(const Dims& d, const Tables& t, int f, int c, int b, in
       }
     }
   } else {  // hand-eye: chain camera . G . B_f . Wb . board ; local blocks: cam | wb | gc | board
-    const double* Wb = t.pose + (size_t)(d.pose_motion + 0) * POSE_STRIDE;
-    const double* G = t.pose + (size_t)(d.pose_motion + 1) * POSE_STRIDE;
-    const double* Bf = t.bwg + 12 * (size_t)f;
+    const double* Wb = Pm0;
+    const double* G = Pm1;
     if (k == 0) {
       view_pose_column(I3, Pc + POSE_L, tc, jj, col, stride);
     } else {
@@ -118,6 +121,42 @@ MCBA_HD void view_column(const Dims& d, const Tables& t, int f, int c, int b, in
       }
     }
   }
+}
+MCBA_HD void view_column(const Dims& d, const Tables& t, int f, int c, int b, int j, double* col, int stride = 1) {
+  const double* Pc = t.pose + (size_t)(d.pose_cam + c) * POSE_STRIDE;
+  const double* Pb = t.pose + (size_t)(d.pose_board + b) * POSE_STRIDE;
+  const double* Pm0;
+  const double* Pm1;
+  if (d.motion == MOTION_STATIC) {
+    Pm0 = Pm1 = t.pose + (size_t)(d.pose_motion + f) * POSE_STRIDE;
+  } else if (d.motion == MOTION_ROLLING) {
+    Pm0 = t.pose + (size_t)(d.pose_motion + f) * POSE_STRIDE;
+    Pm1 = t.pose + (size_t)(d.pose_motion + d.F + f) * POSE_STRIDE;
+  } else {
+    Pm0 = t.pose + (size_t)(d.pose_motion + 0) * POSE_STRIDE;
+    Pm1 = t.pose + (size_t)(d.pose_motion + 1) * POSE_STRIDE;
+  }
+  view_column_p(d, Pc, Pb, Pm0, Pm1, t.bwg + 12 * (size_t)f, j, col, stride);
+}
+
+// chain matrix board -> camera from explicit pose entries (Pm = the motion entry of the wanted chain; hand-eye: Pm0 =
+// world_wrt_base, Pm1 = gripper_wrt_camera): out[12] = R | t
+MCBA_HD void view_chain_p(const Dims& d, const double* Pc, const double* Pb, const double* Pm0, const double* Pm1,
+                          const double* Bf, double* out) {
+  double R1[9], t1[3], R2[9], t2[3];
+  if (d.motion == MOTION_HAND_EYE) {
+    const double* Wb = Pm0;
+    const double* G = Pm1;
+    se3_mul(Pc + POSE_R, Pc + POSE_T, G + POSE_R, G + POSE_T, R1, t1);
+    se3_mul(R1, t1, Bf, Bf + 9, R2, t2);
+    se3_mul(R2, t2, Wb + POSE_R, Wb + POSE_T, R1, t1);
+    se3_mul(R1, t1, Pb + POSE_R, Pb + POSE_T, R2, t2);
+  } else {
+    se3_mul(Pc + POSE_R, Pc + POSE_T, Pm0 + POSE_R, Pm0 + POSE_T, R1, t1);
+    se3_mul(R1, t1, Pb + POSE_R, Pb + POSE_T, R2, t2);
+  }
+  for (int k = 0; k < 9; ++k) out[k] = R2[k];
+  for (int k = 0; k < 3; ++k) out[9 + k] = t2[k];
 }
 
 // Where the pose entries (R, t, L) of a view come from: the global pose table written by k_prep, or a workgroup-local
@@ -252,9 +291,10 @@ struct PointState {
 // ROBUST = false compiles the linear loss in (no loss switch, no row scaling: the hot kernel's default instantiation)
 template <int ND, bool FISH, bool ROLL, bool ROBUST = true>
 MCBA_HD double point_state(const Dims& d, const Tables& t, int v, int c, int b, int p, double2 ob,
-                           PointState<ND, ROLL>& st, const double* Xpre = nullptr) {
+                           PointState<ND, ROLL>& st, const double* Xpre = nullptr, const double* Vpre = nullptr,
+                           const double* camp = nullptr) {
   double uv[2];
-  slot_forward<ND, FISH, ROLL, true>(d, t, v, c, b, p, ob, uv, st.A, st.Kc, st.Xs, st.Xe, st.tr, Xpre);
+  slot_forward<ND, FISH, ROLL, true>(d, t, v, c, b, p, ob, uv, st.A, st.Kc, st.Xs, st.Xe, st.tr, Xpre, Vpre, camp);
   st.e[0] = uv[0] - ob.x;
   st.e[1] = uv[1] - ob.y;
   double rho = 0.0;

@@ -155,11 +155,12 @@ def _evaluate(c0, x):
   return (c.reprojected.points - c.point_table.points)[c0.inliers].ravel()
 
 
-def _dense_polish(calib, x, iters=12):
+def _dense_polish(calib, x, iters=60):
   """Converged optimum of the reference's residual function on the inlier set of `calib`, for problems too large for
-  scipy's exact (SVD) trust-region solver: damped Gauss-Newton on the DENSE normal equations of the reference's own
-  `evaluate`, Jacobian by scipy's 3-point differences with the reference's sparsity (column scaling like x_scale='jac',
-  damping 1e-10 in the scaled space: the 12 gauge directions have zero gradient).  Independent of the HIP code."""
+  scipy's exact (SVD) trust-region solver: Levenberg-Marquardt on the DENSE normal equations of the reference's own
+  `evaluate`, Jacobian by scipy's 3-point differences with the reference's sparsity (column scaling like x_scale='jac';
+  the damping starts at 1e-8 in the scaled space -- the 12 gauge directions have zero gradient -- and adapts).  Stops
+  when two consecutive accepted steps reduce the cost by less than 1e-14 relative.  Independent of the HIP code."""
   from scipy.optimize._numdiff import approx_derivative, group_columns
   from scipy.sparse import csr_matrix
   S = csr_matrix(calib.sparsity_matrix)
@@ -167,6 +168,7 @@ def _dense_polish(calib, x, iters=12):
   fun = lambda v: _evaluate(calib, v)
   f = fun(x)
   cost = 0.5 * f @ f
+  lam, small = 1e-8, 0
   for it in range(iters):
     J = csr_matrix(approx_derivative(fun, x, method='3-point', f0=f, sparsity=(S, groups)))
     H = (J.T @ J).toarray()
@@ -174,19 +176,22 @@ def _dense_polish(calib, x, iters=12):
     d = np.sqrt(np.diag(H))
     d[d == 0] = 1
     Hs = H / d[:, None] / d[None, :]
-    step = -np.linalg.solve(Hs + 1e-10 * np.eye(x.size), g / d) / d
-    lam = 1.0
-    while lam > 1e-4:
-      fn = fun(x + lam * step)
+    accepted = False
+    for _ in range(12):
+      step = -np.linalg.solve(Hs + lam * np.eye(x.size), g / d) / d
+      fn = fun(x + step)
       cn = 0.5 * fn @ fn
       if cn <= cost:
+        accepted = True
         break
-      lam *= 0.5
-    if not cn <= cost:
+      lam *= 10.0
+    if not accepted:
       break
     rel = (cost - cn) / cost
-    x, f, cost = x + lam * step, fn, cn
-    if rel < 1e-15:
+    x, f, cost = x + step, fn, cn
+    lam = max(lam * 0.1, 1e-12)
+    small = small + 1 if rel < 1e-14 else 0
+    if small >= 2:
       break
   return x, cost
 

@@ -226,6 +226,29 @@ class OracleCalibration(object):
       local = self._transform(tabs[0], wp)
     return self._project_cameras(local), valid
 
+  def projected(self, max_iterations=4):
+    """calibration.py:113-119 -> motion.project(cameras, camera_poses, world_points) WITHOUT estimates: what the GUI /
+    interface/view_table.py:43-52 consume.  Static / hand-eye: the plain projection.  Rolling shutter
+    (motion/rolling_frames.py:115-133): scan time 0.5 for the first pass, then `max_iterations` fixed-point passes with the
+    scan time taken from the PROJECTED row of the previous pass."""
+    wp, wvalid = self.world_points
+    view_valid = np.expand_dims(self.camera_valid, 1) & np.expand_dims(self.motion.valid, 0)
+    valid = np.expand_dims(view_valid, (2, 3)) & np.expand_dims(wvalid, (0, 1))
+    tabs = self._frame_tables()
+    if self.motion.kind != 'rolling':
+      return self._project_cameras(self._transform(tabs[0], wp)), valid
+    heights = np.array([cam.image_size[1] for cam in self.cameras])
+    start, end = self._transform(tabs[0], wp), self._transform(tabs[1], wp)
+
+    def project_at(times):
+      t = np.expand_dims(times, times.ndim)
+      return self._project_cameras(start * (1 - t) + end * t)
+
+    points = project_at(np.full(valid.shape, 0.5))                                 # rolling_frames.py:119-120
+    for _ in range(max_iterations):                                                # :128-131
+      points = project_at(points[..., 1] / np.expand_dims(heights, (1, 2, 3)))     # rolling_times(cameras, points)
+    return points, valid
+
   # --- parameters (calibration.py:146-171, parameters.py:44-50,88-106) -----------------------------
   def _blocks(self):
     m = self.motion

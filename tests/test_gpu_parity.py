@@ -476,3 +476,58 @@ def test_handle_cache_sees_a_changed_validity_mask_and_float32_tables():
     cm = mirror(rg)
     ocm = restate.from_rig(rg)
     assert np.abs(cm.residuals() - ocm.evaluate(cm.param_vec)).max() < 1e-9
+
+
+def test_fused_linearisation_form_matches_the_table_form():
+  """MCBA_FUSED=1: k_linearize forms That / the chain matrices / the intrinsics straight from x (no k_prep / k_tmat
+  launch).  Runs in a subprocess (the switch is read once per process) and must reproduce the normal equations of the
+  default table form to round-off, for every motion model, and the same solve."""
+  import os, subprocess, sys, json
+  code = r'''
+import sys, json, numpy as np
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+from util import load_golden, mirror
+from multical_amd.backend import Handle
+out = {}
+for name in ["tiny", "tiny_rolling", "tiny_handeye", "tiny_fisheye", "tiny_edge", "tiny_pin4", "cfg1"]:
+  g, rig = load_golden(name)
+  with Handle(mirror(rig)) as h:
+    cost, grad, diag = h.normal_equations(g["x0"])
+    H = h.dense_hessian()
+    res = h.solve(g["x0"])
+  out[name] = dict(cost=cost, grad=grad.tolist(), hsum=float(np.abs(H).sum()), H=H.ravel()[::7].tolist(), nfev=res.nfev,
+                   final=res.cost)
+print("RESULT" + json.dumps(out))
+'''
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  res = {}
+  for fused in ("0", "1"):
+    env = dict(os.environ, MCBA_FUSED=fused)
+    p = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    res[fused] = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT")][0][6:])
+  for name, a in res["0"].items():
+    b = res["1"][name]
+    assert b["cost"] == pytest.approx(a["cost"], rel=1e-13), name
+    ga, gb = np.array(a["grad"]), np.array(b["grad"])
+    assert np.abs(ga - gb).max() <= 1e-11 * np.abs(ga).max(), name
+    Ha, Hb = np.array(a["H"]), np.array(b["H"])
+    assert np.abs(Ha - Hb).max() <= 1e-11 * np.abs(Ha).max(), name
+    assert b["nfev"] == a["nfev"] and b["final"] == pytest.approx(a["final"], rel=1e-9), name
+
+
+@pytest.mark.parametrize("name", ["tiny_rolling", "tiny", "tiny_handeye", "tiny_fisheye"])
+def test_projected_matches_the_oracle(name):
+  """mcba_project_model == Calibration.projected of the reference (oracle pinned to it in test_oracle_vs_reference):
+  rolling shutter iterates the scan time from the projected row (t = 0.5, then 4 passes)."""
+  g, rig = load_golden(name)
+  c = mirror(rig)
+  want, valid = oracle(rig).projected()
+  with Handle(c) as h:
+    got = h.project_model(g["x0"])
+    assert np.abs(got - want)[valid].max() < 1e-9
+    if name == "tiny_rolling":     # differs from `reprojected` (scan time from the OBSERVED row) where both are defined
+      assert np.abs(got - h.project(g["x0"]))[valid & rig.valid].max() > 1e-6
+      assert np.abs(h.project_model(g["x0"], max_iterations=0) - oracle(rig).projected(max_iterations=0)[0])[valid].max() < 1e-9
+  tab = c.projected
+  assert np.array_equal(tab.valid, valid) and np.abs(tab.points - want)[valid].max() < 1e-9

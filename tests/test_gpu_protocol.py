@@ -216,7 +216,10 @@ def test_robust_loss_solve_matches_reference(name, loss, f_scale):
   # agrees to a hundredth of ftol; the RMS -- not what a robust loss minimises -- to 1e-4 px at default tolerance and to
   # 1e-6 px once both are converged (below).  The scipy-driven protocol (B) is within 1e-6 px at default tolerance.
   assert res.cost <= float(g["ba_cost"]) * (1 + 1e-6)
-  assert abs(rms - float(g["ba_rms"])) <= max(1e-4, 3 * spread_of(g))
+  # (soft_l1: the reference stops 2e-3 px short of its own converged optimum `ba_tight_rms`; the exact normal-equation
+  #  steps land on the optimum: the result lies between the two)
+  ref, tight, tol = float(g["ba_rms"]), float(g["ba_tight_rms"]), max(1e-4, 3 * spread_of(g))
+  assert min(ref, tight) - tol <= rms <= max(ref, tight) + tol
   if name == "tiny_huber":   # reproducible reference end point (spread 9e-8 px): 1e-6 px
     tight = out.bundle_adjust(loss=loss, f_scale=f_scale, tolerance=1e-14, xtol=1e-14, gtol=1e-14, max_iterations=300)
     assert abs(calibration.error_stats(tight.reprojection_error).rms - float(g["ba_tight_rms"])) < 1e-6

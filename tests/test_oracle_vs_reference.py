@@ -75,3 +75,16 @@ def test_export_json_equals_reference_export(name, master):
   mine.camera_poses.names = list(names.camera)
   got = mexport.export_json(mine, names, filenames, master=master)
   assert json.loads(json.dumps(got)) == json.loads(json.dumps(want))
+
+
+@pytest.mark.parametrize("name", ["tiny_rolling", "tiny", "tiny_handeye"])
+def test_projected_restatement_is_bit_identical_to_reference(name):
+  """Calibration.projected (calibration.py:113-119; rolling shutter: the t = 0.5 start + max_iterations fixed-point
+  passes of motion/rolling_frames.py:125-133): the oracle's restatement against the unmodified reference."""
+  from oracle import build_reference
+  rig = synthetic.make_rig(name)
+  ref_calib, ref = build_reference.reference_calibration(rig)
+  want = ref_calib.projected
+  got, valid = restate.from_rig(rig).projected()
+  assert np.array_equal(np.asarray(want.valid), valid)
+  assert np.array_equal(np.asarray(want.points)[valid], got[valid])
