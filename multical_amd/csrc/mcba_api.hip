@@ -365,7 +365,7 @@ void launch_linearize(mcba_handle_s* h, const double* dx) {
   // grows from 3.8 k to 14 k cycles and k_linearize from 49.5 to 62 us -- the table form stays the default until the
   // in-kernel prologue is lane-uniform.
   static const bool fused_on = getenv("MCBA_FUSED") != nullptr && getenv("MCBA_FUSED")[0] == '1';
-  if (dx != nullptr && h->use_mfma && d.ND != 14 && d.off_boards < 0 && fused_on) {
+  if (dx != nullptr && h->use_mfma && d.ND != 14 && d.off_boards < 0 && fused_on && h->t.dbg == nullptr) {
     h->ops->linearize(d, h->t, h->stream, h->rec.p, h->tri.p, true, h->lin_grid, dx, h->gbuf.p, 2 * d.n + 2, h->Hss.p,
                       d.ns * d.ns);
     return;

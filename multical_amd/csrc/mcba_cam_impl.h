@@ -52,6 +52,10 @@ void lin2(const Dims& d, const Tables& t, hipStream_t s, double* rec, const uint
   const dim3 grid(std::max(1, d.views() < want ? d.views() : want)), block(64);
   // the linear loss (the reference's default, calibration.py:199) has its own instantiation of the MFMA kernel: no loss
   // switch and no robust-scale constants in the hot loop; the plain-FMA validation build keeps the generic form
+  if (t.dbg != nullptr) {   // per-phase cycle stamps (debug API): the table form of the MFMA kernel
+    hipLaunchKernelGGL((k_linearize<ND_, FISH_, MOTION, OPTK, true, true, false, true>), grid, block, 0, s, d, t, rec, tri, epoch, x, za, na, zb, nb);
+    return;
+  }
   if (x != nullptr && mfma && d.loss == 0)
     hipLaunchKernelGGL((k_linearize<ND_, FISH_, MOTION, OPTK, true, false, true>), grid, block, 0, s, d, t, rec, tri, epoch, x, za, na, zb, nb);
   else if (x != nullptr && mfma)

@@ -32,9 +32,15 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void lds_fence() {
   // LDS operations of one wavefront complete in issue order; the fence only stops the compiler from moving
   // accesses across it and drains lgkmcnt (single-wave workgroups: no s_barrier needed).
+#if defined(MCBA_EXP_LIGHT_FENCE)
+  // experiment: scheduling barrier only.  In-order LDS + the compiler's own may-alias ordering of LDS accesses make the
+  // drain (s_waitcnt lgkmcnt(0)) unnecessary for a single wavefront; data dependences get their own waits.
+  __builtin_amdgcn_wave_barrier();
+#else
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#endif
 }
 
 // p[i] where ok, else 0 -- as an UNCONDITIONAL load from a clamped address whose value always enters the arithmetic.
@@ -63,6 +69,14 @@ __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
   return v;
+}
+
+// A wave-uniform double as a SCALAR value: every lane holds the same number (it was loaded from one address); reading
+// lane 0 back through v_readfirstlane puts it into an SGPR pair, so that it costs no vector register and serves as the
+// scalar operand of the FP64 instructions that use it.  (hipcc does not turn the uniform table reads of k_linearize into
+// s_load by itself: the LDS fences of the view loop count as clobbers of global memory in its analysis.)
+__device__ __forceinline__ double uniform_f64(double v) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
 
 // Pairwise in-register folding of per-lane partial sums with the gfx950 lane-swap instructions (VALU, no LDS traffic):
@@ -447,7 +461,11 @@ __global__ __launch_bounds__(256) void k_points(Dims d, Tables t, double* __rest
 // assembly: no k_prep / k_tmat launch, no That table (18 MB written + 10 MB read per evaluation at the north-star rig),
 // one kernel boundary less.  Not used for the tilted model (its tilt matrices live in the camera table) and when the
 // board points are optimised (the board-point table must be refreshed): those keep the k_tmat path.
-template <int ND, bool FISH, int MOTION, bool OPTK, bool MFMA, bool ROBUST, bool FUSED>
+// PROF: the instantiation with s_memtime stamps per phase (mcba_debug_linearize_profile).  The production instantiations
+// contain no global store besides the record (a __restrict__ argument): hipcc can then prove that the wave-uniform reads
+// of the view / camera tables are never clobbered and issues them as scalar loads (s_load, operands in SGPRs) instead of
+// 17 vector loads of one address per 64-observation chunk.
+template <int ND, bool FISH, int MOTION, bool OPTK, bool MFMA, bool ROBUST, bool FUSED, bool PROF = false>
 __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* __restrict__ rec,
                                                      const uint16_t* __restrict__ tri, int epoch,
                                                      const double* __restrict__ x, double* __restrict__ zero_a, int na,
@@ -479,7 +497,10 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
   __shared__ __attribute__((aligned(16))) double Buf[BUF];   // staging rows in the main loop; [S | Y | M] in the epilogue
   __shared__ double Tm[DE * NPC];
   __shared__ uint16_t pidx[LIN_MAX_POINTS];
-  __shared__ double Vm[FUSED ? (ROLL ? 2 : 1) * VIEW_STRIDE : 1];   // chain matrices of the view (FUSED)
+  // chain matrices of the view in LDS: written by the fused prologue; the rolling-shutter kernels (two chains = 48 scalar
+  // registers, more than the SGPR file has left) also read them from here in the main loop
+  constexpr bool VLDS = FUSED || ROLL;
+  __shared__ double Vm[VLDS ? (ROLL ? 2 : 1) * VIEW_STRIDE : 1];
   double* Vbuf = Buf;
   if constexpr (FUSED) {   // the assembly that follows accumulates into [g | diag | cost] and H_ss
     for (int e = blockIdx.x * 64 + threadIdx.x; e < na; e += gridDim.x * 64) zero_a[e] = 0.0;
@@ -498,7 +519,7 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
   const int b = v % d.B, c = (v / d.B) % d.C, fl = v / (d.B * d.C), f = d.f0 + fl;
   (void)f;
   long long stamp[6] = {0, 0, 0, 0, 0, 0};
-  const bool prof = t.dbg != nullptr;
+  constexpr bool prof = PROF;
   if (prof) stamp[0] = clock64();
   // Opaque copy of the lane id: the prologue offsets depend on the lane only, so hipcc hoists their 64-bit forms out of
   // the view loop and SPILLS them (256 registers are taken) -- every load was then preceded by a scratch reload and a
@@ -595,6 +616,33 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
   lds_fence();
   if (prof) stamp[1] = clock64();
 
+  // the view's chain matrices and the camera's parameters: read ONCE per view and kept as scalars (SGPRs).  Left to the
+  // compiler they were 17 vector loads of one address each in EVERY chunk, with 68 vector registers to hold them.
+  constexpr int NVS = (ROLL ? 2 : 1) * VIEW_STRIDE;
+  double Vr[ROLL ? 1 : NVS], camr[5 + ND], extr[CAM_STRIDE - CAM_TILT];
+  {
+    const double* vsrc = FUSED ? Vm : t.view + (size_t)v * NVS;
+    const double* csrc = FUSED ? camp : t.cam + (size_t)c * CAM_STRIDE;
+    const double* esrc = t.cam + (size_t)c * CAM_STRIDE + CAM_TILT;
+    if constexpr (ROLL) {
+      if constexpr (!FUSED) {
+        if (pl < NVS) Vm[pl] = vsrc[pl];      // (visible to the main loop after the fence below)
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NVS; ++k) Vr[k] = uniform_f64(vsrc[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 5 + ND; ++k) camr[k] = uniform_f64(csrc[k]);
+#pragma unroll
+    for (int k = 0; k < CAM_STRIDE - CAM_TILT; ++k) extr[k] = 0.0;
+    extr[CAM_HEIGHT - CAM_TILT] = uniform_f64(esrc[CAM_HEIGHT - CAM_TILT]);
+    extr[CAM_FIXASPECT - CAM_TILT] = uniform_f64(esrc[CAM_FIXASPECT - CAM_TILT]);
+  }
+  // (the tilted model reads its 27 tilt-matrix entries from the table: rare, not worth the scalar registers)
+  const double* extp = ND >= 14 ? t.cam + (size_t)c * CAM_STRIDE + CAM_TILT : extr;
+  if constexpr (ROLL && !FUSED) lds_fence();   // Vm
+
   // software prefetch: observation + board point of the NEXT chunk are requested before the current one is processed
   int p_cur = lane < count ? pidx[lane] : 0;
   double2 ob_cur = t.obs[(size_t)v * d.P + p_cur];
@@ -611,7 +659,11 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
     long long t0 = 0;
     if (prof) t0 = clock64();
     if (in) {
+#if defined(MCBA_EXP_NO_SCALAR_TABLES)   // A/B switch of the profiling builds: table reads left to the compiler
       cost += point_state<ND, FISH, ROLL, ROBUST>(d, t, v, c, b, p_cur, ob_cur, ps, X_cur, FUSED ? Vm : nullptr, camp);
+#else
+      cost += point_state<ND, FISH, ROLL, ROBUST>(d, t, v, c, b, p_cur, ob_cur, ps, X_cur, ROLL ? Vm : Vr, camr, extp);
+#endif
     } else {   // lanes past the end of the list stage zero rows
       ps = PointState<ND, ROLL>{};
     }

@@ -27,11 +27,12 @@ MCBA_HD void slot_forward(const Dims& d, const Tables& t, int v, int c, int b, i
                                              double* uv, double* A, double* Kc, double* Xs, double* Xe, double& tr,
                                              const double* Xpre = nullptr /* prefetched board point */,
                                              const double* Vpre = nullptr /* chain matrices of the view (registers / LDS) */,
-                                             const double* camp = nullptr /* the camera's parameter block inside x */) {
+                                             const double* camp = nullptr /* the camera's parameter block (x / registers) */,
+                                             const double* extp = nullptr /* tail of the camera entry, CAM_TILT onwards */) {
   const double* X = Xpre != nullptr ? Xpre : t.board_points + 3 * (size_t)(b * d.P + p);
   const double* V = Vpre != nullptr ? Vpre : t.view + (size_t)v * (VIEW_STRIDE * (ROLL ? 2 : 1));
   const double* cam = t.cam + (size_t)c * CAM_STRIDE;
-  const double* ext = cam + CAM_TILT;
+  const double* ext = extp != nullptr ? extp : cam + CAM_TILT;
   if (camp != nullptr) cam = camp;
   const double bx = X[0], by = X[1], bz = X[2];
   double Xc[3];
@@ -292,9 +293,9 @@ struct PointState {
 template <int ND, bool FISH, bool ROLL, bool ROBUST = true>
 MCBA_HD double point_state(const Dims& d, const Tables& t, int v, int c, int b, int p, double2 ob,
                            PointState<ND, ROLL>& st, const double* Xpre = nullptr, const double* Vpre = nullptr,
-                           const double* camp = nullptr) {
+                           const double* camp = nullptr, const double* extp = nullptr) {
   double uv[2];
-  slot_forward<ND, FISH, ROLL, true>(d, t, v, c, b, p, ob, uv, st.A, st.Kc, st.Xs, st.Xe, st.tr, Xpre, Vpre, camp);
+  slot_forward<ND, FISH, ROLL, true>(d, t, v, c, b, p, ob, uv, st.A, st.Kc, st.Xs, st.Xe, st.tr, Xpre, Vpre, camp, extp);
   st.e[0] = uv[0] - ob.x;
   st.e[1] = uv[1] - ob.y;
   double rho = 0.0;
