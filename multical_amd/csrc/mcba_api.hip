@@ -157,6 +157,7 @@ struct mcba_handle_s {
   DevBuf<unsigned int> sel_hist;
   DevBuf<unsigned long long> sel_state;   // SelState x SEL_MAX | ranks | per-block (count, next) of k_selm_next
   bool obs_index_dirty = false;
+  bool view_first_dirty = false;         // view_first (first residual index per view) is stale w.r.t. the inlier table
 
   // linearisation
   DevBuf<double> rec, partial, Hss, Hfs, Hff, gbuf;   // gbuf = [g (n) | diag (n) | cost, count]
@@ -241,6 +242,7 @@ void scan_views(mcba_handle_s* h) {
   HIP_OK(hipStreamSynchronize(h->stream));
   REQUIRE(h->h_totals[0] < (1LL << 30), "too many observations for 32-bit residual indices");
   h->n_inliers = h->h_totals[0];
+  h->view_first_dirty = false;
 }
 
 // (re)build inlier table and per-view counts of the shard ON THE DEVICE; mask in reference order or null (= valid).
@@ -553,6 +555,14 @@ void launch_gn_solve(mcba_handle_s* h, double reg, bool root_rank, double* dots_
 }
 
 // ---- device outlier loop -------------------------------------------------------------------------------------------
+// first residual index of every view for the current inlier table (k_residual writes each view's residuals as one run)
+void ensure_view_first(mcba_handle_s* h) {
+  if (!h->view_first_dirty) return;
+  hipLaunchKernelGGL(k_view_scan, dim3(1), dim3(1024), 0, h->stream, h->d, h->view_count.p, (const int32_t*)nullptr,
+                     h->view_first.p, h->totals.p);
+  h->view_first_dirty = false;
+}
+
 void ensure_obs_index(mcba_handle_s* h) {
   if (!h->obs_index_dirty) return;
   // residual ordering of the current inlier table (needed by residuals / jacobian only): prefix sums on the device
@@ -578,7 +588,7 @@ void compute_errors(mcba_handle_s* h, const double* x) {
   if (h->err_valid && h->err_x.size() == (size_t)d.n && memcmp(h->err_x.data(), x, (size_t)d.n * sizeof(double)) == 0) return;
   upload_x(h, x, h->x.p);
   eval_tables(h, h->x.p);
-  h->ops->residual(d, h->t, h->stream, nullptr, nullptr, h->err_fm.p, nullptr);   // frame-major errors
+  h->ops->residual(d, h->t, h->stream, nullptr, nullptr, nullptr, h->err_fm.p, nullptr);   // frame-major errors
   h->err_x.assign(x, x + d.n);
   h->err_valid = true;
 }
@@ -973,10 +983,10 @@ int32_t mcba_debug_set_lin_grid(mcba_handle h, int32_t grid) {
 int32_t mcba_residuals(mcba_handle h, const double* x, double* r) {
   API_BEGIN
   REQUIRE(h && x && r, "null argument");
-  ensure_obs_index(h);
+  ensure_view_first(h);
   upload_x(h, x, h->x.p);
   eval_tables(h, h->x.p);
-  h->ops->residual(h->d, h->t, h->stream, h->out_r.p, nullptr, nullptr, nullptr);
+  h->ops->residual(h->d, h->t, h->stream, h->view_first.p, h->out_r.p, nullptr, nullptr, nullptr);
   HIP_OK(hipMemcpyAsync(r, h->out_r.p, 2 * (size_t)h->n_inliers * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   sync(h);
   API_END
@@ -1018,7 +1028,7 @@ int32_t mcba_reprojection_error(mcba_handle h, const double* x, double* err, uin
   h->out_valid.alloc(nref, true);
   upload_x(h, x, h->x.p);
   eval_tables(h, h->x.p);
-  h->ops->residual(d, h->t, h->stream, nullptr, nullptr, h->out_big.p, h->out_valid.p);
+  h->ops->residual(d, h->t, h->stream, nullptr, nullptr, nullptr, h->out_big.p, h->out_valid.p);
   HIP_OK(hipMemcpyAsync(err, h->out_big.p, nref * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipMemcpyAsync(valid, h->out_valid.p, nref, hipMemcpyDeviceToHost, h->stream));
   sync(h);
@@ -1034,7 +1044,7 @@ int32_t mcba_project(mcba_handle h, const double* x, double* projected) {
   h->out_big.alloc(2 * nref, true);
   upload_x(h, x, h->x.p);
   eval_tables(h, h->x.p);
-  h->ops->residual(d, h->t, h->stream, nullptr, h->out_big.p, nullptr, nullptr);
+  h->ops->residual(d, h->t, h->stream, nullptr, nullptr, h->out_big.p, nullptr, nullptr);
   HIP_OK(hipMemcpyAsync(projected, h->out_big.p, 2 * nref * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   sync(h);
   API_END
@@ -1500,6 +1510,7 @@ int32_t mcba_reject_outliers(mcba_handle h, const double* x, double threshold, i
   fetch_scalars(h, 4);
   h->n_inliers = (int64_t)h->h_scal[1];      // this shard's inliers
   h->obs_index_dirty = true;
+  h->view_first_dirty = true;
   h->out_r.alloc((size_t)std::max<int64_t>(2 * h->n_inliers, 1), false);
   double tot[2] = {h->h_scal[1], h->h_scal[3]};
   if (h->allreduce) {
@@ -1557,12 +1568,14 @@ int32_t mcba_time_linearize(mcba_handle h, const double* x, const mcba_options* 
 int32_t mcba_time_residuals(mcba_handle h, const double* x, int32_t repeats, double* avg_ms) {
   API_BEGIN
   REQUIRE(h && x && avg_ms && repeats > 0, "bad argument");
+  ensure_view_first(h);
   upload_x(h, x, h->x.p);
   eval_tables(h, h->x.p);
-  h->ops->residual(h->d, h->t, h->stream, h->out_r.p, nullptr, nullptr, nullptr);
+  h->ops->residual(h->d, h->t, h->stream, h->view_first.p, h->out_r.p, nullptr, nullptr, nullptr);
   sync(h);
   HIP_OK(hipEventRecord(h->ev0, h->stream));
-  for (int i = 0; i < repeats; ++i) h->ops->residual(h->d, h->t, h->stream, h->out_r.p, nullptr, nullptr, nullptr);
+  for (int i = 0; i < repeats; ++i)
+    h->ops->residual(h->d, h->t, h->stream, h->view_first.p, h->out_r.p, nullptr, nullptr, nullptr);
   HIP_OK(hipEventRecord(h->ev1, h->stream));
   sync(h);
   float ms = 0.f;

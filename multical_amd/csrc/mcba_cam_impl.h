@@ -15,11 +15,14 @@ inline int slot_grid(const Dims& d) {
   return g < 1 ? 1 : (g > 4096 ? 4096 : g);
 }
 
-void residual(const Dims& d, const Tables& t, hipStream_t s, double* r, double* proj, double* err, uint8_t* valid) {
+void residual(const Dims& d, const Tables& t, hipStream_t s, const int32_t* first, double* r, double* proj, double* err,
+              uint8_t* valid) {
+  if (d.views() == 0) return;
+  const dim3 grid(std::min(8192, (d.views() + 3) / 4)), block(256);   // one wavefront per view, four views per block
   if (d.motion == MOTION_ROLLING)
-    hipLaunchKernelGGL((k_residual<ND_, FISH_, true>), dim3(slot_grid(d)), dim3(256), 0, s, d, t, r, proj, err, valid);
+    hipLaunchKernelGGL((k_residual<ND_, FISH_, true>), grid, block, 0, s, d, t, first, r, proj, err, valid);
   else
-    hipLaunchKernelGGL((k_residual<ND_, FISH_, false>), dim3(slot_grid(d)), dim3(256), 0, s, d, t, r, proj, err, valid);
+    hipLaunchKernelGGL((k_residual<ND_, FISH_, false>), grid, block, 0, s, d, t, first, r, proj, err, valid);
 }
 
 void project_model(const Dims& d, const Tables& t, hipStream_t s, int iterations, double* proj) {

@@ -10,7 +10,9 @@
 namespace mcba {
 
 struct CamOps {
-  void (*residual)(const Dims&, const Tables&, hipStream_t, double* r, double* proj, double* err, uint8_t* valid);
+  // first: per-view first residual index (k_view_scan), needed when r is written
+  void (*residual)(const Dims&, const Tables&, hipStream_t, const int32_t* first, double* r, double* proj, double* err,
+                   uint8_t* valid);
   void (*project_model)(const Dims&, const Tables&, hipStream_t, int iterations, double* proj);
   void (*cost)(const Dims&, const Tables&, hipStream_t, double* partial, int nblk);
   void (*jacobian)(const Dims&, const Tables&, hipStream_t, int row_nnz, double* vals, int32_t* cols);

@@ -120,41 +120,61 @@ __device__ __forceinline__ double block_reduce(double v, double* scratch /*[16]*
 
 // ---------------------------------------------------------------------------------------------------------------
 // k_residual: evaluate() of optimization/calibration.py:204-206 (+ projections and per-slot errors of
-//             tables.reprojection_error, tables.py:244-249).  One thread per slot, frame-major coalesced loads of the
-//             16-byte observations; outputs are scattered into the reference's [C,F,B,P] order / compacted residual
-//             order through the precomputed obs_index.
+//             tables.reprojection_error, tables.py:244-249).  ONE WAVEFRONT PER VIEW (four views per 256-thread block):
+//             camera, board and chain matrices are wave-uniform (scalar loads), the frame-major 16-byte observations and
+//             the mask bytes stream in coalesced, and the residuals of a view leave as ONE contiguous run: the view's
+//             first residual index comes from k_view_scan (prefix of the inlier counts in the reference's view order) and
+//             the position inside the view from a ballot prefix -- no per-slot index table is read (the round-1 kernel
+//             gathered a 4-byte obs_index per slot and scattered 8-byte stores: 36 % of the HBM peak).
+//             Algorithmic traffic: 17 B per slot read + 16 B per observation written.
 // ---------------------------------------------------------------------------------------------------------------
 template <int ND, bool FISH, bool ROLL>
-__global__ void k_residual(Dims d, Tables t, double* __restrict__ r, double* __restrict__ proj,
-                           double* __restrict__ err, uint8_t* __restrict__ valid) {
-  const int n = d.slots();
-  for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
-    const int idx = t.obs_index[s];
-    if (proj == nullptr && err == nullptr && idx < 0) continue;
-    const int p = s % d.P, v = s / d.P;
+__global__ __launch_bounds__(256) void k_residual(Dims d, Tables t, const int32_t* __restrict__ first,
+                                                  double* __restrict__ r, double* __restrict__ proj,
+                                                  double* __restrict__ err, uint8_t* __restrict__ valid) {
+  const int lane = threadIdx.x & 63;
+  const int nv = d.views();
+  const bool all_slots = proj != nullptr || err != nullptr;
+  for (int vw = blockIdx.x * 4 + (threadIdx.x >> 6); vw < nv; vw += gridDim.x * 4) {
+    const int v = __builtin_amdgcn_readfirstlane(vw);             // wave-uniform: everything derived from it is scalar
+    if (!all_slots && t.view_count[v] == 0) continue;
     const int b = v % d.B, c = (v / d.B) % d.C, fl = v / (d.B * d.C), f = d.f0 + fl;
-    const double2 ob = t.obs[s];
-    double uv[2], Xs[3], Xe[3], tr;
-    slot_forward<ND, FISH, ROLL, false>(d, t, v, c, b, p, ob, uv, nullptr, nullptr, Xs, Xe, tr);
-    const double ex = uv[0] - ob.x, ey = uv[1] - ob.y;
-    if (r != nullptr && idx >= 0) {
-      r[2 * (size_t)idx] = ex;
-      r[2 * (size_t)idx + 1] = ey;
-    }
-    const size_t ri = (((size_t)c * d.F + f) * d.B + b) * d.P + p;
-    if (proj != nullptr) {
-      proj[2 * ri] = uv[0];
-      proj[2 * ri + 1] = uv[1];
-    }
-    if (err != nullptr) {
-      const bool ok = t.evalid[s] != 0;
-      const double e = ok ? sqrt(ex * ex + ey * ey) : 0.0;
-      if (valid != nullptr) {          // reference [C,F,B,P] order (host-facing)
-        err[ri] = e;
-        valid[ri] = ok ? 1 : 0;
-      } else {                         // frame-major, device-internal (outlier loop)
-        err[s] = e;
+    int base = (r != nullptr && first != nullptr) ? first[v] : 0;
+    for (int q0 = 0; q0 < d.P; q0 += 64) {
+      const int p = q0 + lane;
+      const bool ok = p < d.P;
+      const size_t s = (size_t)v * d.P + (ok ? p : 0);
+      const bool in = ok && t.inlier[s] != 0;
+      const unsigned long long m = __ballot(in);
+      if (ok && (in || all_slots)) {
+        const double2 ob = t.obs[s];
+        double uv[2], Xs[3], Xe[3], tr;
+        slot_forward<ND, FISH, ROLL, false>(d, t, v, c, b, p, ob, uv, nullptr, nullptr, Xs, Xe, tr);
+        const double ex = uv[0] - ob.x, ey = uv[1] - ob.y;
+        if (r != nullptr && in) {
+          const size_t idx = (size_t)base + __popcll(m & ((1ull << lane) - 1ull));
+          double2 e2;
+          e2.x = ex;
+          e2.y = ey;
+          reinterpret_cast<double2*>(r)[idx] = e2;
+        }
+        const size_t ri = (((size_t)c * d.F + f) * d.B + b) * d.P + p;
+        if (proj != nullptr) {
+          proj[2 * ri] = uv[0];
+          proj[2 * ri + 1] = uv[1];
+        }
+        if (err != nullptr) {
+          const bool ev = t.evalid[s] != 0;
+          const double e = ev ? sqrt(ex * ex + ey * ey) : 0.0;
+          if (valid != nullptr) {          // reference [C,F,B,P] order (host-facing)
+            err[ri] = e;
+            valid[ri] = ev ? 1 : 0;
+          } else {                         // frame-major, device-internal (outlier loop)
+            err[s] = e;
+          }
+        }
       }
+      base += __popcll(m);
     }
   }
 }

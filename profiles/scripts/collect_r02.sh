@@ -1,0 +1,16 @@
+set -x
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r2p; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o trace -- python $R/bench.py --steps 200 --warmup 20 > $O/bench_traced.json 2> $O/bench_traced.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc -o pmc_fetch -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-solve > /dev/null 2> $O/pmc1.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc -o pmc_write -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-solve > /dev/null 2> $O/pmc2.err
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU --kernel-trace --output-format csv -d $O/pmc -o pmc_mfma -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-solve > /dev/null 2> $O/pmc3.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/solve -o solve -- python $R/tests/prof_cfg.py cfg3 > $O/solve.log 2>&1
+cd $R
+python bench.py > $O/bench.json 2> $O/bench.err
+tail -c 600 $O/bench.json
+python tests/prof_linearize.py > $O/lin_phases.log 2>&1
+MCBA_TIMING=1 python tests/prof_workspace.py cfg3 > $O/workspace_cfg3.log 2>&1; grep "calibrate ms" $O/workspace_cfg3.log
+python tests/prof_lin_cfgs.py cfg2 cfg3 cfg4 cfg5 > $O/lin_cfgs.log 2>&1; cat $O/lin_cfgs.log
+python tests/prof_scale.py > $O/lin_scale.log 2>&1; tail -8 $O/lin_scale.log
+ls $O $O/pmc
