@@ -224,6 +224,20 @@ int32_t mcba_synchronize(mcba_handle h);
 /* dense J^T J [n_params x n_params] assembled from the block form (debug / parity tests; small problems only)  */
 int32_t mcba_dense_hessian(mcba_handle h, double* H);
 
+/* --- initialisation tables (the producer of the hot path's inputs) ---------------------------- */
+/* matrix.align_transforms_robust (transform/matrix.py:140-153) for a batch of problems: problem p owns the pose pairs
+ * [offsets[p], offsets[p+1]) of A and B (row-major 4x4 "points-transforming" matrices), `mask` (or NULL = all) selects
+ * the pairs that enter the estimate.  Per problem: relative poses B_k A_k^-1 -> robust mean (Ward clustering of the
+ * whitened rotation-vector | translation 6-vectors, most common of max(n/10, 3) clusters, transform/common.py:6-21) ->
+ * errors |m A_k - B_k|_F of ALL pairs -> pairs with error < threshold * upper quartile stay -> robust mean again.
+ * out[p] = the transform (identity and out_valid[p] = 0 when no pair is selected: tables.relative_between,
+ * tables.py:326-332); inliers (or NULL) = pairs that passed the test.  invert != 0: relative_between_inv semantics
+ * (inputs inverted, result inverted, tables.py:334-335).  This is the numeric core of tables.estimate_transform
+ * (tables.py:153-176; default threshold 1.5) and tables.relative_between_n (tables.py:337-345).                      */
+int32_t mcba_align_poses_robust(int32_t n_problems, const int64_t* offsets, const double* A, const double* B,
+                                const uint8_t* mask, double threshold, int32_t invert, double* out, uint8_t* out_valid,
+                                uint8_t* inliers);
+
 /* --- solve -------------------------------------------------------------------------------------------------- */
 /* Trust-region least squares: replaces scipy.optimize.least_squares(method='trf', x_scale='jac', jac_sparsity=S,
  * loss, f_scale, ftol, max_nfev) at calibration.py:209-210.  x is updated in place to `res.x`.                 */

@@ -28,6 +28,7 @@
 #include "mcba_camops.h"
 #include "mcba_lower.h"
 #include "mcba_solver_kernels.h"
+#include "mcba_init_kernels.h"
 
 using namespace mcba;
 
@@ -1047,6 +1048,73 @@ int32_t mcba_project(mcba_handle h, const double* x, double* projected) {
   h->ops->residual(d, h->t, h->stream, nullptr, nullptr, h->out_big.p, nullptr, nullptr);
   HIP_OK(hipMemcpyAsync(projected, h->out_big.p, 2 * nref * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   sync(h);
+  API_END
+}
+
+/* matrix.align_transforms_robust (transform/matrix.py:140-153) for a BATCH of problems on the device: the numeric core of
+ * tables.estimate_transform (tables.py:153-176) and tables.relative_between_n (tables.py:334-345).  No handle: the
+ * initialisation runs before a Calibration exists.                                                                     */
+int32_t mcba_align_poses_robust(int32_t n_problems, const int64_t* offsets, const double* A, const double* B,
+                                const uint8_t* mask, double threshold, int32_t invert, double* out, uint8_t* out_valid,
+                                uint8_t* inliers) {
+  API_BEGIN
+  REQUIRE(n_problems >= 0 && offsets && A && B && out && out_valid, "bad argument");
+  if (n_problems == 0) return 0;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    throw Error("no HIP device: the mcba back-end is GPU-only (there is no CPU fallback)");
+  const int64_t total = offsets[n_problems];
+  int64_t nmax = 1;
+  for (int p = 0; p < n_problems; ++p) {
+    REQUIRE(offsets[p + 1] >= offsets[p], "offsets must be non-decreasing");
+    nmax = std::max<int64_t>(nmax, offsets[p + 1] - offsets[p]);
+  }
+  REQUIRE(offsets[0] == 0 && total >= 0 && nmax < (1 << 24), "bad offsets");
+  hipStream_t st = nullptr;
+  HIP_OK(hipStreamCreate(&st));
+  struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } guard{st};
+  g_fill_stream = st;
+  DevBuf<long long> d_off;
+  DevBuf<double> dA, dB, d_out, d_f64;
+  DevBuf<uint8_t> d_mask, d_valid, d_inl;
+  DevBuf<int> d_i32;
+  d_off.upload(std::vector<long long>(offsets, offsets + n_problems + 1));
+  const size_t tot = (size_t)std::max<int64_t>(total, 1);
+  dA.alloc(16 * tot, false);
+  dB.alloc(16 * tot, false);
+  if (total > 0) {
+    HIP_OK(hipMemcpyAsync(dA.p, A, 16 * (size_t)total * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(dB.p, B, 16 * (size_t)total * sizeof(double), hipMemcpyHostToDevice, st));
+  }
+  if (mask) {
+    d_mask.alloc(tot, false);
+    if (total > 0) HIP_OK(hipMemcpyAsync(d_mask.p, mask, (size_t)total, hipMemcpyHostToDevice, st));
+  }
+  d_out.alloc(16 * (size_t)n_problems, false);
+  d_valid.alloc((size_t)n_problems, false);
+  d_inl.alloc(tot, false);
+  // per-problem scratch: 14 doubles + 6 ints per entry, sized for the largest problem
+  const size_t per = (size_t)nmax, np_ = (size_t)n_problems;
+  d_f64.alloc(np_ * per * 14, false);
+  d_i32.alloc(np_ * per * 6, false);
+  AlignScratch sc;
+  sc.vec = d_f64.p;
+  sc.cen = sc.vec + np_ * per * 6;
+  sc.err = sc.cen + np_ * per * 6;
+  sc.hgt = sc.err + np_ * per;
+  sc.size = d_i32.p;
+  sc.chain = sc.size + np_ * per;
+  sc.rep_a = sc.chain + np_ * per;
+  sc.rep_b = sc.rep_a + np_ * per;
+  sc.parent = sc.rep_b + np_ * per;
+  sc.list = sc.parent + np_ * per;
+  hipLaunchKernelGGL(k_align_robust, dim3(n_problems), dim3(ALIGN_THREADS), 0, st, d_off.p, dA.p, dB.p,
+                     (const uint8_t*)(mask ? d_mask.p : nullptr), threshold, (int)invert, (long long)per, sc, d_out.p,
+                     d_valid.p, d_inl.p);
+  HIP_OK(hipMemcpyAsync(out, d_out.p, 16 * (size_t)n_problems * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_OK(hipMemcpyAsync(out_valid, d_valid.p, (size_t)n_problems, hipMemcpyDeviceToHost, st));
+  if (inliers && total > 0) HIP_OK(hipMemcpyAsync(inliers, d_inl.p, (size_t)total, hipMemcpyDeviceToHost, st));
+  HIP_OK(hipStreamSynchronize(st));
   API_END
 }
 

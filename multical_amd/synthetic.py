@@ -441,3 +441,25 @@ def rig_from_arrays(arrs):
     board_points=[arrs[f"board_points_{i}"] for i in range(meta["n_boards"])],
     points=arrs["points"], valid=arrs["valid"], camera_valid=arrs["camera_valid"],
     board_valid=arrs["board_valid"], frame_valid=arrs["frame_valid"], optimize=meta["optimize"])
+
+
+# ------------------------------------------------------------------------------------------------
+# per-view board poses for the initialisation tables (tables.make_pose_table would obtain them from cv2.solvePnP)
+# ------------------------------------------------------------------------------------------------
+def make_pose_table(rig, seed=0, rot_sigma=2e-3, trans_sigma=1e-3, outlier_frac=0.03):
+  """Pose table [C, F, B] of the rig: truth chain camera . rig . board perturbed by a small SE(3) noise (a PnP estimate
+  from noisy corners), a fraction of gross outliers (wrong board orientation), validity / detection counts from the rig's
+  observation table.  Returns dict(poses, valid, num_points) of numpy arrays; invalid entries are the identity like
+  tables.invalid_pose (tables.py:38)."""
+  rng = np.random.default_rng([seed, 4241])
+  tr = rig.truth
+  C, F, B, P = rig.valid.shape
+  chain = tr.camera_poses[:, None, None] @ tr.rig[None, :, None] @ tr.board_poses[None, None, :]
+  poses = perturb(chain, rng, rot_sigma, trans_sigma)
+  num_points = rig.valid.sum(axis=3)
+  valid = num_points > 0
+  out = rng.random((C, F, B)) < outlier_frac
+  bad = to_matrix(np.concatenate([rng.normal(0, 0.8, (C, F, B, 3)), rng.normal(0, 0.3, (C, F, B, 3))], axis=-1))
+  poses = np.where(out[..., None, None], bad @ poses, poses)
+  poses = np.where(valid[..., None, None], poses, np.eye(4))
+  return dict(poses=poses, valid=valid, num_points=np.where(valid, num_points, 0))

@@ -1,0 +1,161 @@
+"""Initialisation tables of the pose graph (multical/tables.py:134-230,326-377) with the numeric core on the MI355X.
+
+The reference builds the bundle adjustment's starting point from the per-view board poses [cameras, frames, boards]:
+relative camera poses and relative board poses through a spanning tree of pairwise robust alignments
+(`estimate_relative_poses`, tables.py:207-230) and one rig pose per frame (`relative_between_n`, tables.py:337-345).  Every
+alignment is `matrix.align_transforms_robust` (transform/matrix.py:140-153): relative poses -> robust mean (Ward clustering
+of the whitened rotation-vector | translation 6-vectors, transform/common.py:6-21) -> upper-quartile outlier test -> robust
+mean.  Here all alignments of a stage run as ONE batch on the device (mcba_align_poses_robust: a workgroup per problem);
+what stays on the host is the control logic on tiny arrays -- the overlap matrix, the greedy spanning tree
+(graph.select_pairs, graph.py:7-33), chaining the pair transforms along the tree -- and 4x4 matrix products.
+
+Tables are `structs.Table`s with `poses [..., 4, 4]`, `valid [...]` (+ `num_points` for the pose table), like the
+reference's.  `make_point_table` (tables.py:68-81) is data marshalling of ragged detections and stays in numpy.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check
+from .structs import Table, struct
+
+
+def _f64(a):
+  return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+def align_transforms_robust_batch(problems, threshold=1.5, invert=False):
+  """problems: list of (m1 [n,4,4], m2 [n,4,4], mask [n] bool or None).  Returns (transforms [P,4,4], valid [P] bool,
+  list of inlier masks) -- per problem exactly matrix.align_transforms_robust(m1, m2, valid=mask, threshold)
+  (invert=True: tables.relative_between_inv: inputs and result inverted)."""
+  lib = _lib.load()
+  P = len(problems)
+  if P == 0:
+    return np.zeros((0, 4, 4)), np.zeros(0, dtype=bool), []
+  sizes = [int(np.asarray(p[0]).shape[0]) for p in problems]
+  offsets = np.ascontiguousarray(np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64))
+  total = int(offsets[-1])
+  A = _f64(np.concatenate([np.asarray(p[0], dtype=np.float64).reshape(-1, 4, 4) for p in problems])) if total else np.zeros((1, 4, 4))
+  B = _f64(np.concatenate([np.asarray(p[1], dtype=np.float64).reshape(-1, 4, 4) for p in problems])) if total else np.zeros((1, 4, 4))
+  any_mask = any(p[2] is not None for p in problems)
+  mask = None
+  if any_mask:
+    mask = np.ascontiguousarray(np.concatenate([np.ones(n, dtype=np.uint8) if p[2] is None else np.asarray(p[2]).astype(np.uint8)
+                                                for p, n in zip(problems, sizes)])) if total else np.zeros(1, dtype=np.uint8)
+  out = np.empty((P, 4, 4))
+  valid = np.empty(P, dtype=np.uint8)
+  inl = np.empty(max(total, 1), dtype=np.uint8)
+  dp = C.POINTER(C.c_double)
+  up = C.POINTER(C.c_uint8)
+  check(lib.mcba_align_poses_robust(P, offsets.ctypes.data_as(C.POINTER(C.c_int64)), A.ctypes.data_as(dp), B.ctypes.data_as(dp),
+                                    None if mask is None else mask.ctypes.data_as(up), float(threshold), 1 if invert else 0,
+                                    out.ctypes.data_as(dp), valid.ctypes.data_as(up), inl.ctypes.data_as(up)))
+  inliers = [inl[offsets[i]:offsets[i + 1]].astype(bool) for i in range(P)]
+  return out, valid.astype(bool), inliers
+
+
+# ---- host control logic on [n, n] matrices (tables.py:134-148, graph.py:7-33) -------------------------------------------
+def pattern_overlaps(table, axis=0):
+  n = table.valid.shape[axis]
+  overlaps = np.zeros([n, n])
+  for i in range(n):
+    for j in range(i + 1, n):
+      has_pose = np.take(table.valid, i, axis=axis) & np.take(table.valid, j, axis=axis)
+      weight = np.minimum(np.take(table.num_points, i, axis=axis), np.take(table.num_points, j, axis=axis))
+      overlaps[i, j] = overlaps[j, i] = np.sum(has_pose.astype(np.float32) * weight)
+  return overlaps
+
+
+def select_pairs(overlaps, hop_penalty=0.8):
+  overlaps = overlaps.copy()
+  n = overlaps.shape[0]
+  master = int(np.argmax(overlaps.sum(1)))
+  weight = (np.arange(n) == master).astype(np.float32).reshape(n, 1)
+  overlaps[:, master] = 0
+  pairs = []
+  while len(pairs) + 1 < n:
+    w = overlaps * weight
+    parent, child = np.unravel_index(np.argmax(w), w.shape)
+    if w[parent, child] <= 0:
+      break
+    overlaps[:, child] = 0
+    weight[child] = weight[parent] * hop_penalty
+    pairs.append((int(parent), int(child)))
+  return master, pairs
+
+
+def inverse(table):
+  return table._extend(poses=np.linalg.inv(table.poses))
+
+
+def estimate_relative_poses(table, axis=0, hop_penalty=0.9):
+  """tables.py:207-227: all pair alignments of the spanning tree in one device batch."""
+  n = table.valid.shape[axis]
+  master, pairs = select_pairs(pattern_overlaps(table, axis=axis), hop_penalty)
+  problems = []
+  for parent, child in pairs:
+    ti_p, tj_p = np.take(table.poses, parent, axis=axis), np.take(table.poses, child, axis=axis)
+    valid = (np.take(table.valid, parent, axis=axis) & np.take(table.valid, child, axis=axis)).ravel()
+    problems.append((ti_p.reshape(-1, 4, 4), tj_p.reshape(-1, 4, 4), valid))
+  ts, _, _ = align_transforms_robust_batch(problems)
+  pose_dict = {master: np.eye(4)}
+  for (parent, child), t in zip(pairs, ts):
+    pose_dict[child] = t @ pose_dict[parent]
+  poses = np.broadcast_to(np.eye(4), (n, 4, 4)).copy()
+  valid = np.zeros(n, dtype=bool)
+  for k in sorted(pose_dict):
+    poses[k] = pose_dict[k]
+    valid[k] = True
+  return Table.create(poses=poses @ np.linalg.inv(poses[0]), valid=valid)
+
+
+def estimate_relative_poses_inv(table, axis=2, hop_penalty=0.9):
+  """tables.py:229-230."""
+  return inverse(estimate_relative_poses(inverse(table), axis=axis, hop_penalty=hop_penalty))
+
+
+def relative_between_n(table1, table2, axis=0, inv=False):
+  """tables.py:337-345: one alignment per index of `axis`, restricted to the entries valid in both tables -- a ragged
+  batch of small problems (at most cameras x boards entries each) on the device."""
+  n = table1.valid.shape[axis]
+  problems = []
+  for k in range(n):
+    v = np.take(table1.valid, k, axis=axis) & np.take(table2.valid, k, axis=axis)
+    problems.append((np.take(table1.poses, k, axis=axis)[v], np.take(table2.poses, k, axis=axis)[v], None))
+  poses, valid, _ = align_transforms_robust_batch(problems, invert=inv)
+  return Table.create(poses=poses, valid=valid)
+
+
+def initialise_poses(pose_table, camera_poses=None):
+  """tables.py:353-377: camera / board / rig-pose tables from the per-view board poses [C, F, B]."""
+  camera = estimate_relative_poses(pose_table, axis=0)
+  if camera_poses is not None:
+    camera = Table.create(poses=np.asarray(camera_poses, dtype=np.float64), valid=np.ones(len(camera_poses), dtype=bool))
+  board = estimate_relative_poses_inv(pose_table, axis=2)
+  binv = inverse(board)
+  # cam @ rig @ board = pose  ->  cam @ rig = board_relative = pose @ board^-1
+  board_relative = Table.create(poses=pose_table.poses @ binv.poses[None, None],
+                                valid=pose_table.valid & binv.valid[None, None])
+  expanded = Table.create(poses=np.broadcast_to(camera.poses[:, None, None], board_relative.poses.shape),
+                          valid=np.broadcast_to(camera.valid[:, None, None], board_relative.valid.shape))
+  times = relative_between_n(expanded, board_relative, axis=1, inv=True)
+  return struct(times=times, camera=camera, board=board)
+
+
+def make_point_table(detections, boards):
+  """tables.py:68-81: ragged per-image detections (corners [k, 2], ids [k]) -> dense table [C, F, B, P] (+ mask)."""
+  num_points = int(np.max([b.num_points for b in boards]))
+  C_, F, B = len(detections), len(detections[0]), len(detections[0][0])
+  points = np.zeros((C_, F, B, num_points, 2), dtype=np.asarray(detections[0][0][0].corners).dtype
+                    if np.asarray(detections[0][0][0].corners).size else np.float32)
+  valid = np.zeros((C_, F, B, num_points), dtype=bool)
+  for c in range(C_):
+    for f in range(F):
+      for b in range(B):
+        d = detections[c][f][b]
+        ids = np.asarray(d.ids, dtype=np.int64).reshape(-1)
+        if ids.size:
+          points[c, f, b, ids] = np.asarray(d.corners).reshape(-1, 2)
+          valid[c, f, b, ids] = True
+  return Table.create(points=points, valid=valid)

@@ -535,3 +535,47 @@ def test_projected_matches_the_oracle(name):
       assert np.abs(h.project_model(g["x0"], max_iterations=0) - oracle(rig).projected(max_iterations=0)[0])[valid].max() < 1e-9
   tab = c.projected
   assert np.array_equal(tab.valid, valid) and np.abs(tab.points - want)[seen].max() < 1e-9
+
+
+@pytest.mark.parametrize("name,frames,seed", [("tiny_rolling", None, 5), ("tiny_fisheye", None, 6), ("cfg4", 12, 5),
+                                              ("cfg2", 60, 7), ("cfg3", 40, 8)])
+def test_initialise_poses_on_the_device_matches_the_oracle(name, frames, seed):
+  """multical_amd.tables.initialise_poses (every matrix.align_transforms_robust of the reference's pose-graph
+  initialisation as a device batch: relative poses, Ward-cluster robust mean, quartile outlier test) against the oracle
+  restatement, which is pinned bit-identical to the unmodified reference (test_oracle_vs_reference)."""
+  from multical_amd import tables as mtables
+  from multical_amd.structs import Table
+  from oracle import restate_init
+  rig = synthetic.make_rig(name, frames=frames)
+  pt = synthetic.make_pose_table(rig, seed=seed)
+  want = restate_init.initialise_poses(restate_init.table(pt["poses"], pt["valid"]), pt["num_points"])
+  got = mtables.initialise_poses(Table.create(poses=pt["poses"], valid=pt["valid"], num_points=pt["num_points"]))
+  for k in ("camera", "board", "times"):
+    assert np.array_equal(got[k].valid, want[k]["valid"]), k
+    assert np.abs(got[k].poses - want[k]["poses"]).max() < 1e-9, (k, np.abs(got[k].poses - want[k]["poses"]).max())
+
+
+def test_align_transforms_robust_batch_edge_cases():
+  """single pair, two pairs (fewer points than clusters), an empty problem, masked entries, inlier masks."""
+  from multical_amd import tables as mtables
+  from oracle import restate_init
+  rng = np.random.default_rng(3)
+  def poses(n, sigma):
+    return synthetic.to_matrix(np.concatenate([rng.normal(0, sigma, (n, 3)), rng.normal(0, 1.0, (n, 3))], axis=1))
+  T = synthetic.to_matrix(np.array([0.3, -0.2, 0.5, 0.1, 0.2, -0.4]))
+  problems = []
+  for n in (1, 2, 3, 9, 10, 11, 29, 30, 31, 200):
+    a = poses(n, 0.5)
+    b = synthetic.perturb(T @ a, rng, 1e-3, 1e-3)
+    if n > 8:
+      b[::7] = poses(len(b[::7]), 1.0)         # gross outliers
+    mask = rng.random(n) < 0.85 if n > 3 else None
+    if mask is not None and not mask.any():
+      mask[0] = True
+    problems.append((a, b, mask))
+  out, valid, inl = mtables.align_transforms_robust_batch(problems + [(np.zeros((0, 4, 4)), np.zeros((0, 4, 4)), None)])
+  assert valid[:-1].all() and not valid[-1] and np.array_equal(out[-1], np.eye(4))
+  for (a, b, m), o, il in zip(problems, out, inl):
+    want, want_inl = restate_init.align_transforms_robust(a, b, valid=m)
+    assert np.array_equal(il, want_inl)
+    assert np.abs(o - want).max() < 1e-9

@@ -88,3 +88,24 @@ def test_projected_restatement_is_bit_identical_to_reference(name):
   got, valid = restate.from_rig(rig).projected()
   assert np.array_equal(np.asarray(want.valid), valid)
   assert np.array_equal(np.asarray(want.points)[valid], got[valid])
+
+
+@pytest.mark.parametrize("name,frames", [("tiny_rolling", None), ("tiny_fisheye", None), ("cfg4", 12), ("cfg2", 30)])
+def test_initialise_poses_restatement_is_bit_identical_to_reference(name, frames):
+  """tables.initialise_poses (tables.py:353-377) -- relative camera / board poses through the overlap
+  spanning tree and the per-frame rig poses, all through matrix.align_transforms_robust / the Ward-cluster robust mean --
+  restated in oracle/restate_init.py, against the unmodified reference on a synthetic pose table with outliers."""
+  from oracle import refload, restate_init
+  refload.load()
+  if not hasattr(np, "bool"):
+    np.bool = bool                     # the reference still spells it np.bool (tables.py:363, transform/matrix.py:145)
+  from multical import tables as ref_tables
+  from structs.numpy import Table
+  rig = synthetic.make_rig(name, frames=frames)
+  pt = synthetic.make_pose_table(rig, seed=5)
+  ref_in = Table.create(poses=pt["poses"].copy(), valid=pt["valid"].copy(), num_points=pt["num_points"].copy())
+  want = ref_tables.initialise_poses(ref_in)
+  got = restate_init.initialise_poses(restate_init.table(pt["poses"], pt["valid"]), pt["num_points"])
+  for k, rk in [("camera", want.camera), ("board", want.board), ("times", want.times)]:
+    assert np.array_equal(np.asarray(rk.valid), got[k]["valid"]), k
+    assert np.array_equal(np.asarray(rk.poses), got[k]["poses"]), k
