@@ -570,7 +570,7 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
       else jf = d.foff_motion + 6 * (pl - 1);
       double rt[6];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) rt[k] = param_value(t, x, jf + k);
+      for (int k = 0; k < 6; ++k) rt[k] = param_value(t, x, jf + k);   // (full -> active index map: one dependent load)
       double pe[POSE_STRIDE];
       pose_entry(rt, pe);
 #pragma unroll
@@ -582,7 +582,10 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
     const double* Pm0 = Pl + POSE_STRIDE;
     const double* Pm1 = Pl + (NPB > 3 ? 2 : 1) * POSE_STRIDE;
     const double* Bf = t.bwg + 12 * (size_t)f;
-    if (pl < NPC) {                        // one column of That per lane
+    if constexpr (MOTION != MOTION_HAND_EYE) {
+      // static / rolling shutter: lane-uniform chain products, per-lane column by selects (no divergent block cases)
+      fused_view_tables<ROLL>(Pc, Pm0, Pm1, Pb, pl, Tm, Vm);
+    } else if (pl < NPC) {                 // hand-eye (five-pose chain): one column of That per lane
       double col[DE];
       view_column_p(d, Pc, Pb, Pm0, Pm1, Bf, pl, col);
 #pragma unroll

@@ -140,6 +140,70 @@ MCBA_HD void view_column(const Dims& d, const Tables& t, int f, int c, int b, in
   view_column_p(d, Pc, Pb, Pm0, Pm1, t.bwg + 12 * (size_t)f, j, col, stride);
 }
 
+// Lane-uniform construction of the That columns and the chain matrices of one view from its pose entries (static and
+// rolling-shutter motion): the chain products camera . frame (. board) are formed ONCE by every lane (same instruction
+// stream, no divergence), then lane j < 6 NPB picks the prefix rotation / left Jacobian / origin of ITS pose block with
+// selects and evaluates one column (view_pose_column written branch-free).  Equivalent to view_column_p, whose four block
+// cases a wavefront had to execute one after the other.  Tm[a * NPC + j] receives column j, Vm the chain matrices.
+template <bool ROLL>
+MCBA_HD void fused_view_tables(const double* Pc, const double* Pm0, const double* Pm1, const double* Pb, int j,
+                               double* Tm, double* Vm) {
+  constexpr int NCH = ROLL ? 2 : 1, NPB = ROLL ? 4 : 3, NPC = 6 * NPB;
+  const double* Rc = Pc + POSE_R;
+  const double* tc = Pc + POSE_T;
+  const double* Lc = Pc + POSE_L;
+  const double* Rb = Pb + POSE_R;
+  const double* tb = Pb + POSE_T;
+  const double* Lb = Pb + POSE_L;
+  const int k = j / 6, jj = j % 6;
+  const bool rotcol = jj < 3;
+  const int ju = rotcol ? jj : jj - 3;
+  const double e0 = ju == 0 ? 1.0 : 0.0, e1 = ju == 1 ? 1.0 : 0.0, e2 = ju == 2 ? 1.0 : 0.0;
+  for (int ch = 0; ch < NCH; ++ch) {
+    const double* Pf = ch == 0 ? Pm0 : Pm1;
+    double R1[9], t1[3], o[3], v3[3], R2[9];
+    se3_mul(Rc, tc, Pf + POSE_R, Pf + POSE_T, R1, t1);            // camera . frame
+    mat3_vec(R1, tb, v3);
+    for (int i = 0; i < 3; ++i) o[i] = t1[i] + v3[i];             // origin of camera . frame . board
+    mat3_mul(R1, Rb, R2);
+    if (j == NPC + ch) {                                          // the chain matrix board -> camera of this chain
+      for (int i = 0; i < 9; ++i) Vm[ch * VIEW_STRIDE + i] = R2[i];
+      for (int i = 0; i < 3; ++i) Vm[ch * VIEW_STRIDE + 9 + i] = o[i];
+    }
+    // pose block of this lane: 0 camera (identity prefix), NPB - 1 board (prefix camera . frame), between: the frame pose
+    // of chain `ch` (prefix camera); rolling shutter: block 1 touches chain 0 only, block 2 chain 1 only
+    const bool is_cam = k == 0, is_board = k == NPB - 1;
+    const bool active = is_cam || is_board || !ROLL || k == 1 + ch;
+    double u[3];                                                  // column ju of L_k (rotation columns) or a unit vector
+    for (int i = 0; i < 3; ++i) {
+      const double lc = Lc[3 * i] * e0 + Lc[3 * i + 1] * e1 + Lc[3 * i + 2] * e2;
+      const double lf = Pf[POSE_L + 3 * i] * e0 + Pf[POSE_L + 3 * i + 1] * e1 + Pf[POSE_L + 3 * i + 2] * e2;
+      const double lb = Lb[3 * i] * e0 + Lb[3 * i + 1] * e1 + Lb[3 * i + 2] * e2;
+      const double unit = i == ju ? 1.0 : 0.0;
+      u[i] = rotcol ? (is_cam ? lc : (is_board ? lb : lf)) : unit;
+    }
+    double tv[3], ov[3];
+    for (int i = 0; i < 3; ++i) {
+      const double r0 = is_cam ? (i == 0 ? 1.0 : 0.0) : (is_board ? R1[3 * i] : Rc[3 * i]);
+      const double r1 = is_cam ? (i == 1 ? 1.0 : 0.0) : (is_board ? R1[3 * i + 1] : Rc[3 * i + 1]);
+      const double r2 = is_cam ? (i == 2 ? 1.0 : 0.0) : (is_board ? R1[3 * i + 2] : Rc[3 * i + 2]);
+      tv[i] = r0 * u[0] + r1 * u[1] + r2 * u[2];                  // R_pre u
+      ov[i] = is_cam ? tc[i] : (is_board ? o[i] : t1[i]);         // o_k
+    }
+    const double c0 = ov[1] * tv[2] - ov[2] * tv[1], c1 = ov[2] * tv[0] - ov[0] * tv[2], c2 = ov[0] * tv[1] - ov[1] * tv[0];
+    const double w = active ? 1.0 : 0.0;
+    if (j < NPC) {
+      double* col = Tm + (size_t)(6 * ch) * NPC + j;
+      col[0 * NPC] = rotcol ? w * tv[0] : 0.0;
+      col[1 * NPC] = rotcol ? w * tv[1] : 0.0;
+      col[2 * NPC] = rotcol ? w * tv[2] : 0.0;
+      col[3 * NPC] = w * (rotcol ? c0 : tv[0]);
+      col[4 * NPC] = w * (rotcol ? c1 : tv[1]);
+      col[5 * NPC] = w * (rotcol ? c2 : tv[2]);
+    }
+  }
+}
+
 // chain matrix board -> camera from explicit pose entries (Pm = the motion entry of the wanted chain; hand-eye: Pm0 =
 // world_wrt_base, Pm1 = gripper_wrt_camera): out[12] = R | t
 MCBA_HD void view_chain_p(const Dims& d, const double* Pc, const double* Pb, const double* Pm0, const double* Pm1,
