@@ -562,15 +562,17 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
     static_assert(NPB * POSE_STRIDE <= BUF, "pose entries do not fit the staging buffer");
     double* Pl = Buf;                      // (the staging buffer is free until the first chunk)
     if (pl < NPB) {
-      int jf;
-      if (pl == 0) jf = d.foff_campose + 6 * c;
-      else if (pl == NPB - 1) jf = d.foff_boardpose + 6 * b;
-      else if (MOTION == MOTION_STATIC) jf = d.foff_motion + 6 * f;
-      else if (MOTION == MOTION_ROLLING) jf = d.foff_motion + 6 * ((pl - 1) * d.F + f);
-      else jf = d.foff_motion + 6 * (pl - 1);
+      int oa, of, r;
+      if (pl == 0) { oa = d.off_campose; of = d.foff_campose; r = 6 * c; }
+      else if (pl == NPB - 1) { oa = d.off_boardpose; of = d.foff_boardpose; r = 6 * b; }
+      else {
+        oa = d.off_motion;
+        of = d.foff_motion;
+        r = MOTION == MOTION_STATIC ? 6 * f : (MOTION == MOTION_ROLLING ? 6 * ((pl - 1) * d.F + f) : 6 * (pl - 1));
+      }
       double rt[6];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) rt[k] = param_value(t, x, jf + k);   // (full -> active index map: one dependent load)
+      for (int k = 0; k < 6; ++k) rt[k] = block_value(t, x, oa, of, r + k);
       double pe[POSE_STRIDE];
       pose_entry(rt, pe);
 #pragma unroll

@@ -63,15 +63,17 @@ __global__ __launch_bounds__(64) void k_tmat(Dims d, Tables t, double* __restric
     const int f_lo = d.f0 + v0 / CB, nfl = (d.f0 + (v0 + nv - 1) / CB) - f_lo + 1;
     const int nmot = d.motion == MOTION_HAND_EYE ? 2 : nch * nfl, np = d.C + d.B + nmot;
     for (int e = threadIdx.x; e < np; e += blockDim.x) {
-      int j;
-      if (e < d.C) j = d.foff_campose + 6 * e;
-      else if (e < d.C + d.B) j = d.foff_boardpose + 6 * (e - d.C);
+      int oa, of, r;
+      if (e < d.C) { oa = d.off_campose; of = d.foff_campose; r = 6 * e; }
+      else if (e < d.C + d.B) { oa = d.off_boardpose; of = d.foff_boardpose; r = 6 * (e - d.C); }
       else {
         const int li = e - d.C - d.B;
-        j = d.motion == MOTION_HAND_EYE ? d.foff_motion + 6 * li : d.foff_motion + 6 * ((li / nfl) * d.F + f_lo + li % nfl);
+        oa = d.off_motion;
+        of = d.foff_motion;
+        r = d.motion == MOTION_HAND_EYE ? 6 * li : 6 * ((li / nfl) * d.F + f_lo + li % nfl);
       }
       double rt[6];
-      for (int k = 0; k < 6; ++k) rt[k] = param_value(t, x, j + k);
+      for (int k = 0; k < 6; ++k) rt[k] = block_value(t, x, oa, of, r + k);
       pose_entry(rt, lpose + (size_t)e * POSE_STRIDE);
     }
     __syncthreads();
@@ -109,9 +111,11 @@ __device__ __forceinline__ void assemble_frame_block(const Dims& d, const Tables
                                                      const double* __restrict__ rec, double* __restrict__ Hff,
                                                      double* __restrict__ Hfs, double* __restrict__ g,
                                                      double* __restrict__ diag) {
-  // activity flags of the frame's C B views, read once: with `if (view_count[v] == 0) continue;` inside the sums every
-  // record load waited for its own flag load (two dependent memory round trips per view, 16 views in a row).  The
-  // record loads below are unconditional (records of empty views hold stale numbers) and are masked after the load.
+  // activity flags of the frame's C B views, read once into LDS: with `if (view_count[v] == 0) continue;` inside the sums
+  // every record load waited for its own flag load (two dependent memory round trips per view, 16 views in a row).  The
+  // record loads below stay unconditional, but the address of an EMPTY view's record is replaced by one hot address
+  // (element 0 of the frame's first record: a cache hit) and its value discarded: 45 % of the views of the north-star rig
+  // are empty, and their stale records were streamed from memory like the live ones.
   __shared__ double act[128];   // C B <= 128 (checked by launch_assemble)
   const int f = d.f0 + fl;
   const int DF = d.DF, ns = d.ns, N1 = d.N1, NL = d.NL, CB = d.C * d.B;
@@ -132,8 +136,9 @@ __device__ __forceinline__ void assemble_frame_block(const Dims& d, const Tables
     const int off = li < lf ? tri_index(li, lf, N1) : tri_index(lf, li, N1);
     double sum = 0.0;
     for (int b = 0; b < d.B; ++b) {
-      const double val = rf[(size_t)(c * d.B + b) * d.rec_stride + off];
-      sum += act[c * d.B + b] != 0.0 ? val : 0.0;
+      const bool on = act[c * d.B + b] != 0.0;
+      const double val = rf[on ? (size_t)(c * d.B + b) * d.rec_stride + off : 0];   // (empty view: one hot address, see above)
+      sum += on ? val : 0.0;
     }
     hfs[dd * ns + d.x_to_shared(gi)] = sum;
   }
@@ -147,14 +152,16 @@ __device__ __forceinline__ void assemble_frame_block(const Dims& d, const Tables
     double s0 = 0.0, s1 = 0.0;
     int c = 0;
     for (; c + 2 <= d.C; c += 2) {
-      const double v0 = rf[(size_t)(c * d.B + b) * d.rec_stride + off];
-      const double v1 = rf[(size_t)((c + 1) * d.B + b) * d.rec_stride + off];
-      s0 += act[c * d.B + b] != 0.0 ? v0 : 0.0;
-      s1 += act[(c + 1) * d.B + b] != 0.0 ? v1 : 0.0;
+      const bool on0 = act[c * d.B + b] != 0.0, on1 = act[(c + 1) * d.B + b] != 0.0;
+      const double v0 = rf[on0 ? (size_t)(c * d.B + b) * d.rec_stride + off : 0];
+      const double v1 = rf[on1 ? (size_t)((c + 1) * d.B + b) * d.rec_stride + off : 0];
+      s0 += on0 ? v0 : 0.0;
+      s1 += on1 ? v1 : 0.0;
     }
     for (; c < d.C; ++c) {
-      const double v0 = rf[(size_t)(c * d.B + b) * d.rec_stride + off];
-      s0 += act[c * d.B + b] != 0.0 ? v0 : 0.0;
+      const bool on0 = act[c * d.B + b] != 0.0;
+      const double v0 = rf[on0 ? (size_t)(c * d.B + b) * d.rec_stride + off : 0];
+      s0 += on0 ? v0 : 0.0;
     }
     hfs[dd * ns + d.x_to_shared(gi)] = s0 + s1;
   }
@@ -166,18 +173,20 @@ __device__ __forceinline__ void assemble_frame_block(const Dims& d, const Tables
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     int cb = 0;
     for (; cb + 4 <= CB; cb += 4) {      // four independent loads in flight, fixed summation order
-      const double v0 = rf[(size_t)cb * d.rec_stride + off];
-      const double v1 = rf[(size_t)(cb + 1) * d.rec_stride + off];
-      const double v2 = rf[(size_t)(cb + 2) * d.rec_stride + off];
-      const double v3 = rf[(size_t)(cb + 3) * d.rec_stride + off];
-      s0 += act[cb] != 0.0 ? v0 : 0.0;
-      s1 += act[cb + 1] != 0.0 ? v1 : 0.0;
-      s2 += act[cb + 2] != 0.0 ? v2 : 0.0;
-      s3 += act[cb + 3] != 0.0 ? v3 : 0.0;
+      const bool o0 = act[cb] != 0.0, o1 = act[cb + 1] != 0.0, o2 = act[cb + 2] != 0.0, o3 = act[cb + 3] != 0.0;
+      const double v0 = rf[o0 ? (size_t)cb * d.rec_stride + off : 0];
+      const double v1 = rf[o1 ? (size_t)(cb + 1) * d.rec_stride + off : 0];
+      const double v2 = rf[o2 ? (size_t)(cb + 2) * d.rec_stride + off : 0];
+      const double v3 = rf[o3 ? (size_t)(cb + 3) * d.rec_stride + off : 0];
+      s0 += o0 ? v0 : 0.0;
+      s1 += o1 ? v1 : 0.0;
+      s2 += o2 ? v2 : 0.0;
+      s3 += o3 ? v3 : 0.0;
     }
     for (; cb < CB; ++cb) {
-      const double v0 = rf[(size_t)cb * d.rec_stride + off];
-      s0 += act[cb] != 0.0 ? v0 : 0.0;
+      const bool o0 = act[cb] != 0.0;
+      const double v0 = rf[o0 ? (size_t)cb * d.rec_stride + off : 0];
+      s0 += o0 ? v0 : 0.0;
     }
     const double sum = (s0 + s1) + (s2 + s3);
     if (d2 < DF) {
@@ -193,19 +202,30 @@ __device__ __forceinline__ void assemble_frame_block(const Dims& d, const Tables
 __device__ __forceinline__ void shared_partial_block(const Dims& d, const Tables& t, int pair, int ch,
                                                      const double* __restrict__ rec, int nchunk,
                                                      double* __restrict__ partial) {
+  __shared__ int vsel[64];   // record to read for every frame of the chunk: the view itself, or -1 = empty view
   const int c = pair / d.B, b = pair % d.B;
   const int per = (d.Fl + nchunk - 1) / nchunk;
   const int fa = ch * per, fb = min(d.Fl, fa + per);
   double* out = partial + ((size_t)pair * nchunk + ch) * d.rec_stride;
-  for (int e = threadIdx.x; e < d.rec_stride; e += blockDim.x) {
-    double sum = 0.0;
-#pragma unroll 4
-    for (int fl = fa; fl < fb; ++fl) {
-      const int v = (fl * d.C + c) * d.B + b;
-      const double val = rec[(size_t)v * d.rec_stride + e];   // records of empty views are never written: mask them
-      sum += t.view_count[v] != 0 ? val : 0.0;
+  for (int f0 = fa; f0 < fb; f0 += 64) {        // (chunks hold at most a few dozen frames: one pass)
+    const int nf = min(64, fb - f0);
+    __syncthreads();
+    if ((int)threadIdx.x < nf) {
+      const int v = ((f0 + (int)threadIdx.x) * d.C + c) * d.B + b;
+      vsel[threadIdx.x] = t.view_count[v] != 0 ? v : -1;
     }
-    out[e] = sum;
+    __syncthreads();
+    for (int e = threadIdx.x; e < d.rec_stride; e += blockDim.x) {
+      double sum = f0 == fa ? 0.0 : out[e];
+#pragma unroll 4
+      for (int k = 0; k < nf; ++k) {
+        // records of empty views are never written: their loads go to one hot address and the value is dropped
+        const int v = vsel[k];
+        const double val = rec[v >= 0 ? (size_t)v * d.rec_stride + e : 0];
+        sum += v >= 0 ? val : 0.0;
+      }
+      out[e] = sum;
+    }
   }
 }
 

@@ -13,4 +13,9 @@ python tests/prof_linearize.py > $O/lin_phases.log 2>&1
 MCBA_TIMING=1 python tests/prof_workspace.py cfg3 > $O/workspace_cfg3.log 2>&1; grep "calibrate ms" $O/workspace_cfg3.log
 python tests/prof_lin_cfgs.py cfg2 cfg3 cfg4 cfg5 > $O/lin_cfgs.log 2>&1; cat $O/lin_cfgs.log
 python tests/prof_scale.py > $O/lin_scale.log 2>&1; tail -8 $O/lin_scale.log
+python tests/prof_init.py cfg2 cfg3 cfg4 > $O/init.log 2>&1; cat $O/init.log
+MCBA_FUSED=1 python bench.py --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_fused.json 2>/dev/null; grep -o '"ms_per_step": [0-9.]*' $O/bench_fused.json | head -1
+MCBA_TIMING=1 python tests/prof_workspace.py cfg4 2>&1 | grep 'calibrate ms'
+MCBA_TIMING=1 python tests/prof_workspace.py cfg2 2>&1 | grep 'calibrate ms'
+python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; grep -E 'passed|failed' $O/pytest_gpu.log
 ls $O $O/pmc
