@@ -22,7 +22,7 @@
 
 namespace mcba {
 
-constexpr int ALIGN_THREADS = 256;
+constexpr int ALIGN_THREADS = 1024;   // the nearest-neighbour scans of the big pair problems (thousands of entries) set the pace
 
 struct AlignScratch {        // per-problem device scratch, sized for the largest problem (n entries)
   double* vec;       // [n][6]  relative poses as rotation vector | translation (compacted)
