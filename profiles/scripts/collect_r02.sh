@@ -5,7 +5,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o trace -- pyt
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc -o pmc_fetch -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-solve > /dev/null 2> $O/pmc1.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc -o pmc_write -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-solve > /dev/null 2> $O/pmc2.err
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU --kernel-trace --output-format csv -d $O/pmc -o pmc_mfma -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-solve > /dev/null 2> $O/pmc3.err
-(cd $R && rocprofv3 --kernel-trace --stats --output-format csv -d $O/solve -o solve -- python tests/prof_cfg.py cfg3 > $O/solve.log 2>&1)
+PYTHONPATH=$R:$R/tests rocprofv3 --kernel-trace --stats --output-format csv -d $O/solve -o solve -- python $R/tests/prof_cfg.py cfg3 > $O/solve.log 2>&1
 cd $R
 python bench.py > $O/bench.json 2> $O/bench.err
 tail -c 600 $O/bench.json
