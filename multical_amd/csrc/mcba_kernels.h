@@ -492,7 +492,12 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
                                                      double* __restrict__ zero_b, int nb) {
   constexpr bool ROLL = MOTION == MOTION_ROLLING;
   constexpr int DE = ROLL ? 12 : 6, NPB = MOTION == MOTION_STATIC ? 3 : 4, KI = OPTK ? 4 + ND : 0;
-  constexpr int NV = DE + KI + 1, NT = (NV + 15) / 16, NVP = 16 * NT, LDV = NVP + 1;
+  constexpr int NV = DE + KI + 1, NT = (NV + 15) / 16, NVP = 16 * NT;
+  // shifted-tile kernels (see TAILV below) never read a column >= NV: their staging rows and their epilogue copy of S are
+  // NV wide instead of 32 (LDS per workgroup 20.4 -> 16.1 KB at NV = 22)
+  constexpr bool NARROW = MFMA && NT == 2 && NV - 16 <= 7;
+  constexpr int LDV = (NARROW ? NV : NVP) + 1;
+  constexpr int SLD = NARROW ? ((NV + 1) & ~1) : NVP, SROWS = NARROW ? NV : NVP;   // epilogue S: SROWS x SLD
   constexpr int NPC = 6 * NPB, NL = NPC + KI, N1 = NL + 1;
   // staging: one LDS row per lane; a chunk of 64 observations is accumulated in TWO rounds, first the u-rows of all 64
   // lanes, then the v-rows (S = sum of the outer products of all rows: the order is free).  Compared with staging the
@@ -511,16 +516,29 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
   constexpr int NTAIL = TAILV ? TW * (TW + 1) / 2 : 1;
   // epilogue footprint: S (NVP^2), Y (DE x 16 ceil(NPC/16)) and the packed record
   constexpr int STAGE = ROWS * LDV;
-  constexpr int EPI = NVP * NVP + (MFMA ? DE * 16 * ((NPC + 15) / 16) + (REC + 2 + 1) / 2 * 2 + 64 : 0);
+  constexpr int EPI = SLD * SROWS + (MFMA ? DE * 16 * ((NPC + 15) / 16) + (REC + 2 + 1) / 2 * 2 + 64 : 0);
   constexpr int BUF = STAGE > EPI ? STAGE : EPI;
 
   __shared__ __attribute__((aligned(16))) double Buf[BUF];   // staging rows in the main loop; [S | Y | M] in the epilogue
-  __shared__ double Tm[DE * NPC];
-  __shared__ uint16_t pidx[LIN_MAX_POINTS];
+  // PIPE: the "front" of the NEXT view (mask bytes, That, chain matrices and camera parameters: two dependent memory round
+  // trips and the compaction) is loaded behind the main loop of the current view and finished in the middle of its
+  // epilogue, into the second copy of the small per-view LDS tables, so that the next main loop starts on resident data.
+  // Measured and NOT adopted (the switch stays for the record): 50.2 us against 48.3 us at cfg3, 92 against 68 us at cfg4.
+  // The front registers are live across the epilogue (static kernels: 124 -> 160 VGPRs, one wave per SIMD less), and the
+  // second wavefront of the SIMD already covers the prologue's round trips.
+#if defined(MCBA_EXP_PIPE)
+  constexpr bool PIPE = MFMA && !FUSED && !PROF;
+#else
+  constexpr bool PIPE = false;
+#endif
+  constexpr int NBUFS = PIPE ? 2 : 1;
+  constexpr int NVS = (ROLL ? 2 : 1) * VIEW_STRIDE;
+  __shared__ double TmBuf[NBUFS * DE * NPC];
+  __shared__ uint16_t PidxBuf[NBUFS * LIN_MAX_POINTS];
   // chain matrices of the view in LDS: written by the fused prologue; the rolling-shutter kernels (two chains = 48 scalar
   // registers, more than the SGPR file has left) also read them from here in the main loop
   constexpr bool VLDS = FUSED || ROLL;
-  __shared__ double Vm[VLDS ? (ROLL ? 2 : 1) * VIEW_STRIDE : 1];
+  __shared__ double VmBuf[VLDS ? NBUFS * NVS : 1];
   double* Vbuf = Buf;
   if constexpr (FUSED) {   // the assembly that follows accumulates into [g | diag | cost] and H_ss
     for (int e = blockIdx.x * 64 + threadIdx.x; e < na; e += gridDim.x * 64) zero_a[e] = 0.0;
@@ -534,10 +552,83 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
   // (a dynamic hand-out of the views through an atomic counter was measured slower at every size: static stride it is)
   const int n_active = t.active_views[0];
   (void)epoch;   // (de-phasing the workgroups with a start-up delay per blockIdx & 3 was measured: only slower)
+  constexpr int NPB64 = LIN_MAX_POINTS / 64;
+  constexpr int NTL = (DE * NPC + 63) / 64;
+  // ---- front of a view: registers filled by front_issue, consumed by front_finish -----------------------------------
+  uint8_t inb[NPB64];
+  double tl[NTL], vm_f = 0.0, cam_f[5 + ND], ext_f[2];
+  double camr[5 + ND], extr[CAM_STRIDE - CAM_TILT], Vr[ROLL ? 1 : NVS];
+#pragma unroll
+  for (int k = 0; k < CAM_STRIDE - CAM_TILT; ++k) extr[k] = 0.0;
+  // all global loads of the front are issued back to back (mask bytes, That, chain matrices, camera): one round trip
+  auto front_issue = [&](int vv, int pl) {
+    const int cc = (vv / d.B) % d.C;
+    const uint8_t* mrow = t.inlier + (size_t)vv * d.P;
+#pragma unroll
+    for (int k = 0; k < NPB64; ++k) inb[k] = masked_load_row(mrow, k * 64 + pl, d.P);
+    if constexpr (!FUSED) {
+      const double* tg = t.tmat + (size_t)vv * (DE * NPC);   // That of this view, precomputed by k_tmat
+#pragma unroll
+      for (int k = 0; k < NTL; ++k) tl[k] = masked_load_row(tg, k * 64 + pl, DE * NPC);
+      const double* vsrc = t.view + (size_t)vv * NVS;
+      if constexpr (ROLL) {
+        vm_f = vsrc[min(pl, NVS - 1)];
+      } else {
+#pragma unroll
+        for (int k = 0; k < NVS; ++k) Vr[k] = vsrc[k];         // (made scalar in front_finish)
+      }
+      const double* csrc = t.cam + (size_t)cc * CAM_STRIDE;
+#pragma unroll
+      for (int k = 0; k < 5 + ND; ++k) cam_f[k] = csrc[k];
+      ext_f[0] = csrc[CAM_HEIGHT];
+      ext_f[1] = csrc[CAM_FIXASPECT];
+    }
+  };
+  // That / chain matrices / compaction list into LDS copy `buf`; camera parameters and (static) chain matrices become
+  // scalars.  Returns the number of inliers of the view.
+  auto front_finish = [&](int buf, int pl) {
+    double* Tm = TmBuf + buf * (DE * NPC);
+    uint16_t* pidx = PidxBuf + buf * LIN_MAX_POINTS;
+    if constexpr (!FUSED) {
+#pragma unroll
+      for (int k = 0; k < NTL; ++k)
+        if (k * 64 + pl < DE * NPC) Tm[k * 64 + pl] = tl[k];
+      if constexpr (ROLL) {
+        if (pl < NVS) VmBuf[buf * NVS + pl] = vm_f;
+      } else {
+#pragma unroll
+        for (int k = 0; k < NVS; ++k) Vr[k] = uniform_f64(Vr[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < 5 + ND; ++k) camr[k] = uniform_f64(cam_f[k]);
+      extr[CAM_HEIGHT - CAM_TILT] = uniform_f64(ext_f[0]);
+      extr[CAM_FIXASPECT - CAM_TILT] = uniform_f64(ext_f[1]);
+    }
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < NPB64; ++k) {
+      const bool in = inb[k] != 0;
+      const unsigned long long m = __ballot(in);
+      if (in) pidx[cnt + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(k * 64 + lane);
+      cnt += __popcll(m);
+    }
+    return cnt;
+  };
+
+  int cur = 0;                 // LDS copy that holds the front of the current view
+  int count = 0, p_cur = 0;
+  double2 ob_cur;
+  ob_cur.x = ob_cur.y = 0.0;
+  double X_cur[3] = {0.0, 0.0, 0.0}, X_nxt[3];
+  bool front_ready = false;    // the front of the view about to be processed is already in LDS copy `cur` (PIPE)
   for (int vi = blockIdx.x; vi < n_active; vi += gridDim.x) {
   const int v = t.active_views[1 + vi];
   const int b = v % d.B, c = (v / d.B) % d.C, fl = v / (d.B * d.C), f = d.f0 + fl;
   (void)f;
+  // (PIPE) the view after this one: its index is needed early, it heads the next front's dependent chain of loads
+  const int vi_n = vi + (int)gridDim.x;
+  const bool has_next = PIPE && vi_n < n_active;
+  const int v_n = has_next ? t.active_views[1 + vi_n] : v;
   long long stamp[6] = {0, 0, 0, 0, 0, 0};
   constexpr bool prof = PROF;
   if (prof) stamp[0] = clock64();
@@ -546,15 +637,11 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
   // vmcnt(0) wait.  Recomputing a 32-bit offset per view is two integer instructions.
   int pl;
   asm volatile("v_mov_b32 %0, %1" : "=v"(pl) : "v"(lane));
+  double* Tm = TmBuf + cur * (DE * NPC);
+  uint16_t* pidx = PidxBuf + cur * LIN_MAX_POINTS;
+  double* Vm = VmBuf + (VLDS ? cur * NVS : 0);
 
-  // all global loads of the prologue are issued back to back (mask bytes, That): one memory round trip
-  constexpr int NPB64 = LIN_MAX_POINTS / 64;
-  uint8_t inb[NPB64];
-  {
-    const uint8_t* mrow = t.inlier + (size_t)v * d.P;
-#pragma unroll
-    for (int k = 0; k < NPB64; ++k) inb[k] = masked_load_row(mrow, k * 64 + pl, d.P);
-  }
+  if (!front_ready) front_issue(v, pl);
   const double* camp = nullptr;   // FUSED: the camera's parameter block [fx fy cx cy skew k...] inside x (or the constants)
   if constexpr (FUSED) {
     camp = d.off_cameras >= 0 ? x + d.off_cameras + c * (5 + ND) : t.xfull + d.foff_cameras + c * (5 + ND);
@@ -600,15 +687,6 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
       for (int k = 0; k < VIEW_STRIDE; ++k) Vm[ch * VIEW_STRIDE + k] = Vc[k];
     }
     lds_fence();                           // Pl is dead: the staging buffer may be written again
-  } else {   // That of this view, precomputed by k_tmat
-    const double* tg = t.tmat + (size_t)v * (DE * NPC);
-    constexpr int NTL = (DE * NPC + 63) / 64;
-    double tl[NTL];
-#pragma unroll
-    for (int k = 0; k < NTL; ++k) tl[k] = masked_load_row(tg, k * 64 + pl, DE * NPC);
-#pragma unroll
-    for (int k = 0; k < NTL; ++k)
-      if (k * 64 + pl < DE * NPC) Tm[k * 64 + pl] = tl[k];
   }
   if (prof) stamp[4] = clock64();
   // only the pad columns need clearing: every staged row is fully rewritten (columns < NV) in every round
@@ -617,14 +695,7 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
     for (int e = lane; e < ROWS * (LDV - NV); e += 64) Vbuf[(e / (LDV - NV)) * LDV + NV + e % (LDV - NV)] = 0.0;
 
   if (prof) stamp[5] = clock64();
-  int count = 0;
-#pragma unroll
-  for (int k = 0; k < NPB64; ++k) {
-    const bool in = inb[k] != 0;
-    const unsigned long long m = __ballot(in);
-    if (in) pidx[count + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(k * 64 + lane);
-    count += __popcll(m);
-  }
+  if (!front_ready) count = front_finish(cur, pl);
 
   constexpr int NACC_V = NVP * NVP / 64;                  // plain-FMA variant: NVP*NVP entries over 64 lanes
   constexpr int NTILE = TAILV ? 2 : NT * (NT + 1) / 2;   // shifted tile: two accumulators (even / odd steps), no dependent MFMAs
@@ -641,38 +712,31 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
   lds_fence();
   if (prof) stamp[1] = clock64();
 
-  // the view's chain matrices and the camera's parameters: read ONCE per view and kept as scalars (SGPRs).  Left to the
-  // compiler they were 17 vector loads of one address each in EVERY chunk, with 68 vector registers to hold them.
-  constexpr int NVS = (ROLL ? 2 : 1) * VIEW_STRIDE;
-  double Vr[ROLL ? 1 : NVS], camr[5 + ND], extr[CAM_STRIDE - CAM_TILT];
-  {
-    const double* vsrc = FUSED ? Vm : t.view + (size_t)v * NVS;
-    const double* csrc = FUSED ? camp : t.cam + (size_t)c * CAM_STRIDE;
+  // The view's chain matrices and the camera's parameters are read ONCE per view (front) and kept as scalars (SGPRs;
+  // rolling shutter: the two chains stay in LDS).  Left to the compiler they were 17 vector loads of one address each in
+  // EVERY chunk, with 68 vector registers to hold them.
+  if constexpr (FUSED) {
+#pragma unroll
+    for (int k = 0; k < 5 + ND; ++k) camr[k] = uniform_f64(camp[k]);
     const double* esrc = t.cam + (size_t)c * CAM_STRIDE + CAM_TILT;
-    if constexpr (ROLL) {
-      if constexpr (!FUSED) {
-        if (pl < NVS) Vm[pl] = vsrc[pl];      // (visible to the main loop after the fence below)
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < NVS; ++k) Vr[k] = uniform_f64(vsrc[k]);
-    }
-#pragma unroll
-    for (int k = 0; k < 5 + ND; ++k) camr[k] = uniform_f64(csrc[k]);
-#pragma unroll
-    for (int k = 0; k < CAM_STRIDE - CAM_TILT; ++k) extr[k] = 0.0;
     extr[CAM_HEIGHT - CAM_TILT] = uniform_f64(esrc[CAM_HEIGHT - CAM_TILT]);
     extr[CAM_FIXASPECT - CAM_TILT] = uniform_f64(esrc[CAM_FIXASPECT - CAM_TILT]);
+    if constexpr (!ROLL) {
+#pragma unroll
+      for (int k = 0; k < NVS; ++k) Vr[k] = uniform_f64(Vm[k]);
+    }
   }
   // (the tilted model reads its 27 tilt-matrix entries from the table: rare, not worth the scalar registers)
   const double* extp = ND >= 14 ? t.cam + (size_t)c * CAM_STRIDE + CAM_TILT : extr;
-  if constexpr (ROLL && !FUSED) lds_fence();   // Vm
 
   // software prefetch: observation + board point of the NEXT chunk are requested before the current one is processed
-  int p_cur = lane < count ? pidx[lane] : 0;
-  double2 ob_cur = t.obs[(size_t)v * d.P + p_cur];
-  double X_cur[3], X_nxt[3];
-  for (int k = 0; k < 3; ++k) X_cur[k] = t.board_points[3 * (size_t)(b * d.P + p_cur) + k];
+  // (the first chunk of a pipelined view was requested from the middle of the previous epilogue)
+  if (!front_ready) {
+    p_cur = lane < count ? pidx[lane] : 0;
+    ob_cur = t.obs[(size_t)v * d.P + p_cur];
+    for (int k = 0; k < 3; ++k) X_cur[k] = t.board_points[3 * (size_t)(b * d.P + p_cur) + k];
+  }
+  int count_n = 0;             // (PIPE) inliers of the next view, known once its front is finished
   for (int base = 0; base < count; base += 64) {
     const int i = base + lane;
     const bool in = i < count;
@@ -762,6 +826,7 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
   }
 
   if (prof) stamp[3] = clock64();
+  if (has_next) front_issue(v_n, pl);   // (PIPE) the next view's front is in flight during the epilogue
 #if defined(MCBA_EXP_PRIO)
   __builtin_amdgcn_s_setprio(MCBA_EXP_PRIO);   // latency-bound epilogue: ask for the issue slots, the partner wave keeps the pipe busy
 #endif
@@ -813,8 +878,8 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
       for (int r = 0; r < 4; ++r) {
         const int row = rsub + 4 * r, col = TW + csub;
         const double val = accm[0][r] + accm[1][r];
-        Sbuf[row * NVP + col] = val;
-        Sbuf[col * NVP + row] = val;
+        Sbuf[row * SLD + col] = val;
+        Sbuf[col * SLD + row] = val;
       }
     } else {
       int ti = 0;
@@ -822,15 +887,15 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
         for (int t1 = t0; t1 < NT; ++t1, ++ti) {
           for (int r = 0; r < 4; ++r) {
             const int row = 16 * t0 + rsub + 4 * r, col = 16 * t1 + csub;
-            Sbuf[row * NVP + col] = accm[ti][r];
-            if (t0 != t1) Sbuf[col * NVP + row] = accm[ti][r];
+            Sbuf[row * SLD + col] = accm[ti][r];
+            if (t0 != t1) Sbuf[col * SLD + row] = accm[ti][r];
           }
         }
     }
   } else {
     constexpr int IW = NVP, JW = NACC_V;
     const int ii = el % IW, j0 = (el / IW) * JW;
-    for (int jj = 0; jj < JW; ++jj) Sbuf[ii * NVP + j0 + jj] = accv[jj];
+    for (int jj = 0; jj < JW; ++jj) Sbuf[ii * SLD + j0 + jj] = accv[jj];
   }
   if constexpr (TAILV) {   // lane e carries packed entry e = (i0 <= i1) of the first (e < NTAIL) or of the last block
     if (el < 2 * NTAIL) {
@@ -838,8 +903,8 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
       int i0 = 0, rem = e;
       while (rem >= TW - i0) { rem -= TW - i0; ++i0; }
       const int i1 = i0 + rem, o = 16 * blk;
-      Sbuf[(o + i0) * NVP + o + i1] = corner_red;
-      Sbuf[(o + i1) * NVP + o + i0] = corner_red;
+      Sbuf[(o + i0) * SLD + o + i1] = corner_red;
+      Sbuf[(o + i1) * SLD + o + i0] = corner_red;
     }
   }
   lds_fence();
@@ -852,8 +917,8 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
     // M is assembled in LDS in the packed record order and leaves the CU with fully coalesced 16-byte stores.
     constexpr int NPCT = (NPC + 15) / 16, NPCP = 16 * NPCT, KR = KI + 1, KRT = (KR + 15) / 16, KS = (DE + 3) / 4;
     constexpr int RECP = (REC + 2 + 1) / 2 * 2;                      // == d.rec_stride
-    static_assert(NVP * NVP + DE * NPCP + RECP + 64 <= BUF, "Y, the packed record and the cost slots do not fit behind S");
-    double* Yb = Buf + NVP * NVP;                                   // [DE][NPCP]
+    static_assert(SLD * SROWS + DE * NPCP + RECP + 64 <= BUF, "Y, the packed record and the cost slots do not fit behind S");
+    double* Yb = Buf + SLD * SROWS;                                   // [DE][NPCP]
     double* Mp = Yb + DE * NPCP;                                    // packed upper triangle + cost, count
     double* Cb = Mp + RECP;                                         // [64] per-lane costs
     // (& 3: el is opaque to the optimiser, the mask tells it that 4 ks + rsub < 4 KS)
@@ -866,7 +931,7 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
     {                                                               // step 1: Y = S_EE That
       double a1[KS], b1[NPCT][KS];
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) a1[ks] = Sbuf[csub * NVP + 4 * ks + rsub];
+      for (int ks = 0; ks < KS; ++ks) a1[ks] = Sbuf[csub * SLD + 4 * ks + rsub];
 #pragma unroll
       for (int tj = 0; tj < NPCT; ++tj)
 #pragma unroll
@@ -888,6 +953,16 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
     }
     lds_fence();
     if (prof) ep1 = clock64();
+    if (has_next) {
+      // (PIPE) the front of the next view has landed: finish it into the other LDS copy and request its first chunk, so
+      // that the remaining half of this epilogue hides that round trip too
+      count_n = front_finish(cur ^ 1, el);
+      const uint16_t* pn = PidxBuf + (cur ^ 1) * LIN_MAX_POINTS;
+      const int b_n = v_n % d.B;
+      p_cur = el < count_n ? pn[el] : 0;
+      ob_cur = t.obs[(size_t)v_n * d.P + p_cur];
+      for (int k = 0; k < 3; ++k) X_cur[k] = t.board_points[3 * (size_t)(b_n * d.P + p_cur) + k];
+    }
 #pragma unroll
     for (int ti = 0; ti < NPCT; ++ti) {
       double av[KS], b2[NPCT][KS], b3[KRT][KS];
@@ -900,7 +975,7 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
 #pragma unroll
         for (int tk = 0; tk < KRT; ++tk) {
           const int jc = 16 * tk + csub;
-          b3[tk][ks] = lmask(Sbuf, k * NVP + DE + jc, k < DE && jc < KR);
+          b3[tk][ks] = lmask(Sbuf, k * SLD + DE + jc, k < DE && jc < KR);
         }
       }
       int rowoff[4];                                                // packed offset of row i:  i (2 N1 - 1 - i) / 2
@@ -934,7 +1009,7 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
     }
     for (int e = el; e < KR * KR; e += 64) {                        // step 4: (intrinsics | residual)^2 block = copy of S
       const int i = e / KR, j = e % KR;
-      if (i <= j) Mp[((NPC + i) * (2 * N1 - 1 - (NPC + i))) / 2 + NPC + j] = Sbuf[(DE + i) * NVP + DE + j];
+      if (i <= j) Mp[((NPC + i) * (2 * N1 - 1 - (NPC + i))) / 2 + NPC + j] = Sbuf[(DE + i) * SLD + DE + j];
     }
     if (el == 0) {   // cost of the view: the 64 per-lane sums in one LDS round trip (a shuffle tree is six of them)
       double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
@@ -969,9 +1044,9 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
         if (pose_col) {
           sum = 0.0;
   #pragma unroll
-          for (int bb = 0; bb < DE; ++bb) sum += Sbuf[a * NVP + bb] * tcol[bb];
+          for (int bb = 0; bb < DE; ++bb) sum += Sbuf[a * SLD + bb] * tcol[bb];
         } else {
-          sum = Sbuf[a * NVP + DE + (j - NPC)];
+          sum = Sbuf[a * SLD + DE + (j - NPC)];
         }
         y[a] = sum;
       }
@@ -985,7 +1060,7 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
       }
       // rows i >= NPC (intrinsics / residual rows): M[i][j] = S[DE + i - NPC][DE + j - NPC]
       if (!pose_col)
-        for (int i = NPC; i <= j; ++i) out[tri_index(i, j, N1)] = Sbuf[(DE + i - NPC) * NVP + DE + (j - NPC)];
+        for (int i = NPC; i <= j; ++i) out[tri_index(i, j, N1)] = Sbuf[(DE + i - NPC) * SLD + DE + (j - NPC)];
     }
   }
   if constexpr (!MFMA) {
@@ -1012,6 +1087,11 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
 #if defined(MCBA_EXP_PRIO)
   __builtin_amdgcn_s_setprio(0);
 #endif
+  front_ready = has_next;
+  if (has_next) {
+    cur ^= 1;
+    count = count_n;
+  }
   }
 }
 
