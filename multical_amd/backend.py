@@ -337,12 +337,13 @@ class Handle(object):
     check(self.lib.mcba_get_inliers(self.h, _ptr(m.view(np.uint8), C.c_uint8)))
     return m
 
-  def linearize_profile(self, x):
+  def linearize_profile(self, x, with_tmat=False):
     x = self._x(x)
     C_, F, B, P = self.shape
-    out = np.zeros((F * C_ * B, 8), dtype=np.int64)
+    nv = F * C_ * B
+    out = np.zeros((nv + (nv + 7) // 8, 8), dtype=np.int64)   # (+ one row per k_tmat workgroup, experimental builds)
     check(self.lib.mcba_debug_linearize_profile(self.h, _ptr(x, C.c_double), out.ctypes.data_as(C.POINTER(C.c_longlong))))
-    return out
+    return (out[:nv], out[nv:]) if with_tmat else out[:nv]
 
   # --- solve --------------------------------------------------------------------------------------------------
   def set_log(self, fn):

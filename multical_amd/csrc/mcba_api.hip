@@ -151,6 +151,8 @@ struct mcba_handle_s {
   DevBuf<int32_t> obs_index, view_count, active_views, work_counter, board_off, full2act;
   DevBuf<double> xfull, bwg, img_h, board_points, pose, cam, view, tmat;
   DevBuf<uint16_t> tri;
+  DevBuf<int4> ftab;   // frame_table(d): what a frame block of k_assemble sums and where it goes
+  int nftab = 0;
   DevBuf<long long> dbg;
   DevBuf<double> err_fm, sel_f64;
   std::vector<double> err_x;           // parameter vector the frame-major error table err_fm was evaluated at
@@ -359,7 +361,6 @@ void launch_linearize(mcba_handle_s* h, const double* dx) {
   const Dims& d = h->d;
   // k_tmat also zeroes [g | diag | cost] and H_ss for the assembly that follows (entries of frames owned by other ranks
   // must be zero before the cross-rank sum: they hold the previous global values after an all-reduce)
-  static_assert(TMV * 4 <= 64, "k_tmat: (view, pose block) threads of a workgroup");
   // Fused form (opt-in, MCBA_FUSED=1): k_linearize itself forms That / the chain matrices from dx, reads the intrinsics
   // from dx and zeroes the assembly targets -- one launch instead of two.  Conditions: the MFMA build, no tilted model
   // (its tilt matrices come from the camera table, which only k_prep refreshes), board points not optimised (the
@@ -378,8 +379,8 @@ void launch_linearize(mcba_handle_s* h, const double* dx) {
     eval_pose_tables(h, dx);
     dx = nullptr;
   }
-  const int nb_prep = dx ? (d.n_pose + d.C + d.B * d.P + 63) / 64 : 0;
-  hipLaunchKernelGGL(k_tmat, dim3(nb_views + nb_prep), dim3(64), 0, h->stream, d, h->t, h->gbuf.p, 2 * d.n + 2, h->Hss.p,
+  const int nb_prep = dx ? (d.n_pose + d.C + d.B * d.P + TM_THREADS - 1) / TM_THREADS : 0;
+  hipLaunchKernelGGL(k_tmat, dim3(nb_views + nb_prep), dim3(TM_THREADS), 0, h->stream, d, h->t, h->gbuf.p, 2 * d.n + 2, h->Hss.p,
                      d.ns * d.ns, dx, nb_views);
   h->ops->linearize(d, h->t, h->stream, h->rec.p, h->tri.p, h->use_mfma, h->lin_grid, nullptr, nullptr, 0, nullptr, 0);
 }
@@ -388,8 +389,20 @@ void launch_assemble(mcba_handle_s* h) {
   const Dims& d = h->d;
   // ([g | diag | cost] and H_ss were zeroed by k_tmat at the start of this linearisation)
   const int nfb = (d.DF > 0) ? d.Fl : 0;
-  hipLaunchKernelGGL(k_assemble, dim3(nfb + d.C * d.B * h->nchunk), dim3(256), 0, h->stream, d, h->t, h->rec.p, nfb,
-                     h->nchunk, h->Hff.p, h->Hfs.p, h->g(), h->diag(), h->partial.p);
+  // frame blocks stage the record entries they sum in LDS, `gviews` records at a time (all C B views of the frame when they
+  // fit the budget: 43.8 KB at the north-star rig)
+  static const int stage_kb = getenv("MCBA_ASM_STAGE_KB") ? std::max(4, atoi(getenv("MCBA_ASM_STAGE_KB"))) : 44;
+  const int ne = frame_entries(d), cb = d.C * d.B;
+  const int ngroups = nfb ? (cb * ne * 8 + stage_kb * 1024 - 1) / (stage_kb * 1024) : 1;
+  const int gviews = (cb + ngroups - 1) / ngroups;
+  const size_t lds = nfb ? (size_t)gviews * ne * sizeof(double) + (size_t)ne * sizeof(int) : 0;
+  int nshared = d.C * d.B * h->nchunk, nfl = nfb;
+  if (const char* e = getenv("MCBA_EXP_ASM_PART")) {   // timing experiment only (wrong results): 1 = frame blocks, 2 = chunk sums
+    if (e[0] == '1') nshared = 0;
+    if (e[0] == '2') nfl = 0;
+  }
+  hipLaunchKernelGGL(k_assemble, dim3(nfl + nshared), dim3(ASM_THREADS), lds, h->stream, d, h->t, h->rec.p, nfl, h->nchunk, gviews,
+                     h->ftab.p, h->nftab, h->Hff.p, h->Hfs.p, h->g(), h->diag(), h->partial.p);
   {
     const int npair = d.C * d.B, pg = std::min(npair, 16);
     REQUIRE((size_t)npair * 64 * sizeof(double) <= 64 * 1024, "too many (camera, board) pairs for the shared assembly");
@@ -788,6 +801,11 @@ int32_t mcba_create(const mcba_problem* p, void* hip_stream, mcba_handle* out) {
   h->fix_aspect.upload(hp.fix_aspect);
   h->bwg.upload(hp.bwg);
   h->tri.upload(hp.tri);
+  {
+    const std::vector<int4> ft = frame_table(h->d);
+    h->ftab.upload(ft);
+    h->nftab = (int)ft.size();
+  }
   h->board_points.alloc((size_t)d.B * d.P * 3);
   h->pose.alloc((size_t)d.n_pose * POSE_STRIDE);
   h->cam.alloc((size_t)d.C * CAM_STRIDE);
@@ -807,7 +825,7 @@ int32_t mcba_create(const mcba_problem* p, void* hip_stream, mcba_handle* out) {
   // partial records per entry, so many pairs get fewer chunks
   {
     const char* e = getenv("MCBA_NCHUNK_TARGET");   // tuning knob: (pair, chunk) workgroups aimed at
-    const int target = e ? std::max(1, atoi(e)) : 512;   // measured at cfg3: 256 -> 114.4 us / step, 512 -> 113.1, 1024 -> 119.3
+    const int target = e ? std::max(1, atoi(e)) : 256;   // measured at cfg3: 256 -> 114.4 us / step, 512 -> 113.1, 1024 -> 119.3
     h->nchunk = std::max(1, std::min(std::min(64, (d.Fl + 7) / 8), std::max(4, target / std::max(1, d.C * d.B))));
   }
   h->partial.alloc((size_t)d.C * d.B * h->nchunk * d.rec_stride);
@@ -1209,7 +1227,7 @@ int32_t mcba_debug_gn_step(mcba_handle h, double reg, double* gn_h, double* g_h,
 int32_t mcba_debug_linearize_profile(mcba_handle h, const double* x, long long* out) {
   API_BEGIN
   REQUIRE(h && x && out, "null argument");
-  const size_t n = (size_t)h->d.views() * 8;
+  const size_t n = ((size_t)h->d.views() + (h->d.views() + TMV - 1) / TMV) * 8;   // (+ one row per k_tmat workgroup)
   h->dbg.alloc(n, true);
   h->t.dbg = h->dbg.p;
   upload_x(h, x, h->x.p);
@@ -1268,6 +1286,19 @@ int32_t mcba_debug_mfma_probe(const double* V, double* out) {
   dout.alloc(256);
   hipLaunchKernelGGL(k_mfma_probe, dim3(1), dim3(64), 0, 0, dv.p, dout.p);
   HIP_OK(hipMemcpy(out, dout.p, 256 * sizeof(double), hipMemcpyDeviceToHost));
+  API_END
+}
+
+// debug: workgroup dispatch rate (k_dispatch_probe): out[blocks][2] = 100 MHz wall-clock ticks at start / end of a workgroup
+int32_t mcba_debug_dispatch_probe(int32_t blocks, int32_t threads, int32_t lds_bytes, int32_t spin, long long* out) {
+  API_BEGIN
+  REQUIRE(out && blocks > 0 && threads > 0 && threads <= 1024 && lds_bytes >= 0 && lds_bytes <= 64 * 1024, "bad argument");
+  DevBuf<long long> buf;
+  buf.alloc((size_t)blocks * 2);
+  for (int rep = 0; rep < 3; ++rep)   // (the last launch is the one reported: code and buffers warm)
+    hipLaunchKernelGGL(k_dispatch_probe, dim3(blocks), dim3(threads), (size_t)lds_bytes, 0, spin, buf.p);
+  HIP_OK(hipDeviceSynchronize());
+  HIP_OK(hipMemcpy(out, buf.p, (size_t)blocks * 2 * sizeof(long long), hipMemcpyDeviceToHost));
   API_END
 }
 

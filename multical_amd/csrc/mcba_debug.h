@@ -14,11 +14,15 @@ int32_t mcba_set_mfma(mcba_handle h, int32_t on);
 int32_t mcba_debug_set_lin_grid(mcba_handle h, int32_t grid);
 /* FP64 VALU vs FP64 MFMA pipe-sharing probe: ms_out[3] = all-FMA, all-MFMA, half / half        */
 int32_t mcba_debug_pipe_probe(int32_t iters, double* ms_out);
+/* workgroup dispatch rate: launches `blocks` workgroups of `threads` threads with `lds_bytes` of LDS, each running `spin`
+ * dependent FMAs; out[blocks][2] = 100 MHz wall-clock ticks at the start / end of every workgroup                   */
+int32_t mcba_debug_dispatch_probe(int32_t blocks, int32_t threads, int32_t lds_bytes, int32_t spin, long long* out);
 /* regularised Gauss-Newton direction (H_h + reg I)^-1 g_h in the column-scaled space, computed by the Schur /
  * Cholesky kernels after a preceding mcba_normal_equations at the same x; g_h and scale_inv may be NULL.           */
 int32_t mcba_debug_gn_step(mcba_handle h, double reg, double* gn_h, double* g_h, double* scale_inv);
 /* per-view s_memtime stamps of the k_linearize phases: out[views][8] = {setup, rows, stage+mfma, epilogue, count,
- * start, end, 0} in shader cycles (profiling aid for DESIGN.md section 5)                                             */
+ * start, end, 0} in shader cycles (profiling aid for DESIGN.md section 5), followed by ceil(views / 8) rows of k_tmat
+ * workgroup stamps (zero unless the library was built with -DMCBA_EXP_TMAT_PROF)                                      */
 int32_t mcba_debug_linearize_profile(mcba_handle h, const double* x, long long* out);
 /* (S + reg I) p = rhs with the device Cholesky kernels; blocked != 0 forces the multi-workgroup path              */
 int32_t mcba_debug_chol(mcba_handle h, int32_t ns, const double* S, const double* rhs, double reg, int32_t blocked,

@@ -155,7 +155,9 @@ MCBA_HD void camera_entry(const double* p, int n_dist, double image_height, bool
   e[CAM_CX] = p[2];
   e[CAM_CY] = p[3];
   e[CAM_SKEW] = p[4];                        // carried, never read by either OpenCV projection
-  for (int i = 0; i < n_dist; ++i) e[CAM_K + i] = p[5 + i];
+#pragma unroll
+  for (int i = 0; i < MAX_DIST; ++i)           // (fixed trip count: p and e stay in registers, no scratch)
+    if (i < n_dist) e[CAM_K + i] = p[5 + i];
   if (n_dist == 14) {
     tilt_matrices(p[5 + 12], p[5 + 13], e + CAM_TILT, e + CAM_DTX, e + CAM_DTY);
   } else {

@@ -2,6 +2,8 @@
 // per-view records into the block normal equations, and the damped normal-equation solve of the trust-region
 // driver (Schur elimination of the per-frame blocks, dense Cholesky, vector updates).  Included only by mcba_api.hip.
 #pragma once
+#include <vector>
+#include <utility>
 #include "mcba_kernels.h"
 #include "mcba_trmath.h"
 
@@ -23,32 +25,38 @@ __global__ void k_views(Dims d, Tables t) {
   view_item(d, t, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
-// That of every non-empty view: tmat[v][a][j], a < DE, j < 6 NPB.  One thread per (view, pose block): the chain prefix
-// of the block is computed once and shared by its six columns (a thread per column re-read the three pose entries and
-// redid the chain 24 times per view); the columns of TMV views are transposed through LDS so that the table is written
-// with coalesced stores (writing 48-byte pieces straight from the (view, block) threads was 2x slower than the
-// thread-per-column kernel).  The kernel opens every linearisation, so it also zeroes the two accumulation targets of
-// the assembly that follows ([g | diag | cost] and H_ss) -- two fill launches less.
+// That of every non-empty view: tmat[v][a][j], a < DE, j < 6 NPB.  A workgroup owns TMV consecutive views and gives each
+// 32 lanes: lane j < 6 NPB evaluates column j with the lane-uniform construction the fused k_linearize uses
+// (fused_view_tables: the chain products are formed by every lane, the pose block of the lane is picked with selects --
+// the earlier thread-per-(view, pose block) form ran its four block cases one after the other on one wavefront: 12.9 k of
+// the workgroup's 26 k cycles, measured with s_memtime stamps), lanes 6 NPB and 6 NPB + 1 the chain matrices of the view
+// table.  The columns go through LDS so that the table is written with coalesced stores.  The kernel opens every
+// linearisation, so it also zeroes the two accumulation targets of the assembly that follows ([g | diag | cost] and H_ss).
 //
 // x != nullptr: the kernel ALSO replaces k_prep.  Every workgroup forms the pose entries its views need (all cameras,
 // all boards, the frames it touches) in LDS straight from x -- a handful of Rodrigues evaluations instead of a kernel
 // boundary and a dependent read of the pose table -- and the blocks behind the view blocks (blockIdx >= nb_views) write
 // the global pose / camera / board-point tables for the kernels that follow (k_linearize reads the camera and board-point
 // tables, k_cost / k_points the pose table).  TM_LOCAL_POSES bounds the local table (the host checks the shape).
-constexpr int TMV = 16;              // views per workgroup
+constexpr int TMV = 8;               // views per workgroup
+constexpr int TM_THREADS = 32 * TMV;
 constexpr int TM_LOCAL_POSES = 64;   // pose entries of the workgroup-local table
 __host__ __device__ inline int tmat_local_poses(const Dims& d) {   // upper bound of the entries one workgroup needs
   const int CB = d.C * d.B;
   const int nfl = (TMV - 1) / (CB > 0 ? CB : 1) + 2;
   return d.C + d.B + (d.motion == MOTION_HAND_EYE ? 2 : (d.motion == MOTION_ROLLING ? 2 : 1) * nfl);
 }
-__global__ __launch_bounds__(64) void k_tmat(Dims d, Tables t, double* __restrict__ zero_a, int na,
-                                             double* __restrict__ zero_b, int nb, const double* __restrict__ x,
-                                             int nb_views) {
+__global__ __launch_bounds__(TM_THREADS, 4) void k_tmat(Dims d, Tables t, double* __restrict__ zero_a, int na,
+                                                     double* __restrict__ zero_b, int nb, const double* __restrict__ x,
+                                                     int nb_views) {
   __shared__ double tile[TMV * 12 * 24];
   __shared__ double lpose[TM_LOCAL_POSES * POSE_STRIDE];
   const int NPB = d.NPB, npc = 6 * NPB, DE = d.DE, vsz = DE * npc;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+#if defined(MCBA_EXP_TMAT_PROF)
+  long long st[6] = {0, 0, 0, 0, 0, 0};
+  st[0] = clock64();
+#endif
   for (int e = i; e < na; e += gridDim.x * blockDim.x) zero_a[e] = 0.0;
   for (int e = i; e < nb; e += gridDim.x * blockDim.x) zero_b[e] = 0.0;
   if ((int)blockIdx.x >= nb_views) {   // table blocks (only launched with x): the body of k_prep
@@ -57,6 +65,8 @@ __global__ __launch_bounds__(64) void k_tmat(Dims d, Tables t, double* __restric
   }
   const int v0 = blockIdx.x * TMV, nv = min(TMV, d.views() - v0);
   if (nv <= 0) return;
+  const int vl = threadIdx.x >> 5, j = threadIdx.x & 31, v = v0 + vl;
+  const bool live = vl < nv && t.view_count[v] != 0;   // (the flag load overlaps the pose entries)
   PoseSrc ps = global_pose_src(d, t);
   if (x != nullptr) {
     const int CB = d.C * d.B, nch = d.motion == MOTION_ROLLING ? 2 : 1;
@@ -83,17 +93,23 @@ __global__ __launch_bounds__(64) void k_tmat(Dims d, Tables t, double* __restric
     ps.chain = nfl;
     ps.f0 = f_lo;
   }
-  const int vl = threadIdx.x / NPB, k = threadIdx.x % NPB, v = v0 + vl;
-  if (vl < nv && t.view_count[v] != 0) {
+#if defined(MCBA_EXP_TMAT_PROF)
+  st[1] = clock64();
+#endif
+  if (live) {
     const int b = v % d.B, c = (v / d.B) % d.C, fl = v / (d.B * d.C), f = d.f0 + fl;
-    view_block_columns(d, ps, t.bwg, f, c, b, k, tile + vl * vsz + 6 * k, npc);
-    if (k == NPB - 1) {   // the view table too: the trial step that led here only ran k_prep (k_cost forms its own chains)
-      const int nch = d.motion == MOTION_ROLLING ? 2 : 1;
-      for (int ch = 0; ch < nch; ++ch)
-        view_chain(d, ps, t.bwg, f, c, b, ch, t.view + (size_t)v * d.view_stride() + ch * VIEW_STRIDE);
+    const int nch = d.motion == MOTION_ROLLING ? 2 : 1;
+    if (j < npc) {
+      view_that_column(d, ps, t.bwg, f, c, b, j, tile + vl * vsz, npc);
+    } else if (j < npc + nch) {   // the view table too: the trial step that led here only ran k_prep (k_cost forms its own chains)
+      const int ch = j - npc;
+      view_chain(d, ps, t.bwg, f, c, b, ch, t.view + (size_t)v * d.view_stride() + ch * VIEW_STRIDE);
     }
   }
   __syncthreads();
+#if defined(MCBA_EXP_TMAT_PROF)
+  st[2] = clock64();
+#endif
   // views of a workgroup are contiguous: coalesced stores; empty views (45 % of the north-star rig) are skipped -- nobody
   // reads their That, and the table is the largest thing this kernel writes (18 MB for all views)
   double* tg = t.tmat + (size_t)v0 * vsz;
@@ -101,130 +117,221 @@ __global__ __launch_bounds__(64) void k_tmat(Dims d, Tables t, double* __restric
     if (t.view_count[v0 + vv] == 0) continue;
     for (int e = threadIdx.x; e < vsz; e += blockDim.x) tg[vv * vsz + e] = tile[vv * vsz + e];
   }
+#if defined(MCBA_EXP_TMAT_PROF)
+  st[3] = clock64();
+  if (t.dbg != nullptr && threadIdx.x == 0) {
+    long long* o = t.dbg + ((size_t)d.views() + blockIdx.x) * 8;
+    o[0] = st[0]; o[1] = st[1]; o[2] = st[2]; o[3] = st[3];
+    o[4] = wall_clock64();
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // assembly of the records (deterministic gathers; no atomics)
 // ---------------------------------------------------------------------------------------------------------------
 // per-frame blocks: H_ff [Fl][DF][DF], H_fs [Fl][DF][ns], g / diag entries of the frame's parameters.
-__device__ __forceinline__ void assemble_frame_block(const Dims& d, const Tables& t, int fl,
+//
+// Every sum runs over records of the frame's C B views.  Gathering them entry by entry from memory made each output
+// element a chain of dependent round trips, and working out which entry goes where (local_to_x, the packed-triangle
+// index, a dozen integer divisions per element) cost more ALU time than the sums.  Both are gone:
+//   * the entries a frame block needs from a record are two short ranges of the packed triangle,
+//       part 1   (l, 6 + dd), l < 6 (camera pose x frame):  6 runs of DF entries
+//       part 2   rows 6 .. 6 + DF - 1 in full (frame x frame | later pose blocks | intrinsics | residual): ONE contiguous run
+//     the workgroup copies those NE entries of `gviews` records at a time into LDS -- independent loads, eleven in flight
+//     per thread, nothing read for an empty view (45 % of the rig's views);
+//   * what to sum and where it goes is a table built once by mcba_create (frame_table below): per output element the
+//     staged entry k, the arithmetic sequence of views (first, stride, count) and the destination.  The same table serves
+//     every frame (the frame only shifts the destinations of its own parameters).
+MCBA_HD int frame_entries(const Dims& d) {   // NE: entries of one record a frame block reads
+  return 6 * d.DF + (tri_index(6 + d.DF, 6 + d.DF, d.N1) - tri_index(6, 6, d.N1));
+}
+enum { FT_HFS = 0, FT_HFF = 1, FT_GRAD = 2 };
+// element: x = staged entry k, y = first view | stride << 8 | count << 16, z = destination, w = kind | (dd + 1) << 8 for a
+// diagonal element of H_ff (whose value is also diag[x index of the frame parameter dd])
+inline std::vector<int4> frame_table(const Dims& d) {
+  std::vector<int4> tab;
+  if (d.DF == 0) return tab;
+  const int DF = d.DF, N1 = d.N1, NL = d.NL, ns = d.ns, CW = 6 + d.KI;
+  const int base2 = tri_index(6, 6, N1), P1 = 6 * DF;
+  auto kidx = [&](int a, int b) {
+    if (a > b) std::swap(a, b);
+    return a < 6 ? a * DF + (b - 6) : P1 + tri_index(a, b, N1) - base2;
+  };
+  for (int c = 0; c < d.C; ++c)            // frame x camera(c): sum over boards
+    for (int dd = 0; dd < DF; ++dd)
+      for (int q = 0; q < CW; ++q) {
+        const int li = q < 6 ? q : 6 * d.NPB + (q - 6);
+        const int gi = local_to_x(d, 0, c, 0, li);
+        if (gi < 0) continue;
+        tab.push_back(make_int4(kidx(li, 6 + dd), (c * d.B) | (1 << 8) | (d.B << 16), dd * ns + d.x_to_shared(gi), FT_HFS));
+      }
+  for (int b = 0; b < d.B; ++b)            // frame x board(b): sum over cameras
+    for (int dd = 0; dd < DF; ++dd)
+      for (int q = 0; q < 6; ++q) {
+        const int li = 6 * (d.NPB - 1) + q;
+        const int gi = local_to_x(d, 0, 0, b, li);
+        if (gi < 0) continue;
+        tab.push_back(make_int4(kidx(6 + dd, li), b | (d.B << 8) | (d.C << 16), dd * ns + d.x_to_shared(gi), FT_HFS));
+      }
+  for (int dd = 0; dd < DF; ++dd)          // frame x frame and the gradient: sum over all views
+    for (int d2 = 0; d2 <= DF; ++d2) {
+      const int y = 0 | (1 << 8) | ((d.C * d.B) << 16);
+      if (d2 < DF) tab.push_back(make_int4(kidx(6 + dd, 6 + d2), y, dd * DF + d2, FT_HFF | (d2 == dd ? (dd + 1) << 8 : 0)));
+      else tab.push_back(make_int4(kidx(6 + dd, NL), y, dd, FT_GRAD));
+    }
+  return tab;
+}
+
+__device__ __forceinline__ void assemble_frame_block(const Dims& d, const Tables& t, int fl, int gviews,
+                                                     const int4* __restrict__ tab, int ntab,
                                                      const double* __restrict__ rec, double* __restrict__ Hff,
                                                      double* __restrict__ Hfs, double* __restrict__ g,
-                                                     double* __restrict__ diag) {
-  // activity flags of the frame's C B views, read once into LDS: with `if (view_count[v] == 0) continue;` inside the sums
-  // every record load waited for its own flag load (two dependent memory round trips per view, 16 views in a row).  The
-  // record loads below stay unconditional, but the address of an EMPTY view's record is replaced by one hot address
-  // (element 0 of the frame's first record: a cache hit) and its value discarded: 45 % of the views of the north-star rig
-  // are empty, and their stale records were streamed from memory like the live ones.
-  __shared__ double act[128];   // C B <= 128 (checked by launch_assemble)
+                                                     double* __restrict__ diag, double* __restrict__ stage) {
+  __shared__ uint8_t act[128];   // C B <= 128 (checked by mcba_create)
   const int f = d.f0 + fl;
-  const int DF = d.DF, ns = d.ns, N1 = d.N1, NL = d.NL, CB = d.C * d.B;
+  const int DF = d.DF, ns = d.ns, N1 = d.N1, CB = d.C * d.B;
+  const int base2 = tri_index(6, 6, N1), NE = frame_entries(d), P1 = 6 * DF;
+  int* soff = reinterpret_cast<int*>(stage + (size_t)gviews * NE);   // record offset of staged entry k
   double* hfs = Hfs + (size_t)fl * DF * ns;
   double* hff = Hff + (size_t)fl * DF * DF;
-  for (int e = threadIdx.x; e < CB; e += blockDim.x) act[e] = t.view_count[fl * CB + e] != 0 ? 1.0 : 0.0;
+  for (int e = threadIdx.x; e < CB; e += blockDim.x) act[e] = t.view_count[fl * CB + e] != 0;
+  for (int k = threadIdx.x; k < NE; k += blockDim.x) soff[k] = k < P1 ? tri_index(k / DF, 6 + k % DF, N1) : base2 + (k - P1);
   for (int e = threadIdx.x; e < DF * ns; e += blockDim.x) hfs[e] = 0.0;
-  __syncthreads();
   const double* rf = rec + (size_t)fl * CB * d.rec_stride;   // records of this frame: view (c, b) at (c B + b) rec_stride
-  const int CW = 6 + d.KI;   // camera pose + intrinsics columns
-  // frame x camera(c) blocks: sum over boards
-  for (int e = threadIdx.x; e < d.C * DF * CW; e += blockDim.x) {
-    const int c = e / (DF * CW), dd = (e / CW) % DF, q = e % CW;
-    const int li = q < 6 ? q : 6 * d.NPB + (q - 6);          // local index of the camera-side column
-    const int gi = local_to_x(d, f, c, 0, li);
-    if (gi < 0) continue;
-    const int lf = 6 + dd;
-    const int off = li < lf ? tri_index(li, lf, N1) : tri_index(lf, li, N1);
-    double sum = 0.0;
-    for (int b = 0; b < d.B; ++b) {
-      const bool on = act[c * d.B + b] != 0.0;
-      const double val = rf[on ? (size_t)(c * d.B + b) * d.rec_stride + off : 0];   // (empty view: one hot address, see above)
-      sum += on ? val : 0.0;
-    }
-    hfs[dd * ns + d.x_to_shared(gi)] = sum;
+  const float inv_ne = 1.0f / (float)NE;
+  constexpr int LB = 11, TB = 7;   // loads / table elements in flight per thread
+  int4 q0[TB];                     // first batch of table elements: in flight together with the activity flags
+#pragma unroll
+  for (int u = 0; u < TB; ++u) {
+    const int e = threadIdx.x + u * blockDim.x;
+    q0[u] = e < ntab ? tab[e] : make_int4(0, 0, 0, -1);
   }
-  // frame x board(b) blocks: sum over cameras
-  for (int e = threadIdx.x; e < d.B * DF * 6; e += blockDim.x) {
-    const int b = e / (DF * 6), dd = (e / 6) % DF, q = e % 6;
-    const int li = 6 * (d.NPB - 1) + q;
-    const int gi = local_to_x(d, f, 0, b, li);
-    if (gi < 0) continue;
-    const int off = tri_index(6 + dd, li, N1);
-    double s0 = 0.0, s1 = 0.0;
-    int c = 0;
-    for (; c + 2 <= d.C; c += 2) {
-      const bool on0 = act[c * d.B + b] != 0.0, on1 = act[(c + 1) * d.B + b] != 0.0;
-      const double v0 = rf[on0 ? (size_t)(c * d.B + b) * d.rec_stride + off : 0];
-      const double v1 = rf[on1 ? (size_t)((c + 1) * d.B + b) * d.rec_stride + off : 0];
-      s0 += on0 ? v0 : 0.0;
-      s1 += on1 ? v1 : 0.0;
+  for (int g0 = 0; g0 < CB; g0 += gviews) {   // (one group at the north-star rig; more only when C B NE exceeds the LDS budget)
+    const int ng = min(gviews, CB - g0), tot = ng * NE;
+    __syncthreads();   // (act, soff, the zeroes of H_fs written; previous group consumed)
+    for (int i0 = threadIdx.x; i0 < tot; i0 += LB * blockDim.x) {
+      double val[LB];
+#pragma unroll
+      for (int u = 0; u < LB; ++u) {
+        const int idx = i0 + u * blockDim.x;
+        val[u] = 0.0;
+        if (idx < tot) {
+          int gv = (int)((float)idx * inv_ne), k = idx - gv * NE;   // idx = gv NE + k (float quotient, corrected)
+          if (k < 0) { --gv; k += NE; } else if (k >= NE) { ++gv; k -= NE; }
+          if (act[g0 + gv]) val[u] = rf[(size_t)(g0 + gv) * d.rec_stride + soff[k]];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < LB; ++u) {
+        const int idx = i0 + u * blockDim.x;
+        if (idx < tot) stage[idx] = val[u];
+      }
     }
-    for (; c < d.C; ++c) {
-      const bool on0 = act[c * d.B + b] != 0.0;
-      const double v0 = rf[on0 ? (size_t)(c * d.B + b) * d.rec_stride + off : 0];
-      s0 += on0 ? v0 : 0.0;
-    }
-    hfs[dd * ns + d.x_to_shared(gi)] = s0 + s1;
-  }
-  // frame x frame and gradient
-  for (int e = threadIdx.x; e < DF * (DF + 1); e += blockDim.x) {
-    const int dd = e / (DF + 1), d2 = e % (DF + 1);
-    const int la = 6 + dd, lb = d2 < DF ? 6 + d2 : NL;
-    const int off = la <= lb ? tri_index(la, lb, N1) : tri_index(lb, la, N1);
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int cb = 0;
-    for (; cb + 4 <= CB; cb += 4) {      // four independent loads in flight, fixed summation order
-      const bool o0 = act[cb] != 0.0, o1 = act[cb + 1] != 0.0, o2 = act[cb + 2] != 0.0, o3 = act[cb + 3] != 0.0;
-      const double v0 = rf[o0 ? (size_t)cb * d.rec_stride + off : 0];
-      const double v1 = rf[o1 ? (size_t)(cb + 1) * d.rec_stride + off : 0];
-      const double v2 = rf[o2 ? (size_t)(cb + 2) * d.rec_stride + off : 0];
-      const double v3 = rf[o3 ? (size_t)(cb + 3) * d.rec_stride + off : 0];
-      s0 += o0 ? v0 : 0.0;
-      s1 += o1 ? v1 : 0.0;
-      s2 += o2 ? v2 : 0.0;
-      s3 += o3 ? v3 : 0.0;
-    }
-    for (; cb < CB; ++cb) {
-      const bool o0 = act[cb] != 0.0;
-      const double v0 = rf[o0 ? (size_t)cb * d.rec_stride + off : 0];
-      s0 += o0 ? v0 : 0.0;
-    }
-    const double sum = (s0 + s1) + (s2 + s3);
-    if (d2 < DF) {
-      hff[dd * DF + d2] = sum;
-      if (d2 == dd) diag[d.frame_to_x(f, dd)] = sum;
-    } else {
-      g[d.frame_to_x(f, dd)] = sum;
+    __syncthreads();
+    // every output element belongs to one thread for all groups: later groups add to what the thread stored before
+    for (int e0 = threadIdx.x; e0 < ntab; e0 += TB * blockDim.x) {
+      int4 q[TB];
+#pragma unroll
+      for (int u = 0; u < TB; ++u) {
+        const int e = e0 + u * blockDim.x;
+        q[u] = e0 == (int)threadIdx.x ? q0[u] : (e < ntab ? tab[e] : make_int4(0, 0, 0, -1));
+      }
+#pragma unroll
+      for (int u = 0; u < TB; ++u) {
+        if (q[u].w < 0) continue;
+        const int k = q[u].x, gv0 = (q[u].y & 255) - g0, gst = (q[u].y >> 8) & 255, cnt = q[u].y >> 16;
+        double s0 = 0.0, s1 = 0.0;
+        int i = 0;
+        for (; i + 2 <= cnt; i += 2) {
+          const int ga = gv0 + i * gst, gb = ga + gst;
+          if (ga >= 0 && ga < ng) s0 += stage[ga * NE + k];
+          if (gb >= 0 && gb < ng) s1 += stage[gb * NE + k];
+        }
+        if (i < cnt) {
+          const int ga = gv0 + i * gst;
+          if (ga >= 0 && ga < ng) s0 += stage[ga * NE + k];
+        }
+        double sum = s0 + s1;
+        const int kind = q[u].w & 255;
+        double* dst = kind == FT_HFS ? hfs + q[u].z : (kind == FT_HFF ? hff + q[u].z : g + d.frame_to_x(f, q[u].z));
+        if (g0 > 0) sum += *dst;
+        *dst = sum;
+        if ((q[u].w >> 8) != 0) diag[d.frame_to_x(f, (q[u].w >> 8) - 1)] = sum;
+      }
     }
   }
 }
 
-// shared part, stage 1: partial[pair=(c,b)][chunk][rec_stride] = sum of the records over a chunk of frames
+// shared part, stage 1: partial[pair=(c,b)][chunk][rec_stride] = sum of the records over a chunk of frames.  The first
+// wavefront compacts the chunk's non-empty views (records of empty views are never written); every thread then owns up to
+// two entries of the record and keeps the loads of eight views in flight for each.
 __device__ __forceinline__ void shared_partial_block(const Dims& d, const Tables& t, int pair, int ch,
                                                      const double* __restrict__ rec, int nchunk,
                                                      double* __restrict__ partial) {
-  __shared__ int vsel[64];   // record to read for every frame of the chunk: the view itself, or -1 = empty view
+  __shared__ int vsel[64];
+  __shared__ int nsel;
   const int c = pair / d.B, b = pair % d.B;
   const int per = (d.Fl + nchunk - 1) / nchunk;
   const int fa = ch * per, fb = min(d.Fl, fa + per);
-  double* out = partial + ((size_t)pair * nchunk + ch) * d.rec_stride;
+  const int rs = d.rec_stride, nt = blockDim.x;
+  double* out = partial + ((size_t)pair * nchunk + ch) * rs;
+  if (fa >= fb) {   // (more chunks than frames)
+    for (int e = threadIdx.x; e < rs; e += nt) out[e] = 0.0;
+    return;
+  }
   for (int f0 = fa; f0 < fb; f0 += 64) {        // (chunks hold at most a few dozen frames: one pass)
     const int nf = min(64, fb - f0);
     __syncthreads();
-    if ((int)threadIdx.x < nf) {
+    if (threadIdx.x < 64) {
       const int v = ((f0 + (int)threadIdx.x) * d.C + c) * d.B + b;
-      vsel[threadIdx.x] = t.view_count[v] != 0 ? v : -1;
+      const bool on = (int)threadIdx.x < nf && t.view_count[v] != 0;
+      const unsigned long long m = __ballot(on);
+      if (on) vsel[__popcll(m & ((1ull << threadIdx.x) - 1ull))] = v;
+      if (threadIdx.x == 0) nsel = __popcll(m);
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < d.rec_stride; e += blockDim.x) {
-      double sum = f0 == fa ? 0.0 : out[e];
-#pragma unroll 4
-      for (int k = 0; k < nf; ++k) {
-        // records of empty views are never written: their loads go to one hot address and the value is dropped
-        const int v = vsel[k];
-        const double val = rec[v >= 0 ? (size_t)v * d.rec_stride + e : 0];
-        sum += v >= 0 ? val : 0.0;
+    const int n = nsel;
+    for (int e0 = threadIdx.x; e0 < rs; e0 += 2 * nt) {
+      const int e1 = e0 + nt;
+      const bool h1 = e1 < rs;
+      double s0 = 0.0, s1 = 0.0;
+      if (f0 != fa) {
+        s0 = out[e0];
+        if (h1) s1 = out[e1];
       }
-      out[e] = sum;
+      int k = 0;
+      for (; k + 8 <= n; k += 8) {
+        double a0[8], a1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const double* r = rec + (size_t)vsel[k + u] * rs;
+          a0[u] = r[e0];
+          a1[u] = h1 ? r[e1] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          s0 += a0[u];
+          s1 += a1[u];
+        }
+      }
+      if (k < n) {   // remainder: up to seven views, loads still issued together
+        double a0[7], a1[7];
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+          const bool on = k + u < n;
+          const double* r = rec + (size_t)vsel[on ? k + u : k] * rs;
+          a0[u] = on ? r[e0] : 0.0;
+          a1[u] = on && h1 ? r[e1] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+          s0 += a0[u];
+          s1 += a1[u];
+        }
+      }
+      out[e0] = s0;
+      if (h1) out[e1] = s1;
     }
   }
 }
@@ -232,12 +339,15 @@ __device__ __forceinline__ void shared_partial_block(const Dims& d, const Tables
 // ONE launch for both gathers (they are independent and each is too small to fill the chip):
 //   blocks [0, nfb)                 frame blocks (nfb = Fl when per-frame parameters are eliminated, else 0)
 //   blocks [nfb, nfb + C B nchunk)  chunk sums of the shared part
-__global__ __launch_bounds__(256) void k_assemble(Dims d, Tables t, const double* __restrict__ rec, int nfb, int nchunk,
+constexpr int ASM_THREADS = 512;
+__global__ __launch_bounds__(ASM_THREADS) void k_assemble(Dims d, Tables t, const double* __restrict__ rec, int nfb, int nchunk,
+                                                  int gviews, const int4* __restrict__ ftab, int nftab,
                                                   double* __restrict__ Hff, double* __restrict__ Hfs,
                                                   double* __restrict__ g, double* __restrict__ diag,
                                                   double* __restrict__ partial) {
+  extern __shared__ double asm_stage[];   // [gviews][NE] staged record entries of a frame block + [NE] record offsets
   if ((int)blockIdx.x < nfb) {
-    assemble_frame_block(d, t, blockIdx.x, rec, Hff, Hfs, g, diag);
+    assemble_frame_block(d, t, blockIdx.x, gviews, ftab, nftab, rec, Hff, Hfs, g, diag, asm_stage);
   } else {
     const int q = blockIdx.x - nfb;
     shared_partial_block(d, t, q / nchunk, q % nchunk, rec, nchunk, partial);
@@ -260,16 +370,21 @@ __global__ __launch_bounds__(1024) void k_shared_final(Dims d, const double* __r
   const int e = blockIdx.x * 64 + el;
   const bool in = e < d.rec_size + 2;
   const size_t rs = d.rec_stride;
+  const int ij = e < d.rec_size ? tri[e] : 0;   // (issued with the chunk sums, used after them)
   for (int pair = pg; pair < npair; pair += PG) {
-    double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double a[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) a[u] = 0.0;
     if (in) {
       const double* base = partial + (size_t)pair * nchunk * rs + e;
       int ch = 0;
-      for (; ch + 8 <= nchunk; ch += 8)
+      for (; ch + 16 <= nchunk; ch += 16)
 #pragma unroll
-        for (int u = 0; u < 8; ++u) a[u] += base[(size_t)(ch + u) * rs];
-      for (; ch < nchunk; ++ch) a[0] += base[(size_t)ch * rs];
+        for (int u = 0; u < 16; ++u) a[u] += base[(size_t)(ch + u) * rs];
+      for (; ch < nchunk; ++ch) a[ch & 15] += base[(size_t)ch * rs];
     }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] += a[u + 8];
     pair_sum[pair * 64 + el] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   }
   __syncthreads();
@@ -277,7 +392,6 @@ __global__ __launch_bounds__(1024) void k_shared_final(Dims d, const double* __r
   bool depc = false, depb = false;
   int i = 0, j = 0;
   if (e < d.rec_size) {
-    const int ij = tri[e];
     i = ij >> 8;
     j = ij & 255;
     if (i == NL) return;                                   // (r, r) = sum f^2: the cost is carried separately
@@ -1882,6 +1996,19 @@ __global__ void k_mfma_probe(const double* __restrict__ V /*[4][32]*/, double* _
 // rounds of 4 independent MFMA f64 16x16x4 (4 x 64 cycles); mode 2: waves 0-3 (one per SIMD) do the FMA loop, waves 4-7 the
 // MFMA loop.  If the two kinds of work shared nothing, mode 2 would take as long as one wave alone per SIMD (half of
 // modes 0 / 1); if FP64 MFMA and FP64 VALU share the pipe, mode 2 takes the sum.
+// workgroup dispatch probe: every workgroup records the 100 MHz wall clock when it starts and after `spin` dependent FMAs
+__global__ void k_dispatch_probe(int spin, long long* __restrict__ out) {
+  extern __shared__ double probe_lds[];
+  const long long t0 = wall_clock64();
+  double a = (double)threadIdx.x;
+  for (int i = 0; i < spin; ++i) a = a * 1.0000001 + 1e-9;
+  if (a == 12345.678) probe_lds[threadIdx.x] = a;   // (keeps the loop and the LDS allocation alive)
+  if (threadIdx.x == 0) {
+    out[2 * blockIdx.x] = t0;
+    out[2 * blockIdx.x + 1] = wall_clock64();
+  }
+}
+
 __global__ __launch_bounds__(512) void k_pipe_probe(int mode, int iters, double* __restrict__ sink) {
   const int wave = threadIdx.x >> 6;
   const bool do_mfma = mode == 1 || (mode == 2 && wave >= 4);

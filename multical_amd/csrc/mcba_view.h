@@ -152,9 +152,9 @@ MCBA_HD void view_column(const Dims& d, const Tables& t, int f, int c, int b, in
 // stream, no divergence), then lane j < 6 NPB picks the prefix rotation / left Jacobian / origin of ITS pose block with
 // selects and evaluates one column (view_pose_column written branch-free).  Equivalent to view_column_p, whose four block
 // cases a wavefront had to execute one after the other.  Tm[a * NPC + j] receives column j, Vm the chain matrices.
-template <bool ROLL>
+template <bool ROLL, bool CHAINS = true>
 MCBA_HD void fused_view_tables(const double* Pc, const double* Pm0, const double* Pm1, const double* Pb, int j,
-                               double* Tm, double* Vm) {
+                               double* Tm, double* Vm, int stride = ROLL ? 24 : 18) {
   constexpr int NCH = ROLL ? 2 : 1, NPB = ROLL ? 4 : 3, NPC = 6 * NPB;
   const double* Rc = Pc + POSE_R;
   const double* tc = Pc + POSE_T;
@@ -173,9 +173,11 @@ MCBA_HD void fused_view_tables(const double* Pc, const double* Pm0, const double
     mat3_vec(R1, tb, v3);
     for (int i = 0; i < 3; ++i) o[i] = t1[i] + v3[i];             // origin of camera . frame . board
     mat3_mul(R1, Rb, R2);
-    if (j == NPC + ch) {                                          // the chain matrix board -> camera of this chain
-      for (int i = 0; i < 9; ++i) Vm[ch * VIEW_STRIDE + i] = R2[i];
-      for (int i = 0; i < 3; ++i) Vm[ch * VIEW_STRIDE + 9 + i] = o[i];
+    if constexpr (CHAINS) {
+      if (j == NPC + ch) {                                        // the chain matrix board -> camera of this chain
+        for (int i = 0; i < 9; ++i) Vm[ch * VIEW_STRIDE + i] = R2[i];
+        for (int i = 0; i < 3; ++i) Vm[ch * VIEW_STRIDE + 9 + i] = o[i];
+      }
     }
     // pose block of this lane: 0 camera (identity prefix), NPB - 1 board (prefix camera . frame), between: the frame pose
     // of chain `ch` (prefix camera); rolling shutter: block 1 touches chain 0 only, block 2 chain 1 only
@@ -200,13 +202,13 @@ MCBA_HD void fused_view_tables(const double* Pc, const double* Pm0, const double
     const double c0 = ov[1] * tv[2] - ov[2] * tv[1], c1 = ov[2] * tv[0] - ov[0] * tv[2], c2 = ov[0] * tv[1] - ov[1] * tv[0];
     const double w = active ? 1.0 : 0.0;
     if (j < NPC) {
-      double* col = Tm + (size_t)(6 * ch) * NPC + j;
-      col[0 * NPC] = rotcol ? w * tv[0] : 0.0;
-      col[1 * NPC] = rotcol ? w * tv[1] : 0.0;
-      col[2 * NPC] = rotcol ? w * tv[2] : 0.0;
-      col[3 * NPC] = w * (rotcol ? c0 : tv[0]);
-      col[4 * NPC] = w * (rotcol ? c1 : tv[1]);
-      col[5 * NPC] = w * (rotcol ? c2 : tv[2]);
+      double* col = Tm + (size_t)(6 * ch) * stride + j;
+      col[0 * stride] = rotcol ? w * tv[0] : 0.0;
+      col[1 * stride] = rotcol ? w * tv[1] : 0.0;
+      col[2 * stride] = rotcol ? w * tv[2] : 0.0;
+      col[3 * stride] = w * (rotcol ? c0 : tv[0]);
+      col[4 * stride] = w * (rotcol ? c1 : tv[1]);
+      col[5 * stride] = w * (rotcol ? c2 : tv[2]);
     }
   }
 }
@@ -252,71 +254,20 @@ MCBA_HD PoseSrc global_pose_src(const Dims& d, const Tables& t) {
   return s;
 }
 
-// All six columns of pose block k of That at once: out[a * stride + jj], a < DE, jj < 6 (same values as six calls of
-// view_column, but the chain prefix of the block is formed once).  Rows a block does not touch are written as zero.
-MCBA_HD void view_block_columns(const Dims& d, const PoseSrc& ps, const double* bwg, int f, int c, int b, int k,
-                                double* out, int stride) {
-  const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+// column j < 6 NPB of That of view (f, c, b) as k_tmat forms it: Tm[a * stride + j], a < DE
+MCBA_HD void view_that_column(const Dims& d, const PoseSrc& ps, const double* bwg, int f, int c, int b, int j, double* Tm,
+                              int stride) {
   const double* Pc = ps.cam + (size_t)c * POSE_STRIDE;
   const double* Pb = ps.board + (size_t)b * POSE_STRIDE;
-  const double* Rc = Pc + POSE_R;
-  const double* tc = Pc + POSE_T;
-  const int last = d.NPB - 1;
-  if (k == 0) {   // camera pose: identity prefix; rolling shutter: the same block acts on both chains
-    for (int jj = 0; jj < 6; ++jj) view_pose_column(I3, Pc + POSE_L, tc, jj, out + jj, stride);
-    if (d.motion == MOTION_ROLLING)
-      for (int a = 0; a < 6; ++a)
-        for (int jj = 0; jj < 6; ++jj) out[(6 + a) * stride + jj] = out[a * stride + jj];
+  if (d.motion == MOTION_HAND_EYE) {
+    view_column_p(d, Pc, Pb, ps.mot, ps.mot + POSE_STRIDE, bwg + 12 * (size_t)f, j, Tm + j, stride);
     return;
   }
-  if (d.motion == MOTION_HAND_EYE) {   // chain camera . G . B_f . Wb . board ; local blocks: cam | wb | gc | board
-    const double* Wb = ps.mot;
-    const double* G = ps.mot + POSE_STRIDE;
-    const double* Bf = bwg + 12 * (size_t)f;
-    double R1[9], t1[3];
-    se3_mul(Rc, tc, G + POSE_R, G + POSE_T, R1, t1);            // camera . G
-    if (k == 2) {
-      for (int jj = 0; jj < 6; ++jj) view_pose_column(Rc, G + POSE_L, t1, jj, out + jj, stride);
-      return;
-    }
-    double R2[9], t2[3], R3[9], t3[3];
-    se3_mul(R1, t1, Bf, Bf + 9, R2, t2);                         // . B_f
-    se3_mul(R2, t2, Wb + POSE_R, Wb + POSE_T, R3, t3);           // . Wb
-    if (k == 1) {
-      for (int jj = 0; jj < 6; ++jj) view_pose_column(R2, Wb + POSE_L, t3, jj, out + jj, stride);
-    } else {
-      double o[3], v3[3];
-      mat3_vec(R3, Pb + POSE_T, v3);
-      for (int i = 0; i < 3; ++i) o[i] = t3[i] + v3[i];
-      for (int jj = 0; jj < 6; ++jj) view_pose_column(R3, Pb + POSE_L, o, jj, out + jj, stride);
-    }
-    return;
-  }
-  const int nch = d.motion == MOTION_ROLLING ? 2 : 1;
-  for (int ch = 0; ch < nch; ++ch) {
-    double* o6 = out + 6 * ch * stride;
-    // rolling shutter: block 1 = start pose (chain 0 only), block 2 = end pose (chain 1 only), block 3 = board (both)
-    const bool touches = k == last || nch == 1 || k == 1 + ch;
-    if (!touches) {
-      for (int a = 0; a < 6; ++a)
-        for (int jj = 0; jj < 6; ++jj) o6[a * stride + jj] = 0.0;
-      continue;
-    }
-    const double* Pf = ps.mot + (size_t)(ch * ps.chain + (f - ps.f0)) * POSE_STRIDE;
-    double R1[9], t1[3];
-    se3_mul(Rc, tc, Pf + POSE_R, Pf + POSE_T, R1, t1);            // camera . frame
-    if (k == last) {
-      double o[3], v3[3];
-      mat3_vec(R1, Pb + POSE_T, v3);
-      for (int i = 0; i < 3; ++i) o[i] = t1[i] + v3[i];
-      for (int jj = 0; jj < 6; ++jj) view_pose_column(R1, Pb + POSE_L, o, jj, o6 + jj, stride);
-    } else {
-      for (int jj = 0; jj < 6; ++jj) view_pose_column(Rc, Pf + POSE_L, t1, jj, o6 + jj, stride);
-    }
-  }
-}
-MCBA_HD void view_block_columns(const Dims& d, const Tables& t, int f, int c, int b, int k, double* out, int stride) {
-  view_block_columns(d, global_pose_src(d, t), t.bwg, f, c, b, k, out, stride);
+  const double* Pm0 = ps.mot + (size_t)(f - ps.f0) * POSE_STRIDE;
+  if (d.motion == MOTION_ROLLING)
+    fused_view_tables<true, false>(Pc, Pm0, Pm0 + (size_t)ps.chain * POSE_STRIDE, Pb, j, Tm, nullptr, stride);
+  else
+    fused_view_tables<false, false>(Pc, Pm0, Pm0, Pb, j, Tm, nullptr, stride);
 }
 
 // x index of local parameter i of view (f, c, b); -1 when its block is not optimised (or i is the residual column)
@@ -445,9 +396,11 @@ MCBA_HD void prep_item(const Dims& d, const Tables& t, const double* x, int i) {
   if (i < d.C) {
     double p[5 + MAX_DIST];
     const int kc = 5 + d.ND;
-    for (int k = 0; k < kc; ++k) p[k] = block_value(t, x, d.off_cameras, d.foff_cameras, i * kc + k);
+#pragma unroll
+    for (int k = 0; k < 5 + MAX_DIST; ++k) p[k] = k < kc ? block_value(t, x, d.off_cameras, d.foff_cameras, i * kc + k) : 0.0;
     double e[CAM_STRIDE];
     camera_entry(p, d.ND, t.img_h[i], t.fix_aspect[i] != 0, e);
+#pragma unroll
     for (int k = 0; k < CAM_STRIDE; ++k) t.cam[(size_t)i * CAM_STRIDE + k] = e[k];
     return;
   }

@@ -133,8 +133,8 @@ void normal_t(Host& h, double* H, double* g, double* cost_out) {
           for (int j = 0; j < NV; ++j) S[i * NV + j] += vr[a * NV + i] * vr[a * NV + j];
     }
     std::fill(That.begin(), That.end(), 0.0);
-    for (int k = 0; k < d.NPB; ++k)   // the block form used by k_tmat (the Jacobian above goes through view_column)
-      view_block_columns(d, h.t, f, c, b, k, That.data() + 6 * k, N1);
+    for (int j = 0; j < NPC; ++j)   // the lane-uniform form used by k_tmat (the Jacobian above goes through view_column)
+      view_that_column(d, global_pose_src(d, h.t), h.t.bwg, f, c, b, j, That.data(), N1);
     for (int q = 0; q < KI + 1; ++q) That[(DE + q) * N1 + NPC + q] = 1.0;
     for (int a = 0; a < NV; ++a)
       for (int j = 0; j < N1; ++j) {
