@@ -51,6 +51,8 @@ __global__ __launch_bounds__(TM_THREADS, 4) void k_tmat(Dims d, Tables t, double
                                                      int nb_views) {
   __shared__ double tile[TMV * 12 * 24];
   __shared__ double lpose[TM_LOCAL_POSES * POSE_STRIDE];
+  __shared__ double pre[TMV * 2 * PRE_STRIDE];
+  __shared__ uint8_t vlive[TMV];
   const int NPB = d.NPB, npc = 6 * NPB, DE = d.DE, vsz = DE * npc;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
 #if defined(MCBA_EXP_TMAT_PROF)
@@ -67,6 +69,7 @@ __global__ __launch_bounds__(TM_THREADS, 4) void k_tmat(Dims d, Tables t, double
   if (nv <= 0) return;
   const int vl = threadIdx.x >> 5, j = threadIdx.x & 31, v = v0 + vl;
   const bool live = vl < nv && t.view_count[v] != 0;   // (the flag load overlaps the pose entries)
+  if (j == 0) vlive[vl] = live;
   PoseSrc ps = global_pose_src(d, t);
   if (x != nullptr) {
     const int CB = d.C * d.B, nch = d.motion == MOTION_ROLLING ? 2 : 1;
@@ -86,25 +89,47 @@ __global__ __launch_bounds__(TM_THREADS, 4) void k_tmat(Dims d, Tables t, double
       for (int k = 0; k < 6; ++k) rt[k] = block_value(t, x, oa, of, r + k);
       pose_entry(rt, lpose + (size_t)e * POSE_STRIDE);
     }
-    __syncthreads();
     ps.cam = lpose;
     ps.board = lpose + (size_t)d.C * POSE_STRIDE;
     ps.mot = lpose + (size_t)(d.C + d.B) * POSE_STRIDE;
     ps.chain = nfl;
     ps.f0 = f_lo;
   }
+  __syncthreads();   // (local pose entries and the liveness flags written)
 #if defined(MCBA_EXP_TMAT_PROF)
   st[1] = clock64();
 #endif
-  if (live) {
-    const int b = v % d.B, c = (v / d.B) % d.C, fl = v / (d.B * d.C), f = d.f0 + fl;
-    const int nch = d.motion == MOTION_ROLLING ? 2 : 1;
-    if (j < npc) {
-      view_that_column(d, ps, t.bwg, f, c, b, j, tile + vl * vsz, npc);
-    } else if (j < npc + nch) {   // the view table too: the trial step that led here only ran k_prep (k_cost forms its own chains)
-      const int ch = j - npc;
-      view_chain(d, ps, t.bwg, f, c, b, ch, t.view + (size_t)v * d.view_stride() + ch * VIEW_STRIDE);
+  // step 1: the chain prefixes of the workgroup's views, one thread per (view, chain); R2 | o is the view table's chain
+  // matrix (the trial step that led here only ran k_prep; k_cost forms its own chains with the same two products)
+  const int nch = d.motion == MOTION_ROLLING ? 2 : 1;
+  const bool hand_eye = d.motion == MOTION_HAND_EYE;
+  if ((int)threadIdx.x < TMV * nch) {
+    const int pv = threadIdx.x / nch, ch = threadIdx.x % nch, vp = v0 + pv;
+    if (vlive[pv]) {
+      const int b = vp % d.B, c = (vp / d.B) % d.C, f = d.f0 + vp / (d.B * d.C);
+      double* out = t.view + (size_t)vp * d.view_stride() + ch * VIEW_STRIDE;
+      if (hand_eye) {
+        view_chain(d, ps, t.bwg, f, c, b, ch, out);
+      } else {
+        double* pr = pre + (pv * 2 + ch) * PRE_STRIDE;
+        view_prefix(ps.cam + (size_t)c * POSE_STRIDE, ps.mot + (size_t)(ch * ps.chain + (f - ps.f0)) * POSE_STRIDE,
+                    ps.board + (size_t)b * POSE_STRIDE, pr);
+        for (int i = 0; i < 12; ++i) out[i] = pr[12 + i];
+      }
     }
+  }
+  __syncthreads();
+  // step 2: lane j < 6 NPB of a view's 32 lanes forms column j of That
+  if (live && j < npc) {
+    const int b = v % d.B, c = (v / d.B) % d.C, f = d.f0 + v / (d.B * d.C);
+    const double* Pc = ps.cam + (size_t)c * POSE_STRIDE;
+    const double* Pb = ps.board + (size_t)b * POSE_STRIDE;
+    const double* Pm0 = ps.mot + (size_t)(f - ps.f0) * POSE_STRIDE;
+    const double* pv = pre + vl * 2 * PRE_STRIDE;
+    double* Tm = tile + vl * vsz;
+    if (hand_eye) view_column_p(d, Pc, Pb, ps.mot, ps.mot + POSE_STRIDE, t.bwg + 12 * (size_t)f, j, Tm + j, npc);
+    else if (nch == 2) that_column_from_prefix<true>(Pc, Pm0, Pm0 + (size_t)ps.chain * POSE_STRIDE, Pb, pv, j, Tm, npc);
+    else that_column_from_prefix<false>(Pc, Pm0, Pm0, Pb, pv, j, Tm, npc);
   }
   __syncthreads();
 #if defined(MCBA_EXP_TMAT_PROF)
@@ -113,9 +138,11 @@ __global__ __launch_bounds__(TM_THREADS, 4) void k_tmat(Dims d, Tables t, double
   // views of a workgroup are contiguous: coalesced stores; empty views (45 % of the north-star rig) are skipped -- nobody
   // reads their That, and the table is the largest thing this kernel writes (18 MB for all views)
   double* tg = t.tmat + (size_t)v0 * vsz;
-  for (int vv = 0; vv < nv; ++vv) {
-    if (t.view_count[v0 + vv] == 0) continue;
-    for (int e = threadIdx.x; e < vsz; e += blockDim.x) tg[vv * vsz + e] = tile[vv * vsz + e];
+  const float inv_vsz = 1.0f / (float)vsz;
+  for (int e = threadIdx.x; e < nv * vsz; e += blockDim.x) {
+    int vv = (int)((float)e * inv_vsz);   // view of element e (float quotient, corrected)
+    if (vv * vsz > e) --vv; else if ((vv + 1) * vsz <= e) ++vv;
+    if (vlive[vv]) tg[e] = tile[e];
   }
 #if defined(MCBA_EXP_TMAT_PROF)
   st[3] = clock64();

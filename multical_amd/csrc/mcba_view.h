@@ -254,7 +254,55 @@ MCBA_HD PoseSrc global_pose_src(const Dims& d, const Tables& t) {
   return s;
 }
 
-// column j < 6 NPB of That of view (f, c, b) as k_tmat forms it: Tm[a * stride + j], a < DE
+// The same construction in two steps, for k_tmat: the chain prefix of a view is formed ONCE per (view, chain) --
+//   pre[24] = R1 (camera . frame) | t1 | R2 (camera . frame . board) | o      (R2 | o IS the view-table chain matrix)
+// -- and the columns of That pick their block's prefix rotation / left Jacobian / origin from it (static and rolling).
+constexpr int PRE_STRIDE = 24;
+MCBA_HD void view_prefix(const double* Pc, const double* Pf, const double* Pb, double* pre) {
+  se3_mul(Pc + POSE_R, Pc + POSE_T, Pf + POSE_R, Pf + POSE_T, pre, pre + 9);
+  se3_mul(pre, pre + 9, Pb + POSE_R, Pb + POSE_T, pre + 12, pre + 21);
+}
+template <bool ROLL>
+MCBA_HD void that_column_from_prefix(const double* Pc, const double* Pm0, const double* Pm1, const double* Pb,
+                                     const double* pre /*[NCH][PRE_STRIDE]*/, int j, double* Tm, int stride) {
+  constexpr int NCH = ROLL ? 2 : 1, NPB = ROLL ? 4 : 3;
+  const double* Rc = Pc + POSE_R;
+  const double* tc = Pc + POSE_T;
+  const int k = j / 6, jj = j % 6;
+  const bool rotcol = jj < 3;
+  const int ju = rotcol ? jj : jj - 3;
+  const bool is_cam = k == 0, is_board = k == NPB - 1;
+  for (int ch = 0; ch < NCH; ++ch) {
+    const double* Pf = ch == 0 ? Pm0 : Pm1;
+    const double* R1 = pre + ch * PRE_STRIDE;
+    const double* t1 = R1 + 9;
+    const double* o = R1 + 21;
+    const bool active = is_cam || is_board || !ROLL || k == 1 + ch;
+    const double* L = is_cam ? Pc + POSE_L : (is_board ? Pb + POSE_L : Pf + POSE_L);   // left Jacobian of the lane's block
+    double u[3];                                                  // column ju of L (rotation columns) or a unit vector
+    for (int i = 0; i < 3; ++i) u[i] = rotcol ? L[3 * i + ju] : (i == ju ? 1.0 : 0.0);
+    double tv[3], ov[3];
+    for (int i = 0; i < 3; ++i) {
+      const double r0 = is_cam ? (i == 0 ? 1.0 : 0.0) : (is_board ? R1[3 * i] : Rc[3 * i]);
+      const double r1 = is_cam ? (i == 1 ? 1.0 : 0.0) : (is_board ? R1[3 * i + 1] : Rc[3 * i + 1]);
+      const double r2 = is_cam ? (i == 2 ? 1.0 : 0.0) : (is_board ? R1[3 * i + 2] : Rc[3 * i + 2]);
+      tv[i] = r0 * u[0] + r1 * u[1] + r2 * u[2];                  // R_pre u
+      ov[i] = is_cam ? tc[i] : (is_board ? o[i] : t1[i]);         // o_k
+    }
+    const double c0 = ov[1] * tv[2] - ov[2] * tv[1], c1 = ov[2] * tv[0] - ov[0] * tv[2], c2 = ov[0] * tv[1] - ov[1] * tv[0];
+    const double w = active ? 1.0 : 0.0;
+    double* col = Tm + (size_t)(6 * ch) * stride + j;
+    col[0 * stride] = rotcol ? w * tv[0] : 0.0;
+    col[1 * stride] = rotcol ? w * tv[1] : 0.0;
+    col[2 * stride] = rotcol ? w * tv[2] : 0.0;
+    col[3 * stride] = w * (rotcol ? c0 : tv[0]);
+    col[4 * stride] = w * (rotcol ? c1 : tv[1]);
+    col[5 * stride] = w * (rotcol ? c2 : tv[2]);
+  }
+}
+
+// column j < 6 NPB of That of view (f, c, b) exactly as k_tmat forms it (which keeps the chain prefixes of its views in
+// LDS and calls the two steps itself): Tm[a * stride + j], a < DE
 MCBA_HD void view_that_column(const Dims& d, const PoseSrc& ps, const double* bwg, int f, int c, int b, int j, double* Tm,
                               int stride) {
   const double* Pc = ps.cam + (size_t)c * POSE_STRIDE;
@@ -264,10 +312,12 @@ MCBA_HD void view_that_column(const Dims& d, const PoseSrc& ps, const double* bw
     return;
   }
   const double* Pm0 = ps.mot + (size_t)(f - ps.f0) * POSE_STRIDE;
-  if (d.motion == MOTION_ROLLING)
-    fused_view_tables<true, false>(Pc, Pm0, Pm0 + (size_t)ps.chain * POSE_STRIDE, Pb, j, Tm, nullptr, stride);
-  else
-    fused_view_tables<false, false>(Pc, Pm0, Pm0, Pb, j, Tm, nullptr, stride);
+  const double* Pm1 = Pm0 + (size_t)ps.chain * POSE_STRIDE;
+  double pre[2 * PRE_STRIDE];
+  view_prefix(Pc, Pm0, Pb, pre);
+  if (d.motion == MOTION_ROLLING) view_prefix(Pc, Pm1, Pb, pre + PRE_STRIDE);
+  if (d.motion == MOTION_ROLLING) that_column_from_prefix<true>(Pc, Pm0, Pm1, Pb, pre, j, Tm, stride);
+  else that_column_from_prefix<false>(Pc, Pm0, Pm0, Pb, pre, j, Tm, stride);
 }
 
 // x index of local parameter i of view (f, c, b); -1 when its block is not optimised (or i is the residual column)
