@@ -375,13 +375,18 @@ void launch_linearize(mcba_handle_s* h, const double* dx) {
     return;
   }
   const int nb_views = std::max((d.views() + TMV - 1) / TMV, 1);
-  if (dx != nullptr && tmat_local_poses(d) > TM_LOCAL_POSES) {   // unusual shape: separate table pass
+  const bool local = tmat_local_poses(d) <= TM_LOCAL_POSES;
+  if (dx != nullptr && !local) {   // unusual shape (cameras + boards exceed the workgroup-local pose table): separate table pass
     eval_pose_tables(h, dx);
     dx = nullptr;
   }
   const int nb_prep = dx ? (d.n_pose + d.C + d.B * d.P + TM_THREADS - 1) / TM_THREADS : 0;
-  hipLaunchKernelGGL(k_tmat, dim3(nb_views + nb_prep), dim3(TM_THREADS), 0, h->stream, d, h->t, h->gbuf.p, 2 * d.n + 2, h->Hss.p,
-                     d.ns * d.ns, dx, nb_views);
+  if (local)
+    hipLaunchKernelGGL(k_tmat<true>, dim3(nb_views + nb_prep), dim3(TM_THREADS), 0, h->stream, d, h->t, h->gbuf.p,
+                       2 * d.n + 2, h->Hss.p, d.ns * d.ns, dx, nb_views);
+  else
+    hipLaunchKernelGGL(k_tmat<false>, dim3(nb_views), dim3(TM_THREADS), 0, h->stream, d, h->t, h->gbuf.p, 2 * d.n + 2,
+                       h->Hss.p, d.ns * d.ns, (const double*)nullptr, nb_views);
   h->ops->linearize(d, h->t, h->stream, h->rec.p, h->tri.p, h->use_mfma, h->lin_grid, nullptr, nullptr, 0, nullptr, 0);
 }
 

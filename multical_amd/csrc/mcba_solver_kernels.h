@@ -46,6 +46,11 @@ __host__ __device__ inline int tmat_local_poses(const Dims& d) {   // upper boun
   const int nfl = (TMV - 1) / (CB > 0 ? CB : 1) + 2;
   return d.C + d.B + (d.motion == MOTION_HAND_EYE ? 2 : (d.motion == MOTION_ROLLING ? 2 : 1) * nfl);
 }
+// LOCAL: the pose entries of the workgroup's views live in LDS -- formed from x, or (x == nullptr) copied from the pose
+// table -- so that the chain products read them with LDS instructions; a pointer that may be either global or LDS made
+// every read a flat load (9.3 k -> cycles for the two steps).  LOCAL = false (a rig whose cameras + boards exceed the local
+// table; x must be nullptr): entries are read from the global pose table.
+template <bool LOCAL>
 __global__ __launch_bounds__(TM_THREADS, 4) void k_tmat(Dims d, Tables t, double* __restrict__ zero_a, int na,
                                                      double* __restrict__ zero_b, int nb, const double* __restrict__ x,
                                                      int nb_views) {
@@ -71,30 +76,45 @@ __global__ __launch_bounds__(TM_THREADS, 4) void k_tmat(Dims d, Tables t, double
   const bool live = vl < nv && t.view_count[v] != 0;   // (the flag load overlaps the pose entries)
   if (j == 0) vlive[vl] = live;
   PoseSrc ps = global_pose_src(d, t);
-  if (x != nullptr) {
+  if constexpr (LOCAL) {
     const int CB = d.C * d.B, nch = d.motion == MOTION_ROLLING ? 2 : 1;
     const int f_lo = d.f0 + v0 / CB, nfl = (d.f0 + (v0 + nv - 1) / CB) - f_lo + 1;
     const int nmot = d.motion == MOTION_HAND_EYE ? 2 : nch * nfl, np = d.C + d.B + nmot;
-    for (int e = threadIdx.x; e < np; e += blockDim.x) {
-      int oa, of, r;
-      if (e < d.C) { oa = d.off_campose; of = d.foff_campose; r = 6 * e; }
-      else if (e < d.C + d.B) { oa = d.off_boardpose; of = d.foff_boardpose; r = 6 * (e - d.C); }
-      else {
-        const int li = e - d.C - d.B;
-        oa = d.off_motion;
-        of = d.foff_motion;
-        r = d.motion == MOTION_HAND_EYE ? 6 * li : 6 * ((li / nfl) * d.F + f_lo + li % nfl);
+    if (x != nullptr) {
+      for (int e = threadIdx.x; e < np; e += blockDim.x) {
+        int oa, of, r;
+        if (e < d.C) { oa = d.off_campose; of = d.foff_campose; r = 6 * e; }
+        else if (e < d.C + d.B) { oa = d.off_boardpose; of = d.foff_boardpose; r = 6 * (e - d.C); }
+        else {
+          const int li = e - d.C - d.B;
+          oa = d.off_motion;
+          of = d.foff_motion;
+          r = d.motion == MOTION_HAND_EYE ? 6 * li : 6 * ((li / nfl) * d.F + f_lo + li % nfl);
+        }
+        double rt[6];
+        for (int k = 0; k < 6; ++k) rt[k] = block_value(t, x, oa, of, r + k);
+        pose_entry(rt, lpose + (size_t)e * POSE_STRIDE);
       }
-      double rt[6];
-      for (int k = 0; k < 6; ++k) rt[k] = block_value(t, x, oa, of, r + k);
-      pose_entry(rt, lpose + (size_t)e * POSE_STRIDE);
+    } else {   // copy the entries from the pose table (same local order)
+      for (int q = threadIdx.x; q < np * POSE_STRIDE; q += blockDim.x) {
+        const int e = q / POSE_STRIDE, k = q - e * POSE_STRIDE;
+        int gi;
+        if (e < d.C) gi = d.pose_cam + e;
+        else if (e < d.C + d.B) gi = d.pose_board + (e - d.C);
+        else {
+          const int li = e - d.C - d.B;
+          gi = d.pose_motion + (d.motion == MOTION_HAND_EYE ? li : (li / nfl) * d.F + f_lo + li % nfl);
+        }
+        lpose[q] = t.pose[(size_t)gi * POSE_STRIDE + k];
+      }
     }
-    ps.cam = lpose;
-    ps.board = lpose + (size_t)d.C * POSE_STRIDE;
-    ps.mot = lpose + (size_t)(d.C + d.B) * POSE_STRIDE;
     ps.chain = nfl;
     ps.f0 = f_lo;
   }
+  // (LOCAL: the three tables are addressed as lpose + ... below, so that the compiler sees LDS pointers)
+  const double* cam_tab = LOCAL ? lpose : ps.cam;
+  const double* board_tab = LOCAL ? lpose + (size_t)d.C * POSE_STRIDE : ps.board;
+  const double* mot_tab = LOCAL ? lpose + (size_t)(d.C + d.B) * POSE_STRIDE : ps.mot;
   __syncthreads();   // (local pose entries and the liveness flags written)
 #if defined(MCBA_EXP_TMAT_PROF)
   st[1] = clock64();
@@ -109,11 +129,12 @@ __global__ __launch_bounds__(TM_THREADS, 4) void k_tmat(Dims d, Tables t, double
       const int b = vp % d.B, c = (vp / d.B) % d.C, f = d.f0 + vp / (d.B * d.C);
       double* out = t.view + (size_t)vp * d.view_stride() + ch * VIEW_STRIDE;
       if (hand_eye) {
-        view_chain(d, ps, t.bwg, f, c, b, ch, out);
+        view_chain_p(d, cam_tab + (size_t)c * POSE_STRIDE, board_tab + (size_t)b * POSE_STRIDE, mot_tab,
+                     mot_tab + POSE_STRIDE, t.bwg + 12 * (size_t)f, out);
       } else {
         double* pr = pre + (pv * 2 + ch) * PRE_STRIDE;
-        view_prefix(ps.cam + (size_t)c * POSE_STRIDE, ps.mot + (size_t)(ch * ps.chain + (f - ps.f0)) * POSE_STRIDE,
-                    ps.board + (size_t)b * POSE_STRIDE, pr);
+        view_prefix(cam_tab + (size_t)c * POSE_STRIDE, mot_tab + (size_t)(ch * ps.chain + (f - ps.f0)) * POSE_STRIDE,
+                    board_tab + (size_t)b * POSE_STRIDE, pr);
         for (int i = 0; i < 12; ++i) out[i] = pr[12 + i];
       }
     }
@@ -122,12 +143,12 @@ __global__ __launch_bounds__(TM_THREADS, 4) void k_tmat(Dims d, Tables t, double
   // step 2: lane j < 6 NPB of a view's 32 lanes forms column j of That
   if (live && j < npc) {
     const int b = v % d.B, c = (v / d.B) % d.C, f = d.f0 + v / (d.B * d.C);
-    const double* Pc = ps.cam + (size_t)c * POSE_STRIDE;
-    const double* Pb = ps.board + (size_t)b * POSE_STRIDE;
-    const double* Pm0 = ps.mot + (size_t)(f - ps.f0) * POSE_STRIDE;
+    const double* Pc = cam_tab + (size_t)c * POSE_STRIDE;
+    const double* Pb = board_tab + (size_t)b * POSE_STRIDE;
+    const double* Pm0 = mot_tab + (size_t)(f - ps.f0) * POSE_STRIDE;
     const double* pv = pre + vl * 2 * PRE_STRIDE;
     double* Tm = tile + vl * vsz;
-    if (hand_eye) view_column_p(d, Pc, Pb, ps.mot, ps.mot + POSE_STRIDE, t.bwg + 12 * (size_t)f, j, Tm + j, npc);
+    if (hand_eye) view_column_p(d, Pc, Pb, mot_tab, mot_tab + POSE_STRIDE, t.bwg + 12 * (size_t)f, j, Tm + j, npc);
     else if (nch == 2) that_column_from_prefix<true>(Pc, Pm0, Pm0 + (size_t)ps.chain * POSE_STRIDE, Pb, pv, j, Tm, npc);
     else that_column_from_prefix<false>(Pc, Pm0, Pm0, Pb, pv, j, Tm, npc);
   }
