@@ -375,7 +375,9 @@ void launch_linearize(mcba_handle_s* h, const double* dx) {
     return;
   }
   const int nb_views = std::max((d.views() + TMV - 1) / TMV, 1);
-  const bool local = tmat_local_poses(d) <= TM_LOCAL_POSES;
+  // (MCBA_TMAT_GLOBAL=1 forces the path of rigs too large for the workgroup-local pose table: tests)
+  static const bool force_global = getenv("MCBA_TMAT_GLOBAL") != nullptr && getenv("MCBA_TMAT_GLOBAL")[0] == '1';
+  const bool local = tmat_local_poses(d) <= TM_LOCAL_POSES && !force_global;
   if (dx != nullptr && !local) {   // unusual shape (cameras + boards exceed the workgroup-local pose table): separate table pass
     eval_pose_tables(h, dx);
     dx = nullptr;

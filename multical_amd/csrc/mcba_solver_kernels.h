@@ -985,8 +985,11 @@ __device__ __forceinline__ double lane_bcast(double v, int src) {   // value of 
 
 // (a): Cholesky factor of the 16 x 16 tile D (first ncol columns; the rest is right-hand-side row / identity padding)
 // and its inverse Xi, by one wavefront.  col0 = global index of the tile's first column (for the pivot report).
-__device__ __forceinline__ void chol_tile_factor(double* __restrict__ D, double* __restrict__ Xi, int ncol, int col0,
-                                                 int lane, int& badcol) {
+// FULL: all 16 columns belong to the matrix -- no per-column branch, so the 16 pivot steps form ONE basic block and the
+// scheduler can start the rsqrt chain of column j + 1 while the broadcasts / updates of column j are still issuing.
+template <bool FULL>
+__device__ __forceinline__ void chol_tile_factor_t(double* __restrict__ D, double* __restrict__ Xi, int ncol, int col0,
+                                                   int lane, int& badcol) {
   const int li = lane & 15;
   double row[CT], dinv[CT];
 #pragma unroll
@@ -994,7 +997,7 @@ __device__ __forceinline__ void chol_tile_factor(double* __restrict__ D, double*
 #pragma unroll
   for (int j = 0; j < CT; ++j) {
     dinv[j] = 1.0;
-    if (j < ncol) {                        // wave-uniform
+    if (FULL || j < ncol) {                // wave-uniform
       double dj = lane_bcast(row[j], j);
       badcol = (dj > 0.0 || badcol != 0) ? badcol : col0 + j + 1;
       dj = fmax(dj, 1e-300);
@@ -1032,6 +1035,14 @@ __device__ __forceinline__ void chol_tile_factor(double* __restrict__ D, double*
 #pragma unroll
     for (int i = 0; i < CT; ++i) Xi[i * CTL + li] = x[i];
   }
+}
+__device__ __forceinline__ void chol_tile_factor(double* __restrict__ D, double* __restrict__ Xi, int ncol, int col0,
+                                                 int lane, int& badcol) {
+#if !defined(MCBA_EXP_CHOL_NOFULL)
+  if (ncol >= CT) chol_tile_factor_t<true>(D, Xi, CT, col0, lane, badcol);
+  else
+#endif
+    chol_tile_factor_t<false>(D, Xi, ncol, col0, lane, badcol);
 }
 
 // C -= Xa Xb^T for one 16 x 16 tile (four MFMA steps), one wavefront

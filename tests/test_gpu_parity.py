@@ -478,10 +478,15 @@ def test_handle_cache_sees_a_changed_validity_mask_and_float32_tables():
     assert np.abs(cm.residuals() - ocm.evaluate(cm.param_vec)).max() < 1e-9
 
 
-def test_fused_linearisation_form_matches_the_table_form():
-  """MCBA_FUSED=1: k_linearize forms That / the chain matrices / the intrinsics straight from x (no k_prep / k_tmat
-  launch).  Runs in a subprocess (the switch is read once per process) and must reproduce the normal equations of the
-  default table form to round-off, for every motion model, and the same solve."""
+@pytest.mark.parametrize("switch", ["MCBA_FUSED=1", "MCBA_ASM_STAGE_KB=4", "MCBA_TMAT_GLOBAL=1", "MCBA_NCHUNK_TARGET=1024"])
+def test_alternative_linearisation_paths_match_the_default(switch):
+  """Paths of the evaluation that the fixtures do not reach by themselves, each forced with its switch in a subprocess
+  (the switches are read once per process); all must reproduce the normal equations of the default form to round-off,
+  for every motion model, and the same solve:
+    MCBA_FUSED=1              k_linearize forms That / the chain matrices / the intrinsics straight from x (no k_tmat)
+    MCBA_ASM_STAGE_KB=4       frame blocks of k_assemble stage their records in several groups (rigs with many views per frame)
+    MCBA_TMAT_GLOBAL=1        k_tmat reads the global pose table (rigs whose cameras + boards exceed the local table)
+    MCBA_NCHUNK_TARGET=1024   more chunk sums than the default split of the shared part"""
   import os, subprocess, sys, json
   code = r'''
 import sys, json, numpy as np
@@ -501,8 +506,9 @@ print("RESULT" + json.dumps(out))
 '''
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
   res = {}
-  for fused in ("0", "1"):
-    env = dict(os.environ, MCBA_FUSED=fused)
+  key, val = switch.split("=")
+  base = {k: v for k, v in os.environ.items() if k != key}
+  for fused, env in (("0", base), ("1", dict(base, **{key: val}))):
     p = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     res[fused] = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT")][0][6:])
