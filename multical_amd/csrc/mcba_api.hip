@@ -107,7 +107,7 @@ struct ScalLayout {
   int q00p = 0;       // [Q00_BLOCKS]      k_q00 partials (all-reduced element-wise when sharded)
   int step = 0;       // [3 nvb]           k_vec_step partials
   int costp = 0;      // [COST_BLOCKS_MAX] k_cost partials (all-reduced element-wise when sharded)
-  int dotp = 0;       // [3 nblk + 1]      partial dots + pivot report (folded by k_tr_step)
+  int dotp = 0;       // [3 nblk + 1]      partial dots + pivot report (folded by k_vec_step)
   int total = 0;
   void init(int n, int dot_blocks) {
     nvb = (n + 255) / 256;
@@ -523,8 +523,11 @@ int gn_dot_blocks(const Dims& d) {
 }
 // tr_dev (device, may be null): the scalar block of the single-GPU driver; the damping is then read from tr_dev[TR_REG]
 // on the device (`reg` is ignored) and added to the reduced system by k_schur_reduce.
+// tr_dev: the damping is S[TR_REG] of that scalar block; with `trp` (the partial sums k_tr_reg would fold) the first kernel
+// of the chain computes and publishes it itself
+struct TrRegPartials { const double* vs; int nvb; const double* q; int nq; int first; double Delta; };
 void launch_gn_solve(mcba_handle_s* h, double reg, bool root_rank, double* dots_out = nullptr,
-                     const double* tr_dev = nullptr) {
+                     double* tr_dev = nullptr, const TrRegPartials* trp = nullptr) {
   const Dims& d = h->d;
   const int K = d.DF * d.Fl;
   // Whether the frame part of the step is reduced across ranks must not depend on THIS rank's shard size (an empty shard,
@@ -534,14 +537,18 @@ void launch_gn_solve(mcba_handle_s* h, double reg, bool root_rank, double* dots_
   // frame entries of other shards must be zero before the cross-rank sum; a single handle writes every entry of gn
   if (h->allreduce) HIP_OK(hipMemsetAsync(h->gn.p, 0, (size_t)d.n * sizeof(double), h->stream));
   double* fused_dots = sharded_frames ? nullptr : dots_out;
+  if (trp != nullptr && K == 0)   // no frame blocks on this rank: the stand-alone fold
+    hipLaunchKernelGGL(k_tr_reg, dim3(1), dim3(64), 0, h->stream, tr_dev, trp->vs, trp->nvb, trp->q, trp->nq, trp->first,
+                       trp->Delta);
   if (K > 0) {
+    const TrRegPartials z = trp ? *trp : TrRegPartials{nullptr, 0, nullptr, 0, 0, 0.0};
     if (d.DF == 12) {
       hipLaunchKernelGGL((k_frame_factor<12>), dim3((d.Fl + 63) / 64), dim3(64), 0, h->stream, d, h->Hff.p, h->dsc.p, h->gh.p,
-                         reg, h->Lf.p, h->W.p, h->yf.p, tr_dev);
+                         reg, h->Lf.p, h->W.p, h->yf.p, tr_dev, z.vs, z.nvb, z.q, z.nq, z.first, z.Delta);
       hipLaunchKernelGGL((k_schur_w<12>), dim3(d.Fl), dim3(256), 0, h->stream, d, h->Hfs.p, h->dsc.p, h->Lf.p, h->W.p);
     } else {
       hipLaunchKernelGGL((k_frame_factor<6>), dim3((d.Fl + 63) / 64), dim3(64), 0, h->stream, d, h->Hff.p, h->dsc.p, h->gh.p,
-                         reg, h->Lf.p, h->W.p, h->yf.p, tr_dev);
+                         reg, h->Lf.p, h->W.p, h->yf.p, tr_dev, z.vs, z.nvb, z.q, z.nq, z.first, z.Delta);
       hipLaunchKernelGGL((k_schur_w<6>), dim3(d.Fl), dim3(256), 0, h->stream, d, h->Hfs.p, h->dsc.p, h->Lf.p, h->W.p);
     }
     const int nt2 = h->ntile * (h->ntile + 1) / 2;
@@ -1344,7 +1351,7 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
   const int max_nfev = opt->max_nfev > 0 ? opt->max_nfev : d.n * 100;
   const double NaN = std::numeric_limits<double>::quiet_NaN();
   const bool is_root = h->shard_root;
-  // The scalar trust-region algebra runs in one-wave kernels between the vector kernels (k_tr_reg, k_tr_step), so that a
+  // The scalar trust-region algebra runs in one-wave kernels between the vector kernels (k_tr_reg; the subspace step is the head of k_vec_step), so that a
   // whole iteration -- scaling, Cauchy curvature, damped Gauss-Newton solve, 2-D subspace step, trial cost -- is enqueued
   // at once and the host synchronises ONCE per iteration.  Frame-sharded handles insert their all-reduces into the same
   // chain (stream-ordered: native RCCL or the torch.distributed hook): H-dependent per-block partials are reduced element-
@@ -1352,7 +1359,13 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
   // same algebra (mcba_trmath.h) only for the retries after a rejected step.
   double* S = h->h_scal;   // host copy of the scalar block scal[0 .. TR_NSLOTS)
 
+  static const bool trace = getenv("MCBA_SOLVE_TRACE") != nullptr;   // host wall clock of the driver's stages (stderr)
+  auto mark = [&](const char* what) {
+    if (trace) fprintf(stderr, "[mcba_solve] %8.3f ms  %s\n", (now_seconds() - t_start) * 1e3, what);
+  };
+  mark("enter");
   upload_x(h, x_inout, h->x.p);
+  mark("x uploaded");
   float lin_ms_total = 0.f;
   // dx: linearise at that parameter vector (tables prepared by k_tmat itself); nullptr: the pose tables already hold the
   // point (the trial step's k_prep)
@@ -1370,11 +1383,15 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
   // them on the device first, so that the trial cost crosses the ranks as ONE double
   const int cost_grid = h->cost_blocks;
   const int cost_fetch = h->allreduce ? 1 : cost_grid;
-  // trial step for coefficients given by the host (retries) or by k_tr_step (tr_dev)
-  auto enqueue_trial = [&](double alpha, double beta, const double* tr_dev) {
-    hipLaunchKernelGGL(k_vec_step, dim3(sl.nvb), dim3(256), 0, h->stream, d, h->x.p, h->dsc.p, h->gh.p, h->gn.p, alpha, beta,
-                       h->xnew.p, h->scal.p + sl.step, tr_dev);
-    eval_pose_tables(h, h->xnew.p);   // k_cost forms the view chains itself; k_tmat rebuilds the view table if accepted
+  // trial step for coefficients given by the host (retries) or computed on the device (tr_dev)
+  // (tr_dev: k_vec_step first finishes the device-side algebra -- fold of the back-substitution's dots, 2-D subspace step;
+  //  its trailing workgroups write the pose / camera / board-point tables of x_new for k_cost, which forms the view chains
+  //  itself; k_tmat rebuilds the view table if the step is accepted)
+  const int prep_blocks = (d.n_pose + d.C + d.B * d.P + 255) / 256;
+  const int dot_blocks = (h->allreduce && d.DF > 0) ? 1 : gn_dot_blocks(d);   // (a shard gets the complete dots: one "block")
+  auto enqueue_trial = [&](double alpha, double beta, double* tr_dev) {
+    hipLaunchKernelGGL(k_vec_step, dim3(sl.nvb + prep_blocks), dim3(256), 0, h->stream, d, h->t, h->x.p, h->dsc.p, h->gh.p,
+                       h->gn.p, alpha, beta, h->xnew.p, h->scal.p + sl.step, tr_dev, h->scal.p + sl.dotp, dot_blocks, sl.nvb);
     h->ops->cost(d, h->t, h->stream, h->scal.p + sl.costp, cost_grid);   // (an empty shard writes partial[0] = 0)
     if (h->allreduce) {
       hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(64), 0, h->stream, h->scal.p + sl.costp, cost_grid);
@@ -1417,12 +1434,9 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
         hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(64), 0, h->stream, h->scal.p + sl.q00p, Q00_BLOCKS);
         call_allreduce(h, h->scal.p + sl.q00p, 1, 0);
       }
-      hipLaunchKernelGGL(k_tr_reg, dim3(1), dim3(64), 0, h->stream, h->scal.p, h->scal.p + sl.vs, sl.nvb,
-                         h->scal.p + sl.q00p, h->allreduce ? 1 : Q00_BLOCKS, first ? 1 : 0, Delta);
-      launch_gn_solve(h, 0.0, is_root, h->scal.p + sl.dotp, h->scal.p);
-      // (a handle that owns only a shard of the frames gets the three complete dots + the pivot report: one "block")
-      hipLaunchKernelGGL(k_tr_step, dim3(1), dim3(64), 0, h->stream, h->scal.p, h->scal.p + sl.dotp,
-                         (h->allreduce && d.DF > 0) ? 1 : gn_dot_blocks(d));
+      // (the fold of the k_vec_scale / k_q00 partials and the damping: head of the first kernel of the solve)
+      const TrRegPartials trp{h->scal.p + sl.vs, sl.nvb, h->scal.p + sl.q00p, h->allreduce ? 1 : Q00_BLOCKS, first ? 1 : 0, Delta};
+      launch_gn_solve(h, 0.0, is_root, h->scal.p + sl.dotp, h->scal.p, &trp);
       enqueue_trial(0.0, 0.0, h->scal.p);
       fetch_scalars_begin(h, trial_fetch_end);
       // Speculation: most trial steps are accepted, so the linearisation at x_new is enqueued right behind the copy and
@@ -1431,7 +1445,9 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
       // are rebuilt before anything reads them again.
       timed_linearize(h->xnew.p);   // (fused form: straight from x_new; table form: k_tmat re-derives its entries)
       spec_lin = true;
+      mark("iteration enqueued");
       fetch_scalars_end(h);
+      mark("trial cost fetched");
       have_trial = true;
     }
     if (fresh_lin) { collect_lin_time(); fresh_lin = false; }
@@ -1514,8 +1530,14 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
   }
   if (status == -100) status = 0;
 
-  HIP_OK(hipMemcpyAsync(x_inout, h->x.p, (size_t)d.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  mark("loop left");
+  // (through the pinned staging buffer, like every other small result.  Known one-time cost of the HIP runtime: ONE of the
+  //  first device-to-host copies of this size in a process spends ~8 ms inside hipMemcpyAsync on the host -- seen in the
+  //  first or second solve of a process at cfg3 (n = 6140), not at cfg2, pinned or pageable destination alike;
+  //  MCBA_SOLVE_TRACE=1 prints the driver's stage times)
+  HIP_OK(hipMemcpyAsync(h->h_x, h->x.p, (size_t)d.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   sync(h);
+  memcpy(x_inout, h->h_x, (size_t)d.n * sizeof(double));
   if (result) {
     result->cost = cost;
     result->initial_cost = initial_cost;
@@ -1524,6 +1546,7 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
     result->njev = njev;
     result->status = status;
     result->iterations = iteration;
+    mark("done");
     result->solve_seconds = now_seconds() - t_start;
     result->linearize_seconds = lin_ms_total * 1e-3;
   }

@@ -612,14 +612,58 @@ __global__ void k_dots3(int n, const double* __restrict__ u0, const double* __re
 // hundreds of them: a lane per system needs no cross-lane traffic at all (the block-per-frame version spent 39 us of
 // LDS latency in a single thread of each block).  Linv is stored dense [DF][DF] (zeros above the diagonal); y goes to
 // yf and to the EXTRA COLUMN ns of W (row stride ns + 1), so that the SYRK below also delivers W^T y.
+// One wavefront: folds the k_vec_scale / k_q00 partials, fixes the trust radius of the first iteration and computes the
+// damping of the Gauss-Newton solve; returns it in every lane.  S (may be null): the scalar block that receives the folded
+// values for the kernels and the host that read them later.
+__device__ __forceinline__ double tr_reg_wave(double* S, const double* __restrict__ vs_part, int nvb,
+                                              const double* __restrict__ q_part, int nq, int first, double Delta_in,
+                                              int lane) {
+  double mx = 0, gg = 0, xs = 0, q = 0;
+  for (int b = lane; b < nvb; b += 64) {
+    mx = fmax(mx, vs_part[3 * b]);
+    gg += vs_part[3 * b + 1];
+    xs += vs_part[3 * b + 2];
+  }
+  for (int b = lane; b < nq; b += 64) q += q_part[b];
+  mx = wave_max(mx);
+  gg = wave_sum(gg);
+  xs = wave_sum(xs);
+  q = wave_sum(q);
+  double reg = 0.0;
+  if (lane == 0) {
+    double Delta = Delta_in;
+    if (first) {   // trf.py:428-430
+      Delta = sqrt(xs);
+      if (Delta == 0) Delta = 1.0;
+    }
+    reg = gg > 0 ? tr_reg_term(q, gg, Delta) : TR_REG_FLOOR;
+    if (S != nullptr) {
+      S[TR_GNORM] = mx;
+      S[TR_GH2] = gg;
+      S[TR_XS2] = xs;
+      S[TR_Q00] = q;
+      S[TR_DELTA] = Delta;
+      S[TR_REG] = reg;
+    }
+  }
+  return __shfl(reg, 0, 64);
+}
+
 template <int DF>
 __global__ __launch_bounds__(64) void k_frame_factor(Dims d, const double* __restrict__ Hff, const double* __restrict__ dsc,
                                                      const double* __restrict__ gh, double reg, double* __restrict__ Linv,
                                                      double* __restrict__ W, double* __restrict__ yf,
-                                                     const double* __restrict__ tr = nullptr) {
+                                                     double* tr = nullptr, const double* __restrict__ vs_part = nullptr,
+                                                     int nvb = 0, const double* __restrict__ q_part = nullptr, int nq = 0,
+                                                     int first = 0, double Delta_in = 0.0) {
+  // tr != nullptr: the damping comes from the device-side trust-region algebra.  With the partials (vs_part) the kernel
+  // computes it itself -- every workgroup (one wavefront) folds the ~600 partial sums redundantly, workgroup 0 publishes the
+  // scalar block for k_schur_reduce, k_vec_step and the host (one launch less: k_tr_reg); without them it reads S[TR_REG].
+  if (tr != nullptr) reg = vs_part != nullptr ? tr_reg_wave(blockIdx.x == 0 ? tr : nullptr, vs_part, nvb, q_part, nq, first,
+                                                           Delta_in, threadIdx.x)
+                                              : tr[TR_REG];
   const int fl = blockIdx.x * blockDim.x + threadIdx.x;
   if (fl >= d.Fl) return;
-  if (tr != nullptr) reg = tr[TR_REG];   // damping computed on the device by k_tr_reg
   const int f = d.f0 + fl, ldw = d.ns + 1;
   const double* hff = Hff + (size_t)fl * DF * DF;
   double ds[DF], L[DF][DF], X[DF][DF];
@@ -1601,24 +1645,64 @@ __global__ __launch_bounds__(64) void k_schur_backsub(Dims d, const double* __re
   }
 }
 
+// folds the partial dots of the back-substitution, builds the 2-D subspace model and solves it for the current radius.
+// One wavefront; S may be the global scalar block or a copy of it.
+__device__ __forceinline__ void tr_step_wave(double* S, const double* __restrict__ dot_part, int nblk, int lane) {
+  double dt[3] = {0, 0, 0};
+  for (int b = lane; b < nblk; b += 64)
+    for (int k = 0; k < 3; ++k) dt[k] += dot_part[3 * b + k];
+  for (int k = 0; k < 3; ++k) dt[k] = wave_sum(dt[k]);
+  if (lane == 0) {
+    S[TR_D00] = dt[0];
+    S[TR_D01] = dt[1];
+    S[TR_D11] = dt[2];
+    S[TR_INFO] = dot_part[3 * nblk];
+    tr_subspace(S);
+    tr_trial(S, S[TR_DELTA]);
+  }
+}
+
 // step: p_h = alpha u0 + beta u1; step = d * p_h; x_new = x + step, one element per thread.
 // part[3 blk + {0,1,2}] = {|p_h|^2, |step|^2, |x|^2} of the block (folded by the host)
-__global__ __launch_bounds__(256) void k_vec_step(Dims d, const double* __restrict__ x, const double* __restrict__ dsc,
-                                                  const double* __restrict__ u0, const double* __restrict__ u1,
-                                                  double alpha, double beta, double* __restrict__ xnew,
-                                                  double* __restrict__ part, const double* __restrict__ tr = nullptr) {
+//
+// The kernel is also the END of the device-side trust-region algebra and the START of the trial evaluation (two launches
+// less per iteration, ~5 us of timeline each):
+//   * S != nullptr: the coefficients come from the 2-D subspace step.  The first wavefront of EVERY workgroup runs that
+//     scalar algebra (tr_step_wave: fold of the back-substitution's partial dots, subspace model, trial step) on a copy of
+//     the scalar block in LDS -- redundant, identical arithmetic -- and workgroup 0 publishes the block for the host.
+//   * workgroups behind the nvb vector blocks (prep_blocks of them, 0 = none) form the pose / camera / board-point table
+//     entries of the trial point for k_cost; they evaluate the entries of x_new they need with the same two fused
+//     operations as the vector blocks (StepX), so they do not wait for x_new to be stored.
+__global__ __launch_bounds__(256) void k_vec_step(Dims d, Tables t, const double* __restrict__ x,
+                                                  const double* __restrict__ dsc, const double* __restrict__ u0,
+                                                  const double* __restrict__ u1, double alpha, double beta,
+                                                  double* __restrict__ xnew, double* __restrict__ part, double* S,
+                                                  const double* __restrict__ dot_part, int nblk, int nvb) {
   __shared__ double scratch[16];
-  if (tr != nullptr) {   // coefficients computed on the device by k_tr_step
-    alpha = tr[TR_ALPHA];
-    beta = tr[TR_BETA];
+  __shared__ double Sl[TR_NSLOTS];
+  if (S != nullptr) {
+    if (threadIdx.x < 64) {
+      const int lane = threadIdx.x;
+      if (lane < TR_NSLOTS) Sl[lane] = S[lane];
+      lds_fence();
+      tr_step_wave(Sl, dot_part, nblk, lane);
+    }
+    __syncthreads();
+    alpha = Sl[TR_ALPHA];
+    beta = Sl[TR_BETA];
+    if (blockIdx.x == 0 && threadIdx.x < TR_NSLOTS) S[threadIdx.x] = Sl[threadIdx.x];
+  }
+  if ((int)blockIdx.x >= nvb) {
+    prep_item(d, t, StepX{x, dsc, u0, u1, alpha, beta}, ((int)blockIdx.x - nvb) * blockDim.x + threadIdx.x);
+    return;
   }
   double ph = 0, st = 0, xx = 0;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < d.n) {
-    const double p = alpha * u0[i] + beta * u1[i];
+    const double p = step_direction(alpha, u0[i], beta, u1[i]);
     const double s = dsc[i] * p;
     const double xi = x[i];
-    xnew[i] = xi + s;
+    xnew[i] = step_point(xi, dsc[i], p);
     ph = p * p;
     st = s * s;
     xx = xi * xi;
@@ -1633,8 +1717,6 @@ __global__ __launch_bounds__(256) void k_vec_step(Dims d, const double* __restri
   }
 }
 
-// frame-sharded handles: fold a per-block partial array into its first element BEFORE the cross-rank sum, so that the
-// collective carries one double instead of the whole array (fixed order: deterministic)
 __global__ __launch_bounds__(64) void k_fold_partials(double* __restrict__ part, int n) {
   double s = 0.0;
   for (int b = threadIdx.x; b < n; b += 64) s += part[b];
@@ -1646,52 +1728,12 @@ __global__ __launch_bounds__(64) void k_fold_partials(double* __restrict__ part,
 // one-wave kernels that keep the scalar trust-region algebra on the device between the vector kernels (single-GPU
 // driver: one host synchronisation per iteration).  S = scal[0 .. TR_NSLOTS), see mcba_trmath.h.
 // ---------------------------------------------------------------------------------------------------------------
-// folds the k_vec_scale / k_q00 partials, fixes the trust radius of the first iteration and computes the damping
+// (stand-alone form of tr_reg_wave: problems without eliminated frame blocks, where k_frame_factor is not launched)
 __global__ __launch_bounds__(64) void k_tr_reg(double* __restrict__ S, const double* __restrict__ vs_part, int nvb,
                                                const double* __restrict__ q_part, int nq, int first, double Delta_in) {
-  const int lane = threadIdx.x;
-  double mx = 0, gg = 0, xs = 0, q = 0;
-  for (int b = lane; b < nvb; b += 64) {
-    mx = fmax(mx, vs_part[3 * b]);
-    gg += vs_part[3 * b + 1];
-    xs += vs_part[3 * b + 2];
-  }
-  for (int b = lane; b < nq; b += 64) q += q_part[b];
-  mx = wave_max(mx);
-  gg = wave_sum(gg);
-  xs = wave_sum(xs);
-  q = wave_sum(q);
-  if (lane == 0) {
-    double Delta = Delta_in;
-    if (first) {   // trf.py:428-430
-      Delta = sqrt(xs);
-      if (Delta == 0) Delta = 1.0;
-    }
-    S[TR_GNORM] = mx;
-    S[TR_GH2] = gg;
-    S[TR_XS2] = xs;
-    S[TR_Q00] = q;
-    S[TR_DELTA] = Delta;
-    S[TR_REG] = gg > 0 ? tr_reg_term(q, gg, Delta) : TR_REG_FLOOR;
-  }
+  tr_reg_wave(S, vs_part, nvb, q_part, nq, first, Delta_in, threadIdx.x);
 }
 
-// folds the partial dots of the back-substitution, builds the 2-D subspace model and solves it for the current radius
-__global__ __launch_bounds__(64) void k_tr_step(double* __restrict__ S, const double* __restrict__ dot_part, int nblk) {
-  const int lane = threadIdx.x;
-  double dt[3] = {0, 0, 0};
-  for (int b = lane; b < nblk; b += 64)
-    for (int k = 0; k < 3; ++k) dt[k] += dot_part[3 * b + k];
-  for (int k = 0; k < 3; ++k) dt[k] = wave_sum(dt[k]);
-  if (lane == 0) {
-    S[TR_D00] = dt[0];
-    S[TR_D01] = dt[1];
-    S[TR_D11] = dt[2];
-    S[TR_INFO] = dot_part[3 * nblk];
-    tr_subspace(S);
-    tr_trial(S, S[TR_DELTA]);
-  }
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // outlier loop on the device (Calibration.reject_outliers / report, calibration.py:240-252,290-310):

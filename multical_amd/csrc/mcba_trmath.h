@@ -1,7 +1,7 @@
 // mcba_trmath.h -- the scalar algebra of scipy's trust-region-reflective driver without bounds
 // (scipy/optimize/_lsq/trf.py:trf_no_bounds, common.py): Cauchy regularisation, the 2-D subspace problem, the radius
 // update and the termination tests.  __host__ __device__: the single-GPU driver evaluates it in one-thread kernels
-// between the vector kernels (k_tr_reg, k_tr_step in mcba_solver_kernels.h) so that an iteration needs one host
+// between the vector kernels (k_tr_reg and the head of k_vec_step in mcba_solver_kernels.h) so that an iteration needs one host
 // synchronisation instead of three; the host runs the SAME source for rejected trial steps and for frame-sharded
 // handles.  No std:: containers or std::complex here.
 #pragma once

@@ -18,6 +18,24 @@ MCBA_HD double param_value(const Tables& t, const double* x, int j) {
 // the same value without the dependent read of the full -> active index map: the caller names the block (offsets inside
 // the active vector x and inside the full vector come from Dims) -- one memory round trip less on the latency-bound
 // table kernels
+// The active vector may also be one that is not stored anywhere yet: StepX evaluates entry i of the trial point
+// x + D (alpha u0 + beta u1) exactly as k_vec_step stores it (same two fused operations), so that the table entries of a
+// trial point can be formed by the kernel that produces the point.
+struct PlainX {
+  const double* x;
+  MCBA_HD double operator()(int i) const { return x[i]; }
+};
+MCBA_HD double step_direction(double alpha, double u0, double beta, double u1) { return fma(alpha, u0, beta * u1); }
+MCBA_HD double step_point(double x, double dsc, double p) { return fma(dsc, p, x); }
+struct StepX {
+  const double* x; const double* dsc; const double* u0; const double* u1;
+  double alpha, beta;
+  MCBA_HD double operator()(int i) const { return step_point(x[i], dsc[i], step_direction(alpha, u0[i], beta, u1[i])); }
+};
+template <class XV>
+MCBA_HD double block_value(const Tables& t, const XV& xv, int off_active, int off_full, int i) {
+  return off_active >= 0 ? xv(off_active + i) : t.xfull[off_full + i];
+}
 MCBA_HD double block_value(const Tables& t, const double* x, int off_active, int off_full, int i) {
   return off_active >= 0 ? x[off_active + i] : t.xfull[off_full + i];
 }
@@ -429,7 +447,8 @@ MCBA_HD double point_rows(const Dims& d, const Tables& t, int v, int c, int b, i
 // ---------------------------------------------------------------------------------------------------------------
 // table preparation (bodies of k_prep / k_views)
 // ---------------------------------------------------------------------------------------------------------------
-MCBA_HD void prep_item(const Dims& d, const Tables& t, const double* x, int i) {
+template <class XV>
+MCBA_HD void prep_item(const Dims& d, const Tables& t, const XV& x, int i) {
   if (i < d.n_pose) {
     int oa, of, r;
     if (i < d.pose_board) { oa = d.off_campose; of = d.foff_campose; r = 6 * i; }
@@ -462,6 +481,7 @@ MCBA_HD void prep_item(const Dims& d, const Tables& t, const double* x, int i) {
       t.board_points[3 * i + k] = (p < nb) ? block_value(t, x, d.off_boards, d.foff_boards, 3 * (t.board_off[b] + p) + k) : 0.0;
   }
 }
+MCBA_HD void prep_item(const Dims& d, const Tables& t, const double* x, int i) { prep_item(d, t, PlainX{x}, i); }
 
 // chain matrix board -> camera of view (f, c, b), chain ch (rolling shutter: 0 = start pose, 1 = end pose): out[12] = R | t
 MCBA_HD void view_chain(const Dims& d, const PoseSrc& ps, const double* bwg, int f, int c, int b, int ch, double* out) {
