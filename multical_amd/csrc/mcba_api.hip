@@ -94,7 +94,7 @@ struct DevBuf {
 };
 
 constexpr int SEL_NEXT_BLOCKS = 256;    // workgroups (= per-block partials) of k_selm_next
-constexpr int COST_BLOCKS_MAX = 3072;   // persistent single-wave workgroups of k_cost (see LIN_GRID_MAX)
+constexpr int COST_BLOCKS_MAX = 4608;   // persistent single-wave workgroups of k_cost (see LIN_GRID_MAX; one view each at cfg3)
 // Scalars and per-block partial sums fetched by the trust-region driver: ONE contiguous device-to-host copy per
 // iteration.  Partials are folded in a fixed order by the one-wave driver kernels or by the host, which saves the tiny
 // final-sum kernels and device-to-device copies of a latency-bound loop (every launch costs ~5 us of GPU timeline).

@@ -118,6 +118,8 @@ __device__ __forceinline__ double block_reduce(double v, double* scratch /*[16]*
 //  same-address atomic serialises 500-1000 tickets into 40-90 us.  Single-GPU solves copy the partials to the host with
 //  the scalars they already fetch instead; sharded solves keep the small final-sum kernels.)
 
+constexpr int LIN_MAX_POINTS = 512;    // points per board supported by the compaction lists (mcba_create checks it)
+
 // ---------------------------------------------------------------------------------------------------------------
 // k_residual: evaluate() of optimization/calibration.py:204-206 (+ projections and per-slot errors of
 //             tables.reprojection_error, tables.py:244-249).  ONE WAVEFRONT PER VIEW (four views per 256-thread block):
@@ -135,6 +137,56 @@ __global__ __launch_bounds__(256) void k_residual(Dims d, Tables t, const int32_
   const int lane = threadIdx.x & 63;
   const int nv = d.views();
   const bool all_slots = proj != nullptr || err != nullptr;
+  if (!all_slots) {
+    // residuals only (evaluate(), the hot entry): like k_cost, the inlier bytes of a view are ballot-compacted into a point
+    // list first and the projections run on dense 64-lane chunks -- a loop over the table slots evaluated the forward
+    // model for every 64-slot group although 29 % of the slots of the north-star rig hold an inlier (VALU-bound on idle
+    // lanes).  Residual i of the view's list goes to first[v] + i: the list order is the slot order.
+    __shared__ uint16_t plist[4][LIN_MAX_POINTS];
+    uint16_t* pidx = plist[threadIdx.x >> 6];
+    const int n_active = t.active_views[0];
+    constexpr int NPB64 = LIN_MAX_POINTS / 64;
+    for (int vi = blockIdx.x * 4 + (threadIdx.x >> 6); vi < n_active; vi += gridDim.x * 4) {
+      const int v = __builtin_amdgcn_readfirstlane(t.active_views[1 + vi]);
+      const int b = v % d.B, c = (v / d.B) % d.C;
+      const size_t out0 = (size_t)first[v];
+      uint8_t inb[NPB64];
+#pragma unroll
+      for (int k = 0; k < NPB64; ++k) inb[k] = masked_load_row(t.inlier + (size_t)v * d.P, k * 64 + lane, d.P);
+      int count = 0;
+#pragma unroll
+      for (int k = 0; k < NPB64; ++k) {
+        const bool in = inb[k] != 0;
+        const unsigned long long m = __ballot(in);
+        if (in) pidx[count + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(k * 64 + lane);
+        count += __popcll(m);
+      }
+      lds_fence();
+      int p_cur = lane < count ? pidx[lane] : 0;
+      double2 ob_cur = t.obs[(size_t)v * d.P + p_cur];
+      double X_cur[3], X_nxt[3];
+      for (int k = 0; k < 3; ++k) X_cur[k] = t.board_points[3 * (size_t)(b * d.P + p_cur) + k];
+      for (int base = 0; base < count; base += 64) {
+        const int i = base + lane, inx = i + 64;
+        const int p_nxt = inx < count ? pidx[inx] : p_cur;
+        const double2 ob_nxt = t.obs[(size_t)v * d.P + p_nxt];
+        for (int k = 0; k < 3; ++k) X_nxt[k] = t.board_points[3 * (size_t)(b * d.P + p_nxt) + k];
+        if (i < count) {
+          double uv[2], Xs[3], Xe[3], tr;
+          slot_forward<ND, FISH, ROLL, false>(d, t, v, c, b, p_cur, ob_cur, uv, nullptr, nullptr, Xs, Xe, tr, X_cur);
+          double2 e2;
+          e2.x = uv[0] - ob_cur.x;
+          e2.y = uv[1] - ob_cur.y;
+          reinterpret_cast<double2*>(r)[out0 + i] = e2;
+        }
+        p_cur = p_nxt;
+        ob_cur = ob_nxt;
+        for (int k = 0; k < 3; ++k) X_cur[k] = X_nxt[k];
+      }
+      lds_fence();   // the next view rewrites the list
+    }
+    return;
+  }
   for (int vw = blockIdx.x * 4 + (threadIdx.x >> 6); vw < nv; vw += gridDim.x * 4) {
     const int v = __builtin_amdgcn_readfirstlane(vw);             // wave-uniform: everything derived from it is scalar
     if (!all_slots && t.view_count[v] == 0) continue;
@@ -215,8 +267,6 @@ __global__ void k_project_model(Dims d, Tables t, int iterations, double* __rest
 // a view are ballot-compacted into a point list first, so the projections run on dense 64-lane chunks (about a quarter
 // of the table slots of a real rig hold an inlier; a thread-per-slot loop idles three lanes out of four).
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int LIN_MAX_POINTS = 512;    // points per board supported by the compaction lists (mcba_create checks it)
-
 template <int ND, bool FISH, bool ROLL>
 __global__ __launch_bounds__(64) void k_cost(Dims d, Tables t, double* __restrict__ partial) {
   __shared__ uint16_t pidx[LIN_MAX_POINTS];
@@ -247,17 +297,26 @@ __global__ __launch_bounds__(64) void k_cost(Dims d, Tables t, double* __restric
       count += __popcll(m);
     }
     lds_fence();
+    // observation + board point of the NEXT chunk are requested before the current one is evaluated (as in k_linearize)
+    int p_cur = lane < count ? pidx[lane] : 0;
+    double2 ob_cur = t.obs[(size_t)v * d.P + p_cur];
+    double X_cur[3], X_nxt[3];
+    for (int k = 0; k < 3; ++k) X_cur[k] = t.board_points[3 * (size_t)(b * d.P + p_cur) + k];
     for (int base = 0; base < count; base += 64) {
-      const int i = base + lane;
+      const int i = base + lane, inx = i + 64;
+      const int p_nxt = inx < count ? pidx[inx] : p_cur;
+      const double2 ob_nxt = t.obs[(size_t)v * d.P + p_nxt];
+      for (int k = 0; k < 3; ++k) X_nxt[k] = t.board_points[3 * (size_t)(b * d.P + p_nxt) + k];
       if (i < count) {
-        const int p = pidx[i];
-        const double2 ob = t.obs[(size_t)v * d.P + p];
         double uv[2], Xs[3], Xe[3], tr;
-        slot_forward<ND, FISH, ROLL, false>(d, t, v, c, b, p, ob, uv, nullptr, nullptr, Xs, Xe, tr, nullptr, Vc);
+        slot_forward<ND, FISH, ROLL, false>(d, t, v, c, b, p_cur, ob_cur, uv, nullptr, nullptr, Xs, Xe, tr, X_cur, Vc);
         double rs, fs;
-        acc += robust_loss(d.loss, d.f_scale, uv[0] - ob.x, &rs, &fs);
-        acc += robust_loss(d.loss, d.f_scale, uv[1] - ob.y, &rs, &fs);
+        acc += robust_loss(d.loss, d.f_scale, uv[0] - ob_cur.x, &rs, &fs);
+        acc += robust_loss(d.loss, d.f_scale, uv[1] - ob_cur.y, &rs, &fs);
       }
+      p_cur = p_nxt;
+      ob_cur = ob_nxt;
+      for (int k = 0; k < 3; ++k) X_cur[k] = X_nxt[k];
     }
     lds_fence();   // the next view rewrites the list
   }
