@@ -232,7 +232,11 @@ def main():
                   algorithmic_bytes=alg_bytes,
                   hbm=dict(achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS),
                   residual_kernel=dict(bound="hbm", launch_ms=res_ms, achieved=alg_bytes / (res_ms * 1e-3) / 1e9,
-                                       frac=alg_bytes / (res_ms * 1e-3) / 1e9 / HBM_PEAK_GBS))
+                                       frac=alg_bytes / (res_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                       note="algorithmic bytes (17 B per table slot + 16 B per observation) over the launch "
+                                            "time; the kernel gathers the observations of the inlier slots only (mask bytes "
+                                            "compacted per view), so the bytes it moves are below the algorithmic figure "
+                                            "(PMC: profiles/r02_pmc.json)"))
   # HBM bytes per launch from the PMC counters: they cannot be read inside an un-profiled run, so the figure of the
   # committed rocprofv3 passes of the same command is quoted and labelled as such (profiles/hbm_traffic.json: separate
   # --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction)

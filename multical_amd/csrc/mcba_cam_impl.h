@@ -33,10 +33,11 @@ void project_model(const Dims& d, const Tables& t, hipStream_t s, int iterations
 }
 
 void cost(const Dims& d, const Tables& t, hipStream_t s, double* partial, int nblk) {
-  if (d.motion == MOTION_ROLLING)
-    hipLaunchKernelGGL((k_cost<ND_, FISH_, true>), dim3(nblk), dim3(64), 0, s, d, t, partial);
-  else
-    hipLaunchKernelGGL((k_cost<ND_, FISH_, false>), dim3(nblk), dim3(64), 0, s, d, t, partial);
+  const bool roll = d.motion == MOTION_ROLLING, robust = d.loss != 0;
+  if (roll && robust) hipLaunchKernelGGL((k_cost<ND_, FISH_, true, true>), dim3(nblk), dim3(64), 0, s, d, t, partial);
+  else if (roll) hipLaunchKernelGGL((k_cost<ND_, FISH_, true, false>), dim3(nblk), dim3(64), 0, s, d, t, partial);
+  else if (robust) hipLaunchKernelGGL((k_cost<ND_, FISH_, false, true>), dim3(nblk), dim3(64), 0, s, d, t, partial);
+  else hipLaunchKernelGGL((k_cost<ND_, FISH_, false, false>), dim3(nblk), dim3(64), 0, s, d, t, partial);
 }
 
 void jacobian(const Dims& d, const Tables& t, hipStream_t s, int row_nnz, double* vals, int32_t* cols) {

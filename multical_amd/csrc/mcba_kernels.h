@@ -267,9 +267,51 @@ __global__ void k_project_model(Dims d, Tables t, int iterations, double* __rest
 // a view are ballot-compacted into a point list first, so the projections run on dense 64-lane chunks (about a quarter
 // of the table slots of a real rig hold an inlier; a thread-per-slot loop idles three lanes out of four).
 // ---------------------------------------------------------------------------------------------------------------
-template <int ND, bool FISH, bool ROLL>
+// entry q of the rigid product (R1 | t1) . (R2 | t2) = (R1 R2 | R1 t2 + t1); A, B: R[9] t[3] (the expressions of se3_mul)
+__device__ __forceinline__ double se3_mul_entry(const double* A, const double* B, int q) {
+  if (q < 9) {
+    const int i = q / 3, j = q % 3;
+    return A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+  }
+  const int i = q - 9;
+  return (A[3 * i] * B[9] + A[3 * i + 1] * B[10] + A[3 * i + 2] * B[11]) + A[9 + i];
+}
+
+// Chain matrices board -> camera of view (f, c, b) straight from the pose table, by the lanes of ONE wavefront: lane
+// (chain, entry) forms one entry of each product, the intermediate goes through LDS (tmp [2][12], out [NCH][VIEW_STRIDE]).
+// The same matrices as view_chain; formed by every lane in registers they kept 36 doubles live (k_cost: 191 VGPRs).
+template <bool ROLL>
+__device__ __forceinline__ void view_chain_wave(const Dims& d, const Tables& t, int f, int c, int b, int lane,
+                                                double* tmp, double* out) {
+  const double* Pc = t.pose + (size_t)(d.pose_cam + c) * POSE_STRIDE;
+  const double* Pb = t.pose + (size_t)(d.pose_board + b) * POSE_STRIDE;
+  const double* Pm = t.pose + (size_t)d.pose_motion * POSE_STRIDE;
+  constexpr int NCH = ROLL ? 2 : 1;
+  const int ch = lane / 12, q = lane % 12;
+  const bool on = lane < 12 * NCH;
+  if (d.motion == MOTION_HAND_EYE) {   // camera . G . B_f . Wb . board  (mot[0] = world_wrt_base, mot[1] = gripper_wrt_camera)
+    if (on) tmp[q] = se3_mul_entry(Pc, Pm + POSE_STRIDE, q);
+    lds_fence();
+    if (on) tmp[12 + q] = se3_mul_entry(tmp, t.bwg + 12 * (size_t)f, q);
+    lds_fence();
+    if (on) tmp[q] = se3_mul_entry(tmp + 12, Pm, q);
+    lds_fence();
+    if (on) out[q] = se3_mul_entry(tmp, Pb, q);
+  } else {
+    const double* Pf = Pm + (size_t)((on ? ch : 0) * d.F + f) * POSE_STRIDE;
+    if (on) tmp[12 * ch + q] = se3_mul_entry(Pc, Pf, q);
+    lds_fence();
+    if (on) out[VIEW_STRIDE * ch + q] = se3_mul_entry(tmp + 12 * ch, Pb, q);
+  }
+  lds_fence();
+}
+
+// ROBUST = false: the linear loss compiled in (the loss switch pulls log1p / atan into the kernel: 182 VGPRs = 2 waves per
+// SIMD, i.e. two rounds of workgroups at the north-star rig)
+template <int ND, bool FISH, bool ROLL, bool ROBUST>
 __global__ __launch_bounds__(64) void k_cost(Dims d, Tables t, double* __restrict__ partial) {
   __shared__ uint16_t pidx[LIN_MAX_POINTS];
+  __shared__ double Vc[2 * VIEW_STRIDE], Vtmp[24];   // chain matrices of the view, intermediate products
   const int lane = threadIdx.x;
   const int n_active = t.active_views[0];
   double acc = 0.0;
@@ -278,9 +320,7 @@ __global__ __launch_bounds__(64) void k_cost(Dims d, Tables t, double* __restric
     const int b = v % d.B, c = (v / d.B) % d.C, f = d.f0 + v / (d.B * d.C);
     // the chain matrices of the view straight from the pose table (wave-uniform work, done by every lane): a trial step
     // then needs k_prep only, not the per-view table pass k_views
-    double Vc[ROLL ? 2 * VIEW_STRIDE : VIEW_STRIDE];
-    view_chain(d, t, f, c, b, 0, Vc);
-    if constexpr (ROLL) view_chain(d, t, f, c, b, 1, Vc + VIEW_STRIDE);
+    view_chain_wave<ROLL>(d, t, f, c, b, lane, Vtmp, Vc);
     constexpr int NPB64 = LIN_MAX_POINTS / 64;
     uint8_t inb[NPB64];
 #pragma unroll
@@ -311,8 +351,9 @@ __global__ __launch_bounds__(64) void k_cost(Dims d, Tables t, double* __restric
         double uv[2], Xs[3], Xe[3], tr;
         slot_forward<ND, FISH, ROLL, false>(d, t, v, c, b, p_cur, ob_cur, uv, nullptr, nullptr, Xs, Xe, tr, X_cur, Vc);
         double rs, fs;
-        acc += robust_loss(d.loss, d.f_scale, uv[0] - ob_cur.x, &rs, &fs);
-        acc += robust_loss(d.loss, d.f_scale, uv[1] - ob_cur.y, &rs, &fs);
+        const int loss = ROBUST ? d.loss : 0;
+        acc += robust_loss(loss, d.f_scale, uv[0] - ob_cur.x, &rs, &fs);
+        acc += robust_loss(loss, d.f_scale, uv[1] - ob_cur.y, &rs, &fs);
       }
       p_cur = p_nxt;
       ob_cur = ob_nxt;

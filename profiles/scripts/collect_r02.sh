@@ -17,5 +17,8 @@ python tests/prof_init.py cfg2 cfg3 cfg4 > $O/init.log 2>&1; cat $O/init.log
 MCBA_FUSED=1 python bench.py --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_fused.json 2>/dev/null; grep -o '"ms_per_step": [0-9.]*' $O/bench_fused.json | head -1
 MCBA_TIMING=1 python tests/prof_workspace.py cfg4 2>&1 | grep 'calibrate ms'
 MCBA_TIMING=1 python tests/prof_workspace.py cfg2 2>&1 | grep 'calibrate ms'
+python tests/prof_chol_phases.py > $O/chol_phases.log 2>&1; tail -9 $O/chol_phases.log
+python tests/prof_dispatch.py > $O/dispatch.log 2>&1; tail -16 $O/dispatch.log
+python tests/prof_solve_repeat.py cfg3 > $O/solve_repeat.log 2>&1; head -4 $O/solve_repeat.log
 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; grep -E 'passed|failed' $O/pytest_gpu.log
 ls $O $O/pmc
