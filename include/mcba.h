@@ -148,6 +148,10 @@ int32_t mcba_full_size(const mcba_problem* p, int64_t* out);
  * sparsity build (calibration.py:173-196).  `hip_stream` may be NULL.                                          */
 int32_t mcba_create(const mcba_problem* p, void* hip_stream, mcba_handle* out);
 int32_t mcba_destroy(mcba_handle h);
+/* mcba_destroy parks the handle's device buffers, pinned buffers and stream in a process-wide cache (bounded: 4 GB of device
+ * memory) so that the next mcba_create of a problem of the same shape does not pay for ~50 allocations again
+ * (Workspace.calibrate creates one handle per call).  This returns everything in the cache to the HIP runtime.         */
+int32_t mcba_release_cached_memory(void);
 const char* mcba_last_error(void);
 /* "gfx950:<device name>" of the device the handle lives on                                                    */
 int32_t mcba_device_info(mcba_handle h, char* buf, size_t buf_len);

@@ -55,6 +55,7 @@ SYMBOLS = [
   ("mcba_full_size", C.c_int32, [C.POINTER(Problem), C.POINTER(C.c_int64)]),
   ("mcba_create", C.c_int32, [C.POINTER(Problem), C.c_void_p, C.POINTER(H)]),
   ("mcba_destroy", C.c_int32, [H]),
+  ("mcba_release_cached_memory", C.c_int32, []),
   ("mcba_device_info", C.c_int32, [H, C.c_char_p, C.c_size_t]),
   ("mcba_num_params", C.c_int32, [H, C.POINTER(C.c_int64)]),
   ("mcba_num_residuals", C.c_int32, [H, C.POINTER(C.c_int64)]),

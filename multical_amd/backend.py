@@ -418,6 +418,11 @@ class Handle(object):
     return ms.value
 
 
+def release_cached_memory():
+  """Return the device buffers, pinned buffers and streams that closed handles left in the library's cache to the runtime."""
+  check(_lib.load().mcba_release_cached_memory())
+
+
 def mfma_probe(V):
   lib = _lib.load()
   V = _f64(V)

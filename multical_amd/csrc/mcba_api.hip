@@ -18,7 +18,9 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -53,6 +55,91 @@ struct Error : std::runtime_error {
 
 thread_local hipStream_t g_fill_stream = nullptr;   // stream of the running API call (see DevBuf::alloc)
 
+// ---------------------------------------------------------------------------------------------------------------
+// Process-wide cache of the resources a handle owns.  A Workspace.calibrate creates one handle per Calibration and
+// destroys it afterwards: ~50 hipMalloc / hipFree pairs, four pinned host buffers and a stream cost more than the three
+// bundle adjustments they serve (4 ms of a 15 ms calibrate at the north-star rig).  mcba_destroy parks them here (its
+// stream is idle by then) and the next mcba_create of a problem of the same shape takes them back, exact size match only.
+// Bounded (CACHE_BYTES_MAX of device memory); mcba_release_cached_memory() returns everything to the runtime.
+// ---------------------------------------------------------------------------------------------------------------
+struct ResourceCache {
+  static constexpr size_t CACHE_BYTES_MAX = 4ull << 30, HOST_BYTES_MAX = 64ull << 20;
+  std::mutex m;
+  std::multimap<std::pair<int, size_t>, void*> dev, host;   // (device, bytes) -> pointer
+  std::vector<std::pair<int, hipStream_t>> streams;
+  size_t dev_bytes = 0, host_bytes = 0;
+  static int device() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    return d;
+  }
+  void* take(std::multimap<std::pair<int, size_t>, void*>& pool, size_t& total, size_t bytes) {
+    std::lock_guard<std::mutex> lock(m);
+    auto it = pool.find({device(), bytes});
+    if (it == pool.end()) return nullptr;
+    void* p = it->second;
+    pool.erase(it);
+    total -= bytes;
+    return p;
+  }
+  bool park(std::multimap<std::pair<int, size_t>, void*>& pool, size_t& total, size_t cap, void* p, size_t bytes) {
+    std::lock_guard<std::mutex> lock(m);
+    if (total + bytes > cap) return false;
+    pool.insert({{device(), bytes}, p});
+    total += bytes;
+    return true;
+  }
+  void* take_dev(size_t bytes) { return take(dev, dev_bytes, bytes); }
+  void* take_host(size_t bytes) { return take(host, host_bytes, bytes); }
+  bool park_dev(void* p, size_t bytes) { return park(dev, dev_bytes, CACHE_BYTES_MAX, p, bytes); }
+  bool park_host(void* p, size_t bytes) { return park(host, host_bytes, HOST_BYTES_MAX, p, bytes); }
+  hipStream_t take_stream() {
+    std::lock_guard<std::mutex> lock(m);
+    const int d = device();
+    for (size_t i = 0; i < streams.size(); ++i)
+      if (streams[i].first == d) {
+        hipStream_t s = streams[i].second;
+        streams.erase(streams.begin() + i);
+        return s;
+      }
+    return nullptr;
+  }
+  bool park_stream(hipStream_t s) {
+    std::lock_guard<std::mutex> lock(m);
+    if (streams.size() >= 4) return false;
+    streams.push_back({device(), s});
+    return true;
+  }
+  void clear() {
+    std::lock_guard<std::mutex> lock(m);
+    for (auto& e : dev) (void)hipFree(e.second);
+    for (auto& e : host) (void)hipHostFree(e.second);
+    for (auto& e : streams) (void)hipStreamDestroy(e.second);
+    dev.clear(); host.clear(); streams.clear();
+    dev_bytes = host_bytes = 0;
+  }
+};
+ResourceCache& resource_cache() {
+  static ResourceCache* c = new ResourceCache();   // (never destroyed: the HIP runtime may be gone at exit)
+  return *c;
+}
+thread_local bool g_park_on_release = false;   // set by mcba_destroy while the handle's members go away
+
+// pinned host memory through the cache (hipHostMalloc is ~0.2 ms a call)
+void* pinned_alloc(size_t bytes) {
+  bytes = std::max<size_t>(bytes, 8);
+  if (void* p = resource_cache().take_host(bytes)) return p;
+  void* p = nullptr;
+  hipError_t e = hipHostMalloc(&p, bytes);
+  if (e != hipSuccess) throw std::runtime_error(std::string("hipHostMalloc failed: ") + hipGetErrorString(e));
+  return p;
+}
+void pinned_free(void* p, size_t bytes) {
+  bytes = std::max<size_t>(bytes, 8);
+  if (p == nullptr) return;
+  if (!(g_park_on_release && resource_cache().park_host(p, bytes))) (void)hipHostFree(p);
+}
+
 template <class T>
 struct DevBuf {
   T* p = nullptr;
@@ -61,8 +148,9 @@ struct DevBuf {
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
   ~DevBuf() { release(); }
+  static size_t bytes_of(size_t count) { return (std::max<size_t>(count, 1) * sizeof(T) + 511) / 512 * 512; }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p && !(g_park_on_release && resource_cache().park_dev(p, bytes_of(n)))) (void)hipFree(p);
     p = nullptr;
     n = 0;
   }
@@ -71,7 +159,8 @@ struct DevBuf {
     if (p == nullptr || n < count) {   // (a buffer that is large enough is reused: hipFree / hipMalloc cost ~100 us each)
       release();
       n = count;
-      HIP_OK(hipMalloc((void**)&p, bytes));
+      p = (T*)resource_cache().take_dev(bytes_of(count));
+      if (p == nullptr) HIP_OK(hipMalloc((void**)&p, bytes_of(count)));
     }
     if (zero) {
       // zero-fill ON THE HANDLE'S STREAM (g_fill_stream is set by every API entry that allocates): ordered against the
@@ -186,16 +275,17 @@ struct mcba_handle_s {
 
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fetch = nullptr;
 
+  size_t h_scal_bytes = 0, h_x_bytes = 0, h_gbuf_bytes = 0, h_totals_bytes = 0;   // sizes of the pinned buffers
   ~mcba_handle_s() {
-    if (h_scal) (void)hipHostFree(h_scal);
-    if (h_x) (void)hipHostFree(h_x);
-    if (h_gbuf) (void)hipHostFree(h_gbuf);
-    if (h_totals) (void)hipHostFree(h_totals);
+    pinned_free(h_scal, h_scal_bytes);
+    pinned_free(h_x, h_x_bytes);
+    pinned_free(h_gbuf, h_gbuf_bytes);
+    pinned_free(h_totals, h_totals_bytes);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     if (ev_fetch) (void)hipEventDestroy(ev_fetch);
     if (rccl_comm) destroy_rccl_comm(rccl_comm);
-    if (own_stream && stream) (void)hipStreamDestroy(stream);
+    if (own_stream && stream && !(g_park_on_release && resource_cache().park_stream(stream))) (void)hipStreamDestroy(stream);
   }
   double* g() { return gbuf.p; }
   double* diag() { return gbuf.p + d.n; }
@@ -739,7 +829,8 @@ int32_t mcba_create(const mcba_problem* p, void* hip_stream, mcba_handle* out) {
   if (hip_stream) {
     h->stream = (hipStream_t)hip_stream;
   } else {
-    HIP_OK(hipStreamCreate(&h->stream));
+    h->stream = resource_cache().take_stream();
+    if (h->stream == nullptr) HIP_OK(hipStreamCreate(&h->stream));
     h->own_stream = true;
   }
   if (const char* env = getenv("MCBA_NO_MFMA")) h->use_mfma = !(env[0] == '1');
@@ -763,7 +854,8 @@ int32_t mcba_create(const mcba_problem* p, void* hip_stream, mcba_handle* out) {
   h->view_count.alloc((size_t)d.views(), false);
   h->view_first.alloc((size_t)d.views(), false);
   h->totals.alloc(2);
-  HIP_OK(hipHostMalloc((void**)&h->h_totals, 2 * sizeof(long long)));
+  h->h_totals_bytes = 2 * sizeof(long long);
+  h->h_totals = (long long*)pinned_alloc(h->h_totals_bytes);
   h->board_off.upload(hp.board_off);
   h->cam_valid.upload(std::vector<uint8_t>(p->camera_valid, p->camera_valid + d.C));
   h->frame_valid.upload(std::vector<uint8_t>(p->frame_valid, p->frame_valid + d.F));
@@ -863,9 +955,12 @@ int32_t mcba_create(const mcba_problem* p, void* hip_stream, mcba_handle* out) {
   h->sbuf.alloc((size_t)d.ns * d.ns + d.ns);
   h->ps.alloc((size_t)d.ns);
   h->info.alloc(4);
-  HIP_OK(hipHostMalloc((void**)&h->h_scal, h->scal.n * sizeof(double)));
-  HIP_OK(hipHostMalloc((void**)&h->h_x, std::max<size_t>(d.n, 1) * sizeof(double)));
-  HIP_OK(hipHostMalloc((void**)&h->h_gbuf, (2 * (size_t)d.n + 2) * sizeof(double)));
+  h->h_scal_bytes = h->scal.n * sizeof(double);
+  h->h_x_bytes = std::max<size_t>(d.n, 1) * sizeof(double);
+  h->h_gbuf_bytes = (2 * (size_t)d.n + 2) * sizeof(double);
+  h->h_scal = (double*)pinned_alloc(h->h_scal_bytes);
+  h->h_x = (double*)pinned_alloc(h->h_x_bytes);
+  h->h_gbuf = (double*)pinned_alloc(h->h_gbuf_bytes);
   HIP_OK(hipEventCreate(&h->ev0));
   HIP_OK(hipEventCreate(&h->ev1));
   HIP_OK(hipEventCreateWithFlags(&h->ev_fetch, hipEventDisableTiming));
@@ -888,8 +983,17 @@ int32_t mcba_destroy(mcba_handle h) {
   API_BEGIN
   if (h) {
     (void)hipStreamSynchronize(h->stream);
+    g_park_on_release = true;    // the handle's stream is idle: its buffers / stream go to the resource cache
     delete h;
+    g_park_on_release = false;
   }
+  API_END
+}
+
+/* returns the device buffers, pinned buffers and streams that destroyed handles left in the process-wide cache          */
+int32_t mcba_release_cached_memory(void) {
+  API_BEGIN
+  resource_cache().clear();
   API_END
 }
 

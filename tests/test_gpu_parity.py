@@ -585,3 +585,29 @@ def test_align_transforms_robust_batch_edge_cases():
     want, want_inl = restate_init.align_transforms_robust(a, b, valid=m)
     assert np.array_equal(il, want_inl)
     assert np.abs(o - want).max() < 1e-9
+
+
+def test_resource_cache_reuses_buffers_of_closed_handles():
+  """mcba_destroy parks buffers / stream, the next mcba_create of the same shape takes them back: identical results from
+  recycled (dirty) memory, also after a handle of ANOTHER shape ran in between, and after the cache was emptied."""
+  from multical_amd.backend import release_cached_memory
+  g, rig = load_golden("tiny_rolling")
+  g2, rig2 = load_golden("tiny")
+  ref = None
+  for k in range(4):
+    with Handle(mirror(rig)) as h:
+      cost, grad, diag = h.normal_equations(g["x0"])
+      H = h.dense_hessian()
+      res = h.solve(g["x0"])
+      r = h.residuals(g["x0"])
+    cur = (cost, grad.copy(), H.copy(), res.cost, res.nfev, r.copy())
+    if ref is None:
+      ref = cur
+    else:
+      assert cur[0] == ref[0] and np.array_equal(cur[1], ref[1]) and np.array_equal(cur[2], ref[2])
+      assert cur[3] == ref[3] and cur[4] == ref[4] and np.array_equal(cur[5], ref[5])
+    if k == 1:
+      with Handle(mirror(rig2)) as h2:
+        assert np.abs(h2.residuals(g2["x0"]) - g2["r0"]).max() < 1e-9
+    if k == 2:
+      release_cached_memory()
