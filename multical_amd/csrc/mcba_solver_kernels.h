@@ -1031,7 +1031,8 @@ __device__ __forceinline__ double lane_bcast(double v, int src) {   // value of 
 // and its inverse Xi, by one wavefront.  col0 = global index of the tile's first column (for the pivot report).
 // FULL: all 16 columns belong to the matrix -- no per-column branch, so the 16 pivot steps form ONE basic block and the
 // scheduler can start the rsqrt chain of column j + 1 while the broadcasts / updates of column j are still issuing.
-template <bool FULL>
+// INV = false: no inverse; Xi[0 .. 16) receives 1 / L_jj instead (k_chol_blk solves with the factor itself, see there).
+template <bool FULL, bool INV = true>
 __device__ __forceinline__ void chol_tile_factor_t(double* __restrict__ D, double* __restrict__ Xi, int ncol, int col0,
                                                    int lane, int& badcol) {
   const int li = lane & 15;
@@ -1061,6 +1062,13 @@ __device__ __forceinline__ void chol_tile_factor_t(double* __restrict__ D, doubl
 #pragma unroll
     for (int c = 0; c < CT; ++c) D[li * CTL + c] = row[c];
   }
+  if constexpr (!INV) {
+    if (lane == 0) {
+#pragma unroll
+      for (int j = 0; j < CT; ++j) Xi[j] = dinv[j];
+    }
+    return;
+  }
   // inverse: lane c solves L x = e_c (L_im is lane i's row[m]); the padding has a unit diagonal
   double x[CT];
 #pragma unroll
@@ -1088,6 +1096,51 @@ __device__ __forceinline__ void chol_tile_factor(double* __restrict__ D, double*
 #endif
     chol_tile_factor_t<false>(D, Xi, ncol, col0, lane, badcol);
 }
+// factor only; dinv[0 .. 16) = 1 / L_jj
+__device__ __forceinline__ void chol_tile_factor_noinv(double* __restrict__ D, double* __restrict__ dinv, int ncol, int col0,
+                                                       int lane, int& badcol) {
+  if (ncol >= CT) chol_tile_factor_t<true, false>(D, dinv, CT, col0, lane, badcol);
+  else chol_tile_factor_t<false, false>(D, dinv, ncol, col0, lane, badcol);
+}
+
+// X = A L^-T for FOUR 16 x 16 tiles at once by forward substitution: lane (lg, li) owns row li of tile lg (A4[lg], may be
+// null).  Nothing crosses lanes: x_j = a_j / L_jj, then a_m -= x_j L_mj for the columns m > j; L and 1 / L_jj are read from
+// LDS with wave-uniform addresses (broadcast reads).  Replaces "multiply by the inverted diagonal tile", which needed the
+// 16 dependent columns of the inverse on the critical path of every block column.
+__device__ __forceinline__ void chol_panel_solve4(const double* __restrict__ L, const double* __restrict__ dinv,
+                                                  double* __restrict__ A, int li) {
+  if (A == nullptr) return;
+  double a[CT], dv[CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c) a[c] = A[li * CTL + c];
+#pragma unroll
+  for (int c = 0; c < CT; ++c) dv[c] = dinv[c];
+  // left-looking: x_j = (a_j - sum_{m < j} x_m L_jm) / L_jj reads ROW j of L (adjacent entries: ds_read2_b64).  The rows
+  // are requested THREE steps ahead into rotating registers: left to the compiler every broadcast read was followed by
+  // its own s_waitcnt (67 LDS round trips per tile, 3.2 k cycles per block column)
+  double lr[4][CT];
+#pragma unroll
+  for (int r = 1; r < 4; ++r)
+#pragma unroll
+    for (int m = 0; m < r; ++m) lr[r][m] = L[r * CTL + m];
+#pragma unroll
+  for (int j = 0; j < CT; ++j) {
+    if (j + 3 < CT) {
+#pragma unroll
+      for (int m = 0; m < j + 3; ++m) lr[(j + 3) & 3][m] = L[(j + 3) * CTL + m];
+    }
+    double s0 = a[j], s1 = 0.0;
+#pragma unroll
+    for (int m = 0; m < j; ++m) {
+      const double l = lr[j & 3][m];
+      if (m & 1) s1 -= a[m] * l; else s0 -= a[m] * l;
+    }
+    a[j] = (s0 + s1) * dv[j];
+  }
+#pragma unroll
+  for (int c = 0; c < CT; ++c) A[li * CTL + c] = a[c];
+}
+
 
 // C -= Xa Xb^T for one 16 x 16 tile (four MFMA steps), one wavefront
 __device__ __forceinline__ void chol_tile_syrk(const double* __restrict__ Xa, const double* __restrict__ Xb,
@@ -1123,20 +1176,26 @@ __global__ __launch_bounds__(CHOL_BLK_THREADS) void k_chol_blk(int ns, double re
   if (prof) tc = clock64();
 #define CHOL_STAMP(i) if (prof) { const long long now = clock64(); tp[i] += now - tc; tc = now; }
   {   // load: two tiles per pass, thread (r, c) of each; padding rows / columns continue the matrix with the identity
-    const int r = (tid >> 4) & 15, c = tid & 15, half = tid >> 8;
-    constexpr int UN = 12;
+    const int r = (tid >> 4) & 15, c = tid & 15, half = __builtin_amdgcn_readfirstlane(tid >> 8);
+    constexpr int UN = 23;   // 2 x 23 tiles per pass: the 45 tiles of ns = 140 in ONE round trip
     for (int t0 = 0; t0 < ntile; t0 += 2 * UN) {
       double v[UN];
+      // (bi, bj) of the pass's first tile once, then stepped by two tiles: wave-uniform integers (the per-element form with
+      //  a square root per tile cost more issue slots than the loads: 17 k cycles for 92 KB)
+      const int tile0 = t0 + half;
+      int bi = (int)((sqrtf(8.0f * (float)tile0 + 1.0f) - 1.0f) * 0.5f);
+      bi += ((bi + 1) * (bi + 2) / 2 <= tile0) ? 1 : 0;
+      bi -= (bi * (bi + 1) / 2 > tile0) ? 1 : 0;
+      bi = __builtin_amdgcn_readfirstlane(bi);
+      int bj = tile0 - bi * (bi + 1) / 2;
 #pragma unroll
       for (int u = 0; u < UN; ++u) {
         const int tile = t0 + 2 * u + half;
-        int bi = (int)((sqrtf(8.0f * (float)tile + 1.0f) - 1.0f) * 0.5f);
-        bi += ((bi + 1) * (bi + 2) / 2 <= tile) ? 1 : 0;
-        bi -= (bi * (bi + 1) / 2 > tile) ? 1 : 0;
-        const int bj = tile - bi * (bi + 1) / 2;
         const int gi = CT * bi + r, gj = CT * bj + c;
         const bool in = tile < ntile && gi < n1 && gj < ns && gj <= gi;
         v[u] = masked_load(buf, (size_t)gi * ns + gj, in) + (in ? ((gi == gj) ? reg : 0.0) : ((gi == gj) ? 1.0 : 0.0));
+        bj += 2;
+        while (bj > bi) { bj -= bi + 1; ++bi; }
       }
 #pragma unroll
       for (int u = 0; u < UN; ++u) {
@@ -1149,28 +1208,17 @@ __global__ __launch_bounds__(CHOL_BLK_THREADS) void k_chol_blk(int ns, double re
   __syncthreads();
   CHOL_STAMP(0)
   const int li = lane & 15, lg = lane >> 4;
-  if (wave == 0 && ns > 0) chol_tile_factor(Lb, Li, min(CT, ns), 0, lane, badcol);
+  // (Li + k CTS holds 1 / L_jj of block column k in its first 16 entries: the tiles are never inverted)
+  if (wave == 0 && ns > 0) chol_tile_factor_noinv(Lb, Li, min(CT, ns), 0, lane, badcol);
   __syncthreads();
   CHOL_STAMP(1)
   for (int k = 0; k < nb; ++k) {
     if (ns - CT * k <= 0) break;               // no column of S in this block (right-hand-side row / padding only)
     {
-      // (b) panel tiles below the diagonal:  X = A L_kk^-T   (D[i][j] = sum_m A[i][m] Linv[j][m])
-      const double* Xi = Li + (size_t)k * CTS;
-      double bv[4];
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) bv[s4] = Xi[li * CTL + 4 * s4 + lg];
-      for (int bi = k + 1 + wave; bi < nb; bi += NW) {
-        double* A = Lb + (size_t)(bi * (bi + 1) / 2 + k) * CTS;
-        double av[4];
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) av[s4] = A[li * CTL + 4 * s4 + lg];
-        double4_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s4], bv[s4], acc, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) A[(lg + 4 * r) * CTL + li] = acc[r];
-      }
+      // (b) panel tiles below the diagonal:  X = A L_kk^-T by forward substitution, four tiles per wavefront
+      const int bi = k + 1 + 4 * wave + lg;
+      chol_panel_solve4(Lb + (size_t)(k * (k + 1) / 2 + k) * CTS, Li + (size_t)k * CTS,
+                        bi < nb ? Lb + (size_t)(bi * (bi + 1) / 2 + k) * CTS : nullptr, li);
     }
     __syncthreads();
     CHOL_STAMP(2)
@@ -1186,7 +1234,7 @@ __global__ __launch_bounds__(CHOL_BLK_THREADS) void k_chol_blk(int ns, double re
           chol_tile_syrk(X1, X1, D1, li, lg);
           lds_fence();
           const int ncol1 = min(CT, ns - CT * b1);
-          if (ncol1 > 0) chol_tile_factor(D1, Li + (size_t)b1 * CTS, ncol1, CT * b1, lane, badcol);
+          if (ncol1 > 0) chol_tile_factor_noinv(D1, Li + (size_t)b1 * CTS, ncol1, CT * b1, lane, badcol);
         }
       } else {
         for (int tt = wave; tt < nt; tt += NW - 1) {
@@ -1211,15 +1259,28 @@ __global__ __launch_bounds__(CHOL_BLK_THREADS) void k_chol_blk(int ns, double re
     lds_fence();
     const int nbc = (ns + CT - 1) / CT;
     for (int kb = nbc - 1; kb >= 0; --kb) {
-      {   // p_k = L_kk^-T z_k   (the strict upper part of the stored inverse is zero)
-        const double* Xi = Li + (size_t)kb * CTS;
-        double sp[4] = {0.0, 0.0, 0.0, 0.0};
+      {   // p_k = L_kk^-T z_k by backward substitution: lane i carries z_i; p_i travels through v_readlane
+        const double* Lk = Lb + (size_t)(kb * (kb + 1) / 2 + kb) * CTS;
+        const double* dk = Li + (size_t)kb * CTS;
+        double z = yv[CT * kb + li];
+        // column li of L_kk and 1 / L_ii first: the LDS reads do not depend on z, only mul / readlane / fma stay on the chain
+        double lc[CT], dv[CT];
 #pragma unroll
-        for (int i = 0; i < CT; ++i) sp[i & 3] += Xi[i * CTL + li] * yv[CT * kb + i];
-        const double sum = (sp[0] + sp[1]) + (sp[2] + sp[3]);
+        for (int i = 0; i < CT; ++i) {
+          lc[i] = (li < i) ? Lk[i * CTL + li] : 0.0;   // (masked: lanes >= i keep their z in the update below)
+          dv[i] = dk[i];
+        }
+        double pfin = 0.0;
+#pragma unroll
+        for (int i = CT - 1; i >= 0; --i) {
+          const double pi = lane_bcast(z * dv[i], i);   // chain per step: fma -> mul -> readlane
+          pfin = (li == i) ? pi : pfin;
+          z -= lc[i] * pi;
+        }
+        z = pfin;
         if (lane < CT) {
-          pv[CT * kb + li] = sum;
-          if (CT * kb + li < ns) ps[CT * kb + li] = sum;
+          pv[CT * kb + li] = z;
+          if (CT * kb + li < ns) ps[CT * kb + li] = z;
         }
       }
       lds_fence();
