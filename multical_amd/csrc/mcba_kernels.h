@@ -1,10 +1,12 @@
 // mcba_kernels.h -- HIP kernels of the bundle-adjustment hot path, written for gfx950 (CDNA4, wave64).
 //
 // Evaluation pipeline at a parameter vector x (all FP64):
-//   k_prep        x -> pose table (R, t, left Jacobian per pose), camera table, board points
+//   k_prep        x -> pose table (R, t, left Jacobian per pose), camera table, board points (the non-linearising entry
+//                 points; a linearisation gets these from k_tmat, a trial step from the tail of k_vec_step)
 //   k_views       pose table -> one board->camera chain matrix per view (camera, frame, board)
-//   k_tmat        pose table -> That (pose-block structure) and chain matrix of every non-empty view; opens a linearisation
-//   k_residual    one thread per table slot: residuals / projections / reprojection errors         (evaluate())
+//   k_tmat        x -> That (pose-block structure) and chain matrix of every non-empty view + the tables; opens a linearisation
+//   k_residual    a wavefront per non-empty view over its compacted inliers: residuals (evaluate()); a loop over the table
+//                 slots for projections / reprojection errors
 //   k_cost        persistent wavefronts over the non-empty views (largest first): robust cost of a trial step
 //   k_jacobian    analytic Jacobian rows in the reference's sparsity pattern                        (parity / scipy-driven mode)
 //   k_linearize   persistent wavefronts, ONE WAVEFRONT PER VIEW at a time: per-point row pairs V = [E | K | r] are staged
