@@ -82,10 +82,15 @@ struct ResourceCache {
     total -= bytes;
     return p;
   }
+  // (resources are parked under the device of the handle that owned them, which need not be the caller's current device)
+  static int& park_device() {
+    static thread_local int d = -1;
+    return d;
+  }
   bool park(std::multimap<std::pair<int, size_t>, void*>& pool, size_t& total, size_t cap, void* p, size_t bytes) {
     std::lock_guard<std::mutex> lock(m);
     if (total + bytes > cap) return false;
-    pool.insert({{device(), bytes}, p});
+    pool.insert({{park_device() >= 0 ? park_device() : device(), bytes}, p});
     total += bytes;
     return true;
   }
@@ -107,7 +112,7 @@ struct ResourceCache {
   bool park_stream(hipStream_t s) {
     std::lock_guard<std::mutex> lock(m);
     if (streams.size() >= 4) return false;
-    streams.push_back({device(), s});
+    streams.push_back({park_device() >= 0 ? park_device() : device(), s});
     return true;
   }
   void clear() {
@@ -984,7 +989,9 @@ int32_t mcba_destroy(mcba_handle h) {
   if (h) {
     (void)hipStreamSynchronize(h->stream);
     g_park_on_release = true;    // the handle's stream is idle: its buffers / stream go to the resource cache
+    ResourceCache::park_device() = h->device;
     delete h;
+    ResourceCache::park_device() = -1;
     g_park_on_release = false;
   }
   API_END
