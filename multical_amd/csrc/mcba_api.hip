@@ -633,15 +633,12 @@ void launch_gn_solve(mcba_handle_s* h, double reg, bool root_rank, double* dots_
                        trp->Delta);
   if (K > 0) {
     const TrRegPartials z = trp ? *trp : TrRegPartials{nullptr, 0, nullptr, 0, 0, 0.0};
-    if (d.DF == 12) {
-      hipLaunchKernelGGL((k_frame_factor<12>), dim3((d.Fl + 63) / 64), dim3(64), 0, h->stream, d, h->Hff.p, h->dsc.p, h->gh.p,
-                         reg, h->Lf.p, h->W.p, h->yf.p, tr_dev, z.vs, z.nvb, z.q, z.nq, z.first, z.Delta);
-      hipLaunchKernelGGL((k_schur_w<12>), dim3(d.Fl), dim3(256), 0, h->stream, d, h->Hfs.p, h->dsc.p, h->Lf.p, h->W.p);
-    } else {
-      hipLaunchKernelGGL((k_frame_factor<6>), dim3((d.Fl + 63) / 64), dim3(64), 0, h->stream, d, h->Hff.p, h->dsc.p, h->gh.p,
-                         reg, h->Lf.p, h->W.p, h->yf.p, tr_dev, z.vs, z.nvb, z.q, z.nq, z.first, z.Delta);
-      hipLaunchKernelGGL((k_schur_w<6>), dim3(d.Fl), dim3(256), 0, h->stream, d, h->Hfs.p, h->dsc.p, h->Lf.p, h->W.p);
-    }
+    if (d.DF == 12)
+      hipLaunchKernelGGL((k_schur_frame<12>), dim3(d.Fl), dim3(256), 0, h->stream, d, h->Hff.p, h->Hfs.p, h->dsc.p, h->gh.p, reg,
+                         h->Lf.p, h->W.p, h->yf.p, tr_dev, z.vs, z.nvb, z.q, z.nq, z.first, z.Delta);
+    else
+      hipLaunchKernelGGL((k_schur_frame<6>), dim3(d.Fl), dim3(256), 0, h->stream, d, h->Hff.p, h->Hfs.p, h->dsc.p, h->gh.p, reg,
+                         h->Lf.p, h->W.p, h->yf.p, tr_dev, z.vs, z.nvb, z.q, z.nq, z.first, z.Delta);
     const int nt2 = h->ntile * (h->ntile + 1) / 2;
     if (h->use_mfma)
       hipLaunchKernelGGL((k_schur_syrk<true>), dim3(nt2, h->ksplit), dim3(64), 0, h->stream, K, d.ns + 1, h->ntile,

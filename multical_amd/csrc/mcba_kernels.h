@@ -14,7 +14,7 @@
 //                 reduction); the view's local normal equations M = That^T S That are written as one record.
 //   k_assemble, k_shared_final   deterministic reductions of the records into H_ss (dense, shared parameters),
 //                 H_fs / H_ff (per-frame blocks), g and diag(H)                                    (mcba_solver_kernels.h)
-//   k_frame_factor / k_schur_* / k_chol_* / k_vec_* / k_tr_*   the damped normal-equation solve and the scalar algebra of
+//   k_schur_* / k_chol_* / k_vec_* / k_tr_*   the damped normal-equation solve and the scalar algebra of
 //                 the trust-region driver                                                           (mcba_solver_kernels.h)
 //
 // There is no reference counterpart for the normal-equation kernels (the reference hands a finite-difference

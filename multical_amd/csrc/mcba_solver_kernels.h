@@ -607,11 +607,6 @@ __global__ void k_dots3(int n, const double* __restrict__ u0, const double* __re
   if (info != nullptr && threadIdx.x == 0) out[3] = (double)info[0];   // pivot report of the reduced Cholesky
 }
 
-// Schur step 1a, one THREAD per frame:  A_ff = D_f H_ff D_f + reg I = L L^T entirely in registers (DF = 6 or 12: 21 / 78
-// doubles), then L^-1 by forward substitution and y = L^-1 g_h,f.  The per-frame systems are tiny and there are
-// hundreds of them: a lane per system needs no cross-lane traffic at all (the block-per-frame version spent 39 us of
-// LDS latency in a single thread of each block).  Linv is stored dense [DF][DF] (zeros above the diagonal); y goes to
-// yf and to the EXTRA COLUMN ns of W (row stride ns + 1), so that the SYRK below also delivers W^T y.
 // One wavefront: folds the k_vec_scale / k_q00 partials, fixes the trust radius of the first iteration and computes the
 // damping of the Gauss-Newton solve; returns it in every lane.  S (may be null): the scalar block that receives the folded
 // values for the kernels and the host that read them later.
@@ -649,102 +644,7 @@ __device__ __forceinline__ double tr_reg_wave(double* S, const double* __restric
   return __shfl(reg, 0, 64);
 }
 
-template <int DF>
-__global__ __launch_bounds__(64) void k_frame_factor(Dims d, const double* __restrict__ Hff, const double* __restrict__ dsc,
-                                                     const double* __restrict__ gh, double reg, double* __restrict__ Linv,
-                                                     double* __restrict__ W, double* __restrict__ yf,
-                                                     double* tr = nullptr, const double* __restrict__ vs_part = nullptr,
-                                                     int nvb = 0, const double* __restrict__ q_part = nullptr, int nq = 0,
-                                                     int first = 0, double Delta_in = 0.0) {
-  // tr != nullptr: the damping comes from the device-side trust-region algebra.  With the partials (vs_part) the kernel
-  // computes it itself -- every workgroup (one wavefront) folds the ~600 partial sums redundantly, workgroup 0 publishes the
-  // scalar block for k_schur_reduce, k_vec_step and the host (one launch less: k_tr_reg); without them it reads S[TR_REG].
-  if (tr != nullptr) reg = vs_part != nullptr ? tr_reg_wave(blockIdx.x == 0 ? tr : nullptr, vs_part, nvb, q_part, nq, first,
-                                                           Delta_in, threadIdx.x)
-                                              : tr[TR_REG];
-  const int fl = blockIdx.x * blockDim.x + threadIdx.x;
-  if (fl >= d.Fl) return;
-  const int f = d.f0 + fl, ldw = d.ns + 1;
-  const double* hff = Hff + (size_t)fl * DF * DF;
-  double ds[DF], L[DF][DF], X[DF][DF];
-#pragma unroll
-  for (int i = 0; i < DF; ++i) ds[i] = dsc[d.frame_to_x(f, i)];
-#pragma unroll
-  for (int i = 0; i < DF; ++i)
-#pragma unroll
-    for (int j = 0; j <= i; ++j) L[i][j] = ds[i] * hff[i * DF + j] * ds[j] + (i == j ? reg : 0.0);
-  double dinv[DF];
-#pragma unroll
-  for (int j = 0; j < DF; ++j) {
-    double sj = L[j][j];
-#pragma unroll
-    for (int k = 0; k < j; ++k) sj -= L[j][k] * L[j][k];
-    const double inv = rsqrt(fmax(sj, 1e-300));
-    dinv[j] = inv;
-#pragma unroll
-    for (int i = j + 1; i < DF; ++i) {
-      double v = L[i][j];
-#pragma unroll
-      for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k];
-      L[i][j] = v * inv;
-    }
-  }
-  // X = L^-1 (lower triangular), column c by forward substitution
-#pragma unroll
-  for (int c = 0; c < DF; ++c) {
-#pragma unroll
-    for (int i = c; i < DF; ++i) {
-      double v = (i == c) ? 1.0 : 0.0;
-#pragma unroll
-      for (int m = c; m < i; ++m) v -= L[i][m] * X[m][c];
-      X[i][c] = v * dinv[i];
-    }
-  }
-  double* xo = Linv + (size_t)fl * DF * DF;
-#pragma unroll
-  for (int i = 0; i < DF; ++i)
-#pragma unroll
-    for (int j = 0; j < DF; ++j) xo[i * DF + j] = (j <= i) ? X[i][j] : 0.0;
-  double gf[DF];
-#pragma unroll
-  for (int i = 0; i < DF; ++i) gf[i] = gh[d.frame_to_x(f, i)];
-  double* w = W + (size_t)fl * DF * ldw;
-#pragma unroll
-  for (int i = 0; i < DF; ++i) {
-    double y = 0.0;
-#pragma unroll
-    for (int k = 0; k <= i; ++k) y += X[i][k] * gf[k];
-    yf[fl * DF + i] = y;
-    w[i * ldw + d.ns] = y;
-  }
-}
-
-// Schur step 1b, one block per frame, one thread per shared column s:  W[:, s] = L^-1 (D_f H_fs D_s)[:, s]  as a plain
-// triangular product with the inverse from step 1a (wave-uniform operand: scalar loads, no dependent chain).
-template <int DF>
-__global__ __launch_bounds__(256) void k_schur_w(Dims d, const double* __restrict__ Hfs, const double* __restrict__ dsc,
-                                                 const double* __restrict__ Linv, double* __restrict__ W) {
-  const int fl = blockIdx.x, f = d.f0 + fl, ns = d.ns, ldw = d.ns + 1;
-  const double* X = Linv + (size_t)fl * DF * DF;
-  const double* hfs = Hfs + (size_t)fl * DF * ns;
-  double* w = W + (size_t)fl * DF * ldw;
-  double df[DF];
-#pragma unroll
-  for (int i = 0; i < DF; ++i) df[i] = dsc[d.frame_to_x(f, i)];
-  for (int s = threadIdx.x; s < ns; s += blockDim.x) {
-    const double dsv = dsc[d.shared_to_x(s)];
-    double bcol[DF];
-#pragma unroll
-    for (int i = 0; i < DF; ++i) bcol[i] = df[i] * hfs[i * ns + s] * dsv;
-#pragma unroll
-    for (int i = 0; i < DF; ++i) {
-      double v = 0.0;
-#pragma unroll
-      for (int k = 0; k <= i; ++k) v += X[i * DF + k] * bcol[k];
-      w[i * ldw + s] = v;
-    }
-  }
-}
+// (Schur step 1 -- the per-frame factor and W = L^-1 D_f H_fs D_s -- is k_schur_frame below, behind the Cholesky tile helpers)
 
 // Schur step 2: partial SYRK  P[split][tile] = sum_{k in split} W'[k][ti*16..]^T W'[k][tj*16..]  over the stacked rows
 // k = (frame, dd) of W' = [W | y]  [K x (ns+1)].  One wavefront per (upper tile, K split); MFMA f64 16x16x4 reads its
@@ -1637,6 +1537,84 @@ __global__ void k_cholb_back_update(int ns, int k0, double* __restrict__ A) {
 // column dd of L^-1.  The last block copies the shared part.  dots (may be null): partial dots over the entries the
 // block has written, dots[3 blk + {0,1,2}] = {g_h.g_h, g_h.gn, gn.gn}, and the Cholesky pivot report in
 // dots[3 gridDim.x] -- summed on the host by the single-GPU driver (sharded handles need the all-reduced gn: k_dots3).
+// ---------------------------------------------------------------------------------------------------------------
+// Schur step 1, ONE workgroup per frame (round 2; replaces k_tr_reg + k_frame_factor + k_schur_w):
+//   * the first wavefront folds the k_vec_scale / k_q00 partials and computes the damping (tr_reg_wave; workgroup 0
+//     publishes the scalar block), when the device-side trust-region algebra is on;
+//   * A_ff = D_f H_ff D_f + reg I goes into a 16 x 16 LDS tile (identity padding) and is factored by the first wavefront in
+//     registers (chol_tile_factor_noinv: lane = row, pivots through v_readlane) -- one thread per frame did the same
+//     12 x 12 factor AND its inverse as a serial chain of ~700 dependent operations (8.8 us);
+//   * thread s takes column s of [D_f H_fs D_s | g_f] and solves L w = b by forward substitution (L is a broadcast read of
+//     LDS): W[:, s], and y = W[:, ns].
+// L (strict lower part) with 1 / L_ii on the diagonal is kept for the back substitution (Lf [Fl][DF][DF]).
+// ---------------------------------------------------------------------------------------------------------------
+template <int DF>
+__global__ __launch_bounds__(256) void k_schur_frame(Dims d, const double* __restrict__ Hff, const double* __restrict__ Hfs,
+                                                    const double* __restrict__ dsc, const double* __restrict__ gh, double reg,
+                                                    double* __restrict__ Lf, double* __restrict__ W, double* __restrict__ yf,
+                                                    double* tr, const double* __restrict__ vs_part, int nvb,
+                                                    const double* __restrict__ q_part, int nq, int first, double Delta_in) {
+  __shared__ double Dt[CTS];
+  __shared__ double dinv_s[CT], df_s[CT];
+  __shared__ double reg_s;
+  const int fl = blockIdx.x, f = d.f0 + fl, ns = d.ns, ldw = ns + 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (wave == 0) {
+    double r = reg;
+    if (tr != nullptr)
+      r = vs_part != nullptr ? tr_reg_wave(blockIdx.x == 0 ? tr : nullptr, vs_part, nvb, q_part, nq, first, Delta_in, lane)
+                             : tr[TR_REG];
+    if (lane == 0) reg_s = r;
+  }
+  if (tid >= 64 && tid < 64 + CT) df_s[tid - 64] = (tid - 64) < DF ? dsc[d.frame_to_x(f, tid - 64)] : 0.0;
+  __syncthreads();
+  const double* hff = Hff + (size_t)fl * DF * DF;
+  {
+    const int i = tid >> 4, j = tid & 15;   // 256 threads = the 16 x 16 tile
+    double v = (i == j) ? 1.0 : 0.0;
+    if (i < DF && j < DF) v = df_s[i] * hff[i * DF + j] * df_s[j] + (i == j ? reg_s : 0.0);
+    Dt[i * CTL + j] = v;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    int badcol = 0;   // (a non-positive pivot is clamped, as in the reduced system's factor: the step is then rejected by its cost)
+    chol_tile_factor_noinv(Dt, dinv_s, DF, 0, lane, badcol);
+  }
+  __syncthreads();
+  const double* hfs = Hfs + (size_t)fl * DF * ns;
+  double* w = W + (size_t)fl * DF * ldw;
+  for (int s = tid; s <= ns; s += blockDim.x) {
+    double b[DF];
+    if (s < ns) {
+      const double dsv = dsc[d.shared_to_x(s)];
+#pragma unroll
+      for (int i = 0; i < DF; ++i) b[i] = df_s[i] * hfs[i * ns + s] * dsv;
+    } else {
+#pragma unroll
+      for (int i = 0; i < DF; ++i) b[i] = gh[d.frame_to_x(f, i)];
+    }
+#pragma unroll
+    for (int i = 0; i < DF; ++i) {
+      double s0 = b[i], s1 = 0.0;
+#pragma unroll
+      for (int m = 0; m < i; ++m) {
+        if (m & 1) s1 -= Dt[i * CTL + m] * b[m]; else s0 -= Dt[i * CTL + m] * b[m];
+      }
+      b[i] = (s0 + s1) * dinv_s[i];
+    }
+#pragma unroll
+    for (int i = 0; i < DF; ++i) w[i * ldw + s] = b[i];
+    if (s == ns) {
+#pragma unroll
+      for (int i = 0; i < DF; ++i) yf[fl * DF + i] = b[i];
+    }
+  }
+  if (tid < DF * DF) {
+    const int i = tid / DF, j = tid % DF;
+    Lf[(size_t)fl * DF * DF + tid] = (i == j) ? dinv_s[i] : (j < i ? Dt[i * CTL + j] : 0.0);
+  }
+}
+
 template <int DF>
 __global__ __launch_bounds__(64) void k_schur_backsub(Dims d, const double* __restrict__ Linv, const double* __restrict__ W,
                                                       const double* __restrict__ yf, const double* __restrict__ ps,
@@ -1682,11 +1660,28 @@ __global__ __launch_bounds__(64) void k_schur_backsub(Dims d, const double* __re
     for (int r = 0; r < 4; ++r) zs[kq + 4 * r] = acc[r];
   }
   lds_fence();
+  // gn_f = L^-T (y - W p_s) by back substitution with the factor k_schur_frame left (strict lower part, 1 / L_ii on the
+  // diagonal): lane m < DF carries r_m; v_i travels through v_readlane.  The column of L is read first: only
+  // mul -> readlane -> fma stay on the chain.
   double a = 0.0, v = 0.0;
-  if (lane < DF) {
-    const double* X = Linv + (size_t)fl * DF * DF;
+  {
+    const double* Lg = Linv + (size_t)fl * DF * DF;
+    const int lm = lane < DF ? lane : 0;
+    double lc[DF], dv[DF];
 #pragma unroll
-    for (int k = 0; k < DF; ++k) v += (k >= lane) ? X[k * DF + lane] * (yf[fl * DF + k] - zs[k]) : 0.0;
+    for (int i = 0; i < DF; ++i) {
+      lc[i] = (lane < i) ? Lg[i * DF + lm] : 0.0;
+      dv[i] = Lg[i * DF + i];
+    }
+    double r = lane < DF ? yf[fl * DF + lm] - zs[lm] : 0.0;
+#pragma unroll
+    for (int i = DF - 1; i >= 0; --i) {
+      const double vi = lane_bcast(r * dv[i], i);
+      v = (lane == i) ? vi : v;
+      r -= lc[i] * vi;
+    }
+  }
+  if (lane < DF) {
     const int xi = d.frame_to_x(d.f0 + fl, lane);
     gn[xi] = v;
     a = gh[xi];
@@ -1789,7 +1784,7 @@ __global__ __launch_bounds__(64) void k_fold_partials(double* __restrict__ part,
 // one-wave kernels that keep the scalar trust-region algebra on the device between the vector kernels (single-GPU
 // driver: one host synchronisation per iteration).  S = scal[0 .. TR_NSLOTS), see mcba_trmath.h.
 // ---------------------------------------------------------------------------------------------------------------
-// (stand-alone form of tr_reg_wave: problems without eliminated frame blocks, where k_frame_factor is not launched)
+// (stand-alone form of tr_reg_wave: problems without eliminated frame blocks, where k_schur_frame is not launched)
 __global__ __launch_bounds__(64) void k_tr_reg(double* __restrict__ S, const double* __restrict__ vs_part, int nvb,
                                                const double* __restrict__ q_part, int nq, int first, double Delta_in) {
   tr_reg_wave(S, vs_part, nvb, q_part, nq, first, Delta_in, threadIdx.x);
