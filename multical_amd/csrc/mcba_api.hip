@@ -648,7 +648,7 @@ void launch_gn_solve(mcba_handle_s* h, double reg, bool root_rank, double* dots_
                          h->ksplit, h->W.p, h->P.p);
   }
   const int total = d.ns * d.ns + d.ns;
-  hipLaunchKernelGGL(k_schur_reduce, dim3(std::min(1024, (total + 255) / 256)), dim3(256), 0, h->stream, d, h->Hss.p,
+  hipLaunchKernelGGL(k_schur_reduce, dim3(std::min(2048, (4 * total + 255) / 256)), dim3(256), 0, h->stream, d, h->Hss.p,
                      h->dsc.p, h->gh.p, h->P.p, h->ntile, h->ksplit, K, root_rank ? 1.0 : 0.0, h->sbuf.p, tr_dev);
   call_allreduce(h, h->sbuf.p, (size_t)total, 0);
   launch_chol(h, d.ns, tr_dev ? 0.0 : reg, h->sbuf.p, h->ps.p);

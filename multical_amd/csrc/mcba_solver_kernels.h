@@ -691,13 +691,19 @@ __global__ __launch_bounds__(64, 2) void k_schur_syrk(int K, int ncol, int ntile
 
 // Schur step 3:  S = D_s H_ss D_s - W^T W  (reg I is added after the cross-rank reduction),
 //                rhs = [own shared gradient] - W^T y.   buf = [S (ns*ns) | rhs (ns)]: rhs is "row ns" of the matrix.
-__global__ void k_schur_reduce(Dims d, const double* __restrict__ Hss, const double* __restrict__ dsc,
-                               const double* __restrict__ gh, const double* __restrict__ P, int ntile, int ksplit,
-                               int K, double g_weight, double* __restrict__ buf, const double* __restrict__ tr = nullptr) {
+// FOUR threads per element: thread q of a quad sums the splits q, q + 4, ... (four loads in flight each), the quad is
+// folded with two shuffles in a fixed order.  One thread per element walked its 32 splits as eight dependent round trips.
+__global__ __launch_bounds__(256) void k_schur_reduce(Dims d, const double* __restrict__ Hss, const double* __restrict__ dsc,
+                                                      const double* __restrict__ gh, const double* __restrict__ P, int ntile,
+                                                      int ksplit, int K, double g_weight, double* __restrict__ buf,
+                                                      const double* __restrict__ tr = nullptr) {
   const int ns = d.ns;
   const int nt2 = ntile * (ntile + 1) / 2;
   const int total = ns * ns + ns;
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+  const int q = threadIdx.x & 3;
+  for (int e0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 2; e0 < ((total + 63) & ~63); e0 += (gridDim.x * blockDim.x) >> 2) {
+    const bool live = e0 < total;
+    const int e = live ? e0 : 0;
     const int i = e / ns, j = e % ns;            // i == ns: the right-hand-side row
     const int a = min(i, j), b = max(i, j);
     const int ti = a / 16, tj = b / 16;
@@ -707,16 +713,19 @@ __global__ void k_schur_reduce(Dims d, const double* __restrict__ Hss, const dou
       const double* pp = P + (size_t)tile * 256 + (a % 16) * 16 + (b % 16);
       const size_t st = (size_t)nt2 * 256;
       double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-      int sp = 0;
-      for (; sp + 4 <= ksplit; sp += 4) {          // four independent loads in flight, fixed summation order
+      int sp = q;
+      for (; sp + 12 < ksplit; sp += 16) {         // four independent loads in flight, fixed summation order
         s0 += pp[(size_t)sp * st];
-        s1 += pp[(size_t)(sp + 1) * st];
-        s2 += pp[(size_t)(sp + 2) * st];
-        s3 += pp[(size_t)(sp + 3) * st];
+        s1 += pp[(size_t)(sp + 4) * st];
+        s2 += pp[(size_t)(sp + 8) * st];
+        s3 += pp[(size_t)(sp + 12) * st];
       }
-      for (; sp < ksplit; ++sp) s0 += pp[(size_t)sp * st];
+      for (; sp < ksplit; sp += 4) s0 += pp[(size_t)sp * st];
       sum = (s0 + s1) + (s2 + s3);
     }
+    sum += __shfl_down(sum, 2, 4);                 // (all 64 lanes take part: the element loop is padded to whole waves)
+    sum += __shfl_down(sum, 1, 4);
+    if (q != 0 || !live) continue;
     // (the damping lives on the device, tr[TR_REG]; only the root rank adds it: the buffer is summed over the ranks next)
     if (i < ns) buf[e] = dsc[d.shared_to_x(i)] * Hss[e] * dsc[d.shared_to_x(j)] - sum + ((tr != nullptr && i == j) ? g_weight * tr[TR_REG] : 0.0);
     else buf[e] = g_weight * gh[d.shared_to_x(j)] - sum;
