@@ -102,6 +102,14 @@ BIG_CASES = {
   "cfg4_40": ("cfg4_40", None),
   "cfg5_40": ("cfg5_40", None),
 }
+# evaluation-only goldens of the BASELINE configurations AT THEIR STATED SIZE (one reference `evaluate` costs seconds
+# there, a reference solve hours): residual checksums, a strided sample of the residual vector, error statistics at x0
+# and at a seeded perturbed point x1, and a central-difference directional derivative of the reference's cost
+FULL_CASES = {
+  "cfg3_full": "cfg3",     # 8 x 500 x 2 rolling shutter: the rig bench.py measures
+  "cfg4_full": "cfg4",     # 16 x 1000 x 5
+  "cfg5_full": "cfg5",     # 6 x 400 x 5 fisheye hand-eye
+}
 N_PERT = 3            # perturbed re-runs per reference call
 PERT_SIGMA = 1e-12    # px
 
@@ -361,10 +369,58 @@ def run_big_case(name):
         f"in {out['seconds']:.0f} s -> {path} ({os.path.getsize(path) / 1024:.0f} KiB)", flush=True)
 
 
+def full_case_points(x0, seed=7):
+  """The seeded perturbed point x1 and direction v of the full-size goldens (shared with the tests)."""
+  rng = np.random.default_rng(seed)
+  x1 = x0 + rng.normal(size=x0.size) * 1e-3 * np.maximum(1.0, np.abs(x0)) * 1e-1
+  v = rng.normal(size=x0.size) * np.maximum(1e-3, 1e-3 * np.abs(x0))
+  return x1, v
+
+
+def run_full_case(name):
+  """Evaluation-only golden of a BASELINE configuration at its stated size, from the real reference: what the bench
+  measures (cfg3) and the 8- / 2-GPU configurations are pinned by `evaluate` (calibration.py:204-206),
+  `reprojection_error` + `error_stats` (calibration.py:134-136,304-310) at two points."""
+  import time
+  cfg = FULL_CASES[name]
+  rig = synthetic.make_rig(cfg)
+  calib, ref = build_reference.reference_calibration(rig)
+  error_stats = ref.optimization_calibration.error_stats
+  t0 = time.time()
+  out = dict(config=np.array(cfg), frames=np.array(rig.valid.shape[1]), shape=np.array(rig.valid.shape),
+             points_sum=np.array(rig.points.sum()), points_abs_sum=np.array(np.abs(rig.points).sum()),
+             valid_count=np.array(int(rig.valid.sum())))
+  x0 = calib.param_vec
+  x1, v = full_case_points(x0)
+  out["x0"], out["x1"], out["v"] = x0, x1, v
+  for tag, x in (("0", x0), ("1", x1)):
+    r = _evaluate(calib, x)
+    c = calib.with_param_vec(x)
+    es = error_stats(c.reprojection_error)
+    stride = max(1, r.size // 4096)
+    out["r%s_size" % tag], out["r%s_sum" % tag], out["r%s_sq" % tag] = r.size, r.sum(), r @ r
+    out["r%s_abs_sum" % tag] = np.abs(r).sum()
+    out["r%s_head" % tag], out["r%s_stride" % tag], out["r%s_sample" % tag] = r[:64], stride, r[::stride]
+    # weighted checksum: sensitive to any permutation of the residual order
+    out["r%s_wsum" % tag] = float(np.dot(r, np.cos(np.arange(r.size) * 0.001)))
+    out["rms%s" % tag], out["mse%s" % tag], out["n%s" % tag] = es.rms, es.mse, es.n
+    out["quantiles%s" % tag] = np.asarray(es.quantiles)
+  h = 1e-4
+  fp, fm = _evaluate(calib, x0 + h * v), _evaluate(calib, x0 - h * v)
+  out["dd_h"], out["dd"] = h, (0.5 * fp @ fp - 0.5 * fm @ fm) / (2 * h)    # ~ g(x0) . v
+  out["seconds"] = time.time() - t0
+  path = os.path.join(GOLDEN_DIR, f"{name}.npz")
+  np.savez_compressed(path, **out)
+  print(f"{name}: n={x0.size} m={int(out['r0_size'])} rms0={float(out['rms0']):.6f} rms1={float(out['rms1']):.6f} "
+        f"dd={float(out['dd']):.6e} in {out['seconds']:.0f} s -> {path} ({os.path.getsize(path) / 1024:.0f} KiB)", flush=True)
+
+
 def main(argv):
   names = argv or list(CASES)
   for n in names:
-    if n in BIG_CASES:
+    if n in FULL_CASES:
+      run_full_case(n)
+    elif n in BIG_CASES:
       run_big_case(n)
     else:
       run_case(n)

@@ -47,3 +47,44 @@ def test_oracle_outlier_loop_matches_reference():
   assert np.array_equal(ao.inliers, g["ao_inliers"])
   assert np.array_equal(ao.param_vec, g["ao_x"])
   assert restate.error_stats(ao.reprojection_error).rms == float(g["ao_rms"])
+
+
+def full_golden(name):
+  """Evaluation-only golden of a BASELINE configuration at its stated size (oracle/make_golden.py: run_full_case) and
+  the rig regenerated from its seed; the observation table's checksums tie the two together."""
+  import os
+  from multical_amd import synthetic
+  from util import GOLDEN
+  g = dict(np.load(os.path.join(GOLDEN, f"{name}_full.npz"), allow_pickle=False))
+  rig = synthetic.make_rig(str(g["config"]))
+  assert tuple(g["shape"]) == rig.valid.shape and int(g["valid_count"]) == int(rig.valid.sum())
+  assert float(g["points_sum"]) == rig.points.sum() and float(g["points_abs_sum"]) == np.abs(rig.points).sum()
+  return g, rig
+
+
+def check_full_residuals(g, tag, r, tol):
+  """residual vector r at point `tag` ("0": x0, "1": the perturbed point) against the reference's checksums"""
+  assert r.size == int(g[f"r{tag}_size"])
+  stride = int(g[f"r{tag}_stride"])
+  assert np.abs(r[:64] - g[f"r{tag}_head"]).max() <= tol
+  assert np.abs(r[::stride] - g[f"r{tag}_sample"]).max() <= tol
+  assert abs(r.sum() - float(g[f"r{tag}_sum"])) <= tol * r.size
+  assert abs(np.abs(r).sum() - float(g[f"r{tag}_abs_sum"])) <= tol * r.size
+  assert abs(r @ r - float(g[f"r{tag}_sq"])) <= 1e-12 * float(g[f"r{tag}_sq"]) + tol
+  assert abs(np.dot(r, np.cos(np.arange(r.size) * 0.001)) - float(g[f"r{tag}_wsum"])) <= tol * r.size
+
+
+@pytest.mark.parametrize("name", ["cfg3", "cfg4", "cfg5"])
+def test_oracle_matches_reference_at_full_size(name):
+  """BASELINE configs[2..4] at their stated size (8x500x2 rolling, 16x1000x5, 6x400x5 fisheye hand-eye): the oracle's
+  whole residual vector and error statistics against the real reference's checksums, at x0 and at a perturbed point."""
+  g, rig = full_golden(name)
+  oc = oracle(rig)
+  assert np.array_equal(oc.param_vec, g["x0"])
+  for tag in ("0", "1"):
+    x = g[f"x{tag}"]
+    check_full_residuals(g, tag, oc.evaluate(x), 0.0 if tag == "0" else 1e-12)
+    es = restate.error_stats(oc.with_param_vec(x).reprojection_error)
+    assert es.n == int(g[f"n{tag}"])
+    assert es.rms == pytest.approx(float(g[f"rms{tag}"]), rel=1e-14)
+    assert np.allclose(es.quantiles, g[f"quantiles{tag}"], rtol=1e-13, atol=0)
