@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """bench.py -- the hot path's headline metric on MI355X (contract: see the task statement / DESIGN.md section 6).
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W          (N > 1: one rank per GPU, either started by the caller through
+                                                          torch.distributed.run or, when WORLD_SIZE is not set, by
+                                                          bench.py itself -- the same launcher on 127.0.0.1)
 
 metric  : residual+Jacobian evaluations per second (BASELINE.json `metric`, first component); LM iterations/s and
           the final reprojection RMS of a full solve are reported alongside in the same JSON line.
@@ -93,14 +95,34 @@ def cpu_baseline(n_frames_sample=25):
                        f"finite-difference Jacobians and LSMR; one LSMR iteration (J v + J^T u) = {t_lsmr_iter * 1e3:.1f} ms"))
 
 
+def self_launch(args):
+  """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU) through
+  torch.distributed.run on the loopback address, exactly as the driver's multi-GPU command line does, and pass rank 0's
+  JSON line through.  Under torchrun (WORLD_SIZE set) this is never reached."""
+  import socket
+  import subprocess
+  s = socket.socket()
+  s.bind(("127.0.0.1", 0))
+  port = s.getsockname()[1]
+  s.close()
+  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+  env = dict(os.environ)
+  env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # RCCL across processes needs dmabuf IPC on this driver
+  return subprocess.call(cmd, env=env)
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
   ap.add_argument("--steps", type=int, default=200)
   ap.add_argument("--warmup", type=int, default=20)
+  ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; the median is reported")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-solve", action="store_true")
   args = ap.parse_args()
+  if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    sys.exit(self_launch(args))
 
   import torch
   import torch.distributed as dist
@@ -112,6 +134,10 @@ def main():
   rank = int(os.environ.get("RANK", "0"))
   local_rank = int(os.environ.get("LOCAL_RANK", "0"))
   assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+  if not torch.cuda.is_available():
+    # the product is HIP-only: there is no CPU path to fall back to, and the bench must not pretend otherwise
+    sys.stderr.write(f"[bench rank {rank}/{world}] no HIP device visible: the mcba back-end is GPU-only\n")
+    sys.exit(3)
   # MCBA_BENCH_BACKEND=gloo is a test hook: it lets the N > 1 code path run with several ranks on ONE GPU (all-reduces
   # staged through the host); the measured configuration is always nccl (= RCCL over xGMI), one GPU per rank
   backend = os.environ.get("MCBA_BENCH_BACKEND", "nccl")
@@ -168,23 +194,31 @@ def main():
     # the same evaluation through the host boundary: x upload (49 KB), cost download, one synchronisation per call
     check(h.lib.mcba_normal_equations(h.h, _ptr(xbuf, C.c_double), C.byref(opt), C.byref(cost), None, None))
 
-  def timed(fn):
-    """W untimed warm-up steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks."""
+  def timed(fn, all_times=None):
+    """W untimed warm-up steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks.
+    The timed region is repeated --repeats times (K steps each, nothing between them but the barrier) and the MEDIAN
+    region is reported: at ~0.07 ms per step a single 20-step window is 1.5 ms of wall clock, too short for one sample."""
     for _ in range(args.warmup):
       fn()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-      fn()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-      tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-      dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-      dt = float(tmax.item())
-    return dt
+    times = []
+    for _ in range(max(1, args.repeats)):
+      barrier()
+      t0 = time.perf_counter()
+      for _ in range(args.steps):
+        fn()
+      barrier()
+      dt = time.perf_counter() - t0
+      if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+      times.append(dt)
+    if all_times is not None:
+      all_times.extend(times)
+    return sorted(times)[len(times) // 2]
 
-  dt = timed(step)
+  region_times = []
+  dt = timed(step, region_times)
   ms_per_step = dt / args.steps * 1e3
   value = world * args.steps / dt                       # shard evaluations per second, whole job
 
@@ -209,12 +243,7 @@ def main():
                   note="one rig, frame-sharded over all ranks; every evaluation ends with the all-reduce of [g | diag | cost]")
     hs.close()
   # PCIe-inclusive variant (never `value`): every evaluation enters and leaves through the host boundary
-  barrier()
-  t0 = time.perf_counter()
-  for _ in range(args.steps):
-    step_host()
-  barrier()
-  host_ms_per_step = (time.perf_counter() - t0) / args.steps * 1e3
+  host_ms_per_step = timed(step_host) / args.steps * 1e3
 
   # ---- dominant kernel: k_linearize, HIP events on the handle's stream --------------------------------------------
   lin_ms = h.time_linearize(x0, repeats=50)
@@ -279,6 +308,10 @@ def main():
                            parallelism=(f"frame-sharded x{world}, " + ("native RCCL all-reduce" if native else
                                         f"torch.distributed ({backend}) all-reduce hook")) if world > 1 else "single GPU",
                            device=h.device_info()),
+               obs_per_s=value * float(n_obs),            # observations linearised per second, whole job
+               step_roofline_frac=alg_flops / (ms_per_step * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,   # the STEP (all kernels of an
+               # evaluation + launch gaps), not just the dominant kernel, against the FP64 peak
+               timed_regions_ms=[t * 1e3 for t in region_times], repeats=len(region_times),
                host_boundary=dict(ms_per_step=host_ms_per_step, evals_per_s=world * 1e3 / host_ms_per_step,
                                   note="same evaluation with x uploaded and the cost downloaded on every call"),
                roofline=roofline, **extra)

@@ -205,3 +205,45 @@ def test_native_rccl_two_gpus(name, tmp_path):
   assert int(sh["nfev"]) == res.nfev and int(sh["status"]) == res.status
   assert float(sh["final_cost"]) == pytest.approx(res.cost, rel=1e-10)
   assert np.abs(sh["x"] - res.x).max() < 1e-7
+
+
+def _run_bench(extra_env, *args, timeout=900):
+  import subprocess
+  env = dict(os.environ)
+  env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+  env.update(extra_env)
+  return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), env=env, capture_output=True,
+                        text=True, timeout=timeout, cwd=ROOT)
+
+
+def test_bench_self_launches_its_ranks_and_fails_loudly_without_a_gpu():
+  """`python bench.py --gpus 2` with no launcher around it must start its own ranks (torch.distributed.run on the
+  loopback address).  On the GPU-less build box every rank then stops with the product's own message -- there is no CPU
+  path -- and the launcher returns non-zero."""
+  from util import gpu_available
+  if gpu_available():
+    pytest.skip("GPU box: covered by test_bench_two_ranks_on_one_gpu")
+  r = _run_bench({"MCBA_BENCH_BACKEND": "gloo"}, "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline")
+  assert r.returncode != 0
+  assert "[bench rank 0/2]" in r.stderr and "[bench rank 1/2]" in r.stderr, r.stderr[-2000:]
+  assert "GPU-only" in r.stderr
+  assert not r.stdout.strip().startswith("{")                      # no JSON line from a run that measured nothing
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu():
+  """The N > 1 path of bench.py end to end, self-launched (no torchrun on the command line): two ranks share the one
+  GPU of the test box with host-staged gloo all-reduces.  The JSON line must carry the weak-scaling value, the strong-
+  scaling object of the fixed 8 x 500 x 2 rig and the contract's fields."""
+  import json
+  r = _run_bench({"MCBA_BENCH_BACKEND": "gloo"}, "--gpus", "2", "--steps", "5", "--warmup", "2", "--repeats", "2",
+                 "--no-cpu-baseline")
+  assert r.returncode == 0, r.stderr[-3000:]
+  line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+  out = json.loads(line)
+  assert out["n_gpus"] == 2 and out["steps"] == 5 and out["warmup"] == 2 and out["scaling"] == "weak"
+  assert out["metric"] == "residual+Jacobian evals/sec" and out["dtype"] == "f64" and out["value"] > 0
+  assert out["strong_scaling"]["frames_per_gpu"] == [250, 250] and out["strong_scaling"]["value"] > 0
+  assert "gloo" in out["config"]["parallelism"]
+  assert out["roofline"]["frac"] > 0 and out["obs_per_s"] > 0 and 0 < out["step_roofline_frac"] < 1
+  assert out["final_rms_px"] < 1.0
