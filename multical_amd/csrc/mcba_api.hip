@@ -60,10 +60,22 @@ thread_local hipStream_t g_fill_stream = nullptr;   // stream of the running API
 // destroys it afterwards: ~50 hipMalloc / hipFree pairs, four pinned host buffers and a stream cost more than the three
 // bundle adjustments they serve (4 ms of a 15 ms calibrate at the north-star rig).  mcba_destroy parks them here (its
 // stream is idle by then) and the next mcba_create of a problem of the same shape takes them back, exact size match only.
-// Bounded (CACHE_BYTES_MAX of device memory); mcba_release_cached_memory() returns everything to the runtime.
+// Bounded (MCBA_CACHE_MB of device memory, default 512 MB; 0 = off), emptied by the allocator before it reports
+// out-of-memory; mcba_release_cached_memory() returns everything to the runtime.
 // ---------------------------------------------------------------------------------------------------------------
 struct ResourceCache {
-  static constexpr size_t CACHE_BYTES_MAX = 4ull << 30, HOST_BYTES_MAX = 64ull << 20;
+  // Device memory parked for the next handle of the same shape: MCBA_CACHE_MB (default 512; 0 disables parking -- every
+  // mcba_destroy then returns its memory to the runtime).  A process that shares the GPU with torch keeps at most this
+  // much idle, and an allocation that fails with out-of-memory empties the cache and is retried once (DevBuf::alloc).
+  static size_t cache_bytes_max() {
+    static const size_t cap = [] {
+      const char* e = getenv("MCBA_CACHE_MB");
+      const long mb = e ? atol(e) : 512;
+      return (size_t)(mb > 0 ? mb : 0) << 20;
+    }();
+    return cap;
+  }
+  static constexpr size_t HOST_BYTES_MAX = 64ull << 20;
   std::mutex m;
   std::multimap<std::pair<int, size_t>, void*> dev, host;   // (device, bytes) -> pointer
   std::vector<std::pair<int, hipStream_t>> streams;
@@ -96,8 +108,8 @@ struct ResourceCache {
   }
   void* take_dev(size_t bytes) { return take(dev, dev_bytes, bytes); }
   void* take_host(size_t bytes) { return take(host, host_bytes, bytes); }
-  bool park_dev(void* p, size_t bytes) { return park(dev, dev_bytes, CACHE_BYTES_MAX, p, bytes); }
-  bool park_host(void* p, size_t bytes) { return park(host, host_bytes, HOST_BYTES_MAX, p, bytes); }
+  bool park_dev(void* p, size_t bytes) { return park(dev, dev_bytes, cache_bytes_max(), p, bytes); }
+  bool park_host(void* p, size_t bytes) { return cache_bytes_max() > 0 && park(host, host_bytes, HOST_BYTES_MAX, p, bytes); }
   hipStream_t take_stream() {
     std::lock_guard<std::mutex> lock(m);
     const int d = device();
@@ -111,7 +123,7 @@ struct ResourceCache {
   }
   bool park_stream(hipStream_t s) {
     std::lock_guard<std::mutex> lock(m);
-    if (streams.size() >= 4) return false;
+    if (streams.size() >= 4 || cache_bytes_max() == 0) return false;
     streams.push_back({park_device() >= 0 ? park_device() : device(), s});
     return true;
   }
@@ -136,6 +148,11 @@ void* pinned_alloc(size_t bytes) {
   if (void* p = resource_cache().take_host(bytes)) return p;
   void* p = nullptr;
   hipError_t e = hipHostMalloc(&p, bytes);
+  if (e == hipErrorOutOfMemory) {   // parked buffers are the first thing to give back
+    (void)hipGetLastError();
+    resource_cache().clear();
+    e = hipHostMalloc(&p, bytes);
+  }
   if (e != hipSuccess) throw std::runtime_error(std::string("hipHostMalloc failed: ") + hipGetErrorString(e));
   return p;
 }
@@ -165,7 +182,19 @@ struct DevBuf {
       release();
       n = count;
       p = (T*)resource_cache().take_dev(bytes_of(count));
-      if (p == nullptr) HIP_OK(hipMalloc((void**)&p, bytes_of(count)));
+      if (p == nullptr) {
+        hipError_t e = hipMalloc((void**)&p, bytes_of(count));
+        if (e == hipErrorOutOfMemory) {   // memory parked by destroyed handles must never cause an out-of-memory failure
+          (void)hipGetLastError();
+          resource_cache().clear();
+          e = hipMalloc((void**)&p, bytes_of(count));
+        }
+        if (e != hipSuccess) {
+          p = nullptr;
+          n = 0;
+          throw Error(std::string("hipMalloc of ") + std::to_string(bytes_of(count)) + " bytes failed: " + hipGetErrorString(e));
+        }
+      }
     }
     if (zero) {
       // zero-fill ON THE HANDLE'S STREAM (g_fill_stream is set by every API entry that allocates): ordered against the
@@ -449,6 +478,15 @@ int call_allreduce(mcba_handle_s* h, double* buf, size_t count, int op) {
 }
 
 
+// A kernel launch that the runtime rejects (too much dynamic LDS, a bad grid) does not throw by itself: it leaves an
+// error behind and the stream simply lacks that kernel -- the solver would go on with stale H, g or tables.  Every
+// synchronisation point of the API therefore also collects the launch status, and the launches whose LDS size / grid are
+// computed at run time check right away.
+void check_launch(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) throw Error(std::string("kernel launch failed (") + what + "): " + hipGetErrorString(e));
+}
+
 // fused residual+Jacobian -> block normal equations.  dx != nullptr: at the parameter vector dx (device); k_tmat then also
 // prepares the pose / camera / board-point tables (no k_prep launch).  dx == nullptr: at the tables already prepared
 // (the trial step that was just accepted ran k_prep for its cost evaluation).
@@ -493,7 +531,8 @@ void launch_assemble(mcba_handle_s* h) {
   const int nfb = (d.DF > 0) ? d.Fl : 0;
   // frame blocks stage the record entries they sum in LDS, `gviews` records at a time (all C B views of the frame when they
   // fit the budget: 43.8 KB at the north-star rig)
-  static const int stage_kb = getenv("MCBA_ASM_STAGE_KB") ? std::max(4, atoi(getenv("MCBA_ASM_STAGE_KB"))) : 44;
+  // (clamped to what a workgroup may ask for by default: 64 KB of dynamic LDS minus the kernel's static tables)
+  static const int stage_kb = getenv("MCBA_ASM_STAGE_KB") ? std::min(60, std::max(4, atoi(getenv("MCBA_ASM_STAGE_KB")))) : 44;
   const int ne = frame_entries(d), cb = d.C * d.B;
   const int ngroups = nfb ? (cb * ne * 8 + stage_kb * 1024 - 1) / (stage_kb * 1024) : 1;
   const int gviews = (cb + ngroups - 1) / ngroups;
@@ -501,11 +540,13 @@ void launch_assemble(mcba_handle_s* h) {
   // (timed apart at cfg3: frame blocks alone 10.0 us, chunk sums alone 6.9 us, together 12.4 us)
   hipLaunchKernelGGL(k_assemble, dim3(nfb + d.C * d.B * h->nchunk), dim3(ASM_THREADS), lds, h->stream, d, h->t, h->rec.p, nfb, h->nchunk, gviews,
                      h->ftab.p, h->nftab, h->Hff.p, h->Hfs.p, h->g(), h->diag(), h->partial.p);
+  check_launch("k_assemble");
   {
     const int npair = d.C * d.B, pg = std::min(npair, 16);
     REQUIRE((size_t)npair * 64 * sizeof(double) <= 64 * 1024, "too many (camera, board) pairs for the shared assembly");
     hipLaunchKernelGGL(k_shared_final, dim3((d.rec_size + 2 + 63) / 64), dim3(64 * pg), (size_t)npair * 64 * sizeof(double),
                        h->stream, d, h->partial.p, h->nchunk, h->tri.p, h->Hss.p, h->g(), h->diag(), h->costcount());
+    check_launch("k_shared_final");
   }
   if (d.off_boards >= 0) {   // adjusted board points: their blocks of H_ss / H_fs / g (unique entries, plain stores)
     h->ops->points(d, h->t, h->stream, (d.n - d.off_boards) / 3, h->Hss.p, h->Hfs.p, h->g());
@@ -514,7 +555,11 @@ void launch_assemble(mcba_handle_s* h) {
   call_allreduce(h, h->gbuf.p, 2 * (size_t)d.n + 2, 0);
 }
 
-void sync(mcba_handle_s* h) { HIP_OK(hipStreamSynchronize(h->stream)); }
+void sync(mcba_handle_s* h) {
+  check_launch("before synchronisation");
+  HIP_OK(hipStreamSynchronize(h->stream));
+  check_launch("after synchronisation");
+}
 
 void fetch_scalars(mcba_handle_s* h, int count, int first = 0) {   // scal[first, first + count) -> h_scal (same offsets)
   HIP_OK(hipMemcpyAsync(h->h_scal + first, h->scal.p + first, count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -525,7 +570,10 @@ void fetch_scalars_begin(mcba_handle_s* h, int count, int first = 0) {
   HIP_OK(hipMemcpyAsync(h->h_scal + first, h->scal.p + first, count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipEventRecord(h->ev_fetch, h->stream));
 }
-void fetch_scalars_end(mcba_handle_s* h) { HIP_OK(hipEventSynchronize(h->ev_fetch)); }
+void fetch_scalars_end(mcba_handle_s* h) {
+  check_launch("iteration enqueue");
+  HIP_OK(hipEventSynchronize(h->ev_fetch));
+}
 double host_sum(const double* p, int n) {   // fixed order: the result does not depend on block scheduling
   double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
   int i = 0;
@@ -652,6 +700,7 @@ void launch_gn_solve(mcba_handle_s* h, double reg, bool root_rank, double* dots_
                      h->dsc.p, h->gh.p, h->P.p, h->ntile, h->ksplit, K, root_rank ? 1.0 : 0.0, h->sbuf.p, tr_dev);
   call_allreduce(h, h->sbuf.p, (size_t)total, 0);
   launch_chol(h, d.ns, tr_dev ? 0.0 : reg, h->sbuf.p, h->ps.p);
+  check_launch("reduced Cholesky");
   if (d.DF == 12) {
     const int nblk = gn_dot_blocks(d);
     hipLaunchKernelGGL((k_schur_backsub<12>), dim3(nblk), dim3(64), 0, h->stream, d, h->Lf.p, h->W.p, h->yf.p, h->ps.p,
@@ -817,6 +866,8 @@ int32_t mcba_create(const mcba_problem* p, void* hip_stream, mcba_handle* out) {
   {   // the architecture check costs a hipGetDeviceProperties (milliseconds): once per device and process
     static std::string arch_of[64];
     static bool arch_known[64] = {false};
+    static std::mutex arch_mutex;             // handles may be created from several threads at once
+    std::lock_guard<std::mutex> arch_lock(arch_mutex);
     const int di = h->device;
     if (di < 0 || di >= 64 || !arch_known[di]) {
       hipDeviceProp_t prop;

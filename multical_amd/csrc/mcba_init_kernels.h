@@ -202,7 +202,11 @@ __device__ void robust_mean_block(int n, const AlignScratch& s, double* out /* s
       }
       __syncthreads();
     }
-    // ---- cut: the n - t_clust merges of smallest height (stable in merge order for equal heights) ------------------
+    // ---- cut: scipy's fcluster(criterion='maxclust') finds the smallest merge height thr that leaves at most t_clust
+    // clusters and then applies EVERY merge of height <= thr (cluster_maxclust_monocrit + cluster_monocrit: for a monotone
+    // Ward dendrogram the criterion is the merge height itself).  thr is the (n - t_clust)-th smallest height; merges that
+    // tie with it are applied too -- exact duplicates among the relative poses (noise-free or repeated detections) give
+    // zero-height merges, and the flat clusters then hold fewer than t_clust groups, exactly as in the reference.
     const int nm = n - 1, keep = n - t_clust;
     for (int k = tid; k < nm; k += nthr) {
       const double hk = s.hgt[k];
@@ -211,12 +215,13 @@ __device__ void robust_mean_block(int n, const AlignScratch& s, double* out /* s
         const double hq = s.hgt[q];
         rank += (hq < hk || (hq == hk && q < k)) ? 1 : 0;
       }
-      s.chain[k] = rank;      // (the chain array is free now)
+      if (rank == keep - 1) sv[0] = hk;      // (ranks are a permutation: exactly one writer)
     }
     __syncthreads();
     if (tid == 0) {
+      const double thr = sv[0];
       for (int k = 0; k < nm; ++k) {
-        if (s.chain[k] >= keep) continue;
+        if (!(s.hgt[k] <= thr)) continue;
         int a = s.rep_a[k], b = s.rep_b[k];
         while (s.parent[a] != a) a = s.parent[a];
         while (s.parent[b] != b) b = s.parent[b];

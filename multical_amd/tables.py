@@ -98,9 +98,14 @@ def estimate_relative_poses(table, axis=0, hop_penalty=0.9):
     ti_p, tj_p = np.take(table.poses, parent, axis=axis), np.take(table.poses, child, axis=axis)
     valid = (np.take(table.valid, parent, axis=axis) & np.take(table.valid, child, axis=axis)).ravel()
     problems.append((ti_p.reshape(-1, 4, 4), tj_p.reshape(-1, 4, 4), valid))
-  ts, _, _ = align_transforms_robust_batch(problems)
+  ts, ok, _ = align_transforms_robust_batch(problems)
   pose_dict = {master: np.eye(4)}
-  for (parent, child), t in zip(pairs, ts):
+  for (parent, child), t, good in zip(pairs, ts, ok):
+    if not good:
+      # no common entry, or none that passes the upper-quartile test of the first pass: the reference's
+      # align_transforms_robust takes the mean of an empty set there (transform/matrix.py:140-153) and fails; the device
+      # reports the case instead of a pose (an identity transform must never be chained into the spanning tree)
+      raise ValueError(f"estimate_relative_poses (axis={axis}): no usable common poses for pair ({parent}, {child})")
     pose_dict[child] = t @ pose_dict[parent]
   poses = np.broadcast_to(np.eye(4), (n, 4, 4)).copy()
   valid = np.zeros(n, dtype=bool)

@@ -246,4 +246,4 @@ def test_bench_two_ranks_on_one_gpu():
   assert out["strong_scaling"]["frames_per_gpu"] == [250, 250] and out["strong_scaling"]["value"] > 0
   assert "gloo" in out["config"]["parallelism"]
   assert out["roofline"]["frac"] > 0 and out["obs_per_s"] > 0 and 0 < out["step_roofline_frac"] < 1
-  assert out["final_rms_px"] < 1.0
+  assert 2.5 < out["final_rms_px"] < 3.5                     # 1 % gross outliers stay in: ~3 px (single GPU: 3.03)

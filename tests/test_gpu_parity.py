@@ -603,6 +603,34 @@ def test_align_transforms_robust_batch_edge_cases():
     assert np.abs(o - want).max() < 1e-9
 
 
+def test_align_transforms_robust_with_duplicated_poses():
+  """Exact duplicates among the relative poses (repeated or noise-free detections) give zero-height merges that TIE at
+  the dendrogram cut: scipy's fcluster(maxclust) applies every merge up to the threshold height, so fewer than t flat
+  clusters come out and the 'most common' cluster differs from a cut after exactly n - t merges."""
+  from multical_amd import tables as mtables
+  from oracle import restate_init
+  rng = np.random.default_rng(11)
+  def poses(n, sigma):
+    return synthetic.to_matrix(np.concatenate([rng.normal(0, sigma, (n, 3)), rng.normal(0, 1.0, (n, 3))], axis=1))
+  T = synthetic.to_matrix(np.array([0.3, -0.2, 0.5, 0.1, 0.2, -0.4]))
+  problems = []
+  for groups, reps, extra in ((4, 2, 0), (6, 3, 2), (3, 8, 5), (10, 4, 0), (1, 12, 3)):
+    a0 = poses(groups, 0.5)
+    b0 = synthetic.perturb(T @ a0, rng, 2e-3, 2e-3)
+    a = np.concatenate([np.repeat(a0, reps, axis=0), poses(extra, 0.5)])
+    b = np.concatenate([np.repeat(b0, reps, axis=0), T @ a[groups * reps:]]) if extra else np.repeat(b0, reps, axis=0)
+    if extra:
+      b[groups * reps:] = synthetic.perturb(b[groups * reps:], rng, 2e-3, 2e-3)
+    perm = rng.permutation(len(a))
+    problems.append((a[perm], b[perm], None))
+  out, valid, inl = mtables.align_transforms_robust_batch(problems)
+  assert valid.all()
+  for (a, b, m), o, il in zip(problems, out, inl):
+    want, want_inl = restate_init.align_transforms_robust(a, b, valid=m)
+    assert np.array_equal(il, want_inl)
+    assert np.abs(o - want).max() < 1e-9
+
+
 def test_resource_cache_reuses_buffers_of_closed_handles():
   """mcba_destroy parks buffers / stream, the next mcba_create of the same shape takes them back: identical results from
   recycled (dirty) memory, also after a handle of ANOTHER shape ran in between, and after the cache was emptied."""
