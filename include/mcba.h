@@ -17,9 +17,10 @@
  *   - one handle per thread; handles are independent.
  *   - the library is HIP-only: `mcba_create` fails when no gfx950 device is present.  There is no CPU fallback.
  *   - limits of this implementation (the reference has none; all are checked by `mcba_create`, which fails with a
- *     message instead of producing a handle that cannot be solved): at most 512 points per board (n_points <= 512),
- *     at most 128 (camera, board) pairs (n_cameras * n_boards <= 128), one camera model and one distortion size
- *     (n_dist in {4, 5, 8, 12, 14} pinhole, 4 fisheye) for all cameras of a rig.
+ *     message instead of producing a handle that cannot be solved):
+ *     at most 65535 points per board; one projection FAMILY per rig (pinhole cameras may carry different numbers of
+ *     distortion coefficients -- 4, 5, 8, 12, 14: mcba_problem.camera_n_dist -- but pinhole and fisheye cameras cannot
+ *     share a rig).
  *
  * Parameter vector `x` (length `n_params`): exactly `Calibration.param_vec` (optimization/parameters.py:44-46):
  * the ENABLED blocks, in the order camera_poses | board_poses | motion | cameras | boards
@@ -47,7 +48,7 @@
 extern "C" {
 #endif
 
-#define MCBA_VERSION 1
+#define MCBA_VERSION 2
 
 /* motion models (multical/motion/) */
 #define MCBA_MOTION_STATIC   0   /* motion/static_frames.py  */
@@ -100,6 +101,12 @@ typedef struct mcba_problem {
                                 /* values of disabled blocks are taken from here                        */
   int32_t frame_begin;          /* frame shard owned by this handle: [frame_begin, frame_end) (may be empty);     */
   int32_t frame_end;            /* frame_begin < 0 = all frames.  Arrays above always describe ALL frames.       */
+  const int32_t* camera_n_dist; /* [C] distortion coefficients of EACH camera (camera.dist.size), or NULL: every   */
+                                /* camera carries n_dist.  The reference's ParamList holds independent Camera      */
+                                /* objects (optimization/parameters.py:54-85, camera.py:144-155), so the cameras   */
+                                /* block of x / x_full is ragged: camera c contributes 5 + camera_n_dist[c]        */
+                                /* entries.  n_dist must then be the maximum; pinhole sizes (4, 5, 8, 12, 14) mix  */
+                                /* freely (a smaller model is the larger one with its extra coefficients at zero). */
 } mcba_problem;
 
 typedef struct mcba_options {          /* scipy.optimize.least_squares arguments used at calibration.py:209-210 */
@@ -246,6 +253,12 @@ int32_t mcba_align_poses_robust(int32_t n_problems, const int64_t* offsets, cons
 /* Trust-region least squares: replaces scipy.optimize.least_squares(method='trf', x_scale='jac', jac_sparsity=S,
  * loss, f_scale, ftol, max_nfev) at calibration.py:209-210.  x is updated in place to `res.x`.                 */
 int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba_result* result);
+
+/* Collectives issued by a frame-sharded handle since the last reset (observability of SURVEY 8(e)): number of
+ * all-reduce calls, doubles moved, and the element counts of the first `cap` calls in issue order (negative = max
+ * reduction).  Any of the output pointers may be NULL.                                                           */
+int32_t mcba_allreduce_stats(mcba_handle h, int32_t reset, int64_t* calls, int64_t* doubles, int64_t* sizes, int32_t cap,
+                             int32_t* n_sizes);
 
 /* --- measurement ------------------------------------------------------------------------------------------- */
 /* Run the fused linearisation `repeats` times at x and return the average GPU time per pass in milliseconds

@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MCBA_LIB_PATH") or os.path.join(HERE, "_build", "libmcba.so")   # (override: kernel experiments)
 
-MCBA_VERSION = 1
+MCBA_VERSION = 2
 MOTION_STATIC, MOTION_ROLLING, MOTION_HAND_EYE = 0, 1, 2
 CAMERA_PINHOLE, CAMERA_FISHEYE = 0, 1
 LOSSES = dict(linear=0, soft_l1=1, huber=2, cauchy=3, arctan=4)
@@ -31,6 +31,7 @@ class Problem(C.Structure):
     ("image_heights", c_double_p), ("fix_aspect", c_uint8_p), ("base_wrt_gripper", c_double_p),
     ("optimize", C.c_uint32), ("x_full", c_double_p),
     ("frame_begin", C.c_int32), ("frame_end", C.c_int32),
+    ("camera_n_dist", c_int32_p),
   ]
 
 
@@ -62,6 +63,8 @@ SYMBOLS = [
   ("mcba_set_inliers", C.c_int32, [H, c_uint8_p]),
   ("mcba_set_allreduce", C.c_int32, [H, ALLREDUCE_FN, C.c_void_p]),
   ("mcba_set_shard_root", C.c_int32, [H, C.c_int32]),
+  ("mcba_allreduce_stats", C.c_int32, [H, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                       C.c_int32, C.POINTER(C.c_int32)]),
   ("mcba_set_log", C.c_int32, [H, LOG_FN, C.c_void_p]),
   ("mcba_residuals", C.c_int32, [H, c_double_p, c_double_p]),
   ("mcba_jacobian", C.c_int32, [H, c_double_p, c_int32_p, c_double_p, c_int32_p]),

@@ -78,10 +78,16 @@ def lower(calib):
   if any(fisheye) != all(fisheye):
     raise ValueError("mixed pinhole / fisheye cameras are not supported")
   p.camera_model = CAMERA_FISHEYE if all(fisheye) else CAMERA_PINHOLE
-  nd = {int(np.asarray(c.dist).size) for c in cams}
-  if len(nd) != 1:
-    raise ValueError(f"cameras carry different numbers of distortion coefficients: {sorted(nd)}")
-  p.n_dist = nd.pop()
+  # every Camera is an independent object (optimization/parameters.py:54-85): the distortion size may differ from camera
+  # to camera (models `standard` / `rational` / `thin_prism` / `tilted`, or a 4-coefficient file); the library pads to the
+  # largest and freezes the coefficients a camera does not have
+  nds = [int(np.asarray(c.dist).size) for c in cams]
+  p.n_dist = max(nds)
+  p.camera_n_dist = None
+  if len(set(nds)) != 1:
+    if all(fisheye):
+      raise ValueError(f"fisheye cameras carry 4 distortion coefficients, got {sorted(set(nds))}")
+    p.camera_n_dist = np.ascontiguousarray(np.array(nds, dtype=np.int32))
   p.image_heights = _f64([c.image_size[1] for c in cams])
   p.fix_aspect = _u8([bool(c.fix_aspect) for c in cams])
 
@@ -115,6 +121,7 @@ def _to_struct(p, frame_range=None):
   s.optimize = p.optimize
   s.x_full = _ptr(p.x_full, C.c_double)
   s.frame_begin, s.frame_end = (-1, -1) if frame_range is None else frame_range
+  s.camera_n_dist = None if getattr(p, "camera_n_dist", None) is None else _ptr(p.camera_n_dist, C.c_int32)
   return s
 
 
@@ -226,6 +233,10 @@ class Handle(object):
                                  _ptr(cols, C.c_int32)))
     indices = np.repeat(cols, 2, axis=0).ravel()
     indptr = np.arange(0, m * k + 1, k)
+    if (cols < 0).any():   # ragged camera blocks: slots of coefficients a camera's model does not have carry column -1
+      keep = indices >= 0
+      counts = keep.reshape(m, k).sum(axis=1)
+      return csr_matrix((vals.ravel()[keep], indices[keep], np.concatenate([[0], np.cumsum(counts)])), shape=(m, self.n_params))
     return csr_matrix((vals.ravel(), indices, indptr), shape=(m, self.n_params))
 
   def reprojection_error(self, x):
@@ -357,6 +368,14 @@ class Handle(object):
 
   def set_shard_root(self, is_root):
     check(self.lib.mcba_set_shard_root(self.h, 1 if is_root else 0))
+
+  def allreduce_stats(self, reset=True, cap=4096):
+    """(calls, doubles, sizes): collectives this (frame-sharded) handle issued since the last reset; `sizes` lists the
+    element counts in issue order (negative = max reduction)."""
+    calls, doubles, n = C.c_int64(), C.c_int64(), C.c_int32()
+    sizes = (C.c_int64 * cap)()
+    check(self.lib.mcba_allreduce_stats(self.h, 1 if reset else 0, C.byref(calls), C.byref(doubles), sizes, cap, C.byref(n)))
+    return calls.value, doubles.value, [int(sizes[i]) for i in range(n.value)]
 
   def set_allreduce(self, fn):
     """fn(device_ptr:int, count:int, op:int, stream:int) -> int (0 = ok); see multical_amd.distributed."""

@@ -76,7 +76,8 @@ class _HandleCache(object):
         calib._mcba_problem = prob                   # (not part of __getstate__: never pickled)
       except AttributeError:
         pass
-    key = (prob.shape, prob.optimize, prob.motion, prob.camera_model, prob.n_dist, prob.fix_aspect.tobytes(),
+    key = (prob.shape, prob.optimize, prob.motion, prob.camera_model, prob.n_dist,
+           None if prob.camera_n_dist is None else prob.camera_n_dist.tobytes(), prob.fix_aspect.tobytes(),
            prob.camera_valid.tobytes(), prob.frame_valid.tobytes(), prob.board_valid.tobytes(),
            prob.board_sizes.tobytes(), prob.image_heights.tobytes())
     points, valid = calib.point_table.points, calib.point_table.valid

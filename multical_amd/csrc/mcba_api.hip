@@ -257,7 +257,7 @@ struct mcba_handle_s {
   bool use_mfma = true;
   bool shard_root = true;
   ScalLayout sl;
-  size_t chol_lds_set = 0, chol_lds2_set = 0, chol_lds3_set = 0, chol_lds4_set = 0;
+  size_t chol_lds_set = 0, chol_lds2_set = 0, chol_lds3_set = 0, chol_lds4_set = 0, chol_lds5_set = 0;
   DevBuf<double> chol_linv;   // inverted diagonal tiles of k_chol_glb
   int lin_grid = 0;          // 0 = automatic (see lin2), > 0 = forced number of persistent workgroups (debug)
 
@@ -271,7 +271,7 @@ struct mcba_handle_s {
   DevBuf<int32_t> view_first;            // first residual pair of every view (k_view_scan)
   DevBuf<long long> totals;              // {inliers, evalid points} of the shard
   long long* h_totals = nullptr;         // pinned
-  DevBuf<int32_t> obs_index, view_count, active_views, work_counter, board_off, full2act;
+  DevBuf<int32_t> obs_index, view_count, active_views, av_counts, work_counter, board_off, full2act;
   DevBuf<double> xfull, bwg, img_h, board_points, pose, cam, view, tmat;
   DevBuf<uint16_t> tri;
   DevBuf<int4> ftab;   // frame_table(d): what a frame block of k_assemble sums and where it goes
@@ -301,13 +301,29 @@ struct mcba_handle_s {
   DevBuf<uint8_t> out_valid;
   DevBuf<int32_t> out_cols;
 
+  // ragged camera blocks (mcba_problem.camera_n_dist): maps between the caller's parameter vector and the padded one
+  std::vector<int32_t> ext2int;      // empty = identity
+  int n_ext = 0;                     // length of the caller's vector (== d.n without a map)
+  DevBuf<uint32_t> cam_kmask;
+  DevBuf<int32_t> int2ext;
+  std::vector<double> xmap_tmp;      // staging of mapped outputs
+
   mcba_allreduce_fn allreduce = nullptr;
   void* allreduce_ctx = nullptr;
+  // collectives issued through call_allreduce since the last mcba_allreduce_stats(reset): count, doubles moved and the
+  // sizes of the first calls in issue order (the sequence the world-2 tests assert)
+  int64_t ar_calls = 0, ar_doubles = 0;
+  std::vector<int64_t> ar_trace;
   void* rccl_comm = nullptr;   // ncclComm_t of the native all-reduce path (mcba_rccl_init)
   mcba_log_fn log = nullptr;
   void* log_ctx = nullptr;
 
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fetch = nullptr;
+  // captured evaluation (MCBA_GRAPH=1): the launch sequence of one residual+Jacobian evaluation as a hipGraph
+  hipGraphExec_t eval_graph = nullptr;
+  const double* eval_graph_x = nullptr;
+  int eval_graph_loss = -1;
+  double eval_graph_fscale = 0.0;
 
   size_t h_scal_bytes = 0, h_x_bytes = 0, h_gbuf_bytes = 0, h_totals_bytes = 0;   // sizes of the pinned buffers
   ~mcba_handle_s() {
@@ -318,6 +334,7 @@ struct mcba_handle_s {
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     if (ev_fetch) (void)hipEventDestroy(ev_fetch);
+    if (eval_graph) (void)hipGraphExecDestroy(eval_graph);
     if (rccl_comm) destroy_rccl_comm(rccl_comm);
     if (own_stream && stream && !(g_park_on_release && resource_cache().park_stream(stream))) (void)hipStreamDestroy(stream);
   }
@@ -344,7 +361,11 @@ const CamOps* pick_ops(int model, int nd) {
 }
 
 void refresh_active_views(mcba_handle_s* h) {
-  hipLaunchKernelGGL(k_active_views, dim3(1), dim3(1024), 0, h->stream, h->d.views(), h->view_count.p, h->active_views.p);
+  const int nv = h->d.views(), nblk = std::max(1, (nv + AV_THREADS - 1) / AV_THREADS);
+  if (h->av_counts.n < (size_t)nblk * AV_CLASSES) h->av_counts.alloc((size_t)nblk * AV_CLASSES, false);
+  hipLaunchKernelGGL(k_active_count, dim3(nblk), dim3(AV_THREADS), 0, h->stream, nv, h->view_count.p, h->av_counts.p);
+  hipLaunchKernelGGL(k_active_scatter, dim3(nblk), dim3(AV_THREADS), 0, h->stream, nv, h->view_count.p, h->av_counts.p,
+                     h->active_views.p);
 }
 
 // upload the shard's frames of a [C,F,B,P] host array (element size esz bytes) as C contiguous slabs [C][Fl][B][P]
@@ -405,7 +426,12 @@ void set_loss(mcba_handle_s* h, const mcba_options* opt) {
 // x goes up through a pinned staging buffer (a pageable source makes the runtime stage and synchronise internally).
 // The previous upload from the buffer has completed: every API entry synchronises the stream before it returns.
 void upload_x(mcba_handle_s* h, const double* x, double* dst) {
-  memcpy(h->h_x, x, (size_t)h->d.n * sizeof(double));
+  if (h->ext2int.empty()) {
+    memcpy(h->h_x, x, (size_t)h->d.n * sizeof(double));
+  } else {   // the caller's cameras block is ragged: scatter into the padded layout (absent coefficients are zero)
+    memset(h->h_x, 0, (size_t)h->d.n * sizeof(double));
+    for (int i = 0; i < h->n_ext; ++i) h->h_x[h->ext2int[i]] = x[i];
+  }
   HIP_OK(hipMemcpyAsync(dst, h->h_x, (size_t)h->d.n * sizeof(double), hipMemcpyHostToDevice, h->stream));
 }
 
@@ -472,6 +498,9 @@ int32_t rccl_allreduce_native(void* ctx, void* device_buf, size_t count, int32_t
 
 int call_allreduce(mcba_handle_s* h, double* buf, size_t count, int op) {
   if (!h->allreduce) return 0;
+  ++h->ar_calls;
+  h->ar_doubles += (int64_t)count;
+  if (h->ar_trace.size() < 4096) h->ar_trace.push_back(op == 0 ? (int64_t)count : -(int64_t)count);
   const int rc = h->allreduce(h->allreduce_ctx, buf, count, op, (void*)h->stream);
   if (rc != 0) throw Error("all-reduce hook failed with code " + std::to_string(rc));
   return 0;
@@ -485,6 +514,12 @@ int call_allreduce(mcba_handle_s* h, double* buf, size_t count, int op) {
 void check_launch(const char* what) {
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) throw Error(std::string("kernel launch failed (") + what + "): " + hipGetErrorString(e));
+}
+
+// MCBA_FUSED: 0 = table form (k_tmat + k_linearize), 1 = k_linearize forms everything from x, 2 = table-fed fused form
+int linearize_fused_mode() {
+  static const int mode = getenv("MCBA_FUSED") != nullptr ? atoi(getenv("MCBA_FUSED")) : 0;
+  return mode;
 }
 
 // fused residual+Jacobian -> block normal equations.  dx != nullptr: at the parameter vector dx (device); k_tmat then also
@@ -501,9 +536,26 @@ void launch_linearize(mcba_handle_s* h, const double* dx) {
   // drops from 88.8 to 86.6 us, but the per-view prologue (Rodrigues of four poses on four lanes, divergent column code)
   // grows from 3.8 k to 14 k cycles and k_linearize from 49.5 to 62 us -- the table form stays the default until the
   // in-kernel prologue is lane-uniform.
-  static const bool fused_on = getenv("MCBA_FUSED") != nullptr && getenv("MCBA_FUSED")[0] == '1';
+  const int fused_mode = linearize_fused_mode();
+  const bool fused_on = fused_mode == 1;
   if (dx != nullptr && h->use_mfma && d.ND != 14 && d.off_boards < 0 && fused_on && h->t.dbg == nullptr) {
     h->ops->linearize(d, h->t, h->stream, h->rec.p, h->tri.p, true, h->lin_grid, dx, h->gbuf.p, 2 * d.n + 2, h->Hss.p,
+                      d.ns * d.ns);
+    return;
+  }
+  // Table-fed fused form (MCBA_FUSED=2): no k_tmat, no That table.  The pose / camera tables of the point come from k_prep
+  // (dx given) or from the tail of the k_vec_step that produced the point (dx == nullptr); k_linearize copies its view's
+  // four pose entries from the table and forms the chain products / That columns itself.  Not with adjusted board points
+  // (k_points reads the per-view chain table that only k_tmat / k_views write).
+  // Default policy (MCBA_FUSED unset): the table-fed fused form whenever the tables already hold the point (dx == nullptr:
+  // the speculative linearisation behind a trial step -- k_tmat would only re-derive what the kernel can form itself:
+  // LM iteration 235 -> 228 us at the north-star rig), and for rigs with many views per frame, where k_tmat's per-view table
+  // pass is the larger cost (16 x 1000 x 5: evaluation 180 -> 147 us, k_tmat 48 us against +7.5 us in k_linearize).  The
+  // table form otherwise (8 x 500 x 2: 73.7 against 74.3 us per evaluation).
+  const bool auto_fused = getenv("MCBA_FUSED") == nullptr && (dx == nullptr || d.C * d.B >= 32);
+  if ((fused_mode == 2 || auto_fused) && h->use_mfma && d.off_boards < 0 && h->t.dbg == nullptr) {
+    if (dx != nullptr) eval_pose_tables(h, dx);
+    h->ops->linearize(d, h->t, h->stream, h->rec.p, h->tri.p, true, h->lin_grid, nullptr, h->gbuf.p, 2 * d.n + 2, h->Hss.p,
                       d.ns * d.ns);
     return;
   }
@@ -536,16 +588,21 @@ void launch_assemble(mcba_handle_s* h) {
   const int ne = frame_entries(d), cb = d.C * d.B;
   const int ngroups = nfb ? (cb * ne * 8 + stage_kb * 1024 - 1) / (stage_kb * 1024) : 1;
   const int gviews = (cb + ngroups - 1) / ngroups;
-  const size_t lds = nfb ? (size_t)gviews * ne * sizeof(double) + (size_t)ne * sizeof(int) : 0;
+  const size_t lds = nfb ? (size_t)gviews * ne * sizeof(double) + (size_t)ne * sizeof(int) + (size_t)((cb + 7) / 8 * 8) : 0;
   // (timed apart at cfg3: frame blocks alone 10.0 us, chunk sums alone 6.9 us, together 12.4 us)
   hipLaunchKernelGGL(k_assemble, dim3(nfb + d.C * d.B * h->nchunk), dim3(ASM_THREADS), lds, h->stream, d, h->t, h->rec.p, nfb, h->nchunk, gviews,
                      h->ftab.p, h->nftab, h->Hff.p, h->Hfs.p, h->g(), h->diag(), h->partial.p);
   check_launch("k_assemble");
   {
     const int npair = d.C * d.B, pg = std::min(npair, 16);
-    REQUIRE((size_t)npair * 64 * sizeof(double) <= 64 * 1024, "too many (camera, board) pairs for the shared assembly");
-    hipLaunchKernelGGL(k_shared_final, dim3((d.rec_size + 2 + 63) / 64), dim3(64 * pg), (size_t)npair * 64 * sizeof(double),
-                       h->stream, d, h->partial.p, h->nchunk, h->tri.p, h->Hss.p, h->g(), h->diag(), h->costcount());
+    // MCBA_SHARED_FINAL_BIG=1 forces the many-pairs kernel (tests)
+    static const bool force_big = getenv("MCBA_SHARED_FINAL_BIG") != nullptr && getenv("MCBA_SHARED_FINAL_BIG")[0] == '1';
+    if (npair <= SHARED_FINAL_MAX_PAIRS && !force_big)   // pair sums in LDS
+      hipLaunchKernelGGL(k_shared_final, dim3((d.rec_size + 2 + 63) / 64), dim3(64 * pg), (size_t)npair * 64 * sizeof(double),
+                         h->stream, d, h->partial.p, h->nchunk, h->tri.p, h->Hss.p, h->g(), h->diag(), h->costcount());
+    else                                                 // more (camera, board) pairs than the LDS table holds
+      hipLaunchKernelGGL(k_shared_final_big, dim3((d.rec_size + 2 + 63) / 64, (npair + 15) / 16), dim3(1024), 0, h->stream, d,
+                         h->partial.p, h->nchunk, h->tri.p, h->Hss.p, h->g(), h->diag(), h->costcount());
     check_launch("k_shared_final");
   }
   if (d.off_boards >= 0) {   // adjusted board points: their blocks of H_ss / H_fs / g (unique entries, plain stores)
@@ -553,6 +610,13 @@ void launch_assemble(mcba_handle_s* h) {
     hipLaunchKernelGGL(k_shared_diag, dim3((d.ns + 255) / 256), dim3(256), 0, h->stream, d, h->Hss.p, h->diag());
   }
   call_allreduce(h, h->gbuf.p, 2 * (size_t)d.n + 2, 0);
+}
+
+// internal (padded) n-vector -> the caller's vector
+void to_caller(const mcba_handle_s* h, double* dst, const double* src_internal) {
+  if (h->ext2int.empty()) memcpy(dst, src_internal, (size_t)h->d.n * sizeof(double));
+  else
+    for (int i = 0; i < h->n_ext; ++i) dst[i] = src_internal[h->ext2int[i]];
 }
 
 void sync(mcba_handle_s* h) {
@@ -590,19 +654,45 @@ bool g_force_blocked_chol = false;   // test hooks
 bool g_force_panel_chol = false;
 bool g_force_column_chol = false;
 bool g_force_glb_chol = false;
+bool g_force_panel2_chol = false;    // the multi-launch panel kernels (k_cholp_*) at any size
 long long* g_chol_prof = nullptr;    // device buffer of 8 phase stamps (mcba_debug_chol, blocked == 4)
 
 // (S + reg I) p = rhs for buf = [S (ns x ns) | rhs (ns)]; S is overwritten by its Cholesky factor
 void launch_chol(mcba_handle_s* h, int ns, double reg, double* buf, double* ps) {
   const int max_rows = ns + 1;
   const size_t lds_packed = ((size_t)(ns + 1) * (ns + 2) / 2 + (ns + 1) + 2) * sizeof(double);
-  if (ns + 1 <= CHOL_BLK_MAX_N1 && !g_force_blocked_chol && !g_force_panel_chol && !g_force_column_chol && !g_force_glb_chol) {
+  if (ns + 1 <= CHOL_BLK_MAX_N1 && !g_force_blocked_chol && !g_force_panel_chol && !g_force_column_chol && !g_force_glb_chol &&
+      !g_force_panel2_chol) {
     const size_t lds_blk = chol_blk_lds_bytes(ns);
     if (lds_blk > h->chol_lds3_set) {
       HIP_OK(hipFuncSetAttribute((const void*)k_chol_blk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_blk));
       h->chol_lds3_set = lds_blk;
     }
     hipLaunchKernelGGL(k_chol_blk, dim3(1), dim3(CHOL_BLK_THREADS), lds_blk, h->stream, ns, reg, buf, ps, h->info.p, g_chol_prof);
+    return;
+  }
+  const bool forced_other = g_force_blocked_chol || g_force_panel_chol || g_force_column_chol || g_force_glb_chol;
+  if ((g_force_panel2_chol || !forced_other) && ns + 1 <= CHOL_GLB_MAX_N1) {
+    // 160 < ns + 1 <= 1024: block columns of up to 48 columns factored in LDS by one workgroup, the trailing update on
+    // the whole chip, back substitution with inverted diagonal tiles (k_cholp_*)
+    const int nb = (ns + 1 + CT - 1) / CT, nbc = (ns + CT - 1) / CT;
+    const size_t nlinv = (size_t)nb * CT * CT;
+    if (h->chol_linv.n < nlinv) h->chol_linv.alloc(nlinv, false);
+    for (int kt0 = 0; kt0 < nbc;) {
+      const int wt = cholp_panel_tiles(ns, kt0);
+      const size_t lds = cholp_lds_bytes(ns, kt0, wt);
+      if (lds > h->chol_lds5_set) {
+        HIP_OK(hipFuncSetAttribute((const void*)k_cholp_panel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        h->chol_lds5_set = lds;
+      }
+      hipLaunchKernelGGL(k_cholp_panel, dim3(1), dim3(CHOLP_THREADS), lds, h->stream, ns, kt0, wt, reg, buf, h->chol_linv.p,
+                         h->info.p);
+      const int k1 = kt0 + wt, m = nb - k1, nt = m * (m + 1) / 2;
+      if (k1 < nbc && nt > 0)
+        hipLaunchKernelGGL(k_cholp_trail, dim3((nt + 3) / 4), dim3(256), 0, h->stream, ns, kt0, wt, buf);
+      kt0 = k1;
+    }
+    hipLaunchKernelGGL(k_cholp_back, dim3(1), dim3(1024), 0, h->stream, ns, (const double*)buf, (const double*)h->chol_linv.p, ps);
     return;
   }
   if (ns + 1 <= (g_force_glb_chol ? CHOL_GLB_MAX_N1 : CHOL_GLB_AUTO_N1) && !g_force_blocked_chol && !g_force_panel_chol &&
@@ -750,11 +840,12 @@ void compute_errors(mcba_handle_s* h, const double* x) {
   }
   // the per-slot errors depend on x only (the observation tables of a handle are fixed): report() asks for the statistics
   // of the same point several times (all valid points, inliers, the rejection threshold) -- evaluate once
-  if (h->err_valid && h->err_x.size() == (size_t)d.n && memcmp(h->err_x.data(), x, (size_t)d.n * sizeof(double)) == 0) return;
+  const size_t nx = h->ext2int.empty() ? (size_t)d.n : (size_t)h->n_ext;   // length of the caller's vector
+  if (h->err_valid && h->err_x.size() == nx && memcmp(h->err_x.data(), x, nx * sizeof(double)) == 0) return;
   upload_x(h, x, h->x.p);
   eval_tables(h, h->x.p);
   h->ops->residual(d, h->t, h->stream, nullptr, nullptr, nullptr, h->err_fm.p, nullptr);   // frame-major errors
-  h->err_x.assign(x, x + d.n);
+  h->err_x.assign(x, x + nx);
   h->err_valid = true;
 }
 
@@ -897,6 +988,13 @@ int32_t mcba_create(const mcba_problem* p, void* hip_stream, mcba_handle* out) {
   const double tc1 = now_seconds();
   h->d = hp.d;
   Dims& d = h->d;
+  h->ext2int = hp.ext2int;
+  h->n_ext = hp.n_ext;
+  if (!hp.cam_kmask.empty()) {
+    h->cam_kmask.upload(hp.cam_kmask);
+    d.cam_kmask = h->cam_kmask.p;      // (device pointer: kernels only; host code below uses hp.cam_kmask)
+    if (!hp.int2ext.empty()) h->int2ext.upload(hp.int2ext);
+  }
   // ---- raw upload + device lowering (k_lower_view): the caller's [C,F,B,P] arrays go up as they are ------------------
   const size_t nslot = (size_t)d.slots();
   h->obs.alloc(nslot, false);
@@ -957,7 +1055,9 @@ int32_t mcba_create(const mcba_problem* p, void* hip_stream, mcba_handle* out) {
   h->bwg.upload(hp.bwg);
   h->tri.upload(hp.tri);
   {
-    const std::vector<int4> ft = frame_table(h->d);
+    Dims dh = h->d;
+    dh.cam_kmask = hp.cam_kmask.empty() ? nullptr : hp.cam_kmask.data();   // host copy for the host-side index arithmetic
+    const std::vector<int4> ft = frame_table(dh);
     h->ftab.upload(ft);
     h->nftab = (int)ft.size();
   }
@@ -972,6 +1072,7 @@ int32_t mcba_create(const mcba_problem* p, void* hip_stream, mcba_handle* out) {
   t.view_count = h->view_count.p; t.active_views = h->active_views.p; t.work_counter = h->work_counter.p; t.board_off = h->board_off.p; t.full2act = h->full2act.p; t.xfull = h->xfull.p;
   t.bwg = h->bwg.p; t.img_h = h->img_h.p; t.fix_aspect = h->fix_aspect.p; t.board_points = h->board_points.p;
   t.pose = h->pose.p; t.cam = h->cam.p; t.view = h->view.p; t.tmat = h->tmat.p; t.dbg = nullptr;
+  t.int2ext = h->int2ext.p;
   refresh_active_views(h.get());
 
   // ---- work buffers -----------------------------------------------------------------------------------------
@@ -1065,7 +1166,7 @@ int32_t mcba_device_info(mcba_handle h, char* buf, size_t buf_len) {
 int32_t mcba_num_params(mcba_handle h, int64_t* n) {
   API_BEGIN
   REQUIRE(h && n, "null argument");
-  *n = h->d.n;
+  *n = h->ext2int.empty() ? h->d.n : h->n_ext;   // length of the CALLER's vector (Calibration.param_vec)
   API_END
 }
 
@@ -1134,6 +1235,22 @@ int32_t mcba_rccl_shutdown(mcba_handle h) {
     h->rccl_comm = nullptr;
     if (h->allreduce == rccl_allreduce_native) { h->allreduce = nullptr; h->allreduce_ctx = nullptr; }
   }
+  API_END
+}
+
+/* collectives this handle issued since the last reset: number of all-reduce calls, doubles moved, and the sizes of the
+ * first `cap` calls in issue order (negative = max reduction).  The sharded solver's chain per accepted iteration is
+ * [g | diag | cost] -> Cauchy curvature (1) -> Schur system (ns^2 + ns) -> frame part of the step (n_motion).           */
+int32_t mcba_allreduce_stats(mcba_handle h, int32_t reset, int64_t* calls, int64_t* doubles, int64_t* sizes, int32_t cap,
+                             int32_t* n_sizes) {
+  API_BEGIN
+  REQUIRE(h, "null handle");
+  if (calls) *calls = h->ar_calls;
+  if (doubles) *doubles = h->ar_doubles;
+  const int n = (int)std::min<size_t>(h->ar_trace.size(), (size_t)std::max(cap, 0));
+  if (sizes) for (int i = 0; i < n; ++i) sizes[i] = h->ar_trace[i];
+  if (n_sizes) *n_sizes = n;
+  if (reset) { h->ar_calls = 0; h->ar_doubles = 0; h->ar_trace.clear(); }
   API_END
 }
 
@@ -1333,8 +1450,8 @@ int32_t mcba_normal_equations(mcba_handle h, const double* x, const mcba_options
   const size_t first = (g || diag) ? 0 : 2 * (size_t)d.n, count = 2 * (size_t)d.n + 2 - first;
   HIP_OK(hipMemcpyAsync(h->h_gbuf + first, h->gbuf.p + first, count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   sync(h);
-  if (g) memcpy(g, h->h_gbuf, (size_t)d.n * sizeof(double));
-  if (diag) memcpy(diag, h->h_gbuf + d.n, (size_t)d.n * sizeof(double));
+  if (g) to_caller(h, g, h->h_gbuf);
+  if (diag) to_caller(h, diag, h->h_gbuf + d.n);
   if (cost) *cost = h->h_gbuf[2 * (size_t)d.n];
   API_END
 }
@@ -1346,6 +1463,33 @@ int32_t mcba_normal_equations_device(mcba_handle h, const mcba_options* opt) {
   API_BEGIN
   REQUIRE(h, "null handle");
   set_loss(h, opt);
+  // MCBA_GRAPH=1: the four launches of an evaluation are captured once per (x buffer, loss) into a hipGraph and replayed
+  // with one hipGraphLaunch (single-GPU handles; a sharded handle's collectives stay stream-ordered launches)
+  static const bool graph_on = getenv("MCBA_GRAPH") != nullptr && getenv("MCBA_GRAPH")[0] == '1';
+  if (graph_on && !h->allreduce) {
+    if (h->eval_graph == nullptr || h->eval_graph_x != h->x.p || h->eval_graph_loss != h->d.loss ||
+        h->eval_graph_fscale != h->d.f_scale) {
+      if (h->eval_graph) { (void)hipGraphExecDestroy(h->eval_graph); h->eval_graph = nullptr; }
+      hipGraph_t graph = nullptr;
+      HIP_OK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+      try {
+        launch_linearize(h, h->x.p);
+        launch_assemble(h);
+      } catch (...) {
+        (void)hipStreamEndCapture(h->stream, &graph);
+        if (graph) (void)hipGraphDestroy(graph);
+        throw;
+      }
+      HIP_OK(hipStreamEndCapture(h->stream, &graph));
+      HIP_OK(hipGraphInstantiate(&h->eval_graph, graph, nullptr, nullptr, 0));
+      (void)hipGraphDestroy(graph);
+      h->eval_graph_x = h->x.p;
+      h->eval_graph_loss = h->d.loss;
+      h->eval_graph_fscale = h->d.f_scale;
+    }
+    HIP_OK(hipGraphLaunch(h->eval_graph, h->stream));
+    return 0;
+  }
   launch_linearize(h, h->x.p);
   launch_assemble(h);
   API_END
@@ -1367,8 +1511,17 @@ int32_t mcba_dense_hessian(mcba_handle h, double* H) {
   h->out_big.alloc(nn, false);
   hipLaunchKernelGGL(k_dense_hessian, dim3(std::min<size_t>(4096, (nn + 255) / 256)), dim3(256), 0, h->stream, d,
                      h->Hss.p, h->Hfs.p, h->Hff.p, h->out_big.p);
-  HIP_OK(hipMemcpyAsync(H, h->out_big.p, nn * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  sync(h);
+  if (h->ext2int.empty()) {
+    HIP_OK(hipMemcpyAsync(H, h->out_big.p, nn * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    sync(h);
+  } else {   // rows and columns of the caller's (ragged) parameter order
+    std::vector<double> full(nn);
+    HIP_OK(hipMemcpyAsync(full.data(), h->out_big.p, nn * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    sync(h);
+    const int ne = h->n_ext;
+    for (int i = 0; i < ne; ++i)
+      for (int j = 0; j < ne; ++j) H[(size_t)i * ne + j] = full[(size_t)h->ext2int[i] * d.n + h->ext2int[j]];
+  }
   API_END
 }
 
@@ -1381,11 +1534,23 @@ int32_t mcba_debug_gn_step(mcba_handle h, double reg, double* gn_h, double* g_h,
   hipLaunchKernelGGL(k_vec_scale, dim3(h->sl.nvb), dim3(256), 0, h->stream, d, h->x.p, h->g(), h->diag(), h->scale_inv.p,
                      h->dsc.p, h->gh.p, 1, h->scal.p + h->sl.vs, (const double*)nullptr, (double*)nullptr);
   launch_gn_solve(h, reg, h->shard_root);
-  HIP_OK(hipMemcpyAsync(gn_h, h->gn.p, (size_t)d.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  if (g_h) HIP_OK(hipMemcpyAsync(g_h, h->gh.p, (size_t)d.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  if (scale_inv)
-    HIP_OK(hipMemcpyAsync(scale_inv, h->scale_inv.p, (size_t)d.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  sync(h);
+  if (h->ext2int.empty()) {
+    HIP_OK(hipMemcpyAsync(gn_h, h->gn.p, (size_t)d.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (g_h) HIP_OK(hipMemcpyAsync(g_h, h->gh.p, (size_t)d.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (scale_inv)
+      HIP_OK(hipMemcpyAsync(scale_inv, h->scale_inv.p, (size_t)d.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    sync(h);
+  } else {
+    h->xmap_tmp.resize(3 * (size_t)d.n);
+    double* tmp = h->xmap_tmp.data();
+    HIP_OK(hipMemcpyAsync(tmp, h->gn.p, (size_t)d.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipMemcpyAsync(tmp + d.n, h->gh.p, (size_t)d.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipMemcpyAsync(tmp + 2 * d.n, h->scale_inv.p, (size_t)d.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    sync(h);
+    to_caller(h, gn_h, tmp);
+    if (g_h) to_caller(h, g_h, tmp + d.n);
+    if (scale_inv) to_caller(h, scale_inv, tmp + 2 * d.n);
+  }
   int info = 0;
   HIP_OK(hipMemcpy(&info, h->info.p, sizeof(int), hipMemcpyDeviceToHost));
   REQUIRE(info == 0, "Cholesky of the reduced system hit a non-positive pivot at column " + std::to_string(info));
@@ -1422,6 +1587,7 @@ int32_t mcba_debug_chol(mcba_handle h, int32_t ns, const double* S, const double
   g_force_panel_chol = blocked == 2;
   g_force_column_chol = blocked == 3;    // 3: column-by-column LDS kernel (the round-1 baseline of k_chol_blk)
   g_force_glb_chol = blocked == 5;       // 5: one-workgroup kernel with the matrix in global memory
+  g_force_panel2_chol = blocked == 6;    // 6: multi-launch panel kernels (k_cholp_*: the default for 160 < ns + 1 <= 1024)
   DevBuf<long long> stamps;
   if (blocked == 4) {                    // 4: k_chol_blk with phase stamps; p_out[0..7] receives the shader-clock totals
     REQUIRE(ns >= 8 && ns + 1 <= CHOL_BLK_MAX_N1, "profiling needs 8 <= ns < 160");
@@ -1429,8 +1595,8 @@ int32_t mcba_debug_chol(mcba_handle h, int32_t ns, const double* S, const double
     g_chol_prof = stamps.p;
   }
   try { launch_chol(h, ns, reg, buf.p, ps.p); }
-  catch (...) { g_force_blocked_chol = g_force_panel_chol = g_force_column_chol = g_force_glb_chol = false; g_chol_prof = nullptr; throw; }
-  g_force_blocked_chol = g_force_panel_chol = g_force_column_chol = g_force_glb_chol = false;
+  catch (...) { g_force_blocked_chol = g_force_panel_chol = g_force_column_chol = g_force_glb_chol = g_force_panel2_chol = false; g_chol_prof = nullptr; throw; }
+  g_force_blocked_chol = g_force_panel_chol = g_force_column_chol = g_force_glb_chol = g_force_panel2_chol = false;
   g_chol_prof = nullptr;
   if (blocked == 4) {
     long long st[8];
@@ -1544,15 +1710,21 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
   //  itself; k_tmat rebuilds the view table if the step is accepted)
   const int prep_blocks = (d.n_pose + d.C + d.B * d.P + 255) / 256;
   const int dot_blocks = (h->allreduce && d.DF > 0) ? 1 : gn_dot_blocks(d);   // (a shard gets the complete dots: one "block")
-  auto enqueue_trial = [&](double alpha, double beta, double* tr_dev) {
+  // with_cost = false (sharded handles, first trial of an iteration): no k_cost pass and no 1-double all-reduce -- the
+  // speculative linearisation at x_new that follows delivers the cost of the very same point inside its own
+  // [g | diag | cost] message (one dependent collective less per accepted iteration)
+  auto enqueue_trial = [&](double alpha, double beta, double* tr_dev, bool with_cost = true) {
     hipLaunchKernelGGL(k_vec_step, dim3(sl.nvb + prep_blocks), dim3(256), 0, h->stream, d, h->t, h->x.p, h->dsc.p, h->gh.p,
                        h->gn.p, alpha, beta, h->xnew.p, h->scal.p + sl.step, tr_dev, h->scal.p + sl.dotp, dot_blocks, sl.nvb);
+    if (!with_cost) return;
     h->ops->cost(d, h->t, h->stream, h->scal.p + sl.costp, cost_grid);   // (an empty shard writes partial[0] = 0)
     if (h->allreduce) {
       hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(64), 0, h->stream, h->scal.p + sl.costp, cost_grid);
       call_allreduce(h, h->scal.p + sl.costp, 1, 0);
     }
   };
+  static const bool merge_off = getenv("MCBA_NO_MERGED_TRIAL_COST") != nullptr && getenv("MCBA_NO_MERGED_TRIAL_COST")[0] == '1';
+  const bool merged_trial_cost = h->allreduce != nullptr && !merge_off;
   auto fold_trial = [&](double* step_h2, double* step2, double* x2) {   // after a fetch that covers [sl.step, ...)
     double s3[3] = {0, 0, 0};
     for (int blk = 0; blk < sl.nvb; ++blk)
@@ -1592,14 +1764,21 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
       // (the fold of the k_vec_scale / k_q00 partials and the damping: head of the first kernel of the solve)
       const TrRegPartials trp{h->scal.p + sl.vs, sl.nvb, h->scal.p + sl.q00p, h->allreduce ? 1 : Q00_BLOCKS, first ? 1 : 0, Delta};
       launch_gn_solve(h, 0.0, is_root, h->scal.p + sl.dotp, h->scal.p, &trp);
-      enqueue_trial(0.0, 0.0, h->scal.p);
-      fetch_scalars_begin(h, trial_fetch_end);
+      enqueue_trial(0.0, 0.0, h->scal.p, !merged_trial_cost);
+      if (!merged_trial_cost) fetch_scalars_begin(h, trial_fetch_end);
       // Speculation: most trial steps are accepted, so the linearisation at x_new is enqueued right behind the copy and
       // runs while the host looks at the trial cost and prepares the next iteration.  A rejected step leaves the
       // records / H / g of x_new behind (lin_stale): they are not needed by the retries with a smaller radius, and
       // are rebuilt before anything reads them again.
-      timed_linearize(h->xnew.p);   // (fused form: straight from x_new; table form: k_tmat re-derives its entries)
+      // (fused form: straight from x_new; table form: k_tmat re-derives its entries; table-fed fused form: the tail of
+      //  k_vec_step has just written the pose / camera tables of x_new -- no table kernel at all)
+      timed_linearize((linearize_fused_mode() == 2 || getenv("MCBA_FUSED") == nullptr) && d.off_boards < 0 && h->use_mfma
+                          ? nullptr : h->xnew.p);
       spec_lin = true;
+      if (merged_trial_cost) {      // the cost of x_new arrived with the linearisation's all-reduced [g | diag | cost]
+        HIP_OK(hipMemcpyAsync(h->scal.p + sl.costp, h->costcount(), sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        fetch_scalars_begin(h, trial_fetch_end);
+      }
       mark("iteration enqueued");
       fetch_scalars_end(h);
       mark("trial cost fetched");
@@ -1692,7 +1871,7 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
   //  MCBA_SOLVE_TRACE=1 prints the driver's stage times)
   HIP_OK(hipMemcpyAsync(h->h_x, h->x.p, (size_t)d.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   sync(h);
-  memcpy(x_inout, h->h_x, (size_t)d.n * sizeof(double));
+  to_caller(h, x_inout, h->h_x);
   if (result) {
     result->cost = cost;
     result->initial_cost = initial_cost;
@@ -1834,9 +2013,12 @@ int32_t mcba_time_linearize(mcba_handle h, const double* x, const mcba_options* 
   HIP_OK(hipEventRecord(h->ev0, h->stream));
   for (int i = 0; i < repeats; ++i) {   // the dominant kernel alone, as rocprofv3 reports it (table form: k_tmat ran above)
     const Dims& d = h->d;
-    static const bool fused_on = getenv("MCBA_FUSED") != nullptr && getenv("MCBA_FUSED")[0] == '1';
-    if (h->use_mfma && d.ND != 14 && d.off_boards < 0 && fused_on)
+    const int fused_mode = linearize_fused_mode();
+    if (h->use_mfma && d.ND != 14 && d.off_boards < 0 && fused_mode == 1)
       h->ops->linearize(d, h->t, h->stream, h->rec.p, h->tri.p, true, h->lin_grid, h->x.p, h->gbuf.p, 2 * d.n + 2, h->Hss.p,
+                        d.ns * d.ns);
+    else if (h->use_mfma && d.off_boards < 0 && (fused_mode == 2 || (getenv("MCBA_FUSED") == nullptr && d.C * d.B >= 32)))
+      h->ops->linearize(d, h->t, h->stream, h->rec.p, h->tri.p, true, h->lin_grid, nullptr, h->gbuf.p, 2 * d.n + 2, h->Hss.p,
                         d.ns * d.ns);
     else
       h->ops->linearize(d, h->t, h->stream, h->rec.p, h->tri.p, h->use_mfma, h->lin_grid, nullptr, nullptr, 0, nullptr, 0);

@@ -50,7 +50,10 @@ void jacobian(const Dims& d, const Tables& t, hipStream_t s, int row_nnz, double
 template <int MOTION, bool OPTK>
 void lin2(const Dims& d, const Tables& t, hipStream_t s, double* rec, const uint16_t* tri, bool mfma, int epoch,
           const double* x, double* za, int na, double* zb, int nb) {
-  if (d.views() == 0 && x == nullptr) return;   // empty frame shard (the fused form still zeroes the assembly targets)
+  // fused forms: za != nullptr.  x != nullptr: pose entries / intrinsics straight from x; x == nullptr: from the pose and
+  // camera tables (table-fed fused form).  Both zero the assembly targets za[na], zb[nb].
+  const bool fused = za != nullptr;
+  if (d.views() == 0 && !fused) return;   // empty frame shard (the fused form still zeroes the assembly targets)
   // persistent wavefronts: 8 single-wave workgroups per CU (2 per SIMD: 256-VGPR budget, 20 KB LDS each) x 256 CUs
   const int want = epoch > 0 ? epoch : LIN_GRID_MAX;   // the last argument carries the debug grid override
   const dim3 grid(std::max(1, d.views() < want ? d.views() : want)), block(64);
@@ -60,9 +63,9 @@ void lin2(const Dims& d, const Tables& t, hipStream_t s, double* rec, const uint
     hipLaunchKernelGGL((k_linearize<ND_, FISH_, MOTION, OPTK, true, true, false, true>), grid, block, 0, s, d, t, rec, tri, epoch, x, za, na, zb, nb);
     return;
   }
-  if (x != nullptr && mfma && d.loss == 0)
+  if (fused && mfma && d.loss == 0)
     hipLaunchKernelGGL((k_linearize<ND_, FISH_, MOTION, OPTK, true, false, true>), grid, block, 0, s, d, t, rec, tri, epoch, x, za, na, zb, nb);
-  else if (x != nullptr && mfma)
+  else if (fused && mfma)
     hipLaunchKernelGGL((k_linearize<ND_, FISH_, MOTION, OPTK, true, true, true>), grid, block, 0, s, d, t, rec, tri, epoch, x, za, na, zb, nb);
   else if (mfma && d.loss == 0)
     hipLaunchKernelGGL((k_linearize<ND_, FISH_, MOTION, OPTK, true, false, false>), grid, block, 0, s, d, t, rec, tri, epoch, x, za, na, zb, nb);

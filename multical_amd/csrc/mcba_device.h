@@ -45,6 +45,12 @@ struct Dims {
   double f_scale;
   // pose table layout
   int pose_cam, pose_board, pose_motion, n_pose;
+  // Rigs whose cameras carry DIFFERENT numbers of distortion coefficients (mcba_problem.camera_n_dist): internally every
+  // camera has ND = the largest size, a camera with fewer keeps the rest at zero.  Bit q of cam_kmask[c] marks intrinsic
+  // column q (0..3 = fx fy cx cy, 4 + k = distortion coefficient k) of camera c as FROZEN: local_to_x reports it as "not
+  // a parameter", so the assembly never writes its rows / columns of H and g (zero column: unit scale, zero step).
+  // nullptr for uniform rigs.  A device pointer inside the kernels; host code substitutes a host copy.
+  const uint32_t* cam_kmask;
 
   // global x index of a shared-parameter index (x order with the eliminated motion block removed)
   MCBA_HD int shared_to_x(int s) const {
@@ -88,6 +94,7 @@ struct Tables {
   int32_t* work_counter;       // [2] dynamic view hand-out of k_linearize (alternating between launches)
   double* tmat;                // [Fl][C][B][DE*NPC] That columns per view (k_tmat), consumed by k_linearize
   long long* dbg;              // optional [views][8] cycle stamps of k_linearize phases (profiling aid), else null
+  const int32_t* int2ext;      // [n] index in the CALLER's (ragged) parameter vector, -1 = padded coefficient; null = identity
 };
 
 }  // namespace mcba

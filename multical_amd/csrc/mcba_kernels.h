@@ -120,7 +120,11 @@ __device__ __forceinline__ double block_reduce(double v, double* scratch /*[16]*
 //  same-address atomic serialises 500-1000 tickets into 40-90 us.  Single-GPU solves copy the partials to the host with
 //  the scalars they already fetch instead; sharded solves keep the small final-sum kernels.)
 
-constexpr int LIN_MAX_POINTS = 512;    // points per board supported by the compaction lists (mcba_create checks it)
+// Points of a view that the compaction lists hold at a time.  Boards with more points (the reference has no cap:
+// tables.stack_boards, tables.py:385-394 -- a 25 x 35 charuco has 816 corners) are walked in SEGMENTS of this many table
+// slots: masks of a segment are compacted, its dense chunks are processed, and the accumulators / the residual run of the
+// view carry on into the next segment.  Point indices are kept as uint16 (mcba_create checks n_points <= 65535).
+constexpr int LIN_MAX_POINTS = 512;
 
 // ---------------------------------------------------------------------------------------------------------------
 // k_residual: evaluate() of optimization/calibration.py:204-206 (+ projections and per-slot errors of
@@ -151,16 +155,17 @@ __global__ __launch_bounds__(256) void k_residual(Dims d, Tables t, const int32_
     for (int vi = blockIdx.x * 4 + (threadIdx.x >> 6); vi < n_active; vi += gridDim.x * 4) {
       const int v = __builtin_amdgcn_readfirstlane(t.active_views[1 + vi]);
       const int b = v % d.B, c = (v / d.B) % d.C;
-      const size_t out0 = (size_t)first[v];
+      size_t out0 = (size_t)first[v];
+      for (int seg0 = 0; seg0 < d.P; seg0 += LIN_MAX_POINTS) {   // (one segment unless a board has > LIN_MAX_POINTS points)
       uint8_t inb[NPB64];
 #pragma unroll
-      for (int k = 0; k < NPB64; ++k) inb[k] = masked_load_row(t.inlier + (size_t)v * d.P, k * 64 + lane, d.P);
+      for (int k = 0; k < NPB64; ++k) inb[k] = masked_load_row(t.inlier + (size_t)v * d.P, seg0 + k * 64 + lane, d.P);
       int count = 0;
 #pragma unroll
       for (int k = 0; k < NPB64; ++k) {
         const bool in = inb[k] != 0;
         const unsigned long long m = __ballot(in);
-        if (in) pidx[count + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(k * 64 + lane);
+        if (in) pidx[count + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(seg0 + k * 64 + lane);
         count += __popcll(m);
       }
       lds_fence();
@@ -185,7 +190,9 @@ __global__ __launch_bounds__(256) void k_residual(Dims d, Tables t, const int32_
         ob_cur = ob_nxt;
         for (int k = 0; k < 3; ++k) X_cur[k] = X_nxt[k];
       }
-      lds_fence();   // the next view rewrites the list
+      out0 += (size_t)count;
+      lds_fence();   // the next segment / view rewrites the list
+      }
     }
     return;
   }
@@ -324,10 +331,11 @@ __global__ __launch_bounds__(64) void k_cost(Dims d, Tables t, double* __restric
     // then needs k_prep only, not the per-view table pass k_views
     view_chain_wave<ROLL>(d, t, f, c, b, lane, Vtmp, Vc);
     constexpr int NPB64 = LIN_MAX_POINTS / 64;
+    for (int seg0 = 0; seg0 < d.P; seg0 += LIN_MAX_POINTS) {   // (one segment unless a board has > LIN_MAX_POINTS points)
     uint8_t inb[NPB64];
 #pragma unroll
     for (int k = 0; k < NPB64; ++k) {
-      const int p = k * 64 + lane;
+      const int p = seg0 + k * 64 + lane;
       inb[k] = masked_load_row(t.inlier + (size_t)v * d.P, p, d.P);
     }
     int count = 0;
@@ -335,7 +343,7 @@ __global__ __launch_bounds__(64) void k_cost(Dims d, Tables t, double* __restric
     for (int k = 0; k < NPB64; ++k) {
       const bool in = inb[k] != 0;
       const unsigned long long m = __ballot(in);
-      if (in) pidx[count + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(k * 64 + lane);
+      if (in) pidx[count + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(seg0 + k * 64 + lane);
       count += __popcll(m);
     }
     lds_fence();
@@ -361,7 +369,8 @@ __global__ __launch_bounds__(64) void k_cost(Dims d, Tables t, double* __restric
       ob_cur = ob_nxt;
       for (int k = 0; k < 3; ++k) X_cur[k] = X_nxt[k];
     }
-    lds_fence();   // the next view rewrites the list
+    lds_fence();   // the next segment / view rewrites the list
+    }
   }
   const double tot = wave_sum(acc);
   if (lane == 0) partial[blockIdx.x] = 0.5 * tot;
@@ -384,6 +393,7 @@ __global__ void k_jacobian(Dims d, Tables t, int row_nnz, double* __restrict__ v
     dl.loss = 0;   // the Jacobian of evaluate() itself: no robust scaling
     double vr[2 * NV], jp[6];
     point_rows<ND, FISH, ROLL, true>(dl, t, v, c, b, p, t.obs[s], vr, jp);
+    auto xcol = [&](int col) { return t.int2ext != nullptr ? t.int2ext[col] : col; };   // caller's (ragged) column index
     double* o0 = vals + (size_t)(2 * idx) * row_nnz;
     double* o1 = o0 + row_nnz;
     int32_t* oc = cols + (size_t)idx * row_nnz;
@@ -403,7 +413,7 @@ __global__ void k_jacobian(Dims d, Tables t, int row_nnz, double* __restrict__ v
         }
         o0[pos] = a0;
         o1[pos] = a1;
-        oc[pos] = local_to_x(d, f, c, b, 6 * k + jj);
+        oc[pos] = xcol(local_to_x(d, f, c, b, 6 * k + jj));
         ++pos;
       }
     }
@@ -411,10 +421,13 @@ __global__ void k_jacobian(Dims d, Tables t, int row_nnz, double* __restrict__ v
       const int base = d.off_cameras + c * (5 + ND);
       for (int q = 0; q < 5 + ND; ++q) {
         const int lq = q < 4 ? q : q - 1;
+        // the skew slot is structurally present with a zero derivative; a coefficient this camera's model does not have
+        // (ragged rigs) is no column at all: value 0, column -1
         const bool skew = q == 4;
-        o0[pos] = skew ? 0.0 : vr[DE + lq];
-        o1[pos] = skew ? 0.0 : vr[NV + DE + lq];
-        oc[pos] = base + q;
+        const bool absent = !skew && d.cam_kmask != nullptr && ((d.cam_kmask[c] >> lq) & 1u);
+        o0[pos] = (skew || absent) ? 0.0 : vr[DE + lq];
+        o1[pos] = (skew || absent) ? 0.0 : vr[NV + DE + lq];
+        oc[pos] = absent ? -1 : xcol(base + q);
         ++pos;
       }
     }
@@ -423,7 +436,7 @@ __global__ void k_jacobian(Dims d, Tables t, int row_nnz, double* __restrict__ v
       for (int k = 0; k < 3; ++k) {
         o0[pos] = jp[k];
         o1[pos] = jp[3 + k];
-        oc[pos] = base + k;
+        oc[pos] = xcol(base + k);
         ++pos;
       }
     }
@@ -746,11 +759,25 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
   if (!front_ready) front_issue(v, pl);
   const double* camp = nullptr;   // FUSED: the camera's parameter block [fx fy cx cy skew k...] inside x (or the constants)
   if constexpr (FUSED) {
-    camp = d.off_cameras >= 0 ? x + d.off_cameras + c * (5 + ND) : t.xfull + d.foff_cameras + c * (5 + ND);
+    // x == nullptr: the TABLE-FED fused form -- the pose / camera tables already hold the point (k_prep, or the tail of the
+    // k_vec_step that produced it): the view's pose entries are copied from the pose table (no trigonometry here) and the
+    // intrinsics come from the camera table; the chain products and the That columns are formed below all the same.
+    const bool from_x = x != nullptr;
+    camp = !from_x ? t.cam + (size_t)c * CAM_STRIDE
+                   : (d.off_cameras >= 0 ? x + d.off_cameras + c * (5 + ND) : t.xfull + d.foff_cameras + c * (5 + ND));
     // pose entries of the view from x: lane 0 camera, lane NPB - 1 board, the lanes between the motion poses
     static_assert(NPB * POSE_STRIDE <= BUF, "pose entries do not fit the staging buffer");
     double* Pl = Buf;                      // (the staging buffer is free until the first chunk)
-    if (pl < NPB) {
+    if (!from_x) {
+#pragma unroll
+      for (int u = 0; u < (NPB * POSE_STRIDE + 63) / 64; ++u) {
+        const int e = min(pl + 64 * u, NPB * POSE_STRIDE - 1), k = e / POSE_STRIDE, q = e - k * POSE_STRIDE;
+        const int gi = k == 0 ? d.pose_cam + c
+                     : (k == NPB - 1 ? d.pose_board + b
+                                     : d.pose_motion + (MOTION == MOTION_STATIC ? f : (MOTION == MOTION_ROLLING ? (k - 1) * d.F + f : k - 1)));
+        Pl[e] = t.pose[(size_t)gi * POSE_STRIDE + q];
+      }
+    } else if (pl < NPB) {
       int oa, of, r;
       if (pl == 0) { oa = d.off_campose; of = d.foff_campose; r = 6 * c; }
       else if (pl == NPB - 1) { oa = d.off_boardpose; of = d.foff_boardpose; r = 6 * b; }
@@ -839,6 +866,8 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
     for (int k = 0; k < 3; ++k) X_cur[k] = t.board_points[3 * (size_t)(b * d.P + p_cur) + k];
   }
   int count_n = 0;             // (PIPE) inliers of the next view, known once its front is finished
+  int count_total = count;     // inliers of the whole view (a board with > LIN_MAX_POINTS points is walked in segments)
+  for (int seg0 = 0;;) {
   for (int base = 0; base < count; base += 64) {
     const int i = base + lane;
     const bool in = i < count;
@@ -925,6 +954,28 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
       }
       lds_fence();
     }
+  }
+  seg0 += LIN_MAX_POINTS;
+  if (seg0 >= d.P) break;
+  {   // next segment of a large board: its mask bytes are compacted into the (now free) list, the accumulators carry on
+    const uint8_t* mrow = t.inlier + (size_t)v * d.P;
+#pragma unroll
+    for (int k = 0; k < NPB64; ++k) inb[k] = masked_load_row(mrow, seg0 + k * 64 + pl, d.P);
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < NPB64; ++k) {
+      const bool in = inb[k] != 0;
+      const unsigned long long m = __ballot(in);
+      if (in) pidx[cnt + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(seg0 + k * 64 + lane);
+      cnt += __popcll(m);
+    }
+    lds_fence();
+    count = cnt;
+    count_total += cnt;
+    p_cur = lane < count ? pidx[lane] : 0;
+    ob_cur = t.obs[(size_t)v * d.P + p_cur];
+    for (int k = 0; k < 3; ++k) X_cur[k] = t.board_points[3 * (size_t)(b * d.P + p_cur) + k];
+  }
   }
 
   if (prof) stamp[3] = clock64();
@@ -1123,7 +1174,7 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
         c3 += Cb[4 * q + 3];
       }
       Mp[REC] = 0.5 * ((c0 + c1) + (c2 + c3));
-      Mp[REC + 1] = (double)count;
+      Mp[REC + 1] = (double)count_total;
       if (RECP > REC + 2) Mp[REC + 2] = 0.0;
     }
     lds_fence();
@@ -1169,7 +1220,7 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
     cost = wave_sum(cost);
     if (lane == 0) {
       out[REC] = 0.5 * cost;
-      out[REC + 1] = (double)count;
+      out[REC + 1] = (double)count_total;
     }
   }
   if (lane == 0) {
@@ -1179,7 +1230,7 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
       o[1] = stamp[2];                            // forward model + Jacobian rows (all chunks)
       o[2] = stamp[3] - stamp[1] - stamp[2];      // LDS staging + MFMA
       o[3] = clock64() - stamp[3];                // epilogue
-      o[4] = count;
+      o[4] = count_total;
       o[5] = ep0 - stamp[3];                      // epilogue part 1: corner reduction + S -> LDS
       o[6] = ep1 - ep0;                           // epilogue part 2: Y = S_EE That
       o[7] = clock64() - stamp[0];                // lifetime

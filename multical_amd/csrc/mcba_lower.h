@@ -73,6 +73,12 @@ struct HostProblem {
   std::vector<double> xfull, bwg, img_h;
   std::vector<uint16_t> tri;
   int64_t n_inliers = 0;
+  // ragged camera blocks (mcba_problem.camera_n_dist): the caller's vectors use the reference's layout, camera c carries
+  // 5 + cam_nd[c] entries; the library pads every camera to 5 + ND.  ext2int[i] = internal index of entry i of the caller's
+  // active vector; int2ext = the inverse (-1 for the padded coefficients).  Empty for uniform rigs (identity).
+  std::vector<int32_t> cam_nd, ext2int, int2ext;
+  std::vector<uint32_t> cam_kmask;
+  int n_ext = 0;                     // length of the caller's active vector (== d.n for uniform rigs)
 };
 
 inline int64_t full_size_of(const mcba_problem* p) {
@@ -80,7 +86,12 @@ inline int64_t full_size_of(const mcba_problem* p) {
   for (int b = 0; b < p->n_boards; ++b) nb += p->board_sizes[b];
   const int64_t nm = p->motion == MCBA_MOTION_STATIC ? 6LL * p->n_frames
                      : p->motion == MCBA_MOTION_ROLLING ? 12LL * p->n_frames : 12LL;
-  return 6LL * p->n_cameras + 6LL * p->n_boards + nm + (int64_t)p->n_cameras * (5 + p->n_dist) + 3 * nb;
+  int64_t ncam = (int64_t)p->n_cameras * (5 + p->n_dist);
+  if (p->camera_n_dist != nullptr) {   // ragged camera blocks (the reference's own layout)
+    ncam = 0;
+    for (int c = 0; c < p->n_cameras; ++c) ncam += 5 + p->camera_n_dist[c];
+  }
+  return 6LL * p->n_cameras + 6LL * p->n_boards + nm + ncam + 3 * nb;
 }
 
 // (re)build inlier table, residual ordering and per-view counts of the shard; mask in reference order or null
@@ -136,9 +147,8 @@ inline void lower_dims(const mcba_problem* p, HostProblem& hp) {
   MCBA_REQUIRE(p->motion >= 0 && p->motion <= 2, "unknown motion model");
   MCBA_REQUIRE(p->motion != MCBA_MOTION_HAND_EYE || p->base_wrt_gripper, "hand-eye motion needs base_wrt_gripper");
   MCBA_REQUIRE(p->optimize != 0, "no parameter block enabled");
-  MCBA_REQUIRE(p->n_points <= 512, "boards with more than 512 points are not supported (k_linearize compaction list)");
-  MCBA_REQUIRE((int64_t)p->n_cameras * p->n_boards <= 128,
-               "more than 128 (camera, board) pairs are not supported (pair sums of the shared assembly live in LDS)");
+  MCBA_REQUIRE(p->n_points <= 65535, "boards with more than 65535 points are not supported (16-bit point lists)");
+  MCBA_REQUIRE((int64_t)p->n_cameras * p->n_boards < (1 << 24), "too many (camera, board) pairs");
   if (p->camera_model == MCBA_CAMERA_FISHEYE)
     MCBA_REQUIRE(p->n_dist == 4, "fisheye cameras carry 4 distortion coefficients (camera_fisheye.py:113-117)");
   else
@@ -146,6 +156,24 @@ inline void lower_dims(const mcba_problem* p, HostProblem& hp) {
                  "pinhole cameras carry 4, 5, 8, 12 or 14 distortion coefficients (cv2.projectPoints)");
 
   Dims& d = hp.d;
+  d.cam_kmask = nullptr;
+  // per-camera distortion sizes: a ParamList of independent Camera objects (optimization/parameters.py:54-85)
+  bool ragged = false;
+  hp.cam_nd.assign((size_t)p->n_cameras, p->n_dist);
+  if (p->camera_n_dist != nullptr) {
+    int mx = 0;
+    for (int c = 0; c < p->n_cameras; ++c) {
+      const int nd = p->camera_n_dist[c];
+      MCBA_REQUIRE(nd == 4 || nd == 5 || nd == 8 || nd == 12 || nd == 14,
+                   "pinhole cameras carry 4, 5, 8, 12 or 14 distortion coefficients (cv2.projectPoints)");
+      hp.cam_nd[c] = nd;
+      mx = std::max(mx, nd);
+      ragged = ragged || nd != p->n_dist;
+    }
+    MCBA_REQUIRE(mx == p->n_dist, "n_dist must be the largest entry of camera_n_dist");
+    MCBA_REQUIRE(!ragged || p->camera_model == MCBA_CAMERA_PINHOLE,
+                 "cameras of different distortion sizes must all be pinhole cameras (fisheye cameras carry exactly 4)");
+  }
   d.C = p->n_cameras; d.F = p->n_frames; d.B = p->n_boards; d.P = p->n_points;
   d.f0 = 0; d.Fl = d.F;
   if (p->frame_begin >= 0) {
@@ -198,7 +226,32 @@ inline void lower_dims(const mcba_problem* p, HostProblem& hp) {
       if (aoff[k] >= 0)
         for (int i = 0; i < sizes[k]; ++i) f2a[foff[k] + i] = aoff[k] + i;
     hp.full2act = f2a;
-    hp.xfull.assign(p->x_full, p->x_full + d.nfull);
+    hp.n_ext = d.n;
+    if (!ragged) {
+      hp.xfull.assign(p->x_full, p->x_full + d.nfull);
+    } else {
+      // the caller's vectors are ragged in the cameras block: scatter x_full into the padded layout (absent coefficients
+      // are zero), and build the maps of the ACTIVE vector
+      hp.xfull.assign((size_t)d.nfull, 0.0);
+      hp.cam_kmask.assign((size_t)d.C, 0u);
+      std::vector<int32_t> fe2i;   // caller's full index -> internal full index
+      for (int j = 0; j < d.foff_cameras; ++j) fe2i.push_back(j);
+      for (int c = 0; c < d.C; ++c) {
+        for (int q = 0; q < 5 + hp.cam_nd[c]; ++q) fe2i.push_back(d.foff_cameras + c * (5 + d.ND) + q);
+        for (int k = hp.cam_nd[c]; k < d.ND; ++k) hp.cam_kmask[c] |= 1u << (4 + k);
+      }
+      for (int j = d.foff_boards; j < d.nfull; ++j) fe2i.push_back(j);
+      for (size_t j = 0; j < fe2i.size(); ++j) hp.xfull[fe2i[j]] = p->x_full[j];
+      hp.int2ext.assign((size_t)d.n, -1);
+      for (size_t j = 0; j < fe2i.size(); ++j) {
+        const int a = f2a[fe2i[j]];
+        if (a >= 0) {
+          hp.int2ext[a] = (int32_t)hp.ext2int.size();
+          hp.ext2int.push_back(a);
+        }
+      }
+      hp.n_ext = (int)hp.ext2int.size();
+    }
     hp.board_off = board_off;
     hp.img_h.assign(p->image_heights, p->image_heights + d.C);
     hp.fix_aspect.assign(p->fix_aspect, p->fix_aspect + d.C);

@@ -195,8 +195,11 @@ MCBA_HD int frame_entries(const Dims& d) {   // NE: entries of one record a fram
   return 6 * d.DF + (tri_index(6 + d.DF, 6 + d.DF, d.N1) - tri_index(6, 6, d.N1));
 }
 enum { FT_HFS = 0, FT_HFF = 1, FT_GRAD = 2 };
-// element: x = staged entry k, y = first view | stride << 8 | count << 16, z = destination, w = kind | (dd + 1) << 8 for a
-// diagonal element of H_ff (whose value is also diag[x index of the frame parameter dd])
+// element: x = staged entry k, y = view sequence (ft_seq: first view, stride 1 or B, count B, C or C B -- no limit on the
+// number of (camera, board) pairs), z = destination, w = kind | (dd + 1) << 8 for a diagonal element of H_ff (whose value
+// is also diag[x index of the frame parameter dd])
+enum { FT_CNT_B = 0, FT_CNT_C = 1, FT_CNT_CB = 2 };
+MCBA_HD int ft_seq(int first, bool stride_b, int count_sel) { return first | ((stride_b ? 1 : 0) << 24) | (count_sel << 25); }
 inline std::vector<int4> frame_table(const Dims& d) {
   std::vector<int4> tab;
   if (d.DF == 0) return tab;
@@ -212,7 +215,7 @@ inline std::vector<int4> frame_table(const Dims& d) {
         const int li = q < 6 ? q : 6 * d.NPB + (q - 6);
         const int gi = local_to_x(d, 0, c, 0, li);
         if (gi < 0) continue;
-        tab.push_back(make_int4(kidx(li, 6 + dd), (c * d.B) | (1 << 8) | (d.B << 16), dd * ns + d.x_to_shared(gi), FT_HFS));
+        tab.push_back(make_int4(kidx(li, 6 + dd), ft_seq(c * d.B, false, FT_CNT_B), dd * ns + d.x_to_shared(gi), FT_HFS));
       }
   for (int b = 0; b < d.B; ++b)            // frame x board(b): sum over cameras
     for (int dd = 0; dd < DF; ++dd)
@@ -220,11 +223,11 @@ inline std::vector<int4> frame_table(const Dims& d) {
         const int li = 6 * (d.NPB - 1) + q;
         const int gi = local_to_x(d, 0, 0, b, li);
         if (gi < 0) continue;
-        tab.push_back(make_int4(kidx(6 + dd, li), b | (d.B << 8) | (d.C << 16), dd * ns + d.x_to_shared(gi), FT_HFS));
+        tab.push_back(make_int4(kidx(6 + dd, li), ft_seq(b, true, FT_CNT_C), dd * ns + d.x_to_shared(gi), FT_HFS));
       }
   for (int dd = 0; dd < DF; ++dd)          // frame x frame and the gradient: sum over all views
     for (int d2 = 0; d2 <= DF; ++d2) {
-      const int y = 0 | (1 << 8) | ((d.C * d.B) << 16);
+      const int y = ft_seq(0, false, FT_CNT_CB);
       if (d2 < DF) tab.push_back(make_int4(kidx(6 + dd, 6 + d2), y, dd * DF + d2, FT_HFF | (d2 == dd ? (dd + 1) << 8 : 0)));
       else tab.push_back(make_int4(kidx(6 + dd, NL), y, dd, FT_GRAD));
     }
@@ -236,11 +239,11 @@ __device__ __forceinline__ void assemble_frame_block(const Dims& d, const Tables
                                                      const double* __restrict__ rec, double* __restrict__ Hff,
                                                      double* __restrict__ Hfs, double* __restrict__ g,
                                                      double* __restrict__ diag, double* __restrict__ stage) {
-  __shared__ uint8_t act[128];   // C B <= 128 (checked by mcba_create)
   const int f = d.f0 + fl;
   const int DF = d.DF, ns = d.ns, N1 = d.N1, CB = d.C * d.B;
   const int base2 = tri_index(6, 6, N1), NE = frame_entries(d), P1 = 6 * DF;
   int* soff = reinterpret_cast<int*>(stage + (size_t)gviews * NE);   // record offset of staged entry k
+  uint8_t* act = reinterpret_cast<uint8_t*>(soff + NE);              // [C B] view has inliers
   double* hfs = Hfs + (size_t)fl * DF * ns;
   double* hff = Hff + (size_t)fl * DF * DF;
   for (int e = threadIdx.x; e < CB; e += blockDim.x) act[e] = t.view_count[fl * CB + e] != 0;
@@ -288,7 +291,8 @@ __device__ __forceinline__ void assemble_frame_block(const Dims& d, const Tables
 #pragma unroll
       for (int u = 0; u < TB; ++u) {
         if (q[u].w < 0) continue;
-        const int k = q[u].x, gv0 = (q[u].y & 255) - g0, gst = (q[u].y >> 8) & 255, cnt = q[u].y >> 16;
+        const int k = q[u].x, gv0 = (q[u].y & 0xFFFFFF) - g0, gst = ((q[u].y >> 24) & 1) ? d.B : 1;
+        const int csel = q[u].y >> 25, cnt = csel == FT_CNT_B ? d.B : (csel == FT_CNT_C ? d.C : CB);
         double s0 = 0.0, s1 = 0.0;
         int i = 0;
         for (; i + 2 <= cnt; i += 2) {
@@ -408,6 +412,7 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(Dims d, Tables t, cons
 // only (camera pose / intrinsics columns), on the board only (board pose), on both, or on neither (hand-eye blocks):
 // the thread of the FIRST pair of each equivalence class owns the element, adds the pair sums of its class from LDS in
 // a fixed order and stores -- no atomics, no read-modify-write chains, every element written once.
+constexpr int SHARED_FINAL_MAX_PAIRS = 128;   // pair sums of k_shared_final: [pairs][64] doubles of LDS
 __global__ __launch_bounds__(1024) void k_shared_final(Dims d, const double* __restrict__ partial, int nchunk,
                                                        const uint16_t* __restrict__ tri, double* __restrict__ Hss,
                                                        double* __restrict__ g, double* __restrict__ diag,
@@ -476,6 +481,68 @@ __global__ __launch_bounds__(1024) void k_shared_final(Dims d, const double* __r
       if (si != sj) Hss[(size_t)sj * ns + si] = val;
       else diag[gi] = val;
     }
+  }
+}
+
+// The same reduction for rigs with MORE (camera, board) pairs than the LDS pair sums of k_shared_final hold (C B > 128,
+// e.g. 16 cameras x 10 boards): the owner thread of an element adds the chunk sums of all pairs of its class straight from
+// memory, class by class in the same fixed order.  grid = (entry blocks, pair groups of 16), block = 64 x 16.
+__global__ __launch_bounds__(1024) void k_shared_final_big(Dims d, const double* __restrict__ partial, int nchunk,
+                                                           const uint16_t* __restrict__ tri, double* __restrict__ Hss,
+                                                           double* __restrict__ g, double* __restrict__ diag,
+                                                           double* __restrict__ cost_count) {
+  const int ns = d.ns, NL = d.NL, npose = 6 * d.NPB, npair = d.C * d.B;
+  const int el = threadIdx.x & 63, pair = blockIdx.y * 16 + (threadIdx.x >> 6);
+  const int e = blockIdx.x * 64 + el;
+  if (e >= d.rec_size + 2 || pair >= npair) return;
+  const size_t rs = d.rec_stride;
+  bool depc = false, depb = false;
+  int i = 0, j = 0;
+  if (e < d.rec_size) {
+    const int ij = tri[e];
+    i = ij >> 8;
+    j = ij & 255;
+    if (i == NL) return;
+    if (local_is_frame(d, i) || local_is_frame(d, j)) return;
+    auto dep_c = [&](int l) { return l < 6 || l >= npose; };
+    auto dep_b = [&](int l) { return l >= npose - 6 && l < npose; };
+    depc = dep_c(i) || (j < NL && dep_c(j));
+    depb = dep_b(i) || (j < NL && dep_b(j));
+  }
+  const int c = pair / d.B, b = pair % d.B;
+  if ((!depc && c != 0) || (!depb && b != 0)) return;        // not the first pair of its class
+  int gi = -1, gj = -1;
+  if (e < d.rec_size) {
+    gi = local_to_x(d, 0, c, b, i);
+    if (gi < 0) return;
+    if (j < NL) {
+      gj = local_to_x(d, 0, c, b, j);
+      if (gj < 0) return;
+    }
+  }
+  const int c0 = depc ? c : 0, c1 = depc ? c + 1 : d.C, b0 = depb ? b : 0, b1 = depb ? b + 1 : d.B;
+  double val = 0.0;
+  for (int cc = c0; cc < c1; ++cc)
+    for (int bb = b0; bb < b1; ++bb) {
+      const double* base = partial + (size_t)(cc * d.B + bb) * nchunk * rs + e;
+      double s0 = 0.0, s1 = 0.0;
+      int ch = 0;
+      for (; ch + 2 <= nchunk; ch += 2) {
+        s0 += base[(size_t)ch * rs];
+        s1 += base[(size_t)(ch + 1) * rs];
+      }
+      if (ch < nchunk) s0 += base[(size_t)ch * rs];
+      val += s0 + s1;
+    }
+  if (e >= d.rec_size) {
+    cost_count[e - d.rec_size] = val;
+  } else if (j == NL) {
+    g[gi] = val;
+  } else {
+    const int si = d.x_to_shared(gi), sj = d.x_to_shared(gj);
+    Hss[(size_t)si * ns + sj] = val;
+    if (si != sj) Hss[(size_t)sj * ns + si] = val;
+    else diag[gi] = val;
   }
 }
 
@@ -1409,6 +1476,207 @@ __global__ __launch_bounds__(CHOL_BLK_THREADS) void k_chol_glb(int ns, double re
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// k_cholp_*: PANEL Cholesky for reduced systems that do not fit one workgroup's LDS (ns + 1 > 160: many cameras --
+// 16 cameras x 5 boards give ns = 286 -- or adjust_board).  k_chol_glb keeps the matrix in L2 and pays a global round trip
+// for every 16-column step on ONE compute unit (265 us at ns = 286: the trailing update of up to 153 tiles per step is the
+// critical path).  Here a block column of up to 96 columns (as many 16-column tiles as fit 150 KB of LDS, at most six: the
+// panels get wider as the remaining matrix gets shorter -- 286: 3 + 4 + 6 + 5 tile columns, eight launches) lives in LDS while it is factored with the
+// register / LDS tile kernels of k_chol_blk, and the trailing update of the rest of the matrix runs on the WHOLE chip:
+//   k_cholp_panel   ONE workgroup: block column [c0, c0 + 16 wt) x rows [c0, ns] from L2 into LDS; per tile column the
+//                   diagonal tile is factored in registers (wave 0), the tiles below are solved by forward substitution
+//                   (four per wavefront) while the last wave inverts the diagonal tile for the back substitution, and the
+//                   remaining tile columns of the panel are updated on the matrix pipe; L goes back to memory
+//   k_cholp_trail   one wavefront per 16 x 16 tile of the trailing lower triangle:  C -= X_i X_j^T  with K = 16 wt, X from
+//                   L2, twelve MFMAs, every load issued before the first one
+//   k_cholp_back    one workgroup: p = L^-T y with the stored inverses of the diagonal tiles (a mat-vec per tile, no serial
+//                   pivot chain) and the row block of L of the next step requested before the current tile is solved
+// Same in-place layout as the other kernels: buf = [S (ns x ns, lower triangle used) | rhs (ns)] = an (ns + 1) x ns matrix
+// whose last row becomes the forward-substituted right-hand side.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int CHOLP_THREADS = 512, CHOLP_WT = 6, CHOLP_LDS_MAX = 150 * 1024;
+__host__ __device__ inline int cholp_panel_tiles(int ns, int kt0) {      // tile columns of the panel that starts at kt0
+  const int nb = (ns + 1 + CT - 1) / CT, nbc = (ns + CT - 1) / CT, nbr = nb - kt0;
+  int wt = CHOLP_LDS_MAX / (int)(nbr * CTS * sizeof(double));
+  wt = wt < 1 ? 1 : (wt > CHOLP_WT ? CHOLP_WT : wt);
+  return wt < nbc - kt0 ? wt : nbc - kt0;
+}
+__host__ __device__ inline size_t cholp_lds_bytes(int ns, int kt0, int wt) {
+  const int nb = (ns + 1 + CT - 1) / CT;
+  return ((size_t)(nb - kt0) * wt * CTS + (size_t)wt * CTS + wt * CT) * sizeof(double);
+}
+
+// inverse of a factored 16 x 16 tile (L in LDS, dinv = 1 / L_jj): lane c < 16 solves L x = e_c; Xi[i][c] = x_i.  Runs on a
+// wavefront that is off the critical path; every L entry is a broadcast read.
+__device__ __forceinline__ void chol_tile_invert(const double* __restrict__ L, const double* __restrict__ dinv,
+                                                 double* __restrict__ Xi, int lane) {
+  const int c = lane & 15;
+  double x[CT];
+#pragma unroll
+  for (int i = 0; i < CT; ++i) {
+    double s0 = (i == c) ? 1.0 : 0.0, s1 = 0.0;
+#pragma unroll
+    for (int m = 0; m < i; ++m) {
+      const double l = L[i * CTL + m];
+      if (m & 1) s1 -= l * x[m]; else s0 -= l * x[m];
+    }
+    x[i] = (i >= c) ? (s0 + s1) * dinv[i] : 0.0;
+  }
+  if (lane < CT) {
+#pragma unroll
+    for (int i = 0; i < CT; ++i) Xi[i * CTL + c] = x[i];
+  }
+}
+
+__global__ __launch_bounds__(CHOLP_THREADS) void k_cholp_panel(int ns, int kt0, int wt, double reg, double* __restrict__ buf,
+                                                               double* __restrict__ Linv, int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) double cholp[];
+  constexpr int NW = CHOLP_THREADS / 64;
+  const int n1 = ns + 1, nb = (n1 + CT - 1) / CT, nbr = nb - kt0, c0 = CT * kt0;
+  double* P = cholp;                              // tile (bl, kk) of the panel at (bl * wt + kk) * CTS, bl = block row - kt0
+  double* Xi = P + (size_t)nbr * wt * CTS;        // inverted diagonal tiles [wt]
+  double* dinv = Xi + (size_t)wt * CTS;           // 1 / L_jj [wt][16]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+  int badcol = 0;
+  // ---- load: rows of 16 doubles (128 B) per 16 threads; outside the matrix the identity continues it -----------------
+  {
+    const int total = nbr * wt * CT * CT;
+    constexpr int UN = 8;
+    for (int e0 = tid; e0 < total; e0 += UN * CHOLP_THREADS) {
+      double v[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int e = e0 + u * CHOLP_THREADS;
+        const int tile = e >> 8, r = (e >> 4) & 15, c = e & 15, bl = tile / wt, kk = tile - bl * wt;
+        const int gi = c0 + CT * bl + r, gj = c0 + CT * kk + c;
+        const bool in = e < total && gi < n1 && gj < ns && gj <= gi;
+        v[u] = masked_load(buf, (size_t)gi * ns + gj, in) + (in ? (gi == gj ? reg : 0.0) : (gi == gj ? 1.0 : 0.0));
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int e = e0 + u * CHOLP_THREADS;
+        if (e < total) P[(size_t)(e >> 8) * CTS + ((e >> 4) & 15) * CTL + (e & 15)] = v[u];
+      }
+    }
+  }
+  __syncthreads();
+  for (int kk = 0; kk < wt; ++kk) {
+    double* Dk = P + (size_t)(kk * wt + kk) * CTS;
+    if (wave == 0) chol_tile_factor_noinv(Dk, dinv + kk * CT, min(CT, ns - (c0 + CT * kk)), c0 + CT * kk, lane, badcol);
+    __syncthreads();
+    // tiles below the diagonal: X = A L_kk^-T (four per wavefront); the last wave first inverts the diagonal tile
+    if (wave == NW - 1) chol_tile_invert(Dk, dinv + kk * CT, Xi + (size_t)kk * CTS, lane);
+    for (int b0 = kk + 1 + 4 * wave; b0 < nbr; b0 += 4 * NW) {
+      const int bl = b0 + lg;
+      chol_panel_solve4(Dk, dinv + kk * CT, bl < nbr ? P + (size_t)(bl * wt + kk) * CTS : nullptr, li);
+    }
+    __syncthreads();
+    // remaining tile columns of the panel: C(bl, bj) -= X(bl, kk) X(bj, kk)^T for kk < bj < wt, bl >= bj
+    {
+      const int ncol = wt - kk - 1;
+      int nt = 0;
+      for (int q = 0; q < ncol; ++q) nt += nbr - (kk + 1 + q);
+      for (int tt = wave; tt < nt; tt += NW) {
+        int q = 0, rem = tt;
+        while (rem >= nbr - (kk + 1 + q)) { rem -= nbr - (kk + 1 + q); ++q; }
+        const int bj = kk + 1 + q, bl = bj + rem;
+        chol_tile_syrk(P + (size_t)(bl * wt + kk) * CTS, P + (size_t)(bj * wt + kk) * CTS, P + (size_t)(bl * wt + bj) * CTS, li, lg);
+      }
+    }
+    __syncthreads();
+  }
+  // ---- store the factor (lower triangle incl. the right-hand-side row) and the inverted diagonal tiles -----------------
+  {
+    const int total = nbr * wt * CT * CT;
+    for (int e = tid; e < total; e += CHOLP_THREADS) {
+      const int tile = e >> 8, r = (e >> 4) & 15, c = e & 15, bl = tile / wt, kk = tile - bl * wt;
+      const int gi = c0 + CT * bl + r, gj = c0 + CT * kk + c;
+      if (gi < n1 && gj < ns && gj <= gi) buf[(size_t)gi * ns + gj] = P[(size_t)tile * CTS + r * CTL + c];
+    }
+    for (int e = tid; e < wt * CT * CT; e += CHOLP_THREADS) {
+      const int kk = e >> 8, r = (e >> 4) & 15, c = e & 15;
+      Linv[(size_t)(kt0 + kk) * CT * CT + r * CT + c] = Xi[(size_t)kk * CTS + r * CTL + c];
+    }
+  }
+  // first non-positive pivot (1-based; 0 = none): the first panel initialises the report, later ones only add to it
+  if (tid == 0 && (kt0 == 0 || (badcol != 0 && info[0] == 0))) info[0] = badcol;
+}
+
+// trailing update behind the panel [kt0, kt0 + wt): one wavefront per tile (bi, bj), bj <= bi, both >= kt0 + wt
+__global__ __launch_bounds__(256) void k_cholp_trail(int ns, int kt0, int wt, double* __restrict__ buf) {
+  const int n1 = ns + 1, nb = (n1 + CT - 1) / CT, nbc = (ns + CT - 1) / CT, k1 = kt0 + wt;
+  const int m = nb - k1, nt = m * (m + 1) / 2;
+  const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
+  const int tt = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tt >= nt) return;
+  int a = (int)((sqrtf(8.0f * (float)tt + 1.0f) - 1.0f) * 0.5f);   // tt -> (a, rem), rem <= a
+  a += ((a + 1) * (a + 2) / 2 <= tt) ? 1 : 0;
+  a -= (a * (a + 1) / 2 > tt) ? 1 : 0;
+  const int rem = tt - a * (a + 1) / 2, bi = k1 + a, bj = k1 + rem;
+  if (bj >= nbc) return;                                            // (a column block behind the matrix: rhs-row tile only)
+  double4_t acc;
+  double av[CHOLP_WT * 4], bv[CHOLP_WT * 4];
+  const int gia = CT * bi + li, gib = CT * bj + li, gjc = CT * bj + li;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int gi = CT * bi + lg + 4 * r;
+    acc[r] = masked_load(buf, (size_t)gi * ns + gjc, gi < n1 && gjc < ns);
+  }
+#pragma unroll
+  for (int q = 0; q < CHOLP_WT * 4; ++q) {
+    const int gk = CT * kt0 + 4 * q + lg;                          // column of L inside the panel
+    const bool on = q < 4 * wt;
+    av[q] = -masked_load(buf, (size_t)gia * ns + gk, on && gia < n1);
+    bv[q] = masked_load(buf, (size_t)gib * ns + gk, on && gib < n1);
+  }
+#pragma unroll
+  for (int q = 0; q < CHOLP_WT * 4; ++q)
+    if (q < 4 * wt) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int gi = CT * bi + lg + 4 * r;
+    if (gi < n1 && gjc < ns && gjc <= gi) buf[(size_t)gi * ns + gjc] = acc[r];
+  }
+}
+
+// p = L^-T y: y = row ns of the factored matrix; Linv = inverted diagonal tiles
+__global__ __launch_bounds__(1024) void k_cholp_back(int ns, const double* __restrict__ buf, const double* __restrict__ Linv,
+                                                     double* __restrict__ ps) {
+  __shared__ double yv[1024 + CT], pv[CT];
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15;
+  const int nbc = (ns + CT - 1) / CT;
+  for (int e = tid; e < nbc * CT; e += 1024) yv[e] = e < ns ? buf[(size_t)ns * ns + e] : 0.0;
+  __syncthreads();
+  for (int kb = nbc - 1; kb >= 0; --kb) {
+    // row block kb of L for the update that follows the tile solve: requested first (column e of the block, 16 rows)
+    double lt[CT];
+#pragma unroll
+    for (int r = 0; r < CT; ++r) {
+      const int gi = CT * kb + r;
+      lt[r] = masked_load(buf, (size_t)gi * ns + tid, tid < CT * kb && gi < ns);
+    }
+    if (tid < 64) {   // p_k = L_kk^-T z_k (the strict upper part of the stored inverse is zero)
+      const double* Xi = Linv + (size_t)kb * CT * CT;
+      double sp[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int i = 0; i < CT; ++i) sp[i & 3] += Xi[i * CT + li] * yv[CT * kb + i];
+      const double sum = (sp[0] + sp[1]) + (sp[2] + sp[3]);
+      if (lane < CT) {
+        pv[li] = sum;
+        if (CT * kb + li < ns) ps[CT * kb + li] = sum;
+      }
+    }
+    __syncthreads();
+    if (tid < CT * kb) {
+      double sp[4] = {yv[tid], 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int r = 0; r < CT; ++r) sp[r & 3] -= lt[r] * pv[r];
+      yv[tid] = (sp[0] + sp[1]) + (sp[2] + sp[3]);
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Multi-workgroup blocked Cholesky for large reduced systems (adjust_board: ns = shared + 3 x #board points, up to a
 // few thousand).  Same data layout as k_chol_solve ((ns+1) x ns, row ns = rhs), 64-column panels, three launches per
 // panel: diagonal block (one workgroup), panel solve (one row per thread), symmetric rank-64 trailing update with
@@ -1990,35 +2258,56 @@ __global__ void k_reject(Dims d, const double* __restrict__ err, const uint8_t* 
 // compact list of the non-empty views: out[0] = count, out[1..] = view indices, LARGEST views first (by the number of
 // 64-observation chunks; ascending index within a class, so the list is deterministic).  The persistent kernels hand
 // the list out front to back: the long views start first and the short ones fill the tail of the launch (longest-
-// processing-time-first list scheduling).  Single workgroup; runs only when the inlier set changes.
-__global__ void k_active_views(int nviews, const int32_t* __restrict__ view_count, int32_t* __restrict__ out) {
-  __shared__ int wave_tot[16];
-  __shared__ int base;
-  if (threadIdx.x == 0) base = 0;
+// processing-time-first list scheduling).  Runs only when the inlier set changes.
+// Two launches of ceil(nviews / 1024) workgroups (a single workgroup walking all views class by class took 0.82 ms for
+// the 80 000 views of the 16 x 1000 x 5 rig): k_active_count leaves per-workgroup class counts, k_active_scatter turns
+// them into the workgroup's write offsets (classes descending, workgroups ascending) and places its views.
+constexpr int AV_CLASSES = LIN_MAX_POINTS / 64, AV_THREADS = 1024;
+__device__ __forceinline__ int active_class(int cnt) { return cnt == 0 ? 0 : min((cnt + 63) / 64, AV_CLASSES); }
+__global__ __launch_bounds__(AV_THREADS) void k_active_count(int nviews, const int32_t* __restrict__ view_count,
+                                                             int32_t* __restrict__ counts /*[blocks][AV_CLASSES]*/) {
+  __shared__ int tot[AV_CLASSES];
+  if (threadIdx.x < AV_CLASSES) tot[threadIdx.x] = 0;
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  constexpr int NCLASS = LIN_MAX_POINTS / 64;
-  for (int cls = NCLASS; cls >= 1; --cls) {
-    for (int v0 = 0; v0 < nviews; v0 += blockDim.x) {
-      const int v = v0 + threadIdx.x;
-      const int cnt = v < nviews ? view_count[v] : 0;
-      const bool on = cnt != 0 && min((cnt + 63) / 64, NCLASS) == cls;
-      const unsigned long long m = __ballot(on);
-      if (lane == 0) wave_tot[wave] = __popcll(m);
-      __syncthreads();
-      int off = base;
-      for (int w = 0; w < wave; ++w) off += wave_tot[w];
-      if (on) out[1 + off + __popcll(m & ((1ull << lane) - 1ull))] = v;
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        int tot = 0;
-        for (int w = 0; w < nw; ++w) tot += wave_tot[w];
-        base += tot;
-      }
-      __syncthreads();
-    }
+  const int v = blockIdx.x * AV_THREADS + threadIdx.x;
+  const int cls = v < nviews ? active_class(view_count[v]) : 0;
+  for (int k = 1; k <= AV_CLASSES; ++k) {
+    const unsigned long long m = __ballot(cls == k);
+    if ((threadIdx.x & 63) == 0 && m != 0) atomicAdd(&tot[k - 1], (int)__popcll(m));   // (integer sums: order-free)
   }
-  if (threadIdx.x == 0) out[0] = base;
+  __syncthreads();
+  if (threadIdx.x < AV_CLASSES) counts[blockIdx.x * AV_CLASSES + threadIdx.x] = tot[threadIdx.x];
+}
+__global__ __launch_bounds__(AV_THREADS) void k_active_scatter(int nviews, const int32_t* __restrict__ view_count,
+                                                               const int32_t* __restrict__ counts, int32_t* __restrict__ out) {
+  __shared__ int base[AV_CLASSES], wave_tot[AV_THREADS / 64], total;
+  const int nblk = gridDim.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x < AV_CLASSES) {   // thread k: offset of class k + 1 for this workgroup
+    const int k = threadIdx.x;
+    int before = 0, all = 0;
+    for (int b = 0; b < nblk; ++b) {
+      for (int kk = k + 1; kk < AV_CLASSES; ++kk) before += counts[b * AV_CLASSES + kk];   // larger classes come first
+      if (b < (int)blockIdx.x) before += counts[b * AV_CLASSES + k];
+      if (k == 0)
+        for (int kk = 0; kk < AV_CLASSES; ++kk) all += counts[b * AV_CLASSES + kk];
+    }
+    base[k] = before;
+    if (k == 0) total = all;
+  }
+  __syncthreads();
+  const int v = blockIdx.x * AV_THREADS + threadIdx.x;
+  const int cls = v < nviews ? active_class(view_count[v]) : 0;
+  for (int k = AV_CLASSES; k >= 1; --k) {
+    const bool on = cls == k;
+    const unsigned long long m = __ballot(on);
+    if (lane == 0) wave_tot[wave] = __popcll(m);
+    __syncthreads();
+    int off = base[k - 1];
+    for (int w = 0; w < wave; ++w) off += wave_tot[w];
+    if (on) out[1 + off + __popcll(m & ((1ull << lane) - 1ull))] = v;
+    __syncthreads();
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) out[0] = total;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -352,6 +352,7 @@ MCBA_HD int local_to_x(const Dims& d, int f, int c, int b, int i) {
   }
   const int q = i - npose;
   if (q >= d.KI || d.off_cameras < 0) return -1;
+  if (d.cam_kmask != nullptr && ((d.cam_kmask[c] >> q) & 1u)) return -1;   // coefficient this camera's model does not have
   return d.off_cameras + c * (5 + d.ND) + (q < 4 ? q : q + 1);   // skip the skew slot (camera.py:153)
 }
 

@@ -48,6 +48,7 @@ BOARDS = dict(
   charuco_16x22=lambda: charuco_points((16, 22), 0.025),       # example_boards/charuco_16x22.yaml
   aprilgrid_9x9=lambda: aprilgrid_points((9, 9), 0.06, 0.3),   # example_boards/aprilgrid_9x9.yaml
   charuco_10x10=lambda: charuco_points((10, 10), 0.040),       # example_boards/cube_10x10.yaml (x5)
+  charuco_25x35=lambda: charuco_points((25, 35), 0.020),       # 24 x 34 = 816 corners: more than one 512-slot segment
 )
 
 
@@ -142,6 +143,17 @@ CONFIGS = {
   # from a calibration file written by OpenCV with CALIB_FIX_K3 (cv2.projectPoints accepts 4, 5, 8, 12 or 14)
   "tiny_pin4": dict(cameras=2, frames=8, boards=["charuco_10x10"], motion="static", model="pin4",
                     optimize_cameras=True, layout="stereo", seed=18),
+  # rigs beyond the former limits of the HIP back-end (the reference has none): a board with more than 512 points
+  # (tables.stack_boards pads to the largest board, tables.py:385-394) next to a small one, and more than 128
+  # (camera, board) pairs
+  "tiny_bigboard": dict(cameras=2, frames=6, boards=["charuco_25x35", "charuco_10x10"], motion="rolling",
+                        model="standard", optimize_cameras=True, layout="stereo", seed=31),
+  "tiny_manypairs": dict(cameras=16, frames=10, boards=["charuco_10x10"] * 10, motion="static", model="standard",
+                         optimize_cameras=True, layout="stereo", board_grid=5, distance=3.0, seed=32),
+  # cameras of DIFFERENT models in one rig (a ParamList of independent Camera objects, optimization/parameters.py:54-85):
+  # 5, 8, 14 and 4 distortion coefficients -- the cameras block of the parameter vector is ragged
+  "tiny_mixed": dict(cameras=4, frames=8, boards=["charuco_10x10"], motion="static",
+                     model=["standard", "rational", "tilted", "pin4"], optimize_cameras=True, layout="stereo", seed=33),
   # reduced-frame variants of BASELINE configs[2..4] whose complete reference run (adjust_outliers) finishes in minutes
   "cfg3_40": dict(cameras=8, frames=40, boards=["charuco_16x22", "aprilgrid_9x9"], motion="rolling",
                   model="standard", optimize_cameras=True, layout="stereo", seed=3),
@@ -220,7 +232,10 @@ def make_rig(name_or_cfg, frames=None, seed=None, noise=0.2, outlier_frac=0.01, 
   P = max(p.shape[0] for p in board_pts)
   ring = cfg.get("layout") == "ring"
 
-  cameras = [_make_camera(cfg["model"], rng, focal=1000.0 if ring else 2250.0) for _ in range(C)]
+  # `model` may be a list: one model per camera (the reference's cameras are independent objects)
+  models = cfg["model"] if isinstance(cfg["model"], (list, tuple)) else [cfg["model"]] * C
+  assert len(models) == C
+  cameras = [_make_camera(m, rng, focal=1000.0 if ring else 2250.0) for m in models]
 
   # --- camera poses (rig -> camera) ------------------------------------------------------------
   cam_poses = np.tile(np.eye(4), (C, 1, 1))
@@ -252,6 +267,13 @@ def make_rig(name_or_cfg, frames=None, seed=None, noise=0.2, outlier_frac=0.01, 
       m[:3, :3] = Rb
       m[:3, 3] = 1.0 * out - Rb @ np.array([0.2, 0.2, 0.0])
       board_poses[b] = m
+  elif cfg.get("board_grid"):
+    # boards on a planar grid (board_grid columns, 0.42 m pitch) whose middle lies where a single board would be
+    cols = cfg["board_grid"]
+    rows = (B + cols - 1) // cols
+    for b in range(B):
+      off = [0.42 * (b % cols - (cols - 1) / 2), 0.42 * (b // cols - (rows - 1) / 2), 0.02 * (b % 3)]
+      board_poses[b] = to_matrix(np.concatenate([rng.normal(0, 0.05, 3), off]))
   else:
     for b in range(1, B):
       d = np.concatenate([rng.normal(0, 0.05, 3), [0.45 * b, 0.05 * b, 0.02 * b]])
@@ -266,6 +288,8 @@ def make_rig(name_or_cfg, frames=None, seed=None, noise=0.2, outlier_frac=0.01, 
       rig[f] = to_matrix(np.concatenate([rng.normal(0, 0.05, 3), [0, 0, 0]])) @ to_matrix(d)
   else:
     centre = np.array([-0.2, -0.25, 1.0]) if not cfg.get("cube") else np.array([-0.2, -0.2, 1.1])
+    if cfg.get("board_grid"):   # look at the middle of the grid from `distance`
+      centre = np.array([-0.2, -0.25, cfg.get("distance", 1.0)])
     d = np.concatenate([rng.normal(0, 0.25, (F, 3)), centre + rng.normal(0, 0.1, (F, 3))], axis=1)
     rig = to_matrix(d)
 
@@ -330,7 +354,7 @@ def make_rig(name_or_cfg, frames=None, seed=None, noise=0.2, outlier_frac=0.01, 
         facing = np.ones_like(facing)
       ok = (Xc[..., 2] > 0.1) & (uv[..., 0] >= 0) & (uv[..., 0] < w) & (uv[..., 1] >= 0) & (uv[..., 1] < h)
       ok &= np.isfinite(uv).all(axis=-1) & facing & pvalid
-      if cfg["model"] == 'fisheye':
+      if cameras[c].model == 'fisheye':
         ok &= np.arctan2(np.hypot(Xc[..., 0], Xc[..., 1]), Xc[..., 2]) < np.deg2rad(75)
       else:
         ok &= np.hypot(Xc[..., 0], Xc[..., 1]) < 0.62 * Xc[..., 2]  # stay inside the monotone range of the radial model
@@ -400,7 +424,12 @@ def _pose_set_arrays(prefix, ps, out):
     out[prefix + "he_world_wrt_base"] = ps.hand_eye.world_wrt_base
     out[prefix + "he_gripper_wrt_camera"] = ps.hand_eye.gripper_wrt_camera
   out[prefix + "K"] = np.stack([c.intrinsic for c in ps.cameras])
-  out[prefix + "dist"] = np.stack([c.dist for c in ps.cameras])
+  sizes = [c.dist.size for c in ps.cameras]
+  if len(set(sizes)) == 1:
+    out[prefix + "dist"] = np.stack([c.dist for c in ps.cameras])
+  else:   # cameras of different models: rows padded with zeros, true sizes alongside
+    out[prefix + "dist"] = np.stack([np.concatenate([c.dist, np.zeros(max(sizes) - c.dist.size)]) for c in ps.cameras])
+    out[prefix + "dist_sizes"] = np.array(sizes)
 
 
 def rig_to_arrays(rig):
@@ -424,8 +453,10 @@ def rig_from_arrays(arrs):
   meta = json.loads(str(arrs["meta_json"]))
 
   def pose_set(prefix):
+    nds = arrs[prefix + "dist_sizes"] if prefix + "dist_sizes" in arrs else None
     cams = [SimpleNamespace(model=m["model"], image_size=tuple(m["image_size"]), intrinsic=arrs[prefix + "K"][i],
-                            dist=arrs[prefix + "dist"][i], fix_aspect=m["fix_aspect"], has_skew=m["has_skew"])
+                            dist=arrs[prefix + "dist"][i] if nds is None else arrs[prefix + "dist"][i][:int(nds[i])],
+                            fix_aspect=m["fix_aspect"], has_skew=m["has_skew"])
             for i, m in enumerate(meta["cameras"])]
     he = None
     if prefix + "he_world_wrt_base" in arrs:

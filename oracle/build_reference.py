@@ -13,6 +13,7 @@ BOARD_ARGS = {
   "charuco_10x10": ("charuco", dict(size=(10, 10), square_length=0.040, marker_length=0.032, aruco_dict='5X5_1000',
                                     min_rows=3, min_points=9)),
   "aprilgrid_9x9": ("aprilgrid", dict(size=(9, 9), tag_length=0.06, tag_spacing=0.3)),
+  "charuco_25x35": ("charuco", dict(size=(25, 35), square_length=0.020, marker_length=0.015, aruco_dict='5X5_1000')),
 }
 
 

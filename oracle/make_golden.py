@@ -88,6 +88,8 @@ CASES = {
   # Workspace.calibrate(loss=..., auto_scale=...) (workspace.py:239-244): f_scale = quantile_0.75(errors) * auto_scale
   "tiny_autoscale": ("tiny", None, dict(loss='soft_l1', f_scale=1.5), True, False),
   "tiny_autoscale_huber": ("tiny_rolling", None, dict(loss='huber', f_scale=2.0), True, False),
+  # a board with more points than one 512-slot compaction segment of the HIP kernels (25 x 35 charuco: 816 corners)
+  "tiny_bigboard": ("tiny_bigboard", None, {}, True, True),
 }
 
 AO_KWARGS = {   # Workspace.calibrate arguments of the adjust_outliers run (default: loss='linear', no auto_scale)
@@ -101,6 +103,7 @@ BIG_CASES = {
   "cfg3_40": ("cfg3_40", None),
   "cfg4_40": ("cfg4_40", None),
   "cfg5_40": ("cfg5_40", None),
+  "manypairs": ("tiny_manypairs", None),   # 16 cameras x 10 boards = 160 (camera, board) pairs
 }
 # evaluation-only goldens of the BASELINE configurations AT THEIR STATED SIZE (one reference `evaluate` costs seconds
 # there, a reference solve hours): residual checksums, a strided sample of the residual vector, error statistics at x0
@@ -110,7 +113,7 @@ FULL_CASES = {
   "cfg4_full": "cfg4",     # 16 x 1000 x 5
   "cfg5_full": "cfg5",     # 6 x 400 x 5 fisheye hand-eye
 }
-N_PERT = 3            # perturbed re-runs per reference call
+N_PERT = 10           # perturbed re-runs per reference call (oracle/make_pert.py widened the older fixtures to the same 10)
 PERT_SIGMA = 1e-12    # px
 
 

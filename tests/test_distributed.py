@@ -87,13 +87,16 @@ def _gpu_worker(rank, world, port, name, out, empty_last=False):
   # empty_last: rank 0 owns every frame, the other ranks own nothing (legal: frame_shards does that when F < world)
   h = mdist.sharded_handle(c, shards=[(0, F)] + [(F, F)] * (world - 1) if empty_last else None)
   cost, grad, diag = h.normal_equations(g["x0"])
+  h.allreduce_stats(reset=True)
   res = h.solve(g["x0"])
+  ar_calls, ar_doubles, ar_sizes = h.allreduce_stats(reset=True)
   e, v = h.reprojection_error(res.x)
   sq = torch.tensor([float((e[v] ** 2).sum()), float(v.sum())], dtype=torch.float64)
   dist.all_reduce(sq)
   if rank == 0:
     np.savez(out, cost=cost, grad=grad, diag=diag, x=res.x, nfev=res.nfev, status=res.status, final_cost=res.cost,
-             rms=float(np.sqrt(sq[0] / sq[1])))
+             rms=float(np.sqrt(sq[0] / sq[1])), ar_calls=ar_calls, ar_doubles=ar_doubles, ar_sizes=np.array(ar_sizes),
+             njev=res.njev)
   h.close()
   dist.destroy_process_group()
 
@@ -123,6 +126,29 @@ def test_sharded_solve_two_ranks_one_gpu(name, empty_last, tmp_path):
   # (two shards sum H and the partial arrays in a different order than one handle; weakly determined gauge directions
   #  amplify the last-bit differences)
   assert np.abs(sh["x"] - res.x).max() < 1e-7
+  # ---- the chain of collectives of the sharded trust-region iteration, in issue order ----------------
+  #   [g | diag | cost] (2 n + 2)  ->  Cauchy curvature (1)  ->  reduced Schur system (ns^2 + ns)  ->  frame part of the
+  #   step (n_motion; not for hand-eye, which has no per-frame parameters)  ->  the next [g | diag | cost], which carries
+  #   the trial cost of the accepted step: FOUR dependent reductions per accepted iteration, no separate cost message.
+  sizes = [int(v) for v in sh["ar_sizes"]]
+  n = res.x.size
+  motion = rig.cfg["motion"]
+  n_motion = {"static": 6, "rolling": 12}.get(motion, 0) * rig.valid.shape[1]
+  ns = n - n_motion
+  G, S = 2 * n + 2, ns * ns + ns
+  assert sizes[0] == G and int(sh["ar_calls"]) == len(sizes) and int(sh["ar_doubles"]) == sum(abs(v) for v in sizes)
+  at = [i for i, v in enumerate(sizes) if v == S]
+  assert len(at) >= 1
+  for i in at:
+    assert sizes[i - 1] == 1                                   # curvature scalar right before the Schur system
+    k = i + 1
+    if n_motion:
+      assert sizes[k] == n_motion
+      k += 1
+    assert sizes[k] == G, sizes                                # speculative linearisation: carries the trial cost
+  extra_cost_msgs = sum(1 for i, v in enumerate(sizes) if v == 1 and (i + 1 >= len(sizes) or sizes[i + 1] != S))
+  assert extra_cost_msgs == res.nfev - 1 - len(at)             # one 1-double message per RETRY only
+  assert sizes.count(G) >= int(sh["njev"])                     # (+ one per re-linearisation after a rejected step)
 
 
 def _rccl_single_rank_worker(rank, out_path):
