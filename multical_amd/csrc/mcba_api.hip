@@ -655,7 +655,7 @@ bool g_force_panel_chol = false;
 bool g_force_column_chol = false;
 bool g_force_glb_chol = false;
 bool g_force_panel2_chol = false;    // the multi-launch panel kernels (k_cholp_*) at any size
-long long* g_chol_prof = nullptr;    // device buffer of 8 phase stamps (mcba_debug_chol, blocked == 4)
+long long* g_chol_prof = nullptr;    // device buffer of 8 phase stamps (mcba_debug_chol, blocked == 4 / 7)
 
 // (S + reg I) p = rhs for buf = [S (ns x ns) | rhs (ns)]; S is overwritten by its Cholesky factor
 void launch_chol(mcba_handle_s* h, int ns, double reg, double* buf, double* ps) {
@@ -686,13 +686,21 @@ void launch_chol(mcba_handle_s* h, int ns, double reg, double* buf, double* ps) 
         h->chol_lds5_set = lds;
       }
       hipLaunchKernelGGL(k_cholp_panel, dim3(1), dim3(CHOLP_THREADS), lds, h->stream, ns, kt0, wt, reg, buf, h->chol_linv.p,
-                         h->info.p);
+                         h->info.p, g_chol_prof);
       const int k1 = kt0 + wt, m = nb - k1, nt = m * (m + 1) / 2;
       if (k1 < nbc && nt > 0)
         hipLaunchKernelGGL(k_cholp_trail, dim3((nt + 3) / 4), dim3(256), 0, h->stream, ns, kt0, wt, buf);
       kt0 = k1;
     }
-    hipLaunchKernelGGL(k_cholp_back, dim3(1), dim3(1024), 0, h->stream, ns, (const double*)buf, (const double*)h->chol_linv.p, ps);
+    if (ns <= CHOLP_BACK_COLS)
+      hipLaunchKernelGGL((k_cholp_back<1, 4>), dim3(1), dim3(CHOLP_BACK_THREADS), 0, h->stream, ns, (const double*)buf,
+                         (const double*)h->chol_linv.p, ps);
+    else if (ns <= 2 * CHOLP_BACK_COLS)
+      hipLaunchKernelGGL((k_cholp_back<2, 2>), dim3(1), dim3(CHOLP_BACK_THREADS), 0, h->stream, ns, (const double*)buf,
+                         (const double*)h->chol_linv.p, ps);
+    else
+      hipLaunchKernelGGL((k_cholp_back<3, 1>), dim3(1), dim3(CHOLP_BACK_THREADS), 0, h->stream, ns, (const double*)buf,
+                         (const double*)h->chol_linv.p, ps);
     return;
   }
   if (ns + 1 <= (g_force_glb_chol ? CHOL_GLB_MAX_N1 : CHOL_GLB_AUTO_N1) && !g_force_blocked_chol && !g_force_panel_chol &&
@@ -1594,11 +1602,17 @@ int32_t mcba_debug_chol(mcba_handle h, int32_t ns, const double* S, const double
     stamps.alloc(8);
     g_chol_prof = stamps.p;
   }
+  if (blocked == 7) {                    // 7: k_cholp_panel with phase stamps summed over the panels (p_out[0..5])
+    REQUIRE(ns >= 8 && ns + 1 <= CHOL_GLB_MAX_N1, "profiling needs 8 <= ns < 1024");
+    stamps.alloc(8);
+    g_chol_prof = stamps.p;
+    g_force_panel2_chol = true;
+  }
   try { launch_chol(h, ns, reg, buf.p, ps.p); }
   catch (...) { g_force_blocked_chol = g_force_panel_chol = g_force_column_chol = g_force_glb_chol = g_force_panel2_chol = false; g_chol_prof = nullptr; throw; }
   g_force_blocked_chol = g_force_panel_chol = g_force_column_chol = g_force_glb_chol = g_force_panel2_chol = false;
   g_chol_prof = nullptr;
-  if (blocked == 4) {
+  if (blocked == 4 || blocked == 7) {
     long long st[8];
     sync(h);
     HIP_OK(hipMemcpy(st, stamps.p, sizeof(st), hipMemcpyDeviceToHost));

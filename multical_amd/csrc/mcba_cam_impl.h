@@ -60,19 +60,17 @@ void lin2(const Dims& d, const Tables& t, hipStream_t s, double* rec, const uint
   // the linear loss (the reference's default, calibration.py:199) has its own instantiation of the MFMA kernel: no loss
   // switch and no robust-scale constants in the hot loop; the plain-FMA validation build keeps the generic form
   if (t.dbg != nullptr) {   // per-phase cycle stamps (debug API): the table form of the MFMA kernel
-    hipLaunchKernelGGL((k_linearize<ND_, FISH_, MOTION, OPTK, true, true, false, true>), grid, block, 0, s, d, t, rec, tri, epoch, x, za, na, zb, nb);
+    hipLaunchKernelGGL((k_linearize<ND_, FISH_, MOTION, OPTK, true, true, 0, true>), grid, block, 0, s, d, t, rec, tri, epoch, x, za, na, zb, nb);
     return;
   }
-  if (fused && mfma && d.loss == 0)
-    hipLaunchKernelGGL((k_linearize<ND_, FISH_, MOTION, OPTK, true, false, true>), grid, block, 0, s, d, t, rec, tri, epoch, x, za, na, zb, nb);
-  else if (fused && mfma)
-    hipLaunchKernelGGL((k_linearize<ND_, FISH_, MOTION, OPTK, true, true, true>), grid, block, 0, s, d, t, rec, tri, epoch, x, za, na, zb, nb);
-  else if (mfma && d.loss == 0)
-    hipLaunchKernelGGL((k_linearize<ND_, FISH_, MOTION, OPTK, true, false, false>), grid, block, 0, s, d, t, rec, tri, epoch, x, za, na, zb, nb);
-  else if (mfma)
-    hipLaunchKernelGGL((k_linearize<ND_, FISH_, MOTION, OPTK, true, true, false>), grid, block, 0, s, d, t, rec, tri, epoch, x, za, na, zb, nb);
+  const bool robust = d.loss != 0;
+#define MCBA_LIN(ROB, FM) hipLaunchKernelGGL((k_linearize<ND_, FISH_, MOTION, OPTK, true, ROB, FM>), grid, block, 0, s, d, t, rec, tri, epoch, x, za, na, zb, nb)
+  if (mfma && fused && x != nullptr) { if (robust) MCBA_LIN(true, 1); else MCBA_LIN(false, 1); }
+  else if (mfma && fused) { if (robust) MCBA_LIN(true, 2); else MCBA_LIN(false, 2); }
+  else if (mfma) { if (robust) MCBA_LIN(true, 0); else MCBA_LIN(false, 0); }
   else
-    hipLaunchKernelGGL((k_linearize<ND_, FISH_, MOTION, OPTK, false, true, false>), grid, block, 0, s, d, t, rec, tri, epoch, x, za, na, zb, nb);
+    hipLaunchKernelGGL((k_linearize<ND_, FISH_, MOTION, OPTK, false, true, 0>), grid, block, 0, s, d, t, rec, tri, epoch, x, za, na, zb, nb);
+#undef MCBA_LIN
 }
 
 template <int MOTION>

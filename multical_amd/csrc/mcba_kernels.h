@@ -600,11 +600,19 @@ __global__ __launch_bounds__(256) void k_points(Dims d, Tables t, double* __rest
 // contain no global store besides the record (a __restrict__ argument): hipcc can then prove that the wave-uniform reads
 // of the view / camera tables are never clobbered and issues them as scalar loads (s_load, operands in SGPRs) instead of
 // 17 vector loads of one address per 64-observation chunk.
-template <int ND, bool FISH, int MOTION, bool OPTK, bool MFMA, bool ROBUST, bool FUSED, bool PROF = false>
-__global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* __restrict__ rec,
+template <int ND, bool FISH, int MOTION, bool OPTK, bool MFMA, bool ROBUST, int FUSED_MODE, bool PROF = false>
+// (static pinhole kernels with the linear loss fit 128 registers: they ask for four waves per SIMD explicitly, so that the
+//  table-fed fused form -- 132 registers under the two-wave budget -- is allocated into 128 as well)
+__global__ __launch_bounds__(64, (MOTION == MOTION_STATIC && !FISH && MFMA && !ROBUST && !PROF && FUSED_MODE != 1 && OPTK && ND <= 5) ? 4 : 2)
+void k_linearize(Dims d, Tables t, double* __restrict__ rec,
                                                      const uint16_t* __restrict__ tri, int epoch,
                                                      const double* __restrict__ x, double* __restrict__ zero_a, int na,
                                                      double* __restrict__ zero_b, int nb) {
+  // FUSED_MODE: 0 = table form (That / chains from k_tmat), 1 = everything from x (incl. the trigonometry of the pose
+  // entries), 2 = table-fed fused form (pose entries copied from the pose table, intrinsics from the camera table).  Modes 1
+  // and 2 are separate instantiations: the trigonometry of mode 1 costs registers that mode 2 never needs (compiled together,
+  // the rolling-shutter kernel spilled 44 bytes per lane and the static one lost its fourth wave per SIMD).
+  constexpr bool FUSED = FUSED_MODE != 0, FUSED_X = FUSED_MODE == 1;
   constexpr bool ROLL = MOTION == MOTION_ROLLING;
   constexpr int DE = ROLL ? 12 : 6, NPB = MOTION == MOTION_STATIC ? 3 : 4, KI = OPTK ? 4 + ND : 0;
   constexpr int NV = DE + KI + 1, NT = (NV + 15) / 16, NVP = 16 * NT;
@@ -692,6 +700,8 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
 #pragma unroll
         for (int k = 0; k < NVS; ++k) Vr[k] = vsrc[k];         // (made scalar in front_finish)
       }
+    }
+    if constexpr (FUSED_MODE != 1) {   // camera entry from the table (table form and table-fed fused form): same round trip
       const double* csrc = t.cam + (size_t)cc * CAM_STRIDE;
 #pragma unroll
       for (int k = 0; k < 5 + ND; ++k) cam_f[k] = csrc[k];
@@ -714,6 +724,8 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
 #pragma unroll
         for (int k = 0; k < NVS; ++k) Vr[k] = uniform_f64(Vr[k]);
       }
+    }
+    if constexpr (FUSED_MODE != 1) {
 #pragma unroll
       for (int k = 0; k < 5 + ND; ++k) camr[k] = uniform_f64(cam_f[k]);
       extr[CAM_HEIGHT - CAM_TILT] = uniform_f64(ext_f[0]);
@@ -762,13 +774,13 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
     // x == nullptr: the TABLE-FED fused form -- the pose / camera tables already hold the point (k_prep, or the tail of the
     // k_vec_step that produced it): the view's pose entries are copied from the pose table (no trigonometry here) and the
     // intrinsics come from the camera table; the chain products and the That columns are formed below all the same.
-    const bool from_x = x != nullptr;
+    constexpr bool from_x = FUSED_X;
     camp = !from_x ? t.cam + (size_t)c * CAM_STRIDE
                    : (d.off_cameras >= 0 ? x + d.off_cameras + c * (5 + ND) : t.xfull + d.foff_cameras + c * (5 + ND));
     // pose entries of the view from x: lane 0 camera, lane NPB - 1 board, the lanes between the motion poses
     static_assert(NPB * POSE_STRIDE <= BUF, "pose entries do not fit the staging buffer");
     double* Pl = Buf;                      // (the staging buffer is free until the first chunk)
-    if (!from_x) {
+    if constexpr (!from_x) {
 #pragma unroll
       for (int u = 0; u < (NPB * POSE_STRIDE + 63) / 64; ++u) {
         const int e = min(pl + 64 * u, NPB * POSE_STRIDE - 1), k = e / POSE_STRIDE, q = e - k * POSE_STRIDE;
@@ -777,7 +789,8 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
                                      : d.pose_motion + (MOTION == MOTION_STATIC ? f : (MOTION == MOTION_ROLLING ? (k - 1) * d.F + f : k - 1)));
         Pl[e] = t.pose[(size_t)gi * POSE_STRIDE + q];
       }
-    } else if (pl < NPB) {
+    } else {
+     if (pl < NPB) {
       int oa, of, r;
       if (pl == 0) { oa = d.off_campose; of = d.foff_campose; r = 6 * c; }
       else if (pl == NPB - 1) { oa = d.off_boardpose; of = d.foff_boardpose; r = 6 * b; }
@@ -793,6 +806,7 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
       pose_entry(rt, pe);
 #pragma unroll
       for (int k = 0; k < POSE_STRIDE; ++k) Pl[pl * POSE_STRIDE + k] = pe[k];
+     }
     }
     lds_fence();
     const double* Pc = Pl;
@@ -801,8 +815,26 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
     const double* Pm1 = Pl + (NPB > 3 ? 2 : 1) * POSE_STRIDE;
     const double* Bf = t.bwg + 12 * (size_t)f;
     if constexpr (MOTION != MOTION_HAND_EYE) {
-      // static / rolling shutter: lane-uniform chain products, per-lane column by selects (no divergent block cases)
-      fused_view_tables<ROLL>(Pc, Pm0, Pm1, Pb, pl, Tm, Vm);
+      // static / rolling shutter: the chain prefixes  R1 | t1 = camera . frame  and  R2 | o = camera . frame . board  are formed
+      // ONCE per view, one entry per lane in two dependent steps through LDS (48 lanes x 3 FMAs each for the two chains of a
+      // rolling-shutter view), then lane j < 6 NPB forms column j of That from the prefixes -- the construction k_tmat uses.
+      // (fused_view_tables let EVERY lane form every product: ~400 FP64 instructions per view against ~60 here; the
+      //  table-fed fused kernel took 50.5 us against 44.3 us of the table form at the north-star rig.)
+      static_assert(NPB * POSE_STRIDE + 2 * PRE_STRIDE <= BUF, "chain prefixes do not fit the staging buffer");
+      constexpr int NCH = ROLL ? 2 : 1;
+      double* pre = Buf + NPB * POSE_STRIDE;
+      const int pch = pl / 12, pq = pl - 12 * pch;
+      const bool pon = pl < 12 * NCH;
+      const int pcc = pon ? pch : 0;
+      if (pon) pre[pcc * PRE_STRIDE + pq] = se3_mul_entry(Pc, pcc == 0 ? Pm0 : Pm1, pq);
+      lds_fence();
+      if (pon) {
+        const double val = se3_mul_entry(pre + pcc * PRE_STRIDE, Pb, pq);
+        pre[pcc * PRE_STRIDE + 12 + pq] = val;
+        Vm[pcc * VIEW_STRIDE + pq] = val;   // the chain matrix board -> camera of this chain
+      }
+      lds_fence();
+      if (pl < NPC) that_column_from_prefix<ROLL>(Pc, Pm0, Pm1, Pb, pre, pl, Tm, NPC);
     } else if (pl < NPC) {                 // hand-eye (five-pose chain): one column of That per lane
       double col[DE];
       view_column_p(d, Pc, Pb, Pm0, Pm1, Bf, pl, col);
@@ -845,11 +877,13 @@ __global__ __launch_bounds__(64, 2) void k_linearize(Dims d, Tables t, double* _
   // rolling shutter: the two chains stay in LDS).  Left to the compiler they were 17 vector loads of one address each in
   // EVERY chunk, with 68 vector registers to hold them.
   if constexpr (FUSED) {
+    if constexpr (FUSED_X) {   // (the table-fed form took its camera entry with the front loads)
 #pragma unroll
-    for (int k = 0; k < 5 + ND; ++k) camr[k] = uniform_f64(camp[k]);
-    const double* esrc = t.cam + (size_t)c * CAM_STRIDE + CAM_TILT;
-    extr[CAM_HEIGHT - CAM_TILT] = uniform_f64(esrc[CAM_HEIGHT - CAM_TILT]);
-    extr[CAM_FIXASPECT - CAM_TILT] = uniform_f64(esrc[CAM_FIXASPECT - CAM_TILT]);
+      for (int k = 0; k < 5 + ND; ++k) camr[k] = uniform_f64(camp[k]);
+      const double* esrc = t.cam + (size_t)c * CAM_STRIDE + CAM_TILT;
+      extr[CAM_HEIGHT - CAM_TILT] = uniform_f64(esrc[CAM_HEIGHT - CAM_TILT]);
+      extr[CAM_FIXASPECT - CAM_TILT] = uniform_f64(esrc[CAM_FIXASPECT - CAM_TILT]);
+    }
     if constexpr (!ROLL) {
 #pragma unroll
       for (int k = 0; k < NVS; ++k) Vr[k] = uniform_f64(Vm[k]);

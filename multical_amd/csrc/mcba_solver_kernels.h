@@ -2,6 +2,7 @@
 // per-view records into the block normal equations, and the damped normal-equation solve of the trust-region
 // driver (Schur elimination of the per-frame blocks, dense Cholesky, vector updates).  Included only by mcba_api.hip.
 #pragma once
+#include <type_traits>
 #include <vector>
 #include <utility>
 #include "mcba_kernels.h"
@@ -1484,8 +1485,9 @@ __global__ __launch_bounds__(CHOL_BLK_THREADS) void k_chol_glb(int ns, double re
 // register / LDS tile kernels of k_chol_blk, and the trailing update of the rest of the matrix runs on the WHOLE chip:
 //   k_cholp_panel   ONE workgroup: block column [c0, c0 + 16 wt) x rows [c0, ns] from L2 into LDS; per tile column the
 //                   diagonal tile is factored in registers (wave 0), the tiles below are solved by forward substitution
-//                   (four per wavefront) while the last wave inverts the diagonal tile for the back substitution, and the
-//                   remaining tile columns of the panel are updated on the matrix pipe; L goes back to memory
+//                   (four per wavefront), the remaining tile columns of the panel are updated on the matrix pipe (the next
+//                   diagonal tile first: wave 0 factors it at once), the diagonal tiles are inverted for the back
+//                   substitution at the end; L goes back to memory
 //   k_cholp_trail   one wavefront per 16 x 16 tile of the trailing lower triangle:  C -= X_i X_j^T  with K = 16 wt, X from
 //                   L2, twelve MFMAs, every load issued before the first one
 //   k_cholp_back    one workgroup: p = L^-T y with the stored inverses of the diagonal tiles (a mat-vec per tile, no serial
@@ -1528,7 +1530,8 @@ __device__ __forceinline__ void chol_tile_invert(const double* __restrict__ L, c
 }
 
 __global__ __launch_bounds__(CHOLP_THREADS) void k_cholp_panel(int ns, int kt0, int wt, double reg, double* __restrict__ buf,
-                                                               double* __restrict__ Linv, int* __restrict__ info) {
+                                                               double* __restrict__ Linv, int* __restrict__ info,
+                                                               long long* __restrict__ prof = nullptr) {
   extern __shared__ __attribute__((aligned(16))) double cholp[];
   constexpr int NW = CHOLP_THREADS / 64;
   const int n1 = ns + 1, nb = (n1 + CT - 1) / CT, nbr = nb - kt0, c0 = CT * kt0;
@@ -1537,10 +1540,16 @@ __global__ __launch_bounds__(CHOLP_THREADS) void k_cholp_panel(int ns, int kt0, 
   double* dinv = Xi + (size_t)wt * CTS;           // 1 / L_jj [wt][16]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
   int badcol = 0;
+  long long tp[6] = {0, 0, 0, 0, 0, 0}, tc = 0;   // phase stamps (prof != nullptr): load, first factor, solve, trailing, invert, store
+  if (prof) tc = clock64();
+#define CHOLP_STAMP(i) if (prof) { const long long now = clock64(); tp[i] += now - tc; tc = now; }
   // ---- load: rows of 16 doubles (128 B) per 16 threads; outside the matrix the identity continues it -----------------
   {
     const int total = nbr * wt * CT * CT;
-    constexpr int UN = 8;
+    // the panel comes from memory other compute units (other XCDs) have just written: ~3 us per dependent round trip.  32
+    // loads per thread cover the largest panel the LDS holds (150 KB = 19.2 k entries / 512 threads = 37.5) in two batches
+    // and every panel of ns <= 286 in ONE (measured with 8 per batch: 15 k cycles of load per panel, half of its arithmetic)
+    constexpr int UN = 32;
     for (int e0 = tid; e0 < total; e0 += UN * CHOLP_THREADS) {
       double v[UN];
 #pragma unroll
@@ -1559,32 +1568,51 @@ __global__ __launch_bounds__(CHOLP_THREADS) void k_cholp_panel(int ns, int kt0, 
     }
   }
   __syncthreads();
+  CHOLP_STAMP(0)
+  if (wave == 0) chol_tile_factor_noinv(P, dinv, min(CT, ns - c0), c0, lane, badcol);
+  __syncthreads();
+  CHOLP_STAMP(1)
   for (int kk = 0; kk < wt; ++kk) {
-    double* Dk = P + (size_t)(kk * wt + kk) * CTS;
-    if (wave == 0) chol_tile_factor_noinv(Dk, dinv + kk * CT, min(CT, ns - (c0 + CT * kk)), c0 + CT * kk, lane, badcol);
-    __syncthreads();
-    // tiles below the diagonal: X = A L_kk^-T (four per wavefront); the last wave first inverts the diagonal tile
-    if (wave == NW - 1) chol_tile_invert(Dk, dinv + kk * CT, Xi + (size_t)kk * CTS, lane);
+    double* Dk = P + (size_t)(kk * wt + kk) * CTS;       // (factored: by the line above or by the look-ahead of step kk - 1)
+    // tiles below the diagonal: X = A L_kk^-T (four per wavefront)
     for (int b0 = kk + 1 + 4 * wave; b0 < nbr; b0 += 4 * NW) {
       const int bl = b0 + lg;
       chol_panel_solve4(Dk, dinv + kk * CT, bl < nbr ? P + (size_t)(bl * wt + kk) * CTS : nullptr, li);
     }
     __syncthreads();
-    // remaining tile columns of the panel: C(bl, bj) -= X(bl, kk) X(bj, kk)^T for kk < bj < wt, bl >= bj
+    CHOLP_STAMP(2)
+    // remaining tile columns of the panel: C(bl, bj) -= X(bl, kk) X(bj, kk)^T for kk < bj < wt, bl >= bj.  Tile 0 of the
+    // enumeration is the next diagonal tile: wave 0 updates it and factors it at once (look-ahead) while the other waves
+    // share the rest.
     {
       const int ncol = wt - kk - 1;
       int nt = 0;
       for (int q = 0; q < ncol; ++q) nt += nbr - (kk + 1 + q);
-      for (int tt = wave; tt < nt; tt += NW) {
-        int q = 0, rem = tt;
-        while (rem >= nbr - (kk + 1 + q)) { rem -= nbr - (kk + 1 + q); ++q; }
-        const int bj = kk + 1 + q, bl = bj + rem;
-        chol_tile_syrk(P + (size_t)(bl * wt + kk) * CTS, P + (size_t)(bj * wt + kk) * CTS, P + (size_t)(bl * wt + bj) * CTS, li, lg);
+      if (wave == 0) {
+        if (nt > 0) {
+          const int b1 = kk + 1;
+          double* D1 = P + (size_t)(b1 * wt + b1) * CTS;
+          const double* X1 = P + (size_t)(b1 * wt + kk) * CTS;
+          chol_tile_syrk(X1, X1, D1, li, lg);
+          lds_fence();
+          const int ncol1 = min(CT, ns - (c0 + CT * b1));
+          if (ncol1 > 0) chol_tile_factor_noinv(D1, dinv + b1 * CT, ncol1, c0 + CT * b1, lane, badcol);
+        }
+      } else {
+        for (int tt = wave; tt < nt; tt += NW - 1) {
+          int q = 0, rem = tt;
+          while (rem >= nbr - (kk + 1 + q)) { rem -= nbr - (kk + 1 + q); ++q; }
+          const int bj = kk + 1 + q, bl = bj + rem;
+          chol_tile_syrk(P + (size_t)(bl * wt + kk) * CTS, P + (size_t)(bj * wt + kk) * CTS, P + (size_t)(bl * wt + bj) * CTS, li, lg);
+        }
       }
     }
     __syncthreads();
+    CHOLP_STAMP(3)
   }
-  // ---- store the factor (lower triangle incl. the right-hand-side row) and the inverted diagonal tiles -----------------
+  // ---- store the factor (lower triangle incl. the right-hand-side row); while those stores are in flight the diagonal tiles
+  // are inverted for the back substitution, one wavefront per tile (inverting tile kk inside step kk put 3 k cycles of one
+  // wave in front of every panel solve; inverting before the store added 4.6 k cycles per panel to the critical path)
   {
     const int total = nbr * wt * CT * CT;
     for (int e = tid; e < total; e += CHOLP_THREADS) {
@@ -1592,13 +1620,23 @@ __global__ __launch_bounds__(CHOLP_THREADS) void k_cholp_panel(int ns, int kt0, 
       const int gi = c0 + CT * bl + r, gj = c0 + CT * kk + c;
       if (gi < n1 && gj < ns && gj <= gi) buf[(size_t)gi * ns + gj] = P[(size_t)tile * CTS + r * CTL + c];
     }
-    for (int e = tid; e < wt * CT * CT; e += CHOLP_THREADS) {
-      const int kk = e >> 8, r = (e >> 4) & 15, c = e & 15;
-      Linv[(size_t)(kt0 + kk) * CT * CT + r * CT + c] = Xi[(size_t)kk * CTS + r * CTL + c];
-    }
+  }
+  CHOLP_STAMP(5)
+  if (wave < wt) chol_tile_invert(P + (size_t)(wave * wt + wave) * CTS, dinv + wave * CT, Xi + (size_t)wave * CTS, lane);
+  __syncthreads();
+  CHOLP_STAMP(4)
+  for (int e = tid; e < wt * CT * CT; e += CHOLP_THREADS) {
+    const int kk = e >> 8, r = (e >> 4) & 15, c = e & 15;
+    Linv[(size_t)(kt0 + kk) * CT * CT + r * CT + c] = Xi[(size_t)kk * CTS + r * CTL + c];
   }
   // first non-positive pivot (1-based; 0 = none): the first panel initialises the report, later ones only add to it
   if (tid == 0 && (kt0 == 0 || (badcol != 0 && info[0] == 0))) info[0] = badcol;
+  if (prof) {
+    __syncthreads();
+    if (tid == 0)
+      for (int i = 0; i < 6; ++i) prof[i] += tp[i];   // (panels run one after the other: plain accumulation)
+  }
+#undef CHOLP_STAMP
 }
 
 // trailing update behind the panel [kt0, kt0 + wt): one wavefront per tile (bi, bj), bj <= bi, both >= kt0 + wt
@@ -1638,42 +1676,91 @@ __global__ __launch_bounds__(256) void k_cholp_trail(int ns, int kt0, int wt, do
   }
 }
 
-// p = L^-T y: y = row ns of the factored matrix; Linv = inverted diagonal tiles
-__global__ __launch_bounds__(1024) void k_cholp_back(int ns, const double* __restrict__ buf, const double* __restrict__ Linv,
-                                                     double* __restrict__ ps) {
-  __shared__ double yv[1024 + CT], pv[CT];
+// p = L^-T y: y = row ns of the factored matrix; Linv = inverted diagonal tiles.  ONE workgroup of 512 threads, thread t owns
+// columns t (and t + 512: NCOL = 2 for ns > 512).  A step of the blocked back substitution is a 16 x 16 mat-vec with the
+// stored inverse (wave 0) and a rank-16 update of the entries above by all threads; everything it reads from memory -- the
+// inverse of the NEXT tile and the next row block of L -- is requested a step ahead into the other half of a register
+// ping-pong (the step loop is unrolled by two, no copies), so that no global round trip sits between two steps.  (First
+// version: both waited for in every step, 40 us for the 18 steps of ns = 286; a 1024-thread version with the same
+// prefetch spilled its 128-register budget and took 143 us.)
+constexpr int CHOLP_BACK_THREADS = 512;
+// DEPTH: steps whose inverse tile / row block of L are in flight at any time (a ring of register sets; the step loop is
+// unrolled by DEPTH so that the ring index is a compile-time constant).  One step ahead was not enough: the factor was
+// written by other compute units (other XCDs), so every request is a ~2 us round trip to memory, ten times the ~0.2 us of
+// a step -- 41.8 us at ns = 286 with DEPTH = 2, whatever the order of the instructions.
+// Wave 0 owns the tile solves (its ring slots hold the inverse tiles), waves 1 .. 7 own the columns (their slots hold the row
+// blocks of L): ONE register ring serves both roles -- two rings side by side did not fit the register file.
+constexpr int CHOLP_BACK_COLS = CHOLP_BACK_THREADS - 64;   // columns per pass of the column waves
+template <int NCOL, int DEPTH>
+__global__ __launch_bounds__(CHOLP_BACK_THREADS) void k_cholp_back(int ns, const double* __restrict__ buf,
+                                                                    const double* __restrict__ Linv, double* __restrict__ ps) {
+  __shared__ double yv[NCOL * CHOLP_BACK_COLS + 2 * CT], pv[CT], pall[NCOL * CHOLP_BACK_COLS + 2 * CT];
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 15;
+  const bool solver = tid < 64;
+  const int col0 = tid - 64;                                 // first column of a column thread
   const int nbc = (ns + CT - 1) / CT;
-  for (int e = tid; e < nbc * CT; e += 1024) yv[e] = e < ns ? buf[(size_t)ns * ns + e] : 0.0;
-  __syncthreads();
-  for (int kb = nbc - 1; kb >= 0; --kb) {
-    // row block kb of L for the update that follows the tile solve: requested first (column e of the block, 16 rows)
-    double lt[CT];
+  for (int e = tid; e < nbc * CT; e += CHOLP_BACK_THREADS) yv[e] = e < ns ? buf[(size_t)ns * ns + e] : 0.0;
+  double ring[DEPTH][NCOL][CT];
+  auto fetch = [&](int kb, auto slot) {
+    constexpr int S = decltype(slot)::value;
+    // RAW loads from clamped (always valid) addresses: whatever does not belong to the step is masked when the slot is
+    // USED.  (masked_load multiplies the loaded value by its 0 / 1 mask at once -- an ALU instruction that has to wait for
+    // the data: the "prefetch" of the first version was a synchronous load.)
+    const int kc = max(kb, 0);
+    if (solver) {   // inverse of tile kb, column li
 #pragma unroll
-    for (int r = 0; r < CT; ++r) {
-      const int gi = CT * kb + r;
-      lt[r] = masked_load(buf, (size_t)gi * ns + tid, tid < CT * kb && gi < ns);
+      for (int i = 0; i < CT; ++i) ring[S][0][i] = Linv[(size_t)kc * CT * CT + i * CT + li];
+    } else {        // row block kb of L, the thread's columns
+#pragma unroll
+      for (int q = 0; q < NCOL; ++q) {
+        const int col = min(col0 + q * CHOLP_BACK_COLS, ns - 1);
+#pragma unroll
+        for (int r = 0; r < CT; ++r) ring[S][q][r] = buf[(size_t)min(CT * kc + r, ns - 1) * ns + col];
+      }
     }
-    if (tid < 64) {   // p_k = L_kk^-T z_k (the strict upper part of the stored inverse is zero)
-      const double* Xi = Linv + (size_t)kb * CT * CT;
+  };
+  auto step = [&](int kb, auto slot) {
+    constexpr int S = decltype(slot)::value;
+    if (solver) {          // p_k = L_kk^-T z_k (the strict upper part of the stored inverse is zero)
       double sp[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int i = 0; i < CT; ++i) sp[i & 3] += Xi[i * CT + li] * yv[CT * kb + i];
+      for (int i = 0; i < CT; ++i) sp[i & 3] += ring[S][0][i] * yv[CT * kb + i];
       const double sum = (sp[0] + sp[1]) + (sp[2] + sp[3]);
       if (lane < CT) {
         pv[li] = sum;
-        if (CT * kb + li < ns) ps[CT * kb + li] = sum;
+        pall[CT * kb + li] = sum;   // (written to memory once, after the last step: a global store in front of the barrier
+      }                             //  made the solver wave wait for its ~2 us write round trip in EVERY step)
+    }
+    __syncthreads();
+    if (!solver) {
+#pragma unroll
+      for (int q = 0; q < NCOL; ++q) {
+        const int col = col0 + q * CHOLP_BACK_COLS;
+        if (col < CT * kb) {
+          double sp[4] = {yv[col], 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int r = 0; r < CT; ++r) sp[r & 3] -= (CT * kb + r < ns ? ring[S][q][r] : 0.0) * pv[r];   // (rows behind the matrix)
+          yv[col] = (sp[0] + sp[1]) + (sp[2] + sp[3]);
+        }
       }
     }
+    fetch(kb - DEPTH, slot);   // the slot is free again: request the step DEPTH behind this one
     __syncthreads();
-    if (tid < CT * kb) {
-      double sp[4] = {yv[tid], 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int r = 0; r < CT; ++r) sp[r & 3] -= lt[r] * pv[r];
-      yv[tid] = (sp[0] + sp[1]) + (sp[2] + sp[3]);
-    }
-    __syncthreads();
+  };
+  // fill the ring: steps nbc - 1 .. nbc - DEPTH
+  if constexpr (DEPTH >= 1) fetch(nbc - 1, std::integral_constant<int, 0>());
+  if constexpr (DEPTH >= 2) fetch(nbc - 2, std::integral_constant<int, 1 % DEPTH>());
+  if constexpr (DEPTH >= 3) fetch(nbc - 3, std::integral_constant<int, 2 % DEPTH>());
+  if constexpr (DEPTH >= 4) fetch(nbc - 4, std::integral_constant<int, 3 % DEPTH>());
+  static_assert(DEPTH >= 1 && DEPTH <= 4, "ring depth");
+  __syncthreads();
+  for (int kb = nbc - 1; kb >= 0; kb -= DEPTH) {
+    step(kb, std::integral_constant<int, 0>());
+    if constexpr (DEPTH >= 2) { if (kb - 1 >= 0) step(kb - 1, std::integral_constant<int, 1 % DEPTH>()); }
+    if constexpr (DEPTH >= 3) { if (kb - 2 >= 0) step(kb - 2, std::integral_constant<int, 2 % DEPTH>()); }
+    if constexpr (DEPTH >= 4) { if (kb - 3 >= 0) step(kb - 3, std::integral_constant<int, 3 % DEPTH>()); }
   }
+  for (int e = tid; e < ns; e += CHOLP_BACK_THREADS) ps[e] = pall[e];
 }
 
 // ---------------------------------------------------------------------------------------------------------------

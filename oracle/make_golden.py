@@ -113,7 +113,9 @@ FULL_CASES = {
   "cfg4_full": "cfg4",     # 16 x 1000 x 5
   "cfg5_full": "cfg5",     # 6 x 400 x 5 fisheye hand-eye
 }
-N_PERT = 10           # perturbed re-runs per reference call (oracle/make_pert.py widened the older fixtures to the same 10)
+N_PERT = int(os.environ.get("MCBA_GOLDEN_NPERT", "10"))   # perturbed re-runs per reference call (oracle/make_pert.py widened the older
+                                                          # fixtures to the same 10; the 160-pair rig keeps 3: 44 reference solves of
+                                                          # 138 k residuals are hours)
 PERT_SIGMA = 1e-12    # px
 
 
@@ -372,6 +374,35 @@ def run_big_case(name):
         f"in {out['seconds']:.0f} s -> {path} ({os.path.getsize(path) / 1024:.0f} KiB)", flush=True)
 
 
+def run_mixed_case(name="tiny_mixed"):
+  """Cameras of DIFFERENT distortion models in one rig.  Every reference object accepts that (a ParamList of independent
+  Camera objects, optimization/parameters.py:54-85) and `evaluate` / `reprojection_error` work, but `bundle_adjust` does
+  not: Calibration.sparsity_matrix reshapes the cameras block to [n_cameras, -1] (calibration.py:179), which raises for a
+  ragged block.  The fixture pins what the reference CAN compute -- x0, r0, err0, rms0, a dense 2-point Jacobian of its
+  `evaluate` -- and records the exception of its bundle_adjust."""
+  from scipy.optimize._numdiff import approx_derivative
+  rig = synthetic.make_rig(name)
+  rig.name = name
+  calib, ref = build_reference.reference_calibration(rig)
+  error_stats = ref.optimization_calibration.error_stats
+  out = synthetic.rig_to_arrays(rig)
+  x0 = calib.param_vec
+  r0 = _evaluate(calib, x0)
+  out["x0"], out["r0"], out["inliers0"] = x0, r0, calib.inliers
+  out["err0"] = calib.reprojection_error
+  out["rms0"] = error_stats(out["err0"]).rms
+  out["J_dense"] = approx_derivative(lambda v: _evaluate(calib, v), x0, method='2-point', f0=r0)
+  try:
+    calib.bundle_adjust()
+    out["ba_error"] = np.array("")
+  except Exception as e:   # noqa: BLE001 -- the point of the fixture
+    out["ba_error"] = np.array(f"{type(e).__name__}: {e}")
+  path = os.path.join(GOLDEN_DIR, f"{name}.npz")
+  np.savez_compressed(path, **out)
+  print(f"{name}: n={x0.size} m={r0.size} rms0={float(out['rms0']):.4f} reference bundle_adjust -> {str(out['ba_error'])!r} "
+        f"-> {path} ({os.path.getsize(path) / 1024:.0f} KiB)", flush=True)
+
+
 def full_case_points(x0, seed=7):
   """The seeded perturbed point x1 and direction v of the full-size goldens (shared with the tests)."""
   rng = np.random.default_rng(seed)
@@ -421,7 +452,9 @@ def run_full_case(name):
 def main(argv):
   names = argv or list(CASES)
   for n in names:
-    if n in FULL_CASES:
+    if n == "tiny_mixed":
+      run_mixed_case(n)
+    elif n in FULL_CASES:
       run_full_case(n)
     elif n in BIG_CASES:
       run_big_case(n)
