@@ -547,12 +547,12 @@ void launch_linearize(mcba_handle_s* h, const double* dx) {
   // (dx given) or from the tail of the k_vec_step that produced the point (dx == nullptr); k_linearize copies its view's
   // four pose entries from the table and forms the chain products / That columns itself.  Not with adjusted board points
   // (k_points reads the per-view chain table that only k_tmat / k_views write).
-  // Default policy (MCBA_FUSED unset): the table-fed fused form whenever the tables already hold the point (dx == nullptr:
-  // the speculative linearisation behind a trial step -- k_tmat would only re-derive what the kernel can form itself:
-  // LM iteration 235 -> 228 us at the north-star rig), and for rigs with many views per frame, where k_tmat's per-view table
-  // pass is the larger cost (16 x 1000 x 5: evaluation 180 -> 147 us, k_tmat 48 us against +7.5 us in k_linearize).  The
-  // table form otherwise (8 x 500 x 2: 73.7 against 74.3 us per evaluation).
-  const bool auto_fused = getenv("MCBA_FUSED") == nullptr && (dx == nullptr || d.C * d.B >= 32);
+  // DEFAULT (MCBA_FUSED unset).  Measured on MI355X, evaluation step / LM iteration in us, table form -> table-fed fused
+  // form: 8 x 500 x 2 rolling 73.6 -> 71.4 / 233 -> 225, 16 x 1000 x 5 181 -> 147 / 529 -> 481, 4 x 200 x 1 33.7 -> 31.9 /
+  // 123 -> 117 -- although k_linearize itself grows (44.5 -> 47.3 us at the north-star rig: the chain products and That
+  // columns are now inside it), the k_tmat launch, its That table (10 MB written + read per evaluation) and, behind a trial
+  // step, any table kernel at all are gone.  MCBA_FUSED=0 forces the table form (k_tmat).
+  const bool auto_fused = getenv("MCBA_FUSED") == nullptr;
   if ((fused_mode == 2 || auto_fused) && h->use_mfma && d.off_boards < 0 && h->t.dbg == nullptr) {
     if (dx != nullptr) eval_pose_tables(h, dx);
     h->ops->linearize(d, h->t, h->stream, h->rec.p, h->tri.p, true, h->lin_grid, nullptr, h->gbuf.p, 2 * d.n + 2, h->Hss.p,
@@ -586,9 +586,10 @@ void launch_assemble(mcba_handle_s* h) {
   // (clamped to what a workgroup may ask for by default: 64 KB of dynamic LDS minus the kernel's static tables)
   static const int stage_kb = getenv("MCBA_ASM_STAGE_KB") ? std::min(60, std::max(4, atoi(getenv("MCBA_ASM_STAGE_KB")))) : 44;
   const int ne = frame_entries(d), cb = d.C * d.B;
-  const int ngroups = nfb ? (cb * ne * 8 + stage_kb * 1024 - 1) / (stage_kb * 1024) : 1;
-  const int gviews = (cb + ngroups - 1) / ngroups;
-  const size_t lds = nfb ? (size_t)gviews * ne * sizeof(double) + (size_t)ne * sizeof(int) + (size_t)((cb + 7) / 8 * 8) : 0;
+  // staging slots: as many non-empty views of a frame as the budget holds (all C B when they fit); a frame with more active
+  // views than slots takes several passes
+  const int gviews = nfb ? std::max(1, std::min(cb, stage_kb * 1024 / (ne * 8))) : 1;
+  const size_t lds = nfb ? (size_t)gviews * ne * sizeof(double) + (size_t)ne * sizeof(int) + 2 * (size_t)((cb + 3) & ~3) * sizeof(uint16_t) + 16 : 0;
   // (timed apart at cfg3: frame blocks alone 10.0 us, chunk sums alone 6.9 us, together 12.4 us)
   hipLaunchKernelGGL(k_assemble, dim3(nfb + d.C * d.B * h->nchunk), dim3(ASM_THREADS), lds, h->stream, d, h->t, h->rec.p, nfb, h->nchunk, gviews,
                      h->ftab.p, h->nftab, h->Hff.p, h->Hfs.p, h->g(), h->diag(), h->partial.p);
@@ -1651,6 +1652,27 @@ int32_t mcba_debug_dispatch_probe(int32_t blocks, int32_t threads, int32_t lds_b
   API_END
 }
 
+// debug: cycles ONE workgroup needs to read n doubles that workgroup `region` of the preceding kernel wrote (8 writer workgroups:
+// region 0 shares the reader's XCD if the dispatcher starts every kernel on XCD 0); out[r] for r = 0 .. 7, then out[8] = the
+// same region read a second time (warm in the reader's own caches)
+int32_t mcba_debug_xcd_probe(int32_t n, long long* out) {
+  API_BEGIN
+  REQUIRE(out && n > 0 && n <= (1 << 22), "bad argument");
+  DevBuf<double> buf, sink;
+  DevBuf<long long> cyc;
+  buf.alloc((size_t)8 * n, false);
+  sink.alloc(512);
+  cyc.alloc(16);
+  for (int rep = 0; rep < 2; ++rep)
+    for (int r = 0; r < 9; ++r) {
+      if (r < 8) hipLaunchKernelGGL(k_xcd_write, dim3(8), dim3(256), 0, 0, buf.p, n);
+      hipLaunchKernelGGL(k_xcd_read, dim3(1), dim3(512), 0, 0, (const double*)buf.p, n, r < 8 ? r : 7, sink.p, cyc.p + r);
+    }
+  HIP_OK(hipDeviceSynchronize());
+  HIP_OK(hipMemcpy(out, cyc.p, 9 * sizeof(long long), hipMemcpyDeviceToHost));
+  API_END
+}
+
 // debug: FP64 VALU / FP64 MFMA pipe-sharing probe (k_pipe_probe); ms_out[3] = milliseconds of modes 0, 1, 2
 int32_t mcba_debug_pipe_probe(int32_t iters, double* ms_out) {
   API_BEGIN
@@ -2031,7 +2053,7 @@ int32_t mcba_time_linearize(mcba_handle h, const double* x, const mcba_options* 
     if (h->use_mfma && d.ND != 14 && d.off_boards < 0 && fused_mode == 1)
       h->ops->linearize(d, h->t, h->stream, h->rec.p, h->tri.p, true, h->lin_grid, h->x.p, h->gbuf.p, 2 * d.n + 2, h->Hss.p,
                         d.ns * d.ns);
-    else if (h->use_mfma && d.off_boards < 0 && (fused_mode == 2 || (getenv("MCBA_FUSED") == nullptr && d.C * d.B >= 32)))
+    else if (h->use_mfma && d.off_boards < 0 && (fused_mode == 2 || getenv("MCBA_FUSED") == nullptr))
       h->ops->linearize(d, h->t, h->stream, h->rec.p, h->tri.p, true, h->lin_grid, nullptr, h->gbuf.p, 2 * d.n + 2, h->Hss.p,
                         d.ns * d.ns);
     else

@@ -17,6 +17,7 @@ int32_t mcba_debug_pipe_probe(int32_t iters, double* ms_out);
 /* workgroup dispatch rate: launches `blocks` workgroups of `threads` threads with `lds_bytes` of LDS, each running `spin`
  * dependent FMAs; out[blocks][2] = 100 MHz wall-clock ticks at the start / end of every workgroup                   */
 int32_t mcba_debug_dispatch_probe(int32_t blocks, int32_t threads, int32_t lds_bytes, int32_t spin, long long* out);
+int32_t mcba_debug_xcd_probe(int32_t n, long long* out);
 /* regularised Gauss-Newton direction (H_h + reg I)^-1 g_h in the column-scaled space, computed by the Schur /
  * Cholesky kernels after a preceding mcba_normal_equations at the same x; g_h and scale_inv may be NULL.           */
 int32_t mcba_debug_gn_step(mcba_handle h, double reg, double* gn_h, double* g_h, double* scale_inv);

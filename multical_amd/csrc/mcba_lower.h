@@ -148,7 +148,7 @@ inline void lower_dims(const mcba_problem* p, HostProblem& hp) {
   MCBA_REQUIRE(p->motion != MCBA_MOTION_HAND_EYE || p->base_wrt_gripper, "hand-eye motion needs base_wrt_gripper");
   MCBA_REQUIRE(p->optimize != 0, "no parameter block enabled");
   MCBA_REQUIRE(p->n_points <= 65535, "boards with more than 65535 points are not supported (16-bit point lists)");
-  MCBA_REQUIRE((int64_t)p->n_cameras * p->n_boards < (1 << 24), "too many (camera, board) pairs");
+  MCBA_REQUIRE((int64_t)p->n_cameras * p->n_boards < 65535, "more than 65534 (camera, board) pairs are not supported (16-bit view ranks)");
   if (p->camera_model == MCBA_CAMERA_FISHEYE)
     MCBA_REQUIRE(p->n_dist == 4, "fisheye cameras carry 4 distortion coefficients (camera_fisheye.py:113-117)");
   else

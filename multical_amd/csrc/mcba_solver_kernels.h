@@ -240,14 +240,33 @@ __device__ __forceinline__ void assemble_frame_block(const Dims& d, const Tables
                                                      const double* __restrict__ rec, double* __restrict__ Hff,
                                                      double* __restrict__ Hfs, double* __restrict__ g,
                                                      double* __restrict__ diag, double* __restrict__ stage) {
+  // `gviews` = staging SLOTS.  Only the frame's NON-EMPTY views are staged, compactly: slot[view] = rank of the view among
+  // the frame's active views (0xFFFF = empty).  A rig with many views per frame stages one group as long as the active views
+  // of the frame fit the slots (16 x 1000 x 5: 80 views per frame, about a third of them active -- staging a slot for every
+  // view took three barrier-separated groups per frame: 57 us); a frame with more active views than slots takes several
+  // passes over slot ranges.
   const int f = d.f0 + fl;
   const int DF = d.DF, ns = d.ns, N1 = d.N1, CB = d.C * d.B;
   const int base2 = tri_index(6, 6, N1), NE = frame_entries(d), P1 = 6 * DF;
   int* soff = reinterpret_cast<int*>(stage + (size_t)gviews * NE);   // record offset of staged entry k
-  uint8_t* act = reinterpret_cast<uint8_t*>(soff + NE);              // [C B] view has inliers
+  uint16_t* slot = reinterpret_cast<uint16_t*>(soff + NE);            // [C B] staging rank of a view, 0xFFFF = empty
+  uint16_t* vlist = slot + ((CB + 3) & ~3);                           // [C B] active views in rank order
+  __shared__ int n_act_s;
   double* hfs = Hfs + (size_t)fl * DF * ns;
   double* hff = Hff + (size_t)fl * DF * DF;
-  for (int e = threadIdx.x; e < CB; e += blockDim.x) act[e] = t.view_count[fl * CB + e] != 0;
+  if (threadIdx.x < 64) {   // ranks of the active views: ballot prefix over chunks of 64 views (first wavefront)
+    int basec = 0;
+    for (int e0 = 0; e0 < CB; e0 += 64) {
+      const int e = e0 + (int)threadIdx.x;
+      const bool on = e < CB && t.view_count[fl * CB + e] != 0;
+      const unsigned long long m = __ballot(on);
+      const int rk = basec + __popcll(m & ((1ull << threadIdx.x) - 1ull));
+      if (e < CB) slot[e] = on ? (uint16_t)rk : (uint16_t)0xFFFF;
+      if (on) vlist[rk] = (uint16_t)e;
+      basec += __popcll(m);
+    }
+    if (threadIdx.x == 0) n_act_s = basec;
+  }
   for (int k = threadIdx.x; k < NE; k += blockDim.x) soff[k] = k < P1 ? tri_index(k / DF, 6 + k % DF, N1) : base2 + (k - P1);
   for (int e = threadIdx.x; e < DF * ns; e += blockDim.x) hfs[e] = 0.0;
   const double* rf = rec + (size_t)fl * CB * d.rec_stride;   // records of this frame: view (c, b) at (c B + b) rec_stride
@@ -259,9 +278,11 @@ __device__ __forceinline__ void assemble_frame_block(const Dims& d, const Tables
     const int e = threadIdx.x + u * blockDim.x;
     q0[u] = e < ntab ? tab[e] : make_int4(0, 0, 0, -1);
   }
-  for (int g0 = 0; g0 < CB; g0 += gviews) {   // (one group at the north-star rig; more only when C B NE exceeds the LDS budget)
-    const int ng = min(gviews, CB - g0), tot = ng * NE;
-    __syncthreads();   // (act, soff, the zeroes of H_fs written; previous group consumed)
+  __syncthreads();   // (slot, vlist, n_act_s, soff, the zeroes of H_fs written)
+  const int n_act = n_act_s;
+  for (int s0 = 0; s0 == 0 || s0 < n_act; s0 += gviews) {   // (one pass unless the frame has more active views than slots)
+    const int ng = min(gviews, n_act - s0), tot = max(ng, 0) * NE;
+    if (s0 > 0) __syncthreads();   // (previous pass consumed)
     for (int i0 = threadIdx.x; i0 < tot; i0 += LB * blockDim.x) {
       double val[LB];
 #pragma unroll
@@ -271,7 +292,7 @@ __device__ __forceinline__ void assemble_frame_block(const Dims& d, const Tables
         if (idx < tot) {
           int gv = (int)((float)idx * inv_ne), k = idx - gv * NE;   // idx = gv NE + k (float quotient, corrected)
           if (k < 0) { --gv; k += NE; } else if (k >= NE) { ++gv; k -= NE; }
-          if (act[g0 + gv]) val[u] = rf[(size_t)(g0 + gv) * d.rec_stride + soff[k]];
+          val[u] = rf[(size_t)vlist[s0 + gv] * d.rec_stride + soff[k]];
         }
       }
 #pragma unroll
@@ -281,7 +302,7 @@ __device__ __forceinline__ void assemble_frame_block(const Dims& d, const Tables
       }
     }
     __syncthreads();
-    // every output element belongs to one thread for all groups: later groups add to what the thread stored before
+    // every output element belongs to one thread for all passes: later passes add to what the thread stored before
     for (int e0 = threadIdx.x; e0 < ntab; e0 += TB * blockDim.x) {
       int4 q[TB];
 #pragma unroll
@@ -292,23 +313,23 @@ __device__ __forceinline__ void assemble_frame_block(const Dims& d, const Tables
 #pragma unroll
       for (int u = 0; u < TB; ++u) {
         if (q[u].w < 0) continue;
-        const int k = q[u].x, gv0 = (q[u].y & 0xFFFFFF) - g0, gst = ((q[u].y >> 24) & 1) ? d.B : 1;
+        const int k = q[u].x, gv0 = q[u].y & 0xFFFFFF, gst = ((q[u].y >> 24) & 1) ? d.B : 1;
         const int csel = q[u].y >> 25, cnt = csel == FT_CNT_B ? d.B : (csel == FT_CNT_C ? d.C : CB);
-        double s0 = 0.0, s1 = 0.0;
+        double s0a = 0.0, s1a = 0.0;
         int i = 0;
         for (; i + 2 <= cnt; i += 2) {
-          const int ga = gv0 + i * gst, gb = ga + gst;
-          if (ga >= 0 && ga < ng) s0 += stage[ga * NE + k];
-          if (gb >= 0 && gb < ng) s1 += stage[gb * NE + k];
+          const int ra = (int)slot[gv0 + i * gst] - s0, rb = (int)slot[gv0 + (i + 1) * gst] - s0;   // (0xFFFF - s0 >= ng)
+          if (ra >= 0 && ra < ng) s0a += stage[ra * NE + k];
+          if (rb >= 0 && rb < ng) s1a += stage[rb * NE + k];
         }
         if (i < cnt) {
-          const int ga = gv0 + i * gst;
-          if (ga >= 0 && ga < ng) s0 += stage[ga * NE + k];
+          const int ra = (int)slot[gv0 + i * gst] - s0;
+          if (ra >= 0 && ra < ng) s0a += stage[ra * NE + k];
         }
-        double sum = s0 + s1;
+        double sum = s0a + s1a;
         const int kind = q[u].w & 255;
         double* dst = kind == FT_HFS ? hfs + q[u].z : (kind == FT_HFF ? hff + q[u].z : g + d.frame_to_x(f, q[u].z));
-        if (g0 > 0) sum += *dst;
+        if (s0 > 0) sum += *dst;
         *dst = sum;
         if ((q[u].w >> 8) != 0) diag[d.frame_to_x(f, (q[u].w >> 8) - 1)] = sum;
       }
@@ -398,7 +419,7 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(Dims d, Tables t, cons
                                                   double* __restrict__ Hff, double* __restrict__ Hfs,
                                                   double* __restrict__ g, double* __restrict__ diag,
                                                   double* __restrict__ partial) {
-  extern __shared__ double asm_stage[];   // [gviews][NE] staged record entries of a frame block + [NE] record offsets
+  extern __shared__ double asm_stage[];   // [slots][NE] staged record entries of a frame block + [NE] record offsets + view ranks
   if ((int)blockIdx.x < nfb) {
     assemble_frame_block(d, t, blockIdx.x, gviews, ftab, nftab, rec, Hff, Hfs, g, diag, asm_stage);
   } else {
@@ -1543,27 +1564,33 @@ __global__ __launch_bounds__(CHOLP_THREADS) void k_cholp_panel(int ns, int kt0, 
   long long tp[6] = {0, 0, 0, 0, 0, 0}, tc = 0;   // phase stamps (prof != nullptr): load, first factor, solve, trailing, invert, store
   if (prof) tc = clock64();
 #define CHOLP_STAMP(i) if (prof) { const long long now = clock64(); tp[i] += now - tc; tc = now; }
-  // ---- load: rows of 16 doubles (128 B) per 16 threads; outside the matrix the identity continues it -----------------
+  // ---- load: a wavefront per tile (tile indices are wave-uniform: no per-element index arithmetic -- the first version
+  // spent 15-19 k cycles per panel here, three times what the memory system needs for 117 KB, on integer divisions), lane
+  // (r = lane / 4, c4 = lane % 4) reads four consecutive entries of row r; the loads of up to eight tiles are in flight
+  // per wavefront.  Outside the matrix the identity continues it; the upper triangle is not read.
   {
-    const int total = nbr * wt * CT * CT;
-    // the panel comes from memory other compute units (other XCDs) have just written: ~3 us per dependent round trip.  32
-    // loads per thread cover the largest panel the LDS holds (150 KB = 19.2 k entries / 512 threads = 37.5) in two batches
-    // and every panel of ns <= 286 in ONE (measured with 8 per batch: 15 k cycles of load per panel, half of its arithmetic)
-    constexpr int UN = 32;
-    for (int e0 = tid; e0 < total; e0 += UN * CHOLP_THREADS) {
-      double v[UN];
+    const int ntl = nbr * wt, r = lane >> 2, c4 = (lane & 3) * 4;
+    constexpr int TB = 8;
+    for (int t0 = wave; t0 < ntl; t0 += TB * NW) {
+      double v[TB][4];
 #pragma unroll
-      for (int u = 0; u < UN; ++u) {
-        const int e = e0 + u * CHOLP_THREADS;
-        const int tile = e >> 8, r = (e >> 4) & 15, c = e & 15, bl = tile / wt, kk = tile - bl * wt;
-        const int gi = c0 + CT * bl + r, gj = c0 + CT * kk + c;
-        const bool in = e < total && gi < n1 && gj < ns && gj <= gi;
-        v[u] = masked_load(buf, (size_t)gi * ns + gj, in) + (in ? (gi == gj ? reg : 0.0) : (gi == gj ? 1.0 : 0.0));
+      for (int u = 0; u < TB; ++u) {
+        const int tile = t0 + u * NW, tc = tile < ntl ? tile : 0, bl = tc / wt, kk = tc - bl * wt;
+        const int gi = c0 + CT * bl + r, gj0 = c0 + CT * kk + c4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int gj = gj0 + q;
+          const bool in = tile < ntl && gi < n1 && gj < ns && gj <= gi;
+          v[u][q] = masked_load(buf, (size_t)gi * ns + gj, in) + (in ? (gi == gj ? reg : 0.0) : (gi == gj ? 1.0 : 0.0));
+        }
       }
 #pragma unroll
-      for (int u = 0; u < UN; ++u) {
-        const int e = e0 + u * CHOLP_THREADS;
-        if (e < total) P[(size_t)(e >> 8) * CTS + ((e >> 4) & 15) * CTL + (e & 15)] = v[u];
+      for (int u = 0; u < TB; ++u) {
+        const int tile = t0 + u * NW;
+        if (tile < ntl) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) P[(size_t)tile * CTS + r * CTL + c4 + q] = v[u][q];
+        }
       }
     }
   }
@@ -1614,11 +1641,16 @@ __global__ __launch_bounds__(CHOLP_THREADS) void k_cholp_panel(int ns, int kt0, 
   // are inverted for the back substitution, one wavefront per tile (inverting tile kk inside step kk put 3 k cycles of one
   // wave in front of every panel solve; inverting before the store added 4.6 k cycles per panel to the critical path)
   {
-    const int total = nbr * wt * CT * CT;
-    for (int e = tid; e < total; e += CHOLP_THREADS) {
-      const int tile = e >> 8, r = (e >> 4) & 15, c = e & 15, bl = tile / wt, kk = tile - bl * wt;
-      const int gi = c0 + CT * bl + r, gj = c0 + CT * kk + c;
-      if (gi < n1 && gj < ns && gj <= gi) buf[(size_t)gi * ns + gj] = P[(size_t)tile * CTS + r * CTL + c];
+    const int ntl = nbr * wt, r = lane >> 2, c4 = (lane & 3) * 4;
+    for (int tile = wave; tile < ntl; tile += NW) {
+      const int bl = tile / wt, kk = tile - bl * wt;
+      if (bl < kk) continue;                                   // (above the diagonal)
+      const int gi = c0 + CT * bl + r, gj0 = c0 + CT * kk + c4;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int gj = gj0 + q;
+        if (gi < n1 && gj < ns && gj <= gi) buf[(size_t)gi * ns + gj] = P[(size_t)tile * CTS + r * CTL + c4 + q];
+      }
     }
   }
   CHOLP_STAMP(5)
@@ -2539,6 +2571,30 @@ __global__ void k_mfma_probe(const double* __restrict__ V /*[4][32]*/, double* _
 // MFMA loop.  If the two kinds of work shared nothing, mode 2 would take as long as one wave alone per SIMD (half of
 // modes 0 / 1); if FP64 MFMA and FP64 VALU share the pipe, mode 2 takes the sum.
 // workgroup dispatch probe: every workgroup records the 100 MHz wall clock when it starts and after `spin` dependent FMAs
+// debug: does data written by workgroup w of one kernel stay in the L2 of w's XCD for the next kernel?  k_xcd_write: workgroup
+// b fills region b (n doubles); k_xcd_read: ONE workgroup sums region `region` with 16 loads in flight per thread and reports
+// its shader-clock cycles.  Workgroups are handed to the XCDs round-robin, so workgroup 0 of both kernels shares an XCD.
+__global__ void k_xcd_write(double* __restrict__ buf, int n) {
+  double* p = buf + (size_t)blockIdx.x * n;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = (double)(i + blockIdx.x);
+}
+__global__ __launch_bounds__(512) void k_xcd_read(const double* __restrict__ buf, int n, int region, double* __restrict__ sink,
+                                                  long long* __restrict__ cycles) {
+  const double* p = buf + (size_t)region * n;
+  const long long t0 = clock64();
+  double acc = 0.0;
+  for (int i0 = threadIdx.x; i0 < n; i0 += 16 * 512) {
+    double v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = p[min(i0 + u * 512, n - 1)];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc += v[u];
+  }
+  sink[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) cycles[0] = clock64() - t0;
+}
+
 __global__ void k_dispatch_probe(int spin, long long* __restrict__ out) {
   extern __shared__ double probe_lds[];
   const long long t0 = wall_clock64();

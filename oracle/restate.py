@@ -431,3 +431,31 @@ def from_rig(rig, which='init'):
                              world_wrt_base=he.world_wrt_base, gripper_wrt_camera=he.gripper_wrt_camera)
   return OracleCalibration(cams, rig.board_points, rig.points, rig.valid, src.camera_poses, rig.camera_valid,
                            src.board_poses, rig.board_valid, motion, optimize=rig.optimize)
+
+
+# ---- interface/view_table.py (the numeric part of the GUI's reprojection tables) -------------------------
+VIEW_TABLE_AXES = dict(overall=None, views=(2, 3), board_views=(3,), boards=(0, 1, 3), cameras=(1, 2, 3), frames=(0, 2, 3))
+
+
+def reprojection_tables(calib, inlier_only=False):
+  """view_table.py:19-52: error of `projected` (NOT `reprojected`: no measured scan time) against the point table, reduced
+  per axis: detected, outliers, mse, rms and the five quantiles (nanquantile over the masked errors)."""
+  proj, pvalid = calib.projected()
+  valid = calib.inliers if inlier_only else calib.point_valid
+  valid = pvalid & valid                                                      # tables.py:244-249
+  error = np.linalg.norm(proj - calib.points, axis=-1)
+  error[~valid] = 0
+  out = {}
+  for k, axis in VIEW_TABLE_AXES.items():
+    n = valid.sum(axis=axis)
+    mse = np.square(error).sum(axis=axis) / np.maximum(n, 1)
+    e = error.copy()
+    e[~valid] = np.nan
+    with np.errstate(all='ignore'):
+      import warnings
+      with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        q = np.nanquantile(e, [0, 0.25, 0.5, 0.75, 1.0], axis=axis)
+    out[k] = dict(detected=n, outliers=(valid & ~calib.inliers).sum(axis=axis), mse=mse, rms=np.sqrt(mse), min=q[0],
+                  lower_q=q[1], median=q[2], upper_q=q[3], max=q[4])
+  return out

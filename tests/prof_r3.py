@@ -33,7 +33,8 @@ with Handle(c) as h:
   for rep in range(3):
     t0 = time.perf_counter(); res = h.solve(x1, tolerance=1e-15, xtol=1e-15, gtol=1e-15, max_iterations=41); dt = time.perf_counter() - t0
     ts.append(dt / max(res.nfev - 1, 1) * 1e6)
-  out["lm_iter_us"] = sorted(ts)[1]; out["nfev"] = res.nfev; out["cost"] = res.cost
+  out["lm_iter_us"] = sorted(ts)[1]; out["nfev"] = res.nfev; out["njev"] = res.njev; out["cost"] = res.cost
+  out["lm_lin_us"] = sorted(ts)[1] * max(res.nfev - 1, 1) / max(res.njev, 1)
   t0 = time.perf_counter(); res = h.solve(x0); out["solve_ms"] = (time.perf_counter() - t0) * 1e3; out["solve_nfev"] = res.nfev
   out["solve_cost"] = res.cost
 print("RESULT" + json.dumps(out))
@@ -57,8 +58,8 @@ def main():
         print(cfg, var, "FAILED", p.stderr[-1500:], flush=True)
         continue
       r = json.loads(line[0][6:])
-      print(f"{cfg:6s} {var:40s} step {r['step_us']:8.2f} us  k_linearize {r['lin_us']:7.2f} us  LM iteration {r['lm_iter_us']:8.1f} us "
-            f"(nfev {r['nfev']}, cost {r['cost']:.9e})  default solve {r['solve_ms']:.2f} ms nfev {r['solve_nfev']} cost {r['solve_cost']:.9e}", flush=True)
+      print(f"{cfg:6s} {var:40s} step {r['step_us']:8.2f} us  k_linearize {r['lin_us']:7.2f} us  LM trial step {r['lm_iter_us']:8.1f} us, per linearisation {r['lm_lin_us']:8.1f} us "
+            f"(nfev {r['nfev']}, njev {r['njev']}, cost {r['cost']:.9e})  default solve {r['solve_ms']:.2f} ms nfev {r['solve_nfev']} cost {r['solve_cost']:.9e}", flush=True)
 
 if __name__ == "__main__":
   main()

@@ -570,15 +570,16 @@ def test_handle_cache_sees_a_changed_validity_mask_and_float32_tables():
     assert np.abs(cm.residuals() - ocm.evaluate(cm.param_vec)).max() < 1e-9
 
 
-@pytest.mark.parametrize("switch", ["MCBA_FUSED=1", "MCBA_FUSED=2", "MCBA_ASM_STAGE_KB=4", "MCBA_TMAT_GLOBAL=1",
+@pytest.mark.parametrize("switch", ["MCBA_FUSED=0", "MCBA_FUSED=1", "MCBA_ASM_STAGE_KB=4", "MCBA_FUSED=0,MCBA_TMAT_GLOBAL=1",
                                     "MCBA_NCHUNK_TARGET=1024", "MCBA_SHARED_FINAL_BIG=1"])
 def test_alternative_linearisation_paths_match_the_default(switch):
   """Paths of the evaluation that the fixtures do not reach by themselves, each forced with its switch in a subprocess
   (the switches are read once per process); all must reproduce the normal equations of the default form to round-off,
   for every motion model, and the same solve:
-    MCBA_FUSED=1              k_linearize forms That / the chain matrices / the intrinsics straight from x (no k_tmat)
-    MCBA_FUSED=2              table-fed fused form: pose entries from the pose table (k_prep / k_vec_step), chains and That
+    (default)                 table-fed fused form: pose entries from the pose table (k_prep / k_vec_step), chains and That
                               in k_linearize (no k_tmat, no That table)
+    MCBA_FUSED=0              table form: k_tmat writes That and the chain matrices of every view, k_linearize reads them
+    MCBA_FUSED=1              k_linearize forms That / the chain matrices / the intrinsics straight from x (no table kernel)
     MCBA_SHARED_FINAL_BIG=1   the final sum of the shared part for rigs with more than 128 (camera, board) pairs
     MCBA_ASM_STAGE_KB=4       frame blocks of k_assemble stage their records in several groups (rigs with many views per frame)
     MCBA_TMAT_GLOBAL=1        k_tmat reads the global pose table (rigs whose cameras + boards exceed the local table)
@@ -602,9 +603,9 @@ print("RESULT" + json.dumps(out))
 '''
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
   res = {}
-  key, val = switch.split("=")
-  base = {k: v for k, v in os.environ.items() if k != key}
-  for fused, env in (("0", base), ("1", dict(base, **{key: val}))):
+  sw = dict(kv.split("=") for kv in switch.split(","))
+  base = {k: v for k, v in os.environ.items() if k not in sw}
+  for fused, env in (("0", base), ("1", dict(base, **sw))):
     p = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     res[fused] = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT")][0][6:])
@@ -637,6 +638,31 @@ def test_projected_matches_the_oracle(name):
       assert np.abs(h.project_model(g["x0"], max_iterations=0) - oracle(rig).projected(max_iterations=0)[0])[valid].max() < 1e-9
   tab = c.projected
   assert np.array_equal(tab.valid, valid) and np.abs(tab.points - want)[seen].max() < 1e-9
+
+
+@pytest.mark.parametrize("name", ["tiny_rolling", "tiny_edge", "tiny_handeye"])
+def test_reprojection_tables_consumer(name):
+  """the GUI's reprojection tables (interface/view_table.py:43-52) built from the back-end's `projected`
+  (mcba_project_model) and the inlier mask after an outlier round: per overall / view / board-view / board / camera /
+  frame the detected and outlier counts are identical, mse / rms / quantiles within 1e-9 px of the oracle's tables."""
+  import warnings
+  from multical_amd import view_table
+  g, rig = load_golden(name)
+  c = mirror(rig)
+  c = c.reject_outliers_quantile(0.75, 5.0) if hasattr(c, "reject_outliers_quantile") else c
+  oc = oracle(rig).copy(inlier_mask=c.inliers)
+  for inlier_only in (False, True):
+    with warnings.catch_warnings():
+      warnings.simplefilter("ignore")                      # (all-NaN slices of views without detections)
+      got = view_table.reprojection_tables(c, inlier_only=inlier_only)
+    want = restate.reprojection_tables(oc, inlier_only=inlier_only)
+    for axis_name, w in want.items():
+      t = got[axis_name]
+      assert np.array_equal(t.detected, w["detected"]) and np.array_equal(t.outliers, w["outliers"]), axis_name
+      for k in ("mse", "rms", "min", "lower_q", "median", "upper_q", "max"):
+        a, b = np.asarray(t[k], dtype=np.float64), np.asarray(w[k], dtype=np.float64)
+        assert np.array_equal(np.isnan(a), np.isnan(b)), (axis_name, k)
+        assert np.nanmax(np.abs(a - b), initial=0.0) < 1e-9 * max(1.0, np.nanmax(np.abs(b), initial=0.0)), (axis_name, k)
 
 
 @pytest.mark.parametrize("name,frames,seed", [("tiny_rolling", None, 5), ("tiny_fisheye", None, 6), ("cfg4", 12, 5),

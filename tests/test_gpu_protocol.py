@@ -34,7 +34,7 @@ pytestmark = pytest.mark.gpu
 
 PROTOCOL_CASES = ["tiny", "tiny_rolling", "tiny_fisheye", "tiny_handeye", "tiny_rational", "tiny_thin_prism",
                   "tiny_tilted", "tiny_edge", "tiny_fixintr", "tiny_pin4", "cfg1", "tiny_softl1", "tiny_huber",
-                  "tiny_boards"]
+                  "tiny_boards", "tiny_bigboard"]
 # fixtures whose reference end point is reproducible to better than 1e-6 px (spread < 3e-7): plain 1e-6 assertion
 WELL_DEFINED = ["tiny_handeye", "tiny_fixintr", "cfg1", "tiny_huber"]
 # over-parameterised distortion models on 8 frames: a flat valley that neither the reference's own tight polish nor any
@@ -238,9 +238,10 @@ def load_big(name):
   return g, rig
 
 
-@pytest.mark.parametrize("name", ["cfg2", "cfg3_40", "cfg4_40", "cfg5_40"])
+@pytest.mark.parametrize("name", ["cfg2", "cfg3_40", "cfg4_40", "cfg5_40", "manypairs"])
 def test_baseline_configs_against_reference_trajectories(name):
-  """BASELINE configs[1] at full size (4 x 200, 84 s per reference solve) and configs[2..4] at 40 frames: residuals at the
+  """BASELINE configs[1] at full size (4 x 200, 84 s per reference solve), configs[2..4] at 40 frames and the 16-camera x
+  10-board rig (160 (camera, board) pairs: the many-pairs path of the shared assembly): residuals at the
   start point, the bundle adjustment from the start point, and Workspace.calibrate's complete outlier loop against the
   unmodified reference: identical inlier masks after three rounds; final RMS (all / inliers) within 1e-6 px of the
   converged optimum of the reference's residual function and within the reference's own spread of its end point."""
