@@ -319,6 +319,10 @@ struct mcba_handle_s {
   void* log_ctx = nullptr;
 
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fetch = nullptr;
+  // side stream of the trust-region driver: the trial cost (k_cost + the scalar copy) of a single-GPU solve runs beside the
+  // speculative linearisation of the same point instead of in front of it
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_side = nullptr;
   // captured evaluation (MCBA_GRAPH=1): the launch sequence of one residual+Jacobian evaluation as a hipGraph
   hipGraphExec_t eval_graph = nullptr;
   const double* eval_graph_x = nullptr;
@@ -334,6 +338,8 @@ struct mcba_handle_s {
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     if (ev_fetch) (void)hipEventDestroy(ev_fetch);
+    if (ev_side) (void)hipEventDestroy(ev_side);
+    if (stream2) (void)hipStreamDestroy(stream2);
     if (eval_graph) (void)hipGraphExecDestroy(eval_graph);
     if (rccl_comm) destroy_rccl_comm(rccl_comm);
     if (own_stream && stream && !(g_park_on_release && resource_cache().park_stream(stream))) (void)hipStreamDestroy(stream);
@@ -1127,6 +1133,8 @@ int32_t mcba_create(const mcba_problem* p, void* hip_stream, mcba_handle* out) {
   HIP_OK(hipEventCreate(&h->ev0));
   HIP_OK(hipEventCreate(&h->ev1));
   HIP_OK(hipEventCreateWithFlags(&h->ev_fetch, hipEventDisableTiming));
+  HIP_OK(hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming));
+  HIP_OK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
   {   // the tables of the initial point: the camera table's constant part (image height, fix_aspect) and the board points
       // when they are not optimised are only ever written here (the fused k_linearize reads them, nothing refreshes them)
     for (int j = 0; j < d.nfull; ++j)
@@ -1800,16 +1808,29 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
       // (the fold of the k_vec_scale / k_q00 partials and the damping: head of the first kernel of the solve)
       const TrRegPartials trp{h->scal.p + sl.vs, sl.nvb, h->scal.p + sl.q00p, h->allreduce ? 1 : Q00_BLOCKS, first ? 1 : 0, Delta};
       launch_gn_solve(h, 0.0, is_root, h->scal.p + sl.dotp, h->scal.p, &trp);
-      enqueue_trial(0.0, 0.0, h->scal.p, !merged_trial_cost);
-      if (!merged_trial_cost) fetch_scalars_begin(h, trial_fetch_end);
+      // Single GPU, table-fed fused linearisation: the trial cost and the speculative linearisation both only READ the tables
+      // that the tail of k_vec_step wrote, so k_cost + the scalar copy go to a side stream and run BESIDE k_linearize (13 us
+      // of every iteration's critical path at the north-star rig); the host still decides on the trial cost alone.
+      const bool spec_tables_ready = (linearize_fused_mode() == 2 || getenv("MCBA_FUSED") == nullptr) && d.off_boards < 0 && h->use_mfma;
+      static const bool side_off = getenv("MCBA_NO_SIDE_COST") != nullptr && getenv("MCBA_NO_SIDE_COST")[0] == '1';
+      const bool side_cost = !h->allreduce && spec_tables_ready && !side_off;
+      enqueue_trial(0.0, 0.0, h->scal.p, !merged_trial_cost && !side_cost);
+      if (side_cost) {
+        HIP_OK(hipEventRecord(h->ev_side, h->stream));
+        HIP_OK(hipStreamWaitEvent(h->stream2, h->ev_side, 0));
+        h->ops->cost(d, h->t, h->stream2, h->scal.p + sl.costp, cost_grid);
+        HIP_OK(hipMemcpyAsync(h->h_scal, h->scal.p, trial_fetch_end * sizeof(double), hipMemcpyDeviceToHost, h->stream2));
+        HIP_OK(hipEventRecord(h->ev_fetch, h->stream2));
+      } else if (!merged_trial_cost) {
+        fetch_scalars_begin(h, trial_fetch_end);
+      }
       // Speculation: most trial steps are accepted, so the linearisation at x_new is enqueued right behind the copy and
       // runs while the host looks at the trial cost and prepares the next iteration.  A rejected step leaves the
       // records / H / g of x_new behind (lin_stale): they are not needed by the retries with a smaller radius, and
       // are rebuilt before anything reads them again.
       // (fused form: straight from x_new; table form: k_tmat re-derives its entries; table-fed fused form: the tail of
       //  k_vec_step has just written the pose / camera tables of x_new -- no table kernel at all)
-      timed_linearize((linearize_fused_mode() == 2 || getenv("MCBA_FUSED") == nullptr) && d.off_boards < 0 && h->use_mfma
-                          ? nullptr : h->xnew.p);
+      timed_linearize(spec_tables_ready ? nullptr : h->xnew.p);
       spec_lin = true;
       if (merged_trial_cost) {      // the cost of x_new arrived with the linearisation's all-reduced [g | diag | cost]
         HIP_OK(hipMemcpyAsync(h->scal.p + sl.costp, h->costcount(), sizeof(double), hipMemcpyDeviceToDevice, h->stream));

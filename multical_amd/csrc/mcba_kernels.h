@@ -781,14 +781,26 @@ void k_linearize(Dims d, Tables t, double* __restrict__ rec,
     static_assert(NPB * POSE_STRIDE <= BUF, "pose entries do not fit the staging buffer");
     double* Pl = Buf;                      // (the staging buffer is free until the first chunk)
     if constexpr (!from_x) {
+      // the pose entries are requested with the front loads (same round trip as the mask bytes); then the masks are
+      // compacted and the FIRST CHUNK's observations / board points are requested, and only then the chain products and That
+      // columns are formed -- under that round trip instead of in front of it
+      constexpr int NPE = (NPB * POSE_STRIDE + 63) / 64;
+      double pe_f[NPE];
 #pragma unroll
-      for (int u = 0; u < (NPB * POSE_STRIDE + 63) / 64; ++u) {
+      for (int u = 0; u < NPE; ++u) {
         const int e = min(pl + 64 * u, NPB * POSE_STRIDE - 1), k = e / POSE_STRIDE, q = e - k * POSE_STRIDE;
         const int gi = k == 0 ? d.pose_cam + c
                      : (k == NPB - 1 ? d.pose_board + b
                                      : d.pose_motion + (MOTION == MOTION_STATIC ? f : (MOTION == MOTION_ROLLING ? (k - 1) * d.F + f : k - 1)));
-        Pl[e] = t.pose[(size_t)gi * POSE_STRIDE + q];
+        pe_f[u] = t.pose[(size_t)gi * POSE_STRIDE + q];
       }
+      count = front_finish(cur, pl);
+      lds_fence();
+      p_cur = lane < count ? pidx[lane] : 0;
+      ob_cur = t.obs[(size_t)v * d.P + p_cur];
+      for (int k = 0; k < 3; ++k) X_cur[k] = t.board_points[3 * (size_t)(b * d.P + p_cur) + k];
+#pragma unroll
+      for (int u = 0; u < NPE; ++u) Pl[min(pl + 64 * u, NPB * POSE_STRIDE - 1)] = pe_f[u];
     } else {
      if (pl < NPB) {
       int oa, of, r;
@@ -856,7 +868,9 @@ void k_linearize(Dims d, Tables t, double* __restrict__ rec,
     for (int e = lane; e < ROWS * (LDV - NV); e += 64) Vbuf[(e / (LDV - NV)) * LDV + NV + e % (LDV - NV)] = 0.0;
 
   if (prof) stamp[5] = clock64();
-  if (!front_ready) count = front_finish(cur, pl);
+  if constexpr (FUSED_MODE != 2) {   // (the table-fed fused form has compacted its masks above)
+    if (!front_ready) count = front_finish(cur, pl);
+  }
 
   constexpr int NACC_V = NVP * NVP / 64;                  // plain-FMA variant: NVP*NVP entries over 64 lanes
   constexpr int NTILE = TAILV ? 2 : NT * (NT + 1) / 2;   // shifted tile: two accumulators (even / odd steps), no dependent MFMAs
@@ -894,7 +908,7 @@ void k_linearize(Dims d, Tables t, double* __restrict__ rec,
 
   // software prefetch: observation + board point of the NEXT chunk are requested before the current one is processed
   // (the first chunk of a pipelined view was requested from the middle of the previous epilogue)
-  if (!front_ready) {
+  if (FUSED_MODE != 2 && !front_ready) {   // (table-fed fused form: requested before the chain arithmetic)
     p_cur = lane < count ? pidx[lane] : 0;
     ob_cur = t.obs[(size_t)v * d.P + p_cur];
     for (int k = 0; k < 3; ++k) X_cur[k] = t.board_points[3 * (size_t)(b * d.P + p_cur) + k];
