@@ -1390,7 +1390,7 @@ int32_t mcba_align_poses_robust(int32_t n_problems, const int64_t* offsets, cons
     REQUIRE(offsets[p + 1] >= offsets[p], "offsets must be non-decreasing");
     nmax = std::max<int64_t>(nmax, offsets[p + 1] - offsets[p]);
   }
-  REQUIRE(offsets[0] == 0 && total >= 0 && nmax < (1 << 24), "bad offsets");
+  REQUIRE(offsets[0] == 0 && total >= 0 && nmax <= 64 * ALIGN_THREADS, "bad offsets (at most 65536 entries per problem)");
   hipStream_t st = nullptr;
   HIP_OK(hipStreamCreate(&st));
   struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } guard{st};
@@ -1414,28 +1414,66 @@ int32_t mcba_align_poses_robust(int32_t n_problems, const int64_t* offsets, cons
   d_out.alloc(16 * (size_t)n_problems, false);
   d_valid.alloc((size_t)n_problems, false);
   d_inl.alloc(tot, false);
-  // per-problem scratch: 14 doubles + 6 ints per entry, sized for the largest problem
+  // per-problem scratch: 14 doubles + 7 ints per entry, sized for the largest problem
   const size_t per = (size_t)nmax, np_ = (size_t)n_problems;
   d_f64.alloc(np_ * per * 14, false);
-  d_i32.alloc(np_ * per * 6, false);
+  d_i32.alloc(np_ * per * 7, false);
   AlignScratch sc;
   sc.vec = d_f64.p;
   sc.cen = sc.vec + np_ * per * 6;
   sc.err = sc.cen + np_ * per * 6;
   sc.hgt = sc.err + np_ * per;
+  sc.nd = sc.err;   // (nearest-neighbour distances of the clustering rounds: the error array is idle while a clustering runs)
   sc.size = d_i32.p;
   sc.chain = sc.size + np_ * per;
   sc.rep_a = sc.chain + np_ * per;
   sc.rep_b = sc.rep_a + np_ * per;
   sc.parent = sc.rep_b + np_ * per;
   sc.list = sc.parent + np_ * per;
-  hipLaunchKernelGGL(k_align_robust, dim3(n_problems), dim3(ALIGN_THREADS), 0, st, d_off.p, dA.p, dB.p,
+  sc.live = sc.list + np_ * per;
+  DevBuf<long long> d_prof;
+  static const bool align_prof = getenv("MCBA_ALIGN_PROF") != nullptr;
+  sc.prof = nullptr;
+  if (align_prof) {
+    d_prof.alloc(np_ * 32);
+    sc.prof = d_prof.p;
+  }
+  // dynamic LDS for the clustering state of problems with up to lds_cap selected entries (small batches of big problems get
+  // the full 125 KB; batches of many small problems only what their largest problem needs, so that several fit a CU)
+  // (a batch with a problem of more than ALIGN_LDS_CAP entries takes the full size: its error array -- 8 B per entry, up to
+  //  18 150 entries -- is ranked from LDS too)
+  const int lds_cap = (int)std::min<int64_t>(nmax, ALIGN_LDS_CAP);
+  const size_t lds = align_lds_bytes(lds_cap);
+  {
+    static std::mutex mtx;
+    static size_t lds_set = 0;
+    std::lock_guard<std::mutex> lock(mtx);
+    if (lds > lds_set) {
+      HIP_OK(hipFuncSetAttribute((const void*)k_align_robust, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      lds_set = lds;
+    }
+  }
+  hipLaunchKernelGGL(k_align_robust, dim3(n_problems), dim3(ALIGN_THREADS), lds, st, d_off.p, dA.p, dB.p,
                      (const uint8_t*)(mask ? d_mask.p : nullptr), threshold, (int)invert, (long long)per, sc, d_out.p,
-                     d_valid.p, d_inl.p);
+                     d_valid.p, d_inl.p, lds_cap);
+  check_launch("k_align_robust");
   HIP_OK(hipMemcpyAsync(out, d_out.p, 16 * (size_t)n_problems * sizeof(double), hipMemcpyDeviceToHost, st));
   HIP_OK(hipMemcpyAsync(out_valid, d_valid.p, (size_t)n_problems, hipMemcpyDeviceToHost, st));
   if (inliers && total > 0) HIP_OK(hipMemcpyAsync(inliers, d_inl.p, (size_t)total, hipMemcpyDeviceToHost, st));
   HIP_OK(hipStreamSynchronize(st));
+  if (align_prof) {   // phase cycles of the largest problem
+    std::vector<long long> hp(np_ * 32);
+    HIP_OK(hipMemcpy(hp.data(), d_prof.p, hp.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    int big = 0;
+    for (int p = 1; p < n_problems; ++p)
+      if (offsets[p + 1] - offsets[p] > offsets[big + 1] - offsets[big]) big = p;
+    const char* names[9] = {"compaction", "relative poses", "robust mean", "errors", "quantile + test", "  whitening", "  clustering",
+                            "  cut+labels+mean", "  rounds (count)"};
+    for (int pass = 0; pass < 2; ++pass)
+      for (int k = 0; k < 9; ++k)
+        fprintf(stderr, "[k_align_robust] problem %d (n = %lld) pass %d %-18s %10lld\n", big,
+                (long long)(offsets[big + 1] - offsets[big]), pass, names[k], hp[(size_t)big * 32 + 16 * pass + k]);
+  }
   API_END
 }
 

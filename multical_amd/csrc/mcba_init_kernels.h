@@ -8,14 +8,14 @@
 // used by tables.estimate_transform (tables.py:153-176: camera and board pairs of the overlap spanning tree, hundreds to
 // thousands of entries each) and tables.relative_between_n (tables.py:334-345: one small problem per frame).
 //
-// ONE WORKGROUP PER PROBLEM, all stages inside the kernel.  The Ward clustering is the nearest-neighbour-chain algorithm
-// scipy runs (scipy/cluster/_hierarchy.pyx: nn_chain), on cluster centroids and sizes instead of a condensed distance
-// matrix (for Ward the Lance-Williams recurrence equals d(A,B) = sqrt(2 nA nB / (nA + nB)) |cA - cB|): every nearest-
-// neighbour search is a parallel scan over the live clusters with scipy's tie rules (lowest index; the previous chain
-// element wins ties).  Cutting the dendrogram at `maxclust` = applying the n - t merges of smallest height (union-find on
-// representatives), the most common cluster is the largest component (ties: the one whose first member comes first).
-// Floating point is not bit-identical to scipy (different summation orders): the result agrees to ~1e-12 unless two
-// merge heights tie to the last bit.
+// ONE WORKGROUP PER PROBLEM, all stages inside the kernel.  The Ward clustering produces the dendrogram of the nearest-
+// neighbour-chain algorithm scipy runs (scipy/cluster/_hierarchy.pyx: nn_chain), on cluster centroids and sizes instead of a
+// condensed distance matrix (for Ward the Lance-Williams recurrence equals d(A,B) = sqrt(2 nA nB / (nA + nB)) |cA - cB|), by
+// rounds of PARALLEL reciprocal-nearest-neighbour merges (Ward is reducible: see robust_mean_block); the clustering state of
+// problems with up to ALIGN_LDS_CAP selected entries lives in LDS.  Cutting the dendrogram at `maxclust` = applying every merge
+// up to the threshold height (union-find on representatives), the most common cluster is the largest component (ties: the
+// one whose first member comes first).  Floating point is not bit-identical to scipy (different summation orders): the
+// result agrees to ~1e-12 unless two merge heights tie to the last bit.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "mcba_math.h"
@@ -23,18 +23,23 @@
 namespace mcba {
 
 constexpr int ALIGN_THREADS = 1024;   // the nearest-neighbour scans of the big pair problems (thousands of entries) set the pace
+constexpr int ALIGN_LDS_CAP = 1600;   // entries whose clustering state (8 doubles + 7 ints = 92 B) fits 147 KB of dynamic LDS
+__host__ __device__ inline size_t align_lds_bytes(int cap) { return (size_t)cap * (8 * sizeof(double) + 7 * sizeof(int)) + 16; }
 
 struct AlignScratch {        // per-problem device scratch, sized for the largest problem (n entries)
   double* vec;       // [n][6]  relative poses as rotation vector | translation (compacted)
   double* cen;       // [n][6]  whitened cluster centroids
   double* err;       // [n]     alignment errors of all entries
   double* hgt;       // [n]     merge heights
+  double* nd;        // [n]     distance to the nearest neighbour (clustering rounds); shares storage with err in memory
   int* size;         // [n]     cluster sizes (0 = dead)
   int* chain;        // [n]
   int* rep_a;        // [n]     representative members of the two merged clusters
   int* rep_b;        // [n]
   int* parent;       // [n]     union-find / labels
+  int* live;         // [n]     slots of the live clusters (clustering rounds)
   int* list;         // [n]     compacted entry indices
+  long long* prof;   // optional [problems][16] phase cycles (debug), else null
 };
 
 // ---- SE(3) helpers on row-major 4x4 ---------------------------------------------------------------------------------
@@ -111,24 +116,44 @@ __device__ __forceinline__ void block_argmin(double& v, int& idx, double* sv, in
 
 // robust mean of the n 6-vectors vec[0..n) (transform/common.py:6-21) -> out[6]; every thread of the block takes part
 __device__ void robust_mean_block(int n, const AlignScratch& s, double* out /* shared [6] */, double* sv, int* si,
-                                  int* s_int /* shared [4] */) {
+                                  int* s_int /* shared [4] */, long long* prof = nullptr /* [16] phase cycles of this pass */) {
+  long long tprof = prof ? clock64() : 0;
+#define RM_STAMP(k) if (prof != nullptr && threadIdx.x == 0) { const long long now = clock64(); prof[k] += now - tprof; tprof = now; }
   const int tid = threadIdx.x, nthr = blockDim.x;
   if (n == 1) {
     if (tid < 6) out[tid] = s.vec[tid];
     __syncthreads();
     return;
   }
-  __shared__ double stdv[6];
-  if (tid < 6) {     // scipy.cluster.vq.whiten: divide by the population standard deviation (zero -> 1)
-    double mean = 0.0;
-    for (int i = 0; i < n; ++i) mean += s.vec[6 * i + tid];
-    mean /= n;
-    double var = 0.0;
-    for (int i = 0; i < n; ++i) {
-      const double dlt = s.vec[6 * i + tid] - mean;
-      var += dlt * dlt;
+  // scipy.cluster.vq.whiten: divide by the population standard deviation (zero -> 1).  Column sums by all threads: thread t
+  // adds the rows t, t + nthr, ... of its column set in order, the per-thread partials are folded in a fixed tree (six
+  // threads walking n rows of memory one after the other took ~1.5 ms per thousand rows)
+  __shared__ double stdv[6], red6[6];
+  auto column_sums = [&](auto f) {   // red6[j] = sum over rows of f(row value of column j, j)
+    double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int i = tid; i < n; i += nthr)
+      for (int j = 0; j < 6; ++j) acc[j] += f(s.vec[6 * i + j], j);
+    for (int j = 0; j < 6; ++j) {
+      double v = acc[j];
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+      __syncthreads();
+      if ((tid & 63) == 0) sv[tid >> 6] = v;
+      __syncthreads();
+      if (tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < (nthr >> 6); ++w) t += sv[w];
+        red6[j] = t;
+      }
     }
-    const double sd = sqrt(var / n);
+    __syncthreads();
+  };
+  column_sums([](double v, int) { return v; });
+  double mean_j[6];
+  for (int j = 0; j < 6; ++j) mean_j[j] = red6[j] / n;
+  __syncthreads();
+  column_sums([&](double v, int j) { const double dlt = v - mean_j[j]; return dlt * dlt; });
+  if (tid < 6) {
+    const double sd = sqrt(red6[tid] / n);
     stdv[tid] = sd == 0.0 ? 1.0 : sd;
   }
   __syncthreads();
@@ -138,69 +163,115 @@ __device__ void robust_mean_block(int n, const AlignScratch& s, double* out /* s
     s.parent[i] = i;
   }
   __syncthreads();
+  RM_STAMP(5)
   const int t_clust = max((int)fmax((double)n / 10.0, 3.0), 1);   // fcluster(..., t = max(n / 10, 3)): int(t)
   if (t_clust < n) {
-    // ---- nearest-neighbour chain (scipy _hierarchy.nn_chain, method 'ward') ----------------------------------------
-    int chain_len = 0;
-    for (int k = 0; k < n - 1; ++k) {
-      if (chain_len == 0) {
-        // first live cluster
-        double fv = 0.0;
-        int fi = 0x7fffffff;
-        for (int i = tid; i < n; i += nthr)
-          if (s.size[i] > 0 && i < fi) fi = i;
-        fv = (double)fi;
-        block_argmin(fv, fi, sv, si);
-        if (tid == 0) s.chain[0] = fi;
-        chain_len = 1;
-        __syncthreads();
-      }
-      int x, y;
-      double dmin;
+    // ---- Ward linkage by PARALLEL RECIPROCAL-NEAREST-NEIGHBOUR rounds -------------------------------------------------
+    // scipy builds the dendrogram with the nearest-neighbour-chain algorithm (scipy/cluster/_hierarchy.pyx: nn_chain): ~3 n
+    // SEQUENTIAL nearest-neighbour searches, each a block-wide scan + argmin (round 2 ran exactly that: ~10 k cycles per
+    // search, 40 M cycles = 17 ms per clustering of 1300 relative poses, two clusterings per alignment -- profiled with
+    // -DMCBA_EXP_ALIGN_PROF).  Ward linkage is REDUCIBLE: merging a reciprocal nearest-neighbour pair never changes the
+    // nearest neighbours of the other clusters into something closer, so every RNN pair that exists at a time is a merge
+    // of the final dendrogram and all of them can be applied AT ONCE.  A round = every live cluster finds its nearest
+    // neighbour (thread per cluster, all threads scan the live centroids: n^2 / threads distance evaluations, throughput
+    // instead of latency), the reciprocal pairs merge in parallel (they are disjoint).  A constant fraction of the clusters
+    // merges per round on real data, so the work is ~2 n^2 distance evaluations in a few dozen barriers.  The tree, the slot
+    // that holds a merged cluster (the larger index), the centroid arithmetic and therefore every merge height are exactly
+    // those of the chain algorithm; only the ORDER in which the merges are recorded differs (atomic counter), which neither
+    // the threshold cut nor the union-find below depends on.  Distances are bit-symmetric (d(i, j) == d(j, i)), ties go to
+    // the lowest index: the closest pair with the smallest indices is always reciprocal, so every round merges something.
+    {
+      int* nn = s.chain;
+      double* nd = s.nd;
+      __shared__ int s_nm;
+      if (tid == 0) s_nm = 0;
+      __syncthreads();
+      int nm_prev = 0, rounds = 0;
+      __shared__ int s_nlive;
+      int* live = s.live;
       while (true) {
-        x = s.chain[chain_len - 1];
-        const int prev = chain_len > 1 ? s.chain[chain_len - 2] : -1;
-        double cx[6];
-        for (int j = 0; j < 6; ++j) cx[j] = s.cen[6 * x + j];
-        const double nx = (double)s.size[x];
-        auto ward = [&](int i) {
-          const double ni = (double)s.size[i];
-          double d2 = 0.0;
-          for (int j = 0; j < 6; ++j) {
-            const double dl = cx[j] - s.cen[6 * i + j];
-            d2 += dl * dl;
+        ++rounds;
+        // live clusters in ascending slot order (stable ballot compaction by the first wavefront): the scans below only visit
+        // them, so a round costs live^2 distance evaluations, not live x n
+        if (tid < 64) {
+          int c = 0;
+          for (int k0 = 0; k0 < n; k0 += 64) {
+            const int k = k0 + tid;
+            const bool on = k < n && s.size[k] > 0;
+            const unsigned long long m = __ballot(on);
+            if (on) live[c + __popcll(m & ((1ull << tid) - 1ull))] = k;
+            c += __popcll(m);
           }
-          return sqrt(2.0 * nx * ni / (nx + ni) * d2);
-        };
-        const double dprev = prev >= 0 ? ward(prev) : INFINITY;
-        double bv = INFINITY;
-        int bi = 0x7fffffff;
-        for (int i = tid; i < n; i += nthr) {
-          if (s.size[i] == 0 || i == x) continue;
-          const double dd = ward(i);
-          if (dd < bv) { bv = dd; bi = i; }      // (ascending i per thread: the first minimum)
+          if (tid == 0) s_nlive = c;
         }
-        block_argmin(bv, bi, sv, si);
-        if (prev >= 0 && !(bv < dprev)) { y = prev; dmin = dprev; } else { y = bi; dmin = bv; }   // previous element wins ties
-        if (prev >= 0 && y == prev) break;
-        if (tid == 0) s.chain[chain_len] = y;
-        ++chain_len;
         __syncthreads();
+        const int nlive = s_nlive;
+        for (int li = tid; li < nlive; li += nthr) {
+          const int i = live[li];
+          double cx[6];
+          for (int j = 0; j < 6; ++j) cx[j] = s.cen[6 * i + j];
+          const double nx = (double)s.size[i];
+          // the candidates are compared on  d^2 n_c / (n_x + n_c)  -- the Ward distance squared without the factor 2 n_x that
+          // is common to the scan: the same order as the distances (the square root and the factor are monotone), one division
+          // and no square root per candidate; the height sqrt(2 n_x n_c / (n_x + n_c) d^2) is formed once, for the winner,
+          // with the expression of the chain algorithm (bit-symmetric in the pair)
+          double bkey = INFINITY, bd2 = 0.0;
+          int bi = -1, bn = 1;
+          for (int lc = 0; lc < nlive; ++lc) {       // ascending slots: the first minimum is the lowest index
+            const int c = live[lc];
+            if (c == i) continue;
+            const int nci = s.size[c];
+            double d2 = 0.0;
+            for (int j = 0; j < 6; ++j) {
+              const double dl = cx[j] - s.cen[6 * c + j];
+              d2 += dl * dl;
+            }
+            const double ni = (double)nci, key = d2 * ni / (nx + ni);
+            if (key < bkey) { bkey = key; bi = c; bd2 = d2; bn = nci; }
+          }
+          nn[i] = bi;
+          const double ni = (double)bn;
+          nd[i] = sqrt(2.0 * nx * ni / (nx + ni) * bd2);
+        }
+        __syncthreads();
+        unsigned long long mrg = 0ull;               // reciprocal pairs owned by this thread (cluster i < its partner)
+        {
+          int q = 0;
+          for (int i = tid; i < n; i += nthr, ++q)
+            if (s.size[i] > 0) {
+              const int j = nn[i];
+              if (j > i && nn[j] == i) mrg |= 1ull << q;
+            }
+        }
+        __syncthreads();
+        {
+          int q = 0;
+          for (int i = tid; i < n; i += nthr, ++q)
+            if ((mrg >> q) & 1ull) {
+              const int j = nn[i], m = atomicAdd(&s_nm, 1);
+              const int nx = s.size[i], ny = s.size[j];
+              s.hgt[m] = nd[i];
+              s.rep_a[m] = i;      // slot indices double as representatives: slot j keeps holding the merged cluster, i dies;
+              s.rep_b[m] = j;      // a slot index is always a member of the cluster it holds (it is one of the original points)
+              for (int k = 0; k < 6; ++k)
+                s.cen[6 * j + k] = ((double)nx * s.cen[6 * i + k] + (double)ny * s.cen[6 * j + k]) / (double)(nx + ny);
+              s.size[j] = nx + ny;
+              s.size[i] = 0;
+            }
+        }
+        __syncthreads();
+        const int nm_now = s_nm;
+        // (no merge in a round can only happen with non-finite poses -- every comparison false: stop instead of spinning;
+        //  the heights left unset make the cut keep the remaining clusters apart)
+        if (nm_now >= n - 1 || nm_now == nm_prev) {
+          for (int m = nm_now + tid; m < n - 1; m += nthr) { s.hgt[m] = INFINITY; s.rep_a[m] = 0; s.rep_b[m] = 0; }
+          break;
+        }
+        nm_prev = nm_now;
       }
-      chain_len -= 2;
-      if (x > y) { const int tmp = x; x = y; y = tmp; }
       __syncthreads();
-      if (tid == 0) {
-        const int nx = s.size[x], ny = s.size[y];
-        s.hgt[k] = dmin;
-        s.rep_a[k] = x;       // slot indices double as representatives: slot y keeps holding the merged cluster, x dies;
-        s.rep_b[k] = y;       // a slot index is always a member of the cluster it holds (it is one of the original points)
-        for (int j = 0; j < 6; ++j)
-          s.cen[6 * y + j] = ((double)nx * s.cen[6 * x + j] + (double)ny * s.cen[6 * y + j]) / (double)(nx + ny);
-        s.size[y] = nx + ny;
-        s.size[x] = 0;
-      }
-      __syncthreads();
+      RM_STAMP(6)
+      if (prof != nullptr && tid == 0) prof[8] += rounds;
     }
     // ---- cut: scipy's fcluster(criterion='maxclust') finds the smallest merge height thr that leaves at most t_clust
     // clusters and then applies EVERY merge of height <= thr (cluster_maxclust_monocrit + cluster_monocrit: for a monotone
@@ -218,45 +289,70 @@ __device__ void robust_mean_block(int n, const AlignScratch& s, double* out /* s
       if (rank == keep - 1) sv[0] = hk;      // (ranks are a permutation: exactly one writer)
     }
     __syncthreads();
-    if (tid == 0) {
+    {
+      // Every slot dies at most once (a merge moves the cluster of the smaller slot into the larger one), so the applied
+      // merges form a forest of "dies into" links that can be written in parallel; the flat cluster of a point is the slot
+      // its links end in.  (The first version ran a union-find without path compression on ONE thread: 37 M cycles for
+      // 1300 points, more than the clustering itself.)
       const double thr = sv[0];
-      for (int k = 0; k < nm; ++k) {
-        if (!(s.hgt[k] <= thr)) continue;
-        int a = s.rep_a[k], b = s.rep_b[k];
-        while (s.parent[a] != a) a = s.parent[a];
-        while (s.parent[b] != b) b = s.parent[b];
-        if (a != b) s.parent[max(a, b)] = min(a, b);
-      }
+      for (int k = tid; k < nm; k += nthr)
+        if (s.hgt[k] <= thr) s.parent[s.rep_a[k]] = s.rep_b[k];
     }
     __syncthreads();
+    // pointer jumping: parent <- parent of parent, ceil(log2 n) + 1 rounds.  In place: a concurrent reader sees the old or the
+    // new link of another point -- both are ancestors on the same path, so the distance to the root still at least halves
+    // per round and the fixed point (every point linked to its final slot) does not depend on the interleaving.
+    for (int span = 1; span < 2 * n; span *= 2) {
+      for (int i = tid; i < n; i += nthr) s.parent[i] = s.parent[s.parent[i]];
+      __syncthreads();
+    }
   }
-  // labels = root of every point; component sizes; the most common cluster (ties: first encountered in index order)
+  // labels = final slot of every point; component sizes and smallest members; the most common cluster (ties: the cluster
+  // that is met first in index order, i.e. the one with the smallest member -- collections.Counter.most_common)
   for (int i = tid; i < n; i += nthr) {
-    int r = i;
-    while (s.parent[r] != r) r = s.parent[r];
-    s.list[i] = r;            // label = smallest member (roots are minima)
+    s.size[i] = 0;
+    s.chain[i] = 0x7fffffff;
   }
-  for (int i = tid; i < n; i += nthr) s.size[i] = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += nthr) {
+    const int r = s.parent[i];
+    s.list[i] = r;
+    atomicAdd(&s.size[r], 1);
+    atomicMin(&s.chain[r], i);
+  }
   __syncthreads();
   if (tid == 0) {
-    for (int i = 0; i < n; ++i) s.size[s.list[i]] += 1;
-    int best = -1, bestc = 0;
-    for (int i = 0; i < n; ++i) {          // first-encountered label in index order = its root (the smallest member)
-      const int c = s.size[i];
-      if (s.list[i] == i && c > bestc) { bestc = c; best = i; }
+    int best = -1, bestc = 0, bestm = 0x7fffffff;
+    for (int i = 0; i < n; ++i) {
+      const int c = s.size[i], mm = s.chain[i];
+      if (c > bestc || (c == bestc && c > 0 && mm < bestm)) { bestc = c; best = i; bestm = mm; }
     }
     s_int[0] = best;
     s_int[1] = bestc;
   }
   __syncthreads();
-  if (tid < 6) {      // numpy mean over axis 0: rows are added in index order
+  {                   // mean of the most common cluster (numpy adds the rows in index order; here: fixed tree, ~1e-16 apart)
     const int best = s_int[0];
-    double acc = 0.0;
-    for (int i = 0; i < n; ++i)
-      if (s.list[i] == best) acc += s.vec[6 * i + tid];
-    out[tid] = acc / (double)s_int[1];
+    double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int i = tid; i < n; i += nthr)
+      if (s.list[i] == best)
+        for (int j = 0; j < 6; ++j) acc[j] += s.vec[6 * i + j];
+    for (int j = 0; j < 6; ++j) {
+      double v = acc[j];
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+      __syncthreads();
+      if ((tid & 63) == 0) sv[tid >> 6] = v;
+      __syncthreads();
+      if (tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < (nthr >> 6); ++w) t += sv[w];
+        out[j] = t / (double)s_int[1];
+      }
+    }
   }
   __syncthreads();
+  RM_STAMP(7)
+#undef RM_STAMP
 }
 
 // rtvec -> 4x4 (rtvec.py:24-27)
@@ -274,7 +370,9 @@ __global__ __launch_bounds__(ALIGN_THREADS) void k_align_robust(const long long*
                                                                 const double* __restrict__ B, const uint8_t* __restrict__ mask,
                                                                 double threshold, int invert, long long scratch_stride,
                                                                 AlignScratch base, double* __restrict__ out,
-                                                                uint8_t* __restrict__ out_valid, uint8_t* __restrict__ inliers) {
+                                                                uint8_t* __restrict__ out_valid, uint8_t* __restrict__ inliers,
+                                                                int lds_cap) {
+  extern __shared__ __attribute__((aligned(16))) double align_lds[];   // [lds_cap][6] centroids | [lds_cap] sizes
   __shared__ double sv[ALIGN_THREADS / 64], mean6[6], Rm[9], tm[3];
   __shared__ int si[ALIGN_THREADS / 64], s_int[4], s_cnt;
   const int p = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
@@ -283,8 +381,8 @@ __global__ __launch_bounds__(ALIGN_THREADS) void k_align_robust(const long long*
   AlignScratch s = base;
   {
     const long long o = (long long)p * scratch_stride;
-    s.vec += 6 * o; s.cen += 6 * o; s.err += o; s.hgt += o; s.size += o; s.chain += o; s.rep_a += o; s.rep_b += o;
-    s.parent += o; s.list += o;
+    s.vec += 6 * o; s.cen += 6 * o; s.err += o; s.hgt += o; s.nd += o; s.size += o; s.chain += o; s.rep_a += o; s.rep_b += o;
+    s.parent += o; s.list += o; s.live += o;
   }
   const double* Ap = A + 16 * e0;
   const double* Bp = B + 16 * e0;
@@ -302,18 +400,29 @@ __global__ __launch_bounds__(ALIGN_THREADS) void k_align_robust(const long long*
       for (int i = 0; i < 3; ++i) tb[i] = ti[i];
     }
   };
+  // phase stamps (s.prof != nullptr: MCBA_ALIGN_PROF=1): prof[p][16 * pass + k], k = 0 compaction, 1 relative poses, 2 robust
+  // mean (whitening + clustering + cut + mean), 3 errors, 4 quantile + outlier test; robust_mean_block adds 5 whitening,
+  // 6 clustering rounds, 7 cut + labels + mean, 8 number of rounds
+  long long tprev = clock64();
+  int stamp_pass = 0;
+#define ALIGN_STAMP(k) if (s.prof != nullptr && tid == 0) { const long long now = clock64(); s.prof[(size_t)p * 32 + 16 * stamp_pass + (k)] += now - tprev; tprev = now; }
   // pass = 0: entries of the mask; pass = 1: inliers of the outlier test
   for (int pass = 0; pass < 2; ++pass) {
-    // ---- stable compaction of the selected entries (serial prefix by one thread: n is at most a few thousand) ------
-    if (tid == 0) {
+    // ---- stable compaction of the selected entries ---------------------------------------------------------------
+    if (tid < 64) {   // first wavefront: 64 entries per step, ranks from a ballot prefix (a one-thread loop took n dependent steps)
       int c = 0;
-      for (int k = 0; k < n; ++k) {
-        const bool sel = pass == 0 ? (mp == nullptr || mp[k] != 0) : (s.parent[k] != 0);   // (pass 1 reads the inlier flags)
-        if (sel) s.list[c++] = k;
+      for (int k0 = 0; k0 < n; k0 += 64) {
+        const int k = k0 + tid;
+        const bool sel = k < n && (pass == 0 ? (mp == nullptr || mp[k] != 0) : (s.parent[k] != 0));   // (pass 1: inlier flags)
+        const unsigned long long m = __ballot(sel);
+        if (sel) s.list[c + __popcll(m & ((1ull << tid) - 1ull))] = k;
+        c += __popcll(m);
       }
-      s_cnt = c;
+      if (tid == 0) s_cnt = c;
     }
     __syncthreads();
+    stamp_pass = pass;
+    ALIGN_STAMP(0)
     const int cnt = s_cnt;
     if (cnt == 0) {     // tables.relative_between: no common entry -> invalid pose (identity)
       if (tid < 16) out[16 * (size_t)p + tid] = (tid % 5 == 0) ? 1.0 : 0.0;
@@ -333,7 +442,28 @@ __global__ __launch_bounds__(ALIGN_THREADS) void k_align_robust(const long long*
       for (int j = 0; j < 3; ++j) { s.vec[6 * i + j] = w[j]; s.vec[6 * i + 3 + j] = tr3[j]; }
     }
     __syncthreads();
-    robust_mean_block(cnt, s, mean6, sv, si, s_int);
+    {
+      // The nearest-neighbour chain of the clustering reads centroids and sizes ~3 n times each, one dependent round trip
+      // per search when they live in memory (the chain is sequential: ~2.5 us per search, 30 ms for a 1400-entry pair
+      // problem).  Problems whose SELECTED entries fit the workgroup's dynamic LDS keep both there.
+      AlignScratch sl = s;
+      if (cnt <= lds_cap) {   // centroids, heights and every integer array of the clustering (the union-find and the label
+        sl.cen = align_lds;   // count are single-thread walks: at LDS latency instead of one memory round trip per step)
+        sl.hgt = align_lds + 6 * (size_t)lds_cap;
+        sl.nd = align_lds + 7 * (size_t)lds_cap;
+        int* ib = reinterpret_cast<int*>(align_lds + 8 * (size_t)lds_cap);
+        sl.size = ib;
+        sl.parent = ib + lds_cap;
+        sl.chain = ib + 2 * (size_t)lds_cap;
+        sl.rep_a = ib + 3 * (size_t)lds_cap;
+        sl.rep_b = ib + 4 * (size_t)lds_cap;
+        sl.list = ib + 5 * (size_t)lds_cap;     // (labels; the caller's entry list is rebuilt by the next pass)
+        sl.live = ib + 6 * (size_t)lds_cap;
+      }
+      ALIGN_STAMP(1)
+      robust_mean_block(cnt, sl, mean6, sv, si, s_int, s.prof ? s.prof + (size_t)p * 32 + 16 * pass : nullptr);
+      ALIGN_STAMP(2)
+    }
     if (tid == 0) rtvec_to_matrix4(mean6, Rm, tm);
     __syncthreads();
     if (pass == 1) break;
@@ -348,19 +478,40 @@ __global__ __launch_bounds__(ALIGN_THREADS) void k_align_robust(const long long*
       s.err[k] = sqrt(e2);
     }
     __syncthreads();
+    ALIGN_STAMP(3)
     {   // numpy quantile 0.75, method 'linear': virtual index (n - 1) * 0.75 between two order statistics
       const double virt = (double)(n - 1) * 0.75;
       const int lo = (int)floor(virt), hi = min(lo + 1, n - 1);
       const double gamma = virt - floor(virt);
-      for (int k = tid; k < n; k += nthr) {
-        const double ek = s.err[k];
-        int rank = 0;
-        for (int q = 0; q < n; ++q) {
-          const double eq = s.err[q];
-          rank += (eq < ek || (eq == ek && q < k)) ? 1 : 0;
+      // the two order statistics by RADIX SELECT on the bit patterns (errors are non-negative: the IEEE bits order like the
+      // values): eight 8-bit passes per statistic, a 256-bin histogram in LDS.  (Ranking every error against every other
+      // was n^2 = 2.6e8 comparisons on ONE compute unit for the 16 000 entries of a board pair: 82 M cycles, more than both
+      // clusterings together.)
+      __shared__ unsigned int r_hist[256];
+      __shared__ unsigned long long r_prefix;
+      __shared__ int r_rank;
+      for (int which = 0; which < 2; ++which) {
+        if (tid == 0) { r_prefix = 0ull; r_rank = which == 0 ? lo : hi; }
+        for (int shift = 56; shift >= 0; shift -= 8) {
+          if (tid < 256) r_hist[tid] = 0u;
+          __syncthreads();
+          const unsigned long long pre = r_prefix;
+          for (int k = tid; k < n; k += nthr) {
+            const unsigned long long key = (unsigned long long)__double_as_longlong(s.err[k]);
+            const bool match = shift == 56 || (key >> (shift + 8)) == (pre >> (shift + 8));
+            if (match) atomicAdd(&r_hist[(unsigned)(key >> shift) & 255u], 1u);
+          }
+          __syncthreads();
+          if (tid == 0) {
+            int r = r_rank, dgt = 0;
+            while (dgt < 255 && r >= (int)r_hist[dgt]) { r -= (int)r_hist[dgt]; ++dgt; }
+            r_rank = r;
+            r_prefix = pre | ((unsigned long long)dgt << shift);
+          }
+          __syncthreads();
         }
-        if (rank == lo) sv[0] = ek;            // (sv doubles as the hand-over of the two order statistics)
-        if (rank == hi) sv[1] = ek;
+        if (tid == 0) sv[which] = __longlong_as_double((long long)r_prefix);
+        __syncthreads();
       }
       __syncthreads();
       const double a = sv[0], b = sv[1], diff = b - a;
@@ -372,6 +523,7 @@ __global__ __launch_bounds__(ALIGN_THREADS) void k_align_robust(const long long*
         if (inliers != nullptr) inliers[e0 + k] = in ? 1 : 0;
       }
       __syncthreads();
+      ALIGN_STAMP(4)
     }
   }
   if (tid == 0) {

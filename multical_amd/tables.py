@@ -25,34 +25,55 @@ def _f64(a):
   return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
 
 
-def align_transforms_robust_batch(problems, threshold=1.5, invert=False):
-  """problems: list of (m1 [n,4,4], m2 [n,4,4], mask [n] bool or None).  Returns (transforms [P,4,4], valid [P] bool,
-  list of inlier masks) -- per problem exactly matrix.align_transforms_robust(m1, m2, valid=mask, threshold)
-  (invert=True: tables.relative_between_inv: inputs and result inverted)."""
+def align_transforms_robust_ragged(A, B, sizes, mask=None, threshold=1.5, invert=False):
+  """The device call on an already concatenated batch: A, B [total, 4, 4], sizes [P] entries per problem (in order), mask
+  [total] or None.  Returns (transforms [P,4,4], valid [P] bool, inlier flags [total] bool)."""
   lib = _lib.load()
-  P = len(problems)
+  sizes = np.asarray(sizes, dtype=np.int64).reshape(-1)
+  P = int(sizes.size)
   if P == 0:
-    return np.zeros((0, 4, 4)), np.zeros(0, dtype=bool), []
-  sizes = [int(np.asarray(p[0]).shape[0]) for p in problems]
+    return np.zeros((0, 4, 4)), np.zeros(0, dtype=bool), np.zeros(0, dtype=bool)
   offsets = np.ascontiguousarray(np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64))
   total = int(offsets[-1])
-  A = _f64(np.concatenate([np.asarray(p[0], dtype=np.float64).reshape(-1, 4, 4) for p in problems])) if total else np.zeros((1, 4, 4))
-  B = _f64(np.concatenate([np.asarray(p[1], dtype=np.float64).reshape(-1, 4, 4) for p in problems])) if total else np.zeros((1, 4, 4))
-  any_mask = any(p[2] is not None for p in problems)
-  mask = None
-  if any_mask:
-    mask = np.ascontiguousarray(np.concatenate([np.ones(n, dtype=np.uint8) if p[2] is None else np.asarray(p[2]).astype(np.uint8)
-                                                for p, n in zip(problems, sizes)])) if total else np.zeros(1, dtype=np.uint8)
+  A = _f64(A).reshape(-1, 4, 4) if total else np.zeros((1, 4, 4))
+  B = _f64(B).reshape(-1, 4, 4) if total else np.zeros((1, 4, 4))
+  assert A.shape[0] == max(total, 1) and B.shape[0] == max(total, 1)
+  if mask is not None:
+    mask = np.ascontiguousarray(np.asarray(mask).astype(np.uint8).reshape(-1)) if total else np.zeros(1, dtype=np.uint8)
   out = np.empty((P, 4, 4))
   valid = np.empty(P, dtype=np.uint8)
   inl = np.empty(max(total, 1), dtype=np.uint8)
   dp = C.POINTER(C.c_double)
   up = C.POINTER(C.c_uint8)
+  import os, time
+  t0 = time.perf_counter()
   check(lib.mcba_align_poses_robust(P, offsets.ctypes.data_as(C.POINTER(C.c_int64)), A.ctypes.data_as(dp), B.ctypes.data_as(dp),
                                     None if mask is None else mask.ctypes.data_as(up), float(threshold), 1 if invert else 0,
                                     out.ctypes.data_as(dp), valid.ctypes.data_as(up), inl.ctypes.data_as(up)))
-  inliers = [inl[offsets[i]:offsets[i + 1]].astype(bool) for i in range(P)]
-  return out, valid.astype(bool), inliers
+  if os.environ.get("MCBA_TIMING"):
+    print(f"[mcba_align_poses_robust] {P} problems, {total} entries, largest {int(sizes.max())}: {(time.perf_counter() - t0) * 1e3:.2f} ms",
+          flush=True)
+  return out, valid.astype(bool), inl[:total].astype(bool)
+
+
+def align_transforms_robust_batch(problems, threshold=1.5, invert=False):
+  """problems: list of (m1 [n,4,4], m2 [n,4,4], mask [n] bool or None).  Returns (transforms [P,4,4], valid [P] bool,
+  list of inlier masks) -- per problem exactly matrix.align_transforms_robust(m1, m2, valid=mask, threshold)
+  (invert=True: tables.relative_between_inv: inputs and result inverted)."""
+  P = len(problems)
+  if P == 0:
+    return np.zeros((0, 4, 4)), np.zeros(0, dtype=bool), []
+  sizes = [int(np.asarray(p[0]).shape[0]) for p in problems]
+  total = sum(sizes)
+  A = np.concatenate([np.asarray(p[0], dtype=np.float64).reshape(-1, 4, 4) for p in problems]) if total else np.zeros((0, 4, 4))
+  B = np.concatenate([np.asarray(p[1], dtype=np.float64).reshape(-1, 4, 4) for p in problems]) if total else np.zeros((0, 4, 4))
+  mask = None
+  if any(p[2] is not None for p in problems):
+    mask = np.concatenate([np.ones(n, dtype=np.uint8) if p[2] is None else np.asarray(p[2]).astype(np.uint8)
+                           for p, n in zip(problems, sizes)]) if total else np.zeros(0, dtype=np.uint8)
+  out, valid, inl = align_transforms_robust_ragged(A, B, sizes, mask, threshold, invert)
+  offsets = np.concatenate([[0], np.cumsum(sizes)])
+  return out, valid, [inl[offsets[i]:offsets[i + 1]] for i in range(P)]
 
 
 # ---- host control logic on [n, n] matrices (tables.py:134-148, graph.py:7-33) -------------------------------------------
@@ -86,7 +107,16 @@ def select_pairs(overlaps, hop_penalty=0.8):
 
 
 def inverse(table):
-  return table._extend(poses=np.linalg.inv(table.poses))
+  """tables.inverse (tables.py:229-230 use): the poses are rigid transforms, so the inverse is (R^T | -R^T t) -- the closed
+  form agrees with the reference's np.linalg.inv to the last bits (1e-16) and costs a tenth (80 000 4x4 LU inverses: 6 ms
+  each of the five calls of an initialisation)."""
+  m = np.asarray(table.poses, dtype=np.float64)
+  Rt = np.swapaxes(m[..., :3, :3], -1, -2)
+  out = np.zeros_like(m)
+  out[..., :3, :3] = Rt
+  out[..., :3, 3] = -np.einsum('...ij,...j->...i', Rt, m[..., :3, 3])
+  out[..., 3, 3] = 1.0
+  return table._extend(poses=out)
 
 
 def estimate_relative_poses(table, axis=0, hop_penalty=0.9):
@@ -122,13 +152,14 @@ def estimate_relative_poses_inv(table, axis=2, hop_penalty=0.9):
 
 def relative_between_n(table1, table2, axis=0, inv=False):
   """tables.py:337-345: one alignment per index of `axis`, restricted to the entries valid in both tables -- a ragged
-  batch of small problems (at most cameras x boards entries each) on the device."""
+  batch of small problems (at most cameras x boards entries each) on the device.  The batch is cut out of the tables with ONE
+  boolean selection (the per-index `np.take` of the first version cost 0.7 s for the 1000 frames of a 16 x 1000 x 5 table --
+  more than the device work of the whole initialisation)."""
   n = table1.valid.shape[axis]
-  problems = []
-  for k in range(n):
-    v = np.take(table1.valid, k, axis=axis) & np.take(table2.valid, k, axis=axis)
-    problems.append((np.take(table1.poses, k, axis=axis)[v], np.take(table2.poses, k, axis=axis)[v], None))
-  poses, valid, _ = align_transforms_robust_batch(problems, invert=inv)
+  v = np.moveaxis(np.asarray(table1.valid) & np.asarray(table2.valid), axis, 0).reshape(n, -1)      # [n, entries]
+  p1 = np.moveaxis(np.asarray(table1.poses), axis, 0).reshape(n, -1, 4, 4)
+  p2 = np.moveaxis(np.asarray(table2.poses), axis, 0).reshape(n, -1, 4, 4)
+  poses, valid, _ = align_transforms_robust_ragged(p1[v], p2[v], v.sum(axis=1), None, invert=inv)   # (k, entry) order
   return Table.create(poses=poses, valid=valid)
 
 

@@ -40,6 +40,8 @@ WELL_DEFINED = ["tiny_handeye", "tiny_fixintr", "cfg1", "tiny_huber"]
 # over-parameterised distortion models on 8 frames: a flat valley that neither the reference's own tight polish nor any
 # other solver bottoms out in 400 evaluations (ba_tight_status 0); no converged optimum to compare with
 FLAT_VALLEY = ["tiny_rational", "tiny_thin_prism", "tiny_tilted"]
+# fixtures on which the reference's own driver with the HIP fun + jac reproduces the reference's end point to 1e-6 px
+B_TIGHT = WELL_DEFINED + ["tiny_thin_prism"]
 
 
 def spread_of(g, key="ba"):
@@ -66,7 +68,9 @@ def test_protocol_b_scipy_driven_with_hip_fun_and_jac(name, record_property):
     res = least_squares(h.residuals, g["x0"], jac=h.jacobian, **scipy_args(g))
     rms = rms_of(h, res.x)
   ref, spread = float(g["ba_rms"]), spread_of(g)
-  tol = 1e-6 if name in WELL_DEFINED else max(1e-6, 3 * spread)
+  # (B_TIGHT: measured 5e-14 ... 7e-8 px in profiles/parity_table.md; elsewhere the reference's own end point is only
+  #  defined to its spread over ten perturbed re-runs)
+  tol = 1e-6 if name in B_TIGHT else max(1e-6, 3 * spread)
   record_property("delta_rms_px", abs(rms - ref))
   record_property("nfev", (int(res.nfev), int(g["ba_nfev"])))
   assert res.status == int(g["ba_status"]) or name not in WELL_DEFINED
@@ -287,13 +291,17 @@ def test_baseline_configs_against_reference_trajectories(name):
     assert 0.5 * r @ r <= float(g["ao_tight_cost"])
 
 
-@pytest.mark.parametrize("name", ["cfg5_40", "cfg4_40"])
+@pytest.mark.parametrize("name", ["cfg2", "cfg3_40", "cfg4_40", "cfg5_40", "manypairs"])
 def test_baseline_configs_scipy_driven(name):
-  """protocol (B) on reduced BASELINE configs[3..4]: scipy TRF/LSMR driven by the HIP fun + jac from the reference's
-  start point ends within the reference's spread of the reference's end point."""
+  """protocol (B) on the BASELINE-sized fixtures (configs[1] at full size, configs[2..4] at 40 frames, the 160-pair rig): the
+  reference's own solver call -- scipy TRF / LSMR -- driven by the HIP fun + analytic jac from the reference's start point ends
+  within 1e-6 px of the reference's end point, with the reference's number of function evaluations (profiles/parity_table.md:
+  measured 4e-8 ... 7e-8 px; 6e-7 px on the 160-pair rig, whose own reproducibility is 1.6e-6 px)."""
   from scipy.optimize import least_squares
   g, rig = load_big(name)
   with Handle(mirror(rig)) as h:
     res = least_squares(h.residuals, g["x0"], jac=h.jacobian, x_scale='jac', ftol=1e-4, max_nfev=100, method='trf')
     rms = rms_of(h, res.x)
-  assert abs(rms - float(g["ba_rms"])) <= max(1e-6, 3 * spread_of(g)), (rms, float(g["ba_rms"]), spread_of(g))
+  tol = 1e-6 if name != "manypairs" else max(1e-6, 3 * spread_of(g))
+  assert abs(rms - float(g["ba_rms"])) <= tol, (rms, float(g["ba_rms"]), spread_of(g))
+  assert res.nfev == int(g["ba_nfev"])
