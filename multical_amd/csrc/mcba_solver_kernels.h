@@ -1094,11 +1094,77 @@ __device__ __forceinline__ void chol_tile_factor(double* __restrict__ D, double*
 #endif
     chol_tile_factor_t<false>(D, Xi, ncol, col0, lane, badcol);
 }
+// The same factor in 4 x 4 BLOCKS with the trailing update on the matrix pipe (round 3).  Lane (li, lg) keeps four entries of
+// row li -- the columns lg, lg + 4, lg + 8, lg + 12 -- which is exactly the accumulator layout of v_mfma_f64_16x16x4 for the
+// symmetric update C -= A A^T (lane (li, lg) receives C[lg + 4 r][li] = C[li][lg + 4 r]) and, for block b, exactly its operand
+// layout (lane (li, lg) supplies L[li][4 b + lg]): no data movement between the steps.  Per block: the four columns of the block
+// are gathered into every lane (four cross-lane reads), factored redundantly by all lanes (pivot j touches only the columns left
+// in the block: 3 + 2 + 1 broadcasts instead of 15 + ... + 12), written back, and ONE rank-4 MFMA updates the rest of the tile.
+// The column-by-column version above issues 16 x (2 + 2 (15 - j)) readlanes and 120 FMAs in one dependent chain: ~310 cycles per
+// pivot, 5 k cycles per tile -- the serial floor of every Cholesky kernel of the solver.
+template <bool FULL>
+__device__ __forceinline__ void chol_tile_factor_b4(double* __restrict__ D, double* __restrict__ dinv, int ncol, int col0,
+                                                    int lane, int& badcol) {
+  const int li = lane & 15, lg = lane >> 4;
+  double4_t a4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) a4[r] = D[li * CTL + lg + 4 * r];
+  double dv[CT];
+#pragma unroll
+  for (int j = 0; j < CT; ++j) dv[j] = 1.0;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    if (FULL || 4 * b < ncol) {                      // wave-uniform
+      double blk[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) blk[g] = __shfl(a4[b], li + 16 * g, 64);   // row li, columns 4 b .. 4 b + 3
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int j = 4 * b + jj;
+        if (FULL || j < ncol) {
+          double dj = lane_bcast(blk[jj], j);
+          badcol = (dj > 0.0 || badcol != 0) ? badcol : col0 + j + 1;
+          dj = fmax(dj, 1e-300);
+          const double inv = rsqrt(dj);
+          dv[j] = inv;
+          const double l = (li == j) ? dj * inv : blk[jj] * inv;
+          blk[jj] = l;
+          double lk[4];
+#pragma unroll
+          for (int kk = jj + 1; kk < 4; ++kk) lk[kk] = lane_bcast(l, 4 * b + kk);
+#pragma unroll
+          for (int kk = jj + 1; kk < 4; ++kk) blk[kk] -= l * lk[kk];
+        }
+      }
+      // own column of the block back into the accumulator layout
+      a4[b] = lg == 0 ? blk[0] : (lg == 1 ? blk[1] : (lg == 2 ? blk[2] : blk[3]));
+      if (b < 3) {
+        // rest of the tile: C[i][c] -= sum_k L[i][4 b + k] L[c][4 b + k] for i, c >= 4 b + 4 (columns of pivots that do not exist
+        // -- the padding behind the matrix -- contribute nothing)
+        const bool on = li >= 4 * b + 4 && (FULL || 4 * b + lg < ncol);
+        const double op = on ? a4[b] : 0.0;
+        a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(-op, op, a4, 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) D[li * CTL + lg + 4 * r] = a4[r];
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < CT; ++j) dinv[j] = dv[j];
+  }
+}
+
 // factor only; dinv[0 .. 16) = 1 / L_jj
 __device__ __forceinline__ void chol_tile_factor_noinv(double* __restrict__ D, double* __restrict__ dinv, int ncol, int col0,
                                                        int lane, int& badcol) {
+#if defined(MCBA_EXP_CHOL_NO_B4)   // A/B switch: the column-by-column factor
   if (ncol >= CT) chol_tile_factor_t<true, false>(D, dinv, CT, col0, lane, badcol);
   else chol_tile_factor_t<false, false>(D, dinv, ncol, col0, lane, badcol);
+#else
+  if (ncol >= CT) chol_tile_factor_b4<true>(D, dinv, CT, col0, lane, badcol);
+  else chol_tile_factor_b4<false>(D, dinv, ncol, col0, lane, badcol);
+#endif
 }
 
 // X = A L^-T for FOUR 16 x 16 tiles at once by forward substitution: lane (lg, li) owns row li of tile lg (A4[lg], may be
