@@ -1016,7 +1016,7 @@ constexpr int CT = 16, CTL = 17, CTS = CT * CTL;
 constexpr int CHOL_BLK_MAX_N1 = 160, CHOL_BLK_THREADS = 512;
 __host__ __device__ inline size_t chol_blk_lds_bytes(int ns) {
   const int nb = (ns + 1 + CT - 1) / CT;
-  return ((size_t)(nb * (nb + 1) / 2 + nb) * CTS + 2 * nb * CT) * sizeof(double) + 16;
+  return ((size_t)(nb * (nb + 1) / 2 + nb) * CTS + 3 * nb * CT) * sizeof(double) + 16;
 }
 
 __device__ __forceinline__ double lane_bcast(double v, int src) {   // value of lane src (wave-uniform) in every lane
@@ -1118,22 +1118,31 @@ __device__ __forceinline__ void chol_tile_factor_b4(double* __restrict__ D, doub
       double blk[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) blk[g] = __shfl(a4[b], li + 16 * g, 64);   // row li, columns 4 b .. 4 b + 3
+      // Pivot chain: d_j -> 1 / sqrt(d_j) -> l = a_j / sqrt(d_j) -> d_(j+1) = a_(j+1) - l_(j+1)^2, the last step on the two
+      // broadcast values directly (lane j + 1 forms the same fma on the same operands in the update below).  v_rsq_f64 + one
+      // third-order correction, no clamp / class selects on the chain: a non-positive pivot is reported through badcol and
+      // poisons the factor with NaN (every caller discards the solve then).
+      double dn = lane_bcast(blk[0], 4 * b);
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
         const int j = 4 * b + jj;
         if (FULL || j < ncol) {
-          double dj = lane_bcast(blk[jj], j);
+          const double dj = dn;
           badcol = (dj > 0.0 || badcol != 0) ? badcol : col0 + j + 1;
-          dj = fmax(dj, 1e-300);
-          const double inv = rsqrt(dj);
+          const double y = __builtin_amdgcn_rsq(dj), e = fma(-y * dj, y, 1.0);
+          const double inv = fma(y * e, fma(e, 0.375, 0.5), y);
           dv[j] = inv;
-          const double l = (li == j) ? dj * inv : blk[jj] * inv;
+          const double l = blk[jj] * inv;
           blk[jj] = l;
+          if (jj < 3) {
+            const double apre = lane_bcast(blk[jj + 1], j + 1), ln = lane_bcast(l, j + 1);
+            dn = fma(-ln, ln, apre);
+          }
           double lk[4];
 #pragma unroll
           for (int kk = jj + 1; kk < 4; ++kk) lk[kk] = lane_bcast(l, 4 * b + kk);
 #pragma unroll
-          for (int kk = jj + 1; kk < 4; ++kk) blk[kk] -= l * lk[kk];
+          for (int kk = jj + 1; kk < 4; ++kk) blk[kk] = fma(-l, lk[kk], blk[kk]);
         }
       }
       // own column of the block back into the accumulator layout
@@ -1147,8 +1156,13 @@ __device__ __forceinline__ void chol_tile_factor_b4(double* __restrict__ D, doub
       }
     }
   }
+  // stored SYMMETRICALLY (L below the diagonal, L^T above): the panel solve reads column j of L as the adjacent entries of row j
 #pragma unroll
-  for (int r = 0; r < 4; ++r) D[li * CTL + lg + 4 * r] = a4[r];
+  for (int r = 0; r < 4; ++r) {
+    const int c = lg + 4 * r;
+    if (c <= li) D[li * CTL + c] = a4[r];
+    if (c < li) D[c * CTL + li] = a4[r];
+  }
   if (lane == 0) {
 #pragma unroll
     for (int j = 0; j < CT; ++j) dinv[j] = dv[j];
@@ -1158,19 +1172,18 @@ __device__ __forceinline__ void chol_tile_factor_b4(double* __restrict__ D, doub
 // factor only; dinv[0 .. 16) = 1 / L_jj
 __device__ __forceinline__ void chol_tile_factor_noinv(double* __restrict__ D, double* __restrict__ dinv, int ncol, int col0,
                                                        int lane, int& badcol) {
-#if defined(MCBA_EXP_CHOL_NO_B4)   // A/B switch: the column-by-column factor
-  if (ncol >= CT) chol_tile_factor_t<true, false>(D, dinv, CT, col0, lane, badcol);
-  else chol_tile_factor_t<false, false>(D, dinv, ncol, col0, lane, badcol);
-#else
   if (ncol >= CT) chol_tile_factor_b4<true>(D, dinv, CT, col0, lane, badcol);
   else chol_tile_factor_b4<false>(D, dinv, ncol, col0, lane, badcol);
-#endif
 }
 
 // X = A L^-T for FOUR 16 x 16 tiles at once by forward substitution: lane (lg, li) owns row li of tile lg (A4[lg], may be
-// null).  Nothing crosses lanes: x_j = a_j / L_jj, then a_m -= x_j L_mj for the columns m > j; L and 1 / L_jj are read from
-// LDS with wave-uniform addresses (broadcast reads).  Replaces "multiply by the inverted diagonal tile", which needed the
-// 16 dependent columns of the inverse on the critical path of every block column.
+// null).  Nothing crosses lanes; L and 1 / L_jj are read from LDS with wave-uniform addresses (broadcast reads).  Replaces
+// "multiply by the inverted diagonal tile", which needed the 16 dependent columns of the inverse on the critical path of every
+// block column.  RIGHT-looking: x_j = a_j / L_jj, then a_m -= x_j L_mj for the columns m > j -- the 15 - j updates of a step are
+// independent, so the dependent chain is mul -> fma per column (32 operations) where the left-looking form (round 2) summed
+// j products in two chains per column (92 operations, 2.0 k cycles per block column).  Column j of L is row j of the factored
+// tile above the diagonal (chol_tile_factor_b4 stores L^T there): adjacent entries, requested three steps ahead into rotating
+// registers (left to the compiler every broadcast read is followed by its own s_waitcnt).
 __device__ __forceinline__ void chol_panel_solve4(const double* __restrict__ L, const double* __restrict__ dinv,
                                                   double* __restrict__ A, int li) {
   if (A == nullptr) return;
@@ -1179,32 +1192,60 @@ __device__ __forceinline__ void chol_panel_solve4(const double* __restrict__ L, 
   for (int c = 0; c < CT; ++c) a[c] = A[li * CTL + c];
 #pragma unroll
   for (int c = 0; c < CT; ++c) dv[c] = dinv[c];
-  // left-looking: x_j = (a_j - sum_{m < j} x_m L_jm) / L_jj reads ROW j of L (adjacent entries: ds_read2_b64).  The rows
-  // are requested THREE steps ahead into rotating registers: left to the compiler every broadcast read was followed by
-  // its own s_waitcnt (67 LDS round trips per tile, 3.2 k cycles per block column)
   double lr[4][CT];
 #pragma unroll
-  for (int r = 1; r < 4; ++r)
+  for (int r = 0; r < 3; ++r)
 #pragma unroll
-    for (int m = 0; m < r; ++m) lr[r][m] = L[r * CTL + m];
+    for (int m = r + 1; m < CT; ++m) lr[r][m] = L[r * CTL + m];
 #pragma unroll
   for (int j = 0; j < CT; ++j) {
     if (j + 3 < CT) {
 #pragma unroll
-      for (int m = 0; m < j + 3; ++m) lr[(j + 3) & 3][m] = L[(j + 3) * CTL + m];
+      for (int m = j + 4; m < CT; ++m) lr[(j + 3) & 3][m] = L[(j + 3) * CTL + m];
     }
-    double s0 = a[j], s1 = 0.0;
+    const double x = a[j] * dv[j];
+    a[j] = x;
 #pragma unroll
-    for (int m = 0; m < j; ++m) {
-      const double l = lr[j & 3][m];
-      if (m & 1) s1 -= a[m] * l; else s0 -= a[m] * l;
-    }
-    a[j] = (s0 + s1) * dv[j];
+    for (int m = j + 1; m < CT; ++m) a[m] = fma(-x, lr[j & 3][m], a[m]);
   }
 #pragma unroll
   for (int c = 0; c < CT; ++c) A[li * CTL + c] = a[c];
 }
 
+// inverse of a factored 16 x 16 tile (L in LDS with L^T above the diagonal, dinv = 1 / L_jj): lane c < 16 solves L x = e_c by
+// the right-looking substitution of chol_panel_solve4 (chain: mul -> fma per row); Xi[i][c] = x_i.  Runs on a wavefront that is
+// off the critical path; every L entry is a broadcast read.  Only the leading ncol x ncol part is inverted (the rest of Xi is
+// zero): a last tile carries the right-hand-side row and identity padding behind the matrix.
+__device__ __forceinline__ void chol_tile_invert(const double* __restrict__ L, const double* __restrict__ dinv,
+                                                 double* __restrict__ Xi, int lane, int ncol = CT) {
+  const int c = lane & 15;
+  double a[CT], dv[CT];
+#pragma unroll
+  for (int i = 0; i < CT; ++i) {
+    a[i] = (i == c) ? 1.0 : 0.0;
+    dv[i] = (i < ncol) ? dinv[i] : 0.0;
+  }
+  double lr[4][CT];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int m = r + 1; m < CT; ++m) lr[r][m] = L[r * CTL + m];
+#pragma unroll
+  for (int j = 0; j < CT; ++j) {
+    if (j + 3 < CT) {
+#pragma unroll
+      for (int m = j + 4; m < CT; ++m) lr[(j + 3) & 3][m] = L[(j + 3) * CTL + m];
+    }
+    const double x = a[j] * dv[j];
+    a[j] = x;
+#pragma unroll
+    for (int m = j + 1; m < CT; ++m) a[m] = fma(-x, lr[j & 3][m], a[m]);
+  }
+  if (lane < CT) {
+#pragma unroll
+    for (int i = 0; i < CT; ++i) Xi[i * CTL + c] = a[i];
+  }
+}
 
 // C -= Xa Xb^T for one 16 x 16 tile (four MFMA steps), one wavefront
 __device__ __forceinline__ void chol_tile_syrk(const double* __restrict__ Xa, const double* __restrict__ Xb,
@@ -1234,6 +1275,7 @@ __global__ __launch_bounds__(CHOL_BLK_THREADS) void k_chol_blk(int ns, double re
   double* Li = Lb + (size_t)ntile * CTS;       // inverted diagonal tiles
   double* yv = Li + (size_t)nb * CTS;          // forward-substituted right-hand side, updated by the back substitution
   double* pv = yv + nb * CT;                   // solution
+  double* dvv = pv + nb * CT;                  // 1 / L_jj
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int badcol = 0;                              // wave 0: first non-positive pivot (1-based)
   long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tc = 0;   // phase stamps (prof != nullptr): load, a0, b, c + a, back
@@ -1272,8 +1314,9 @@ __global__ __launch_bounds__(CHOL_BLK_THREADS) void k_chol_blk(int ns, double re
   __syncthreads();
   CHOL_STAMP(0)
   const int li = lane & 15, lg = lane >> 4;
-  // (Li + k CTS holds 1 / L_jj of block column k in its first 16 entries: the tiles are never inverted)
-  if (wave == 0 && ns > 0) chol_tile_factor_noinv(Lb, Li, min(CT, ns), 0, lane, badcol);
+  // (the panels are solved with L itself and 1 / L_jj; the INVERSES of the diagonal tiles, which only the back substitution
+  //  uses, are formed one block column late by a wavefront with slack: off the critical path)
+  if (wave == 0 && ns > 0) chol_tile_factor_noinv(Lb, dvv, min(CT, ns), 0, lane, badcol);
   __syncthreads();
   CHOL_STAMP(1)
   for (int k = 0; k < nb; ++k) {
@@ -1281,7 +1324,7 @@ __global__ __launch_bounds__(CHOL_BLK_THREADS) void k_chol_blk(int ns, double re
     {
       // (b) panel tiles below the diagonal:  X = A L_kk^-T by forward substitution, four tiles per wavefront
       const int bi = k + 1 + 4 * wave + lg;
-      chol_panel_solve4(Lb + (size_t)(k * (k + 1) / 2 + k) * CTS, Li + (size_t)k * CTS,
+      chol_panel_solve4(Lb + (size_t)(k * (k + 1) / 2 + k) * CTS, dvv + k * CT,
                         bi < nb ? Lb + (size_t)(bi * (bi + 1) / 2 + k) * CTS : nullptr, li);
     }
     __syncthreads();
@@ -1298,10 +1341,14 @@ __global__ __launch_bounds__(CHOL_BLK_THREADS) void k_chol_blk(int ns, double re
           chol_tile_syrk(X1, X1, D1, li, lg);
           lds_fence();
           const int ncol1 = min(CT, ns - CT * b1);
-          if (ncol1 > 0) chol_tile_factor_noinv(D1, Li + (size_t)b1 * CTS, ncol1, CT * b1, lane, badcol);
+          if (ncol1 > 0) chol_tile_factor_noinv(D1, dvv + b1 * CT, ncol1, CT * b1, lane, badcol);
         }
       } else {
-        for (int tt = wave; tt < nt; tt += NW - 1) {
+        // the last wavefront inverts the diagonal tile of this block column (about as long as wave 0's look-ahead factor) and
+        // takes no trailing tiles
+        if (wave == NW - 1)
+          chol_tile_invert(Lb + (size_t)(k * (k + 1) / 2 + k) * CTS, dvv + k * CT, Li + (size_t)k * CTS, lane, min(CT, ns - CT * k));
+        else for (int tt = wave; tt < nt; tt += NW - 2) {
           int a = 0, rem = tt;
           while (rem > a) { rem -= a + 1; ++a; }           // tt -> (a, rem), rem <= a
           const int bi = k + 1 + a, bj = k + 1 + rem;
@@ -1323,40 +1370,31 @@ __global__ __launch_bounds__(CHOL_BLK_THREADS) void k_chol_blk(int ns, double re
     lds_fence();
     const int nbc = (ns + CT - 1) / CT;
     for (int kb = nbc - 1; kb >= 0; --kb) {
-      {   // p_k = L_kk^-T z_k by backward substitution: lane i carries z_i; p_i travels through v_readlane
-        const double* Lk = Lb + (size_t)(kb * (kb + 1) / 2 + kb) * CTS;
-        const double* dk = Li + (size_t)kb * CTS;
-        double z = yv[CT * kb + li];
-        // column li of L_kk and 1 / L_ii first: the LDS reads do not depend on z, only mul / readlane / fma stay on the chain
-        double lc[CT], dv[CT];
+      double p;
+      {   // p_k = L_kk^-T z_k as a mat-vec with the inverted tile: lane (c, q) sums the rows i = q, q + 4, .. of column c
+        const double* Xk = Li + (size_t)kb * CTS;
+        double s4[4];
 #pragma unroll
-        for (int i = 0; i < CT; ++i) {
-          lc[i] = (li < i) ? Lk[i * CTL + li] : 0.0;   // (masked: lanes >= i keep their z in the update below)
-          dv[i] = dk[i];
-        }
-        double pfin = 0.0;
-#pragma unroll
-        for (int i = CT - 1; i >= 0; --i) {
-          const double pi = lane_bcast(z * dv[i], i);   // chain per step: fma -> mul -> readlane
-          pfin = (li == i) ? pi : pfin;
-          z -= lc[i] * pi;
-        }
-        z = pfin;
-        if (lane < CT) {
-          pv[CT * kb + li] = z;
-          if (CT * kb + li < ns) ps[CT * kb + li] = z;
-        }
+        for (int r = 0; r < 4; ++r) s4[r] = Xk[(lg + 4 * r) * CTL + li] * yv[CT * kb + lg + 4 * r];
+        p = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        p = fold32(p, p);
+        p = fold16(p, p);                        // every lane (c, *) holds p_c
+        if (lane < CT && CT * kb + li < ns) ps[CT * kb + li] = p;
       }
-      lds_fence();
-      for (int e = lane; e < CT * kb; e += 64) {   // z_j -= L_kj^T p_k for the blocks above
-        const int bj = e / CT, c = e % CT;
-        const double* Lt = Lb + (size_t)(kb * (kb + 1) / 2 + bj) * CTS;
-        double sp[4] = {yv[e], 0.0, 0.0, 0.0};
+      if (kb > 0) {   // z_j -= L_kj^T p_k for the blocks above; p_r as scalars
+        double pr[CT];
 #pragma unroll
-        for (int r = 0; r < CT; ++r) sp[r & 3] -= Lt[r * CTL + c] * pv[CT * kb + r];
-        yv[e] = (sp[0] + sp[1]) + (sp[2] + sp[3]);
+        for (int r = 0; r < CT; ++r) pr[r] = lane_bcast(p, r);
+        for (int e = lane; e < CT * kb; e += 64) {
+          const int bj = e / CT, c = e % CT;
+          const double* Lt = Lb + (size_t)(kb * (kb + 1) / 2 + bj) * CTS;
+          double sp[4] = {yv[e], 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int r = 0; r < CT; ++r) sp[r & 3] -= Lt[r * CTL + c] * pr[r];
+          yv[e] = (sp[0] + sp[1]) + (sp[2] + sp[3]);
+        }
+        lds_fence();
       }
-      lds_fence();
     }
     CHOL_STAMP(4)
     if (lane == 0) {
@@ -1594,28 +1632,6 @@ __host__ __device__ inline size_t cholp_lds_bytes(int ns, int kt0, int wt) {
   return ((size_t)(nb - kt0) * wt * CTS + (size_t)wt * CTS + wt * CT) * sizeof(double);
 }
 
-// inverse of a factored 16 x 16 tile (L in LDS, dinv = 1 / L_jj): lane c < 16 solves L x = e_c; Xi[i][c] = x_i.  Runs on a
-// wavefront that is off the critical path; every L entry is a broadcast read.
-__device__ __forceinline__ void chol_tile_invert(const double* __restrict__ L, const double* __restrict__ dinv,
-                                                 double* __restrict__ Xi, int lane) {
-  const int c = lane & 15;
-  double x[CT];
-#pragma unroll
-  for (int i = 0; i < CT; ++i) {
-    double s0 = (i == c) ? 1.0 : 0.0, s1 = 0.0;
-#pragma unroll
-    for (int m = 0; m < i; ++m) {
-      const double l = L[i * CTL + m];
-      if (m & 1) s1 -= l * x[m]; else s0 -= l * x[m];
-    }
-    x[i] = (i >= c) ? (s0 + s1) * dinv[i] : 0.0;
-  }
-  if (lane < CT) {
-#pragma unroll
-    for (int i = 0; i < CT; ++i) Xi[i * CTL + c] = x[i];
-  }
-}
-
 __global__ __launch_bounds__(CHOLP_THREADS) void k_cholp_panel(int ns, int kt0, int wt, double reg, double* __restrict__ buf,
                                                                double* __restrict__ Linv, int* __restrict__ info,
                                                                long long* __restrict__ prof = nullptr) {
@@ -1720,7 +1736,8 @@ __global__ __launch_bounds__(CHOLP_THREADS) void k_cholp_panel(int ns, int kt0, 
     }
   }
   CHOLP_STAMP(5)
-  if (wave < wt) chol_tile_invert(P + (size_t)(wave * wt + wave) * CTS, dinv + wave * CT, Xi + (size_t)wave * CTS, lane);
+  if (wave < wt) chol_tile_invert(P + (size_t)(wave * wt + wave) * CTS, dinv + wave * CT, Xi + (size_t)wave * CTS, lane,
+                                    min(CT, ns - c0 - CT * wave));
   __syncthreads();
   CHOLP_STAMP(4)
   for (int e = tid; e < wt * CT * CT; e += CHOLP_THREADS) {
