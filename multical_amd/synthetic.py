@@ -124,8 +124,10 @@ CONFIGS = {
                model="standard", optimize_cameras=True, layout="stereo", seed=3),
   "cfg4": dict(cameras=16, frames=1000, boards=["charuco_10x10"] * 5, motion="static", model="standard",
                optimize_cameras=True, layout="stereo", cube=True, seed=4),
+  # "outlier pose rejection": views whose PnP pose reprojects worse than pose_error_limit never reach the initialisation
+  # tables (tables.py:44-56; the reference's default limit, config/arguments.py:50)
   "cfg5": dict(cameras=6, frames=400, boards=["charuco_10x10"] * 5, motion="static", model="fisheye",
-               optimize_cameras=True, layout="ring", seed=5),
+               optimize_cameras=True, layout="ring", seed=5, pose_error_limit=1.0, pose_noise=(2e-4, 1e-4)),
   # small variants used by unit tests / smoke (same generators, fewer frames)
   "tiny": dict(cameras=2, frames=6, boards=["charuco_10x10"], motion="static", model="standard",
                optimize_cameras=True, layout="stereo", seed=11),
@@ -160,7 +162,7 @@ CONFIGS = {
   "cfg4_40": dict(cameras=16, frames=40, boards=["charuco_10x10"] * 5, motion="static", model="standard",
                   optimize_cameras=True, layout="stereo", cube=True, seed=4),
   "cfg5_40": dict(cameras=6, frames=40, boards=["charuco_10x10"] * 5, motion="static", model="fisheye",
-                  optimize_cameras=True, layout="ring", seed=5),
+                  optimize_cameras=True, layout="ring", seed=5, pose_error_limit=1.0, pose_noise=(2e-4, 1e-4)),
 }
 
 DIST_SIZE = dict(standard=5, rational=8, thin_prism=12, tilted=14, fisheye=4, pin4=4)
@@ -477,20 +479,52 @@ def rig_from_arrays(arrs):
 # ------------------------------------------------------------------------------------------------
 # per-view board poses for the initialisation tables (tables.make_pose_table would obtain them from cv2.solvePnP)
 # ------------------------------------------------------------------------------------------------
-def make_pose_table(rig, seed=0, rot_sigma=2e-3, trans_sigma=1e-3, outlier_frac=0.03):
+def view_pose_errors(rig, poses):
+  """Reprojection error of the per-view board poses [C, F, B] against the rig's detections: the RMS distance (px) that
+  board.estimate_pose_points reports to tables.extract_pose (tables.py:44-46), with the true cameras standing in for the
+  intrinsic calibration that precedes it.  Views without detections get 0."""
+  C, F, B, P = rig.valid.shape
+  padded = np.zeros((B, P, 3))
+  for b, pts in enumerate(rig.board_points):
+    padded[b, :pts.shape[0]] = pts
+  err = np.zeros((C, F, B))
+  for c in range(C):
+    X = np.einsum('fbij,bpj->fbpi', poses[c, :, :, :3, :3], padded) + poses[c, :, :, None, :3, 3]
+    d2 = ((_project(rig.truth.cameras[c], X) - rig.points[c]) ** 2).sum(axis=-1)
+    v = rig.valid[c]
+    n = v.sum(axis=-1)
+    with np.errstate(all='ignore'):
+      err[c] = np.where(n > 0, np.sqrt(np.where(v, d2, 0.0).sum(axis=-1) / np.maximum(n, 1)), 0.0)
+  return np.nan_to_num(err, nan=np.inf)
+
+
+def make_pose_table(rig, seed=0, rot_sigma=None, trans_sigma=None, outlier_frac=0.03, pose_error_limit=None):
   """Pose table [C, F, B] of the rig: truth chain camera . rig . board perturbed by a small SE(3) noise (a PnP estimate
   from noisy corners), a fraction of gross outliers (wrong board orientation), validity / detection counts from the rig's
   observation table.  Returns dict(poses, valid, num_points) of numpy arrays; invalid entries are the identity like
-  tables.invalid_pose (tables.py:38)."""
+  tables.invalid_pose (tables.py:38).
+
+  pose_error_limit (px; default: the rig configuration's, BASELINE configs[4] "outlier pose rejection" uses the reference's
+  1.0): views whose pose reprojects its detections worse than the limit are dropped from the table -- invalid, identity,
+  zero points -- as tables.extract_pose does with exclude_bad_poses (tables.py:48-56, workspace.py:196-198).  With the rig
+  generator's 1 % gross corner outliers about half of the views of cfg5 go: every view that holds such a corner, and the
+  wrong-orientation poses."""
   rng = np.random.default_rng([seed, 4241])
   tr = rig.truth
   C, F, B, P = rig.valid.shape
   chain = tr.camera_poses[:, None, None] @ tr.rig[None, :, None] @ tr.board_poses[None, None, :]
-  poses = perturb(chain, rng, rot_sigma, trans_sigma)
+  noise = rig.cfg.get("pose_noise", (2e-3, 1e-3))   # (rad, m)
+  poses = perturb(chain, rng, noise[0] if rot_sigma is None else rot_sigma, noise[1] if trans_sigma is None else trans_sigma)
   num_points = rig.valid.sum(axis=3)
   valid = num_points > 0
   out = rng.random((C, F, B)) < outlier_frac
   bad = to_matrix(np.concatenate([rng.normal(0, 0.8, (C, F, B, 3)), rng.normal(0, 0.3, (C, F, B, 3))], axis=-1))
   poses = np.where(out[..., None, None], bad @ poses, poses)
+  if pose_error_limit is None:
+    pose_error_limit = rig.cfg.get("pose_error_limit")
+  rejected = np.zeros_like(valid)
+  if pose_error_limit is not None:
+    rejected = valid & (view_pose_errors(rig, poses) > pose_error_limit)
+    valid = valid & ~rejected
   poses = np.where(valid[..., None, None], poses, np.eye(4))
-  return dict(poses=poses, valid=valid, num_points=np.where(valid, num_points, 0))
+  return dict(poses=poses, valid=valid, num_points=np.where(valid, num_points, 0), rejected=rejected)

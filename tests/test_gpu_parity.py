@@ -666,11 +666,12 @@ def test_reprojection_tables_consumer(name):
 
 
 @pytest.mark.parametrize("name,frames,seed", [("tiny_rolling", None, 5), ("tiny_fisheye", None, 6), ("cfg4", 12, 5),
-                                              ("cfg2", 60, 7), ("cfg3", 40, 8)])
+                                              ("cfg2", 60, 7), ("cfg3", 40, 8), ("cfg5", 40, 9)])
 def test_initialise_poses_on_the_device_matches_the_oracle(name, frames, seed):
   """multical_amd.tables.initialise_poses (every matrix.align_transforms_robust of the reference's pose-graph
   initialisation as a device batch: relative poses, Ward-cluster robust mean, quartile outlier test) against the oracle
-  restatement, which is pinned bit-identical to the unmodified reference (test_oracle_vs_reference)."""
+  restatement, which is pinned bit-identical to the unmodified reference (test_oracle_vs_reference).  cfg5: the pose table
+  after the reference's outlier pose rejection (pose_error_limit, tables.py:44-56) -- about half of its views are invalid."""
   from multical_amd import tables as mtables
   from multical_amd.structs import Table
   from oracle import restate_init

@@ -141,3 +141,27 @@ def test_device_math_robust_loss_scaling(loss, f_scale):
   assert cost == pytest.approx(cost_ref, rel=1e-12)
   assert np.abs(H - Js.T @ Js).max() <= 1e-11 * np.abs(H).max()
   assert np.abs(grad - Js.T @ fs).max() <= 1e-11 * np.abs(grad).max()
+
+
+def test_pose_table_outlier_pose_rejection():
+  """BASELINE configs[4] "outlier pose rejection": tables.extract_pose (tables.py:44-56) drops every view whose PnP pose
+  reprojects its detections worse than pose_error_limit before the initialisation tables are built.  The synthetic pose
+  table of cfg5 models it: rejected views are invalid_pose entries (identity, no points, tables.py:38), the surviving
+  ones meet the limit, and the wrong-orientation poses are among the rejected."""
+  from multical_amd import synthetic
+  rig = synthetic.make_rig("cfg5", frames=20)
+  assert rig.cfg["pose_error_limit"] == 1.0                      # the reference's default (config/arguments.py:50)
+  pt = synthetic.make_pose_table(rig, seed=3)
+  free = synthetic.make_pose_table(rig, seed=3, pose_error_limit=np.inf)
+  detected = rig.valid.sum(axis=3) > 0
+  assert np.array_equal(free["valid"], detected) and not free["rejected"].any()
+  rej = pt["rejected"]
+  assert np.array_equal(pt["valid"], detected & ~rej) and 0.2 < rej.sum() / detected.sum() < 0.8
+  assert np.array_equal(pt["poses"][~pt["valid"]], np.broadcast_to(np.eye(4), pt["poses"][~pt["valid"]].shape))
+  assert (pt["num_points"][~pt["valid"]] == 0).all() and (pt["num_points"][pt["valid"]] >= 12).all()
+  err = synthetic.view_pose_errors(rig, free["poses"])
+  assert (err[pt["valid"]] <= 1.0).all() and (err[rej] > 1.0).all()
+  assert np.array_equal(pt["poses"][pt["valid"]], free["poses"][pt["valid"]])
+  # a rig without the key keeps every detected view (the other BASELINE configurations)
+  rig2 = synthetic.make_rig("cfg2", frames=5)
+  assert not synthetic.make_pose_table(rig2, seed=3)["rejected"].any()

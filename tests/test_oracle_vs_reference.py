@@ -90,7 +90,8 @@ def test_projected_restatement_is_bit_identical_to_reference(name):
   assert np.array_equal(np.asarray(want.points)[valid], got[valid])
 
 
-@pytest.mark.parametrize("name,frames", [("tiny_rolling", None), ("tiny_fisheye", None), ("cfg4", 12), ("cfg2", 30)])
+@pytest.mark.parametrize("name,frames", [("tiny_rolling", None), ("tiny_fisheye", None), ("cfg4", 12), ("cfg2", 30),
+                                         ("cfg5", 30)])
 def test_initialise_poses_restatement_is_bit_identical_to_reference(name, frames):
   """tables.initialise_poses (tables.py:353-377) -- relative camera / board poses through the overlap
   spanning tree and the per-frame rig poses, all through matrix.align_transforms_robust / the Ward-cluster robust mean --
