@@ -770,6 +770,15 @@ int gn_dot_blocks(const Dims& d) {
 // tr_dev: the damping is S[TR_REG] of that scalar block; with `trp` (the partial sums k_tr_reg would fold) the first kernel
 // of the chain computes and publishes it itself
 struct TrRegPartials { const double* vs; int nvb; const double* q; int nq; int first; double Delta; };
+// 3 x 3 register-blocked Schur SYRK (MCBA_SYRK3=0 keeps one wavefront per tile pair)
+// (reduced systems of nine tile columns or more: below that the blocks are mostly padding -- 6.9 against 4.5 us at 4 x 200 x 1;
+//  MCBA_SYRK3=1 forces it for every size)
+static bool syrk3_enabled(const mcba_handle_s* h) {
+  static const char* env = getenv("MCBA_SYRK3");
+  if (env != nullptr && env[0] == '0') return false;
+  return h->use_mfma && (h->ntile >= 9 || (env != nullptr && env[0] == '1'));
+}
+
 void launch_gn_solve(mcba_handle_s* h, double reg, bool root_rank, double* dots_out = nullptr,
                      double* tr_dev = nullptr, const TrRegPartials* trp = nullptr) {
   const Dims& d = h->d;
@@ -793,11 +802,15 @@ void launch_gn_solve(mcba_handle_s* h, double reg, bool root_rank, double* dots_
       hipLaunchKernelGGL((k_schur_frame<6>), dim3(d.Fl), dim3(256), 0, h->stream, d, h->Hff.p, h->Hfs.p, h->dsc.p, h->gh.p, reg,
                          h->Lf.p, h->W.p, h->yf.p, tr_dev, z.vs, z.nvb, z.q, z.nq, z.first, z.Delta);
     const int nt2 = h->ntile * (h->ntile + 1) / 2;
-    if (h->use_mfma)
-      hipLaunchKernelGGL((k_schur_syrk<true>), dim3(nt2, h->ksplit), dim3(64), 0, h->stream, K, d.ns + 1, h->ntile,
+    if (syrk3_enabled(h)) {
+      const int nt3 = (h->ntile + 2) / 3;
+      hipLaunchKernelGGL(k_schur_syrk3, dim3(h->ksplit, nt3 * (nt3 + 1) / 2), dim3(SYRK3_THREADS), 0, h->stream, K, d.ns + 1,
+                         h->ntile, h->ksplit, h->W.p, h->P.p);
+    } else if (h->use_mfma)
+      hipLaunchKernelGGL((k_schur_syrk<true>), dim3(h->ksplit, nt2), dim3(64), 0, h->stream, K, d.ns + 1, h->ntile,
                          h->ksplit, h->W.p, h->P.p);
     else
-      hipLaunchKernelGGL((k_schur_syrk<false>), dim3(nt2, h->ksplit), dim3(64), 0, h->stream, K, d.ns + 1, h->ntile,
+      hipLaunchKernelGGL((k_schur_syrk<false>), dim3(h->ksplit, nt2), dim3(64), 0, h->stream, K, d.ns + 1, h->ntile,
                          h->ksplit, h->W.p, h->P.p);
   }
   const int total = d.ns * d.ns + d.ns;
@@ -1117,7 +1130,12 @@ int32_t mcba_create(const mcba_problem* p, void* hip_stream, mcba_handle* out) {
     const int K = d.DF * d.Fl;
     const int nt2 = h->ntile * (h->ntile + 1) / 2;
     int ks = 1;
-    while (ks < 64 && nt2 * ks < 1024 && K / (ks * 2) >= 32) ks *= 2;
+    if (syrk3_enabled(h.get())) {   // k_schur_syrk3: four wavefronts per (48 x 48 block, split); >= 192 workgroups, >= 16 rows each
+      const int nt3 = (h->ntile + 2) / 3, np3 = nt3 * (nt3 + 1) / 2;
+      while (ks < 64 && np3 * ks < 192 && K / (ks * 2 * SYRK3_WAVES) >= 16) ks *= 2;
+    } else {
+      while (ks < 64 && nt2 * ks < 1024 && K / (ks * 2) >= 32) ks *= 2;
+    }
     h->ksplit = ks;
     h->P.alloc((size_t)ks * nt2 * 256);
   }
@@ -1728,10 +1746,14 @@ int32_t mcba_debug_pipe_probe(int32_t iters, double* ms_out) {
   hipEvent_t e0, e1;
   HIP_OK(hipEventCreate(&e0));
   HIP_OK(hipEventCreate(&e1));
+  // (MCBA_PROBE_THREADS / MCBA_PROBE_BLOCKS: other occupancies, e.g. 256 threads = one wavefront per SIMD)
+  const int thr = getenv("MCBA_PROBE_THREADS") ? atoi(getenv("MCBA_PROBE_THREADS")) : 512;
+  const int blk = getenv("MCBA_PROBE_BLOCKS") ? atoi(getenv("MCBA_PROBE_BLOCKS")) : 256;
+  REQUIRE(thr >= 64 && thr <= 512 && thr % 64 == 0 && blk > 0, "bad probe shape");
   for (int mode = 0; mode < 3; ++mode) {
-    hipLaunchKernelGGL(k_pipe_probe, dim3(256), dim3(512), 0, 0, mode, 16, sink.p);   // warm-up
+    hipLaunchKernelGGL(k_pipe_probe, dim3(blk), dim3(thr), 0, 0, mode, 16, sink.p);   // warm-up
     HIP_OK(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL(k_pipe_probe, dim3(256), dim3(512), 0, 0, mode, iters, sink.p);
+    hipLaunchKernelGGL(k_pipe_probe, dim3(blk), dim3(thr), 0, 0, mode, iters, sink.p);
     HIP_OK(hipEventRecord(e1, 0));
     HIP_OK(hipEventSynchronize(e1));
     float ms = 0.f;

@@ -741,7 +741,10 @@ __device__ __forceinline__ double tr_reg_wave(double* S, const double* __restric
 template <bool MFMA>
 __global__ __launch_bounds__(64, 2) void k_schur_syrk(int K, int ncol, int ntile, int ksplit, const double* __restrict__ W,
                                                    double* __restrict__ P) {
-  const int tile = blockIdx.x, split = blockIdx.y, lane = threadIdx.x;
+  // XCD-aware launch: workgroups go to the eight XCDs round-robin by their linear index, so with the SPLIT as the fast grid
+  // dimension (ksplit is a multiple of 8) every tile pair of the splits s, s + 8, .. runs on XCD s and that XCD's L2 holds only
+  // its eighth of W' -- with the tile as the fast dimension every XCD pulled all of W' from memory (8 x 6.8 MB per launch)
+  const int tile = blockIdx.y, split = blockIdx.x, lane = threadIdx.x;
   int ti = 0, rem = tile;
   while (rem >= ntile - ti) { rem -= ntile - ti; ++ti; }
   const int tj = ti + rem;
@@ -751,20 +754,44 @@ __global__ __launch_bounds__(64, 2) void k_schur_syrk(int K, int ncol, int ntile
   const int rsub = lane >> 4, csub = lane & 15;
   const int ci = ti * 16 + csub, cj = tj * 16 + csub;
   if constexpr (MFMA) {
-    double4_t acc = {0.0, 0.0, 0.0, 0.0};
-    constexpr int UB = 8;                           // operand loads of 8 MFMA steps in flight at once
-    for (int k = k0; k < k1; k += 4 * UB) {
-      double av[UB], bv[UB];
+    // Operand loads of 8 MFMA steps per batch, the NEXT batch requested before the MFMAs of the current one are issued (a
+    // wavefront that loads, waits, multiplies and loads again spends three quarters of its time in memory round trips: two
+    // accumulators so that the eight MFMAs of a batch are not one dependent chain either).  Raw loads of clamped addresses;
+    // the 0 / 1 masks are applied when the batch is consumed (see k_schur_syrk3).
+    double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    constexpr int UB = 8;
+    const double mi = ci < ncol ? 1.0 : 0.0, mj = cj < ncol ? 1.0 : 0.0;
+    const int cic = min(ci, ncol - 1), cjc = min(cj, ncol - 1);
+    double av[2][UB], bv[2][UB];
+    auto request = [&](int buf, int k) {
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
-        const int kk = k + 4 * u + rsub;
-        av[u] = masked_load(W, (size_t)kk * ncol + ci, kk < k1 && ci < ncol);
-        bv[u] = masked_load(W, (size_t)kk * ncol + cj, kk < k1 && cj < ncol);
+        const size_t row = (size_t)min(k + 4 * u + rsub, K - 1) * ncol;
+        av[buf][u] = W[row + cic];
+        bv[buf][u] = W[row + cjc];
       }
+    };
+    auto multiply = [&](int buf, int k) {
 #pragma unroll
-      for (int u = 0; u < UB; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+      for (int u = 0; u < UB; u += 2) {
+        const double m0 = (k + 4 * u + rsub < k1) ? mi : 0.0, m1 = (k + 4 * u + 4 + rsub < k1) ? mi : 0.0;
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[buf][u] * m0, bv[buf][u] * mj, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[buf][u + 1] * m1, bv[buf][u + 1] * mj, acc1, 0, 0, 0);
+      }
+    };
+    request(0, k0);
+    for (int k = k0; k < k1; k += 8 * UB) {
+      request(1, k + 4 * UB);
+      __builtin_amdgcn_sched_barrier(0);
+      multiply(0, k);
+      __builtin_amdgcn_sched_barrier(0);
+      if (k + 4 * UB >= k1) break;
+      request(0, k + 8 * UB);
+      __builtin_amdgcn_sched_barrier(0);
+      multiply(1, k + 4 * UB);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    for (int r = 0; r < 4; ++r) out[(rsub + 4 * r) * 16 + csub] = acc[r];
+    for (int r = 0; r < 4; ++r) out[(rsub + 4 * r) * 16 + csub] = acc0[r] + acc1[r];
   } else {
     double acc[4] = {0, 0, 0, 0};
     for (int k = k0; k < k1; ++k) {
@@ -775,6 +802,129 @@ __global__ __launch_bounds__(64, 2) void k_schur_syrk(int K, int ncol, int ntile
       }
     }
     for (int r = 0; r < 4; ++r) out[(rsub + 4 * r) * 16 + csub] = acc[r];
+  }
+}
+
+// The same partial SYRK with 3 x 3 REGISTER BLOCKING (round 3), used for reduced systems of nine tile columns or more.
+// k_schur_syrk gives every (tile pair, K split) its own wavefront, which loads two 16-column strips of W' per MFMA: 1 KB of
+// operands per 64-cycle matrix instruction, 69 MB of L2 reads per launch for a 6.8 MB matrix at the north-star rig.  Here a
+// wavefront owns a 48 x 48 block of S (nine tiles, 72 accumulator registers) and loads three + three strips per nine MFMAs:
+// 21 MB.  Four wavefronts of a workgroup split the rows of one K split among themselves and fold their accumulators through
+// LDS in a fixed order.  P keeps the layout of k_schur_syrk: [split][upper tile][16 x 16].
+// What it took (profiles/r03_syrk_experiments.txt): 8 wavefronts x 96 workgroups: 18.9 us (384 SIMDs carry all MFMAs); a
+// wave-uniform `if (!diag)` around the B loads: eight serial round trips per batch (16.8); masked_load's multiply at request
+// time: vmcnt(0) at the end of every trip; no scheduling barriers: both requests hoisted, all MFMAs behind one wait (12.6);
+// the diagonal choice inside multiply(): 503 v_accvgpr_mov per trip (11.3); a `break` in the middle of the trip or a register
+// budget above 256: AGPR-form MFMAs whose 72 accumulators are copied to VGPRs and back in every trip (10.9; 31 us at 16
+// cameras x 5 boards) -- __launch_bounds__(256, 2) keeps the budget at 256 and the MFMAs in VGPR form: 8.7 / 20.8 us against
+// 9.4 / 27.2 us of the one-tile kernel (which gained its own double buffering and the XCD-aware grid order on the way).
+constexpr int SYRK3_WAVES = 4, SYRK3_THREADS = 64 * SYRK3_WAVES;
+__global__ __launch_bounds__(SYRK3_THREADS, 2) void k_schur_syrk3(int K, int ncol, int ntile, int ksplit,
+                                                               const double* __restrict__ W, double* __restrict__ P) {
+  __shared__ double red[4][9][256];
+  const int nt3 = (ntile + 2) / 3;
+  int si = 0, rem = blockIdx.y;                      // (split = fast grid dimension: see k_schur_syrk)
+  while (rem >= nt3 - si) { rem -= nt3 - si; ++si; }
+  const int sj = si + rem, split = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, rsub = lane >> 4, csub = lane & 15;
+  // rows of this split, a multiple of 4 per wavefront
+  const int per = ((K + ksplit - 1) / ksplit + 4 * SYRK3_WAVES - 1) / (4 * SYRK3_WAVES) * (4 * SYRK3_WAVES);
+  const int pw = per / SYRK3_WAVES, k0 = split * per + wave * pw, k1 = min(K, k0 + pw);
+  int ca[3], cb[3];
+#pragma unroll
+  for (int x = 0; x < 3; ++x) {
+    ca[x] = (3 * si + x) * 16 + csub;
+    cb[x] = (3 * sj + x) * 16 + csub;
+  }
+  double4_t acc[3][3];
+#pragma unroll
+  for (int x = 0; x < 3; ++x)
+#pragma unroll
+    for (int y = 0; y < 3; ++y) acc[x][y] = double4_t{0.0, 0.0, 0.0, 0.0};
+  // Operand loads of four K steps (24 loads) per batch, and the NEXT batch is requested before the 36 MFMAs of the current one
+  // are issued (the wavefront has its SIMD to itself: nothing else would cover the round trip).  The B strips are loaded on
+  // the diagonal too -- same addresses as the A strips, so they hit L1 -- because a wave-uniform `if (!diag)` inside the
+  // unrolled batch made hipcc branch around every group of three loads and drain vmcnt behind each (eight serial round trips
+  // per batch: 16.8 us).
+  // (The loads are RAW reads of clamped addresses; the 0 / 1 masks of rows behind the split and columns behind the matrix are
+  //  applied when a batch is consumed: masked_load's multiply at request time made hipcc wait for the next batch at the end of
+  //  every trip, vmcnt(0).)
+  constexpr int UB = 2;                              // (3: 9.9 instead of 8.7 us at the north-star rig; 4: spills)
+  double av[2][UB][3], bv[2][UB][3];
+  double ma[3], mb[3];
+#pragma unroll
+  for (int x = 0; x < 3; ++x) {
+    ma[x] = ca[x] < ncol ? 1.0 : 0.0;
+    mb[x] = cb[x] < ncol ? 1.0 : 0.0;
+    ca[x] = min(ca[x], ncol - 1);
+    cb[x] = min(cb[x], ncol - 1);
+  }
+  auto request = [&](int buf, int k) {
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const size_t row = (size_t)min(k + 4 * u + rsub, K - 1) * ncol;
+#pragma unroll
+      for (int x = 0; x < 3; ++x) {
+        av[buf][u][x] = W[row + ca[x]];
+        bv[buf][u][x] = W[row + cb[x]];
+      }
+    }
+  };
+  // (The diagonal / off-diagonal choice is made ONCE around the whole loop: as a wave-uniform branch inside multiply() it made
+  //  the 72 accumulator registers phi nodes of every batch -- 503 v_accvgpr_mov per trip, each waiting for the MFMA that wrote
+  //  its source: 31 us at 16 cameras x 5 boards.)
+  auto run = [&](auto diag_tag) {
+    constexpr bool DIAGB = decltype(diag_tag)::value;
+    auto multiply = [&](int buf, int k) {
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const double mk = (k + 4 * u + rsub < k1) ? 1.0 : 0.0;
+        double a[3], b[3];
+#pragma unroll
+        for (int x = 0; x < 3; ++x) {
+          a[x] = av[buf][u][x] * (mk * ma[x]);
+          b[x] = bv[buf][u][x] * mb[x];
+        }
+#pragma unroll
+        for (int x = 0; x < 3; ++x)
+#pragma unroll
+          for (int y = DIAGB ? x : 0; y < 3; ++y)   // (the three tiles below the diagonal of a diagonal block are never stored)
+            acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[y], acc[x][y], 0, 0, 0);
+      }
+    };
+    request(0, k0);
+    int k = k0;
+    // two batches per trip (the buffer index stays a compile-time constant), an odd last batch behind the loop: a `break` in
+    // the middle of the trip made hipcc keep the accumulators in VGPRs and copy all 72 to the AGPRs and back in every trip
+    for (; k + 4 * UB < k1; k += 8 * UB) {
+      // (scheduling barriers: left alone, hipcc moves both requests of a trip to its top and all MFMAs behind one vmcnt(0))
+      request(1, k + 4 * UB);
+      __builtin_amdgcn_sched_barrier(0);
+      multiply(0, k);
+      __builtin_amdgcn_sched_barrier(0);
+      request(0, k + 8 * UB);
+      __builtin_amdgcn_sched_barrier(0);
+      multiply(1, k + 4 * UB);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (k < k1) multiply(0, k);
+  };
+  if (si == sj) run(std::true_type{});
+  else run(std::false_type{});
+  // fold the four wavefronts through LDS: every thread sums the four partials of its elements in a fixed order
+#pragma unroll
+  for (int x = 0; x < 3; ++x)
+#pragma unroll
+    for (int y = 0; y < 3; ++y)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave][3 * x + y][(rsub + 4 * r) * 16 + csub] = acc[x][y][r];
+  __syncthreads();
+  const int nt2 = ntile * (ntile + 1) / 2;
+  for (int e = tid; e < 9 * 256; e += SYRK3_THREADS) {
+    const int t9 = e >> 8, el = e & 255, ti = 3 * si + t9 / 3, tj = 3 * sj + t9 % 3;
+    if (ti > tj || tj >= ntile) continue;            // (lower tile of a diagonal block / padding behind the last strip)
+    const int tile = ti * ntile - (ti * (ti - 1)) / 2 + (tj - ti);
+    P[((size_t)split * nt2 + tile) * 256 + el] = (red[0][t9][el] + red[1][t9][el]) + (red[2][t9][el] + red[3][t9][el]);
   }
 }
 

@@ -1,13 +1,14 @@
-# per-kernel average durations of the evaluation step: bash profiles/scripts/kstats.sh <tag> [env assignments ...]
-R=$GRAFT_REPO_ROOT; T=$1; shift; O=$R/gpurun_out/ks_$T; mkdir -p $O
+# kernel statistics of a long solve: bash profiles/scripts/kstats.sh <tag> <cfg> [ENV=VAL ...]   -> gpurun_out/ks/<tag>.txt
+R=$GRAFT_REPO_ROOT; TAG=$1; CFG=$2; shift 2
+O=$R/gpurun_out/ks; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-env "$@" rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o trace -- python $R/bench.py --steps 300 --warmup 20 --no-cpu-baseline --no-solve > $O/bench.json 2> $O/bench.err
+env "$@" PYTHONPATH=$R:$R/tests rocprofv3 --kernel-trace --stats --output-format csv -d $O/$TAG -o solve -- python $R/tests/prof_cfg.py $CFG > $O/$TAG.log 2>&1
 python - <<PY
 import csv, glob
-f = glob.glob("$O/trace/**/*kernel_stats.csv", recursive=True)[0]
-for r in csv.DictReader(open(f)):
-  n = r["Name"]
-  if "mcba" in n and int(r["Calls"]) > 100: print("$T", n.split("(")[0][-40:], r["Calls"], round(float(r["AverageNs"]) / 1e3, 2))
+f = glob.glob("$O/$TAG/**/solve_kernel_stats.csv", recursive=True)[0]
+rows = list(csv.DictReader(open(f)))
+with open("$O/$TAG.txt", "w") as out:
+    for r in rows[:22]:
+        line = "%-60s calls %5s avg %8.1f us" % (r["Name"].split("(")[0][-60:], r["Calls"], float(r["AverageNs"]) / 1e3)
+        print(line); out.write(line + "\n")
 PY
-grep -o '"ms_per_step": [0-9.]*' $O/bench.json | head -1
-cd $R
