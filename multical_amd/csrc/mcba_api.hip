@@ -1794,10 +1794,16 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
   float lin_ms_total = 0.f;
   // dx: linearise at that parameter vector (tables prepared by k_tmat itself); nullptr: the pose tables already hold the
   // point (the trial step's k_prep)
+  // Only the FIRST linearisation of a solve is timed (result->linearize_seconds): an event record is a barrier packet in the
+  // queue, and the two around every later linearisation cost 5 us between k_vec_step and k_linearize and 4.5 us between
+  // k_linearize and k_assemble in every LM iteration (gaps in the rocprofv3 kernel trace of a long solve).
+  bool lin_timed = false;
   auto timed_linearize = [&](const double* dx) {
-    HIP_OK(hipEventRecord(h->ev0, h->stream));
+    const bool timing = !lin_timed;
+    lin_timed = true;
+    if (timing) HIP_OK(hipEventRecord(h->ev0, h->stream));
     launch_linearize(h, dx);
-    HIP_OK(hipEventRecord(h->ev1, h->stream));
+    if (timing) HIP_OK(hipEventRecord(h->ev1, h->stream));
     launch_assemble(h);
   };
   auto collect_lin_time = [&]() {
