@@ -78,7 +78,7 @@ struct ResourceCache {
   static constexpr size_t HOST_BYTES_MAX = 64ull << 20;
   std::mutex m;
   std::multimap<std::pair<int, size_t>, void*> dev, host;   // (device, bytes) -> pointer
-  std::vector<std::pair<int, hipStream_t>> streams;
+  std::vector<std::pair<int, hipStream_t>> streams, side_streams;
   size_t dev_bytes = 0, host_bytes = 0;
   static int device() {
     int d = 0;
@@ -110,21 +110,26 @@ struct ResourceCache {
   void* take_host(size_t bytes) { return take(host, host_bytes, bytes); }
   bool park_dev(void* p, size_t bytes) { return park(dev, dev_bytes, cache_bytes_max(), p, bytes); }
   bool park_host(void* p, size_t bytes) { return cache_bytes_max() > 0 && park(host, host_bytes, HOST_BYTES_MAX, p, bytes); }
-  hipStream_t take_stream() {
+  // (side = the non-blocking second stream of a handle, which carries the trial cost beside the speculative linearisation:
+  //  its own pool -- the main stream must stay a blocking stream, the synchronous copies of the API rely on that.  Creating
+  //  it anew cost every mcba_create 2-3 ms.)
+  hipStream_t take_stream(bool side = false) {
     std::lock_guard<std::mutex> lock(m);
+    auto& pool = side ? side_streams : streams;
     const int d = device();
-    for (size_t i = 0; i < streams.size(); ++i)
-      if (streams[i].first == d) {
-        hipStream_t s = streams[i].second;
-        streams.erase(streams.begin() + i);
+    for (size_t i = 0; i < pool.size(); ++i)
+      if (pool[i].first == d) {
+        hipStream_t s = pool[i].second;
+        pool.erase(pool.begin() + i);
         return s;
       }
     return nullptr;
   }
-  bool park_stream(hipStream_t s) {
+  bool park_stream(hipStream_t s, bool side = false) {
     std::lock_guard<std::mutex> lock(m);
-    if (streams.size() >= 4 || cache_bytes_max() == 0) return false;
-    streams.push_back({park_device() >= 0 ? park_device() : device(), s});
+    auto& pool = side ? side_streams : streams;
+    if (pool.size() >= 4 || cache_bytes_max() == 0) return false;
+    pool.push_back({park_device() >= 0 ? park_device() : device(), s});
     return true;
   }
   void clear() {
@@ -132,7 +137,8 @@ struct ResourceCache {
     for (auto& e : dev) (void)hipFree(e.second);
     for (auto& e : host) (void)hipHostFree(e.second);
     for (auto& e : streams) (void)hipStreamDestroy(e.second);
-    dev.clear(); host.clear(); streams.clear();
+    for (auto& e : side_streams) (void)hipStreamDestroy(e.second);
+    dev.clear(); host.clear(); streams.clear(); side_streams.clear();
     dev_bytes = host_bytes = 0;
   }
 };
@@ -339,7 +345,7 @@ struct mcba_handle_s {
     if (ev1) (void)hipEventDestroy(ev1);
     if (ev_fetch) (void)hipEventDestroy(ev_fetch);
     if (ev_side) (void)hipEventDestroy(ev_side);
-    if (stream2) (void)hipStreamDestroy(stream2);
+    if (stream2 && !(g_park_on_release && resource_cache().park_stream(stream2, true))) (void)hipStreamDestroy(stream2);
     if (eval_graph) (void)hipGraphExecDestroy(eval_graph);
     if (rccl_comm) destroy_rccl_comm(rccl_comm);
     if (own_stream && stream && !(g_park_on_release && resource_cache().park_stream(stream))) (void)hipStreamDestroy(stream);
@@ -1152,7 +1158,8 @@ int32_t mcba_create(const mcba_problem* p, void* hip_stream, mcba_handle* out) {
   HIP_OK(hipEventCreate(&h->ev1));
   HIP_OK(hipEventCreateWithFlags(&h->ev_fetch, hipEventDisableTiming));
   HIP_OK(hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming));
-  HIP_OK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+  h->stream2 = resource_cache().take_stream(true);
+  if (h->stream2 == nullptr) HIP_OK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
   {   // the tables of the initial point: the camera table's constant part (image height, fix_aspect) and the board points
       // when they are not optimised are only ever written here (the fused k_linearize reads them, nothing refreshes them)
     for (int j = 0; j < d.nfull; ++j)
