@@ -298,6 +298,8 @@ struct mcba_handle_s {
   DevBuf<double> x, xnew, scale_inv, dsc, gh, gn, scal, costpart, Lf, W, yf, P, sbuf, ps;
   DevBuf<int32_t> info;
   double* h_scal = nullptr;   // pinned
+  unsigned long long* h_pub_seq = nullptr;   // pinned: sequence number of the last k_publish (see there)
+  unsigned long long pub_seq = 0;
   double* h_x = nullptr;      // pinned staging of x uploads [n]
   double* h_gbuf = nullptr;   // pinned landing zone of [g | diag | cost, count]
   int ntile = 0, ksplit = 1, cost_blocks = 1;
@@ -338,6 +340,7 @@ struct mcba_handle_s {
   size_t h_scal_bytes = 0, h_x_bytes = 0, h_gbuf_bytes = 0, h_totals_bytes = 0;   // sizes of the pinned buffers
   ~mcba_handle_s() {
     pinned_free(h_scal, h_scal_bytes);
+    pinned_free(h_pub_seq, 64);
     pinned_free(h_x, h_x_bytes);
     pinned_free(h_gbuf, h_gbuf_bytes);
     pinned_free(h_totals, h_totals_bytes);
@@ -651,6 +654,27 @@ void fetch_scalars_end(mcba_handle_s* h) {
   check_launch("iteration enqueue");
   HIP_OK(hipEventSynchronize(h->ev_fetch));
 }
+double now_seconds() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+// k_publish form of the fetch: scal[0, count) and a sequence number go to pinned host memory from a kernel on `st`; the host
+// spins on the number (falls back to a stream synchronisation after 20 ms: a failed launch must not hang the caller)
+void publish_scalars_begin(mcba_handle_s* h, int count, hipStream_t st) {
+  ++h->pub_seq;
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, st, h->scal.p, h->h_scal, count, h->h_pub_seq, h->pub_seq);
+}
+void publish_scalars_end(mcba_handle_s* h, hipStream_t st) {
+  check_launch("iteration enqueue");
+  const double t0 = now_seconds();
+  int spins = 0;
+  while (__atomic_load_n(h->h_pub_seq, __ATOMIC_ACQUIRE) != h->pub_seq) {
+    if ((++spins & 1023) == 0 && now_seconds() - t0 > 0.02) {
+      HIP_OK(hipStreamSynchronize(st));
+      REQUIRE(__atomic_load_n(h->h_pub_seq, __ATOMIC_ACQUIRE) == h->pub_seq, "the published scalars did not arrive");
+      break;
+    }
+  }
+}
 double host_sum(const double* p, int n) {   // fixed order: the result does not depend on block scheduling
   double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
   int i = 0;
@@ -943,10 +967,6 @@ void select_ranks_multi(mcba_handle_s* h, const uint8_t* m2, int nsel, const lon
   }
 }
 
-double now_seconds() {
-  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
-}
-
 }  // namespace
 
 // =================================================================================================================
@@ -1152,6 +1172,8 @@ int32_t mcba_create(const mcba_problem* p, void* hip_stream, mcba_handle* out) {
   h->h_x_bytes = std::max<size_t>(d.n, 1) * sizeof(double);
   h->h_gbuf_bytes = (2 * (size_t)d.n + 2) * sizeof(double);
   h->h_scal = (double*)pinned_alloc(h->h_scal_bytes);
+  h->h_pub_seq = (unsigned long long*)pinned_alloc(64);
+  *h->h_pub_seq = 0;
   h->h_x = (double*)pinned_alloc(h->h_x_bytes);
   h->h_gbuf = (double*)pinned_alloc(h->h_gbuf_bytes);
   HIP_OK(hipEventCreate(&h->ev0));
@@ -1841,7 +1863,9 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
     }
   };
   static const bool merge_off = getenv("MCBA_NO_MERGED_TRIAL_COST") != nullptr && getenv("MCBA_NO_MERGED_TRIAL_COST")[0] == '1';
-  const bool merged_trial_cost = h->allreduce != nullptr && !merge_off;
+  // (MCBA_FORCE_MERGED_TRIAL_COST=1: experiment -- a single GPU takes the trial cost from the speculative linearisation as well)
+  static const bool merge_force = getenv("MCBA_FORCE_MERGED_TRIAL_COST") != nullptr && getenv("MCBA_FORCE_MERGED_TRIAL_COST")[0] == '1';
+  const bool merged_trial_cost = (h->allreduce != nullptr || merge_force) && !merge_off;
   auto fold_trial = [&](double* step_h2, double* step2, double* x2) {   // after a fetch that covers [sl.step, ...)
     double s3[3] = {0, 0, 0};
     for (int blk = 0; blk < sl.nvb; ++blk)
@@ -1866,14 +1890,21 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
     bool spec_lin = false;
     // ---- enqueue: gradient scaling, Cauchy curvature (+ on a single GPU the whole step and its trial evaluation) ----
     // k_vec_scale also forwards {cost, count} of the linearisation into scal[TR_COST, TR_COUNT]
-    hipLaunchKernelGGL(k_vec_scale, dim3(sl.nvb), dim3(256), 0, h->stream, d, h->x.p, h->g(), h->diag(), h->scale_inv.p,
-                       h->dsc.p, h->gh.p, first ? 1 : 0, h->scal.p + sl.vs, h->costcount(), h->scal.p + TR_COST);
+    static const bool split_q00 = getenv("MCBA_SPLIT_Q00") != nullptr && getenv("MCBA_SPLIT_Q00")[0] == '1';
+    if (finishing || split_q00)
+      hipLaunchKernelGGL(k_vec_scale, dim3(sl.nvb), dim3(256), 0, h->stream, d, h->x.p, h->g(), h->diag(), h->scale_inv.p,
+                         h->dsc.p, h->gh.p, first ? 1 : 0, h->scal.p + sl.vs, h->costcount(), h->scal.p + TR_COST);
     bool have_trial = false;
     if (finishing) {
       fetch_scalars(h, sl.q00p);
     } else {
-      hipLaunchKernelGGL(k_q00, dim3(Q00_BLOCKS), dim3(256), 0, h->stream, d, h->Hss.p, h->Hfs.p, h->Hff.p, h->dsc.p,
-                         h->gh.p, h->scal.p + sl.q00p);
+      if (split_q00)
+        hipLaunchKernelGGL(k_q00, dim3(Q00_BLOCKS), dim3(256), 0, h->stream, d, h->Hss.p, h->Hfs.p, h->Hff.p, h->dsc.p,
+                           h->gh.p, h->scal.p + sl.q00p);
+      else   // gradient scaling and Cauchy curvature in one launch (the curvature forms its scaled gradient on the fly)
+        hipLaunchKernelGGL(k_vec_scale_q00, dim3(sl.nvb + Q00_BLOCKS), dim3(256), 0, h->stream, d, h->x.p, h->g(), h->diag(),
+                           h->scale_inv.p, h->dsc.p, h->gh.p, first ? 1 : 0, h->scal.p + sl.vs, h->costcount(),
+                           h->scal.p + TR_COST, sl.nvb, h->Hss.p, h->Hfs.p, h->Hff.p, h->scal.p + sl.q00p);
       if (h->allreduce) {   // one double crosses the ranks, not the 512 per-block partials
         hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(64), 0, h->stream, h->scal.p + sl.q00p, Q00_BLOCKS);
         call_allreduce(h, h->scal.p + sl.q00p, 1, 0);
@@ -1886,14 +1917,19 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
       // of every iteration's critical path at the north-star rig); the host still decides on the trial cost alone.
       const bool spec_tables_ready = (linearize_fused_mode() == 2 || getenv("MCBA_FUSED") == nullptr) && d.off_boards < 0 && h->use_mfma;
       static const bool side_off = getenv("MCBA_NO_SIDE_COST") != nullptr && getenv("MCBA_NO_SIDE_COST")[0] == '1';
-      const bool side_cost = !h->allreduce && spec_tables_ready && !side_off;
+      const bool side_cost = !h->allreduce && spec_tables_ready && !side_off && !merged_trial_cost;
+      static const bool publish = !(getenv("MCBA_NO_PUBLISH") != nullptr && getenv("MCBA_NO_PUBLISH")[0] == '1');
       enqueue_trial(0.0, 0.0, h->scal.p, !merged_trial_cost && !side_cost);
       if (side_cost) {
         HIP_OK(hipEventRecord(h->ev_side, h->stream));
         HIP_OK(hipStreamWaitEvent(h->stream2, h->ev_side, 0));
         h->ops->cost(d, h->t, h->stream2, h->scal.p + sl.costp, cost_grid);
-        HIP_OK(hipMemcpyAsync(h->h_scal, h->scal.p, trial_fetch_end * sizeof(double), hipMemcpyDeviceToHost, h->stream2));
-        HIP_OK(hipEventRecord(h->ev_fetch, h->stream2));
+        if (publish) {
+          publish_scalars_begin(h, trial_fetch_end, h->stream2);
+        } else {
+          HIP_OK(hipMemcpyAsync(h->h_scal, h->scal.p, trial_fetch_end * sizeof(double), hipMemcpyDeviceToHost, h->stream2));
+          HIP_OK(hipEventRecord(h->ev_fetch, h->stream2));
+        }
       } else if (!merged_trial_cost) {
         fetch_scalars_begin(h, trial_fetch_end);
       }
@@ -1910,7 +1946,8 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
         fetch_scalars_begin(h, trial_fetch_end);
       }
       mark("iteration enqueued");
-      fetch_scalars_end(h);
+      if (side_cost && publish) publish_scalars_end(h, h->stream2);
+      else fetch_scalars_end(h);
       mark("trial cost fetched");
       have_trial = true;
     }

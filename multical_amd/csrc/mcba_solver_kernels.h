@@ -678,6 +678,78 @@ __global__ __launch_bounds__(256) void k_q00(Dims d, const double* __restrict__ 
   if (threadIdx.x == 0) partial[blockIdx.x] = r;
 }
 
+// k_vec_scale and k_q00 in ONE launch (round 3): the Cauchy curvature g_h^T H_h g_h needs w_i = g_i / s_i^2 of every parameter,
+// and s_i = max(sqrt(diag_i), previous scale_i) is three loads and a square root away from the linearisation's [g | diag] --
+// nothing k_vec_scale produces.  Blocks [0, nvb) are k_vec_scale, the rest k_q00 with w formed on the fly (the same operations
+// in the same order: bit-identical sums).  The race on scale_inv is benign: the vec_scale blocks replace scale_i by
+// max(sqrt(diag_i), scale_i), and max(sqrt(diag_i), .) of the old and of the new value coincide.  One launch and one dependent
+// kernel boundary less in every LM iteration (k_vec_scale 5.9 us + gap at the north-star rig).
+__global__ __launch_bounds__(256) void k_vec_scale_q00(Dims d, const double* __restrict__ x, const double* __restrict__ g,
+                                                       const double* __restrict__ diag, double* scale_inv,
+                                                       double* __restrict__ dsc, double* __restrict__ gh, int first,
+                                                       double* __restrict__ part, const double* __restrict__ cost_count,
+                                                       double* __restrict__ cost_out, int nvb, const double* __restrict__ Hss,
+                                                       const double* __restrict__ Hfs, const double* __restrict__ Hff,
+                                                       double* __restrict__ partial) {
+  __shared__ double scratch[16];
+  if ((int)blockIdx.x < nvb) {
+    double mx = 0, gg = 0, xs = 0;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < d.n) {
+      double si = sqrt(diag[i]);
+      if (first) { if (si == 0.0) si = 1.0; }
+      else si = fmax(si, scale_inv[i]);
+      scale_inv[i] = si;
+      const double di = 1.0 / si;
+      dsc[i] = di;
+      const double gi = g[i];
+      gh[i] = di * gi;
+      mx = fabs(gi);
+      gg = di * gi * di * gi;
+      xs = x[i] * si * x[i] * si;
+    }
+    const double a = block_reduce<true>(mx, scratch);
+    const double b = block_reduce<false>(gg, scratch);
+    const double c = block_reduce<false>(xs, scratch);
+    if (threadIdx.x == 0) {
+      part[3 * blockIdx.x + 0] = a;
+      part[3 * blockIdx.x + 1] = b;
+      part[3 * blockIdx.x + 2] = c;
+      if (blockIdx.x == 0 && cost_count) { cost_out[0] = cost_count[0]; cost_out[1] = cost_count[1]; }
+    }
+    return;
+  }
+  auto w_of = [&](int xi) {
+    double si = sqrt(diag[xi]);
+    if (first) { if (si == 0.0) si = 1.0; }
+    else si = fmax(si, scale_inv[xi]);
+    const double di = 1.0 / si;
+    return di * (di * g[xi]);
+  };
+  const int qb = (int)blockIdx.x - nvb, nqb = (int)gridDim.x - nvb;
+  const int ns = d.ns, DF = d.DF;
+  const int stride = nqb * blockDim.x, t0 = qb * blockDim.x + threadIdx.x;
+  double q = 0.0;
+  const int rows = DF > 0 ? d.Fl * DF : 0;
+  for (int e = t0; e < rows * ns; e += stride) {
+    const int row = e / ns, s = e - row * ns;
+    const int xi = d.frame_to_x(d.f0 + row / DF, row % DF), xs = d.shared_to_x(s);
+    q += 2.0 * w_of(xi) * Hfs[e] * w_of(xs);
+  }
+  for (int e = t0; e < rows * DF; e += stride) {
+    const int row = e / DF, d2 = e - row * DF, f = d.f0 + row / DF;
+    const int xi = d.frame_to_x(f, row % DF), xj = d.frame_to_x(f, d2);
+    q += w_of(xi) * Hff[e] * w_of(xj);
+  }
+  for (int e = t0; e < ns * ns; e += stride) {
+    const int i = e / ns, j = e - i * ns;
+    const int xi = d.shared_to_x(i), xj = d.shared_to_x(j);
+    q += w_of(xi) * Hss[e] * w_of(xj);
+  }
+  const double r = block_reduce<false>(q, scratch);
+  if (threadIdx.x == 0) partial[qb] = r;
+}
+
 // out[0..2] = {u0.u0, u0.u1, u1.u1} over the full (replicated) vectors
 __global__ void k_dots3(int n, const double* __restrict__ u0, const double* __restrict__ u1, double* __restrict__ out,
                         const int* __restrict__ info = nullptr) {
@@ -2400,6 +2472,18 @@ __global__ __launch_bounds__(256) void k_vec_step(Dims d, Tables t, const double
     part[3 * blockIdx.x + 1] = b;
     part[3 * blockIdx.x + 2] = c;
   }
+}
+
+// The scalars the HOST waits for in every LM iteration (trust-region results, step norms, trial-cost partials) written straight
+// into its pinned memory, followed by a sequence number with system-scope release: the driver spins on that word instead of
+// waiting for a device-to-host copy + event (which delivered the trial cost ~75 us after k_vec_step although k_cost was done
+// after ~45: the host then enqueued the next iteration a few microseconds too late, 10 us of dispatch gaps per iteration).
+__global__ __launch_bounds__(256) void k_publish(const double* __restrict__ scal, double* __restrict__ host_dst, int n,
+                                                 unsigned long long* host_seq, unsigned long long seq) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) host_dst[i] = scal[i];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __global__ __launch_bounds__(64) void k_fold_partials(double* __restrict__ part, int n) {
