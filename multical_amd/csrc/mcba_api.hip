@@ -296,6 +296,7 @@ struct mcba_handle_s {
   int nchunk = 1;
   // solver state
   DevBuf<double> x, xnew, scale_inv, dsc, gh, gn, scal, costpart, Lf, W, yf, P, sbuf, ps;
+  DevBuf<double> scale_inv2, dsc2, gh2;   // scaling of a trial point, computed speculatively (mcba_solve) and swapped in on acceptance
   DevBuf<int32_t> info;
   double* h_scal = nullptr;   // pinned
   unsigned long long* h_pub_seq = nullptr;   // pinned: sequence number of the last k_publish (see there)
@@ -592,7 +593,9 @@ void launch_linearize(mcba_handle_s* h, const double* dx) {
   h->ops->linearize(d, h->t, h->stream, h->rec.p, h->tri.p, h->use_mfma, h->lin_grid, nullptr, nullptr, 0, nullptr, 0);
 }
 
-void launch_assemble(mcba_handle_s* h) {
+// publish_seq != 0: the kernel that forms the cost of the linearisation also writes it to h_scal[cost_slot] (pinned) and then
+// the sequence number to h_pub_seq (publish_cost)
+void launch_assemble(mcba_handle_s* h, unsigned long long publish_seq = 0, int cost_slot = 0) {
   const Dims& d = h->d;
   // ([g | diag | cost] and H_ss were zeroed by k_tmat at the start of this linearisation)
   const int nfb = (d.DF > 0) ? d.Fl : 0;
@@ -615,10 +618,12 @@ void launch_assemble(mcba_handle_s* h) {
     static const bool force_big = getenv("MCBA_SHARED_FINAL_BIG") != nullptr && getenv("MCBA_SHARED_FINAL_BIG")[0] == '1';
     if (npair <= SHARED_FINAL_MAX_PAIRS && !force_big)   // pair sums in LDS
       hipLaunchKernelGGL(k_shared_final, dim3((d.rec_size + 2 + 63) / 64), dim3(64 * pg), (size_t)npair * 64 * sizeof(double),
-                         h->stream, d, h->partial.p, h->nchunk, h->tri.p, h->Hss.p, h->g(), h->diag(), h->costcount());
+                         h->stream, d, h->partial.p, h->nchunk, h->tri.p, h->Hss.p, h->g(), h->diag(), h->costcount(),
+                         publish_seq ? h->h_scal + cost_slot : nullptr, h->h_pub_seq, publish_seq);
     else                                                 // more (camera, board) pairs than the LDS table holds
       hipLaunchKernelGGL(k_shared_final_big, dim3((d.rec_size + 2 + 63) / 64, (npair + 15) / 16), dim3(1024), 0, h->stream, d,
-                         h->partial.p, h->nchunk, h->tri.p, h->Hss.p, h->g(), h->diag(), h->costcount());
+                         h->partial.p, h->nchunk, h->tri.p, h->Hss.p, h->g(), h->diag(), h->costcount(),
+                         publish_seq ? h->h_scal + cost_slot : nullptr, h->h_pub_seq, publish_seq);
     check_launch("k_shared_final");
   }
   if (d.off_boards >= 0) {   // adjusted board points: their blocks of H_ss / H_fs / g (unique entries, plain stores)
@@ -1143,7 +1148,8 @@ int32_t mcba_create(const mcba_problem* p, void* hip_stream, mcba_handle* out) {
   h->Hfs.alloc((size_t)d.Fl * d.DF * d.ns);
   h->Hff.alloc((size_t)d.Fl * d.DF * d.DF);
   h->gbuf.alloc(2 * (size_t)d.n + 2);
-  for (DevBuf<double>* b : {&h->x, &h->xnew, &h->scale_inv, &h->dsc, &h->gh, &h->gn}) b->alloc((size_t)d.n);
+  for (DevBuf<double>* b : {&h->x, &h->xnew, &h->scale_inv, &h->dsc, &h->gh, &h->gn, &h->scale_inv2, &h->dsc2, &h->gh2})
+    b->alloc((size_t)d.n);
   h->sl.init(d.n, d.Fl + 2);
   h->scal.alloc((size_t)h->sl.total);
   h->cost_blocks = std::max(1, std::min(COST_BLOCKS_MAX, d.views()));
@@ -1827,13 +1833,13 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
   // queue, and the two around every later linearisation cost 5 us between k_vec_step and k_linearize and 4.5 us between
   // k_linearize and k_assemble in every LM iteration (gaps in the rocprofv3 kernel trace of a long solve).
   bool lin_timed = false;
-  auto timed_linearize = [&](const double* dx) {
+  auto timed_linearize = [&](const double* dx, unsigned long long publish_seq = 0, int cost_slot = 0) {
     const bool timing = !lin_timed;
     lin_timed = true;
     if (timing) HIP_OK(hipEventRecord(h->ev0, h->stream));
     launch_linearize(h, dx);
     if (timing) HIP_OK(hipEventRecord(h->ev1, h->stream));
-    launch_assemble(h);
+    launch_assemble(h, publish_seq, cost_slot);
   };
   auto collect_lin_time = [&]() {
     float ms = 0.f;
@@ -1852,9 +1858,10 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
   // with_cost = false (sharded handles, first trial of an iteration): no k_cost pass and no 1-double all-reduce -- the
   // speculative linearisation at x_new that follows delivers the cost of the very same point inside its own
   // [g | diag | cost] message (one dependent collective less per accepted iteration)
-  auto enqueue_trial = [&](double alpha, double beta, double* tr_dev, bool with_cost = true) {
+  auto enqueue_trial = [&](double alpha, double beta, double* tr_dev, bool with_cost = true, bool to_host = false) {
     hipLaunchKernelGGL(k_vec_step, dim3(sl.nvb + prep_blocks), dim3(256), 0, h->stream, d, h->t, h->x.p, h->dsc.p, h->gh.p,
-                       h->gn.p, alpha, beta, h->xnew.p, h->scal.p + sl.step, tr_dev, h->scal.p + sl.dotp, dot_blocks, sl.nvb);
+                       h->gn.p, alpha, beta, h->xnew.p, h->scal.p + sl.step, tr_dev, h->scal.p + sl.dotp, dot_blocks, sl.nvb,
+                       to_host ? h->h_scal : nullptr, to_host ? h->h_scal + sl.step : nullptr);
     if (!with_cost) return;
     h->ops->cost(d, h->t, h->stream, h->scal.p + sl.costp, cost_grid);   // (an empty shard writes partial[0] = 0)
     if (h->allreduce) {
@@ -1866,18 +1873,29 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
   // (MCBA_FORCE_MERGED_TRIAL_COST=1: experiment -- a single GPU takes the trial cost from the speculative linearisation as well)
   static const bool merge_force = getenv("MCBA_FORCE_MERGED_TRIAL_COST") != nullptr && getenv("MCBA_FORCE_MERGED_TRIAL_COST")[0] == '1';
   const bool merged_trial_cost = (h->allreduce != nullptr || merge_force) && !merge_off;
-  auto fold_trial = [&](double* step_h2, double* step2, double* x2) {   // after a fetch that covers [sl.step, ...)
+  auto fold_trial = [&](double* step_h2, double* step2, double* x2, int n_cost) {   // after a fetch that covers [sl.step, ...)
     double s3[3] = {0, 0, 0};
     for (int blk = 0; blk < sl.nvb; ++blk)
       for (int k = 0; k < 3; ++k) s3[k] += S[sl.step + 3 * blk + k];
     *step_h2 = s3[0]; *step2 = s3[1]; *x2 = s3[2];
-    return host_sum(S + sl.costp, cost_fetch);
+    return host_sum(S + sl.costp, n_cost);
   };
   const int trial_fetch_end = sl.costp + cost_fetch;
 
   timed_linearize(h->x.p);
   int nfev = 1, njev = 1, iteration = 0, status = -100;
   bool first = true, fresh_lin = true, lin_stale = false;
+  // Speculative acceptance (single GPU, table-fed fused linearisation): NO trial-cost kernel on the path of an accepted step.
+  // k_vec_step publishes its scalars to pinned host memory, the speculative linearisation at x_new delivers the cost of x_new
+  // (k_shared_final writes it + a sequence number to the host), and the gradient scaling + Cauchy curvature of x_new are
+  // enqueued behind it into the second set of scaling buffers BEFORE the host has decided: they run while the host folds,
+  // updates the radius and enqueues the solve of the next iteration.  An accepted step swaps the buffer sets; a rejected one
+  // leaves them behind and goes through the retry path (k_cost, stream-ordered fetch) as before.  Against the side-stream
+  // form: k_linearize is not slowed by a concurrent k_cost (58 -> 49 us), no event packet between k_vec_step and
+  // k_linearize (7 us), no copy.  MCBA_SPEC_ACCEPT=0 restores the side-stream form.
+  static const bool spec_accept_off = getenv("MCBA_SPEC_ACCEPT") != nullptr && getenv("MCBA_SPEC_ACCEPT")[0] == '0';
+  bool scaled_ahead = false;     // the scaling / curvature of h->x are already in place (computed speculatively, swapped in)
+  int trial_cost_values = cost_fetch;
   double cost = 0, Delta = 0, step_norm = NaN, actual_reduction = NaN, g_norm = 0, initial_cost = 0;
 
   while (true) {
@@ -1887,23 +1905,27 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
       timed_linearize(h->x.p);
       lin_stale = false;
     }
-    bool spec_lin = false;
+    bool spec_lin = false, spec_scaled = false;
     // ---- enqueue: gradient scaling, Cauchy curvature (+ on a single GPU the whole step and its trial evaluation) ----
     // k_vec_scale also forwards {cost, count} of the linearisation into scal[TR_COST, TR_COUNT]
     static const bool split_q00 = getenv("MCBA_SPLIT_Q00") != nullptr && getenv("MCBA_SPLIT_Q00")[0] == '1';
-    if (finishing || split_q00)
+    const bool scaled = scaled_ahead;   // (k_vec_scale's partials of this very point are in scal[sl.vs ..) already)
+    scaled_ahead = false;
+    if (scaled) {
+    } else if (finishing || split_q00)
       hipLaunchKernelGGL(k_vec_scale, dim3(sl.nvb), dim3(256), 0, h->stream, d, h->x.p, h->g(), h->diag(), h->scale_inv.p,
                          h->dsc.p, h->gh.p, first ? 1 : 0, h->scal.p + sl.vs, h->costcount(), h->scal.p + TR_COST);
     bool have_trial = false;
     if (finishing) {
       fetch_scalars(h, sl.q00p);
     } else {
-      if (split_q00)
+      if (scaled) {
+      } else if (split_q00)
         hipLaunchKernelGGL(k_q00, dim3(Q00_BLOCKS), dim3(256), 0, h->stream, d, h->Hss.p, h->Hfs.p, h->Hff.p, h->dsc.p,
                            h->gh.p, h->scal.p + sl.q00p);
       else   // gradient scaling and Cauchy curvature in one launch (the curvature forms its scaled gradient on the fly)
         hipLaunchKernelGGL(k_vec_scale_q00, dim3(sl.nvb + Q00_BLOCKS), dim3(256), 0, h->stream, d, h->x.p, h->g(), h->diag(),
-                           h->scale_inv.p, h->dsc.p, h->gh.p, first ? 1 : 0, h->scal.p + sl.vs, h->costcount(),
+                           h->scale_inv.p, h->scale_inv.p, h->dsc.p, h->gh.p, first ? 1 : 0, h->scal.p + sl.vs, h->costcount(),
                            h->scal.p + TR_COST, sl.nvb, h->Hss.p, h->Hfs.p, h->Hff.p, h->scal.p + sl.q00p);
       if (h->allreduce) {   // one double crosses the ranks, not the 512 per-block partials
         hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(64), 0, h->stream, h->scal.p + sl.q00p, Q00_BLOCKS);
@@ -1919,6 +1941,22 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
       static const bool side_off = getenv("MCBA_NO_SIDE_COST") != nullptr && getenv("MCBA_NO_SIDE_COST")[0] == '1';
       const bool side_cost = !h->allreduce && spec_tables_ready && !side_off && !merged_trial_cost;
       static const bool publish = !(getenv("MCBA_NO_PUBLISH") != nullptr && getenv("MCBA_NO_PUBLISH")[0] == '1');
+      const bool spec_accept = side_cost && !spec_accept_off;
+      if (spec_accept) {   // (see the declaration of scaled_ahead)
+        enqueue_trial(0.0, 0.0, h->scal.p, false, true);
+        ++h->pub_seq;
+        timed_linearize(nullptr, h->pub_seq, sl.costp);
+        hipLaunchKernelGGL(k_vec_scale_q00, dim3(sl.nvb + Q00_BLOCKS), dim3(256), 0, h->stream, d, h->xnew.p, h->g(), h->diag(),
+                           h->scale_inv.p, h->scale_inv2.p, h->dsc2.p, h->gh2.p, 0, h->scal.p + sl.vs, h->costcount(),
+                           h->scal.p + TR_COST, sl.nvb, h->Hss.p, h->Hfs.p, h->Hff.p, h->scal.p + sl.q00p);
+        spec_lin = true;
+        spec_scaled = true;
+        trial_cost_values = 1;
+        mark("iteration enqueued");
+        publish_scalars_end(h, h->stream);
+        mark("trial cost fetched");
+        have_trial = true;
+      } else {
       enqueue_trial(0.0, 0.0, h->scal.p, !merged_trial_cost && !side_cost);
       if (side_cost) {
         HIP_OK(hipEventRecord(h->ev_side, h->stream));
@@ -1945,11 +1983,13 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
         HIP_OK(hipMemcpyAsync(h->scal.p + sl.costp, h->costcount(), sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         fetch_scalars_begin(h, trial_fetch_end);
       }
+      if (merged_trial_cost) trial_cost_values = 1;
       mark("iteration enqueued");
       if (side_cost && publish) publish_scalars_end(h, h->stream2);
       else fetch_scalars_end(h);
       mark("trial cost fetched");
       have_trial = true;
+      }
     }
     if (fresh_lin) { collect_lin_time(); fresh_lin = false; }
     if (!have_trial) {   // fold the k_vec_scale partials on the host (the vectors are complete on every rank)
@@ -1997,7 +2037,8 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
       }
       have_trial = false;
       double step_h2, step2, x2;
-      cost_new = fold_trial(&step_h2, &step2, &x2);
+      cost_new = fold_trial(&step_h2, &step2, &x2, trial_cost_values);
+      trial_cost_values = cost_fetch;   // (retries evaluate the cost with k_cost)
       const double predicted = S[TR_PRED];
       ++nfev;
       const double step_h_norm = std::sqrt(step_h2);
@@ -2018,6 +2059,12 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
     if (actual_reduction > 0) {
       std::swap(h->x.p, h->xnew.p);
       cost = cost_new;
+      if (spec_valid && spec_scaled) {   // the scaling / curvature computed ahead belong to the accepted point
+        std::swap(h->scale_inv.p, h->scale_inv2.p);
+        std::swap(h->dsc.p, h->dsc2.p);
+        std::swap(h->gh.p, h->gh2.p);
+        scaled_ahead = true;
+      }
       if (!spec_valid) timed_linearize(h->x.p);   // (x now points at the accepted x_new)
       fresh_lin = true;
       ++njev;

@@ -434,11 +434,21 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(Dims d, Tables t, cons
 // only (camera pose / intrinsics columns), on the board only (board pose), on both, or on neither (hand-eye blocks):
 // the thread of the FIRST pair of each equivalence class owns the element, adds the pair sums of its class from LDS in
 // a fixed order and stores -- no atomics, no read-modify-write chains, every element written once.
+// The cost of a linearisation written straight into the host's pinned memory by the ONE thread that forms it, followed by a
+// sequence number with system-scope release (the scalars that earlier kernels of the iteration published the same way landed
+// at their kernel boundaries): the driver of an LM iteration spins on that number -- no copy, no event, no extra launch.
+__device__ __forceinline__ void publish_cost(double val, double* host_cost, unsigned long long* host_seq,
+                                             unsigned long long seq) {
+  host_cost[0] = val;
+  __threadfence_system();
+  __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 constexpr int SHARED_FINAL_MAX_PAIRS = 128;   // pair sums of k_shared_final: [pairs][64] doubles of LDS
 __global__ __launch_bounds__(1024) void k_shared_final(Dims d, const double* __restrict__ partial, int nchunk,
                                                        const uint16_t* __restrict__ tri, double* __restrict__ Hss,
                                                        double* __restrict__ g, double* __restrict__ diag,
-                                                       double* __restrict__ cost_count) {
+                                                       double* __restrict__ cost_count, double* host_cost = nullptr,
+                                                       unsigned long long* host_seq = nullptr, unsigned long long seq = 0) {
   extern __shared__ double pair_sum[];   // [C B][64]
   const int ns = d.ns, NL = d.NL, npose = 6 * d.NPB, npair = d.C * d.B;
   const int el = threadIdx.x & 63, pg = threadIdx.x >> 6, PG = blockDim.x >> 6;
@@ -495,6 +505,7 @@ __global__ __launch_bounds__(1024) void k_shared_final(Dims d, const double* __r
       for (int bb = b0; bb < b1; ++bb) val += pair_sum[(cc * d.B + bb) * 64 + el];
     if (e >= d.rec_size) {
       cost_count[e - d.rec_size] = val;
+      if (host_cost != nullptr && e == d.rec_size) publish_cost(val, host_cost, host_seq, seq);
     } else if (j == NL) {
       g[gi] = val;
     } else {
@@ -512,7 +523,8 @@ __global__ __launch_bounds__(1024) void k_shared_final(Dims d, const double* __r
 __global__ __launch_bounds__(1024) void k_shared_final_big(Dims d, const double* __restrict__ partial, int nchunk,
                                                            const uint16_t* __restrict__ tri, double* __restrict__ Hss,
                                                            double* __restrict__ g, double* __restrict__ diag,
-                                                           double* __restrict__ cost_count) {
+                                                           double* __restrict__ cost_count, double* host_cost = nullptr,
+                                                           unsigned long long* host_seq = nullptr, unsigned long long seq = 0) {
   const int ns = d.ns, NL = d.NL, npose = 6 * d.NPB, npair = d.C * d.B;
   const int el = threadIdx.x & 63, pair = blockIdx.y * 16 + (threadIdx.x >> 6);
   const int e = blockIdx.x * 64 + el;
@@ -558,6 +570,7 @@ __global__ __launch_bounds__(1024) void k_shared_final_big(Dims d, const double*
     }
   if (e >= d.rec_size) {
     cost_count[e - d.rec_size] = val;
+    if (host_cost != nullptr && e == d.rec_size) publish_cost(val, host_cost, host_seq, seq);
   } else if (j == NL) {
     g[gi] = val;
   } else {
@@ -681,12 +694,13 @@ __global__ __launch_bounds__(256) void k_q00(Dims d, const double* __restrict__ 
 // k_vec_scale and k_q00 in ONE launch (round 3): the Cauchy curvature g_h^T H_h g_h needs w_i = g_i / s_i^2 of every parameter,
 // and s_i = max(sqrt(diag_i), previous scale_i) is three loads and a square root away from the linearisation's [g | diag] --
 // nothing k_vec_scale produces.  Blocks [0, nvb) are k_vec_scale, the rest k_q00 with w formed on the fly (the same operations
-// in the same order: bit-identical sums).  The race on scale_inv is benign: the vec_scale blocks replace scale_i by
-// max(sqrt(diag_i), scale_i), and max(sqrt(diag_i), .) of the old and of the new value coincide.  One launch and one dependent
+// in the same order: bit-identical sums).  scale_out may be scale_inv itself (in place): that race is benign -- the vec_scale
+// blocks replace scale_i by max(sqrt(diag_i), scale_i), and max(sqrt(diag_i), .) of the old and of the new value coincide --
+// or another buffer (the speculative scaling of a trial point, adopted by a pointer swap when the step is accepted).  One launch and one dependent
 // kernel boundary less in every LM iteration (k_vec_scale 5.9 us + gap at the north-star rig).
 __global__ __launch_bounds__(256) void k_vec_scale_q00(Dims d, const double* __restrict__ x, const double* __restrict__ g,
-                                                       const double* __restrict__ diag, double* scale_inv,
-                                                       double* __restrict__ dsc, double* __restrict__ gh, int first,
+                                                       const double* __restrict__ diag, const double* scale_inv,
+                                                       double* scale_out, double* __restrict__ dsc, double* __restrict__ gh, int first,
                                                        double* __restrict__ part, const double* __restrict__ cost_count,
                                                        double* __restrict__ cost_out, int nvb, const double* __restrict__ Hss,
                                                        const double* __restrict__ Hfs, const double* __restrict__ Hff,
@@ -699,7 +713,7 @@ __global__ __launch_bounds__(256) void k_vec_scale_q00(Dims d, const double* __r
       double si = sqrt(diag[i]);
       if (first) { if (si == 0.0) si = 1.0; }
       else si = fmax(si, scale_inv[i]);
-      scale_inv[i] = si;
+      scale_out[i] = si;
       const double di = 1.0 / si;
       dsc[i] = di;
       const double gi = g[i];
@@ -2434,7 +2448,8 @@ __global__ __launch_bounds__(256) void k_vec_step(Dims d, Tables t, const double
                                                   const double* __restrict__ dsc, const double* __restrict__ u0,
                                                   const double* __restrict__ u1, double alpha, double beta,
                                                   double* __restrict__ xnew, double* __restrict__ part, double* S,
-                                                  const double* __restrict__ dot_part, int nblk, int nvb) {
+                                                  const double* __restrict__ dot_part, int nblk, int nvb,
+                                                  double* host_S = nullptr, double* host_part = nullptr) {
   __shared__ double scratch[16];
   __shared__ double Sl[TR_NSLOTS];
   if (S != nullptr) {
@@ -2447,7 +2462,10 @@ __global__ __launch_bounds__(256) void k_vec_step(Dims d, Tables t, const double
     __syncthreads();
     alpha = Sl[TR_ALPHA];
     beta = Sl[TR_BETA];
-    if (blockIdx.x == 0 && threadIdx.x < TR_NSLOTS) S[threadIdx.x] = Sl[threadIdx.x];
+    if (blockIdx.x == 0 && threadIdx.x < TR_NSLOTS) {
+      S[threadIdx.x] = Sl[threadIdx.x];
+      if (host_S != nullptr) host_S[threadIdx.x] = Sl[threadIdx.x];   // (pinned host memory: see publish_cost)
+    }
   }
   if ((int)blockIdx.x >= nvb) {
     prep_item(d, t, StepX{x, dsc, u0, u1, alpha, beta}, ((int)blockIdx.x - nvb) * blockDim.x + threadIdx.x);
@@ -2471,6 +2489,11 @@ __global__ __launch_bounds__(256) void k_vec_step(Dims d, Tables t, const double
     part[3 * blockIdx.x + 0] = a;
     part[3 * blockIdx.x + 1] = b;
     part[3 * blockIdx.x + 2] = c;
+    if (host_part != nullptr) {
+      host_part[3 * blockIdx.x + 0] = a;
+      host_part[3 * blockIdx.x + 1] = b;
+      host_part[3 * blockIdx.x + 2] = c;
+    }
   }
 }
 

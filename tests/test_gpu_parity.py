@@ -571,7 +571,7 @@ def test_handle_cache_sees_a_changed_validity_mask_and_float32_tables():
 
 
 @pytest.mark.parametrize("switch", ["MCBA_FUSED=0", "MCBA_FUSED=1", "MCBA_ASM_STAGE_KB=4", "MCBA_FUSED=0,MCBA_TMAT_GLOBAL=1",
-                                    "MCBA_NCHUNK_TARGET=1024", "MCBA_SHARED_FINAL_BIG=1", "MCBA_SYRK3=1", "MCBA_SPLIT_Q00=1", "MCBA_NO_PUBLISH=1"])
+                                    "MCBA_NCHUNK_TARGET=1024", "MCBA_SHARED_FINAL_BIG=1", "MCBA_SYRK3=1", "MCBA_SPLIT_Q00=1", "MCBA_SPEC_ACCEPT=0", "MCBA_SPEC_ACCEPT=0,MCBA_NO_PUBLISH=1"])
 def test_alternative_linearisation_paths_match_the_default(switch):
   """Paths of the evaluation that the fixtures do not reach by themselves, each forced with its switch in a subprocess
   (the switches are read once per process); all must reproduce the normal equations of the default form to round-off,
