@@ -664,29 +664,49 @@ __global__ __launch_bounds__(256) void k_vec_scale(Dims d, const double* __restr
 // The trust-region driver only needs this for u = g_h (Cauchy curvature): the forms involving the Gauss-Newton step
 // follow from (D H D + reg I) gn = g_h without touching H again (mcba_solve).  partial[blockIdx.x] = block sum
 // (folded by k_tr_reg; a frame-sharded handle all-reduces the partial array element-wise first).
+// Cauchy curvature q = w^T H w over the blocks of H, w_i = g_i / s_i^2: per-block partial sums.  H_fs and H_ff are walked a
+// wavefront per ROW (row = one eliminated frame parameter): w of the row once per wavefront, lanes over the shared columns
+// (coalesced, no integer division per element -- the element-per-thread form spent more on e / ns and on the two w per element
+// than on the loads: 7.4 us standalone, 13.4 us inside the merged launch).  w_x(x index) / w_s(shared index) are supplied by the
+// caller: k_q00 reads the scaled gradient k_vec_scale left behind, k_vec_scale_q00 forms it on the fly.
+template <class WX, class WS>
+__device__ __forceinline__ double q00_partial(const Dims& d, const double* __restrict__ Hss, const double* __restrict__ Hfs,
+                                              const double* __restrict__ Hff, WX w_x, WS w_s, int qb, int nqb) {
+  const int ns = d.ns, DF = d.DF, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+  const int rows = DF > 0 ? d.Fl * DF : 0;
+  double q = 0.0;
+  const int T = nqb * nwave;
+  for (int row0 = qb * nwave + wave; row0 < rows; row0 += 64 * T) {
+    // w of up to 64 rows of this wavefront at once, one per lane (three dependent loads, a square root and a division when it
+    // is formed on the fly: paid once, not per row), then handed out with a shuffle
+    const int myrow = row0 + lane * T;
+    const double wmine = myrow < rows ? w_x(d.frame_to_x(d.f0 + myrow / DF, myrow % DF)) : 0.0;
+    for (int k = 0; k < 64; ++k) {
+      const int row = row0 + k * T;
+      if (row >= rows) break;
+      const int f = d.f0 + row / DF;
+      const double wr = __shfl(wmine, k, 64);
+      const double* hr = Hfs + (size_t)row * ns;
+      double acc = 0.0;
+      for (int sidx = lane; sidx < ns; sidx += 64) acc += hr[sidx] * w_s(sidx);
+      q += 2.0 * wr * acc;
+      if (lane < DF) q += wr * Hff[(size_t)row * DF + lane] * w_x(d.frame_to_x(f, lane));
+    }
+  }
+  for (int e = qb * blockDim.x + threadIdx.x; e < ns * ns; e += nqb * blockDim.x) {
+    const int i = e / ns, j = e - i * ns;
+    q += w_s(i) * Hss[e] * w_s(j);
+  }
+  return q;
+}
+
 __global__ __launch_bounds__(256) void k_q00(Dims d, const double* __restrict__ Hss, const double* __restrict__ Hfs,
                                              const double* __restrict__ Hff, const double* __restrict__ dsc,
                                              const double* __restrict__ u, double* __restrict__ partial) {
   __shared__ double scratch[16];
-  const int ns = d.ns, DF = d.DF;
-  const int stride = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
-  double q = 0.0;
-  const int rows = DF > 0 ? d.Fl * DF : 0;
-  for (int e = t0; e < rows * ns; e += stride) {
-    const int row = e / ns, s = e - row * ns;
-    const int xi = d.frame_to_x(d.f0 + row / DF, row % DF), xs = d.shared_to_x(s);
-    q += 2.0 * (dsc[xi] * u[xi]) * Hfs[e] * (dsc[xs] * u[xs]);
-  }
-  for (int e = t0; e < rows * DF; e += stride) {
-    const int row = e / DF, d2 = e - row * DF, f = d.f0 + row / DF;
-    const int xi = d.frame_to_x(f, row % DF), xj = d.frame_to_x(f, d2);
-    q += (dsc[xi] * u[xi]) * Hff[e] * (dsc[xj] * u[xj]);
-  }
-  for (int e = t0; e < ns * ns; e += stride) {
-    const int i = e / ns, j = e - i * ns;
-    const int xi = d.shared_to_x(i), xj = d.shared_to_x(j);
-    q += (dsc[xi] * u[xi]) * Hss[e] * (dsc[xj] * u[xj]);
-  }
+  auto w_x = [&](int xi) { return dsc[xi] * u[xi]; };
+  auto w_s = [&](int sidx) { const int xi = d.shared_to_x(sidx); return dsc[xi] * u[xi]; };
+  const double q = q00_partial(d, Hss, Hfs, Hff, w_x, w_s, (int)blockIdx.x, (int)gridDim.x);
   const double r = block_reduce<false>(q, scratch);
   if (threadIdx.x == 0) partial[blockIdx.x] = r;
 }
@@ -741,25 +761,17 @@ __global__ __launch_bounds__(256) void k_vec_scale_q00(Dims d, const double* __r
     return di * (di * g[xi]);
   };
   const int qb = (int)blockIdx.x - nvb, nqb = (int)gridDim.x - nvb;
-  const int ns = d.ns, DF = d.DF;
-  const int stride = nqb * blockDim.x, t0 = qb * blockDim.x + threadIdx.x;
-  double q = 0.0;
-  const int rows = DF > 0 ? d.Fl * DF : 0;
-  for (int e = t0; e < rows * ns; e += stride) {
-    const int row = e / ns, s = e - row * ns;
-    const int xi = d.frame_to_x(d.f0 + row / DF, row % DF), xs = d.shared_to_x(s);
-    q += 2.0 * w_of(xi) * Hfs[e] * w_of(xs);
+  const int ns = d.ns;
+  // w of the shared parameters once per block
+  constexpr int WS_MAX = 2048;
+  __shared__ double ws[WS_MAX];
+  const bool cached = ns <= WS_MAX;
+  if (cached) {
+    for (int sidx = threadIdx.x; sidx < ns; sidx += blockDim.x) ws[sidx] = w_of(d.shared_to_x(sidx));
+    __syncthreads();
   }
-  for (int e = t0; e < rows * DF; e += stride) {
-    const int row = e / DF, d2 = e - row * DF, f = d.f0 + row / DF;
-    const int xi = d.frame_to_x(f, row % DF), xj = d.frame_to_x(f, d2);
-    q += w_of(xi) * Hff[e] * w_of(xj);
-  }
-  for (int e = t0; e < ns * ns; e += stride) {
-    const int i = e / ns, j = e - i * ns;
-    const int xi = d.shared_to_x(i), xj = d.shared_to_x(j);
-    q += w_of(xi) * Hss[e] * w_of(xj);
-  }
+  auto w_shared = [&](int sidx) { return cached ? ws[sidx] : w_of(d.shared_to_x(sidx)); };
+  const double q = q00_partial(d, Hss, Hfs, Hff, w_of, w_shared, qb, nqb);
   const double r = block_reduce<false>(q, scratch);
   if (threadIdx.x == 0) partial[qb] = r;
 }
