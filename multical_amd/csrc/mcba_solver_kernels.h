@@ -2276,7 +2276,7 @@ __global__ void k_cholb_back_update(int ns, int k0, double* __restrict__ A) {
 // L (strict lower part) with 1 / L_ii on the diagonal is kept for the back substitution (Lf [Fl][DF][DF]).
 // ---------------------------------------------------------------------------------------------------------------
 template <int DF>
-__global__ __launch_bounds__(256) void k_schur_frame(Dims d, const double* __restrict__ Hff, const double* __restrict__ Hfs,
+__global__ __launch_bounds__(256, 2) void k_schur_frame(Dims d, const double* __restrict__ Hff, const double* __restrict__ Hfs,
                                                     const double* __restrict__ dsc, const double* __restrict__ gh, double reg,
                                                     double* __restrict__ Lf, double* __restrict__ W, double* __restrict__ yf,
                                                     double* tr, const double* __restrict__ vs_part, int nvb,
@@ -2343,7 +2343,7 @@ __global__ __launch_bounds__(256) void k_schur_frame(Dims d, const double* __res
 }
 
 template <int DF>
-__global__ __launch_bounds__(64) void k_schur_backsub(Dims d, const double* __restrict__ Linv, const double* __restrict__ W,
+__global__ __launch_bounds__(64, 8) void k_schur_backsub(Dims d, const double* __restrict__ Linv, const double* __restrict__ W,
                                                       const double* __restrict__ yf, const double* __restrict__ ps,
                                                       double* __restrict__ gn, const double* __restrict__ gh,
                                                       const int* __restrict__ info, double* __restrict__ dots) {
