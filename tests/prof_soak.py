@@ -1,0 +1,20 @@
+"""Soak: many solves on one handle (and re-created handles) -- every result must repeat bit for bit, nothing may hang.
+    python tests/prof_soak.py [n_small] [n_big]"""
+import sys, time, numpy as np
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+from multical_amd import synthetic, calibration
+from multical_amd.backend import Handle
+n_small = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+n_big = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+for name, n in (("tiny_rolling", n_small), ("tiny_handeye", n_small // 3), ("cfg2", n_big), ("cfg3", n_big)):
+    rig = synthetic.make_rig(name); c = calibration.from_rig(rig); x0 = c.param_vec
+    t0 = time.perf_counter()
+    ref = None
+    for rep in range(3):                      # three handles in a row (the resource cache recycles buffers, streams, pinned words)
+        with Handle(c) as h:
+            for i in range(max(n // 3, 1)):
+                r = h.solve(x0)
+                key = (r.nfev, r.status, float(r.cost), r.x.tobytes())
+                if ref is None: ref = key
+                assert key == ref, (name, rep, i, r.nfev, r.status, r.cost)
+    print("%-14s %4d solves identical (nfev %d, status %d, cost %.9e) in %.2f s" % (name, 3 * max(n // 3, 1), ref[0], ref[1], ref[2], time.perf_counter() - t0), flush=True)
