@@ -1291,6 +1291,28 @@ int32_t mcba_rccl_init(mcba_handle h, const uint8_t* id_in, int32_t rank, int32_
   const int rc = api.CommInitRank(&comm, world, id, rank);
   REQUIRE(rc == 0 && comm, std::string("ncclCommInitRank failed: ") + (api.GetErrorString ? api.GetErrorString(rc) : "?"));
   h->rccl_comm = comm;
+  // Self-test of the hard-coded enumerators (ncclFloat64 = 8, ncclSum = 0, ncclMax = 2: librccl is bound through dlopen, no
+  // header): a sum and a max over known doubles must come back exact, otherwise the native path is refused on every rank
+  // (the caller's MIN over the success flags) and the torch.distributed hook takes over.
+  {
+    DevBuf<double> probe;
+    probe.alloc(8);
+    const double in[8] = {1.5, -2.25, (double)(rank + 1), 0.0, (double)rank, 0.0, 0.0, 0.0};
+    HIP_OK(hipMemcpyAsync(probe.p, in, sizeof(in), hipMemcpyHostToDevice, h->stream));
+    const int r0 = rccl_allreduce_native(h, probe.p, 3, 0, (void*)h->stream);
+    const int r1 = rccl_allreduce_native(h, probe.p + 4, 1, 1, (void*)h->stream);
+    double out[8];
+    HIP_OK(hipMemcpyAsync(out, probe.p, sizeof(out), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    const double w = (double)world;
+    const bool good = r0 == 0 && r1 == 0 && out[0] == 1.5 * w && out[1] == -2.25 * w && out[2] == 0.5 * w * (w + 1.0) &&
+                      out[4] == w - 1.0;
+    if (!good) {
+      destroy_rccl_comm(comm);
+      h->rccl_comm = nullptr;
+      throw Error("librccl answered the all-reduce self-test wrongly (enumerator or ABI mismatch)");
+    }
+  }
   h->allreduce = rccl_allreduce_native;
   h->allreduce_ctx = h;
   API_END
