@@ -366,9 +366,13 @@ __device__ __forceinline__ void shared_partial_block(const Dims& d, const Tables
     }
     __syncthreads();
     const int n = nsel;
-    for (int e0 = threadIdx.x; e0 < rs; e0 += 2 * nt) {
-      const int e1 = e0 + nt;
-      const bool h1 = e1 < rs;
+    // The rows of the eliminated frame parameters -- a contiguous block of the packed triangle, 270 of 597 entries at the
+    // north-star rig -- are no business of the shared part (k_shared_final drops them): walked over, not read and summed.
+    const int skip0 = d.DF > 0 ? tri_index(6, 6, d.N1) : rs, nskip = d.DF > 0 ? d.DF * d.N1 - (6 * d.DF + d.DF * (d.DF - 1) / 2) : 0;
+    for (int q0 = threadIdx.x; q0 < rs - nskip; q0 += 2 * nt) {
+      const int q1 = q0 + nt;
+      const int e0 = q0 < skip0 ? q0 : q0 + nskip, e1 = q1 < skip0 ? q1 : q1 + nskip;
+      const bool h1 = q1 < rs - nskip;
       double s0 = 0.0, s1 = 0.0;
       if (f0 != fa) {
         s0 = out[e0];
@@ -453,7 +457,9 @@ __global__ __launch_bounds__(1024) void k_shared_final(Dims d, const double* __r
   const int ns = d.ns, NL = d.NL, npose = 6 * d.NPB, npair = d.C * d.B;
   const int el = threadIdx.x & 63, pg = threadIdx.x >> 6, PG = blockDim.x >> 6;
   const int e = blockIdx.x * 64 + el;
-  const bool in = e < d.rec_size + 2;
+  // (the rows of the eliminated frame parameters hold no chunk sums: shared_partial_block walks over them)
+  const int skip0 = d.DF > 0 ? tri_index(6, 6, d.N1) : 0, nskip = d.DF > 0 ? d.DF * d.N1 - (6 * d.DF + d.DF * (d.DF - 1) / 2) : 0;
+  const bool in = e < d.rec_size + 2 && !(e >= skip0 && e < skip0 + nskip);
   const size_t rs = d.rec_stride;
   const int ij = e < d.rec_size ? tri[e] : 0;   // (issued with the chunk sums, used after them)
   for (int pair = pg; pair < npair; pair += PG) {
