@@ -462,34 +462,7 @@ __global__ __launch_bounds__(1024) void k_shared_final(Dims d, const double* __r
   const bool in = e < d.rec_size + 2 && !(e >= skip0 && e < skip0 + nskip);
   const size_t rs = d.rec_stride;
   const int ij = e < d.rec_size ? tri[e] : 0;   // (issued with the chunk sums, used after them)
-  // (two pairs of a thread group per trip when the chunk sums fit one batch of 16: 32 loads in flight instead of 16 -- a rig with
-  //  many (camera, board) pairs walks five pairs per group and was five dependent round trips long)
-  auto pair_total = [&](int pair, double (&a)[16]) {
-#pragma unroll
-    for (int u = 0; u < 8; ++u) a[u] += a[u + 8];
-    pair_sum[pair * 64 + el] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-  };
-  int pair = pg;
-  if (nchunk <= 16) {
-    for (; pair + PG < npair; pair += 2 * PG) {
-      double a[16], b[16];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) a[u] = b[u] = 0.0;
-      if (in) {
-        const double* ba = partial + (size_t)pair * nchunk * rs + e;
-        const double* bb = partial + (size_t)(pair + PG) * nchunk * rs + e;
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-          const bool on = u < nchunk;
-          a[u] = ba[(size_t)(on ? u : 0) * rs] * (on ? 1.0 : 0.0);
-          b[u] = bb[(size_t)(on ? u : 0) * rs] * (on ? 1.0 : 0.0);
-        }
-      }
-      pair_total(pair, a);
-      pair_total(pair + PG, b);
-    }
-  }
-  for (; pair < npair; pair += PG) {
+  for (int pair = pg; pair < npair; pair += PG) {
     double a[16];
 #pragma unroll
     for (int u = 0; u < 16; ++u) a[u] = 0.0;
@@ -501,7 +474,9 @@ __global__ __launch_bounds__(1024) void k_shared_final(Dims d, const double* __r
         for (int u = 0; u < 16; ++u) a[u] += base[(size_t)(ch + u) * rs];
       for (; ch < nchunk; ++ch) a[ch & 15] += base[(size_t)ch * rs];
     }
-    pair_total(pair, a);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] += a[u + 8];
+    pair_sum[pair * 64 + el] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   }
   __syncthreads();
   if (!in) return;
