@@ -673,6 +673,9 @@ void publish_scalars_end(mcba_handle_s* h, hipStream_t st) {
   const double t0 = now_seconds();
   int spins = 0;
   while (__atomic_load_n(h->h_pub_seq, __ATOMIC_ACQUIRE) != h->pub_seq) {
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
     if ((++spins & 1023) == 0 && now_seconds() - t0 > 0.02) {
       HIP_OK(hipStreamSynchronize(st));
       REQUIRE(__atomic_load_n(h->h_pub_seq, __ATOMIC_ACQUIRE) == h->pub_seq, "the published scalars did not arrive");
