@@ -1171,6 +1171,7 @@ int32_t mcba_create(const mcba_problem* p, void* hip_stream, mcba_handle* out) {
     } else {
       while (ks < 64 && nt2 * ks < 1024 && K / (ks * 2) >= 32) ks *= 2;
     }
+    if (const char* e = getenv("MCBA_KSPLIT")) ks = std::max(1, std::min(64, atoi(e)));   // (experiments)
     h->ksplit = ks;
     h->P.alloc((size_t)ks * nt2 * 256);
   }
@@ -1918,6 +1919,8 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
   // leaves them behind and goes through the retry path (k_cost, stream-ordered fetch) as before.  Against the side-stream
   // form: k_linearize is not slowed by a concurrent k_cost (58 -> 49 us), no event packet between k_vec_step and
   // k_linearize (7 us), no copy.  MCBA_SPEC_ACCEPT=0 restores the side-stream form.
+  // (blocks of the curvature sums: every k_schur_frame workgroup folds their partials -- MCBA_Q00_BLOCKS for experiments)
+  static const int q00_blocks = getenv("MCBA_Q00_BLOCKS") ? std::max(1, std::min(Q00_BLOCKS, atoi(getenv("MCBA_Q00_BLOCKS")))) : Q00_BLOCKS;
   static const bool spec_accept_off = getenv("MCBA_SPEC_ACCEPT") != nullptr && getenv("MCBA_SPEC_ACCEPT")[0] == '0';
   bool scaled_ahead = false;     // the scaling / curvature of h->x are already in place (computed speculatively, swapped in)
   int trial_cost_values = cost_fetch;
@@ -1946,18 +1949,18 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
     } else {
       if (scaled) {
       } else if (split_q00)
-        hipLaunchKernelGGL(k_q00, dim3(Q00_BLOCKS), dim3(256), 0, h->stream, d, h->Hss.p, h->Hfs.p, h->Hff.p, h->dsc.p,
+        hipLaunchKernelGGL(k_q00, dim3(q00_blocks), dim3(256), 0, h->stream, d, h->Hss.p, h->Hfs.p, h->Hff.p, h->dsc.p,
                            h->gh.p, h->scal.p + sl.q00p);
       else   // gradient scaling and Cauchy curvature in one launch (the curvature forms its scaled gradient on the fly)
-        hipLaunchKernelGGL(k_vec_scale_q00, dim3(sl.nvb + Q00_BLOCKS), dim3(256), 0, h->stream, d, h->x.p, h->g(), h->diag(),
+        hipLaunchKernelGGL(k_vec_scale_q00, dim3(sl.nvb + q00_blocks), dim3(256), 0, h->stream, d, h->x.p, h->g(), h->diag(),
                            h->scale_inv.p, h->scale_inv.p, h->dsc.p, h->gh.p, first ? 1 : 0, h->scal.p + sl.vs, h->costcount(),
                            h->scal.p + TR_COST, sl.nvb, h->Hss.p, h->Hfs.p, h->Hff.p, h->scal.p + sl.q00p);
       if (h->allreduce) {   // one double crosses the ranks, not the 512 per-block partials
-        hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(64), 0, h->stream, h->scal.p + sl.q00p, Q00_BLOCKS);
+        hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(64), 0, h->stream, h->scal.p + sl.q00p, q00_blocks);
         call_allreduce(h, h->scal.p + sl.q00p, 1, 0);
       }
       // (the fold of the k_vec_scale / k_q00 partials and the damping: head of the first kernel of the solve)
-      const TrRegPartials trp{h->scal.p + sl.vs, sl.nvb, h->scal.p + sl.q00p, h->allreduce ? 1 : Q00_BLOCKS, first ? 1 : 0, Delta};
+      const TrRegPartials trp{h->scal.p + sl.vs, sl.nvb, h->scal.p + sl.q00p, h->allreduce ? 1 : q00_blocks, first ? 1 : 0, Delta};
       launch_gn_solve(h, 0.0, is_root, h->scal.p + sl.dotp, h->scal.p, &trp);
       // Single GPU, table-fed fused linearisation: the trial cost and the speculative linearisation both only READ the tables
       // that the tail of k_vec_step wrote, so k_cost + the scalar copy go to a side stream and run BESIDE k_linearize (13 us
@@ -1971,7 +1974,7 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
         enqueue_trial(0.0, 0.0, h->scal.p, false, true);
         ++h->pub_seq;
         timed_linearize(nullptr, h->pub_seq, sl.costp);
-        hipLaunchKernelGGL(k_vec_scale_q00, dim3(sl.nvb + Q00_BLOCKS), dim3(256), 0, h->stream, d, h->xnew.p, h->g(), h->diag(),
+        hipLaunchKernelGGL(k_vec_scale_q00, dim3(sl.nvb + q00_blocks), dim3(256), 0, h->stream, d, h->xnew.p, h->g(), h->diag(),
                            h->scale_inv.p, h->scale_inv2.p, h->dsc2.p, h->gh2.p, 0, h->scal.p + sl.vs, h->costcount(),
                            h->scal.p + TR_COST, sl.nvb, h->Hss.p, h->Hfs.p, h->Hff.p, h->scal.p + sl.q00p);
         spec_lin = true;
