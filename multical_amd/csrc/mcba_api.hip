@@ -237,6 +237,7 @@ struct ScalLayout {
   int step = 0;       // [3 nvb]           k_vec_step partials
   int costp = 0;      // [COST_BLOCKS_MAX] k_cost partials (all-reduced element-wise when sharded)
   int dotp = 0;       // [3 nblk + 1]      partial dots + pivot report (folded by k_vec_step)
+  int fold = 0;       // [4]               totals of the vs / q00p partials of a point scaled ahead (k_fold_tr)
   int total = 0;
   void init(int n, int dot_blocks) {
     nvb = (n + 255) / 256;
@@ -245,7 +246,8 @@ struct ScalLayout {
     step = q00p + Q00_BLOCKS;
     costp = step + (3 * nvb + 1) / 2 * 2;
     dotp = costp + COST_BLOCKS_MAX;
-    total = dotp + 3 * dot_blocks + 8;
+    fold = dotp + (3 * dot_blocks + 8 + 1) / 2 * 2;
+    total = fold + 4;
   }
 };
 
@@ -1960,7 +1962,9 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
         call_allreduce(h, h->scal.p + sl.q00p, 1, 0);
       }
       // (the fold of the k_vec_scale / k_q00 partials and the damping: head of the first kernel of the solve)
-      const TrRegPartials trp{h->scal.p + sl.vs, sl.nvb, h->scal.p + sl.q00p, h->allreduce ? 1 : q00_blocks, first ? 1 : 0, Delta};
+      // (scaled ahead: the partials were folded behind it by k_fold_tr -- [mx | gg | xs] is a k_vec_scale block of its own, q one value)
+      const TrRegPartials trp = scaled ? TrRegPartials{h->scal.p + sl.fold, 1, h->scal.p + sl.fold + 3, 1, 0, Delta}
+                                       : TrRegPartials{h->scal.p + sl.vs, sl.nvb, h->scal.p + sl.q00p, h->allreduce ? 1 : q00_blocks, first ? 1 : 0, Delta};
       launch_gn_solve(h, 0.0, is_root, h->scal.p + sl.dotp, h->scal.p, &trp);
       // Single GPU, table-fed fused linearisation: the trial cost and the speculative linearisation both only READ the tables
       // that the tail of k_vec_step wrote, so k_cost + the scalar copy go to a side stream and run BESIDE k_linearize (13 us
@@ -1977,6 +1981,8 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
         hipLaunchKernelGGL(k_vec_scale_q00, dim3(sl.nvb + q00_blocks), dim3(256), 0, h->stream, d, h->xnew.p, h->g(), h->diag(),
                            h->scale_inv.p, h->scale_inv2.p, h->dsc2.p, h->gh2.p, 0, h->scal.p + sl.vs, h->costcount(),
                            h->scal.p + TR_COST, sl.nvb, h->Hss.p, h->Hfs.p, h->Hff.p, h->scal.p + sl.q00p);
+        hipLaunchKernelGGL(k_fold_tr, dim3(1), dim3(64), 0, h->stream, h->scal.p + sl.vs, sl.nvb, h->scal.p + sl.q00p, q00_blocks,
+                           h->scal.p + sl.fold);
         spec_lin = true;
         spec_scaled = true;
         trial_cost_values = 1;
