@@ -268,7 +268,12 @@ __device__ __forceinline__ void assemble_frame_block(const Dims& d, const Tables
     if (threadIdx.x == 0) n_act_s = basec;
   }
   for (int k = threadIdx.x; k < NE; k += blockDim.x) soff[k] = k < P1 ? tri_index(k / DF, 6 + k % DF, N1) : base2 + (k - P1);
-  for (int e = threadIdx.x; e < DF * ns; e += blockDim.x) hfs[e] = 0.0;
+  // H_fs of the frame is cleared only where the table below does not store every element anyway: adjusted board points (their
+  // columns belong to k_points) and rigs with frozen distortion coefficients (columns nobody writes).  Otherwise every
+  // (frame parameter, shared parameter) element is the `*dst = sum` of exactly one thread -- the blanket clear wrote the
+  // 6.7 MB of H_fs twice per launch at the north-star rig.
+  if (d.off_boards >= 0 || d.cam_kmask != nullptr)
+    for (int e = threadIdx.x; e < DF * ns; e += blockDim.x) hfs[e] = 0.0;
   const double* rf = rec + (size_t)fl * CB * d.rec_stride;   // records of this frame: view (c, b) at (c B + b) rec_stride
   const float inv_ne = 1.0f / (float)NE;
   constexpr int LB = 11, TB = 7;   // loads / table elements in flight per thread
