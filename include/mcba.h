@@ -18,7 +18,8 @@
  *   - the library is HIP-only: `mcba_create` fails when no gfx950 device is present.  There is no CPU fallback.
  *   - limits of this implementation (the reference has none; all are checked by `mcba_create`, which fails with a
  *     message instead of producing a handle that cannot be solved):
- *     at most 65535 points per board; one projection FAMILY per rig (pinhole cameras may carry different numbers of
+ *     at most 65535 points per board; about 36 000 (camera, board) pairs when per-frame rig poses are optimised (their
+ *     view-rank tables live in the 150 KB of LDS of a workgroup); one projection FAMILY per rig (pinhole cameras may carry different numbers of
  *     distortion coefficients -- 4, 5, 8, 12, 14: mcba_problem.camera_n_dist -- but pinhole and fisheye cameras cannot
  *     share a rig).
  *

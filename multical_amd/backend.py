@@ -162,6 +162,7 @@ class Handle(object):
     check(self.lib.mcba_num_params(self.h, C.byref(n)))
     self.n_params = n.value
     self._log_cb = self._allreduce_cb = None    # the currently installed ctypes thunks (kept alive, one per kind)
+    self._jac_pattern = None                    # (shape, indices, indptr, keep) of mcba_jacobian for the current inlier set
     self.shape = self.problem.shape
 
   def close(self):
@@ -200,6 +201,7 @@ class Handle(object):
     check(self.lib.mcba_debug_set_lin_grid(self.h, int(grid)))
 
   def set_inliers(self, mask):
+    self._jac_pattern = None
     if mask is None:
       check(self.lib.mcba_set_inliers(self.h, None))
     else:
@@ -220,7 +222,8 @@ class Handle(object):
     return r
 
   def jacobian(self, x):
-    """scipy.sparse.csr_matrix [n_residuals, n_params] in the reference's sparsity pattern."""
+    """scipy.sparse.csr_matrix [n_residuals, n_params] in the reference's sparsity pattern (calibration.py:173-196).
+    The pattern (column indices, row pointers) is fetched once per inlier set; later calls download the values only."""
     from scipy.sparse import csr_matrix
     x = self._x(x)
     nnz = C.c_int32()
@@ -228,16 +231,23 @@ class Handle(object):
     k = nnz.value
     m = self.n_residuals
     vals = np.empty((m, k))
-    cols = np.empty((m // 2, k), dtype=np.int32)
-    check(self.lib.mcba_jacobian(self.h, _ptr(x, C.c_double), C.byref(nnz), _ptr(vals, C.c_double),
-                                 _ptr(cols, C.c_int32)))
-    indices = np.repeat(cols, 2, axis=0).ravel()
-    indptr = np.arange(0, m * k + 1, k)
-    if (cols < 0).any():   # ragged camera blocks: slots of coefficients a camera's model does not have carry column -1
-      keep = indices >= 0
-      counts = keep.reshape(m, k).sum(axis=1)
-      return csr_matrix((vals.ravel()[keep], indices[keep], np.concatenate([[0], np.cumsum(counts)])), shape=(m, self.n_params))
-    return csr_matrix((vals.ravel(), indices, indptr), shape=(m, self.n_params))
+    st = self._jac_pattern
+    if st is None or st[0] != (m, k):
+      cols = np.empty((m // 2, k), dtype=np.int32)
+      check(self.lib.mcba_jacobian(self.h, _ptr(x, C.c_double), C.byref(nnz), _ptr(vals, C.c_double), _ptr(cols, C.c_int32)))
+      indices = np.repeat(cols, 2, axis=0).ravel()
+      if (cols < 0).any():   # ragged camera blocks: slots of coefficients a camera's model does not have carry column -1
+        keep = indices >= 0
+        counts = keep.reshape(m, k).sum(axis=1)
+        st = ((m, k), indices[keep], np.concatenate([[0], np.cumsum(counts)]), keep)
+      else:
+        st = ((m, k), indices, np.arange(0, m * k + 1, k), None)
+      self._jac_pattern = st
+    else:
+      check(self.lib.mcba_jacobian(self.h, _ptr(x, C.c_double), C.byref(nnz), _ptr(vals, C.c_double), None))
+    _, indices, indptr, keep = st
+    data = vals.ravel() if keep is None else vals.ravel()[keep]
+    return csr_matrix((data, indices, indptr), shape=(m, self.n_params))
 
   def reprojection_error(self, x):
     x = self._x(x)
@@ -339,6 +349,7 @@ class Handle(object):
   def reject_outliers(self, x, threshold):
     """inliers = (err < threshold) & valid on the device; returns (n_inliers, n_valid)."""
     x = self._x(x)
+    self._jac_pattern = None
     ni, nvv = C.c_int64(), C.c_int64()
     check(self.lib.mcba_reject_outliers(self.h, _ptr(x, C.c_double), float(threshold), C.byref(ni), C.byref(nvv)))
     return ni.value, nvv.value
@@ -421,6 +432,40 @@ class Handle(object):
                            nfev=res.nfev, njev=res.njev, status=res.status, iterations=res.iterations,
                            message=STATUS_MESSAGES.get(res.status, ""), solve_seconds=res.solve_seconds,
                            linearize_seconds=res.linearize_seconds, success=res.status > 0)
+
+  def solve_scipy(self, x0, tolerance=1e-4, f_scale=1.0, max_iterations=100, loss='linear', verbose=2):
+    """The reference's OWN solver call (optimization/calibration.py:209-210) with the device functions plugged in:
+
+        scipy.optimize.least_squares(evaluate, x0, jac_sparsity=S, verbose=2, x_scale='jac', f_scale=f_scale,
+                                     ftol=tolerance, max_nfev=max_iterations, method='trf', loss=loss)
+
+    `evaluate` = mcba_residuals, and `jac_sparsity=S` (finite differences over S) is replaced by `jac` = mcba_jacobian, the
+    analytic Jacobian in the very same pattern S.  Everything else -- TRF, LSMR steps, `x_scale='jac'`, the termination tests,
+    the verbose table on stdout -- is scipy's, so the trajectory and the END POINT are the reference's: within 1e-6 px of the
+    reference's final RMS with identical `nfev` / `status` wherever the reference's own end point is reproducible to that level
+    (profiles/parity_table.md, tests/test_gpu_protocol.py).  The price is scipy's host-side LSMR (74 % of the
+    reference's wall time); `solve` (mcba_solve) is the fast route and ends at the converged optimum instead."""
+    from scipy.optimize import least_squares
+    t0 = time.perf_counter()
+    first = {}
+
+    def fun(x):
+      r = self.residuals(x)
+      first.setdefault("r0", r)
+      return r
+
+    res = least_squares(fun, self._x(x0), jac=self.jacobian, verbose=verbose, x_scale='jac', f_scale=f_scale, ftol=tolerance,
+                        max_nfev=max_iterations, method='trf', loss=loss)
+    from scipy.optimize._lsq.least_squares import construct_loss_function
+    r0 = first["r0"]
+    if loss == 'linear':
+      c0 = 0.5 * float(r0 @ r0)
+    else:
+      c0 = float(construct_loss_function(r0.size, loss, f_scale)(r0, cost_only=True))
+    return SimpleNamespace(x=res.x, cost=float(res.cost), initial_cost=c0, optimality=float(res.optimality), nfev=int(res.nfev),
+                           njev=int(res.njev), status=int(res.status), iterations=int(res.njev) - 1,
+                           message=res.message, solve_seconds=time.perf_counter() - t0, linearize_seconds=0.0,
+                           success=bool(res.success))
 
   # --- measurement --------------------------------------------------------------------------------------------
   def time_linearize(self, x, repeats=20, loss='linear', f_scale=1.0):

@@ -12,7 +12,9 @@ class, so that callers written against the reference (Workspace.calibrate, works
 Objects hold no device state: like the reference only the 8 constructor fields are pickled (calibration.py:222-226);
 device handles live in a small module-level cache keyed on the observation table.
 """
+import contextlib
 import logging
+import os
 from functools import cached_property
 
 import numpy as np
@@ -26,6 +28,46 @@ logger = logging.getLogger("calibration")   # same logger name as multical/io/lo
 
 def info(msg):
   logger.info(msg)
+
+
+class LogWriter(object):
+  """io/logging.py:53-68: file-like object that forwards what scipy prints with verbose=2 to the "calibration" logger."""
+
+  def __init__(self, level=logging.INFO, ignore_newline=True):
+    self.level, self.ignore_newline = level, ignore_newline
+
+  def write(self, message, *args, **kwargs):
+    if message != '\n' or not self.ignore_newline:
+      logger._log(self.level, message, args, **kwargs)
+
+  def flush(self):
+    pass
+
+  @staticmethod
+  def info(ignore_newline=True):
+    return LogWriter(logging.INFO, ignore_newline)
+
+
+# Which solver `Calibration.bundle_adjust` uses (both run residuals and Jacobian on the MI355X):
+#   "native"  mcba_solve: trust-region driver with exact Schur / Cholesky steps, everything on the device.  Ends at the
+#             CONVERGED optimum (at or below the reference's end point, DESIGN.md section 2).
+#   "scipy"   the reference's own call scipy.optimize.least_squares(method='trf', x_scale='jac', ...) on mcba_residuals +
+#             mcba_jacobian (Handle.solve_scipy): the reference's trajectory and END POINT (1e-6 px, identical nfev / status
+#             wherever the reference reproduces itself to that level), at the price of scipy's host-side LSMR.
+SOLVERS = ("native", "scipy")
+_default_solver = [os.environ.get("MULTICAL_AMD_SOLVER", "native").lower()]
+
+
+def set_solver(name):
+  """Select the solver of every following `bundle_adjust` / `adjust_outliers` / `Workspace.calibrate`; returns the previous one."""
+  if name not in SOLVERS:
+    raise ValueError(f"unknown solver {name!r}, options are {SOLVERS}")
+  prev, _default_solver[0] = _default_solver[0], name
+  return prev
+
+
+def get_solver():
+  return _default_solver[0]
 
 
 default_optimize = struct(cameras=False, boards=False, camera_poses=True, board_poses=True, motion=True)
@@ -252,12 +294,23 @@ class Calibration(parameters.Parameters):
 
   # --- solve (calibration.py:199-212) -----------------------------------------------------------------------
   def bundle_adjust(self, tolerance=1e-4, f_scale=1.0, max_iterations=100, loss='linear', return_result=False,
-                    xtol=1e-8, gtol=1e-8):
-    """Non-linear least squares on point reprojection error, solved on the GPU (mcba_solve).
+                    xtol=1e-8, gtol=1e-8, solver=None):
+    """Non-linear least squares on point reprojection error, solved on the GPU.
 
-    Keeps the reference's signature and semantics; the iteration table scipy prints with verbose=2 is emitted in the
-    same format through the "calibration" logger (calibration.py:208, io/logging.py:53-68)."""
+    Keeps the reference's signature and semantics.  solver = "native" (mcba_solve; default, see `set_solver`): the iteration
+    table scipy prints with verbose=2 is emitted in the same format through the "calibration" logger (calibration.py:208,
+    io/logging.py:53-68).  solver = "scipy": the reference's own `least_squares` call on the device residuals + analytic
+    Jacobian (`Handle.solve_scipy`), scipy's own table redirected to the logger exactly as calibration.py:208 does."""
+    solver = get_solver() if solver is None else solver
+    if solver not in SOLVERS:
+      raise ValueError(f"unknown solver {solver!r}, options are {SOLVERS}")
     h = self._handle()
+    if solver == "scipy":
+      with contextlib.redirect_stdout(LogWriter.info()):
+        res = h.solve_scipy(self.param_vec, tolerance=tolerance, f_scale=f_scale, max_iterations=max_iterations, loss=loss,
+                            verbose=2)
+      out = self.with_param_vec(res.x)
+      return (out, res) if return_result else out
     rows = []
 
     def log_row(it, nfev, cost, red, step, opt):

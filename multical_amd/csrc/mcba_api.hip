@@ -265,6 +265,7 @@ struct mcba_handle_s {
   bool use_mfma = true;
   bool shard_root = true;
   ScalLayout sl;
+  size_t asm_lds_set = 48 * 1024;
   size_t chol_lds_set = 0, chol_lds2_set = 0, chol_lds3_set = 0, chol_lds4_set = 0, chol_lds5_set = 0;
   DevBuf<double> chol_linv;   // inverted diagonal tiles of k_chol_glb
   int lin_grid = 0;          // 0 = automatic (see lin2), > 0 = forced number of persistent workgroups (debug)
@@ -597,6 +598,12 @@ void launch_linearize(mcba_handle_s* h, const double* dx) {
 
 // publish_seq != 0: the kernel that forms the cost of the linearisation also writes it to h_scal[cost_slot] (pinned) and then
 // the sequence number to h_pub_seq (publish_cost)
+// dynamic LDS of a k_assemble frame block besides its staging slots: record offsets + the two view-rank tables
+constexpr size_t ASM_LDS_MAX = 150 * 1024;
+inline size_t assemble_lds_fixed(const Dims& d) {
+  return (size_t)frame_entries(d) * sizeof(int) + 2 * (size_t)((d.C * d.B + 3) & ~3) * sizeof(uint16_t) + 16;
+}
+
 void launch_assemble(mcba_handle_s* h, unsigned long long publish_seq = 0, int cost_slot = 0) {
   const Dims& d = h->d;
   // ([g | diag | cost] and H_ss were zeroed by k_tmat at the start of this linearisation)
@@ -608,8 +615,16 @@ void launch_assemble(mcba_handle_s* h, unsigned long long publish_seq = 0, int c
   const int ne = frame_entries(d), cb = d.C * d.B;
   // staging slots: as many non-empty views of a frame as the budget holds (all C B when they fit); a frame with more active
   // views than slots takes several passes
-  const int gviews = nfb ? std::max(1, std::min(cb, stage_kb * 1024 / (ne * 8))) : 1;
-  const size_t lds = nfb ? (size_t)gviews * ne * sizeof(double) + (size_t)ne * sizeof(int) + 2 * (size_t)((cb + 3) & ~3) * sizeof(uint16_t) + 16 : 0;
+  // rigs with thousands of (camera, board) pairs: the view-rank tables (4 B per pair) take LDS next to the staging slots;
+  // mcba_create has checked that one slot + the tables fit what a workgroup can ask for (assemble_lds_fixed)
+  const size_t fixed = assemble_lds_fixed(d);
+  const size_t stage_bytes = std::min<size_t>((size_t)stage_kb * 1024, ASM_LDS_MAX - fixed);
+  const int gviews = nfb ? std::max(1, std::min(cb, (int)(stage_bytes / ((size_t)ne * 8)))) : 1;
+  const size_t lds = nfb ? (size_t)gviews * ne * sizeof(double) + fixed : 0;
+  if (lds > h->asm_lds_set) {
+    HIP_OK(hipFuncSetAttribute((const void*)k_assemble, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    h->asm_lds_set = lds;
+  }
   // (timed apart at cfg3: frame blocks alone 10.0 us, chunk sums alone 6.9 us, together 12.4 us)
   hipLaunchKernelGGL(k_assemble, dim3(nfb + d.C * d.B * h->nchunk), dim3(ASM_THREADS), lds, h->stream, d, h->t, h->rec.p, nfb, h->nchunk, gviews,
                      h->ftab.p, h->nftab, h->Hff.p, h->Hfs.p, h->g(), h->diag(), h->partial.p);
@@ -1118,6 +1133,9 @@ int32_t mcba_create(const mcba_problem* p, void* hip_stream, mcba_handle* out) {
   h->fix_aspect.upload(hp.fix_aspect);
   h->bwg.upload(hp.bwg);
   h->tri.upload(hp.tri);
+  if (d.DF > 0 && assemble_lds_fixed(d) + (size_t)frame_entries(d) * sizeof(double) > ASM_LDS_MAX)
+    throw Error("too many (camera, board) pairs for the per-frame assembly (view-rank tables of 4 B per pair exceed the 150 KB of "
+                "LDS a workgroup can have: about 36 000 pairs)");
   {
     Dims dh = h->d;
     dh.cam_kmask = hp.cam_kmask.empty() ? nullptr : hp.cam_kmask.data();   // host copy for the host-side index arithmetic
@@ -1407,7 +1425,7 @@ int32_t mcba_jacobian(mcba_handle h, const double* x, int32_t* row_nnz, double* 
   if (d.off_boards >= 0) nnz += 3;
   *row_nnz = nnz;
   if (!vals && !cols) return 0;
-  REQUIRE(x && vals && cols, "null argument");
+  REQUIRE(x && vals, "null argument");   // (cols == NULL: values only -- the pattern does not change between two evaluations)
   ensure_obs_index(h);
   const size_t nv = 2 * (size_t)h->n_inliers * nnz, nc = (size_t)h->n_inliers * nnz;
   h->out_big.alloc(std::max<size_t>(nv, 1), false);
@@ -1416,7 +1434,7 @@ int32_t mcba_jacobian(mcba_handle h, const double* x, int32_t* row_nnz, double* 
   eval_tables(h, h->x.p);
   h->ops->jacobian(d, h->t, h->stream, nnz, h->out_big.p, h->out_cols.p);
   HIP_OK(hipMemcpyAsync(vals, h->out_big.p, nv * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIP_OK(hipMemcpyAsync(cols, h->out_cols.p, nc * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  if (cols) HIP_OK(hipMemcpyAsync(cols, h->out_cols.p, nc * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
   sync(h);
   API_END
 }
@@ -1471,7 +1489,8 @@ int32_t mcba_align_poses_robust(int32_t n_problems, const int64_t* offsets, cons
     REQUIRE(offsets[p + 1] >= offsets[p], "offsets must be non-decreasing");
     nmax = std::max<int64_t>(nmax, offsets[p + 1] - offsets[p]);
   }
-  REQUIRE(offsets[0] == 0 && total >= 0 && nmax <= 64 * ALIGN_THREADS, "bad offsets (at most 65536 entries per problem)");
+  REQUIRE(offsets[0] == 0 && total >= 0, "offsets must start at 0");
+  REQUIRE(nmax < (1ll << 24), "more than 2^24 pose pairs in one alignment problem");
   hipStream_t st = nullptr;
   HIP_OK(hipStreamCreate(&st));
   struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } guard{st};
@@ -1525,15 +1544,8 @@ int32_t mcba_align_poses_robust(int32_t n_problems, const int64_t* offsets, cons
   //  18 150 entries -- is ranked from LDS too)
   const int lds_cap = (int)std::min<int64_t>(nmax, ALIGN_LDS_CAP);
   const size_t lds = align_lds_bytes(lds_cap);
-  {
-    static std::mutex mtx;
-    static size_t lds_set = 0;
-    std::lock_guard<std::mutex> lock(mtx);
-    if (lds > lds_set) {
-      HIP_OK(hipFuncSetAttribute((const void*)k_align_robust, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      lds_set = lds;
-    }
-  }
+  // (a per-DEVICE attribute: set on every call, it costs nothing next to the copies)
+  HIP_OK(hipFuncSetAttribute((const void*)k_align_robust, hipFuncAttributeMaxDynamicSharedMemorySize, (int)align_lds_bytes(ALIGN_LDS_CAP)));
   hipLaunchKernelGGL(k_align_robust, dim3(n_problems), dim3(ALIGN_THREADS), lds, st, d_off.p, dA.p, dB.p,
                      (const uint8_t*)(mask ? d_mask.p : nullptr), threshold, (int)invert, (long long)per, sc, d_out.p,
                      d_valid.p, d_inl.p, lds_cap);

@@ -234,32 +234,37 @@ __device__ void robust_mean_block(int n, const AlignScratch& s, double* out /* s
           nd[i] = sqrt(2.0 * nx * ni / (nx + ni) * bd2);
         }
         __syncthreads();
-        unsigned long long mrg = 0ull;               // reciprocal pairs owned by this thread (cluster i < its partner)
-        {
-          int q = 0;
-          for (int i = tid; i < n; i += nthr, ++q)
-            if (s.size[i] > 0) {
-              const int j = nn[i];
-              if (j > i && nn[j] == i) mrg |= 1ull << q;
-            }
+        // reciprocal pairs owned by this thread (cluster i < its partner), found for 64 of its entries at a time: a merge only
+        // writes the two slots of its own pair, and the partner j > i of a pair never owns one (nn[j] = i < j), so the tests of a
+        // later batch see exactly what they would have seen before the merges of an earlier one
+        for (int base = 0; base < n; base += 64 * nthr) {
+          unsigned long long mrg = 0ull;
+          {
+            int q = 0;
+            for (int i = base + tid; i < n && q < 64; i += nthr, ++q)
+              if (s.size[i] > 0) {
+                const int j = nn[i];
+                if (j > i && nn[j] == i) mrg |= 1ull << q;
+              }
+          }
+          __syncthreads();
+          {
+            int q = 0;
+            for (int i = base + tid; i < n && q < 64; i += nthr, ++q)
+              if ((mrg >> q) & 1ull) {
+                const int j = nn[i], m = atomicAdd(&s_nm, 1);
+                const int nx = s.size[i], ny = s.size[j];
+                s.hgt[m] = nd[i];
+                s.rep_a[m] = i;      // slot indices double as representatives: slot j keeps holding the merged cluster, i dies;
+                s.rep_b[m] = j;      // a slot index is always a member of the cluster it holds (it is one of the original points)
+                for (int k = 0; k < 6; ++k)
+                  s.cen[6 * j + k] = ((double)nx * s.cen[6 * i + k] + (double)ny * s.cen[6 * j + k]) / (double)(nx + ny);
+                s.size[j] = nx + ny;
+                s.size[i] = 0;
+              }
+          }
+          __syncthreads();
         }
-        __syncthreads();
-        {
-          int q = 0;
-          for (int i = tid; i < n; i += nthr, ++q)
-            if ((mrg >> q) & 1ull) {
-              const int j = nn[i], m = atomicAdd(&s_nm, 1);
-              const int nx = s.size[i], ny = s.size[j];
-              s.hgt[m] = nd[i];
-              s.rep_a[m] = i;      // slot indices double as representatives: slot j keeps holding the merged cluster, i dies;
-              s.rep_b[m] = j;      // a slot index is always a member of the cluster it holds (it is one of the original points)
-              for (int k = 0; k < 6; ++k)
-                s.cen[6 * j + k] = ((double)nx * s.cen[6 * i + k] + (double)ny * s.cen[6 * j + k]) / (double)(nx + ny);
-              s.size[j] = nx + ny;
-              s.size[i] = 0;
-            }
-        }
-        __syncthreads();
         const int nm_now = s_nm;
         // (no merge in a round can only happen with non-finite poses -- every comparison false: stop instead of spinning;
         //  the heights left unset make the cut keep the remaining clusters apart)

@@ -2,7 +2,8 @@
 the MI355X back-end while keeping every other line of multical untouched.
 
     import multical_amd.dropin as dropin
-    dropin.install()              # or set MULTICAL_BACKEND=hip and call dropin.install_from_env()
+    dropin.install()              # native solver; or set MULTICAL_BACKEND=hip and call dropin.install_from_env()
+    dropin.install(mode="scipy")  # the reference's own scipy driver on the device fun + jac (MULTICAL_BACKEND=hip-scipy)
 
 After `install()`, `Workspace.calibrate` (workspace.py:228-247), `Calibration.adjust_outliers` (calibration.py:254-268)
 and `HandEyeCalibration.bundle_adjust` (optimization/hand_eye.py:73-75) reach the GPU through the unchanged call chain.
@@ -27,7 +28,8 @@ def _format_row(it, nfev, cost, red, step, opt):
 
 
 def bundle_adjust(self, tolerance=1e-4, f_scale=1.0, max_iterations=100, loss='linear'):
-  """Replacement body of multical.optimization.calibration.Calibration.bundle_adjust (same signature)."""
+  """Replacement body of multical.optimization.calibration.Calibration.bundle_adjust (same signature): the native solver
+  (mcba_solve).  Ends at the converged optimum -- at or below the reference's end point."""
   import logging
   log = logging.getLogger("calibration")        # multical/io/logging.py:11
   rows = []
@@ -43,21 +45,46 @@ def bundle_adjust(self, tolerance=1e-4, f_scale=1.0, max_iterations=100, loss='l
   return self.with_param_vec(res.x)
 
 
+def bundle_adjust_scipy(self, tolerance=1e-4, f_scale=1.0, max_iterations=100, loss='linear'):
+  """Replacement body of Calibration.bundle_adjust that keeps the reference's OWN solver call (calibration.py:208-210) and
+  only swaps the functions it calls: `evaluate` -> mcba_residuals, `jac_sparsity=S` (finite differences) -> `jac` =
+  mcba_jacobian (analytic, same pattern S).  Same driver, same options, same stdout redirection: the reference's trajectory
+  and END POINT (final RMS within 1e-6 px, identical nfev / status where the reference reproduces itself to that level:
+  profiles/parity_table.md), with scipy's LSMR on the host."""
+  import contextlib
+  try:
+    from multical.io.logging import LogWriter       # the reference's own writer when multical is importable
+  except Exception:
+    from .calibration import LogWriter
+  with Handle(lower(self)) as h:
+    with contextlib.redirect_stdout(LogWriter.info()):
+      res = h.solve_scipy(self.param_vec, tolerance=tolerance, f_scale=f_scale, max_iterations=max_iterations, loss=loss,
+                          verbose=2)
+  return self.with_param_vec(res.x)
+
+
+MODES = {"native": bundle_adjust, "scipy": bundle_adjust_scipy}
+
+
 def _reprojection_tables(self):
   """(errors, mask) of tables.reprojection_error(self.reprojected, self.point_table) on the device (tables.py:244-249)."""
   with Handle(lower(self)) as h:
     return h.reprojection_error(self.param_vec)
 
 
-def install(calibration_module=None, patch_errors=False):
+def install(calibration_module=None, patch_errors=False, mode="native"):
   """Patch `Calibration.bundle_adjust` of multical (or of the given module object).  Returns the patched class.
+  mode = "native": mcba_solve (fast; converged optimum).  mode = "scipy": the reference's own scipy driver on the device
+  residuals + analytic Jacobian (the reference's end point to 1e-6 px).
   patch_errors=True additionally evaluates `reprojection_error` / `reject_outliers` on the device."""
+  if mode not in MODES:
+    raise ValueError(f"unknown mode {mode!r}, options are {sorted(MODES)}")
   if calibration_module is None:
     import multical.optimization.calibration as calibration_module
   cls = calibration_module.Calibration
   if not hasattr(cls, "_scipy_bundle_adjust"):
     cls._scipy_bundle_adjust = cls.bundle_adjust
-  cls.bundle_adjust = bundle_adjust
+  cls.bundle_adjust = MODES[mode]
   if patch_errors:
     from functools import cached_property
 
@@ -81,7 +108,11 @@ def uninstall(calibration_module=None):
 
 
 def install_from_env():
-  """MULTICAL_BACKEND=hip -> install(); anything else keeps scipy."""
-  if os.environ.get("MULTICAL_BACKEND", "scipy").lower() == "hip":
+  """MULTICAL_BACKEND=hip -> install() (native solver); MULTICAL_BACKEND=hip-scipy -> install(mode="scipy"); anything else
+  keeps the reference's scipy path untouched."""
+  backend = os.environ.get("MULTICAL_BACKEND", "scipy").lower()
+  if backend == "hip":
     return install()
+  if backend in ("hip-scipy", "hip_scipy"):
+    return install(mode="scipy")
   return None

@@ -66,6 +66,56 @@ def test_install_from_env(monkeypatch):
   finally:
     dropin.uninstall()
   assert refcal.Calibration.bundle_adjust is original
+  monkeypatch.setenv("MULTICAL_BACKEND", "hip-scipy")
+  try:
+    assert dropin.install_from_env() is refcal.Calibration
+    assert refcal.Calibration.bundle_adjust is dropin.bundle_adjust_scipy
+    assert refcal.Calibration._scipy_bundle_adjust is original
+  finally:
+    dropin.uninstall()
+  assert refcal.Calibration.bundle_adjust is original
+
+
+@pytest.mark.needs_reference
+def test_scipy_mode_keeps_the_signature_and_fails_loudly_without_a_gpu():
+  """dropin.install(mode="scipy"): the reference's own least_squares call with mcba_residuals + mcba_jacobian plugged in
+  (calibration.py:208-210).  Same signature; on the GPU-less build box it reaches mcba_create on the REAL reference objects
+  and fails there -- it never falls back to the reference's CPU evaluate."""
+  import inspect
+  from oracle import refload, build_reference
+  refload.load()
+  import multical.optimization.calibration as refcal
+  original = refcal.Calibration.bundle_adjust
+  with pytest.raises(ValueError, match="unknown mode"):
+    dropin.install(mode="cpu")
+  assert refcal.Calibration.bundle_adjust is original
+  try:
+    dropin.install(mode="scipy")
+    assert refcal.Calibration.bundle_adjust is dropin.bundle_adjust_scipy
+    assert list(inspect.signature(dropin.bundle_adjust_scipy).parameters) == list(inspect.signature(original).parameters)
+    if not gpu_available():
+      rig = synthetic.make_rig("tiny_handeye")
+      ref_calib, _ = build_reference.reference_calibration(rig)
+      with pytest.raises(RuntimeError, match="no HIP device|GPU-only"):
+        ref_calib.bundle_adjust()
+  finally:
+    dropin.uninstall()
+  assert refcal.Calibration.bundle_adjust is original
+
+
+def test_solver_selection_of_the_mirror_is_validated():
+  assert calibration.get_solver() in calibration.SOLVERS
+  prev = calibration.set_solver("scipy")
+  try:
+    assert calibration.get_solver() == "scipy"
+    with pytest.raises(ValueError, match="unknown solver"):
+      calibration.set_solver("cpu")
+    assert calibration.get_solver() == "scipy"
+  finally:
+    calibration.set_solver(prev)
+  rig = synthetic.make_rig("tiny_handeye")
+  with pytest.raises(ValueError, match="unknown solver"):
+    mirror(rig).bundle_adjust(solver="lsmr")
 
 
 class _PlainCalibration(calibration.Calibration):
@@ -135,6 +185,31 @@ def test_dropin_runs_the_reference_call_chains_on_the_gpu():
     dropin.uninstall(calibration_module=mod)
   with pytest.raises(AssertionError, match="un-patched"):
     _as_plain(mirror(rig)).bundle_adjust()
+
+
+@pytest.mark.gpu
+def test_dropin_scipy_mode_reproduces_the_reference_end_point_on_the_gpu():
+  """dropin.install(mode="scipy") on the reference-shaped call chains: bundle_adjust and the complete adjust_outliers loop land
+  on the reference's END points (1e-6 px; cfg1 = BASELINE configs[0], hand-eye) with identical inlier masks."""
+  mod = types.SimpleNamespace(Calibration=_PlainCalibration)
+  try:
+    assert dropin.install(calibration_module=mod, mode="scipy") is _PlainCalibration
+    g, rig = load_golden("cfg1")
+    c = _as_plain(mirror(rig))
+    x_before = c.param_vec.copy()
+    out = c.bundle_adjust()
+    assert isinstance(out, _PlainCalibration) and np.array_equal(c.param_vec, x_before)
+    assert abs(calibration.error_stats(out.reprojection_error).rms - float(g["ba_rms"])) < 1e-6
+    ao = c.adjust_outliers(num_adjustments=3, select_outliers=calibration.select_threshold(0.75, 5.0), loss='linear',
+                           tolerance=1e-4)
+    assert np.array_equal(ao.inliers, g["ao_inliers"])
+    assert abs(calibration.error_stats(ao.reprojection_inliers).rms - float(g["ao_rms_inliers"])) < 1e-6
+    g, rig = load_golden("tiny_handeye")
+    he = _HandEyeCalibration(_as_plain(mirror(rig)), np.linalg.inv(rig.init.hand_eye.base_wrt_gripper), rig.init.rig)
+    he2 = he.bundle_adjust()
+    assert abs(calibration.error_stats(he2.calib.reprojection_error).rms - float(g["ba_rms"])) < 1e-6
+  finally:
+    dropin.uninstall(calibration_module=mod)
 
 
 @pytest.mark.gpu
