@@ -363,8 +363,10 @@ def test_product_scipy_mode_logs_scipys_own_table_and_drives_workspace_calibrate
   ref_rows = [l.split() for l in str(g["ba_log"]).splitlines() if l.strip() and l.split()[0].isdigit()]
   rows = [l.split() for l in "\n".join(ba_lines).splitlines() if l.strip() and l.split()[0].isdigit()]
   assert len(rows) == len(ref_rows)
-  for a, b in zip(rows, ref_rows):     # iteration, nfev, cost, cost reduction, step norm to the printed digits
-    assert a[:5] == b[:5], (a, b)
+  for a, b in zip(rows, ref_rows):     # iteration, nfev, cost to the printed digits; cost reduction / step norm to a percent
+    assert a[:3] == b[:3], (a, b)      # (analytic instead of forward-difference Jacobian: the last printed digit may differ)
+    for u, v in zip(a[3:5], b[3:5]):
+      assert float(u) == pytest.approx(float(v), rel=1e-2), (a, b)
   assert any("`ftol` termination condition is satisfied." in l for l in ba_lines)
   assert np.array_equal(ao.inliers, g["ao_inliers"])
   assert abs(ao.error_statistics(True).rms - float(g["ao_rms_inliers"])) <= 1e-6

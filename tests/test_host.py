@@ -165,3 +165,43 @@ def test_pose_table_outlier_pose_rejection():
   # a rig without the key keeps every detected view (the other BASELINE configurations)
   rig2 = synthetic.make_rig("cfg2", frames=5)
   assert not synthetic.make_pose_table(rig2, seed=3)["rejected"].any()
+
+
+def test_parameter_deltas_are_gauge_invariant():
+  """multical_amd.gauge: the 12-dimensional gauge freedom of the bundle adjustment (camera -> camera T^-1, rig -> T rig; rig ->
+  rig S^-1, board -> S board; calibration.py:99-112 removes the first at export time) does not show up in the physical
+  differences, a real change does."""
+  from scipy.spatial.transform import Rotation
+  from multical_amd import gauge
+  for name in ("tiny", "tiny_rolling"):
+    rig = synthetic.make_rig(name)
+    c = calibration.from_rig(rig)
+
+    def rigid(seed):
+      r = np.random.default_rng(seed)
+      T = np.eye(4)
+      T[:3, :3] = Rotation.from_rotvec(r.normal(0, 0.4, 3)).as_matrix()
+      T[:3, 3] = r.normal(0, 0.3, 3)
+      return T
+
+    T, S = rigid(1), rigid(2)
+    moved = c.copy(camera_poses=c.camera_poses.post_transform(np.linalg.inv(T)),
+                   motion=c.motion.pre_transform(T).post_transform(np.linalg.inv(S)),
+                   board_poses=c.board_poses.pre_transform(S))
+    d = gauge.parameter_deltas(c, moved)
+    assert max(d.camera_deg, d.frame_deg, d.board_deg) < 1e-10 and max(d.camera_t, d.frame_t, d.board_t) < 1e-12
+    assert d.focal_rel == 0 and d.principal_px == 0 and d.dist_abs == 0
+    # a real difference: camera 1 rotated by 0.01 degrees, its focal length 0.1 % longer
+    cams = c.camera_poses.poses.copy()
+    R = np.eye(4)
+    R[:3, :3] = Rotation.from_rotvec([0, 0, np.radians(0.01)]).as_matrix()
+    cams[1] = R @ cams[1]
+    cam1 = c.cameras[1]
+    K = cam1.intrinsic.copy()
+    K[0, 0] *= 1.001
+    from multical_amd.parameters import ParamList
+    cameras = ParamList([cam1.copy(intrinsic=K) if i == 1 else cam for i, cam in enumerate(c.cameras)], c.cameras.names)
+    changed = moved.copy(camera_poses=moved.camera_poses.copy(pose_table=moved.camera_poses.pose_table._extend(poses=cams @ np.linalg.inv(T))),
+                         cameras=cameras)
+    d = gauge.parameter_deltas(c, changed)
+    assert abs(d.camera_deg - 0.01) < 1e-9 and abs(d.focal_rel - 1e-3 / 1.001) < 1e-12
