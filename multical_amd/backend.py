@@ -200,6 +200,10 @@ class Handle(object):
   def set_lin_grid(self, grid):
     check(self.lib.mcba_debug_set_lin_grid(self.h, int(grid)))
 
+  def set_frame_groups(self, nw):
+    """experiment: bind the views of a frame to nw waves (0 = the product's largest-first list of views)."""
+    check(self.lib.mcba_debug_set_frame_groups(self.h, int(nw)))
+
   def set_inliers(self, mask):
     self._jac_pattern = None
     if mask is None:

@@ -1401,6 +1401,63 @@ int32_t mcba_debug_set_lin_grid(mcba_handle h, int32_t grid) {
   API_END
 }
 
+// Experiment: what would a FRAME-level linearisation cost in load balance alone?  Replaces the
+// largest-first list of views by a list in which wave (frame rank r, w), w < nw, walks only views of frame r -- the frames
+// largest-first, the views of a frame dealt to its nw waves by greedy longest-processing-time -- and sets the grid to
+// frames x nw single-wave workgroups.  The kernel itself is unchanged (per-view records, no LDS reduction), so the time
+// measured is a LOWER bound for a kernel whose workgroups own whole frames.  nw = 0 restores the product's list.
+int32_t mcba_debug_set_frame_groups(mcba_handle h, int32_t nw) {
+  API_BEGIN
+  REQUIRE(h && nw >= 0 && nw <= 16, "bad argument");
+  const Dims& d = h->d;
+  if (nw == 0) {
+    h->lin_grid = 0;
+    refresh_active_views(h);
+    sync(h);
+    return 0;
+  }
+  const int cb = d.C * d.B, nv = d.views();
+  std::vector<int32_t> cnt((size_t)nv);
+  HIP_OK(hipMemcpyAsync(cnt.data(), h->view_count.p, (size_t)nv * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  sync(h);
+  std::vector<std::pair<long long, int>> frames;   // (observations, local frame)
+  for (int fl = 0; fl < d.Fl; ++fl) {
+    long long tot = 0;
+    for (int k = 0; k < cb; ++k) tot += cnt[(size_t)fl * cb + k];
+    if (tot > 0) frames.push_back({tot, fl});
+  }
+  std::sort(frames.begin(), frames.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+  const int nf = (int)frames.size(), grid = nf * nw;
+  std::vector<std::vector<int>> lists((size_t)grid);
+  size_t rounds = 0;
+  for (int r = 0; r < nf; ++r) {
+    const int fl = frames[r].second;
+    std::vector<std::pair<int, int>> vs;
+    for (int k = 0; k < cb; ++k)
+      if (cnt[(size_t)fl * cb + k] > 0) vs.push_back({cnt[(size_t)fl * cb + k], fl * cb + k});
+    std::sort(vs.begin(), vs.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+    std::vector<long long> load((size_t)nw, 0);
+    for (const auto& e : vs) {
+      int w = 0;
+      for (int q = 1; q < nw; ++q)
+        if (load[q] < load[w]) w = q;
+      load[w] += e.first + 100;     // (+ the fixed cost of a view, in observations)
+      lists[(size_t)r * nw + w].push_back(e.second);
+      rounds = std::max(rounds, lists[(size_t)r * nw + w].size());
+    }
+  }
+  std::vector<int32_t> host(1 + rounds * (size_t)grid, -1);
+  host[0] = (int32_t)(rounds * (size_t)grid);
+  for (int g = 0; g < grid; ++g)
+    for (size_t q = 0; q < lists[g].size(); ++q) host[1 + q * (size_t)grid + g] = lists[g][q];
+  if (h->active_views.n < host.size()) h->active_views.alloc(host.size(), false);
+  h->t.active_views = h->active_views.p;
+  HIP_OK(hipMemcpyAsync(h->active_views.p, host.data(), host.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+  sync(h);
+  h->lin_grid = grid;
+  API_END
+}
+
 int32_t mcba_residuals(mcba_handle h, const double* x, double* r) {
   API_BEGIN
   REQUIRE(h && x && r, "null argument");

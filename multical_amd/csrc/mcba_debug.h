@@ -12,6 +12,9 @@ extern "C" {
 int32_t mcba_set_mfma(mcba_handle h, int32_t on);
 /* number of persistent k_linearize workgroups; 0 = automatic (profiling aid)                                        */
 int32_t mcba_debug_set_lin_grid(mcba_handle h, int32_t grid);
+/* experiment: views of a frame bound to nw waves of "its" workgroup (load-balance bound of a frame-level linearisation);
+ * nw = 0 restores the largest-first list of views                                                                     */
+int32_t mcba_debug_set_frame_groups(mcba_handle h, int32_t nw);
 /* FP64 VALU vs FP64 MFMA pipe-sharing probe: ms_out[3] = all-FMA, all-MFMA, half / half        */
 int32_t mcba_debug_pipe_probe(int32_t iters, double* ms_out);
 /* workgroup dispatch rate: launches `blocks` workgroups of `threads` threads with `lds_bytes` of LDS, each running `spin`

@@ -22,6 +22,7 @@
 // residual function `evaluate` (calibration.py:204-206) and is tested as such.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "mcba_view.h"
 
 namespace mcba {
@@ -289,6 +290,45 @@ __device__ __forceinline__ double se3_mul_entry(const double* A, const double* B
 // Chain matrices board -> camera of view (f, c, b) straight from the pose table, by the lanes of ONE wavefront: lane
 // (chain, entry) forms one entry of each product, the intermediate goes through LDS (tmp [2][12], out [NCH][VIEW_STRIDE]).
 // The same matrices as view_chain; formed by every lane in registers they kept 36 doubles live (k_cost: 191 VGPRs).
+// Column j of That from the chain prefixes, for the lane-per-column prologue of k_linearize: the same construction as
+// that_column_from_prefix (mcba_view.h), but what depends on the lane's pose block -- prefix rotation (identity for the camera,
+// R1 for the board, the camera rotation for a frame pose), origin, left Jacobian or unit vector -- is chosen by selecting the
+// LDS ADDRESS once (a handful of 32-bit selects) instead of selecting every loaded double (~120 v_cndmask per view, a fifth
+// of the prologue's VALU instructions).  eye = a 3 x 3 identity in LDS.
+template <bool ROLL>
+__device__ __forceinline__ void that_column_sel(const double* Pc, const double* Pm0, const double* Pm1, const double* Pb,
+                                                const double* pre /*[NCH][PRE_STRIDE]*/, const double* eye, int j, double* Tm,
+                                                int stride) {
+  constexpr int NCH = ROLL ? 2 : 1, NPB = ROLL ? 4 : 3;
+  const int k = j / 6, jj = j - 6 * k;
+  const bool rotcol = jj < 3;
+  const int ju = rotcol ? jj : jj - 3;
+  const bool is_cam = k == 0, is_board = k == NPB - 1;
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    const double* Pf = ch == 0 ? Pm0 : Pm1;
+    const double* R1 = pre + ch * PRE_STRIDE;
+    const bool active = is_cam || is_board || !ROLL || k == 1 + ch;
+    const double* Lp = !rotcol ? eye : (is_cam ? Pc + POSE_L : (is_board ? Pb + POSE_L : Pf + POSE_L));
+    const double* Rp = is_cam ? eye : (is_board ? R1 : Pc + POSE_R);
+    const double* op = is_cam ? Pc + POSE_T : (is_board ? R1 + 21 : R1 + 9);
+    const double u0 = Lp[ju], u1 = Lp[3 + ju], u2 = Lp[6 + ju];   // column ju of L (rotation columns) or a unit vector
+    double tv[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tv[i] = Rp[3 * i] * u0 + Rp[3 * i + 1] * u1 + Rp[3 * i + 2] * u2;   // R_pre u
+    const double o0 = op[0], o1 = op[1], o2 = op[2];
+    const double c0 = o1 * tv[2] - o2 * tv[1], c1 = o2 * tv[0] - o0 * tv[2], c2 = o0 * tv[1] - o1 * tv[0];
+    const double w = active ? 1.0 : 0.0, wr = rotcol ? w : 0.0, wt = rotcol ? 0.0 : w;
+    double* col = Tm + (size_t)(6 * ch) * stride + j;
+    col[0 * stride] = wr * tv[0];
+    col[1 * stride] = wr * tv[1];
+    col[2 * stride] = wr * tv[2];
+    col[3 * stride] = wr * c0 + wt * tv[0];
+    col[4 * stride] = wr * c1 + wt * tv[1];
+    col[5 * stride] = wr * c2 + wt * tv[2];
+  }
+}
+
 template <bool ROLL>
 __device__ __forceinline__ void view_chain_wave(const Dims& d, const Tables& t, int f, int c, int b, int lane,
                                                 double* tmp, double* out) {
@@ -662,6 +702,8 @@ void k_linearize(Dims d, Tables t, double* __restrict__ rec,
   // registers, more than the SGPR file has left) also read them from here in the main loop
   constexpr bool VLDS = FUSED || ROLL;
   __shared__ double VmBuf[VLDS ? NBUFS * NVS : 1];
+  __shared__ double Eye3[9];                 // 3 x 3 identity for the address selects of that_column_sel
+  if (threadIdx.x < 9) Eye3[threadIdx.x] = (threadIdx.x & 3) == 0 ? 1.0 : 0.0;
   double* Vbuf = Buf;
   if constexpr (FUSED) {   // the assembly that follows accumulates into [g | diag | cost] and H_ss
     for (int e = blockIdx.x * 64 + threadIdx.x; e < na; e += gridDim.x * 64) zero_a[e] = 0.0;
@@ -750,6 +792,7 @@ void k_linearize(Dims d, Tables t, double* __restrict__ rec,
   bool front_ready = false;    // the front of the view about to be processed is already in LDS copy `cur` (PIPE)
   for (int vi = blockIdx.x; vi < n_active; vi += gridDim.x) {
   const int v = t.active_views[1 + vi];
+  if (v < 0) continue;         // (padding of a hand-made list: mcba_debug_set_frame_groups)
   const int b = v % d.B, c = (v / d.B) % d.C, fl = v / (d.B * d.C), f = d.f0 + fl;
   (void)f;
   // (PIPE) the view after this one: its index is needed early, it heads the next front's dependent chain of loads
@@ -846,7 +889,7 @@ void k_linearize(Dims d, Tables t, double* __restrict__ rec,
         Vm[pcc * VIEW_STRIDE + pq] = val;   // the chain matrix board -> camera of this chain
       }
       lds_fence();
-      if (pl < NPC) that_column_from_prefix<ROLL>(Pc, Pm0, Pm1, Pb, pre, pl, Tm, NPC);
+      if (pl < NPC) that_column_sel<ROLL>(Pc, Pm0, Pm1, Pb, pre, Eye3, pl, Tm, NPC);
     } else if (pl < NPC) {                 // hand-eye (five-pose chain): one column of That per lane
       double col[DE];
       view_column_p(d, Pc, Pb, Pm0, Pm1, Bf, pl, col);
@@ -916,9 +959,12 @@ void k_linearize(Dims d, Tables t, double* __restrict__ rec,
   int count_n = 0;             // (PIPE) inliers of the next view, known once its front is finished
   int count_total = count;     // inliers of the whole view (a board with > LIN_MAX_POINTS points is walked in segments)
   for (int seg0 = 0;;) {
-  for (int base = 0; base < count; base += 64) {
+  // one chunk of 64 observations.  FULL = every lane holds an observation: no predicate, no zero state for idle lanes (the
+  // merge of `in ? state : 0` cost 29 moves + a dozen selects per chunk); only the last chunk of a view takes the general form
+  auto do_chunk = [&](int base, auto full_tag) {
+    constexpr bool FULLC = decltype(full_tag)::value;
     const int i = base + lane;
-    const bool in = i < count;
+    const bool in = FULLC || i < count;
     const int inx = i + 64;
     const int p_nxt = inx < count ? pidx[inx] : p_cur;
     const double2 ob_nxt = t.obs[(size_t)v * d.P + p_nxt];
@@ -926,11 +972,18 @@ void k_linearize(Dims d, Tables t, double* __restrict__ rec,
     PointState<ND, ROLL> ps;
     long long t0 = 0;
     if (prof) t0 = clock64();
+    // rolling shutter: the two chain matrices of the view are read from LDS into registers HERE, as LDS reads (handed to
+    // point_state as a pointer that may also be the global view table they became twelve flat loads per chunk)
+    double Vl[ROLL ? NVS : 1];
+    if constexpr (ROLL) {
+#pragma unroll
+      for (int k = 0; k < NVS; ++k) Vl[k] = Vm[k];
+    }
     if (in) {
 #if defined(MCBA_EXP_NO_SCALAR_TABLES)   // A/B switch of the profiling builds: table reads left to the compiler
       cost += point_state<ND, FISH, ROLL, ROBUST>(d, t, v, c, b, p_cur, ob_cur, ps, X_cur, FUSED ? Vm : nullptr, camp);
 #else
-      cost += point_state<ND, FISH, ROLL, ROBUST>(d, t, v, c, b, p_cur, ob_cur, ps, X_cur, ROLL ? Vm : Vr, camr, extp);
+      cost += point_state<ND, FISH, ROLL, ROBUST>(d, t, v, c, b, p_cur, ob_cur, ps, X_cur, ROLL ? Vl : Vr, camr, extp);
 #endif
     } else {   // lanes past the end of the list stage zero rows
       ps = PointState<ND, ROLL>{};
@@ -1002,6 +1055,11 @@ void k_linearize(Dims d, Tables t, double* __restrict__ rec,
       }
       lds_fence();
     }
+  };
+  {
+    int base = 0;
+    for (; base + 64 <= count; base += 64) do_chunk(base, std::true_type{});
+    if (base < count) do_chunk(base, std::false_type{});
   }
   seg0 += LIN_MAX_POINTS;
   if (seg0 >= d.P) break;
