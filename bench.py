@@ -120,6 +120,9 @@ def main():
   ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; the median is reported")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-solve", action="store_true")
+  ap.add_argument("--solve-repeats", type=int, default=5, help="default-tolerance solves; the median is reported")
+  ap.add_argument("--no-scipy-mode", action="store_true")
+  ap.add_argument("--scipy-frames", type=int, default=20, help="frames of the sample the scipy-driven product mode is timed on")
   args = ap.parse_args()
   if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
     sys.exit(self_launch(args))
@@ -166,7 +169,7 @@ def main():
       native = mdist.init_native_allreduce(h, rank, world)
     if not native:
       h.set_allreduce(mdist.make_allreduce_hook(stream=tstream))
-    h.set_shard_root(rank == 0)
+    h.set_shard_rank(rank, world)
   n_slots = int(np.prod(rig.valid.shape[0:1] + (FRAMES_PER_SHARD,) + rig.valid.shape[2:]))
   n_obs = h.n_residuals // 2
 
@@ -234,7 +237,7 @@ def main():
       snative = mdist.init_native_allreduce(hs, rank, world)
     if not snative:
       hs.set_allreduce(mdist.make_allreduce_hook(stream=tstream))
-    hs.set_shard_root(rank == 0)
+    hs.set_shard_rank(rank, world)
     sx = np.ascontiguousarray(scalib.param_vec)
     check(hs.lib.mcba_normal_equations(hs.h, _ptr(sx, C.c_double), C.byref(opt), C.byref(cost), None, None))
     sdt = timed(lambda: check(hs.lib.mcba_normal_equations_device(hs.h, C.byref(opt))))
@@ -260,12 +263,11 @@ def main():
                   frac=tflops / FP64_PEAK_TFLOPS, traffic=None, launch_ms=lin_ms, algorithmic_flops=alg_flops,
                   algorithmic_bytes=alg_bytes,
                   hbm=dict(achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS),
-                  residual_kernel=dict(bound="hbm", launch_ms=res_ms, achieved=alg_bytes / (res_ms * 1e-3) / 1e9,
-                                       frac=alg_bytes / (res_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                       note="algorithmic bytes (17 B per table slot + 16 B per observation) over the launch "
-                                            "time; the kernel gathers the observations of the inlier slots only (mask bytes "
-                                            "compacted per view), so the bytes it moves are below the algorithmic figure "
-                                            "(PMC: profiles/r02_pmc.json)"))
+                  residual_kernel=dict(bound="hbm", launch_ms=res_ms, counter_bytes=None, achieved=None, frac=None,
+                                       note="k_residual gathers the observations of the inlier slots only (mask bytes compacted "
+                                            "per view), so its traffic is taken from the PMC counters of the committed profile "
+                                            "(profiles/hbm_traffic.json: FETCH_SIZE x2 + WRITE_SIZE), not from the algorithmic "
+                                            "17 B / slot + 16 B / observation, which it does not move"))
   # HBM bytes per launch from the PMC counters: they cannot be read inside an un-profiled run, so the figure of the
   # committed rocprofv3 passes of the same command is quoted and labelled as such (profiles/hbm_traffic.json: separate
   # --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction)
@@ -274,6 +276,12 @@ def main():
     try:
       tj = json.load(open(traffic_file))
       roofline["traffic"] = tj.get("k_linearize_bytes_per_launch")
+      rb = tj.get("k_residual_bytes_per_launch")
+      if rb:
+        rk = roofline["residual_kernel"]
+        rk["counter_bytes"] = rb
+        rk["achieved"] = rb / (res_ms * 1e-3) / 1e9
+        rk["frac"] = rk["achieved"] / HBM_PEAK_GBS
       roofline["traffic_source"] = "profiles/hbm_traffic.json (" + str(tj.get("source", "rocprofv3 --pmc passes")) + "), not measured in this run"
     except Exception:
       pass
@@ -281,19 +289,70 @@ def main():
   # ---- LM iterations/s and final RMS: one full bundle adjustment of the same problem (not part of `value`) --------
   extra = {}
   if not args.no_solve:
+    # the default solve of the rig (scipy's defaults: ftol 1e-4), repeated: median of the repeats; and a LONG solve (tight
+    # tolerances, fixed number of trial steps from a perturbed start) whose per-trial-step time is the steady-state figure
+    solves = []
+    for _ in range(max(1, args.solve_repeats)):
+      barrier()
+      t0 = time.perf_counter()
+      res = h.solve(x0)
+      barrier()
+      solves.append((time.perf_counter() - t0, res.nfev))
+    t_solve, nfev_med = sorted(solves)[len(solves) // 2]
+    if world > 1:
+      h.allreduce_stats(reset=True)
+    rng = np.random.default_rng(1)
+    x1 = x0 + 1e-3 * rng.normal(size=x0.size)
     barrier()
     t0 = time.perf_counter()
-    res = h.solve(x0)
+    lres = h.solve(x1, tolerance=1e-15, xtol=1e-15, gtol=1e-15, max_iterations=41)
     barrier()
-    t_solve = time.perf_counter() - t0
+    t_long = time.perf_counter() - t0
     e, v = h.reprojection_error(res.x)
     sq = torch.tensor([float((e[v] ** 2).sum()), float(v.sum())], dtype=torch.float64, device="cuda")
     if world > 1:
       dist.all_reduce(sq)
-    extra = dict(lm_iters_per_s=(res.nfev - 1) / t_solve, lm_trial_steps=res.nfev - 1, lm_linearizations=res.njev,
-                 solve_seconds=t_solve, solve_status=res.status,
+    extra = dict(lm_iters_per_s=(nfev_med - 1) / t_solve, lm_trial_steps=res.nfev - 1, lm_linearizations=res.njev,
+                 solve_seconds=t_solve, solve_seconds_all=[t for t, _ in solves], solve_status=res.status,
+                 lm_long_solve=dict(trial_steps=lres.nfev - 1, seconds=t_long, us_per_trial_step=t_long / max(lres.nfev - 1, 1) * 1e6,
+                                    iters_per_s=max(lres.nfev - 1, 1) / t_long),
                  final_rms_px=float(torch.sqrt(sq[0] / sq[1]).item()), final_cost=res.cost,
                  initial_cost=res.initial_cost)
+    if world > 1:
+      calls, doubles, sizes = h.allreduce_stats(reset=True)
+      extra["lm_long_solve"]["allreduce"] = dict(calls=calls, bytes=8 * doubles, calls_per_trial_step=calls / max(lres.nfev - 1, 1),
+                                                 bytes_per_trial_step=8 * doubles / max(lres.nfev - 1, 1),
+                                                 message_doubles=sorted(set(abs(s) for s in sizes)))
+  # collectives of ONE evaluation step (N > 1)
+  step_comm = None
+  if world > 1:
+    h.allreduce_stats(reset=True)
+    step()
+    barrier()
+    calls, doubles, sizes = h.allreduce_stats(reset=True)
+    step_comm = dict(allreduce_calls=calls, allreduce_bytes=8 * doubles, message_doubles=[abs(s) for s in sizes])
+
+  # ---- the reference's own solver on the device functions (product mode solver="scipy"), beside the native solve -----
+  scipy_mode = None
+  if world == 1 and not args.no_scipy_mode:
+    srig = synthetic.make_rig("cfg3", frames=args.scipy_frames)
+    sc = calibration.from_rig(srig)
+    with Handle(lower(sc)) as hsm:
+      sx0 = sc.param_vec
+      hsm.solve(sx0)
+      t0 = time.perf_counter(); nres = hsm.solve(sx0); t_nat = time.perf_counter() - t0
+      t0 = time.perf_counter(); sres = hsm.solve_scipy(sx0, verbose=0); t_sci = time.perf_counter() - t0
+
+      def rms_at(x):
+        e_, v_ = hsm.reprojection_error(x)
+        return float(np.sqrt(np.mean(e_[v_] ** 2)))
+      scipy_mode = dict(sample=f"first {args.scipy_frames} of {FRAMES_PER_SHARD} frames of the same rig ({hsm.n_residuals} residuals, "
+                               f"{hsm.n_params} parameters)",
+                        scipy_mode_seconds=t_sci, scipy_mode_nfev=sres.nfev, scipy_mode_rms_px=rms_at(sres.x),
+                        native_seconds=t_nat, native_nfev=nres.nfev, native_rms_px=rms_at(nres.x),
+                        note="scipy mode = scipy.optimize.least_squares(method='trf', x_scale='jac') exactly as "
+                             "optimization/calibration.py:209-210 on mcba_residuals + mcba_jacobian: the reference's end point "
+                             "(profiles/parity_table.md), scipy's LSMR on the host")
 
   out = None
   if rank == 0:
@@ -317,6 +376,10 @@ def main():
                roofline=roofline, **extra)
     if strong is not None:
       out["strong_scaling"] = strong
+    if step_comm is not None:
+      out["step_collectives"] = step_comm
+    if scipy_mode is not None:
+      out["scipy_mode"] = scipy_mode
     if world == 1 and not args.no_cpu_baseline:
       out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out), flush=True)

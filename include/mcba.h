@@ -182,6 +182,11 @@ int32_t mcba_rccl_shutdown(mcba_handle h);
 /* exactly one rank of a sharded problem is the root: it contributes the replicated (shared) right-hand side to the
  * reduced system.  Default: root.  Ranks other than 0 call this with 0.                                          */
 int32_t mcba_set_shard_root(mcba_handle h, int32_t is_root);
+/* rank of this handle among the `world` (<= 64) handles of one frame-sharded problem; rank 0 is the root.  Needed with a
+ * callback (mcba_set_allreduce); mcba_rccl_init sets it itself.  The messages of a sharded handle are per-rank partial sums
+ * gathered by summation (block `rank` of a zeroed buffer) and the SHARED entries of [g | diag]: none grows with the number
+ * of frames (mcba_allreduce_stats).                                                                                  */
+int32_t mcba_set_shard_rank(mcba_handle h, int32_t rank, int32_t world);
 int32_t mcba_set_log(mcba_handle h, mcba_log_fn fn, void* ctx);
 
 /* --- evaluation -------------------------------------------------------------------------------------------- */

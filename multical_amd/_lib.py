@@ -63,6 +63,7 @@ SYMBOLS = [
   ("mcba_set_inliers", C.c_int32, [H, c_uint8_p]),
   ("mcba_set_allreduce", C.c_int32, [H, ALLREDUCE_FN, C.c_void_p]),
   ("mcba_set_shard_root", C.c_int32, [H, C.c_int32]),
+  ("mcba_set_shard_rank", C.c_int32, [H, C.c_int32, C.c_int32]),
   ("mcba_allreduce_stats", C.c_int32, [H, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                        C.c_int32, C.POINTER(C.c_int32)]),
   ("mcba_set_log", C.c_int32, [H, LOG_FN, C.c_void_p]),

@@ -384,6 +384,10 @@ class Handle(object):
   def set_shard_root(self, is_root):
     check(self.lib.mcba_set_shard_root(self.h, 1 if is_root else 0))
 
+  def set_shard_rank(self, rank, world):
+    """rank of this handle among the `world` handles of one frame-sharded problem (rank 0 = root)."""
+    check(self.lib.mcba_set_shard_rank(self.h, int(rank), int(world)))
+
   def allreduce_stats(self, reset=True, cap=4096):
     """(calls, doubles, sizes): collectives this (frame-sharded) handle issued since the last reset; `sizes` lists the
     element counts in issue order (negative = max reduction)."""

@@ -230,6 +230,7 @@ constexpr int COST_BLOCKS_MAX = 4608;   // persistent single-wave workgroups of 
 // Frame-sharded handles all-reduce the H-dependent partial arrays element-wise before they are folded.
 constexpr int N_SCALARS = 32;
 constexpr int Q00_BLOCKS = 512;
+constexpr int SHARD_MAX_WORLD = 64;   // ranks of a frame-sharded problem (one node has 8)
 struct ScalLayout {
   int nvb = 0;        // blocks of the element-wise vector kernels, ceil(n / 256)
   int vs = 0;         // [3 nvb]           k_vec_scale partials
@@ -238,6 +239,9 @@ struct ScalLayout {
   int costp = 0;      // [COST_BLOCKS_MAX] k_cost partials (all-reduced element-wise when sharded)
   int dotp = 0;       // [3 nblk + 1]      partial dots + pivot report (folded by k_vec_step)
   int fold = 0;       // [4]               totals of the vs / q00p partials of a point scaled ahead (k_fold_tr)
+  // frame-sharded handles: the per-rank partials of a message, gathered by summation (block r = rank r, k_shard_fold*)
+  int shard2 = 0;     // [4 W]             [|g|_inf, |g_h|^2, |x scale|^2] x W | curvature x W
+  int shard4 = 0;     // [3 W + 1]         {g_h.g_h, g_h.gn, gn.gn} x W | pivot report
   int total = 0;
   void init(int n, int dot_blocks) {
     nvb = (n + 255) / 256;
@@ -247,7 +251,9 @@ struct ScalLayout {
     costp = step + (3 * nvb + 1) / 2 * 2;
     dotp = costp + COST_BLOCKS_MAX;
     fold = dotp + (3 * dot_blocks + 8 + 1) / 2 * 2;
-    total = fold + 4;
+    shard2 = fold + 4;
+    shard4 = shard2 + 4 * SHARD_MAX_WORLD;
+    total = shard4 + 3 * SHARD_MAX_WORLD + 2;
   }
 };
 
@@ -264,10 +270,11 @@ struct mcba_handle_s {
   bool own_stream = false;
   bool use_mfma = true;
   bool shard_root = true;
+  DevBuf<double> comm;   // frame-sharded handles: [g_s | diag_s | cost, count | step norms] of the linearisation's message
   ScalLayout sl;
   size_t asm_lds_set = 48 * 1024;
-  size_t chol_lds_set = 0, chol_lds2_set = 0, chol_lds3_set = 0, chol_lds4_set = 0, chol_lds5_set = 0;
-  DevBuf<double> chol_linv;   // inverted diagonal tiles of k_chol_glb
+  size_t chol_lds3_set = 0, chol_lds5_set = 0;
+  DevBuf<double> chol_linv;   // inverted diagonal tiles of the panel kernels (k_cholp_back)
   int lin_grid = 0;          // 0 = automatic (see lin2), > 0 = forced number of persistent workgroups (debug)
 
   int64_t n_inliers = 0;               // inliers of this shard
@@ -335,11 +342,6 @@ struct mcba_handle_s {
   // speculative linearisation of the same point instead of in front of it
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_side = nullptr;
-  // captured evaluation (MCBA_GRAPH=1): the launch sequence of one residual+Jacobian evaluation as a hipGraph
-  hipGraphExec_t eval_graph = nullptr;
-  const double* eval_graph_x = nullptr;
-  int eval_graph_loss = -1;
-  double eval_graph_fscale = 0.0;
 
   size_t h_scal_bytes = 0, h_x_bytes = 0, h_gbuf_bytes = 0, h_totals_bytes = 0;   // sizes of the pinned buffers
   ~mcba_handle_s() {
@@ -353,7 +355,6 @@ struct mcba_handle_s {
     if (ev_fetch) (void)hipEventDestroy(ev_fetch);
     if (ev_side) (void)hipEventDestroy(ev_side);
     if (stream2 && !(g_park_on_release && resource_cache().park_stream(stream2, true))) (void)hipStreamDestroy(stream2);
-    if (eval_graph) (void)hipGraphExecDestroy(eval_graph);
     if (rccl_comm) destroy_rccl_comm(rccl_comm);
     if (own_stream && stream && !(g_park_on_release && resource_cache().park_stream(stream))) (void)hipStreamDestroy(stream);
   }
@@ -535,10 +536,10 @@ void check_launch(const char* what) {
   if (e != hipSuccess) throw Error(std::string("kernel launch failed (") + what + "): " + hipGetErrorString(e));
 }
 
-// MCBA_FUSED: 0 = table form (k_tmat + k_linearize), 1 = k_linearize forms everything from x, 2 = table-fed fused form
-int linearize_fused_mode() {
-  static const int mode = getenv("MCBA_FUSED") != nullptr ? atoi(getenv("MCBA_FUSED")) : 0;
-  return mode;
+// MCBA_FUSED=0 forces the table form (k_tmat + k_linearize); default: the table-fed fused form wherever it applies
+bool linearize_table_form() {
+  static const bool table = getenv("MCBA_FUSED") != nullptr && atoi(getenv("MCBA_FUSED")) == 0;
+  return table;
 }
 
 // fused residual+Jacobian -> block normal equations.  dx != nullptr: at the parameter vector dx (device); k_tmat then also
@@ -548,21 +549,7 @@ void launch_linearize(mcba_handle_s* h, const double* dx) {
   const Dims& d = h->d;
   // k_tmat also zeroes [g | diag | cost] and H_ss for the assembly that follows (entries of frames owned by other ranks
   // must be zero before the cross-rank sum: they hold the previous global values after an all-reduce)
-  // Fused form (opt-in, MCBA_FUSED=1): k_linearize itself forms That / the chain matrices from dx, reads the intrinsics
-  // from dx and zeroes the assembly targets -- one launch instead of two.  Conditions: the MFMA build, no tilted model
-  // (its tilt matrices come from the camera table, which only k_prep refreshes), board points not optimised (the
-  // board-point table is then constant: written once by mcba_create).  Measured at the north-star rig: the evaluation
-  // drops from 88.8 to 86.6 us, but the per-view prologue (Rodrigues of four poses on four lanes, divergent column code)
-  // grows from 3.8 k to 14 k cycles and k_linearize from 49.5 to 62 us -- the table form stays the default until the
-  // in-kernel prologue is lane-uniform.
-  const int fused_mode = linearize_fused_mode();
-  const bool fused_on = fused_mode == 1;
-  if (dx != nullptr && h->use_mfma && d.ND != 14 && d.off_boards < 0 && fused_on && h->t.dbg == nullptr) {
-    h->ops->linearize(d, h->t, h->stream, h->rec.p, h->tri.p, true, h->lin_grid, dx, h->gbuf.p, 2 * d.n + 2, h->Hss.p,
-                      d.ns * d.ns);
-    return;
-  }
-  // Table-fed fused form (MCBA_FUSED=2): no k_tmat, no That table.  The pose / camera tables of the point come from k_prep
+  // Table-fed fused form: no k_tmat, no That table.  The pose / camera tables of the point come from k_prep
   // (dx given) or from the tail of the k_vec_step that produced the point (dx == nullptr); k_linearize copies its view's
   // four pose entries from the table and forms the chain products / That columns itself.  Not with adjusted board points
   // (k_points reads the per-view chain table that only k_tmat / k_views write).
@@ -571,8 +558,7 @@ void launch_linearize(mcba_handle_s* h, const double* dx) {
   // 123 -> 117 -- although k_linearize itself grows (44.5 -> 47.3 us at the north-star rig: the chain products and That
   // columns are now inside it), the k_tmat launch, its That table (10 MB written + read per evaluation) and, behind a trial
   // step, any table kernel at all are gone.  MCBA_FUSED=0 forces the table form (k_tmat).
-  const bool auto_fused = getenv("MCBA_FUSED") == nullptr;
-  if ((fused_mode == 2 || auto_fused) && h->use_mfma && d.off_boards < 0 && h->t.dbg == nullptr) {
+  if (!linearize_table_form() && h->use_mfma && d.off_boards < 0 && h->t.dbg == nullptr) {
     if (dx != nullptr) eval_pose_tables(h, dx);
     h->ops->linearize(d, h->t, h->stream, h->rec.p, h->tri.p, true, h->lin_grid, nullptr, h->gbuf.p, 2 * d.n + 2, h->Hss.p,
                       d.ns * d.ns);
@@ -604,7 +590,8 @@ inline size_t assemble_lds_fixed(const Dims& d) {
   return (size_t)frame_entries(d) * sizeof(int) + 2 * (size_t)((d.C * d.B + 3) & ~3) * sizeof(uint16_t) + 16;
 }
 
-void launch_assemble(mcba_handle_s* h, unsigned long long publish_seq = 0, int cost_slot = 0) {
+// step_valid (frame-sharded solver): the k_vec_step partials of the step that led to this point ride with the message
+void launch_assemble(mcba_handle_s* h, unsigned long long publish_seq = 0, int cost_slot = 0, bool step_valid = false) {
   const Dims& d = h->d;
   // ([g | diag | cost] and H_ss were zeroed by k_tmat at the start of this linearisation)
   const int nfb = (d.DF > 0) ? d.Fl : 0;
@@ -647,7 +634,32 @@ void launch_assemble(mcba_handle_s* h, unsigned long long publish_seq = 0, int c
     h->ops->points(d, h->t, h->stream, (d.n - d.off_boards) / 3, h->Hss.p, h->Hfs.p, h->g());
     hipLaunchKernelGGL(k_shared_diag, dim3((d.ns + 255) / 256), dim3(256), 0, h->stream, d, h->Hss.p, h->diag());
   }
-  call_allreduce(h, h->gbuf.p, 2 * (size_t)d.n + 2, 0);
+  if (h->allreduce) {
+    // Frame-sharded: ONE message of 2 ns + 6 doubles -- the SHARED entries of [g | diag], {cost, count} and the step norms.
+    // The frame entries of g / diag are sums over the owner's observations alone: they never cross the ranks (round 3: the
+    // whole [g | diag | cost], 2 n + 2 doubles with n growing in the TOTAL number of frames).
+    if (d.shard_world <= 0) throw Error("frame-sharded handle without a rank: call mcba_set_shard_rank (or mcba_rccl_init)");
+    const size_t nc = 2 * (size_t)d.ns + SHARD_TAIL;
+    if (h->comm.n < nc) h->comm.alloc(nc, false);
+    const int grid = std::max(1, std::min(64, (d.ns + 255) / 256));
+    double* stepp = step_valid ? h->scal.p + h->sl.step : nullptr;
+    hipLaunchKernelGGL(k_shard_pack1, dim3(grid), dim3(256), 0, h->stream, d, h->g(), h->diag(), h->costcount(), stepp, h->sl.nvb,
+                       h->comm.p);
+    call_allreduce(h, h->comm.p, nc, 0);
+    hipLaunchKernelGGL(k_shard_unpack1, dim3(grid), dim3(256), 0, h->stream, d, h->comm.p, h->g(), h->diag(), h->costcount(),
+                       stepp, h->sl.nvb);
+  }
+}
+
+// frame-sharded handles: v[motion block] <- the owners' entries on every rank (an all-gather written as a sum of vectors that
+// are zero outside the own frames): the complete x a solve returns, the complete g / diag of the host-boundary evaluation
+void gather_frame_entries(mcba_handle_s* h, double* v) {
+  const Dims& d = h->d;
+  if (!h->allreduce || d.DF == 0 || d.off_motion < 0 || d.n_motion == 0) return;
+  if (h->sbuf.n < (size_t)d.n_motion) h->sbuf.alloc((size_t)d.n_motion, false);
+  hipLaunchKernelGGL(k_shard_own_frames, dim3((d.n_motion + 255) / 256), dim3(256), 0, h->stream, d, v, h->sbuf.p);
+  call_allreduce(h, h->sbuf.p, (size_t)d.n_motion, 0);
+  HIP_OK(hipMemcpyAsync(v + d.off_motion, h->sbuf.p, (size_t)d.n_motion * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
 }
 
 // internal (padded) n-vector -> the caller's vector
@@ -711,20 +723,18 @@ double host_sum(const double* p, int n) {   // fixed order: the result does not 
 
 
 
-constexpr size_t CHOL_SINGLE_MAX_LDS = 96 * 1024;
-bool g_force_blocked_chol = false;   // test hooks
-bool g_force_panel_chol = false;
-bool g_force_column_chol = false;
-bool g_force_glb_chol = false;
-bool g_force_panel2_chol = false;    // the multi-launch panel kernels (k_cholp_*) at any size
+bool g_force_blocked_chol = false;   // test hooks: the multi-workgroup kernels / the panel kernels at any size
+bool g_force_panel2_chol = false;
 long long* g_chol_prof = nullptr;    // device buffer of 8 phase stamps (mcba_debug_chol, blocked == 4 / 7)
 
-// (S + reg I) p = rhs for buf = [S (ns x ns) | rhs (ns)]; S is overwritten by its Cholesky factor
+// (S + reg I) p = rhs for buf = [S (ns x ns) | rhs (ns)]; S is overwritten by its Cholesky factor.  Three paths by size:
+//   ns + 1 <= 160    k_chol_blk     one workgroup, the lower triangle resident in LDS as 16 x 16 tiles
+//   ns + 1 <= 1024   k_cholp_*      block columns factored in LDS by one workgroup, trailing update on the whole chip
+//   larger           k_cholb_*      multi-workgroup 64-column panels (adjust_board with thousands of board points)
+// (The column-by-column LDS kernel of round 1, the 32-column single-workgroup kernel and the matrix-in-L2 tile kernel of
+//  round 2 lost to these at every size and are gone: profiles/r03_cholesky_paths.txt.)
 void launch_chol(mcba_handle_s* h, int ns, double reg, double* buf, double* ps) {
-  const int max_rows = ns + 1;
-  const size_t lds_packed = ((size_t)(ns + 1) * (ns + 2) / 2 + (ns + 1) + 2) * sizeof(double);
-  if (ns + 1 <= CHOL_BLK_MAX_N1 && !g_force_blocked_chol && !g_force_panel_chol && !g_force_column_chol && !g_force_glb_chol &&
-      !g_force_panel2_chol) {
+  if (ns + 1 <= CHOL_BLK_MAX_N1 && !g_force_blocked_chol && !g_force_panel2_chol) {
     const size_t lds_blk = chol_blk_lds_bytes(ns);
     if (lds_blk > h->chol_lds3_set) {
       HIP_OK(hipFuncSetAttribute((const void*)k_chol_blk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_blk));
@@ -733,10 +743,7 @@ void launch_chol(mcba_handle_s* h, int ns, double reg, double* buf, double* ps) 
     hipLaunchKernelGGL(k_chol_blk, dim3(1), dim3(CHOL_BLK_THREADS), lds_blk, h->stream, ns, reg, buf, ps, h->info.p, g_chol_prof);
     return;
   }
-  const bool forced_other = g_force_blocked_chol || g_force_panel_chol || g_force_column_chol || g_force_glb_chol;
-  if ((g_force_panel2_chol || !forced_other) && ns + 1 <= CHOL_GLB_MAX_N1) {
-    // 160 < ns + 1 <= 1024: block columns of up to 48 columns factored in LDS by one workgroup, the trailing update on
-    // the whole chip, back substitution with inverted diagonal tiles (k_cholp_*)
+  if (!g_force_blocked_chol && ns + 1 <= CHOLP_MAX_N1) {
     const int nb = (ns + 1 + CT - 1) / CT, nbc = (ns + CT - 1) / CT;
     const size_t nlinv = (size_t)nb * CT * CT;
     if (h->chol_linv.n < nlinv) h->chol_linv.alloc(nlinv, false);
@@ -763,37 +770,6 @@ void launch_chol(mcba_handle_s* h, int ns, double reg, double* buf, double* ps) 
     else
       hipLaunchKernelGGL((k_cholp_back<3, 1>), dim3(1), dim3(CHOLP_BACK_THREADS), 0, h->stream, ns, (const double*)buf,
                          (const double*)h->chol_linv.p, ps);
-    return;
-  }
-  if (ns + 1 <= (g_force_glb_chol ? CHOL_GLB_MAX_N1 : CHOL_GLB_AUTO_N1) && !g_force_blocked_chol && !g_force_panel_chol &&
-      !g_force_column_chol) {
-    // 160 <= ns + 1 <= 1024: one workgroup, matrix in L2, panel in LDS
-    const size_t lds_glb = chol_glb_lds_bytes(ns);
-    if (lds_glb > h->chol_lds4_set) {
-      HIP_OK(hipFuncSetAttribute((const void*)k_chol_glb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_glb));
-      h->chol_lds4_set = lds_glb;
-    }
-    const size_t nlinv = (size_t)((ns + 1 + CT - 1) / CT) * CT * CT;
-    if (h->chol_linv.n < nlinv) h->chol_linv.alloc(nlinv, false);
-    hipLaunchKernelGGL(k_chol_glb, dim3(1), dim3(CHOL_BLK_THREADS), lds_glb, h->stream, ns, reg, buf, h->chol_linv.p, ps,
-                       h->info.p);
-    return;
-  }
-  if (lds_packed <= 150 * 1024 && !g_force_blocked_chol && !g_force_panel_chol) {
-    if (lds_packed > h->chol_lds2_set) {
-      HIP_OK(hipFuncSetAttribute((const void*)k_chol_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_packed));
-      h->chol_lds2_set = lds_packed;
-    }
-    hipLaunchKernelGGL(k_chol_lds, dim3(1), dim3(1024), lds_packed, h->stream, ns, reg, buf, ps, h->info.p);
-    return;
-  }
-  const size_t lds = (size_t)(CHOL_NB + max_rows) * (CHOL_NB + 1) * sizeof(double) + 16;
-  if (lds <= CHOL_SINGLE_MAX_LDS && !g_force_blocked_chol) {
-    if (lds > h->chol_lds_set) {
-      HIP_OK(hipFuncSetAttribute((const void*)k_chol_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      h->chol_lds_set = lds;
-    }
-    hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(1024), lds, h->stream, ns, reg, buf, ps, h->info.p, max_rows);
     return;
   }
   // large reduced system: multi-workgroup blocked factorisation
@@ -841,10 +817,10 @@ void launch_gn_solve(mcba_handle_s* h, double reg, bool root_rank, double* dots_
   // Whether the frame part of the step is reduced across ranks must not depend on THIS rank's shard size (an empty shard,
   // K == 0, is legal: frame_shards produces them when there are fewer frames than ranks): every rank of a problem with
   // eliminated frame parameters (DF > 0) joins the same sequence of collectives and contributes zeros where it owns nothing.
-  const bool sharded_frames = h->allreduce && d.DF > 0;
-  // frame entries of other shards must be zero before the cross-rank sum; a single handle writes every entry of gn
-  if (h->allreduce) HIP_OK(hipMemsetAsync(h->gn.p, 0, (size_t)d.n * sizeof(double), h->stream));
-  double* fused_dots = sharded_frames ? nullptr : dots_out;
+  // (frame-sharded: the frame entries of gn belong to the owner of the frame and stay zero everywhere else -- the buffer is
+  //  zero-initialised and the back substitution writes own frames + shared entries only; the dots of the 2-D subspace cross
+  //  the ranks as per-rank partial sums, see k_shard_fold_dots)
+  double* fused_dots = dots_out;
   if (trp != nullptr && K == 0)   // no frame blocks on this rank: the stand-alone fold
     hipLaunchKernelGGL(k_tr_reg, dim3(1), dim3(64), 0, h->stream, tr_dev, trp->vs, trp->nvb, trp->q, trp->nq, trp->first,
                        trp->Delta);
@@ -883,12 +859,11 @@ void launch_gn_solve(mcba_handle_s* h, double reg, bool root_rank, double* dots_
     hipLaunchKernelGGL((k_schur_backsub<6>), dim3(nblk), dim3(64), 0, h->stream, d, h->Lf.p, h->W.p, h->yf.p, h->ps.p,
                        h->gn.p, h->gh.p, h->info.p, fused_dots);
   }
-  if (sharded_frames) {
-    // frame entries of gn are known only to the owning rank: zero the (replicated) shared entries on non-root ranks
-    // is not needed -- every rank holds identical p_s; sum only the frame block.
-    call_allreduce(h, h->gn.p + d.off_motion, (size_t)d.n_motion, 0);
-    if (dots_out)   // complete dots + pivot report in the layout of ONE back-substitution block: [d00 d01 d11 | info]
-      hipLaunchKernelGGL(k_dots3, dim3(1), dim3(1024), 0, h->stream, d.n, h->gh.p, h->gn.p, dots_out, h->info.p);
+  if (h->allreduce && dots_out) {   // message 4: 3 doubles per rank (+ the pivot report), gathered by summation
+    const int W = d.shard_world;
+    hipLaunchKernelGGL(k_shard_fold_dots, dim3(1), dim3(64), 0, h->stream, dots_out, gn_dot_blocks(d), d.shard_rank, W,
+                       h->scal.p + h->sl.shard4);
+    call_allreduce(h, h->scal.p + h->sl.shard4, (size_t)3 * W + 1, 0);
   }
 }
 
@@ -1284,6 +1259,7 @@ int32_t mcba_set_allreduce(mcba_handle h, mcba_allreduce_fn fn, void* ctx) {
   REQUIRE(h, "null handle");
   h->allreduce = fn;
   h->allreduce_ctx = ctx;
+  if (fn == nullptr) h->d.shard_world = 0;   // (a hook needs mcba_set_shard_rank as well)
   API_END
 }
 
@@ -1339,6 +1315,10 @@ int32_t mcba_rccl_init(mcba_handle h, const uint8_t* id_in, int32_t rank, int32_
   }
   h->allreduce = rccl_allreduce_native;
   h->allreduce_ctx = h;
+  REQUIRE(world <= SHARD_MAX_WORLD, "at most 64 ranks");
+  h->d.shard_rank = rank;
+  h->d.shard_world = world;
+  h->shard_root = rank == 0;
   API_END
 }
 
@@ -1349,7 +1329,7 @@ int32_t mcba_rccl_shutdown(mcba_handle h) {
   if (h->rccl_comm) {
     destroy_rccl_comm(h->rccl_comm);
     h->rccl_comm = nullptr;
-    if (h->allreduce == rccl_allreduce_native) { h->allreduce = nullptr; h->allreduce_ctx = nullptr; }
+    if (h->allreduce == rccl_allreduce_native) { h->allreduce = nullptr; h->allreduce_ctx = nullptr; h->d.shard_world = 0; }
   }
   API_END
 }
@@ -1374,6 +1354,16 @@ int32_t mcba_set_shard_root(mcba_handle h, int32_t is_root) {
   API_BEGIN
   REQUIRE(h, "null handle");
   h->shard_root = is_root != 0;
+  API_END
+}
+
+/* rank of this handle among the `world` handles that share one frame-sharded problem (rank 0 is the root) */
+int32_t mcba_set_shard_rank(mcba_handle h, int32_t rank, int32_t world) {
+  API_BEGIN
+  REQUIRE(h && world >= 1 && world <= SHARD_MAX_WORLD && rank >= 0 && rank < world, "bad rank / world (at most 64 ranks)");
+  h->d.shard_rank = rank;
+  h->d.shard_world = world;
+  h->shard_root = rank == 0;
   API_END
 }
 
@@ -1651,6 +1641,10 @@ int32_t mcba_normal_equations(mcba_handle h, const double* x, const mcba_options
   launch_linearize(h, h->x.p);   // (k_tmat, the first kernel of the linearisation, prepares every table from x)
   launch_assemble(h);
   const Dims& d = h->d;
+  if (g || diag) {   // frame-sharded: the caller of the HOST boundary gets complete vectors (the solver never needs them)
+    gather_frame_entries(h, h->g());
+    gather_frame_entries(h, h->diag());
+  }
   // [g | diag | cost, count] comes down into pinned memory; only the two scalars when the vectors are not asked for
   const size_t first = (g || diag) ? 0 : 2 * (size_t)d.n, count = 2 * (size_t)d.n + 2 - first;
   HIP_OK(hipMemcpyAsync(h->h_gbuf + first, h->gbuf.p + first, count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -1668,33 +1662,8 @@ int32_t mcba_normal_equations_device(mcba_handle h, const mcba_options* opt) {
   API_BEGIN
   REQUIRE(h, "null handle");
   set_loss(h, opt);
-  // MCBA_GRAPH=1: the four launches of an evaluation are captured once per (x buffer, loss) into a hipGraph and replayed
-  // with one hipGraphLaunch (single-GPU handles; a sharded handle's collectives stay stream-ordered launches)
-  static const bool graph_on = getenv("MCBA_GRAPH") != nullptr && getenv("MCBA_GRAPH")[0] == '1';
-  if (graph_on && !h->allreduce) {
-    if (h->eval_graph == nullptr || h->eval_graph_x != h->x.p || h->eval_graph_loss != h->d.loss ||
-        h->eval_graph_fscale != h->d.f_scale) {
-      if (h->eval_graph) { (void)hipGraphExecDestroy(h->eval_graph); h->eval_graph = nullptr; }
-      hipGraph_t graph = nullptr;
-      HIP_OK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-      try {
-        launch_linearize(h, h->x.p);
-        launch_assemble(h);
-      } catch (...) {
-        (void)hipStreamEndCapture(h->stream, &graph);
-        if (graph) (void)hipGraphDestroy(graph);
-        throw;
-      }
-      HIP_OK(hipStreamEndCapture(h->stream, &graph));
-      HIP_OK(hipGraphInstantiate(&h->eval_graph, graph, nullptr, nullptr, 0));
-      (void)hipGraphDestroy(graph);
-      h->eval_graph_x = h->x.p;
-      h->eval_graph_loss = h->d.loss;
-      h->eval_graph_fscale = h->d.f_scale;
-    }
-    HIP_OK(hipGraphLaunch(h->eval_graph, h->stream));
-    return 0;
-  }
+  // (replaying the four launches as a hipGraph was measured in round 3: 82.3 against 73.7 us at the north-star rig on
+  //  ROCm 7.2 -- the stream-ordered launches already follow each other after ~1 us -- and is gone)
   launch_linearize(h, h->x.p);
   launch_assemble(h);
   API_END
@@ -1788,10 +1757,8 @@ int32_t mcba_debug_chol(mcba_handle h, int32_t ns, const double* S, const double
   ps.alloc((size_t)ns);
   HIP_OK(hipMemcpyAsync(buf.p, S, (size_t)ns * ns * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIP_OK(hipMemcpyAsync(buf.p + (size_t)ns * ns, rhs, (size_t)ns * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  g_force_blocked_chol = blocked == 1;   // 0: automatic, 1: multi-workgroup, 2: single-workgroup panel kernel
-  g_force_panel_chol = blocked == 2;
-  g_force_column_chol = blocked == 3;    // 3: column-by-column LDS kernel (the round-1 baseline of k_chol_blk)
-  g_force_glb_chol = blocked == 5;       // 5: one-workgroup kernel with the matrix in global memory
+  REQUIRE(blocked == 0 || blocked == 1 || blocked == 4 || blocked == 6 || blocked == 7, "unknown Cholesky path");
+  g_force_blocked_chol = blocked == 1;   // 0: automatic, 1: multi-workgroup kernels (k_cholb_*)
   g_force_panel2_chol = blocked == 6;    // 6: multi-launch panel kernels (k_cholp_*: the default for 160 < ns + 1 <= 1024)
   DevBuf<long long> stamps;
   if (blocked == 4) {                    // 4: k_chol_blk with phase stamps; p_out[0..7] receives the shader-clock totals
@@ -1800,14 +1767,14 @@ int32_t mcba_debug_chol(mcba_handle h, int32_t ns, const double* S, const double
     g_chol_prof = stamps.p;
   }
   if (blocked == 7) {                    // 7: k_cholp_panel with phase stamps summed over the panels (p_out[0..5])
-    REQUIRE(ns >= 8 && ns + 1 <= CHOL_GLB_MAX_N1, "profiling needs 8 <= ns < 1024");
+    REQUIRE(ns >= 8 && ns + 1 <= CHOLP_MAX_N1, "profiling needs 8 <= ns < 1024");
     stamps.alloc(8);
     g_chol_prof = stamps.p;
     g_force_panel2_chol = true;
   }
   try { launch_chol(h, ns, reg, buf.p, ps.p); }
-  catch (...) { g_force_blocked_chol = g_force_panel_chol = g_force_column_chol = g_force_glb_chol = g_force_panel2_chol = false; g_chol_prof = nullptr; throw; }
-  g_force_blocked_chol = g_force_panel_chol = g_force_column_chol = g_force_glb_chol = g_force_panel2_chol = false;
+  catch (...) { g_force_blocked_chol = g_force_panel2_chol = false; g_chol_prof = nullptr; throw; }
+  g_force_blocked_chol = g_force_panel2_chol = false;
   g_chol_prof = nullptr;
   if (blocked == 4 || blocked == 7) {
     long long st[8];
@@ -1930,13 +1897,13 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
   // queue, and the two around every later linearisation cost 5 us between k_vec_step and k_linearize and 4.5 us between
   // k_linearize and k_assemble in every LM iteration (gaps in the rocprofv3 kernel trace of a long solve).
   bool lin_timed = false;
-  auto timed_linearize = [&](const double* dx, unsigned long long publish_seq = 0, int cost_slot = 0) {
+  auto timed_linearize = [&](const double* dx, unsigned long long publish_seq = 0, int cost_slot = 0, bool step_valid = false) {
     const bool timing = !lin_timed;
     lin_timed = true;
     if (timing) HIP_OK(hipEventRecord(h->ev0, h->stream));
     launch_linearize(h, dx);
     if (timing) HIP_OK(hipEventRecord(h->ev1, h->stream));
-    launch_assemble(h, publish_seq, cost_slot);
+    launch_assemble(h, publish_seq, cost_slot, step_valid);
   };
   auto collect_lin_time = [&]() {
     float ms = 0.f;
@@ -1951,19 +1918,26 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
   //  its trailing workgroups write the pose / camera / board-point tables of x_new for k_cost, which forms the view chains
   //  itself; k_tmat rebuilds the view table if the step is accepted)
   const int prep_blocks = (d.n_pose + d.C + d.B * d.P + 255) / 256;
-  const int dot_blocks = (h->allreduce && d.DF > 0) ? 1 : gn_dot_blocks(d);   // (a shard gets the complete dots: one "block")
+  // (a frame-sharded handle folds the all-reduced per-RANK dots, one block per rank: sl.shard4)
+  const int dot_blocks = h->allreduce ? d.shard_world : gn_dot_blocks(d);
+  const int dot_slot = h->allreduce ? sl.shard4 : sl.dotp;
+  if (h->allreduce && d.shard_world <= 0)
+    throw Error("frame-sharded handle without a rank: call mcba_set_shard_rank (or mcba_rccl_init)");
   // with_cost = false (sharded handles, first trial of an iteration): no k_cost pass and no 1-double all-reduce -- the
   // speculative linearisation at x_new that follows delivers the cost of the very same point inside its own
   // [g | diag | cost] message (one dependent collective less per accepted iteration)
   auto enqueue_trial = [&](double alpha, double beta, double* tr_dev, bool with_cost = true, bool to_host = false) {
     hipLaunchKernelGGL(k_vec_step, dim3(sl.nvb + prep_blocks), dim3(256), 0, h->stream, d, h->t, h->x.p, h->dsc.p, h->gh.p,
-                       h->gn.p, alpha, beta, h->xnew.p, h->scal.p + sl.step, tr_dev, h->scal.p + sl.dotp, dot_blocks, sl.nvb,
+                       h->gn.p, alpha, beta, h->xnew.p, h->scal.p + sl.step, tr_dev, h->scal.p + dot_slot, dot_blocks, sl.nvb,
                        to_host ? h->h_scal : nullptr, to_host ? h->h_scal + sl.step : nullptr);
     if (!with_cost) return;
     h->ops->cost(d, h->t, h->stream, h->scal.p + sl.costp, cost_grid);   // (an empty shard writes partial[0] = 0)
-    if (h->allreduce) {
-      hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(64), 0, h->stream, h->scal.p + sl.costp, cost_grid);
-      call_allreduce(h, h->scal.p + sl.costp, 1, 0);
+    if (h->allreduce) {   // retry: [trial cost | step norms] of this rank, 4 doubles
+      hipLaunchKernelGGL(k_shard_trial_pack, dim3(1), dim3(64), 0, h->stream, h->scal.p + sl.costp, cost_grid, h->scal.p + sl.step,
+                         sl.nvb, h->comm.p);
+      call_allreduce(h, h->comm.p, 4, 0);
+      hipLaunchKernelGGL(k_shard_trial_unpack, dim3(1), dim3(256), 0, h->stream, h->comm.p, h->scal.p + sl.costp,
+                         h->scal.p + sl.step, sl.nvb);
     }
   };
   static const bool merge_off = getenv("MCBA_NO_MERGED_TRIAL_COST") != nullptr && getenv("MCBA_NO_MERGED_TRIAL_COST")[0] == '1';
@@ -2016,6 +1990,13 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
                          h->dsc.p, h->gh.p, first ? 1 : 0, h->scal.p + sl.vs, h->costcount(), h->scal.p + TR_COST);
     bool have_trial = false;
     if (finishing) {
+      if (h->allreduce) {   // the norms of the final iterate, per rank (message 2 without the curvature)
+        hipLaunchKernelGGL(k_shard_fold2, dim3(1), dim3(64), 0, h->stream, h->scal.p + sl.vs, sl.nvb, (const double*)nullptr, 0,
+                           d.shard_rank, d.shard_world, h->scal.p + sl.shard2);
+        call_allreduce(h, h->scal.p + sl.shard2, (size_t)4 * d.shard_world, 0);
+        HIP_OK(hipMemcpyAsync(h->h_scal + sl.shard2, h->scal.p + sl.shard2, 4 * d.shard_world * sizeof(double),
+                              hipMemcpyDeviceToHost, h->stream));
+      }
       fetch_scalars(h, sl.q00p);
     } else {
       if (scaled) {
@@ -2026,19 +2007,22 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
         hipLaunchKernelGGL(k_vec_scale_q00, dim3(sl.nvb + q00_blocks), dim3(256), 0, h->stream, d, h->x.p, h->g(), h->diag(),
                            h->scale_inv.p, h->scale_inv.p, h->dsc.p, h->gh.p, first ? 1 : 0, h->scal.p + sl.vs, h->costcount(),
                            h->scal.p + TR_COST, sl.nvb, h->Hss.p, h->Hfs.p, h->Hff.p, h->scal.p + sl.q00p);
-      if (h->allreduce) {   // one double crosses the ranks, not the 512 per-block partials
-        hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(64), 0, h->stream, h->scal.p + sl.q00p, q00_blocks);
-        call_allreduce(h, h->scal.p + sl.q00p, 1, 0);
+      if (h->allreduce) {   // message 2: [|g|_inf, |g_h|^2, |x scale|^2, curvature] of every rank, 4 doubles each
+        hipLaunchKernelGGL(k_shard_fold2, dim3(1), dim3(64), 0, h->stream, h->scal.p + sl.vs, sl.nvb, h->scal.p + sl.q00p,
+                           q00_blocks, d.shard_rank, d.shard_world, h->scal.p + sl.shard2);
+        call_allreduce(h, h->scal.p + sl.shard2, (size_t)4 * d.shard_world, 0);
       }
       // (the fold of the k_vec_scale / k_q00 partials and the damping: head of the first kernel of the solve)
       // (scaled ahead: the partials were folded behind it by k_fold_tr -- [mx | gg | xs] is a k_vec_scale block of its own, q one value)
       const TrRegPartials trp = scaled ? TrRegPartials{h->scal.p + sl.fold, 1, h->scal.p + sl.fold + 3, 1, 0, Delta}
-                                       : TrRegPartials{h->scal.p + sl.vs, sl.nvb, h->scal.p + sl.q00p, h->allreduce ? 1 : q00_blocks, first ? 1 : 0, Delta};
+                              : h->allreduce ? TrRegPartials{h->scal.p + sl.shard2, d.shard_world, h->scal.p + sl.shard2 + 3 * d.shard_world,
+                                                             d.shard_world, first ? 1 : 0, Delta}
+                                       : TrRegPartials{h->scal.p + sl.vs, sl.nvb, h->scal.p + sl.q00p, q00_blocks, first ? 1 : 0, Delta};
       launch_gn_solve(h, 0.0, is_root, h->scal.p + sl.dotp, h->scal.p, &trp);
       // Single GPU, table-fed fused linearisation: the trial cost and the speculative linearisation both only READ the tables
       // that the tail of k_vec_step wrote, so k_cost + the scalar copy go to a side stream and run BESIDE k_linearize (13 us
       // of every iteration's critical path at the north-star rig); the host still decides on the trial cost alone.
-      const bool spec_tables_ready = (linearize_fused_mode() == 2 || getenv("MCBA_FUSED") == nullptr) && d.off_boards < 0 && h->use_mfma;
+      const bool spec_tables_ready = !linearize_table_form() && d.off_boards < 0 && h->use_mfma;
       static const bool side_off = getenv("MCBA_NO_SIDE_COST") != nullptr && getenv("MCBA_NO_SIDE_COST")[0] == '1';
       const bool side_cost = !h->allreduce && spec_tables_ready && !side_off && !merged_trial_cost;
       static const bool publish = !(getenv("MCBA_NO_PUBLISH") != nullptr && getenv("MCBA_NO_PUBLISH")[0] == '1');
@@ -2080,7 +2064,7 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
       // are rebuilt before anything reads them again.
       // (fused form: straight from x_new; table form: k_tmat re-derives its entries; table-fed fused form: the tail of
       //  k_vec_step has just written the pose / camera tables of x_new -- no table kernel at all)
-      timed_linearize(spec_tables_ready ? nullptr : h->xnew.p);
+      timed_linearize(spec_tables_ready ? nullptr : h->xnew.p, 0, 0, h->allreduce != nullptr && merged_trial_cost);
       spec_lin = true;
       if (merged_trial_cost) {      // the cost of x_new arrived with the linearisation's all-reduced [g | diag | cost]
         HIP_OK(hipMemcpyAsync(h->scal.p + sl.costp, h->costcount(), sizeof(double), hipMemcpyDeviceToDevice, h->stream));
@@ -2095,12 +2079,13 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
       }
     }
     if (fresh_lin) { collect_lin_time(); fresh_lin = false; }
-    if (!have_trial) {   // fold the k_vec_scale partials on the host (the vectors are complete on every rank)
+    if (!have_trial) {   // fold the k_vec_scale partials on the host (frame-sharded: the per-rank values, gathered by summation)
       double mx = 0, gg = 0, xs = 0;
-      for (int blk = 0; blk < sl.nvb; ++blk) {
-        mx = std::max(mx, S[sl.vs + 3 * blk]);
-        gg += S[sl.vs + 3 * blk + 1];
-        xs += S[sl.vs + 3 * blk + 2];
+      const int nfold = h->allreduce ? d.shard_world : sl.nvb, at = h->allreduce ? sl.shard2 : sl.vs;
+      for (int blk = 0; blk < nfold; ++blk) {
+        mx = std::max(mx, S[at + 3 * blk]);
+        gg += S[at + 3 * blk + 1];
+        xs += S[at + 3 * blk + 2];
       }
       S[TR_GNORM] = mx; S[TR_GH2] = gg; S[TR_XS2] = xs;
     }
@@ -2186,6 +2171,7 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
   //  first device-to-host copies of this size in a process spends ~8 ms inside hipMemcpyAsync on the host -- seen in the
   //  first or second solve of a process at cfg3 (n = 6140), not at cfg2, pinned or pageable destination alike;
   //  MCBA_SOLVE_TRACE=1 prints the driver's stage times)
+  gather_frame_entries(h, h->x.p);   // (frame-sharded: every rank returns the complete x; ONE n_motion message per solve)
   HIP_OK(hipMemcpyAsync(h->h_x, h->x.p, (size_t)d.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   sync(h);
   to_caller(h, x_inout, h->h_x);
@@ -2330,11 +2316,7 @@ int32_t mcba_time_linearize(mcba_handle h, const double* x, const mcba_options* 
   HIP_OK(hipEventRecord(h->ev0, h->stream));
   for (int i = 0; i < repeats; ++i) {   // the dominant kernel alone, as rocprofv3 reports it (table form: k_tmat ran above)
     const Dims& d = h->d;
-    const int fused_mode = linearize_fused_mode();
-    if (h->use_mfma && d.ND != 14 && d.off_boards < 0 && fused_mode == 1)
-      h->ops->linearize(d, h->t, h->stream, h->rec.p, h->tri.p, true, h->lin_grid, h->x.p, h->gbuf.p, 2 * d.n + 2, h->Hss.p,
-                        d.ns * d.ns);
-    else if (h->use_mfma && d.off_boards < 0 && (fused_mode == 2 || getenv("MCBA_FUSED") == nullptr))
+    if (h->use_mfma && d.off_boards < 0 && !linearize_table_form())
       h->ops->linearize(d, h->t, h->stream, h->rec.p, h->tri.p, true, h->lin_grid, nullptr, h->gbuf.p, 2 * d.n + 2, h->Hss.p,
                         d.ns * d.ns);
     else

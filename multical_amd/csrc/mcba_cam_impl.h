@@ -50,8 +50,8 @@ void jacobian(const Dims& d, const Tables& t, hipStream_t s, int row_nnz, double
 template <int MOTION, bool OPTK>
 void lin2(const Dims& d, const Tables& t, hipStream_t s, double* rec, const uint16_t* tri, bool mfma, int epoch,
           const double* x, double* za, int na, double* zb, int nb) {
-  // fused forms: za != nullptr.  x != nullptr: pose entries / intrinsics straight from x; x == nullptr: from the pose and
-  // camera tables (table-fed fused form).  Both zero the assembly targets za[na], zb[nb].
+  // table-fed fused form: za != nullptr (pose entries / intrinsics from the pose and camera tables; zeroes the assembly
+  // targets za[na], zb[nb]); za == nullptr: table form (That / chains per view from k_tmat)
   const bool fused = za != nullptr;
   if (d.views() == 0 && !fused) return;   // empty frame shard (the fused form still zeroes the assembly targets)
   // persistent wavefronts: 8 single-wave workgroups per CU (2 per SIMD: 256-VGPR budget, 20 KB LDS each) x 256 CUs
@@ -65,8 +65,7 @@ void lin2(const Dims& d, const Tables& t, hipStream_t s, double* rec, const uint
   }
   const bool robust = d.loss != 0;
 #define MCBA_LIN(ROB, FM) hipLaunchKernelGGL((k_linearize<ND_, FISH_, MOTION, OPTK, true, ROB, FM>), grid, block, 0, s, d, t, rec, tri, epoch, x, za, na, zb, nb)
-  if (mfma && fused && x != nullptr) { if (robust) MCBA_LIN(true, 1); else MCBA_LIN(false, 1); }
-  else if (mfma && fused) { if (robust) MCBA_LIN(true, 2); else MCBA_LIN(false, 2); }
+  if (mfma && fused) { if (robust) MCBA_LIN(true, 2); else MCBA_LIN(false, 2); }
   else if (mfma) { if (robust) MCBA_LIN(true, 0); else MCBA_LIN(false, 0); }
   else
     hipLaunchKernelGGL((k_linearize<ND_, FISH_, MOTION, OPTK, false, true, 0>), grid, block, 0, s, d, t, rec, tri, epoch, x, za, na, zb, nb);

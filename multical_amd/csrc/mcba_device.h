@@ -51,6 +51,11 @@ struct Dims {
   // a parameter", so the assembly never writes its rows / columns of H and g (zero column: unit scale, zero step).
   // nullptr for uniform rigs.  A device pointer inside the kernels; host code substitutes a host copy.
   const uint32_t* cam_kmask;
+  // Frame sharding: rank / number of ranks of the problem this handle owns a frame shard of (shard_world = 0:
+  // not sharded).  The n-vectors of a sharded handle are complete in the SHARED entries and in the entries of its OWN frames
+  // only -- nothing of length n ever crosses the ranks; sums over all parameters are formed as all-reduced per-rank partial
+  // sums in which every entry is counted exactly once (entry_weight).
+  int shard_rank, shard_world;
 
   // global x index of a shared-parameter index (x order with the eliminated motion block removed)
   MCBA_HD int shared_to_x(int s) const {
@@ -66,6 +71,14 @@ struct Dims {
   // x index of eliminated parameter d (0..DF-1) of GLOBAL frame f
   MCBA_HD int frame_to_x(int f, int d) const {
     return (d < 6) ? off_motion + 6 * f + d : off_motion + 6 * F + 6 * f + (d - 6);
+  }
+  // weight of entry i of an n-vector in this rank's partial of a global sum: eliminated frame parameters count on the rank
+  // that owns the frame, shared parameters on rank 0 (the shared entries are replicated: identical on every rank)
+  MCBA_HD double entry_weight(int i) const {
+    if (shard_world == 0) return 1.0;
+    if (DF == 0 || off_motion < 0 || i < off_motion || i >= off_motion + n_motion) return shard_rank == 0 ? 1.0 : 0.0;
+    const int q = i - off_motion, f = (q >= 6 * F ? q - 6 * F : q) / 6;
+    return (f >= f0 && f < f0 + Fl) ? 1.0 : 0.0;
   }
   MCBA_HD int views() const { return Fl * C * B; }
   MCBA_HD int slots() const { return Fl * C * B * P; }

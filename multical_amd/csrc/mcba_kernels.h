@@ -630,12 +630,12 @@ __global__ __launch_bounds__(256) void k_points(Dims d, Tables t, double* __rest
 // designed for, this makes hipcc select the VGPR form of the MFMA: with the default 512-register budget it keeps the
 // loop-carried accumulators in VGPRs, issues AGPR-form MFMAs and brackets EVERY step with 24 v_accvgpr_write +
 // 24 v_accvgpr_read and a full-latency s_nop (196 instead of 64 cycles per MFMA, measured with s_memtime stamps).
-// FUSED: the kernel forms That and the chain matrices of every view ITSELF, straight from x (lanes 0..NPB-1 evaluate the
-// view's pose entries -- Rodrigues + left Jacobian -- into LDS, lanes 0..6 NPB - 1 one column of That each, two more lanes
-// the chain matrices), reads the intrinsics from the camera's block inside x and zeroes the accumulation targets of the
-// assembly: no k_prep / k_tmat launch, no That table (18 MB written + 10 MB read per evaluation at the north-star rig),
-// one kernel boundary less.  Not used for the tilted model (its tilt matrices live in the camera table) and when the
-// board points are optimised (the board-point table must be refreshed): those keep the k_tmat path.
+// FUSED (table-fed fused form, the default): the kernel copies its view's pose entries from the pose table (written by k_prep,
+// or by the tail of the k_vec_step that produced the point), forms the chain prefixes and the That columns ITSELF and zeroes
+// the accumulation targets of the assembly: no k_tmat launch, no That table (10 MB written + read per evaluation at the
+// north-star rig).  The table form (k_tmat writes That / the chains per view) serves adjusted board points and the profiling
+// instantiation.  (A third form that evaluated the pose entries from x inside this kernel -- trigonometry on 4 of 64 lanes --
+// was measured in rounds 2 and 3, never won and is gone.)
 // PROF: the instantiation with s_memtime stamps per phase (mcba_debug_linearize_profile).  The production instantiations
 // contain no global store besides the record (a __restrict__ argument): hipcc can then prove that the wave-uniform reads
 // of the view / camera tables are never clobbered and issues them as scalar loads (s_load, operands in SGPRs) instead of
@@ -643,16 +643,16 @@ __global__ __launch_bounds__(256) void k_points(Dims d, Tables t, double* __rest
 template <int ND, bool FISH, int MOTION, bool OPTK, bool MFMA, bool ROBUST, int FUSED_MODE, bool PROF = false>
 // (static pinhole kernels with the linear loss fit 128 registers: they ask for four waves per SIMD explicitly, so that the
 //  table-fed fused form -- 132 registers under the two-wave budget -- is allocated into 128 as well)
-__global__ __launch_bounds__(64, (MOTION == MOTION_STATIC && !FISH && MFMA && !ROBUST && !PROF && FUSED_MODE != 1 && OPTK && ND <= 5) ? 4 : 2)
+__global__ __launch_bounds__(64, (MOTION == MOTION_STATIC && !FISH && MFMA && !ROBUST && !PROF && OPTK && ND <= 5) ? 4 : 2)
 void k_linearize(Dims d, Tables t, double* __restrict__ rec,
                                                      const uint16_t* __restrict__ tri, int epoch,
                                                      const double* __restrict__ x, double* __restrict__ zero_a, int na,
                                                      double* __restrict__ zero_b, int nb) {
-  // FUSED_MODE: 0 = table form (That / chains from k_tmat), 1 = everything from x (incl. the trigonometry of the pose
-  // entries), 2 = table-fed fused form (pose entries copied from the pose table, intrinsics from the camera table).  Modes 1
-  // and 2 are separate instantiations: the trigonometry of mode 1 costs registers that mode 2 never needs (compiled together,
-  // the rolling-shutter kernel spilled 44 bytes per lane and the static one lost its fourth wave per SIMD).
-  constexpr bool FUSED = FUSED_MODE != 0, FUSED_X = FUSED_MODE == 1;
+  // FUSED_MODE: 0 = table form (That / chains from k_tmat), 2 = table-fed fused form (pose entries copied from the pose table,
+  // intrinsics from the camera table)
+  static_assert(FUSED_MODE == 0 || FUSED_MODE == 2, "linearisation forms: 0 = table form, 2 = table-fed fused form");
+  constexpr bool FUSED = FUSED_MODE != 0;
+  (void)x;
   constexpr bool ROLL = MOTION == MOTION_ROLLING;
   constexpr int DE = ROLL ? 12 : 6, NPB = MOTION == MOTION_STATIC ? 3 : 4, KI = OPTK ? 4 + ND : 0;
   constexpr int NV = DE + KI + 1, NT = (NV + 15) / 16, NVP = 16 * NT;
@@ -743,7 +743,7 @@ void k_linearize(Dims d, Tables t, double* __restrict__ rec,
         for (int k = 0; k < NVS; ++k) Vr[k] = vsrc[k];         // (made scalar in front_finish)
       }
     }
-    if constexpr (FUSED_MODE != 1) {   // camera entry from the table (table form and table-fed fused form): same round trip
+    {   // camera entry from the table: same round trip
       const double* csrc = t.cam + (size_t)cc * CAM_STRIDE;
 #pragma unroll
       for (int k = 0; k < 5 + ND; ++k) cam_f[k] = csrc[k];
@@ -767,7 +767,7 @@ void k_linearize(Dims d, Tables t, double* __restrict__ rec,
         for (int k = 0; k < NVS; ++k) Vr[k] = uniform_f64(Vr[k]);
       }
     }
-    if constexpr (FUSED_MODE != 1) {
+    {
 #pragma unroll
       for (int k = 0; k < 5 + ND; ++k) camr[k] = uniform_f64(cam_f[k]);
       extr[CAM_HEIGHT - CAM_TILT] = uniform_f64(ext_f[0]);
@@ -817,13 +817,12 @@ void k_linearize(Dims d, Tables t, double* __restrict__ rec,
     // x == nullptr: the TABLE-FED fused form -- the pose / camera tables already hold the point (k_prep, or the tail of the
     // k_vec_step that produced it): the view's pose entries are copied from the pose table (no trigonometry here) and the
     // intrinsics come from the camera table; the chain products and the That columns are formed below all the same.
-    constexpr bool from_x = FUSED_X;
-    camp = !from_x ? t.cam + (size_t)c * CAM_STRIDE
-                   : (d.off_cameras >= 0 ? x + d.off_cameras + c * (5 + ND) : t.xfull + d.foff_cameras + c * (5 + ND));
-    // pose entries of the view from x: lane 0 camera, lane NPB - 1 board, the lanes between the motion poses
+    camp = t.cam + (size_t)c * CAM_STRIDE;
+    (void)camp;
+    // pose entries of the view: entry 0 camera, entry NPB - 1 board, between them the motion poses
     static_assert(NPB * POSE_STRIDE <= BUF, "pose entries do not fit the staging buffer");
     double* Pl = Buf;                      // (the staging buffer is free until the first chunk)
-    if constexpr (!from_x) {
+    {
       // the pose entries are requested with the front loads (same round trip as the mask bytes); then the masks are
       // compacted and the FIRST CHUNK's observations / board points are requested, and only then the chain products and That
       // columns are formed -- under that round trip instead of in front of it
@@ -844,24 +843,6 @@ void k_linearize(Dims d, Tables t, double* __restrict__ rec,
       for (int k = 0; k < 3; ++k) X_cur[k] = t.board_points[3 * (size_t)(b * d.P + p_cur) + k];
 #pragma unroll
       for (int u = 0; u < NPE; ++u) Pl[min(pl + 64 * u, NPB * POSE_STRIDE - 1)] = pe_f[u];
-    } else {
-     if (pl < NPB) {
-      int oa, of, r;
-      if (pl == 0) { oa = d.off_campose; of = d.foff_campose; r = 6 * c; }
-      else if (pl == NPB - 1) { oa = d.off_boardpose; of = d.foff_boardpose; r = 6 * b; }
-      else {
-        oa = d.off_motion;
-        of = d.foff_motion;
-        r = MOTION == MOTION_STATIC ? 6 * f : (MOTION == MOTION_ROLLING ? 6 * ((pl - 1) * d.F + f) : 6 * (pl - 1));
-      }
-      double rt[6];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) rt[k] = block_value(t, x, oa, of, r + k);
-      double pe[POSE_STRIDE];
-      pose_entry(rt, pe);
-#pragma unroll
-      for (int k = 0; k < POSE_STRIDE; ++k) Pl[pl * POSE_STRIDE + k] = pe[k];
-     }
     }
     lds_fence();
     const double* Pc = Pl;
@@ -934,13 +915,6 @@ void k_linearize(Dims d, Tables t, double* __restrict__ rec,
   // rolling shutter: the two chains stay in LDS).  Left to the compiler they were 17 vector loads of one address each in
   // EVERY chunk, with 68 vector registers to hold them.
   if constexpr (FUSED) {
-    if constexpr (FUSED_X) {   // (the table-fed form took its camera entry with the front loads)
-#pragma unroll
-      for (int k = 0; k < 5 + ND; ++k) camr[k] = uniform_f64(camp[k]);
-      const double* esrc = t.cam + (size_t)c * CAM_STRIDE + CAM_TILT;
-      extr[CAM_HEIGHT - CAM_TILT] = uniform_f64(esrc[CAM_HEIGHT - CAM_TILT]);
-      extr[CAM_FIXASPECT - CAM_TILT] = uniform_f64(esrc[CAM_FIXASPECT - CAM_TILT]);
-    }
     if constexpr (!ROLL) {
 #pragma unroll
       for (int k = 0; k < NVS; ++k) Vr[k] = uniform_f64(Vm[k]);

@@ -157,6 +157,7 @@ inline void lower_dims(const mcba_problem* p, HostProblem& hp) {
 
   Dims& d = hp.d;
   d.cam_kmask = nullptr;
+  d.shard_rank = d.shard_world = 0;   // (mcba_set_shard_rank / mcba_rccl_init)
   // per-camera distortion sizes: a ParamList of independent Camera objects (optimization/parameters.py:54-85)
   bool ragged = false;
   hp.cam_nd.assign((size_t)p->n_cameras, p->n_dist);

@@ -654,9 +654,10 @@ __global__ __launch_bounds__(256) void k_vec_scale(Dims d, const double* __restr
     dsc[i] = di;
     const double gi = g[i];
     gh[i] = di * gi;
+    const double w = d.entry_weight(i);   // (1 unless frame-sharded: every entry counts once in the sum over the ranks)
     mx = fabs(gi);
-    gg = di * gi * di * gi;
-    xs = x[i] * si * x[i] * si;
+    gg = w * (di * gi * di * gi);
+    xs = w * (x[i] * si * x[i] * si);
   }
   const double a = block_reduce<true>(mx, scratch);
   const double b = block_reduce<false>(gg, scratch);
@@ -749,9 +750,10 @@ __global__ __launch_bounds__(256) void k_vec_scale_q00(Dims d, const double* __r
       dsc[i] = di;
       const double gi = g[i];
       gh[i] = di * gi;
+      const double w = d.entry_weight(i);
       mx = fabs(gi);
-      gg = di * gi * di * gi;
-      xs = x[i] * si * x[i] * si;
+      gg = w * (di * gi * di * gi);
+      xs = w * (x[i] * si * x[i] * si);
     }
     const double a = block_reduce<true>(mx, scratch);
     const double b = block_reduce<false>(gg, scratch);
@@ -1086,187 +1088,10 @@ __global__ __launch_bounds__(256) void k_schur_reduce(Dims d, const double* __re
   }
 }
 
-// Blocked dense Cholesky solve of (S + reg I) p = rhs in ONE workgroup (the reduced system is small: ns = 18 ... ~300).
-// buf holds an (ns+1) x ns row-major matrix: rows 0..ns-1 = S (lower triangle used), row ns = rhs.  Treating the
-// right-hand side as an extra row makes the forward substitution part of the panel TRSM.  Per 32-column panel:
-//   wave 0 factors the diagonal block in LDS, every thread solves one row of the panel (L21 = A21 L11^-T, kept in LDS),
-//   all threads apply the symmetric rank-32 update to the trailing matrix (4x4 register tiles, global memory = L2).
-// Then a blocked backward substitution.  p is written to ps[ns]; info = first non-positive pivot (1-based) or 0.
-constexpr int CHOL_NB = 32;
-__global__ __launch_bounds__(1024) void k_chol_solve(int ns, double reg, double* __restrict__ buf, double* __restrict__ ps,
-                                                     int* __restrict__ info, int max_rows) {
-  extern __shared__ __attribute__((aligned(16))) double chol_lds[];
-  constexpr int NB = CHOL_NB, LD = NB + 1;
-  double* D = chol_lds;                 // [NB][LD] diagonal block
-  double* L21 = chol_lds + NB * LD;     // [max_rows][LD] panel rows below the diagonal block (+ the rhs row)
-  int& bad = *reinterpret_cast<int*>(L21 + (size_t)max_rows * LD);   // no static LDS in front of the dynamic region
-  const int tid = threadIdx.x, nthr = blockDim.x;
-  double* A = buf;
-  if (tid == 0) bad = 0;
-  for (int i = tid; i < ns; i += nthr) A[(size_t)i * ns + i] += reg;
-  __syncthreads();
-
-  for (int k0 = 0; k0 < ns; k0 += NB) {
-    const int nb = min(NB, ns - k0);
-    const int m = ns - k0 - nb + 1;               // rows below the panel, including the rhs row
-    for (int e = tid; e < NB * NB; e += nthr) {   // pad a short last block with the identity
-      const int i = e / NB, j = e % NB;
-      D[i * LD + j] = (i < nb && j < nb) ? A[(size_t)(k0 + i) * ns + k0 + j] : (i == j ? 1.0 : 0.0);
-    }
-    __syncthreads();
-    if (tid < 64) {   // unblocked factorisation of the nb x nb diagonal block by one wavefront
-      for (int j = 0; j < nb; ++j) {
-        double dj = D[j * LD + j];
-        if (!(dj > 0.0)) { if (tid == 0 && bad == 0) bad = k0 + j + 1; dj = 1e-300; }
-        dj = sqrt(dj);
-        lds_fence();
-        if (tid == 0) D[j * LD + j] = dj;
-        for (int i = j + 1 + tid; i < nb; i += 64) D[i * LD + j] /= dj;
-        lds_fence();
-        const int mm = nb - j - 1;
-        for (int e = tid; e < mm * mm; e += 64) {
-          const int i = j + 1 + e / mm, k = j + 1 + e % mm;
-          if (k <= i) D[i * LD + k] -= D[i * LD + j] * D[k * LD + j];
-        }
-        lds_fence();
-      }
-    }
-    __syncthreads();
-    for (int e = tid; e < nb * nb; e += nthr) {
-      const int i = e / nb, j = e % nb;
-      if (j <= i) A[(size_t)(k0 + i) * ns + k0 + j] = D[i * LD + j];
-    }
-    // panel solve: one row per thread
-    for (int r = tid; r < m; r += nthr) {
-      double* arow = A + (size_t)(k0 + nb + r) * ns + k0;
-      double* xr = L21 + (size_t)r * LD;           // the row is private to this thread: no barrier inside the solve
-      for (int j = 0; j < NB; ++j) xr[j] = j < nb ? arow[j] : 0.0;
-      for (int j = 0; j < nb; ++j) {
-        double v = xr[j];
-        const double* dj = D + j * LD;
-        for (int k = 0; k < j; ++k) v -= xr[k] * dj[k];
-        v /= dj[j];
-        xr[j] = v;
-        arow[j] = v;
-      }
-    }
-    __syncthreads();
-    // trailing update (lower triangle + rhs row): A[r][c] -= L21[r] . L21[c], c <= r, c < m - 1
-    const int mt = (m + 3) / 4;
-    for (int tix = tid; tix < mt * mt; tix += nthr) {
-      const int tr = tix / mt, tc = tix % mt;
-      if (tc > tr) continue;
-      double acc[4][4] = {{0}};
-      for (int k = 0; k < NB; ++k) {   // padded columns of L21 are zero
-        double a[4], b[4];
-        for (int q = 0; q < 4; ++q) {
-          const int r = 4 * tr + q, c = 4 * tc + q;
-          a[q] = r < m ? L21[r * LD + k] : 0.0;
-          b[q] = c < m ? L21[c * LD + k] : 0.0;
-        }
-        for (int p = 0; p < 4; ++p)
-          for (int q = 0; q < 4; ++q) acc[p][q] += a[p] * b[q];
-      }
-      for (int p = 0; p < 4; ++p)
-        for (int q = 0; q < 4; ++q) {
-          const int r = 4 * tr + p, c = 4 * tc + q;
-          if (r < m && c < m - 1 && c <= r) A[(size_t)(k0 + nb + r) * ns + k0 + nb + c] -= acc[p][q];
-        }
-    }
-    __syncthreads();
-  }
-
-  // backward substitution L^T p = y (y = row ns), blocked from the last panel to the first
-  double* y = A + (size_t)ns * ns;
-  const int npanel = (ns + NB - 1) / NB;
-  for (int pi = npanel - 1; pi >= 0; --pi) {
-    const int k0 = pi * NB, nb = min(NB, ns - k0);
-    for (int e = tid; e < nb * nb; e += nthr) {
-      const int i = e / nb, j = e % nb;
-      D[i * LD + j] = A[(size_t)(k0 + i) * ns + k0 + j];
-    }
-    __syncthreads();
-    if (tid < 64) {   // wave-parallel back substitution of the diagonal block: lane l carries y[k0 + l]
-      double yv = tid < nb ? y[k0 + tid] : 0.0;
-      for (int i = nb - 1; i >= 0; --i) {
-        const double pi = __shfl(yv, i, 64) / D[i * LD + i];
-        if (tid == i) yv = pi;
-        else if (tid < i) yv -= D[i * LD + tid] * pi;
-      }
-      if (tid < nb) {
-        y[k0 + tid] = yv;
-        ps[k0 + tid] = yv;
-      }
-    }
-    __syncthreads();
-    for (int j = tid; j < k0; j += nthr) {
-      double sum = 0.0;
-      for (int i = 0; i < nb; ++i) sum += A[(size_t)(k0 + i) * ns + j] * y[k0 + i];
-      y[j] -= sum;
-    }
-    __syncthreads();
-  }
-  if (tid == 0) info[0] = bad;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// LDS-resident Cholesky solve for the common small reduced systems (ns <= ~190: cameras + intrinsics + board poses).
-// The lower triangle of the (ns+1) x (ns+1) matrix [S rhs; rhs^T *] lives packed in LDS (80 KB at ns = 140); the
-// right-hand side is its last row, so the forward substitution is part of the factorisation.  Right-looking, one column
-// per step: phase 1 scales the column into a side vector, phase 2 is the rank-1 update of the trailing triangle by the
-// whole workgroup (32 x 32 thread tile), two barriers per column.  Then a barrier-per-row backward substitution.
-// ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int pk(int i, int j) { return i * (i + 1) / 2 + j; }   // j <= i
-
-__global__ __launch_bounds__(1024) void k_chol_lds(int ns, double reg, const double* __restrict__ buf,
-                                                   double* __restrict__ ps, int* __restrict__ info) {
-  extern __shared__ __attribute__((aligned(16))) double chol_l[];
-  const int n1 = ns + 1;
-  double* L = chol_l;                          // packed lower triangle, n1 (n1 + 1) / 2
-  double* col = chol_l + n1 * (n1 + 1) / 2;    // scaled current column, n1
-  int* bad = reinterpret_cast<int*>(col + n1);
-  const int tid = threadIdx.x, nthr = blockDim.x;
-  if (tid == 0) *bad = 0;
-  // rows of buf: S rows then the rhs row (row ns); flat loop so that many independent global loads are in flight
-#pragma unroll 4
-  for (int e = tid; e < n1 * ns; e += nthr) {
-    const int i = e / ns, j = e - i * ns;
-    if (j <= i) L[pk(i, j)] = buf[e] + ((i == j) ? reg : 0.0);
-  }
-  __syncthreads();
-  const int tx = tid & 31, ty = tid >> 5, nty = nthr >> 5;
-  for (int j = 0; j < ns; ++j) {
-    double dj = L[pk(j, j)];
-    if (!(dj > 0.0)) { if (tid == 0 && *bad == 0) *bad = j + 1; dj = 1e-300; }
-    const double inv = 1.0 / sqrt(dj);
-    for (int i = j + 1 + tid; i < n1; i += nthr) col[i] = L[pk(i, j)] * inv;
-    __syncthreads();
-    for (int i = j + 1 + tid; i < n1; i += nthr) L[pk(i, j)] = col[i];
-    if (tid == 0) L[pk(j, j)] = sqrt(dj);
-    for (int i = j + 1 + ty; i < n1; i += nty) {
-      const double ci = col[i];
-      double* Li = L + pk(i, 0);
-      for (int k = j + 1 + tx; k <= i && k < ns; k += 32) Li[k] -= ci * col[k];
-    }
-    __syncthreads();
-  }
-  // backward substitution  L^T p = y,  y = row ns
-  double* y = L + pk(ns, 0);
-  for (int i = ns - 1; i >= 0; --i) {
-    const double pi = y[i] / L[pk(i, i)];
-    __syncthreads();
-    if (tid == 0) { y[i] = pi; ps[i] = pi; }
-    const double* Li = L + pk(i, 0);
-    for (int k = tid; k < i; k += nthr) y[k] -= Li[k] * pi;
-    __syncthreads();
-  }
-  if (tid == 0) info[0] = *bad;
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // k_chol_blk: the reduced system of the usual calibration (ns <= 159: cameras x (pose + intrinsics) + boards) solved by
 // ONE workgroup of 8 wavefronts with the whole lower triangle resident in LDS as 16 x 16 tiles (row stride 17).
-// The column-by-column k_chol_lds above spends two 1024-thread barriers per column (234 us at ns = 140); here a block
+// (The column-by-column kernel of round 1 spent two 1024-thread barriers per column: 234 us at ns = 140.) here a block
 // column costs two barriers:
 //   (a) wave 0 factors the diagonal tile entirely in REGISTERS: lane i owns row i, the pivot and the scaled column
 //       entries travel through v_readlane (an LDS round trip costs ~250 cycles on this chip and there are ns of them
@@ -1290,83 +1115,14 @@ __device__ __forceinline__ double lane_bcast(double v, int src) {   // value of 
   return __hiloint2double(hi, lo);
 }
 
-// (a): Cholesky factor of the 16 x 16 tile D (first ncol columns; the rest is right-hand-side row / identity padding)
-// and its inverse Xi, by one wavefront.  col0 = global index of the tile's first column (for the pivot report).
-// FULL: all 16 columns belong to the matrix -- no per-column branch, so the 16 pivot steps form ONE basic block and the
-// scheduler can start the rsqrt chain of column j + 1 while the broadcasts / updates of column j are still issuing.
-// INV = false: no inverse; Xi[0 .. 16) receives 1 / L_jj instead (k_chol_blk solves with the factor itself, see there).
-template <bool FULL, bool INV = true>
-__device__ __forceinline__ void chol_tile_factor_t(double* __restrict__ D, double* __restrict__ Xi, int ncol, int col0,
-                                                   int lane, int& badcol) {
-  const int li = lane & 15;
-  double row[CT], dinv[CT];
-#pragma unroll
-  for (int c = 0; c < CT; ++c) row[c] = D[li * CTL + c];
-#pragma unroll
-  for (int j = 0; j < CT; ++j) {
-    dinv[j] = 1.0;
-    if (FULL || j < ncol) {                // wave-uniform
-      double dj = lane_bcast(row[j], j);
-      badcol = (dj > 0.0 || badcol != 0) ? badcol : col0 + j + 1;
-      dj = fmax(dj, 1e-300);
-      const double inv = rsqrt(dj);
-      dinv[j] = inv;
-      const double l = (li == j) ? dj * inv : row[j] * inv;
-      row[j] = l;
-      // all broadcasts of the step first, then the FMAs: distinct SGPR pairs, no s_nop between readlane and use
-      double lk[CT];
-#pragma unroll
-      for (int k2 = j + 1; k2 < CT; ++k2) lk[k2] = lane_bcast(l, k2);
-#pragma unroll
-      for (int k2 = j + 1; k2 < CT; ++k2) row[k2] -= l * lk[k2];
-    }
-  }
-  if (lane < CT) {
-#pragma unroll
-    for (int c = 0; c < CT; ++c) D[li * CTL + c] = row[c];
-  }
-  if constexpr (!INV) {
-    if (lane == 0) {
-#pragma unroll
-      for (int j = 0; j < CT; ++j) Xi[j] = dinv[j];
-    }
-    return;
-  }
-  // inverse: lane c solves L x = e_c (L_im is lane i's row[m]); the padding has a unit diagonal
-  double x[CT];
-#pragma unroll
-  for (int i = 0; i < CT; ++i) {
-    double s0 = (i == li) ? 1.0 : 0.0, s1 = 0.0;
-    double lr[CT];
-#pragma unroll
-    for (int m = 0; m < i; ++m) lr[m] = lane_bcast(row[m], i);
-#pragma unroll
-    for (int m = 0; m < i; ++m) {
-      if (m & 1) s1 -= lr[m] * x[m]; else s0 -= lr[m] * x[m];
-    }
-    x[i] = (i >= li) ? (s0 + s1) * dinv[i] : 0.0;
-  }
-  if (lane < CT) {
-#pragma unroll
-    for (int i = 0; i < CT; ++i) Xi[i * CTL + li] = x[i];
-  }
-}
-__device__ __forceinline__ void chol_tile_factor(double* __restrict__ D, double* __restrict__ Xi, int ncol, int col0,
-                                                 int lane, int& badcol) {
-#if !defined(MCBA_EXP_CHOL_NOFULL)
-  if (ncol >= CT) chol_tile_factor_t<true>(D, Xi, CT, col0, lane, badcol);
-  else
-#endif
-    chol_tile_factor_t<false>(D, Xi, ncol, col0, lane, badcol);
-}
-// The same factor in 4 x 4 BLOCKS with the trailing update on the matrix pipe (round 3).  Lane (li, lg) keeps four entries of
+// Cholesky factor of a 16 x 16 tile by one wavefront, in 4 x 4 BLOCKS with the trailing update on the matrix pipe (round 3;
+// the column-by-column form it replaced -- lane i owns row i, 16 x (2 + 2 (15 - j)) readlanes and 120 FMAs in one dependent chain --
+// took ~310 cycles per pivot, 5 k cycles per tile).  Lane (li, lg) keeps four entries of
 // row li -- the columns lg, lg + 4, lg + 8, lg + 12 -- which is exactly the accumulator layout of v_mfma_f64_16x16x4 for the
 // symmetric update C -= A A^T (lane (li, lg) receives C[lg + 4 r][li] = C[li][lg + 4 r]) and, for block b, exactly its operand
 // layout (lane (li, lg) supplies L[li][4 b + lg]): no data movement between the steps.  Per block: the four columns of the block
 // are gathered into every lane (four cross-lane reads), factored redundantly by all lanes (pivot j touches only the columns left
 // in the block: 3 + 2 + 1 broadcasts instead of 15 + ... + 12), written back, and ONE rank-4 MFMA updates the rest of the tile.
-// The column-by-column version above issues 16 x (2 + 2 (15 - j)) readlanes and 120 FMAs in one dependent chain: ~310 cycles per
-// pivot, 5 k cycles per tile -- the serial floor of every Cholesky kernel of the solver.
 template <bool FULL>
 __device__ __forceinline__ void chol_tile_factor_b4(double* __restrict__ D, double* __restrict__ dinv, int ncol, int col0,
                                                     int lane, int& badcol) {
@@ -1671,204 +1427,11 @@ __global__ __launch_bounds__(CHOL_BLK_THREADS) void k_chol_blk(int ns, double re
 #undef CHOL_STAMP
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// k_chol_glb: the same tile algorithm as k_chol_blk for reduced systems that do not fit LDS (ns = 160 ... 1023: many
-// cameras, or adjust_board).  ONE workgroup; the matrix stays in global memory (it is L2-resident: <= 8 MB) and is
-// factored in place, only the current panel (the X tiles of one block column), the current diagonal tile and its inverse
-// live in LDS.  Per block column: wave 0 factors + inverts the diagonal tile in registers (chol_tile_factor), every wave
-// forms panel tiles X = A L_kk^-T on the matrix pipe (A from global, X to LDS and to global), then the trailing tiles
-// C -= X_i X_j^T are updated in global memory with X from LDS; the next diagonal tile is updated first and factored by
-// wave 0 while the other waves finish the update (look-ahead).  The inverted diagonal tiles are kept (Linv, global) for
-// the backward substitution, which runs on wave 0.
-// ---------------------------------------------------------------------------------------------------------------
-constexpr int CHOL_GLB_MAX_N1 = 1024;    // LDS limit of the kernel (measured: 4.8 ms at ns = 963 against 5.8 ms multi-workgroup)
-constexpr int CHOL_GLB_AUTO_N1 = CHOL_GLB_MAX_N1;
-__host__ __device__ inline size_t chol_glb_lds_bytes(int ns) {
-  const int nb = (ns + 1 + CT - 1) / CT;
-  return ((size_t)(nb + 2) * CTS + 2 * nb * CT) * sizeof(double) + 16;
-}
-
-__global__ __launch_bounds__(CHOL_BLK_THREADS) void k_chol_glb(int ns, double reg, double* __restrict__ buf,
-                                                               double* __restrict__ Linv, double* __restrict__ ps,
-                                                               int* __restrict__ info) {
-  extern __shared__ __attribute__((aligned(16))) double chol_g[];
-  constexpr int NW = CHOL_BLK_THREADS / 64;
-  const int n1 = ns + 1, nb = (n1 + CT - 1) / CT, nbc = (ns + CT - 1) / CT;
-  double* Dt = chol_g;                          // current diagonal tile
-  double* Li = Dt + CTS;                        // its inverse
-  double* Xp = Li + CTS;                        // panel: X tiles of block rows k+1 .. nb-1 (tile bi at (bi - k - 1) CTS)
-  double* yv = Xp + (size_t)nb * CTS;
-  double* pv = yv + nb * CT;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
-  int badcol = 0;
-  // entry (gi, gj) of the augmented matrix; identity outside (padding rows / columns), reg on the diagonal of S
-  auto load_entry = [&](int gi, int gj) {
-    const bool in = gi < n1 && gj < ns;
-    return masked_load(buf, (size_t)gi * ns + gj, in) + (gi == gj ? (in ? reg : 1.0) : 0.0);
-  };
-  if (wave == 0) {   // first diagonal tile
-#pragma unroll
-    for (int r = 0; r < 4; ++r) Dt[(lg + 4 * r) * CTL + li] = load_entry(lg + 4 * r, li);
-    lds_fence();
-    chol_tile_factor(Dt, Li, min(CT, ns), 0, lane, badcol);
-    lds_fence();
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int gi = lg + 4 * r;
-      if (gi < n1 && li < ns) buf[(size_t)gi * ns + li] = Dt[gi * CTL + li];
-      Linv[(lg + 4 * r) * CT + li] = Li[(lg + 4 * r) * CTL + li];
-    }
-  }
-  __syncthreads();
-  for (int k = 0; k < nbc; ++k) {
-    const int c0 = CT * k;
-    {
-      // panel: X = A L_kk^-T for the tiles below the diagonal (rows may run into the rhs row / padding)
-      double bv[4];
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) bv[s4] = Li[li * CTL + 4 * s4 + lg];
-      for (int bi = k + 1 + wave; bi < nb; bi += NW) {
-        const int gi = CT * bi + li;
-        double av[4];
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-          const int gj = c0 + 4 * s4 + lg;
-          av[s4] = masked_load(buf, (size_t)gi * ns + gj, gi < n1 && gj < ns);
-        }
-        double4_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s4], bv[s4], acc, 0, 0, 0);
-        double* X = Xp + (size_t)(bi - k - 1) * CTS;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int ro = lg + 4 * r, gr = CT * bi + ro, gc = c0 + li;
-          X[ro * CTL + li] = acc[r];
-          if (gr < n1 && gc < ns) buf[(size_t)gr * ns + gc] = acc[r];
-        }
-      }
-    }
-    __syncthreads();
-    {
-      // trailing tiles (bi, bj), k < bj <= bi:  C -= X_bi X_bj^T in global memory.  Tile 0 of the enumeration is the next
-      // diagonal tile: wave 0 updates it into LDS and factors it (look-ahead) while waves 1 .. 7 share the others.
-      const int m = nb - k - 1, nt = m * (m + 1) / 2;
-      if (wave == 0) {
-        const int b1 = k + 1;
-        if (nt > 0 && ns - CT * b1 > 0) {
-          const double* X1 = Xp;   // tile b1 is the first of the panel
-          double4_t acc;
-          double av[4], bw[4];
-#pragma unroll
-          for (int s4 = 0; s4 < 4; ++s4) {
-            av[s4] = -X1[li * CTL + 4 * s4 + lg];
-            bw[s4] = X1[li * CTL + 4 * s4 + lg];
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[r] = load_entry(CT * b1 + lg + 4 * r, CT * b1 + li);
-#pragma unroll
-          for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s4], bw[s4], acc, 0, 0, 0);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) Dt[(lg + 4 * r) * CTL + li] = acc[r];
-          lds_fence();
-          // (the panel of column k still needs the inverse of tile k: the new inverse goes to a scratch tile first)
-          double* Ln = Xp + (size_t)(nb - 1) * CTS;   // free: the panel of column k has nb - k - 1 <= nb - 1 tiles
-          chol_tile_factor(Dt, Ln, min(CT, ns - CT * b1), CT * b1, lane, badcol);
-          lds_fence();
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int ro = lg + 4 * r, gi = CT * b1 + ro, gj = CT * b1 + li;
-            if (gi < n1 && gj < ns) buf[(size_t)gi * ns + gj] = Dt[ro * CTL + li];
-            Linv[(size_t)b1 * CT * CT + ro * CT + li] = Ln[ro * CTL + li];
-          }
-        }
-      } else {
-        // TB tiles at a time: the C tiles come from L2 (~1 us per round trip), so the loads of a batch are all issued
-        // before the first MFMA
-        constexpr int TB = 4;
-        for (int t0 = wave; t0 < nt; t0 += TB * (NW - 1)) {
-          double4_t acc[TB];
-          int tbi[TB], tbj[TB], ta[TB], tr[TB];
-#pragma unroll
-          for (int u = 0; u < TB; ++u) {
-            const int tt = t0 + u * (NW - 1);
-            const int tc = tt < nt ? tt : 0;               // tt -> (a, rem), rem <= a: row a of the lower-triangular enumeration
-            int a = (int)((sqrtf(8.0f * (float)tc + 1.0f) - 1.0f) * 0.5f);
-            a += ((a + 1) * (a + 2) / 2 <= tc) ? 1 : 0;
-            a -= (a * (a + 1) / 2 > tc) ? 1 : 0;
-            const int rem = tc - a * (a + 1) / 2;
-            ta[u] = a; tr[u] = rem;
-            tbi[u] = k + 1 + a; tbj[u] = k + 1 + rem;
-            const int gj = CT * tbj[u] + li;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int gi = CT * tbi[u] + lg + 4 * r;
-              acc[u][r] = masked_load(buf, (size_t)gi * ns + gj, tt < nt && gi < n1 && gj < ns);
-            }
-          }
-#pragma unroll
-          for (int u = 0; u < TB; ++u) {
-            const double* Xa = Xp + (size_t)ta[u] * CTS;
-            const double* Xb = Xp + (size_t)tr[u] * CTS;
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4)
-              acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Xa[li * CTL + 4 * s4 + lg], Xb[li * CTL + 4 * s4 + lg], acc[u], 0, 0, 0);
-          }
-#pragma unroll
-          for (int u = 0; u < TB; ++u) {
-            const int tt = t0 + u * (NW - 1);
-            const int gj = CT * tbj[u] + li;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int gi = CT * tbi[u] + lg + 4 * r;
-              if (tt < nt && gi < n1 && gj < ns) buf[(size_t)gi * ns + gj] = acc[u][r];
-            }
-          }
-        }
-      }
-    }
-    __syncthreads();
-    if (wave == 0 && k + 1 < nbc) {   // the inverse of the next diagonal tile becomes the current one
-      const double* Ln = Xp + (size_t)(nb - 1) * CTS;
-      for (int e = lane; e < CTS; e += 64) Li[e] = Ln[e];
-    }
-    __threadfence_block();
-    __syncthreads();
-  }
-  if (wave == 0) {
-    // forward-substituted right-hand side = row ns of the factor; blocked back substitution with the stored inverses
-    for (int e = lane; e < nb * CT; e += 64) yv[e] = e < ns ? buf[(size_t)ns * ns + e] : 0.0;
-    lds_fence();
-    for (int kb = nbc - 1; kb >= 0; --kb) {
-      {   // p_k = L_kk^-T z_k   (the strict upper part of the stored inverse is zero)
-        const double* Xi = Linv + (size_t)kb * CT * CT;
-        double sp[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int i = 0; i < CT; ++i) sp[i & 3] += Xi[i * CT + li] * yv[CT * kb + i];
-        const double sum = (sp[0] + sp[1]) + (sp[2] + sp[3]);
-        if (lane < CT) {
-          pv[CT * kb + li] = sum;
-          if (CT * kb + li < ns) ps[CT * kb + li] = sum;
-        }
-      }
-      lds_fence();
-      for (int e = lane; e < CT * kb; e += 64) {   // z_j -= L_kj^T p_k for the blocks above (L_kj from global)
-        double sp[4] = {yv[e], 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int r = 0; r < CT; ++r) {
-          const int gi = CT * kb + r;
-          sp[r & 3] -= masked_load(buf, (size_t)gi * ns + e, gi < ns) * pv[gi];
-        }
-        yv[e] = (sp[0] + sp[1]) + (sp[2] + sp[3]);
-      }
-      lds_fence();
-    }
-    if (lane == 0) info[0] = badcol;
-  }
-}
+constexpr int CHOLP_MAX_N1 = 1024;       // largest reduced system (ns + 1) of the panel kernels below
 
 // ---------------------------------------------------------------------------------------------------------------
 // k_cholp_*: PANEL Cholesky for reduced systems that do not fit one workgroup's LDS (ns + 1 > 160: many cameras --
-// 16 cameras x 5 boards give ns = 286 -- or adjust_board).  k_chol_glb keeps the matrix in L2 and pays a global round trip
+// 16 cameras x 5 boards give ns = 286 -- or adjust_board).  Round 2's single-workgroup kernel kept the matrix in L2 and paid a global round trip
 // for every 16-column step on ONE compute unit (265 us at ns = 286: the trailing update of up to 153 tiles per step is the
 // critical path).  Here a block column of up to 96 columns (as many 16-column tiles as fit 150 KB of LDS, at most six: the
 // panels get wider as the remaining matrix gets shorter -- 286: 3 + 4 + 6 + 5 tile columns, eight launches) lives in LDS while it is factored with the
@@ -2145,7 +1708,7 @@ __global__ __launch_bounds__(CHOLP_BACK_THREADS) void k_cholp_back(int ns, const
 
 // ---------------------------------------------------------------------------------------------------------------
 // Multi-workgroup blocked Cholesky for large reduced systems (adjust_board: ns = shared + 3 x #board points, up to a
-// few thousand).  Same data layout as k_chol_solve ((ns+1) x ns, row ns = rhs), 64-column panels, three launches per
+// few thousand).  Data layout: (ns+1) x ns, row ns = rhs, 64-column panels, three launches per
 // panel: diagonal block (one workgroup), panel solve (one row per thread), symmetric rank-64 trailing update with
 // v_mfma_f64_16x16x4_f64 on 64 x 64 tiles staged in LDS.  Then a blocked backward substitution (two launches / panel).
 // ---------------------------------------------------------------------------------------------------------------
@@ -2376,6 +1939,7 @@ __global__ __launch_bounds__(64, 8) void k_schur_backsub(Dims d, const double* _
       dt[0] += a * a; dt[1] += a * b; dt[2] += b * b;
     }
     if (dots == nullptr) return;
+    if (d.shard_world > 0 && d.shard_rank != 0) dt[0] = dt[1] = dt[2] = 0.0;   // shared entries count on rank 0 only
     for (int k = 0; k < 3; ++k) {
       const double ds = wave_sum(dt[k]);
       if (lane == 0) dots[3 * blockIdx.x + k] = ds;
@@ -2507,9 +2071,10 @@ __global__ __launch_bounds__(256) void k_vec_step(Dims d, Tables t, const double
     const double s = dsc[i] * p;
     const double xi = x[i];
     xnew[i] = step_point(xi, dsc[i], p);
-    ph = p * p;
-    st = s * s;
-    xx = xi * xi;
+    const double w = d.entry_weight(i);
+    ph = w * (p * p);
+    st = w * (s * s);
+    xx = w * (xi * xi);
   }
   const double a = block_reduce<false>(ph, scratch);
   const double b = block_reduce<false>(st, scratch);
@@ -2564,6 +2129,122 @@ __global__ __launch_bounds__(64) void k_fold_partials(double* __restrict__ part,
   for (int b = threadIdx.x; b < n; b += 64) s += part[b];
   s = wave_sum(s);
   if (threadIdx.x == 0) part[0] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Frame-sharded handles: the messages of the trust-region iteration.  No n-vector crosses the ranks: every
+// message is a handful of per-rank partial sums or the SHARED entries of [g | diag], independent of the number of frames.
+// Per-rank partials travel as "gather by sum": rank r writes its values into block r of a zeroed buffer, the all-reduce adds
+// the buffers, and every rank then folds the blocks in rank order with the very kernels that fold the per-workgroup partials
+// of a single GPU (tr_reg_wave / tr_step_wave) -- the same arithmetic on every rank, and a max (|g|_inf) needs no second
+// collective.
+// ---------------------------------------------------------------------------------------------------------------
+// message 1 (after the assembly): comm = [g_s (ns) | diag_s (ns) | cost, count | |p_h|^2, |step|^2, |x|^2 partial sums of the
+// step that led to this point (k_vec_step partials, own entries only) | trial cost partial (retries)]
+constexpr int SHARD_TAIL = 6;
+__global__ __launch_bounds__(256) void k_shard_pack1(Dims d, const double* __restrict__ g, const double* __restrict__ diag,
+                                                     const double* __restrict__ cost_count, const double* __restrict__ step_part,
+                                                     int nvb, double* __restrict__ comm) {
+  const int ns = d.ns;
+  for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < ns; s += gridDim.x * blockDim.x) {
+    const int xi = d.shared_to_x(s);
+    comm[s] = g[xi];
+    comm[ns + s] = diag[xi];
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    double s3[3] = {0, 0, 0};
+    if (step_part != nullptr)
+      for (int b = lane; b < nvb; b += 64)
+        for (int k = 0; k < 3; ++k) s3[k] += step_part[3 * b + k];
+    for (int k = 0; k < 3; ++k) s3[k] = wave_sum(s3[k]);
+    if (lane == 0) {
+      comm[2 * ns] = cost_count[0];
+      comm[2 * ns + 1] = cost_count[1];
+      for (int k = 0; k < 3; ++k) comm[2 * ns + 2 + k] = s3[k];
+      comm[2 * ns + 5] = 0.0;
+    }
+  }
+}
+// ... and back: the shared entries of g / diag, {cost, count}, and the step norms as block 0 of the k_vec_step partials (the
+// other blocks zero), where the host's fold expects them
+__global__ __launch_bounds__(256) void k_shard_unpack1(Dims d, const double* __restrict__ comm, double* __restrict__ g,
+                                                       double* __restrict__ diag, double* __restrict__ cost_count,
+                                                       double* __restrict__ step_part, int nvb) {
+  const int ns = d.ns;
+  for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < ns; s += gridDim.x * blockDim.x) {
+    const int xi = d.shared_to_x(s);
+    g[xi] = comm[s];
+    diag[xi] = comm[ns + s];
+  }
+  if (blockIdx.x == 0) {
+    if (threadIdx.x < 2) cost_count[threadIdx.x] = comm[2 * ns + threadIdx.x];
+    if (step_part != nullptr)
+      for (int e = threadIdx.x; e < 3 * nvb; e += blockDim.x) step_part[e] = e < 3 ? comm[2 * ns + 2 + e] : 0.0;
+  }
+}
+// message 2 (after the gradient scaling + Cauchy curvature): block r of `vs` = [|g|_inf, |g_h|^2, |x scale|^2] of rank r,
+// q[r] = its curvature partial; out = [vs (3 W) | q (W)], everything but this rank's entries zero
+__global__ __launch_bounds__(64) void k_shard_fold2(const double* __restrict__ vs_part, int nvb, const double* __restrict__ q_part,
+                                                    int nq, int rank, int world, double* __restrict__ out) {
+  const int lane = threadIdx.x;
+  double mx = 0, gg = 0, xs = 0, q = 0;
+  for (int b = lane; b < nvb; b += 64) {
+    mx = fmax(mx, vs_part[3 * b]);
+    gg += vs_part[3 * b + 1];
+    xs += vs_part[3 * b + 2];
+  }
+  for (int b = lane; b < nq; b += 64) q += q_part[b];
+  mx = wave_max(mx);
+  gg = wave_sum(gg);
+  xs = wave_sum(xs);
+  q = wave_sum(q);
+  mx = __shfl(mx, 0, 64); gg = __shfl(gg, 0, 64); xs = __shfl(xs, 0, 64); q = __shfl(q, 0, 64);
+  for (int e = lane; e < 4 * world; e += 64)   // (every entry written once, by one lane)
+    out[e] = e == 3 * rank ? mx : (e == 3 * rank + 1 ? gg : (e == 3 * rank + 2 ? xs : (e == 3 * world + rank ? q : 0.0)));
+}
+// message 4 (after the back substitution): the partial dots {g_h.g_h, g_h.gn, gn.gn} of this rank (own frames; rank 0: +
+// the shared entries) as block `rank` of [3 W | info]; the pivot report is replicated: rank 0 contributes it
+__global__ __launch_bounds__(64) void k_shard_fold_dots(const double* __restrict__ dot_part, int nblk, int rank, int world,
+                                                        double* __restrict__ out) {
+  const int lane = threadIdx.x;
+  double dt[3] = {0, 0, 0};
+  for (int b = lane; b < nblk; b += 64)
+    for (int k = 0; k < 3; ++k) dt[k] += dot_part[3 * b + k];
+  for (int k = 0; k < 3; ++k) dt[k] = wave_sum(dt[k]);
+  for (int k = 0; k < 3; ++k) dt[k] = __shfl(dt[k], 0, 64);
+  const double info = rank == 0 ? dot_part[3 * nblk] : 0.0;
+  for (int e = lane; e < 3 * world + 1; e += 64)
+    out[e] = e == 3 * world ? info : (e == 3 * rank ? dt[0] : (e == 3 * rank + 1 ? dt[1] : (e == 3 * rank + 2 ? dt[2] : 0.0)));
+}
+// retry after a rejected step: [trial cost | step norms] of this rank -> comm[0 .. 4) (summed over the ranks), and back
+__global__ __launch_bounds__(64) void k_shard_trial_pack(const double* __restrict__ cost_part, int ncost,
+                                                         const double* __restrict__ step_part, int nvb, double* __restrict__ comm) {
+  const int lane = threadIdx.x;
+  double c = 0, s3[3] = {0, 0, 0};
+  for (int b = lane; b < ncost; b += 64) c += cost_part[b];
+  for (int b = lane; b < nvb; b += 64)
+    for (int k = 0; k < 3; ++k) s3[k] += step_part[3 * b + k];
+  c = wave_sum(c);
+  for (int k = 0; k < 3; ++k) s3[k] = wave_sum(s3[k]);
+  if (lane == 0) {
+    comm[0] = c;
+    for (int k = 0; k < 3; ++k) comm[1 + k] = s3[k];
+  }
+}
+__global__ __launch_bounds__(256) void k_shard_trial_unpack(const double* __restrict__ comm, double* __restrict__ cost_part,
+                                                            double* __restrict__ step_part, int nvb) {
+  if (threadIdx.x == 0) cost_part[0] = comm[0];
+  for (int e = threadIdx.x; e < 3 * nvb; e += blockDim.x) step_part[e] = e < 3 ? comm[1 + e] : 0.0;
+}
+// the eliminated frame parameters of this rank's frames, zeros elsewhere (the all-reduce that follows is an all-gather: the
+// complete x a solve returns, and the complete g / diag of the host-boundary evaluation)
+__global__ __launch_bounds__(256) void k_shard_own_frames(Dims d, const double* __restrict__ v, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < d.n_motion) {
+    const int xi = d.off_motion + i;
+    out[i] = d.entry_weight(xi) != 0.0 ? v[xi] : 0.0;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -4,11 +4,16 @@ Every observation belongs to exactly one frame, the per-frame pose blocks are pr
 frame, and everything else is a sum -- so a rank keeps only its contiguous frame range of the observation table on
 its GPU and the solver exchanges just the reduced quantities per iteration:
 
-    [g | diag(J^T J) | cost]                 2 n + 2 doubles    after every linearisation
-    quadratic forms for the 2-D subspace     3 doubles          twice per iteration
-    Schur complement + right-hand side       n_s^2 + n_s        once per iteration
-    eliminated-frame part of the GN step     n_motion           once per iteration
-    trial cost                               1 double           once per trial step
+    shared entries of [g | diag] + cost + step norms    2 n_s + 6 doubles   after every linearisation
+    norms + Cauchy curvature, per rank                  4 W doubles         once per iteration
+    Schur complement + right-hand side                  n_s^2 + n_s         once per iteration
+    dots of the 2-D subspace, per rank (+ pivot flag)   3 W + 1 doubles     once per iteration
+    trial cost + step norms                             4 doubles           per RETRY after a rejected step only
+    eliminated-frame part of x                          n_motion            once per SOLVE (the complete x every rank returns)
+
+(W ranks, n_s shared parameters.)  No message grows with the number of frames: the frame entries of every n-vector live on
+the rank that owns the frame, sums over all parameters are all-reduced per-rank partial sums ("gather by summation": rank r
+fills block r of a zeroed buffer).
 
 The C library calls back into `allreduce_hook` with DEVICE pointers (include/mcba.h: mcba_allreduce_fn); with the
 "nccl" backend (RCCL over xGMI on ROCm) the reduction runs in place on the handle's stream -- which is torch's
@@ -136,6 +141,6 @@ def sharded_handle(calib, rank=None, world_size=None, group=None, balance=True, 
     h.native_allreduce = bool(native) and init_native_allreduce(h, rank, world_size, group)
     if not h.native_allreduce:
       h.set_allreduce(make_allreduce_hook(group, stream=tstream))
-    h.set_shard_root(rank == 0)
+    h.set_shard_rank(rank, world_size)
   h.frame_range = shards[rank]
   return h

@@ -10,7 +10,7 @@ with Handle(c) as h:
         M = rng.normal(size=(ns + 20, ns)); S = M.T @ M / ns + 0.1 * np.eye(ns); rhs = rng.normal(size=ns)
         ref = np.linalg.solve(S + 0.05 * np.eye(ns), rhs)
         out = []
-        for mode in (0, 1, 2, 3, 5, 6):
+        for mode in (0, 1, 6):
             try:
                 p = h.debug_chol(S, rhs, reg=0.05, blocked=mode)
                 t0 = time.perf_counter()

@@ -73,22 +73,27 @@ def test_sharded_normal_equations_sum_gloo(name, tmp_path):
   assert red[-1] == hm.m                                           # shards partition the residual vector
 
 
-def _gpu_worker(rank, world, port, name, out, empty_last=False):
+def _gpu_worker(rank, world, port, name, out, empty_last=False, frames=None):
   sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
   import torch
   import torch.distributed as dist
+  from util import sub_rig
   os.environ["MASTER_ADDR"] = "127.0.0.1"
   os.environ["MASTER_PORT"] = str(port)
   torch.cuda.set_device(0)                  # both ranks share the one GPU of the test box (gloo: host-staged sums)
   dist.init_process_group("gloo", rank=rank, world_size=world)
   g, rig = load_golden(name)
+  if frames is not None:
+    rig = sub_rig(rig, frames)
   c = mirror(rig)
+  x0 = c.param_vec
   F = rig.valid.shape[1]
   # empty_last: rank 0 owns every frame, the other ranks own nothing (legal: frame_shards does that when F < world)
   h = mdist.sharded_handle(c, shards=[(0, F)] + [(F, F)] * (world - 1) if empty_last else None)
-  cost, grad, diag = h.normal_equations(g["x0"])
   h.allreduce_stats(reset=True)
-  res = h.solve(g["x0"])
+  cost, grad, diag = h.normal_equations(x0)
+  ne_sizes = h.allreduce_stats(reset=True)[2]
+  res = h.solve(x0)
   ar_calls, ar_doubles, ar_sizes = h.allreduce_stats(reset=True)
   e, v = h.reprojection_error(res.x)
   sq = torch.tensor([float((e[v] ** 2).sum()), float(v.sum())], dtype=torch.float64)
@@ -96,26 +101,33 @@ def _gpu_worker(rank, world, port, name, out, empty_last=False):
   if rank == 0:
     np.savez(out, cost=cost, grad=grad, diag=diag, x=res.x, nfev=res.nfev, status=res.status, final_cost=res.cost,
              rms=float(np.sqrt(sq[0] / sq[1])), ar_calls=ar_calls, ar_doubles=ar_doubles, ar_sizes=np.array(ar_sizes),
-             njev=res.njev)
+             njev=res.njev, ne_sizes=np.array(ne_sizes))
   h.close()
   dist.destroy_process_group()
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,empty_last", [("tiny_rolling", False), ("tiny_handeye", False), ("cfg1", False),
-                                             ("tiny_rolling", True), ("cfg1", True)])
-def test_sharded_solve_two_ranks_one_gpu(name, empty_last, tmp_path):
+@pytest.mark.parametrize("name,empty_last,frames", [("tiny_rolling", False, None), ("tiny_handeye", False, None), ("cfg1", False, None),
+                                                    ("tiny_rolling", True, None), ("cfg1", True, None), ("cfg1", False, 12)])
+def test_sharded_solve_two_ranks_one_gpu(name, empty_last, frames, tmp_path):
   """empty_last: one rank owns all frames and the other an EMPTY shard -- both must issue the same sequence of
-  collectives (the decision to reduce the frame part of the step may not depend on the local shard size)."""
+  collectives (the decision to reduce anything may not depend on the local shard size).  frames: the same rig cut to fewer
+  frames -- no message of the iteration may depend on the frame count."""
   import torch.multiprocessing as mp
   from multical_amd.backend import Handle
+  from util import sub_rig
   out = str(tmp_path / "sharded.npz")
-  mp.spawn(_gpu_worker, args=(2, _free_port(), name, out, empty_last), nprocs=2, join=True)
+  world = 2
+  mp.spawn(_gpu_worker, args=(world, _free_port(), name, out, empty_last, frames), nprocs=world, join=True)
   sh = np.load(out)
   g, rig = load_golden(name)
-  with Handle(mirror(rig)) as h:
-    cost, grad, diag = h.normal_equations(g["x0"])
-    res = h.solve(g["x0"])
+  if frames is not None:
+    rig = sub_rig(rig, frames)
+  c = mirror(rig)
+  x0 = c.param_vec
+  with Handle(c) as h:
+    cost, grad, diag = h.normal_equations(x0)
+    res = h.solve(x0)
     e, v = h.reprojection_error(res.x)
   assert float(sh["cost"]) == pytest.approx(cost, rel=1e-13)
   assert np.abs(sh["grad"] - grad).max() <= 1e-12 * np.abs(grad).max()
@@ -127,28 +139,38 @@ def test_sharded_solve_two_ranks_one_gpu(name, empty_last, tmp_path):
   #  amplify the last-bit differences)
   assert np.abs(sh["x"] - res.x).max() < 1e-7
   # ---- the chain of collectives of the sharded trust-region iteration, in issue order ----------------
-  #   [g | diag | cost] (2 n + 2)  ->  Cauchy curvature (1)  ->  reduced Schur system (ns^2 + ns)  ->  frame part of the
-  #   step (n_motion; not for hand-eye, which has no per-frame parameters)  ->  the next [g | diag | cost], which carries
-  #   the trial cost of the accepted step: FOUR dependent reductions per accepted iteration, no separate cost message.
+  #   G = shared entries of [g | diag] + {cost, count} + step norms (2 ns + 6)  ->  norms + Cauchy curvature per rank (4 W)
+  #   ->  reduced Schur system (ns^2 + ns)  ->  dots of the 2-D subspace per rank + pivot flag (3 W + 1)  ->  the next G, which
+  #   carries the trial cost and the step norms of the accepted step: FOUR dependent reductions per accepted iteration, NONE
+  #   of which grows with the number of frames (round 3: 2 n + 2 and n_motion).  A retry after a rejected step costs one
+  #   4-double message; the complete x every rank returns is ONE n_motion message per solve.
   sizes = [int(v) for v in sh["ar_sizes"]]
   n = res.x.size
   motion = rig.cfg["motion"]
-  n_motion = {"static": 6, "rolling": 12}.get(motion, 0) * rig.valid.shape[1]
+  F = rig.valid.shape[1]
+  n_motion = {"static": 6, "rolling": 12}.get(motion, 0) * F
   ns = n - n_motion
-  G, S = 2 * n + 2, ns * ns + ns
-  assert sizes[0] == G and int(sh["ar_calls"]) == len(sizes) and int(sh["ar_doubles"]) == sum(abs(v) for v in sizes)
-  at = [i for i, v in enumerate(sizes) if v == S]
+  G, S, M2, M4 = 2 * ns + 6, ns * ns + ns, 4 * world, 3 * world + 1
+  assert int(sh["ar_calls"]) == len(sizes) and int(sh["ar_doubles"]) == sum(abs(v) for v in sizes)
+  # host-boundary evaluation: the message of the linearisation, then the frame entries of g and of diag for the CALLER
+  assert [int(v) for v in sh["ne_sizes"]] == [G] + ([n_motion, n_motion] if n_motion else [])
+  assert sizes[0] == G
+  if n_motion:
+    assert sizes[-1] == n_motion and sizes.count(n_motion) == (1 if n_motion not in (G, S, M2, M4, 4) else sizes.count(n_motion))
+    body = sizes[:-1]
+  else:
+    body = sizes
+  assert set(body) <= {G, S, M2, M4, 4}, sizes                   # nothing else, i.e. nothing that scales with F
+  at = [i for i, v in enumerate(body) if v == S]
   assert len(at) >= 1
   for i in at:
-    assert sizes[i - 1] == 1                                   # curvature scalar right before the Schur system
-    k = i + 1
-    if n_motion:
-      assert sizes[k] == n_motion
-      k += 1
-    assert sizes[k] == G, sizes                                # speculative linearisation: carries the trial cost
-  extra_cost_msgs = sum(1 for i, v in enumerate(sizes) if v == 1 and (i + 1 >= len(sizes) or sizes[i + 1] != S))
-  assert extra_cost_msgs == res.nfev - 1 - len(at)             # one 1-double message per RETRY only
-  assert sizes.count(G) >= int(sh["njev"])                     # (+ one per re-linearisation after a rejected step)
+    assert body[i - 1] == M2                                   # norms + curvature right before the Schur system
+    assert body[i + 1] == M4                                   # dots right behind the back substitution
+    assert body[i + 2] == G, sizes                             # speculative linearisation: trial cost + step norms ride along
+  retries = sum(1 for v in body if v == 4) if 4 not in (M2, M4) else None
+  if retries is not None:
+    assert retries == res.nfev - 1 - len(at)                   # one 4-double message per RETRY only
+  assert body.count(G) >= int(sh["njev"])                      # (+ one per re-linearisation after a rejected step)
 
 
 def _rccl_single_rank_worker(rank, out_path):

@@ -503,15 +503,15 @@ def test_adjust_board_rolling_and_handeye_blocks():
       assert np.abs(fd - J[:, j]).max() <= 1e-5 * max(np.abs(J[:, j]).max(), 1.0), (name, j)
 
 
-@pytest.mark.parametrize("ns,blocked", [(5, 0), (16, 0), (18, 0), (31, 0), (32, 0), (40, 0), (40, 1), (40, 2), (40, 3), (140, 0), (140, 3),
-                                        (159, 0), (160, 0), (190, 0), (40, 5), (144, 5), (160, 5), (286, 0), (286, 3), (700, 0), (1022, 5), (1023, 1), (200, 0), (200, 1), (200, 2),
-                                        (333, 1), (700, 0), (1500, 1),
+@pytest.mark.parametrize("ns,blocked", [(5, 0), (16, 0), (18, 0), (31, 0), (32, 0), (40, 0), (40, 1), (140, 0),
+                                        (159, 0), (160, 0), (190, 0), (286, 0), (700, 0), (1023, 1), (200, 0), (200, 1),
+                                        (333, 1), (1500, 1),
                                         # 6: the multi-launch panel kernels k_cholp_* (automatic for 160 < ns + 1 <= 1024)
                                         (5, 6), (16, 6), (17, 6), (47, 6), (48, 6), (49, 6), (140, 6), (286, 6), (288, 6),
-                                        (400, 6), (1023, 6), (286, 5), (1023, 0)])
+                                        (400, 6), (1023, 6), (1023, 0)])
 def test_device_cholesky_paths(ns, blocked):
-  """LDS-resident (0, small ns), single-workgroup panel (2), multi-workgroup MFMA (1), matrix-in-L2 (5) and multi-launch
-  panel (6) Cholesky solves vs numpy."""
+  """The three Cholesky paths of the reduced system vs numpy: LDS-resident tiles (0, ns + 1 <= 160), multi-launch panel
+  kernels (6; automatic up to ns + 1 = 1024), multi-workgroup kernels (1; automatic beyond)."""
   rng = np.random.default_rng(ns)
   M = rng.normal(size=(ns + 20, ns))
   S = M.T @ M / ns + 0.1 * np.eye(ns)
@@ -570,7 +570,7 @@ def test_handle_cache_sees_a_changed_validity_mask_and_float32_tables():
     assert np.abs(cm.residuals() - ocm.evaluate(cm.param_vec)).max() < 1e-9
 
 
-@pytest.mark.parametrize("switch", ["MCBA_FUSED=0", "MCBA_FUSED=1", "MCBA_ASM_STAGE_KB=4", "MCBA_FUSED=0,MCBA_TMAT_GLOBAL=1",
+@pytest.mark.parametrize("switch", ["MCBA_FUSED=0", "MCBA_ASM_STAGE_KB=4", "MCBA_FUSED=0,MCBA_TMAT_GLOBAL=1",
                                     "MCBA_NCHUNK_TARGET=1024", "MCBA_SHARED_FINAL_BIG=1", "MCBA_SYRK3=1", "MCBA_SPLIT_Q00=1", "MCBA_SPEC_ACCEPT=0", "MCBA_SPEC_ACCEPT=0,MCBA_NO_PUBLISH=1"])
 def test_alternative_linearisation_paths_match_the_default(switch):
   """Paths of the evaluation that the fixtures do not reach by themselves, each forced with its switch in a subprocess
@@ -579,7 +579,6 @@ def test_alternative_linearisation_paths_match_the_default(switch):
     (default)                 table-fed fused form: pose entries from the pose table (k_prep / k_vec_step), chains and That
                               in k_linearize (no k_tmat, no That table)
     MCBA_FUSED=0              table form: k_tmat writes That and the chain matrices of every view, k_linearize reads them
-    MCBA_FUSED=1              k_linearize forms That / the chain matrices / the intrinsics straight from x (no table kernel)
     MCBA_SHARED_FINAL_BIG=1   the final sum of the shared part for rigs with more than 128 (camera, board) pairs
     MCBA_ASM_STAGE_KB=4       frame blocks of k_assemble stage their records in several groups (rigs with many views per frame)
     MCBA_TMAT_GLOBAL=1        k_tmat reads the global pose table (rigs whose cameras + boards exceed the local table)
