@@ -19,9 +19,9 @@
  *   - limits of this implementation (the reference has none; all are checked by `mcba_create`, which fails with a
  *     message instead of producing a handle that cannot be solved):
  *     at most 65535 points per board; about 36 000 (camera, board) pairs when per-frame rig poses are optimised (their
- *     view-rank tables live in the 150 KB of LDS of a workgroup); one projection FAMILY per rig (pinhole cameras may carry different numbers of
- *     distortion coefficients -- 4, 5, 8, 12, 14: mcba_problem.camera_n_dist -- but pinhole and fisheye cameras cannot
- *     share a rig).
+ *     view-rank tables live in the 150 KB of LDS of a workgroup).  Cameras of one rig may carry different numbers of
+ *     distortion coefficients (4, 5, 8, 12, 14: mcba_problem.camera_n_dist) and may mix pinhole and fisheye cameras
+ *     (mcba_problem.camera_fisheye).
  *
  * Parameter vector `x` (length `n_params`): exactly `Calibration.param_vec` (optimization/parameters.py:44-46):
  * the ENABLED blocks, in the order camera_poses | board_poses | motion | cameras | boards
@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define MCBA_VERSION 2
+#define MCBA_VERSION 3
 
 /* motion models (multical/motion/) */
 #define MCBA_MOTION_STATIC   0   /* motion/static_frames.py  */
@@ -108,6 +108,9 @@ typedef struct mcba_problem {
                                 /* block of x / x_full is ragged: camera c contributes 5 + camera_n_dist[c]        */
                                 /* entries.  n_dist must then be the maximum; pinhole sizes (4, 5, 8, 12, 14) mix  */
                                 /* freely (a smaller model is the larger one with its extra coefficients at zero). */
+  const uint8_t* camera_fisheye;/* [C] 1 = CameraFisheye (camera_fisheye.py:28), 0 = Camera, or NULL: every camera is of  */
+                                /* `camera_model`.  A rig may MIX the two families (the reference holds independent     */
+                                /* objects, parameters.py:54-85); camera_n_dist is then required unless all carry 4.    */
 } mcba_problem;
 
 typedef struct mcba_options {          /* scipy.optimize.least_squares arguments used at calibration.py:209-210 */
@@ -132,6 +135,16 @@ typedef struct mcba_result {           /* scipy OptimizeResult fields the caller
   double solve_seconds;         /* wall time inside mcba_solve                                          */
   double linearize_seconds;     /* GPU time (HIP events) spent in the fused linearisation kernels       */
 } mcba_result;
+
+typedef struct mcba_round_report {     /* one pass of Calibration.adjust_outliers (calibration.py:254-268)             */
+  double rms_all, rms_inliers;  /* report(): RMS over all valid points / over the inliers                           */
+  int64_t n_all, n_inliers;
+  double quantiles[5];          /* numpy.quantile(errors over all valid points, [0, .25, .5, .75, 1])               */
+  double f_scale;               /* f_scale of this round's solve (auto_scale: quantile x factor)                    */
+  double threshold;             /* rejection threshold of this round (quantile x factor), -1 = none                 */
+  int64_t n_kept, n_valid;      /* reject_outliers: inliers kept / valid points                                      */
+  mcba_result solve;            /* bundle_adjust of this round                                                       */
+} mcba_round_report;
 
 typedef struct mcba_handle_s* mcba_handle;
 
@@ -188,6 +201,14 @@ int32_t mcba_set_shard_root(mcba_handle h, int32_t is_root);
  * of frames (mcba_allreduce_stats).                                                                                  */
 int32_t mcba_set_shard_rank(mcba_handle h, int32_t rank, int32_t world);
 int32_t mcba_set_log(mcba_handle h, mcba_log_fn fn, void* ctx);
+
+/* Calibration.adjust_outliers (calibration.py:254-268; what Workspace.calibrate drives, workspace.py:238-244) in ONE call:
+ * `num_adjustments` rounds of {report, optional f_scale = quantile(errors, scale_quantile) * scale_factor, reject_outliers at
+ * quantile(errors, outlier_quantile) * outlier_factor, bundle_adjust}, then the final report.  rounds[num_adjustments + 1];
+ * a negative factor disables that step; inliers_out (may be NULL) receives the final mask [C,F,B,P].                  */
+int32_t mcba_adjust_outliers(mcba_handle h, double* x_inout, const mcba_options* opt, int32_t num_adjustments,
+                             double outlier_quantile, double outlier_factor, double scale_quantile, double scale_factor,
+                             mcba_round_report* rounds, uint8_t* inliers_out);
 
 /* --- evaluation -------------------------------------------------------------------------------------------- */
 /* r = evaluate(x)                                                   (calibration.py:204-206)                   */

@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MCBA_LIB_PATH") or os.path.join(HERE, "_build", "libmcba.so")   # (override: kernel experiments)
 
-MCBA_VERSION = 2
+MCBA_VERSION = 3
 MOTION_STATIC, MOTION_ROLLING, MOTION_HAND_EYE = 0, 1, 2
 CAMERA_PINHOLE, CAMERA_FISHEYE = 0, 1
 LOSSES = dict(linear=0, soft_l1=1, huber=2, cauchy=3, arctan=4)
@@ -32,6 +32,7 @@ class Problem(C.Structure):
     ("optimize", C.c_uint32), ("x_full", c_double_p),
     ("frame_begin", C.c_int32), ("frame_end", C.c_int32),
     ("camera_n_dist", c_int32_p),
+    ("camera_fisheye", c_uint8_p),
   ]
 
 
@@ -44,6 +45,12 @@ class Result(C.Structure):
   _fields_ = [("cost", C.c_double), ("initial_cost", C.c_double), ("optimality", C.c_double), ("nfev", C.c_int32),
               ("njev", C.c_int32), ("status", C.c_int32), ("iterations", C.c_int32), ("solve_seconds", C.c_double),
               ("linearize_seconds", C.c_double)]
+
+
+class RoundReport(C.Structure):   # mcba_round_report
+  _fields_ = [("rms_all", C.c_double), ("rms_inliers", C.c_double), ("n_all", C.c_int64), ("n_inliers", C.c_int64),
+              ("quantiles", C.c_double * 5), ("f_scale", C.c_double), ("threshold", C.c_double), ("n_kept", C.c_int64),
+              ("n_valid", C.c_int64), ("solve", Result)]
 
 
 LOG_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double)
@@ -79,6 +86,8 @@ SYMBOLS = [
   ("mcba_error_count", C.c_int32, [H, C.c_int32, C.POINTER(C.c_int64)]),
   ("mcba_reject_outliers", C.c_int32, [H, c_double_p, C.c_double, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
   ("mcba_get_inliers", C.c_int32, [H, c_uint8_p]),
+  ("mcba_adjust_outliers", C.c_int32, [H, c_double_p, C.POINTER(Options), C.c_int32, C.c_double, C.c_double, C.c_double,
+                                       C.c_double, C.POINTER(RoundReport), c_uint8_p]),
   ("mcba_normal_equations", C.c_int32, [H, c_double_p, C.POINTER(Options), c_double_p, c_double_p, c_double_p]),
   ("mcba_normal_equations_device", C.c_int32, [H, C.POINTER(Options)]),
   ("mcba_synchronize", C.c_int32, [H]),
@@ -116,9 +125,9 @@ def load():
     try:
       fn = getattr(lib, name)
     except AttributeError:
-      # only a side-by-side build loaded through MCBA_LIB_PATH (A/B measurements against an older library) may lack a
-      # debug hook; the product library must export everything
-      if os.environ.get("MCBA_LIB_PATH") and name.startswith("mcba_debug_"):
+      # only a side-by-side build loaded through MCBA_LIB_PATH (A/B measurements against an older library) may lack an
+      # entry point; the product library must export everything
+      if os.environ.get("MCBA_LIB_PATH"):
         continue
       raise
     fn.restype = restype

@@ -13,7 +13,7 @@ from types import SimpleNamespace
 import numpy as np
 
 from . import _lib
-from ._lib import (Problem, Options, Result, LOSSES, OPT_BITS, PARAM_ORDER, MOTION_STATIC, MOTION_ROLLING,
+from ._lib import (Problem, Options, Result, RoundReport, LOSSES, OPT_BITS, PARAM_ORDER, MOTION_STATIC, MOTION_ROLLING,
                    MOTION_HAND_EYE, CAMERA_PINHOLE, CAMERA_FISHEYE, check)
 
 
@@ -75,12 +75,13 @@ def lower(calib):
 
   cams = list(calib.cameras)
   fisheye = [_class_name(c) == "CameraFisheye" or getattr(c, "model", None) == "fisheye" for c in cams]
-  if any(fisheye) != all(fisheye):
-    raise ValueError("mixed pinhole / fisheye cameras are not supported")
   p.camera_model = CAMERA_FISHEYE if all(fisheye) else CAMERA_PINHOLE
-  # every Camera is an independent object (optimization/parameters.py:54-85): the distortion size may differ from camera
-  # to camera (models `standard` / `rational` / `thin_prism` / `tilted`, or a 4-coefficient file); the library pads to the
-  # largest and freezes the coefficients a camera does not have
+  # every Camera is an independent object (optimization/parameters.py:54-85): the projection family (Camera / CameraFisheye)
+  # and the distortion size (models `standard` / `rational` / `thin_prism` / `tilted`, or a 4-coefficient file) may differ
+  # from camera to camera; the library pads to the largest block and freezes the coefficients a camera does not have
+  p.camera_fisheye = None
+  if any(fisheye) != all(fisheye):
+    p.camera_fisheye = np.ascontiguousarray(np.array(fisheye, dtype=np.uint8))
   nds = [int(np.asarray(c.dist).size) for c in cams]
   p.n_dist = max(nds)
   p.camera_n_dist = None
@@ -122,6 +123,7 @@ def _to_struct(p, frame_range=None):
   s.x_full = _ptr(p.x_full, C.c_double)
   s.frame_begin, s.frame_end = (-1, -1) if frame_range is None else frame_range
   s.camera_n_dist = None if getattr(p, "camera_n_dist", None) is None else _ptr(p.camera_n_dist, C.c_int32)
+  s.camera_fisheye = None if getattr(p, "camera_fisheye", None) is None else _ptr(p.camera_fisheye, C.c_uint8)
   return s
 
 
@@ -357,6 +359,32 @@ class Handle(object):
     ni, nvv = C.c_int64(), C.c_int64()
     check(self.lib.mcba_reject_outliers(self.h, _ptr(x, C.c_double), float(threshold), C.byref(ni), C.byref(nvv)))
     return ni.value, nvv.value
+
+  def adjust_outliers(self, x0, num_adjustments=3, outlier=None, scale=None, tolerance=1e-4, f_scale=1.0, max_iterations=100,
+                      loss='linear', xtol=1e-8, gtol=1e-8):
+    """Calibration.adjust_outliers (calibration.py:254-268) in ONE library call (mcba_adjust_outliers): `num_adjustments` rounds of
+    {report, f_scale from `scale` = (quantile, factor) or None, rejection at `outlier` = (quantile, factor) or None, solve} and
+    the final report.  Returns (x, rounds, inlier mask); rounds[i] = namespace(rms, rms_inliers, n, n_inliers, quantiles,
+    f_scale, threshold, n_kept, n_valid, solve result); the last entry is the final report (no solve)."""
+    x = self._x(x0).copy()
+    self._jac_pattern = None
+    opt = make_options(tolerance, f_scale, max_iterations, loss, xtol, gtol, 2)
+    rounds = (RoundReport * (num_adjustments + 1))()
+    mask = np.empty(self.shape, dtype=np.bool_)
+    oq, of = outlier if outlier is not None else (0.0, -1.0)
+    sq, sf = scale if scale is not None else (0.0, -1.0)
+    check(self.lib.mcba_adjust_outliers(self.h, _ptr(x, C.c_double), C.byref(opt), int(num_adjustments), float(oq), float(of),
+                                        float(sq), float(sf), rounds, _ptr(mask.view(np.uint8), C.c_uint8)))
+    out = []
+    for i, r in enumerate(rounds):
+      res = r.solve
+      solve = None if i == num_adjustments else SimpleNamespace(
+        cost=res.cost, initial_cost=res.initial_cost, optimality=res.optimality, nfev=res.nfev, njev=res.njev, status=res.status,
+        iterations=res.iterations, message=STATUS_MESSAGES.get(res.status, ""), solve_seconds=res.solve_seconds)
+      out.append(SimpleNamespace(rms=r.rms_all, rms_inliers=r.rms_inliers, n=int(r.n_all), n_inliers=int(r.n_inliers),
+                                 quantiles=np.array(list(r.quantiles)), f_scale=r.f_scale, threshold=r.threshold,
+                                 n_kept=int(r.n_kept), n_valid=int(r.n_valid), solve=solve))
+    return x, out, mask
 
   def get_inliers(self):
     m = np.empty(self.shape, dtype=np.bool_)      # the device writes 0 / 1 bytes: a bool array without a second copy

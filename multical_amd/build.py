@@ -21,7 +21,7 @@ OUT = os.path.join(HERE, "_build" + ("_" + VARIANT if VARIANT else ""))
 LIB = os.path.join(OUT, "libmcba.so")
 ARCH = "gfx950"
 SOURCES = ["mcba_api.hip", "mcba_cam_pin4.hip", "mcba_cam_pin5.hip", "mcba_cam_pin8.hip", "mcba_cam_pin12.hip",
-           "mcba_cam_pin14.hip", "mcba_cam_fish4.hip"]
+           "mcba_cam_pin14.hip", "mcba_cam_fish4.hip", "mcba_cam_mix14.hip"]
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "mcba.h")]
 FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-Wall", "-Wno-unused-function"] + \
         os.environ.get("MCBA_EXTRA_FLAGS", "").split()

@@ -70,6 +70,12 @@ def get_solver():
   return _default_solver[0]
 
 
+def fused_outlier_loop_off():
+  """MULTICAL_AMD_FUSED_LOOP=0: adjust_outliers as a Python loop over report / reject_outliers / bundle_adjust on new Calibration
+  objects (the reference's structure, step by step) instead of one mcba_adjust_outliers call."""
+  return os.environ.get("MULTICAL_AMD_FUSED_LOOP", "1") == "0"
+
+
 default_optimize = struct(cameras=False, boards=False, camera_poses=True, board_poses=True, motion=True)
 
 
@@ -119,7 +125,8 @@ class _HandleCache(object):
       except AttributeError:
         pass
     key = (prob.shape, prob.optimize, prob.motion, prob.camera_model, prob.n_dist,
-           None if prob.camera_n_dist is None else prob.camera_n_dist.tobytes(), prob.fix_aspect.tobytes(),
+           None if prob.camera_n_dist is None else prob.camera_n_dist.tobytes(),
+           None if prob.camera_fisheye is None else prob.camera_fisheye.tobytes(), prob.fix_aspect.tobytes(),
            prob.camera_valid.tobytes(), prob.frame_valid.tobytes(), prob.board_valid.tobytes(),
            prob.board_sizes.tobytes(), prob.image_heights.tobytes())
     points, valid = calib.point_table.points, calib.point_table.valid
@@ -343,6 +350,12 @@ class Calibration(parameters.Parameters):
     """selector(self.reprojection_error); tagged select_threshold closures are evaluated on the device
     (exact numpy 'linear' quantile from radix-selected order statistics), anything else gets the error array."""
     if hasattr(selector, "quantile") and hasattr(selector, "factor"):
+      # report() has usually just selected this very quantile (0.75 is one of its five): same object, same errors
+      stats = self.__dict__.get("_overall_stats")
+      if stats is not None:
+        hit = [v for qq, v in zip(stats[0], stats[1].quantiles) if qq == selector.quantile]
+        if hit:
+          return float(hit[0]) * selector.factor
       _, _, q, _ = self._handle().error_stats(self.param_vec, quantiles=[selector.quantile])
       return float(q[0]) * selector.factor
     return selector(self.reprojection_error)
@@ -360,8 +373,72 @@ class Calibration(parameters.Parameters):
     handle_cache.note_inliers(h, inliers)
     return out
 
+  def _adjust_outliers_in_one_call(self, num_adjustments, select_scale, select_outliers, kwargs):
+    """The whole loop inside the library (mcba_adjust_outliers): no Calibration objects, no re-lowering and no rotation-vector <->
+    matrix round trips between the rounds.  The log lines are the reference's, emitted afterwards in the reference's order."""
+    h = self._handle()
+    rows = []
+
+    def log_row(it, nfev, cost, red, step, opt):
+      red_s = " " * 15 if np.isnan(red) else f"{red:^15.2e}"
+      step_s = " " * 15 if np.isnan(step) else f"{step:^15.2e}"
+      rows.append((it, f"{it:^15}{nfev:^15}{cost:^15.4e}{red_s}{step_s}{opt:^15.2e}"))
+
+    h.set_log(log_row)
+    try:
+      x, rounds, mask = h.adjust_outliers(
+        self.param_vec, num_adjustments,
+        outlier=None if select_outliers is None else (select_outliers.quantile, select_outliers.factor),
+        scale=None if select_scale is None else (select_scale.quantile, select_scale.factor), **kwargs)
+    finally:
+      h.set_log(None)
+    tables, cur = [], None                      # the iteration rows of every solve (a solve starts with iteration 0)
+    for it, line in rows:
+      if it == 0:
+        cur = []
+        tables.append(cur)
+      cur.append(line)
+    has_mask = self.inlier_mask is not None
+
+    def report_line(stage, r, with_inliers):
+      n_all = max(r.n, 1)                       # (the reference substitutes a single zero for an empty error set)
+      if with_inliers:
+        info(f"{stage} reprojection RMS={r.rms_inliers:.3f} ({r.rms:.3f}), n={r.n_inliers} ({n_all}), quantiles={r.quantiles}")
+      else:
+        info(f"{stage} reprojection RMS={r.rms:.3f}, n={n_all}, quantiles={r.quantiles}")
+
+    for i, r in enumerate(rounds[:-1]):
+      report_line(f"Adjust_outliers {i}:", r, has_mask)
+      if select_scale is not None:
+        info(f"Auto scaling for outliers influence at {r.f_scale:.2f} pixels")
+      if select_outliers is not None:
+        num_outliers = r.n_valid - r.n_kept
+        info(f"Rejecting {num_outliers} outliers with error > {r.threshold:.2f} pixels, "
+             f"keeping {r.n_kept} / {r.n_valid} inliers, ({100.0 * r.n_kept / max(r.n_valid, 1):.2f}%)")
+        has_mask = True
+      info("{:^15}{:^15}{:^15}{:^15}{:^15}{:^15}".format("Iteration", "Total nfev", "Cost", "Cost reduction", "Step norm",
+                                                         "Optimality"))
+      for line in (tables[i] if i < len(tables) else []):
+        info(line)
+      info(r.solve.message)
+      info(f"Function evaluations {r.solve.nfev}, initial cost {r.solve.initial_cost:.4e}, final cost {r.solve.cost:.4e}, "
+           f"first-order optimality {r.solve.optimality:.2e}.")
+    report_line("Adjust_outliers end:", rounds[-1], has_mask)
+    out = self.with_param_vec(x)
+    if select_outliers is not None and num_adjustments > 0:
+      out = out.copy(inlier_mask=mask)
+      handle_cache.note_inliers(h, mask)
+    final = rounds[-1]
+    out.__dict__["_overall_stats"] = ((0.0, 0.25, 0.5, 0.75, 1.0),
+                                      struct(mse=final.rms ** 2, rms=final.rms, quantiles=final.quantiles, n=max(final.n, 1)))
+    return out
+
   def adjust_outliers(self, num_adjustments=3, select_scale=None, select_outliers=None, **kwargs):
     info(f"Beginning adjustments ({num_adjustments}) enabled: {dict(self.optimize)}, options: {kwargs}")
+    tagged = lambda f: f is None or (hasattr(f, "quantile") and hasattr(f, "factor"))
+    if (get_solver() == "native" and tagged(select_scale) and tagged(select_outliers) and not fused_outlier_loop_off()
+        and set(kwargs) <= {"loss", "tolerance", "f_scale", "max_iterations", "xtol", "gtol"}):
+      return self._adjust_outliers_in_one_call(num_adjustments, select_scale, select_outliers, kwargs)
     for i in range(num_adjustments):
       self.report(f"Adjust_outliers {i}:")
       f_scale = (None if select_scale is None else self._select(select_scale)) or 1.0
@@ -374,9 +451,18 @@ class Calibration(parameters.Parameters):
     return self
 
   def error_statistics(self, inliers_only=False, quantiles=(0, 0.25, 0.5, 0.75, 1)):
-    """error_stats(self.reprojection_error / reprojection_inliers) without downloading the error table."""
+    """error_stats(self.reprojection_error / reprojection_inliers) without downloading the error table.  (A Calibration is
+    immutable: the statistics over all valid points are kept on the object, like the reference's cached properties.)"""
+    key = tuple(float(q) for q in quantiles)
+    if not inliers_only:
+      kept = self.__dict__.get("_overall_stats")
+      if kept is not None and kept[0] == key:
+        return kept[1]
     mse, rms, q, n = self._handle().error_stats(self.param_vec, quantiles=quantiles, inliers_only=inliers_only)
-    return struct(mse=mse, rms=rms, quantiles=q, n=n)
+    out = struct(mse=mse, rms=rms, quantiles=q, n=n)
+    if not inliers_only:
+      self.__dict__["_overall_stats"] = (key, out)
+    return out
 
   def report(self, stage=""):
     overall = self.error_statistics(False)

@@ -365,7 +365,8 @@ struct mcba_handle_s {
 
 namespace {
 
-const CamOps* pick_ops(int model, int nd) {
+const CamOps* pick_ops(int model, int nd) {   // model: Dims.fisheye (0 pinhole, 1 fisheye, 2 mixed)
+  if (model == 2) return cam_ops_mix14();
   if (model == MCBA_CAMERA_FISHEYE) {
     REQUIRE(nd == 4, "fisheye cameras carry 4 distortion coefficients (camera_fisheye.py:113-117)");
     return cam_ops_fish4();
@@ -1032,13 +1033,13 @@ int32_t mcba_create(const mcba_problem* p, void* hip_stream, mcba_handle* out) {
     h->own_stream = true;
   }
   if (const char* env = getenv("MCBA_NO_MFMA")) h->use_mfma = !(env[0] == '1');
-  h->ops = pick_ops(p->camera_model, p->n_dist);
 
   const bool timing = getenv("MCBA_TIMING") != nullptr;
   const double tc0 = now_seconds();
   g_fill_stream = h->stream;      // buffers are zero-filled on the handle's stream (no synchronisation per buffer)
   HostProblem hp;
   lower_dims(p, hp);              // shape, index maps, small parameter tables; the slot tables are built on the device
+  h->ops = pick_ops(hp.d.fisheye, hp.d.ND);   // (a rig that mixes the projection families runs the per-camera instantiation)
   const double tc1 = now_seconds();
   h->d = hp.d;
   Dims& d = h->d;
@@ -1967,6 +1968,8 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
   // (blocks of the curvature sums: every k_schur_frame workgroup folds their partials -- MCBA_Q00_BLOCKS for experiments)
   static const int q00_blocks = getenv("MCBA_Q00_BLOCKS") ? std::max(1, std::min(Q00_BLOCKS, atoi(getenv("MCBA_Q00_BLOCKS")))) : Q00_BLOCKS;
   static const bool spec_accept_off = getenv("MCBA_SPEC_ACCEPT") != nullptr && getenv("MCBA_SPEC_ACCEPT")[0] == '0';
+  // (k_fold_tr behind the speculative scaling: measured neutral against letting every k_schur_frame workgroup fold the
+  //  72 + 512 partials itself -- 135.3 vs 136.1 us per trial step at the north-star rig, round 4 -- kept)
   bool scaled_ahead = false;     // the scaling / curvature of h->x are already in place (computed speculatively, swapped in)
   int trial_cost_values = cost_fetch;
   double cost = 0, Delta = 0, step_norm = NaN, actual_reduction = NaN, g_norm = 0, initial_cost = 0;
@@ -2241,6 +2244,101 @@ int32_t mcba_error_stats(mcba_handle h, const double* x, int32_t inliers_only, i
   *sum_sq = h->h_scal[0];                     // (select_ranks_multi synchronised the stream)
   REQUIRE(!count_known || n_ranks == 0 || (int64_t)h->h_scal[1] == n, "inlier count out of sync with the device table");
   *n_out = n;
+  API_END
+}
+
+namespace {
+// numpy.quantile(errors, q) (default method 'linear') from exact order statistics: virtual index (n - 1) q, its floor / ceil
+// ranks by radix select on the device, numpy's _lerp on the host (numpy/lib/_function_base_impl.py)
+struct ErrorStats { int64_t n = 0; double sum_sq = 0.0; std::vector<double> quantiles; };
+int32_t error_stats_with_quantiles(mcba_handle h, const double* x, int inliers_only, const std::vector<double>& q, ErrorStats& out) {
+  out.quantiles.assign(q.size(), 0.0);
+  int64_t n = 0;
+  if (int32_t rc = mcba_error_count(h, inliers_only, &n)) return rc;
+  double ssq = 0.0;
+  if (n < 0 || q.empty()) {
+    if (int32_t rc = mcba_error_stats(h, x, inliers_only, 0, nullptr, nullptr, &n, &ssq)) return rc;
+  }
+  out.n = n;
+  out.sum_sq = ssq;
+  if (n == 0 || q.empty()) return 0;
+  std::vector<int64_t> ranks(2 * q.size());
+  std::vector<double> gamma(q.size()), vals(2 * q.size());
+  for (size_t i = 0; i < q.size(); ++i) {
+    const double virt = (double)(n - 1) * q[i], fl = std::floor(virt);
+    const int64_t lo = std::min<int64_t>(std::max<int64_t>((int64_t)fl, 0), n - 1);
+    ranks[2 * i] = lo;
+    ranks[2 * i + 1] = std::min<int64_t>((int64_t)fl + 1, n - 1);
+    gamma[i] = virt - fl;
+  }
+  if (int32_t rc = mcba_error_stats(h, x, inliers_only, (int32_t)ranks.size(), ranks.data(), vals.data(), &n, &ssq)) return rc;
+  out.sum_sq = ssq;
+  for (size_t i = 0; i < q.size(); ++i) {
+    const double a = vals[2 * i], b = vals[2 * i + 1], diff = b - a;
+    out.quantiles[i] = gamma[i] >= 0.5 ? b - diff * (1.0 - gamma[i]) : a + diff * gamma[i];
+  }
+  return 0;
+}
+}  // namespace
+
+/* Calibration.adjust_outliers (calibration.py:254-268) as ONE call: num_adjustments rounds of {report, optional f_scale from
+ * a quantile of the errors, reject_outliers(quantile x factor), bundle_adjust}, then the final report -- the loop
+ * Workspace.calibrate drives (workspace.py:238-244), without leaving the library between its steps: no Calibration objects,
+ * no re-lowering and no rotation-vector <-> matrix round trips between the rounds (x continues with the solver's raw
+ * rotation vectors; the reference canonicalises them in with_param_vec, which changes no projection).
+ * rounds[i] (i <= num_adjustments) receives the report in front of round i (i = num_adjustments: the final report) and, for
+ * i < num_adjustments, the threshold / f_scale / solve result of that round.  outlier_factor < 0: no rejection;
+ * scale_factor < 0: f_scale = opt->f_scale.  inliers_out (may be NULL): the final inlier mask in [C,F,B,P] order.       */
+int32_t mcba_adjust_outliers(mcba_handle h, double* x_inout, const mcba_options* opt, int32_t num_adjustments,
+                             double outlier_quantile, double outlier_factor, double scale_quantile, double scale_factor,
+                             mcba_round_report* rounds, uint8_t* inliers_out) {
+  API_BEGIN
+  REQUIRE(h && x_inout && opt && rounds && num_adjustments >= 0, "bad argument");
+  const std::vector<double> five = {0.0, 0.25, 0.5, 0.75, 1.0};
+  auto report = [&](mcba_round_report& r) -> int32_t {
+    ErrorStats all, inl;
+    if (int32_t rc = error_stats_with_quantiles(h, x_inout, 0, five, all)) return rc;
+    if (int32_t rc = error_stats_with_quantiles(h, x_inout, 1, {}, inl)) return rc;
+    r.n_all = all.n; r.n_inliers = inl.n;
+    r.rms_all = all.n > 0 ? std::sqrt(all.sum_sq / (double)all.n) : 0.0;
+    r.rms_inliers = inl.n > 0 ? std::sqrt(inl.sum_sq / (double)inl.n) : 0.0;
+    for (int k = 0; k < 5; ++k) r.quantiles[k] = all.n > 0 ? all.quantiles[k] : 0.0;
+    return 0;
+  };
+  auto quantile_of_all = [&](double q, const mcba_round_report& r, double* out) -> int32_t {
+    for (int k = 0; k < 5; ++k)
+      if (five[k] == q) { *out = r.quantiles[k]; return 0; }     // (the report has just selected it)
+    ErrorStats st;
+    if (int32_t rc = error_stats_with_quantiles(h, x_inout, 0, {q}, st)) return rc;
+    *out = st.n > 0 ? st.quantiles[0] : 0.0;
+    return 0;
+  };
+  for (int i = 0; i < num_adjustments; ++i) {
+    mcba_round_report& r = rounds[i];
+    memset(&r, 0, sizeof(r));
+    if (int32_t rc = report(r)) return rc;
+    mcba_options o = *opt;
+    r.f_scale = opt->f_scale;
+    if (scale_factor >= 0.0) {
+      double qv = 0.0;
+      if (int32_t rc = quantile_of_all(scale_quantile, r, &qv)) return rc;
+      r.f_scale = qv * scale_factor != 0.0 ? qv * scale_factor : 1.0;    // `... or 1.0` (calibration.py:259)
+      o.f_scale = r.f_scale;
+    }
+    r.threshold = -1.0;
+    if (outlier_factor >= 0.0) {
+      double qv = 0.0;
+      if (int32_t rc = quantile_of_all(outlier_quantile, r, &qv)) return rc;
+      r.threshold = qv * outlier_factor;
+      if (int32_t rc = mcba_reject_outliers(h, x_inout, r.threshold, &r.n_kept, &r.n_valid)) return rc;
+    }
+    if (int32_t rc = mcba_solve(h, x_inout, &o, &r.solve)) return rc;
+  }
+  memset(&rounds[num_adjustments], 0, sizeof(mcba_round_report));
+  if (int32_t rc = report(rounds[num_adjustments])) return rc;
+  if (inliers_out) {
+    if (int32_t rc = mcba_get_inliers(h, inliers_out)) return rc;
+  }
   API_END
 }
 

@@ -7,7 +7,7 @@ namespace mcba {
 namespace {
 
 constexpr int ND_ = MCBA_ND;
-constexpr bool FISH_ = MCBA_FISH;
+constexpr int FISH_ = MCBA_FISH;   // 0 pinhole, 1 fisheye, 2 per camera (mixed rig)
 
 inline int slot_grid(const Dims& d) {
   const int n = d.slots();

@@ -28,5 +28,6 @@ const CamOps* cam_ops_pin8();
 const CamOps* cam_ops_pin12();
 const CamOps* cam_ops_pin14();
 const CamOps* cam_ops_fish4();
+const CamOps* cam_ops_mix14();   // pinhole and fisheye cameras in one rig (family per camera, 14-wide coefficient blocks)
 
 }  // namespace mcba

@@ -137,7 +137,7 @@ constexpr int LIN_MAX_POINTS = 512;
 //             gathered a 4-byte obs_index per slot and scattered 8-byte stores: 36 % of the HBM peak).
 //             Algorithmic traffic: 17 B per slot read + 16 B per observation written.
 // ---------------------------------------------------------------------------------------------------------------
-template <int ND, bool FISH, bool ROLL>
+template <int ND, int FISH, bool ROLL>
 __global__ __launch_bounds__(256) void k_residual(Dims d, Tables t, const int32_t* __restrict__ first,
                                                   double* __restrict__ r, double* __restrict__ proj,
                                                   double* __restrict__ err, uint8_t* __restrict__ valid) {
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void k_residual(Dims d, Tables t, const int32_
 // `iterations` fixed-point passes with the scan time taken from the projected row of the previous pass; the other motion
 // models project once.  Output in the reference's [C,F,B,P,2] order (host-facing: GUI / reprojection tables).
 // ---------------------------------------------------------------------------------------------------------------
-template <int ND, bool FISH, bool ROLL>
+template <int ND, int FISH, bool ROLL>
 __global__ void k_project_model(Dims d, Tables t, int iterations, double* __restrict__ proj) {
   const int n = d.slots();
   for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
@@ -357,7 +357,7 @@ __device__ __forceinline__ void view_chain_wave(const Dims& d, const Tables& t, 
 
 // ROBUST = false: the linear loss compiled in (the loss switch pulls log1p / atan into the kernel: 182 VGPRs = 2 waves per
 // SIMD, i.e. two rounds of workgroups at the north-star rig)
-template <int ND, bool FISH, bool ROLL, bool ROBUST>
+template <int ND, int FISH, bool ROLL, bool ROBUST>
 __global__ __launch_bounds__(64) void k_cost(Dims d, Tables t, double* __restrict__ partial) {
   __shared__ uint16_t pidx[LIN_MAX_POINTS];
   __shared__ double Vc[2 * VIEW_STRIDE], Vtmp[24];   // chain matrices of the view, intermediate products
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(64) void k_cost(Dims d, Tables t, double* __restric
 // k_jacobian: analytic Jacobian rows in the column order of Calibration.sparsity_matrix
 //             (optimization/calibration.py:173-196).  One thread per inlier observation (not a hot path).
 // ---------------------------------------------------------------------------------------------------------------
-template <int ND, bool FISH, bool ROLL>
+template <int ND, int FISH, bool ROLL>
 __global__ void k_jacobian(Dims d, Tables t, int row_nnz, double* __restrict__ vals, int32_t* __restrict__ cols) {
   constexpr int DE = ROLL ? 12 : 6, KIA = 4 + ND, NV = DE + KIA + 1;
   const int n = d.slots();
@@ -492,7 +492,7 @@ __global__ void k_jacobian(Dims d, Tables t, int row_nnz, double* __restrict__ v
 //   a fixed reduction order (no atomics).  The local Jacobian columns come from the same view_column / point_rows
 //   functions as k_jacobian.  The remaining blocks come from k_linearize.
 // ---------------------------------------------------------------------------------------------------------------
-template <int ND, bool FISH, int MOTION, bool OPTK>
+template <int ND, int FISH, int MOTION, bool OPTK>
 __global__ __launch_bounds__(256) void k_points(Dims d, Tables t, double* __restrict__ Hss, double* __restrict__ Hfs,
                                                 double* __restrict__ g) {
   constexpr bool ROLL = MOTION == MOTION_ROLLING;
@@ -640,7 +640,7 @@ __global__ __launch_bounds__(256) void k_points(Dims d, Tables t, double* __rest
 // contain no global store besides the record (a __restrict__ argument): hipcc can then prove that the wave-uniform reads
 // of the view / camera tables are never clobbered and issues them as scalar loads (s_load, operands in SGPRs) instead of
 // 17 vector loads of one address per 64-observation chunk.
-template <int ND, bool FISH, int MOTION, bool OPTK, bool MFMA, bool ROBUST, int FUSED_MODE, bool PROF = false>
+template <int ND, int FISH, int MOTION, bool OPTK, bool MFMA, bool ROBUST, int FUSED_MODE, bool PROF = false>
 // (static pinhole kernels with the linear loss fit 128 registers: they ask for four waves per SIMD explicitly, so that the
 //  table-fed fused form -- 132 registers under the two-wave budget -- is allocated into 128 as well)
 __global__ __launch_bounds__(64, (MOTION == MOTION_STATIC && !FISH && MFMA && !ROBUST && !PROF && OPTK && ND <= 5) ? 4 : 2)

@@ -149,7 +149,16 @@ inline void lower_dims(const mcba_problem* p, HostProblem& hp) {
   MCBA_REQUIRE(p->optimize != 0, "no parameter block enabled");
   MCBA_REQUIRE(p->n_points <= 65535, "boards with more than 65535 points are not supported (16-bit point lists)");
   MCBA_REQUIRE((int64_t)p->n_cameras * p->n_boards < 65535, "more than 65534 (camera, board) pairs are not supported (16-bit view ranks)");
-  if (p->camera_model == MCBA_CAMERA_FISHEYE)
+  // projection family of every camera: uniform (camera_model) or per camera (camera_fisheye: the reference's ParamList holds
+  // independent Camera / CameraFisheye objects, optimization/parameters.py:54-85)
+  bool any_fish = p->camera_model == MCBA_CAMERA_FISHEYE, any_pin = !any_fish;
+  if (p->camera_fisheye != nullptr) {
+    any_fish = any_pin = false;
+    for (int c = 0; c < p->n_cameras; ++c) (p->camera_fisheye[c] ? any_fish : any_pin) = true;
+  }
+  const bool mixed = any_fish && any_pin;
+  auto cam_is_fish = [&](int c) { return p->camera_fisheye != nullptr ? p->camera_fisheye[c] != 0 : any_fish; };
+  if (!mixed && any_fish)
     MCBA_REQUIRE(p->n_dist == 4, "fisheye cameras carry 4 distortion coefficients (camera_fisheye.py:113-117)");
   else
     MCBA_REQUIRE(p->n_dist == 4 || p->n_dist == 5 || p->n_dist == 8 || p->n_dist == 12 || p->n_dist == 14,
@@ -165,16 +174,26 @@ inline void lower_dims(const mcba_problem* p, HostProblem& hp) {
     int mx = 0;
     for (int c = 0; c < p->n_cameras; ++c) {
       const int nd = p->camera_n_dist[c];
-      MCBA_REQUIRE(nd == 4 || nd == 5 || nd == 8 || nd == 12 || nd == 14,
-                   "pinhole cameras carry 4, 5, 8, 12 or 14 distortion coefficients (cv2.projectPoints)");
+      if (cam_is_fish(c))
+        MCBA_REQUIRE(nd == 4, "fisheye cameras carry 4 distortion coefficients (camera_fisheye.py:113-117)");
+      else
+        MCBA_REQUIRE(nd == 4 || nd == 5 || nd == 8 || nd == 12 || nd == 14,
+                     "pinhole cameras carry 4, 5, 8, 12 or 14 distortion coefficients (cv2.projectPoints)");
       hp.cam_nd[c] = nd;
       mx = std::max(mx, nd);
       ragged = ragged || nd != p->n_dist;
     }
     MCBA_REQUIRE(mx == p->n_dist, "n_dist must be the largest entry of camera_n_dist");
-    MCBA_REQUIRE(!ragged || p->camera_model == MCBA_CAMERA_PINHOLE,
+    MCBA_REQUIRE(!ragged || !any_fish || mixed,
                  "cameras of different distortion sizes must all be pinhole cameras (fisheye cameras carry exactly 4)");
+  } else if (mixed) {
+    MCBA_REQUIRE(p->n_dist == 4, "a rig that mixes pinhole and fisheye cameras needs camera_n_dist unless every camera carries 4 coefficients");
   }
+  // A MIXED rig runs the one instantiation that decides the family per camera at run time; it is compiled for the widest
+  // coefficient block (14) and every camera is padded to it, exactly like pinhole cameras of different sizes are padded to
+  // the largest (the coefficients a camera does not have stay zero and are frozen: cam_kmask)
+  const int nd_internal = mixed ? MAX_DIST : p->n_dist;
+  if (mixed) ragged = true;
   d.C = p->n_cameras; d.F = p->n_frames; d.B = p->n_boards; d.P = p->n_points;
   d.f0 = 0; d.Fl = d.F;
   if (p->frame_begin >= 0) {
@@ -182,7 +201,7 @@ inline void lower_dims(const mcba_problem* p, HostProblem& hp) {
     d.f0 = p->frame_begin;
     d.Fl = p->frame_end - p->frame_begin;
   }
-  d.motion = p->motion; d.ND = p->n_dist; d.fisheye = p->camera_model == MCBA_CAMERA_FISHEYE;
+  d.motion = p->motion; d.ND = nd_internal; d.fisheye = mixed ? 2 : (any_fish ? 1 : 0);
   int64_t nboardpts = 0;
   std::vector<int32_t> board_off(d.B + 1, 0);
   for (int b = 0; b < d.B; ++b) {
@@ -255,7 +274,8 @@ inline void lower_dims(const mcba_problem* p, HostProblem& hp) {
     }
     hp.board_off = board_off;
     hp.img_h.assign(p->image_heights, p->image_heights + d.C);
-    hp.fix_aspect.assign(p->fix_aspect, p->fix_aspect + d.C);
+    hp.fix_aspect.resize((size_t)d.C);   // bit 0: Camera.fix_aspect, bit 1: fisheye camera (read by the mixed-rig kernels)
+    for (int c = 0; c < d.C; ++c) hp.fix_aspect[c] = (uint8_t)((p->fix_aspect[c] ? 1 : 0) | (cam_is_fish(c) ? 2 : 0));
     std::vector<double> bwg;
     if (d.motion == MOTION_HAND_EYE) {
       bwg.resize((size_t)12 * d.F);

@@ -33,9 +33,9 @@ namespace mcba {
 constexpr int POSE_STRIDE = 24;   // R[9] t[3] L[9] pad[3]      (L = left Jacobian of SO(3) at the rotation vector)
 constexpr int POSE_R = 0, POSE_T = 9, POSE_L = 12;
 constexpr int MAX_DIST = 14;
-constexpr int CAM_STRIDE = 56;    // fx fy cx cy skew | k[14] | T[9] dTx[9] dTy[9] | image_height fix_aspect pad
+constexpr int CAM_STRIDE = 56;    // fx fy cx cy skew | k[14] | T[9] dTx[9] dTy[9] | image_height fix_aspect is_fisheye pad
 constexpr int CAM_FX = 0, CAM_FY = 1, CAM_CX = 2, CAM_CY = 3, CAM_SKEW = 4, CAM_K = 5, CAM_TILT = 19,
-              CAM_DTX = 28, CAM_DTY = 37, CAM_HEIGHT = 46, CAM_FIXASPECT = 47;
+              CAM_DTX = 28, CAM_DTY = 37, CAM_HEIGHT = 46, CAM_FIXASPECT = 47, CAM_ISFISH = 48;
 constexpr int VIEW_STRIDE = 12;   // R[9] t[3] of the full chain board -> camera (x2 for rolling shutter)
 
 // ---------------------------------------------------------------------------------------------------------
@@ -148,7 +148,8 @@ MCBA_HD void tilt_matrices(double tx, double ty, double* T, double* dTx, double*
 }
 
 // camera table entry from the reference's per-camera parameter block [fx fy cx cy skew dist...] (camera.py:144-171)
-MCBA_HD void camera_entry(const double* p, int n_dist, double image_height, bool fix_aspect, double* e) {
+MCBA_HD void camera_entry(const double* p, int n_dist, double image_height, bool fix_aspect, double* e,
+                          bool is_fisheye = false) {
   for (int i = 0; i < CAM_STRIDE; ++i) e[i] = 0.0;
   e[CAM_FX] = p[0];
   e[CAM_FY] = fix_aspect ? p[0] : p[1];      // camera.py:159-160: fx, fy = (f[0], f[0]) under fix_aspect
@@ -165,6 +166,7 @@ MCBA_HD void camera_entry(const double* p, int n_dist, double image_height, bool
   }
   e[CAM_HEIGHT] = image_height;
   e[CAM_FIXASPECT] = fix_aspect ? 1.0 : 0.0;
+  e[CAM_ISFISH] = is_fisheye ? 1.0 : 0.0;      // (read by the mixed-rig instantiation only)
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -177,7 +179,131 @@ MCBA_HD void camera_entry(const double* p, int n_dist, double image_height, bool
 // `cam` points at the parameter block [fx fy cx cy skew k...] -- the head of a camera-table entry, or the camera's block
 // inside x itself (same order, camera.py:150-155) -- and `ext` at the table entry's tail [T dTx dTy height fix_aspect]
 // (CAM_TILT onwards).  Under fix_aspect the second focal entry is ignored (camera.py:159-160).
-template <int ND, bool FISHEYE, bool JAC>
+// distorted normalised coordinates (xd, yd) of the normalised point (x, y), d(xd, yd)/d(x, y) and d(xd, yd)/d k (dk[ND + i]
+// = the y row), for the two projection families.  k = the camera's coefficient block (ND slots).
+template <int ND, bool JAC>
+MCBA_HD void distort_fisheye(const double* k, double x, double y, double& xd, double& yd, double& dxx, double& dxy, double& dyx,
+                             double& dyy, double* dk) {
+  const double r2 = x * x + y * y;
+  const double r = sqrt(r2);
+  const double th = atan(r);
+  const double th2 = th * th, th4 = th2 * th2, th6 = th4 * th2, th8 = th4 * th4;
+  const double poly = 1.0 + k[0] * th2 + k[1] * th4 + k[2] * th6 + k[3] * th8;
+  const double thd = th * poly;
+  const bool big = r > 1e-8;
+  const double inv_r = big ? 1.0 / r : 1.0;
+  const double s = big ? thd * inv_r : 1.0;
+  xd = x * s;
+  yd = y * s;
+  if constexpr (JAC) {
+    if (big) {
+      const double dthd = 1.0 + 3.0 * k[0] * th2 + 5.0 * k[1] * th4 + 7.0 * k[2] * th6 + 9.0 * k[3] * th8;
+      const double ds = (dthd / (1.0 + r2) * r - thd) * inv_r * inv_r;   // ds/dr
+      const double gx = ds * x * inv_r, gy = ds * y * inv_r;             // ds/dx, ds/dy
+      dxx = s + x * gx; dxy = x * gy; dyx = y * gx; dyy = s + y * gy;
+      const double t3 = th * th2 * inv_r;
+      dk[0] = x * t3;        dk[ND + 0] = y * t3;
+      dk[1] = x * t3 * th2;  dk[ND + 1] = y * t3 * th2;
+      dk[2] = x * t3 * th4;  dk[ND + 2] = y * t3 * th4;
+      dk[3] = x * t3 * th6;  dk[ND + 3] = y * t3 * th6;
+    } else {
+      dxx = 1.0; dxy = 0.0; dyx = 0.0; dyy = 1.0;
+      for (int i = 0; i < 2 * ND; ++i) dk[i] = 0.0;
+    }
+  }
+  if constexpr (JAC && ND > 4) {   // (a fisheye camera inside a rig whose coefficient blocks are wider: the rest is not its own)
+    for (int i = 4; i < ND; ++i) dk[i] = dk[ND + i] = 0.0;
+  }
+}
+
+template <int ND, bool JAC>
+MCBA_HD void distort_pinhole(const double* k, const double* ext, double x, double y, double& xd, double& yd, double& dxx,
+                             double& dxy, double& dyx, double& dyy, double* dk) {
+  const double r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
+  const double a1 = 2.0 * x * y, a2 = r2 + 2.0 * x * x, a3 = r2 + 2.0 * y * y;
+  const double k4 = (ND >= 5) ? k[4] : 0.0;
+  const double cdist = 1.0 + k[0] * r2 + k[1] * r4 + k4 * r6;
+  double icd = 1.0, den_d = 0.0;
+  if constexpr (ND >= 8) {
+    icd = 1.0 / (1.0 + k[5] * r2 + k[6] * r4 + k[7] * r6);
+    den_d = k[5] + 2.0 * k[6] * r2 + 3.0 * k[7] * r4;
+  }
+  const double radial = cdist * icd;
+  double xd0 = x * radial + k[2] * a1 + k[3] * a2;
+  double yd0 = y * radial + k[2] * a3 + k[3] * a1;
+  double sx = 0.0, sy = 0.0;   // d(thin prism)/dr2
+  if constexpr (ND >= 12) {
+    xd0 += k[8] * r2 + k[9] * r4;
+    yd0 += k[10] * r2 + k[11] * r4;
+    sx = k[8] + 2.0 * k[9] * r2;
+    sy = k[10] + 2.0 * k[11] * r2;
+  }
+  double j00 = 0, j01 = 0, j10 = 0, j11 = 0;
+  if constexpr (JAC) {
+    const double cd_d = k[0] + 2.0 * k[1] * r2 + 3.0 * k4 * r4;
+    const double rad_d = cd_d * icd - cdist * icd * icd * den_d;   // d radial / d r2
+    j00 = radial + 2.0 * x * x * rad_d + 2.0 * k[2] * y + 6.0 * k[3] * x + 2.0 * x * sx;
+    j01 = 2.0 * x * y * rad_d + 2.0 * k[2] * x + 2.0 * k[3] * y + 2.0 * y * sx;
+    j10 = 2.0 * x * y * rad_d + 2.0 * k[2] * x + 2.0 * k[3] * y + 2.0 * x * sy;
+    j11 = radial + 2.0 * y * y * rad_d + 6.0 * k[2] * y + 2.0 * k[3] * x + 2.0 * y * sy;
+    dk[0] = x * r2 * icd;  dk[ND + 0] = y * r2 * icd;
+    dk[1] = x * r4 * icd;  dk[ND + 1] = y * r4 * icd;
+    dk[2] = a1;            dk[ND + 2] = a3;
+    dk[3] = a2;            dk[ND + 3] = a1;
+    if constexpr (ND >= 5) { dk[4] = x * r6 * icd; dk[ND + 4] = y * r6 * icd; }
+    if constexpr (ND >= 8) {
+      const double q = -cdist * icd * icd;
+      dk[5] = x * q * r2;  dk[ND + 5] = y * q * r2;
+      dk[6] = x * q * r4;  dk[ND + 6] = y * q * r4;
+      dk[7] = x * q * r6;  dk[ND + 7] = y * q * r6;
+    }
+    if constexpr (ND >= 12) {
+      dk[8] = r2;   dk[ND + 8] = 0.0;
+      dk[9] = r4;   dk[ND + 9] = 0.0;
+      dk[10] = 0.0; dk[ND + 10] = r2;
+      dk[11] = 0.0; dk[ND + 11] = r4;
+    }
+  }
+  if constexpr (ND >= 14) {
+    const double* T = ext;
+    const double vx = T[0] * xd0 + T[1] * yd0 + T[2];
+    const double vy = T[3] * xd0 + T[4] * yd0 + T[5];
+    const double vz = T[6] * xd0 + T[7] * yd0 + T[8];
+    const double inv = (vz != 0.0) ? 1.0 / vz : 1.0;
+    xd = vx * inv;
+    yd = vy * inv;
+    if constexpr (JAC) {
+      // d(xd,yd)/d(xd0,yd0)
+      const double t00 = (T[0] - xd * T[6]) * inv, t01 = (T[1] - xd * T[7]) * inv;
+      const double t10 = (T[3] - yd * T[6]) * inv, t11 = (T[4] - yd * T[7]) * inv;
+      dxx = t00 * j00 + t01 * j10; dxy = t00 * j01 + t01 * j11;
+      dyx = t10 * j00 + t11 * j10; dyy = t10 * j01 + t11 * j11;
+      for (int i = 0; i < 12; ++i) {
+        const double ax = dk[i], ay = dk[ND + i];
+        dk[i] = t00 * ax + t01 * ay;
+        dk[ND + i] = t10 * ax + t11 * ay;
+      }
+      const double* D[2] = {ext + (CAM_DTX - CAM_TILT), ext + (CAM_DTY - CAM_TILT)};
+      for (int q = 0; q < 2; ++q) {
+        const double* d = D[q];
+        const double wx = d[0] * xd0 + d[1] * yd0 + d[2];
+        const double wy = d[3] * xd0 + d[4] * yd0 + d[5];
+        const double wz = d[6] * xd0 + d[7] * yd0 + d[8];
+        dk[12 + q] = (wx - xd * wz) * inv;
+        dk[ND + 12 + q] = (wy - yd * wz) * inv;
+      }
+    }
+  } else {
+    xd = xd0;
+    yd = yd0;
+    if constexpr (JAC) { dxx = j00; dxy = j01; dyx = j10; dyy = j11; }
+  }
+}
+
+// FISHEYE: 0 = Brown-Conrady pinhole (cv2.projectPoints), 1 = Kannala-Brandt fisheye (cv2.fisheye.projectPoints), 2 = decided
+// per camera at run time by the camera entry's CAM_ISFISH flag (rigs that MIX the two families; wave-uniform in the kernels:
+// a view has one camera)
+template <int ND, int FISHEYE, bool JAC>
 MCBA_HD void project_point(const double* cam, const double* ext, const double* X, double* uv, double* A, double* Kc) {
   constexpr int KI = 4 + ND;
   const bool fa = ext[CAM_FIXASPECT - CAM_TILT] != 0.0;
@@ -187,117 +313,15 @@ MCBA_HD void project_point(const double* cam, const double* ext, const double* X
   const double iz = (Z != 0.0) ? 1.0 / Z : 1.0;   // cvProjectPoints2Internal: z = z ? 1/z : 1
   const double x = X[0] * iz, y = X[1] * iz;
   double xd, yd;              // distorted normalised coordinates
-  double dxx, dxy, dyx, dyy;  // d(xd,yd)/d(x,y)
+  double dxx = 0, dxy = 0, dyx = 0, dyy = 0;  // d(xd,yd)/d(x,y)
   double dk[2 * (ND > 0 ? ND : 1)];
-
-  if constexpr (FISHEYE) {
-    const double r2 = x * x + y * y;
-    const double r = sqrt(r2);
-    const double th = atan(r);
-    const double th2 = th * th, th4 = th2 * th2, th6 = th4 * th2, th8 = th4 * th4;
-    const double poly = 1.0 + k[0] * th2 + k[1] * th4 + k[2] * th6 + k[3] * th8;
-    const double thd = th * poly;
-    const bool big = r > 1e-8;
-    const double inv_r = big ? 1.0 / r : 1.0;
-    const double s = big ? thd * inv_r : 1.0;
-    xd = x * s;
-    yd = y * s;
-    if constexpr (JAC) {
-      if (big) {
-        const double dthd = 1.0 + 3.0 * k[0] * th2 + 5.0 * k[1] * th4 + 7.0 * k[2] * th6 + 9.0 * k[3] * th8;
-        const double ds = (dthd / (1.0 + r2) * r - thd) * inv_r * inv_r;   // ds/dr
-        const double gx = ds * x * inv_r, gy = ds * y * inv_r;             // ds/dx, ds/dy
-        dxx = s + x * gx; dxy = x * gy; dyx = y * gx; dyy = s + y * gy;
-        const double t3 = th * th2 * inv_r;
-        dk[0] = x * t3;        dk[ND + 0] = y * t3;
-        dk[1] = x * t3 * th2;  dk[ND + 1] = y * t3 * th2;
-        dk[2] = x * t3 * th4;  dk[ND + 2] = y * t3 * th4;
-        dk[3] = x * t3 * th6;  dk[ND + 3] = y * t3 * th6;
-      } else {
-        dxx = 1.0; dxy = 0.0; dyx = 0.0; dyy = 1.0;
-        for (int i = 0; i < 2 * ND; ++i) dk[i] = 0.0;
-      }
-    }
+  if constexpr (FISHEYE == 1) {
+    distort_fisheye<ND, JAC>(k, x, y, xd, yd, dxx, dxy, dyx, dyy, dk);
+  } else if constexpr (FISHEYE == 0) {
+    distort_pinhole<ND, JAC>(k, ext, x, y, xd, yd, dxx, dxy, dyx, dyy, dk);
   } else {
-    const double r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
-    const double a1 = 2.0 * x * y, a2 = r2 + 2.0 * x * x, a3 = r2 + 2.0 * y * y;
-    const double k4 = (ND >= 5) ? k[4] : 0.0;
-    const double cdist = 1.0 + k[0] * r2 + k[1] * r4 + k4 * r6;
-    double icd = 1.0, den_d = 0.0;
-    if constexpr (ND >= 8) {
-      icd = 1.0 / (1.0 + k[5] * r2 + k[6] * r4 + k[7] * r6);
-      den_d = k[5] + 2.0 * k[6] * r2 + 3.0 * k[7] * r4;
-    }
-    const double radial = cdist * icd;
-    double xd0 = x * radial + k[2] * a1 + k[3] * a2;
-    double yd0 = y * radial + k[2] * a3 + k[3] * a1;
-    double sx = 0.0, sy = 0.0;   // d(thin prism)/dr2
-    if constexpr (ND >= 12) {
-      xd0 += k[8] * r2 + k[9] * r4;
-      yd0 += k[10] * r2 + k[11] * r4;
-      sx = k[8] + 2.0 * k[9] * r2;
-      sy = k[10] + 2.0 * k[11] * r2;
-    }
-    double j00 = 0, j01 = 0, j10 = 0, j11 = 0;
-    if constexpr (JAC) {
-      const double cd_d = k[0] + 2.0 * k[1] * r2 + 3.0 * k4 * r4;
-      const double rad_d = cd_d * icd - cdist * icd * icd * den_d;   // d radial / d r2
-      j00 = radial + 2.0 * x * x * rad_d + 2.0 * k[2] * y + 6.0 * k[3] * x + 2.0 * x * sx;
-      j01 = 2.0 * x * y * rad_d + 2.0 * k[2] * x + 2.0 * k[3] * y + 2.0 * y * sx;
-      j10 = 2.0 * x * y * rad_d + 2.0 * k[2] * x + 2.0 * k[3] * y + 2.0 * x * sy;
-      j11 = radial + 2.0 * y * y * rad_d + 6.0 * k[2] * y + 2.0 * k[3] * x + 2.0 * y * sy;
-      dk[0] = x * r2 * icd;  dk[ND + 0] = y * r2 * icd;
-      dk[1] = x * r4 * icd;  dk[ND + 1] = y * r4 * icd;
-      dk[2] = a1;            dk[ND + 2] = a3;
-      dk[3] = a2;            dk[ND + 3] = a1;
-      if constexpr (ND >= 5) { dk[4] = x * r6 * icd; dk[ND + 4] = y * r6 * icd; }
-      if constexpr (ND >= 8) {
-        const double q = -cdist * icd * icd;
-        dk[5] = x * q * r2;  dk[ND + 5] = y * q * r2;
-        dk[6] = x * q * r4;  dk[ND + 6] = y * q * r4;
-        dk[7] = x * q * r6;  dk[ND + 7] = y * q * r6;
-      }
-      if constexpr (ND >= 12) {
-        dk[8] = r2;   dk[ND + 8] = 0.0;
-        dk[9] = r4;   dk[ND + 9] = 0.0;
-        dk[10] = 0.0; dk[ND + 10] = r2;
-        dk[11] = 0.0; dk[ND + 11] = r4;
-      }
-    }
-    if constexpr (ND >= 14) {
-      const double* T = ext;
-      const double vx = T[0] * xd0 + T[1] * yd0 + T[2];
-      const double vy = T[3] * xd0 + T[4] * yd0 + T[5];
-      const double vz = T[6] * xd0 + T[7] * yd0 + T[8];
-      const double inv = (vz != 0.0) ? 1.0 / vz : 1.0;
-      xd = vx * inv;
-      yd = vy * inv;
-      if constexpr (JAC) {
-        // d(xd,yd)/d(xd0,yd0)
-        const double t00 = (T[0] - xd * T[6]) * inv, t01 = (T[1] - xd * T[7]) * inv;
-        const double t10 = (T[3] - yd * T[6]) * inv, t11 = (T[4] - yd * T[7]) * inv;
-        dxx = t00 * j00 + t01 * j10; dxy = t00 * j01 + t01 * j11;
-        dyx = t10 * j00 + t11 * j10; dyy = t10 * j01 + t11 * j11;
-        for (int i = 0; i < 12; ++i) {
-          const double ax = dk[i], ay = dk[ND + i];
-          dk[i] = t00 * ax + t01 * ay;
-          dk[ND + i] = t10 * ax + t11 * ay;
-        }
-        const double* D[2] = {ext + (CAM_DTX - CAM_TILT), ext + (CAM_DTY - CAM_TILT)};
-        for (int q = 0; q < 2; ++q) {
-          const double* d = D[q];
-          const double wx = d[0] * xd0 + d[1] * yd0 + d[2];
-          const double wy = d[3] * xd0 + d[4] * yd0 + d[5];
-          const double wz = d[6] * xd0 + d[7] * yd0 + d[8];
-          dk[12 + q] = (wx - xd * wz) * inv;
-          dk[ND + 12 + q] = (wy - yd * wz) * inv;
-        }
-      }
-    } else {
-      xd = xd0;
-      yd = yd0;
-      if constexpr (JAC) { dxx = j00; dxy = j01; dyx = j10; dyy = j11; }
-    }
+    if (ext[CAM_ISFISH - CAM_TILT] != 0.0) distort_fisheye<ND, JAC>(k, x, y, xd, yd, dxx, dxy, dyx, dyy, dk);
+    else distort_pinhole<ND, JAC>(k, ext, x, y, xd, yd, dxx, dxy, dyx, dyy, dk);
   }
 
   uv[0] = fx * xd + cx;

@@ -47,7 +47,7 @@ MCBA_HD int tri_index(int i, int j, int N1) {   // packed upper triangle, i <= j
 // ---------------------------------------------------------------------------------------------------------------
 // forward model of one table slot (motion/static_frames.py:16-25, motion/rolling_frames.py:15-41)
 // ---------------------------------------------------------------------------------------------------------------
-template <int ND, bool FISH, bool ROLL, bool JAC>
+template <int ND, int FISH, bool ROLL, bool JAC>
 MCBA_HD void slot_forward(const Dims& d, const Tables& t, int v, int c, int b, int p, double2 ob,
                                              double* uv, double* A, double* Kc, double* Xs, double* Xe, double& tr,
                                              const double* Xpre = nullptr /* prefetched board point */,
@@ -381,7 +381,7 @@ struct PointState {
 
 // returns rho0_u + rho0_v
 // ROBUST = false compiles the linear loss in (no loss switch, no row scaling: the hot kernel's default instantiation)
-template <int ND, bool FISH, bool ROLL, bool ROBUST = true>
+template <int ND, int FISH, bool ROLL, bool ROBUST = true>
 MCBA_HD double point_state(const Dims& d, const Tables& t, int v, int c, int b, int p, double2 ob,
                            PointState<ND, ROLL>& st, const double* Xpre = nullptr, const double* Vpre = nullptr,
                            const double* camp = nullptr, const double* extp = nullptr) {
@@ -419,7 +419,7 @@ MCBA_HD void point_row(const PointState<ND, ROLL>& st, int a, double* row /*[NV]
   row[NV - 1] = st.e[a] * st.fs[a];
 }
 
-template <int ND, bool FISH, bool ROLL, bool OPTK>
+template <int ND, int FISH, bool ROLL, bool OPTK>
 MCBA_HD double point_rows(const Dims& d, const Tables& t, int v, int c, int b, int p, double2 ob,
                                              double* vr /*[2][NV]*/, double* jp = nullptr /*[2][3]: d r / d X_board*/,
                                              const double* Xpre = nullptr) {
@@ -469,7 +469,7 @@ MCBA_HD void prep_item(const Dims& d, const Tables& t, const XV& x, int i) {
 #pragma unroll
     for (int k = 0; k < 5 + MAX_DIST; ++k) p[k] = k < kc ? block_value(t, x, d.off_cameras, d.foff_cameras, i * kc + k) : 0.0;
     double e[CAM_STRIDE];
-    camera_entry(p, d.ND, t.img_h[i], t.fix_aspect[i] != 0, e);
+    camera_entry(p, d.ND, t.img_h[i], (t.fix_aspect[i] & 1) != 0, e, (t.fix_aspect[i] & 2) != 0);   // (bit 1: fisheye camera of a mixed rig)
 #pragma unroll
     for (int k = 0; k < CAM_STRIDE; ++k) t.cam[(size_t)i * CAM_STRIDE + k] = e[k];
     return;

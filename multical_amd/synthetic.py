@@ -156,6 +156,15 @@ CONFIGS = {
   # 5, 8, 14 and 4 distortion coefficients -- the cameras block of the parameter vector is ragged
   "tiny_mixed": dict(cameras=4, frames=8, boards=["charuco_10x10"], motion="static",
                      model=["standard", "rational", "tilted", "pin4"], optimize_cameras=True, layout="stereo", seed=33),
+  # pinhole AND fisheye cameras in one rig (independent Camera / CameraFisheye objects in the reference's ParamList): 5 and 4
+  # distortion coefficients, two projection families; rolling shutter so that both chains are exercised
+  # (4-coefficient pinhole + fisheye: every camera block has 9 entries, the one mixed rig the reference's own bundle_adjust
+  #  can solve -- Calibration.sparsity_matrix reshapes the cameras block to [n_cameras, -1], calibration.py:179-180)
+  "tiny_fishmix": dict(cameras=4, frames=10, boards=["charuco_10x10"] * 2, motion="rolling",
+                       model=["pin4", "fisheye", "pin4", "fisheye"], optimize_cameras=True, layout="stereo", seed=34),
+  # (5- and 8-coefficient pinhole + fisheye: ragged cameras block -- the reference evaluates it, its bundle_adjust raises)
+  "tiny_fishmix5": dict(cameras=4, frames=8, boards=["charuco_10x10"], motion="static",
+                        model=["standard", "fisheye", "rational", "fisheye"], optimize_cameras=True, layout="stereo", seed=35),
   # reduced-frame variants of BASELINE configs[2..4] whose complete reference run (adjust_outliers) finishes in minutes
   "cfg3_40": dict(cameras=8, frames=40, boards=["charuco_16x22", "aprilgrid_9x9"], motion="rolling",
                   model="standard", optimize_cameras=True, layout="stereo", seed=3),

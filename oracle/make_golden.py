@@ -90,6 +90,9 @@ CASES = {
   "tiny_autoscale_huber": ("tiny_rolling", None, dict(loss='huber', f_scale=2.0), True, False),
   # a board with more points than one 512-slot compaction segment of the HIP kernels (25 x 35 charuco: 816 corners)
   "tiny_bigboard": ("tiny_bigboard", None, {}, True, True),
+  # pinhole AND fisheye cameras in one rig (missing 3): independent Camera / CameraFisheye objects in the
+  # reference's ParamList; 4-coefficient pinhole + fisheye = equal block sizes, the mix the reference itself can solve
+  "tiny_fishmix": ("tiny_fishmix", None, {}, True, True),
 }
 
 AO_KWARGS = {   # Workspace.calibrate arguments of the adjust_outliers run (default: loss='linear', no auto_scale)
@@ -453,6 +456,8 @@ def main(argv):
   names = argv or list(CASES)
   for n in names:
     if n == "tiny_mixed":
+      run_mixed_case(n)
+    elif n == "tiny_fishmix5":
       run_mixed_case(n)
     elif n in FULL_CASES:
       run_full_case(n)

@@ -33,8 +33,14 @@ struct Host {
     t.xfull = hp.xfull.data(); t.bwg = hp.bwg.data(); t.img_h = hp.img_h.data(); t.fix_aspect = hp.fix_aspect.data();
     t.board_points = board_points.data(); t.pose = pose.data(); t.cam = cam.data(); t.view = view.data();
   }
+  std::vector<double> xint;   // ragged camera blocks: the caller's vector scattered into the padded internal layout
   void eval_tables(const double* x) {
     const Dims& d = hp.d;
+    if (!hp.ext2int.empty()) {
+      xint.assign((size_t)d.n, 0.0);
+      for (int i = 0; i < hp.n_ext; ++i) xint[hp.ext2int[i]] = x[i];
+      x = xint.data();
+    }
     const int items = d.n_pose + d.C + d.B * d.P;
     for (int i = 0; i < items; ++i) prep_item(d, t, x, i);
     const int nv = d.views() * (d.motion == MOTION_ROLLING ? 2 : 1);
@@ -42,7 +48,7 @@ struct Host {
   }
 };
 
-template <int ND, bool FISH, bool ROLL>
+template <int ND, int FISH, bool ROLL>
 void residuals_t(Host& h, double* r, double* err, uint8_t* valid) {
   const Dims& d = h.hp.d;
   for (int s = 0; s < d.slots(); ++s) {
@@ -63,7 +69,7 @@ void residuals_t(Host& h, double* r, double* err, uint8_t* valid) {
   }
 }
 
-template <int ND, bool FISH, bool ROLL>
+template <int ND, int FISH, bool ROLL>
 void jacobian_t(Host& h, int row_nnz, double* vals, int32_t* cols) {
   const Dims& d = h.hp.d;
   constexpr int DE = ROLL ? 12 : 6, KIA = 4 + ND, NV = DE + KIA + 1;
@@ -112,7 +118,7 @@ void jacobian_t(Host& h, int row_nnz, double* vals, int32_t* cols) {
 }
 
 // per-view S = V^T V, M = That^T S That, scattered into dense H / g  (the kernels' algebra, serial)
-template <int ND, bool FISH, bool ROLL, bool OPTK>
+template <int ND, int FISH, bool ROLL, bool OPTK>
 void normal_t(Host& h, double* H, double* g, double* cost_out) {
   const Dims& d = h.hp.d;
   constexpr int DE = ROLL ? 12 : 6, KI = OPTK ? 4 + ND : 0, NV = DE + KI + 1;
@@ -165,17 +171,18 @@ void normal_t(Host& h, double* H, double* g, double* cost_out) {
   do {                                                                                         \
     const Dims& dd_ = h.hp.d;                                                                  \
     const bool roll_ = dd_.motion == MOTION_ROLLING;                                           \
-    if (dd_.fisheye) { if (roll_) FN<4, true, true>(__VA_ARGS__); else FN<4, true, false>(__VA_ARGS__); } \
+    if (dd_.fisheye == 2) { if (roll_) FN<14, 2, true>(__VA_ARGS__); else FN<14, 2, false>(__VA_ARGS__); } \
+    else if (dd_.fisheye) { if (roll_) FN<4, 1, true>(__VA_ARGS__); else FN<4, 1, false>(__VA_ARGS__); } \
     else switch (dd_.ND) {                                                                     \
-      case 4: if (roll_) FN<4, false, true>(__VA_ARGS__); else FN<4, false, false>(__VA_ARGS__); break;   \
-      case 5: if (roll_) FN<5, false, true>(__VA_ARGS__); else FN<5, false, false>(__VA_ARGS__); break;   \
-      case 8: if (roll_) FN<8, false, true>(__VA_ARGS__); else FN<8, false, false>(__VA_ARGS__); break;   \
-      case 12: if (roll_) FN<12, false, true>(__VA_ARGS__); else FN<12, false, false>(__VA_ARGS__); break; \
-      default: if (roll_) FN<14, false, true>(__VA_ARGS__); else FN<14, false, false>(__VA_ARGS__); break; \
+      case 4: if (roll_) FN<4, 0, true>(__VA_ARGS__); else FN<4, 0, false>(__VA_ARGS__); break;   \
+      case 5: if (roll_) FN<5, 0, true>(__VA_ARGS__); else FN<5, 0, false>(__VA_ARGS__); break;   \
+      case 8: if (roll_) FN<8, 0, true>(__VA_ARGS__); else FN<8, 0, false>(__VA_ARGS__); break;   \
+      case 12: if (roll_) FN<12, 0, true>(__VA_ARGS__); else FN<12, 0, false>(__VA_ARGS__); break; \
+      default: if (roll_) FN<14, 0, true>(__VA_ARGS__); else FN<14, 0, false>(__VA_ARGS__); break; \
     }                                                                                          \
   } while (0)
 
-template <int ND, bool FISH, bool ROLL>
+template <int ND, int FISH, bool ROLL>
 void normal_k(Host& h, double* H, double* g, double* cost) {
   if (h.hp.d.KI > 0) normal_t<ND, FISH, ROLL, true>(h, H, g, cost);
   else normal_t<ND, FISH, ROLL, false>(h, H, g, cost);
@@ -194,7 +201,7 @@ int32_t hm_sizes(const mcba_problem* p, int64_t* n_params, int64_t* n_residuals,
   HM_BEGIN
   Host h; h.init(p);
   const Dims& d = h.hp.d;
-  *n_params = d.n;
+  *n_params = h.hp.ext2int.empty() ? d.n : h.hp.n_ext;   // length of the CALLER's vector (ragged camera blocks are padded inside)
   *n_residuals = 2 * h.hp.n_inliers;
   int nnz = 0;
   if (d.off_campose >= 0) nnz += 6;
@@ -217,6 +224,10 @@ int32_t hm_jacobian(const mcba_problem* p, const double* x, int32_t row_nnz, dou
   HM_BEGIN
   Host h; h.init(p); h.eval_tables(x);
   DISPATCH_CAM(jacobian_t, h, row_nnz, vals, cols);
+  if (!h.hp.int2ext.empty()) {   // internal (padded) column -> the caller's column, -1 for a coefficient the camera does not have
+    const size_t nc = (size_t)h.hp.n_inliers * row_nnz;
+    for (size_t i = 0; i < nc; ++i) cols[i] = cols[i] >= 0 ? h.hp.int2ext[cols[i]] : -1;
+  }
   HM_END
 }
 
@@ -227,9 +238,21 @@ int32_t hm_normal_equations(const mcba_problem* p, const double* x, int32_t loss
   h.hp.d.loss = loss; h.hp.d.f_scale = f_scale;
   h.eval_tables(x);
   const size_t n = h.hp.d.n;
-  std::memset(H, 0, n * n * sizeof(double));
-  std::memset(g, 0, n * sizeof(double));
-  DISPATCH_CAM(normal_k, h, H, g, cost);
+  if (h.hp.ext2int.empty()) {
+    std::memset(H, 0, n * n * sizeof(double));
+    std::memset(g, 0, n * sizeof(double));
+    DISPATCH_CAM(normal_k, h, H, g, cost);
+  } else {   // ragged camera blocks: accumulate in the padded layout, hand out the caller's rows / columns
+    std::vector<double> Hi(n * n, 0.0), gi(n, 0.0);
+    double* Hp = Hi.data();
+    double* gp = gi.data();
+    DISPATCH_CAM(normal_k, h, Hp, gp, cost);
+    const size_t ne = (size_t)h.hp.n_ext;
+    for (size_t i = 0; i < ne; ++i) {
+      g[i] = gi[h.hp.ext2int[i]];
+      for (size_t j = 0; j < ne; ++j) H[i * ne + j] = Hi[(size_t)h.hp.ext2int[i] * n + h.hp.ext2int[j]];
+    }
+  }
   HM_END
 }
 

@@ -68,7 +68,12 @@ class HostMath(object):
     vals = np.zeros((m, k))
     cols = np.zeros((m // 2, k), dtype=np.int32)
     _check(lib().hm_jacobian(C.byref(self.struct), _ptr(x, C.c_double), k, _ptr(vals, C.c_double), _ptr(cols, C.c_int32)))
-    return csr_matrix((vals.ravel(), np.repeat(cols, 2, axis=0).ravel(), np.arange(0, m * k + 1, k)), shape=(m, self.n))
+    indices = np.repeat(cols, 2, axis=0).ravel()
+    if (cols < 0).any():   # ragged camera blocks: slots of coefficients a camera's model does not have
+      keep = indices >= 0
+      counts = keep.reshape(m, k).sum(axis=1)
+      return csr_matrix((vals.ravel()[keep], indices[keep], np.concatenate([[0], np.cumsum(counts)])), shape=(m, self.n))
+    return csr_matrix((vals.ravel(), indices, np.arange(0, m * k + 1, k)), shape=(m, self.n))
 
   def normal_equations(self, x, loss='linear', f_scale=1.0):
     x = _f64(x)

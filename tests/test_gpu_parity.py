@@ -208,11 +208,12 @@ def test_randomised_rigs_against_the_oracle(name, noise, outliers, seed):
   assert res.cost <= ref_cost * (1 + 1e-9)
 
 
-@pytest.mark.parametrize("name", ["tiny_bigboard", "tiny_manypairs", "tiny_mixed"])
+@pytest.mark.parametrize("name", ["tiny_bigboard", "tiny_manypairs", "tiny_mixed", "tiny_fishmix5"])
 def test_rigs_beyond_the_former_limits_against_the_oracle(name):
   """Rigs the reference accepts and earlier versions of mcba_create rejected: a board with more than 512 points (816-corner
-  charuco next to an 81-corner one, rolling shutter), more than 128 (camera, board) pairs (16 cameras x 10 boards), and
-  cameras of different distortion models in one rig (5 / 8 / 14 / 4 coefficients: a ragged cameras block).  Against the
+  charuco next to an 81-corner one, rolling shutter), more than 128 (camera, board) pairs (16 cameras x 10 boards),
+  cameras of different distortion models in one rig (5 / 8 / 14 / 4 coefficients: a ragged cameras block), and pinhole AND
+  fisheye cameras in one rig (round 4; 5 / 8 coefficients + two fisheye cameras: ragged as well).  Against the
   oracle (pinned bit for bit to the reference): residuals, errors, the analytic Jacobian inside the reference's sparsity
   pattern and equal to 3-point differences of the oracle, the fused normal equations == J^T J / J^T r, and the solve."""
   from scipy.optimize._numdiff import approx_derivative, group_columns
@@ -231,12 +232,12 @@ def test_rigs_beyond_the_former_limits_against_the_oracle(name):
     eo, vo = oc.reprojection_error_table()
     assert np.array_equal(valid, vo) and np.abs(err[vo] - eo[vo]).max() < 1e-9
     J = h.jacobian(x0)
-    if name == "tiny_mixed":
+    if name in ("tiny_mixed", "tiny_fishmix5"):
       # the reference's own sparsity_matrix reshapes the cameras block to [C, -1] (calibration.py:179) and therefore
       # RAISES for a ragged block -- its bundle_adjust cannot run on such a rig at all (the fixture records the exception);
       # the oracle restates that line.  What the reference CAN compute is pinned by the fixture: residuals, errors and a
       # dense 2-point Jacobian of its `evaluate`; the analytic Jacobian is also checked against dense 3-point differences.
-      g, _ = load_golden("tiny_mixed")
+      g, _ = load_golden(name)
       assert np.array_equal(x0, g["x0"]) and str(g["ba_error"]).startswith("ValueError")
       assert np.abs(r - g["r0"]).max() < 1e-9 and np.abs(err[valid] - g["err0"]).max() < 1e-9
       assert rel_col_error(J, csr_matrix(g["J_dense"])) < 5e-5
@@ -270,7 +271,7 @@ def test_rigs_beyond_the_former_limits_against_the_oracle(name):
     assert abs(rms_of(h, res.x) - restate.error_stats(oc.with_param_vec(res.x).reprojection_error).rms) < 1e-9
     # first-order optimality (scaled gradient) at the solution (the mixed rig contains a `tilted` camera: a flat valley in
     # which ftol = 1e-4 stops early, like tests/test_gpu_protocol.py FLAT_VALLEY -- checked after a tight solve there)
-    xs = res.x if name != "tiny_mixed" else h.solve(res.x, tolerance=1e-13, xtol=1e-13, gtol=1e-13, max_iterations=300).x
+    xs = res.x if name not in ("tiny_mixed", "tiny_fishmix5") else h.solve(res.x, tolerance=1e-13, xtol=1e-13, gtol=1e-13, max_iterations=300).x
     c2, g2, d2 = h.normal_equations(xs)
     si = np.sqrt(d2); si[si == 0] = 1
     assert np.abs(g2 / si).max() < 1e-3 * np.sqrt(2 * c2)
@@ -761,3 +762,45 @@ def test_resource_cache_reuses_buffers_of_closed_handles():
         assert np.abs(h2.residuals(g2["x0"]) - g2["r0"]).max() < 1e-9
     if k == 2:
       release_cached_memory()
+
+
+@pytest.mark.parametrize("name", ["tiny_rolling", "cfg1", "tiny_fishmix"])
+def test_adjust_outliers_in_one_call_equals_the_step_by_step_loop(name, monkeypatch):
+  """Calibration.adjust_outliers as ONE library call (mcba_adjust_outliers: the default) against the reference-shaped Python
+  loop over report / reject_outliers / bundle_adjust on fresh Calibration objects (MULTICAL_AMD_FUSED_LOOP=0): same inlier
+  masks, same log lines up to the printed digits, same result (the step-by-step loop canonicalises the rotation vectors between
+  the rounds -- a change of 1e-16 in x -- the single call does not)."""
+  import logging
+  from multical_amd import Workspace
+  g, rig = load_golden(name)
+
+  def run():
+    lines = []
+
+    class Grab(logging.Handler):
+      def emit(self, rec):
+        lines.append(rec.getMessage())
+
+    log = logging.getLogger("calibration")
+    hd = Grab()
+    log.addHandler(hd)
+    log.setLevel(logging.INFO)
+    try:
+      out = Workspace(mirror(rig)).calibrate(cameras=rig.optimize["cameras"], camera_poses=rig.optimize["camera_poses"],
+                                             auto_scale=2.0 if name == "tiny_rolling" else None,
+                                             loss="soft_l1" if name == "tiny_rolling" else "linear")
+    finally:
+      log.removeHandler(hd)
+    return out, lines
+
+  fast, lf = run()
+  monkeypatch.setenv("MULTICAL_AMD_FUSED_LOOP", "0")
+  slow, ls = run()
+  assert np.array_equal(fast.inliers, slow.inliers)
+  assert fast.error_statistics(True).rms == pytest.approx(slow.error_statistics(True).rms, abs=1e-9)
+  assert fast.error_statistics(False).rms == pytest.approx(slow.error_statistics(False).rms, abs=1e-9)
+  assert np.abs(fast.param_vec - slow.param_vec).max() < 1e-8
+  keep = lambda ls_: [l for l in ls_ if l.startswith(("Adjust_outliers", "Rejecting", "Auto scaling", "Beginning"))]
+  assert keep(lf) == keep(ls)
+  rows = lambda ls_: [l.split()[:3] for l in ls_ if l.strip() and l.split()[0].isdigit()]
+  assert rows(lf) == rows(ls)          # iteration, nfev, cost of every solve

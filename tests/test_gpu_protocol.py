@@ -34,7 +34,7 @@ pytestmark = pytest.mark.gpu
 
 PROTOCOL_CASES = ["tiny", "tiny_rolling", "tiny_fisheye", "tiny_handeye", "tiny_rational", "tiny_thin_prism",
                   "tiny_tilted", "tiny_edge", "tiny_fixintr", "tiny_pin4", "cfg1", "tiny_softl1", "tiny_huber",
-                  "tiny_boards", "tiny_bigboard"]
+                  "tiny_boards", "tiny_bigboard", "tiny_fishmix"]
 # fixtures whose reference end point is reproducible to better than 1e-6 px (spread < 3e-7): plain 1e-6 assertion
 WELL_DEFINED = ["tiny_handeye", "tiny_fixintr", "cfg1", "tiny_huber"]
 # over-parameterised distortion models on 8 frames: a flat valley that neither the reference's own tight polish nor any

@@ -90,11 +90,12 @@ def test_oracle_matches_reference_at_full_size(name):
     assert np.allclose(es.quantiles, g[f"quantiles{tag}"], rtol=1e-13, atol=0)
 
 
-def test_oracle_on_a_mixed_model_rig_matches_the_reference_including_its_failure():
+@pytest.mark.parametrize("name", ["tiny_mixed", "tiny_fishmix5"])
+def test_oracle_on_a_mixed_model_rig_matches_the_reference_including_its_failure(name):
   """Cameras of different distortion models in one rig (5 / 8 / 14 / 4 coefficients): the reference evaluates residuals
   and errors, but its bundle_adjust raises -- sparsity_matrix reshapes the ragged cameras block (calibration.py:179).  The
   oracle reproduces both facts (tests/golden/tiny_mixed.npz records the reference's values and its exception)."""
-  g, rig = load_golden("tiny_mixed")
+  g, rig = load_golden(name)   # (tiny_fishmix5: 5- / 8-coefficient pinhole + fisheye cameras in one rig)
   oc = oracle(rig)
   assert np.array_equal(oc.param_vec, g["x0"]) and np.array_equal(oc.inliers, g["inliers0"])
   assert np.array_equal(oc.evaluate(g["x0"]), g["r0"])

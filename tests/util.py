@@ -8,7 +8,7 @@ from oracle import restate
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 SMALL_CASES = ["tiny", "tiny_rolling", "tiny_fisheye", "tiny_handeye", "tiny_rational", "tiny_thin_prism",
-               "tiny_tilted", "tiny_edge", "tiny_fixintr", "tiny_pin4", "tiny_bigboard"]
+               "tiny_tilted", "tiny_edge", "tiny_fixintr", "tiny_pin4", "tiny_bigboard", "tiny_fishmix"]
 ALL_CASES = SMALL_CASES + ["cfg1"]
 
 
