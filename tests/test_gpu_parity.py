@@ -800,7 +800,13 @@ def test_adjust_outliers_in_one_call_equals_the_step_by_step_loop(name, monkeypa
   assert fast.error_statistics(True).rms == pytest.approx(slow.error_statistics(True).rms, abs=1e-9)
   assert fast.error_statistics(False).rms == pytest.approx(slow.error_statistics(False).rms, abs=1e-9)
   assert np.abs(fast.param_vec - slow.param_vec).max() < 1e-8
+  import re
   keep = lambda ls_: [l for l in ls_ if l.startswith(("Adjust_outliers", "Rejecting", "Auto scaling", "Beginning"))]
-  assert keep(lf) == keep(ls)
+  number = re.compile(r"[-+]?\d+\.?\d*(?:[eE][-+]?\d+)?")
+  assert len(keep(lf)) == len(keep(ls))
+  for a, b in zip(keep(lf), keep(ls)):     # same text; numbers to the printed precision minus the last digit
+    assert number.sub("#", a) == number.sub("#", b), (a, b)
+    for u, v in zip(number.findall(a), number.findall(b)):
+      assert float(u) == pytest.approx(float(v), rel=1e-6, abs=1e-9), (a, b)
   rows = lambda ls_: [l.split()[:3] for l in ls_ if l.strip() and l.split()[0].isdigit()]
   assert rows(lf) == rows(ls)          # iteration, nfev, cost of every solve
