@@ -60,6 +60,12 @@ extern "C" {
 #define MCBA_CAMERA_PINHOLE 0    /* camera.py:124-128         -> cv2.projectPoints, n_dist in {5,8,12,14} */
 #define MCBA_CAMERA_FISHEYE 1    /* camera_fisheye.py:113-117 -> cv2.fisheye.projectPoints, n_dist = 4     */
 
+/* trust-region step of the solver (scipy `tr_solver`) */
+#define MCBA_TR_EXACT 0          /* regularised Gauss-Newton step from the exact normal equations (Schur + Cholesky): fast,     */
+                                 /* ends at the converged optimum                                                              */
+#define MCBA_TR_LSMR  1          /* scipy's choice for the reference's sparse Jacobian: LSMR with atol = btol = 1e-6 -- the     */
+                                 /* reference's trajectory and end point                                                       */
+
 /* robust losses (scipy.optimize.least_squares `loss`, reachable through OptimizerOpts.loss, config/arguments.py:61) */
 #define MCBA_LOSS_LINEAR  0
 #define MCBA_LOSS_SOFT_L1 1
@@ -121,7 +127,8 @@ typedef struct mcba_options {          /* scipy.optimize.least_squares arguments
   int32_t loss;                 /* MCBA_LOSS_*                                                          */
   double f_scale;               /* scipy `f_scale` (soft margin of the robust loss)                     */
   int32_t verbose;              /* 2: per-iteration rows are delivered to the log callback              */
-  int32_t reserved;
+  int32_t tr_solver;            /* MCBA_TR_EXACT (0): exact Schur / Cholesky steps; MCBA_TR_LSMR (1): scipy's own step,     */
+                                /* gn_h = lsmr(J_h, f, damp) (trf.py:481), with the Jacobian products on the device         */
 } mcba_options;
 
 typedef struct mcba_result {           /* scipy OptimizeResult fields the caller needs                    */

@@ -13,6 +13,7 @@ MCBA_VERSION = 3
 MOTION_STATIC, MOTION_ROLLING, MOTION_HAND_EYE = 0, 1, 2
 CAMERA_PINHOLE, CAMERA_FISHEYE = 0, 1
 LOSSES = dict(linear=0, soft_l1=1, huber=2, cauchy=3, arctan=4)
+TR_SOLVERS = dict(exact=0, lsmr=1)     # mcba_options.tr_solver (MCBA_TR_*)
 OPT_BITS = dict(camera_poses=1, board_poses=2, motion=4, cameras=8, boards=16)
 PARAM_ORDER = ["camera_poses", "board_poses", "motion", "cameras", "boards"]   # calibration.py:146-153
 
@@ -38,7 +39,7 @@ class Problem(C.Structure):
 
 class Options(C.Structure):
   _fields_ = [("ftol", C.c_double), ("xtol", C.c_double), ("gtol", C.c_double), ("max_nfev", C.c_int32),
-              ("loss", C.c_int32), ("f_scale", C.c_double), ("verbose", C.c_int32), ("reserved", C.c_int32)]
+              ("loss", C.c_int32), ("f_scale", C.c_double), ("verbose", C.c_int32), ("tr_solver", C.c_int32)]
 
 
 class Result(C.Structure):

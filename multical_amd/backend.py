@@ -127,10 +127,14 @@ def _to_struct(p, frame_range=None):
   return s
 
 
-def make_options(tolerance=1e-4, f_scale=1.0, max_iterations=100, loss='linear', xtol=1e-8, gtol=1e-8, verbose=2):
+def make_options(tolerance=1e-4, f_scale=1.0, max_iterations=100, loss='linear', xtol=1e-8, gtol=1e-8, verbose=2,
+                 tr_solver='exact'):
   if loss not in LOSSES:
     raise ValueError(f"`loss` must be one of {list(LOSSES)} or a callable.")   # scipy's message
+  if tr_solver not in _lib.TR_SOLVERS:
+    raise ValueError("`tr_solver` must be 'exact' or 'lsmr'.")
   o = Options()
+  o.tr_solver = _lib.TR_SOLVERS[tr_solver]
   o.ftol, o.xtol, o.gtol = float(tolerance), float(xtol), float(gtol)
   o.max_nfev = int(max_iterations)
   o.loss = LOSSES[loss]
@@ -361,14 +365,14 @@ class Handle(object):
     return ni.value, nvv.value
 
   def adjust_outliers(self, x0, num_adjustments=3, outlier=None, scale=None, tolerance=1e-4, f_scale=1.0, max_iterations=100,
-                      loss='linear', xtol=1e-8, gtol=1e-8):
+                      loss='linear', xtol=1e-8, gtol=1e-8, tr_solver='exact'):
     """Calibration.adjust_outliers (calibration.py:254-268) in ONE library call (mcba_adjust_outliers): `num_adjustments` rounds of
     {report, f_scale from `scale` = (quantile, factor) or None, rejection at `outlier` = (quantile, factor) or None, solve} and
     the final report.  Returns (x, rounds, inlier mask); rounds[i] = namespace(rms, rms_inliers, n, n_inliers, quantiles,
     f_scale, threshold, n_kept, n_valid, solve result); the last entry is the final report (no solve)."""
     x = self._x(x0).copy()
     self._jac_pattern = None
-    opt = make_options(tolerance, f_scale, max_iterations, loss, xtol, gtol, 2)
+    opt = make_options(tolerance, f_scale, max_iterations, loss, xtol, gtol, 2, tr_solver)
     rounds = (RoundReport * (num_adjustments + 1))()
     mask = np.empty(self.shape, dtype=np.bool_)
     oq, of = outlier if outlier is not None else (0.0, -1.0)
@@ -459,9 +463,12 @@ class Handle(object):
     check(self.lib.mcba_rccl_shutdown(self.h))
 
   def solve(self, x0, tolerance=1e-4, f_scale=1.0, max_iterations=100, loss='linear', xtol=1e-8, gtol=1e-8,
-            verbose=2):
+            verbose=2, tr_solver='exact'):
+    """mcba_solve.  tr_solver = 'exact': regularised Gauss-Newton steps from the exact normal equations (Schur + Cholesky):
+    fast, ends at the converged optimum.  tr_solver = 'lsmr': scipy's own trust-region step gn_h = lsmr(J_h, f, damp) with the
+    Jacobian products on the device: the reference's trajectory and end point."""
     x = self._x(x0).copy()
-    opt = make_options(tolerance, f_scale, max_iterations, loss, xtol, gtol, verbose)
+    opt = make_options(tolerance, f_scale, max_iterations, loss, xtol, gtol, verbose, tr_solver)
     res = Result()
     check(self.lib.mcba_solve(self.h, _ptr(x, C.c_double), C.byref(opt), C.byref(res)))
     return SimpleNamespace(x=x, cost=res.cost, initial_cost=res.initial_cost, optimality=res.optimality,

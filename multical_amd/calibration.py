@@ -54,7 +54,10 @@ class LogWriter(object):
 #   "scipy"   the reference's own call scipy.optimize.least_squares(method='trf', x_scale='jac', ...) on mcba_residuals +
 #             mcba_jacobian (Handle.solve_scipy): the reference's trajectory and END POINT (1e-6 px, identical nfev / status
 #             wherever the reference reproduces itself to that level), at the price of scipy's host-side LSMR.
-SOLVERS = ("native", "scipy")
+#   "lsmr"    mcba_solve with scipy's OWN trust-region step on the device (tr_solver = lsmr): gn_h = lsmr(J_h, f, damp) with the
+#             two Jacobian products as HIP kernels and scipy's driver restated line by line -- the reference's trajectory and
+#             end point like "scipy", without the host-side LSMR (hours at the north-star rig).
+SOLVERS = ("native", "scipy", "lsmr")
 _default_solver = [os.environ.get("MULTICAL_AMD_SOLVER", "native").lower()]
 
 
@@ -330,7 +333,7 @@ class Calibration(parameters.Parameters):
                                                        "Step norm", "Optimality"))
     try:
       res = h.solve(self.param_vec, tolerance=tolerance, f_scale=f_scale, max_iterations=max_iterations, loss=loss,
-                    xtol=xtol, gtol=gtol, verbose=2)
+                    xtol=xtol, gtol=gtol, verbose=2, tr_solver="lsmr" if solver == "lsmr" else "exact")
     finally:
       h.set_log(None)        # cached handles outlive the call: do not keep the closure over `rows` installed
     for r in rows:
@@ -389,7 +392,8 @@ class Calibration(parameters.Parameters):
       x, rounds, mask = h.adjust_outliers(
         self.param_vec, num_adjustments,
         outlier=None if select_outliers is None else (select_outliers.quantile, select_outliers.factor),
-        scale=None if select_scale is None else (select_scale.quantile, select_scale.factor), **kwargs)
+        scale=None if select_scale is None else (select_scale.quantile, select_scale.factor),
+        tr_solver="lsmr" if get_solver() == "lsmr" else "exact", **kwargs)
     finally:
       h.set_log(None)
     tables, cur = [], None                      # the iteration rows of every solve (a solve starts with iteration 0)
@@ -436,7 +440,7 @@ class Calibration(parameters.Parameters):
   def adjust_outliers(self, num_adjustments=3, select_scale=None, select_outliers=None, **kwargs):
     info(f"Beginning adjustments ({num_adjustments}) enabled: {dict(self.optimize)}, options: {kwargs}")
     tagged = lambda f: f is None or (hasattr(f, "quantile") and hasattr(f, "factor"))
-    if (get_solver() == "native" and tagged(select_scale) and tagged(select_outliers) and not fused_outlier_loop_off()
+    if (get_solver() in ("native", "lsmr") and tagged(select_scale) and tagged(select_outliers) and not fused_outlier_loop_off()
         and set(kwargs) <= {"loss", "tolerance", "f_scale", "max_iterations", "xtol", "gtol"}):
       return self._adjust_outliers_in_one_call(num_adjustments, select_scale, select_outliers, kwargs)
     for i in range(num_adjustments):

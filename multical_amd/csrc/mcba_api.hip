@@ -271,6 +271,8 @@ struct mcba_handle_s {
   bool use_mfma = true;
   bool shard_root = true;
   DevBuf<double> comm;   // frame-sharded handles: [g_s | diag_s | cost, count | step norms] of the linearisation's message
+  // solver "lsmr": m-vectors u (bidiagonalisation), J_h g_h, J_h gn; per-view partials of J_h^T u; n-vectors v, v_raw, h, hbar, x
+  DevBuf<double> ls_u, ls_ua, ls_ub, ls_part, ls_v, ls_vraw, ls_h, ls_hbar, ls_x, ls_nrm, ls_partial, ls_out;
   ScalLayout sl;
   size_t asm_lds_set = 48 * 1024;
   size_t chol_lds3_set = 0, chol_lds5_set = 0;
@@ -1865,9 +1867,315 @@ int32_t mcba_debug_pipe_probe(int32_t iters, double* ms_out) {
   API_END
 }
 
+namespace {
+
+// scipy.sparse.linalg._isolve.lsmr._sym_ortho
+void sym_ortho(double a, double b, double& c, double& s, double& r) {
+  auto sign = [](double v) { return v > 0 ? 1.0 : (v < 0 ? -1.0 : 0.0); };
+  if (b == 0) { c = sign(a); s = 0; r = std::fabs(a); }
+  else if (a == 0) { c = 0; s = sign(b); r = std::fabs(b); }
+  else if (std::fabs(b) > std::fabs(a)) { const double tau = a / b; s = sign(b) / std::sqrt(1 + tau * tau); c = s * tau; r = b / s; }
+  else { const double tau = b / a; c = sign(a) / std::sqrt(1 + tau * tau); s = c * tau; r = a / c; }
+}
+
+struct LsmrOps {
+  mcba_handle_s* h;
+  int nblk;            // persistent single-wave workgroups of the two Jacobian products
+  int part_stride;
+  size_t m;
+  double fetch1(const double* dev) {
+    double v = 0.0;
+    HIP_OK(hipMemcpyAsync(h->h_scal, dev, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    sync(h);
+    v = h->h_scal[0];
+    return v;
+  }
+  double fold(double* part, int n) {   // sum of n partials (fixed order), one double back to the host
+    hipLaunchKernelGGL(k_dot, dim3(1), dim3(1024), 0, h->stream, (size_t)n, (const double*)part, (const double*)nullptr, h->ls_out.p, 0);
+    return fetch1(h->ls_out.p);
+  }
+  // u <- J_h v - alpha u (mode 0) | f (mode 1) | J_h v (mode 2); returns |u|^2
+  double jv(int mode, const double* vin, double alpha, double* u) {
+    h->ops->lsmr_jv(h->d, h->t, h->stream, h->view_first.p, mode, h->dsc.p, vin, alpha, u, h->ls_partial.p, nblk);
+    check_launch("k_lsmr_jv");
+    return fold(h->ls_partial.p, nblk);
+  }
+  // vout <- D J^T (u inv_beta) - beta vold (u normalised in place); returns |vout|^2
+  double jtu(double* u, double inv_beta, double beta, const double* vold, double* vout) {
+    h->ops->lsmr_jtu(h->d, h->t, h->stream, h->view_first.p, inv_beta, u, h->ls_part.p, part_stride, nblk);
+    hipLaunchKernelGGL(k_lsmr_gather, dim3(h->d.n), dim3(64), 0, h->stream, h->d, (const double*)h->ls_part.p, part_stride,
+                       (const double*)h->dsc.p, beta, vold, vout, h->ls_nrm.p);
+    check_launch("k_lsmr_jtu / k_lsmr_gather");
+    return fold(h->ls_nrm.p, h->d.n);
+  }
+};
+
+// scipy.sparse.linalg.lsmr(J_h, f, damp, atol = btol = 1e-6, conlim = 1e8, maxiter = min(m, n)) -- the call of trf.py:481 --
+// with the two products on the device and the scalar recurrences (lsmr.py:300-420, transcribed in order) on the host.
+// The solution is left in h->ls_x; returns the number of iterations, *istop_out = scipy's stopping reason.
+int lsmr_solve(LsmrOps& op, double damp, int* istop_out) {
+  mcba_handle_s* h = op.h;
+  const Dims& d = h->d;
+  const int n = d.n;
+  const double atol = 1e-6, btol = 1e-6, conlim = 1e8;
+  const long long maxiter = std::min<long long>((long long)op.m, (long long)(h->ext2int.empty() ? n : h->n_ext));
+  const int nvb = (n + 255) / 256;
+  double* u = h->ls_u.p;
+  double* v = h->ls_v.p;
+  double* vraw = h->ls_vraw.p;
+  HIP_OK(hipMemsetAsync(h->ls_x.p, 0, (size_t)n * sizeof(double), h->stream));
+  HIP_OK(hipMemsetAsync(h->ls_hbar.p, 0, (size_t)n * sizeof(double), h->stream));
+  HIP_OK(hipMemsetAsync(v, 0, (size_t)n * sizeof(double), h->stream));
+  const double normb = std::sqrt(op.jv(1, nullptr, 0.0, u));     // u = b = f
+  double beta = normb, alpha = 0.0;
+  if (beta > 0) {
+    alpha = std::sqrt(op.jtu(u, 1.0 / beta, 0.0, v, vraw));       // v = A^T u (u normalised in place)
+    std::swap(v, vraw);
+  }
+  if (alpha > 0) hipLaunchKernelGGL(k_scale_to, dim3(nvb), dim3(256), 0, h->stream, n, 1.0 / alpha, (const double*)v, v);
+  HIP_OK(hipMemcpyAsync(h->ls_h.p, v, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  int itn = 0, istop = 0;
+  double zetabar = alpha * beta, alphabar = alpha, rho = 1, rhobar = 1, cbar = 1, sbar = 0;
+  double betadd = beta, betad = 0, rhodold = 1, tautildeold = 0, thetatilde = 0, zeta = 0, dd = 0;
+  double normA2 = alpha * alpha, maxrbar = 0, minrbar = 1e+100, normA = std::sqrt(normA2), condA = 1, normx = 0;
+  const double ctol = conlim > 0 ? 1 / conlim : 0;
+  double normr = beta, normar = alpha * beta;
+  if (normar == 0 || normb == 0) {   // x = 0 is the exact solution
+    *istop_out = 0;
+    if (v != h->ls_v.p) std::swap(h->ls_v.p, h->ls_vraw.p);
+    return 0;
+  }
+  while (itn < maxiter) {
+    ++itn;
+    beta = std::sqrt(op.jv(0, v, alpha, u));                      // u = A v - alpha u
+    double inv_alpha = 1.0;
+    if (beta > 0) {
+      alpha = std::sqrt(op.jtu(u, 1.0 / beta, beta, v, vraw));    // v = A^T u - beta v
+      std::swap(v, vraw);
+      if (alpha > 0) inv_alpha = 1.0 / alpha;
+    }
+    double chat, shat, alphahat;
+    sym_ortho(alphabar, damp, chat, shat, alphahat);
+    const double rhoold = rho;
+    double c, sn;
+    sym_ortho(alphahat, beta, c, sn, rho);
+    const double thetanew = sn * alpha;
+    alphabar = c * alpha;
+    const double rhobarold = rhobar, zetaold = zeta;
+    const double thetabar = sbar * rho, rhotemp = cbar * rho;
+    sym_ortho(cbar * rho, thetanew, cbar, sbar, rhobar);
+    zeta = cbar * zetabar;
+    zetabar = -sbar * zetabar;
+    hipLaunchKernelGGL(k_lsmr_update, dim3(nvb), dim3(256), 0, h->stream, n, inv_alpha, -(thetabar * rho / (rhoold * rhobarold)),
+                       zeta / (rho * rhobar), -(thetanew / rho), v, h->ls_hbar.p, h->ls_x.p, h->ls_h.p, h->ls_nrm.p);
+    const double betaacute = chat * betadd, betacheck = -shat * betadd;
+    const double betahat = c * betaacute;
+    betadd = -sn * betaacute;
+    const double thetatildeold = thetatilde;
+    double ctildeold, stildeold, rhotildeold;
+    sym_ortho(rhodold, thetabar, ctildeold, stildeold, rhotildeold);
+    thetatilde = stildeold * rhobar;
+    rhodold = ctildeold * rhobar;
+    betad = -stildeold * betad + ctildeold * betahat;
+    tautildeold = (zetaold - thetatildeold * tautildeold) / rhotildeold;
+    const double taud = (zeta - thetatilde * tautildeold) / rhodold;
+    dd = dd + betacheck * betacheck;
+    normr = std::sqrt(dd + (betad - taud) * (betad - taud) + betadd * betadd);
+    normA2 = normA2 + beta * beta;
+    normA = std::sqrt(normA2);
+    normA2 = normA2 + alpha * alpha;
+    maxrbar = std::max(maxrbar, rhobarold);
+    if (itn > 1) minrbar = std::min(minrbar, rhobarold);
+    condA = std::max(maxrbar, rhotemp) / std::min(minrbar, rhotemp);
+    normar = std::fabs(zetabar);
+    normx = std::sqrt(op.fold(h->ls_nrm.p, n));
+    const double test1 = normr / normb;
+    const double test2 = (normA * normr) != 0 ? normar / (normA * normr) : INFINITY;
+    const double test3 = 1 / condA;
+    const double t1 = test1 / (1 + normA * normx / normb);
+    const double rtol = btol + atol * normA * normx / normb;
+    if (itn >= maxiter) istop = 7;
+    if (1 + test3 <= 1) istop = 6;
+    if (1 + test2 <= 1) istop = 5;
+    if (1 + t1 <= 1) istop = 4;
+    if (test3 <= ctol) istop = 3;
+    if (test2 <= atol) istop = 2;
+    if (test1 <= rtol) istop = 1;
+    if (istop > 0) break;
+  }
+  if (v != h->ls_v.p) std::swap(h->ls_v.p, h->ls_vraw.p);   // (the handle's buffers keep their roles for the next call)
+  *istop_out = istop;
+  return itn;
+}
+
+}  // namespace
+
+/* scipy.optimize.least_squares(method='trf', tr_solver='lsmr', x_scale='jac') -- the reference's solver (calibration.py:209-210;
+ * scipy picks 'lsmr' for a sparse Jacobian) -- with every product on the device: opt->tr_solver == MCBA_TR_LSMR.  The driver is
+ * scipy's trf_no_bounds line by line (trf.py:401-560): Jacobian scaling, Cauchy regularisation, gn_h = lsmr(J_h, f, damp), the
+ * 2-D subspace {g_h, gn_h} with B_S from the products J_h g_h and J_h gn_h, radius update, termination tests.  Unlike the exact
+ * Schur / Cholesky steps of the default driver, the LSMR-truncated steps reproduce the reference's trajectory and END POINT.     */
+static void solve_lsmr(mcba_handle h, double* x_inout, const mcba_options* opt, mcba_result* result) {
+  const double t_start = now_seconds();
+  const Dims& d = h->d;
+  if (h->allreduce) throw Error("the lsmr trust-region solver is not available for frame-sharded handles");
+  if (d.off_boards >= 0) throw Error("the lsmr trust-region solver does not cover adjusted board points (boards=True)");
+  const ScalLayout& sl = h->sl;
+  const double ftol = opt->ftol, xtol = opt->xtol, gtol = opt->gtol;
+  const int max_nfev = opt->max_nfev > 0 ? opt->max_nfev : d.n * 100;
+  const double NaN = std::numeric_limits<double>::quiet_NaN();
+  double* S = h->h_scal;
+  ensure_view_first(h);
+  const size_t m = 2 * (size_t)h->n_inliers;
+  const int NL = 6 * d.NPB + d.KI;
+  LsmrOps op{h, std::max(1, std::min(2048, d.views())), (NL + 1) & ~1, m};
+  for (DevBuf<double>* b : {&h->ls_u, &h->ls_ua, &h->ls_ub})
+    if (b->n < std::max<size_t>(m, 2)) b->alloc(std::max<size_t>(m, 2), false);
+  if (h->ls_part.n < (size_t)std::max(d.views(), 1) * op.part_stride) h->ls_part.alloc((size_t)std::max(d.views(), 1) * op.part_stride, true);
+  else HIP_OK(hipMemsetAsync(h->ls_part.p, 0, h->ls_part.n * sizeof(double), h->stream));
+  for (DevBuf<double>* b : {&h->ls_v, &h->ls_vraw, &h->ls_h, &h->ls_hbar, &h->ls_x, &h->ls_nrm})
+    if (b->n < (size_t)d.n) b->alloc((size_t)d.n, true);
+  if (h->ls_partial.n < (size_t)op.nblk) h->ls_partial.alloc((size_t)op.nblk, false);
+  if (h->ls_out.n < 4) h->ls_out.alloc(4, false);
+
+  upload_x(h, x_inout, h->x.p);
+  float lin_ms_total = 0.f;
+  auto linearize = [&](const double* dx) {   // g, diag, cost at dx + every table the two products read (view chains, That)
+    launch_linearize(h, dx);
+    launch_assemble(h);
+    const int nvw = d.views() * (d.motion == MOTION_ROLLING ? 2 : 1);
+    if (nvw > 0) hipLaunchKernelGGL(k_views, dim3((nvw + 127) / 128), dim3(128), 0, h->stream, d, h->t);
+    const int nb_views = std::max((d.views() + TMV - 1) / TMV, 1);
+    if (tmat_local_poses(d) <= TM_LOCAL_POSES)
+      hipLaunchKernelGGL(k_tmat<true>, dim3(nb_views), dim3(TM_THREADS), 0, h->stream, d, h->t, (double*)nullptr, 0, (double*)nullptr, 0,
+                         (const double*)nullptr, nb_views);
+    else
+      hipLaunchKernelGGL(k_tmat<false>, dim3(nb_views), dim3(TM_THREADS), 0, h->stream, d, h->t, (double*)nullptr, 0, (double*)nullptr, 0,
+                         (const double*)nullptr, nb_views);
+    check_launch("linearisation");
+  };
+  const int prep_blocks = (d.n_pose + d.C + d.B * d.P + 255) / 256;
+  const int cost_grid = h->cost_blocks;
+  linearize(h->x.p);
+  int nfev = 1, njev = 1, iteration = 0, status = -100;
+  bool first = true;
+  double cost = 0, Delta = 0, step_norm = NaN, actual_reduction = NaN, g_norm = 0, initial_cost = 0;
+  long long lsmr_iterations = 0;
+  while (true) {
+    hipLaunchKernelGGL(k_vec_scale, dim3(sl.nvb), dim3(256), 0, h->stream, d, h->x.p, h->g(), h->diag(), h->scale_inv.p, h->dsc.p,
+                       h->gh.p, first ? 1 : 0, h->scal.p + sl.vs, h->costcount(), h->scal.p + TR_COST);
+    fetch_scalars(h, sl.q00p);
+    double mx = 0, gg = 0, xs = 0;
+    for (int blk = 0; blk < sl.nvb; ++blk) {
+      mx = std::max(mx, S[sl.vs + 3 * blk]);
+      gg += S[sl.vs + 3 * blk + 1];
+      xs += S[sl.vs + 3 * blk + 2];
+    }
+    g_norm = mx;
+    if (first) {
+      cost = S[TR_COST];
+      initial_cost = cost;
+      if (!std::isfinite(cost)) throw Error("Residuals are not finite in the initial point.");   // scipy least_squares.py:844-845
+      Delta = std::sqrt(xs);
+      if (Delta == 0) Delta = 1.0;
+      first = false;
+    }
+    if (g_norm < gtol) status = 1;
+    if (h->log && opt->verbose >= 2) h->log(h->log_ctx, iteration, nfev, cost, actual_reduction, step_norm, g_norm);
+    if (status != -100 || nfev >= max_nfev) break;
+
+    // ---- trf.py:474-489 ------------------------------------------------------------------------------------------
+    const double Q00 = op.jv(2, h->gh.p, 0.0, h->ls_ua.p);                       // |J_h g_h|^2 (build_quadratic_1d)
+    const double reg_term = gg > 0 ? tr_reg_term(Q00, gg, Delta, 0.0) : 0.0;
+    int istop = 0;
+    const int itn = lsmr_solve(op, std::sqrt(reg_term), &istop);
+    lsmr_iterations += itn;
+    if (getenv("MCBA_SOLVE_TRACE") != nullptr)
+      fprintf(stderr, "[mcba_solve lsmr] iteration %d: Delta %.17g reg_term %.17g -> lsmr itn %d istop %d\n", iteration, Delta, reg_term,
+              itn, istop);
+    HIP_OK(hipMemcpyAsync(h->gn.p, h->ls_x.p, (size_t)d.n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    op.jv(2, h->gn.p, 0.0, h->ls_ub.p);
+    hipLaunchKernelGGL(k_dot, dim3(1), dim3(1024), 0, h->stream, m, (const double*)h->ls_ua.p, (const double*)h->ls_ub.p, h->ls_out.p, 1);
+    hipLaunchKernelGGL(k_dot, dim3(1), dim3(1024), 0, h->stream, (size_t)d.n, (const double*)h->gh.p, (const double*)h->gn.p,
+                       h->scal.p + TR_D00, 1);   // [g_h.gn | g_h.g_h | gn.gn] -> reordered below
+    double q3[3], d3[3];
+    HIP_OK(hipMemcpyAsync(q3, h->ls_out.p, sizeof(q3), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipMemcpyAsync(d3, h->scal.p + TR_D00, sizeof(d3), hipMemcpyDeviceToHost, h->stream));
+    sync(h);
+    S[TR_REG] = reg_term;
+    S[TR_Q00] = q3[1];
+    S[TR_D00] = d3[1]; S[TR_D01] = d3[0]; S[TR_D11] = d3[2];
+    S[TR_GNORM] = g_norm; S[TR_GH2] = gg; S[TR_XS2] = xs;
+    tr_subspace(S, true, q3[0], q3[2]);
+
+    actual_reduction = -1;
+    double cost_new = cost, ratio = 0;
+    while (actual_reduction <= 0 && nfev < max_nfev) {
+      tr_trial(S, Delta);
+      hipLaunchKernelGGL(k_vec_step, dim3(sl.nvb + prep_blocks), dim3(256), 0, h->stream, d, h->t, h->x.p, h->dsc.p, h->gh.p, h->gn.p,
+                         S[TR_ALPHA], S[TR_BETA], h->xnew.p, h->scal.p + sl.step, (double*)nullptr, h->scal.p + sl.dotp, 0, sl.nvb,
+                         (double*)nullptr, (double*)nullptr);
+      h->ops->cost(d, h->t, h->stream, h->scal.p + sl.costp, cost_grid);
+      fetch_scalars(h, sl.costp + cost_grid - sl.step, sl.step);
+      double s3[3] = {0, 0, 0};
+      for (int blk = 0; blk < sl.nvb; ++blk)
+        for (int k = 0; k < 3; ++k) s3[k] += S[sl.step + 3 * blk + k];
+      cost_new = host_sum(S + sl.costp, cost_grid);
+      const double predicted = S[TR_PRED];
+      ++nfev;
+      const double step_h_norm = std::sqrt(s3[0]);
+      if (!std::isfinite(cost_new)) {
+        Delta = 0.25 * step_h_norm;
+        continue;
+      }
+      actual_reduction = cost - cost_new;
+      double Delta_new = Delta;
+      tr_update_radius(Delta_new, actual_reduction, predicted, step_h_norm, step_h_norm > 0.95 * Delta, ratio);
+      step_norm = std::sqrt(s3[1]);
+      status = tr_check_termination(actual_reduction, cost, step_norm, std::sqrt(s3[2]), ratio, ftol, xtol);
+      if (status != -100) break;
+      Delta = Delta_new;
+    }
+    if (actual_reduction > 0) {
+      std::swap(h->x.p, h->xnew.p);
+      cost = cost_new;
+      linearize(h->x.p);
+      ++njev;
+    } else {
+      step_norm = 0;
+      actual_reduction = 0;
+    }
+    ++iteration;
+  }
+  if (status == -100) status = 0;
+  if (getenv("MCBA_SOLVE_TRACE") != nullptr)
+    fprintf(stderr, "[mcba_solve lsmr] %d trial steps, %lld LSMR iterations, %.3f ms\n", nfev - 1, lsmr_iterations,
+            (now_seconds() - t_start) * 1e3);
+  HIP_OK(hipMemcpyAsync(h->h_x, h->x.p, (size_t)d.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  sync(h);
+  to_caller(h, x_inout, h->h_x);
+  if (result) {
+    result->cost = cost;
+    result->initial_cost = initial_cost;
+    result->optimality = g_norm;
+    result->nfev = nfev;
+    result->njev = njev;
+    result->status = status;
+    result->iterations = iteration;
+    result->solve_seconds = now_seconds() - t_start;
+    result->linearize_seconds = lin_ms_total * 1e-3;
+  }
+}
+
 int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba_result* result) {
   API_BEGIN
   REQUIRE(h && x_inout && opt, "null argument");
+  if (opt->tr_solver == MCBA_TR_LSMR) {
+    set_loss(h, opt);
+    solve_lsmr(h, x_inout, opt, result);
+    return 0;
+  }
+  REQUIRE(opt->tr_solver == MCBA_TR_EXACT, "unknown trust-region solver");
   const double t_start = now_seconds();
   set_loss(h, opt);
   const Dims& d = h->d;

@@ -101,7 +101,49 @@ void points(const Dims& d, const Tables& t, hipStream_t s, int nq, double* Hss, 
   else pts1<MOTION_HAND_EYE>(d, t, s, nq, Hss, Hfs, g);
 }
 
-const CamOps OPS = {residual, project_model, cost, jacobian, linearize, points};
+template <int MOTION, bool OPTK>
+void jv2(const Dims& d, const Tables& t, hipStream_t s, const int32_t* first, int mode, const double* dscale, const double* v,
+         double alpha, double* u, double* partial, int nblk) {
+  if (d.loss != 0)
+    hipLaunchKernelGGL((k_lsmr_jv<ND_, FISH_, MOTION, OPTK, true>), dim3(nblk), dim3(64), 0, s, d, t, first, mode, dscale, v, alpha, u, partial);
+  else
+    hipLaunchKernelGGL((k_lsmr_jv<ND_, FISH_, MOTION, OPTK, false>), dim3(nblk), dim3(64), 0, s, d, t, first, mode, dscale, v, alpha, u, partial);
+}
+template <int MOTION>
+void jv1(const Dims& d, const Tables& t, hipStream_t s, const int32_t* first, int mode, const double* dscale, const double* v,
+         double alpha, double* u, double* partial, int nblk) {
+  if (d.KI > 0) jv2<MOTION, true>(d, t, s, first, mode, dscale, v, alpha, u, partial, nblk);
+  else jv2<MOTION, false>(d, t, s, first, mode, dscale, v, alpha, u, partial, nblk);
+}
+void lsmr_jv(const Dims& d, const Tables& t, hipStream_t s, const int32_t* first, int mode, const double* dscale, const double* v,
+             double alpha, double* u, double* partial, int nblk) {
+  if (d.motion == MOTION_STATIC) jv1<MOTION_STATIC>(d, t, s, first, mode, dscale, v, alpha, u, partial, nblk);
+  else if (d.motion == MOTION_ROLLING) jv1<MOTION_ROLLING>(d, t, s, first, mode, dscale, v, alpha, u, partial, nblk);
+  else jv1<MOTION_HAND_EYE>(d, t, s, first, mode, dscale, v, alpha, u, partial, nblk);
+}
+
+template <int MOTION, bool OPTK>
+void jtu2(const Dims& d, const Tables& t, hipStream_t s, const int32_t* first, double inv_beta, double* u, double* part,
+          int part_stride, int nblk) {
+  if (d.loss != 0)
+    hipLaunchKernelGGL((k_lsmr_jtu<ND_, FISH_, MOTION, OPTK, true>), dim3(nblk), dim3(64), 0, s, d, t, first, inv_beta, u, part, part_stride);
+  else
+    hipLaunchKernelGGL((k_lsmr_jtu<ND_, FISH_, MOTION, OPTK, false>), dim3(nblk), dim3(64), 0, s, d, t, first, inv_beta, u, part, part_stride);
+}
+template <int MOTION>
+void jtu1(const Dims& d, const Tables& t, hipStream_t s, const int32_t* first, double inv_beta, double* u, double* part,
+          int part_stride, int nblk) {
+  if (d.KI > 0) jtu2<MOTION, true>(d, t, s, first, inv_beta, u, part, part_stride, nblk);
+  else jtu2<MOTION, false>(d, t, s, first, inv_beta, u, part, part_stride, nblk);
+}
+void lsmr_jtu(const Dims& d, const Tables& t, hipStream_t s, const int32_t* first, double inv_beta, double* u, double* part,
+              int part_stride, int nblk) {
+  if (d.motion == MOTION_STATIC) jtu1<MOTION_STATIC>(d, t, s, first, inv_beta, u, part, part_stride, nblk);
+  else if (d.motion == MOTION_ROLLING) jtu1<MOTION_ROLLING>(d, t, s, first, inv_beta, u, part, part_stride, nblk);
+  else jtu1<MOTION_HAND_EYE>(d, t, s, first, inv_beta, u, part, part_stride, nblk);
+}
+
+const CamOps OPS = {residual, project_model, cost, jacobian, linearize, points, lsmr_jv, lsmr_jtu};
 
 }  // namespace
 

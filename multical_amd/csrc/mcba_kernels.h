@@ -417,6 +417,179 @@ __global__ __launch_bounds__(64) void k_cost(Dims d, Tables t, double* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// k_lsmr_jv / k_lsmr_jtu: the two products of the Golub-Kahan bidiagonalisation with the column-scaled Jacobian
+// J_h = J diag(dscale), matrix-free (solver = "lsmr": scipy's TRF with its LSMR trust-region solver, trf.py:474-489, run on the
+// device so that the reference's own steps -- not exact normal-equation steps -- are taken).  Both walk the compact list of
+// non-empty views with persistent single-wave workgroups like k_cost: the inlier bytes of a view are ballot-compacted, every
+// lane re-evaluates the forward model and the analytic row pair V = [E | K | r] of its observation (point_state / point_row:
+// the rows k_linearize accumulates), and the pose part goes through the view's That (k_tmat's table):
+//   J_h v  (row a of observation p)  =  E_a . (That vp) + K_a . vK,     vp / vK = the view's scaled local parameters
+//   J_h^T u (per view)               =  That^T (sum_p E_p^T u_p)  |  sum_p K_p^T u_p,   reduced over the views by k_lsmr_gather
+// Vectors of length m live in the residual order (first[v] + position in the view's list).
+//   k_lsmr_jv mode 0:  u <- J_h v - alpha u      mode 1:  u <- f  (the loss-scaled residual vector, LSMR's b)      mode 2:  u <- J_h v
+//   partial[blockIdx.x] = sum of squares of what this workgroup wrote
+// ---------------------------------------------------------------------------------------------------------------
+template <int ND, int FISH, int MOTION, bool OPTK, bool ROBUST>
+__global__ __launch_bounds__(64) void k_lsmr_jv(Dims d, Tables t, const int32_t* __restrict__ first, int mode,
+                                                const double* __restrict__ dscale, const double* __restrict__ vin, double alpha,
+                                                double* __restrict__ u, double* __restrict__ partial) {
+  constexpr bool ROLL = MOTION == MOTION_ROLLING;
+  constexpr int DE = ROLL ? 12 : 6, NPB = MOTION == MOTION_STATIC ? 3 : 4, NPC = 6 * NPB, KI = OPTK ? 4 + ND : 0;
+  constexpr int NV = DE + KI + 1;
+  __shared__ uint16_t pidx[LIN_MAX_POINTS];
+  __shared__ double vp[NPC], wl[DE + KI + 1];
+  const int lane = threadIdx.x;
+  const int n_active = t.active_views[0];
+  double acc = 0.0;
+  for (int vi = blockIdx.x; vi < n_active; vi += gridDim.x) {
+    const int v = t.active_views[1 + vi];
+    if (v < 0) continue;
+    const int b = v % d.B, c = (v / d.B) % d.C, f = d.f0 + v / (d.B * d.C);
+    if (mode != 1) {   // the view's scaled local parameter vector, then w = That vp
+      if (lane < NPC + KI) {
+        const int xi = local_to_x(d, f, c, b, lane);
+        const double val = xi >= 0 ? dscale[xi] * vin[xi] : 0.0;
+        if (lane < NPC) vp[lane] = val; else wl[DE + lane - NPC] = val;
+      }
+      lds_fence();
+      if (lane < DE) {
+        const double* Tm = t.tmat + (size_t)v * (DE * NPC) + lane * NPC;
+        double sum = 0.0;
+#pragma unroll
+        for (int j = 0; j < NPC; ++j) sum += Tm[j] * vp[j];
+        wl[lane] = sum;
+      }
+      lds_fence();
+    }
+    size_t out0 = (size_t)first[v];
+    constexpr int NPB64 = LIN_MAX_POINTS / 64;
+    for (int seg0 = 0; seg0 < d.P; seg0 += LIN_MAX_POINTS) {
+      uint8_t inb[NPB64];
+#pragma unroll
+      for (int k = 0; k < NPB64; ++k) inb[k] = masked_load_row(t.inlier + (size_t)v * d.P, seg0 + k * 64 + lane, d.P);
+      int count = 0;
+#pragma unroll
+      for (int k = 0; k < NPB64; ++k) {
+        const bool in = inb[k] != 0;
+        const unsigned long long m = __ballot(in);
+        if (in) pidx[count + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(seg0 + k * 64 + lane);
+        count += __popcll(m);
+      }
+      lds_fence();
+      for (int base = 0; base < count; base += 64) {
+        const int i = base + lane;
+        if (i < count) {
+          const int p = pidx[i];
+          PointState<ND, ROLL> ps;
+          point_state<ND, FISH, ROLL, ROBUST>(d, t, v, c, b, p, t.obs[(size_t)v * d.P + p], ps);
+          double2 o;
+          double2 old;
+          old.x = old.y = 0.0;
+          if (mode == 0) old = reinterpret_cast<const double2*>(u)[out0 + i];
+#pragma unroll
+          for (int a = 0; a < 2; ++a) {
+            double row[NV];
+            point_row<ND, ROLL, OPTK>(ps, a, row);
+            double val;
+            if (mode != 1) {
+              val = 0.0;
+#pragma unroll
+              for (int k = 0; k < DE + KI; ++k) val += row[k] * wl[k];
+              val -= alpha * (a == 0 ? old.x : old.y);
+            } else {
+              val = row[NV - 1];
+            }
+            if (a == 0) o.x = val; else o.y = val;
+          }
+          reinterpret_cast<double2*>(u)[out0 + i] = o;
+          acc += o.x * o.x + o.y * o.y;
+        }
+      }
+      out0 += (size_t)count;
+      lds_fence();
+    }
+  }
+  const double tot = wave_sum(acc);
+  if (lane == 0) partial[blockIdx.x] = tot;
+}
+
+// per view: part[v][0 .. NPC + KI) = [That^T sum_p E_p^T u_p | sum_p K_p^T u_p] with u <- u * inv_beta (normalised in place)
+template <int ND, int FISH, int MOTION, bool OPTK, bool ROBUST>
+__global__ __launch_bounds__(64) void k_lsmr_jtu(Dims d, Tables t, const int32_t* __restrict__ first, double inv_beta,
+                                                 double* __restrict__ u, double* __restrict__ part, int part_stride) {
+  constexpr bool ROLL = MOTION == MOTION_ROLLING;
+  constexpr int DE = ROLL ? 12 : 6, NPB = MOTION == MOTION_STATIC ? 3 : 4, NPC = 6 * NPB, KI = OPTK ? 4 + ND : 0;
+  constexpr int NV = DE + KI + 1, NS = DE + KI;
+  __shared__ uint16_t pidx[LIN_MAX_POINTS];
+  __shared__ double sl[NS];
+  const int lane = threadIdx.x;
+  const int n_active = t.active_views[0];
+  for (int vi = blockIdx.x; vi < n_active; vi += gridDim.x) {
+    const int v = t.active_views[1 + vi];
+    if (v < 0) continue;
+    const int b = v % d.B, c = (v / d.B) % d.C;
+    double sums[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) sums[k] = 0.0;
+    size_t out0 = (size_t)first[v];
+    constexpr int NPB64 = LIN_MAX_POINTS / 64;
+    for (int seg0 = 0; seg0 < d.P; seg0 += LIN_MAX_POINTS) {
+      uint8_t inb[NPB64];
+#pragma unroll
+      for (int k = 0; k < NPB64; ++k) inb[k] = masked_load_row(t.inlier + (size_t)v * d.P, seg0 + k * 64 + lane, d.P);
+      int count = 0;
+#pragma unroll
+      for (int k = 0; k < NPB64; ++k) {
+        const bool in = inb[k] != 0;
+        const unsigned long long m = __ballot(in);
+        if (in) pidx[count + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(seg0 + k * 64 + lane);
+        count += __popcll(m);
+      }
+      lds_fence();
+      for (int base = 0; base < count; base += 64) {
+        const int i = base + lane;
+        if (i < count) {
+          const int p = pidx[i];
+          PointState<ND, ROLL> ps;
+          point_state<ND, FISH, ROLL, ROBUST>(d, t, v, c, b, p, t.obs[(size_t)v * d.P + p], ps);
+          double2 uu = reinterpret_cast<const double2*>(u)[out0 + i];
+          uu.x *= inv_beta;
+          uu.y *= inv_beta;
+          reinterpret_cast<double2*>(u)[out0 + i] = uu;
+#pragma unroll
+          for (int a = 0; a < 2; ++a) {
+            double row[NV];
+            point_row<ND, ROLL, OPTK>(ps, a, row);
+            const double w = a == 0 ? uu.x : uu.y;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) sums[k] += row[k] * w;
+          }
+        }
+      }
+      out0 += (size_t)count;
+      lds_fence();
+    }
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      const double tot = wave_sum(sums[k]);
+      if (lane == 0) sl[k] = tot;
+    }
+    lds_fence();
+    double* out = part + (size_t)v * part_stride;
+    if (lane < NPC) {
+      const double* Tm = t.tmat + (size_t)v * (DE * NPC);
+      double sum = 0.0;
+#pragma unroll
+      for (int a = 0; a < DE; ++a) sum += Tm[a * NPC + lane] * sl[a];
+      out[lane] = sum;
+    } else if (lane < NPC + KI) {
+      out[lane] = sl[DE + lane - NPC];
+    }
+    lds_fence();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // k_jacobian: analytic Jacobian rows in the column order of Calibration.sparsity_matrix
 //             (optimization/calibration.py:173-196).  One thread per inlier observation (not a hot path).
 // ---------------------------------------------------------------------------------------------------------------

@@ -2132,6 +2132,98 @@ __global__ __launch_bounds__(64) void k_fold_partials(double* __restrict__ part,
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// solver = "lsmr" (scipy's TRF with its LSMR trust-region solver on the device): the reduction of the per-view partials of
+// J_h^T u (k_lsmr_jtu) to the n entries of the vector, and the vector updates of the LSMR iteration.
+// ---------------------------------------------------------------------------------------------------------------
+// vout[i] = dscale[i] * (sum over the views that contain parameter i of part[view][local index]) - beta * vold[i];
+// one wavefront per entry, fixed summation order; nrm[i] = vout[i]^2 (folded afterwards)
+__global__ __launch_bounds__(64) void k_lsmr_gather(Dims d, const double* __restrict__ part, int part_stride,
+                                                    const double* __restrict__ dscale, double beta, const double* __restrict__ vold,
+                                                    double* __restrict__ vout, double* __restrict__ nrm) {
+  const int i = blockIdx.x, lane = threadIdx.x;
+  if (i >= d.n) return;
+  const int CB = d.C * d.B, npc = 6 * d.NPB;
+  int base = 0, na = 0, sa = 0, nb = 1, sb = 0, local = -1;
+  if (d.off_campose >= 0 && i >= d.off_campose && i < d.off_campose + 6 * d.C) {
+    const int q = i - d.off_campose, c = q / 6;
+    local = q % 6; base = c * d.B; na = d.Fl; sa = CB; nb = d.B; sb = 1;
+  } else if (d.off_boardpose >= 0 && i >= d.off_boardpose && i < d.off_boardpose + 6 * d.B) {
+    const int q = i - d.off_boardpose, b = q / 6;
+    local = 6 * (d.NPB - 1) + q % 6; base = b; na = d.Fl; sa = CB; nb = d.C; sb = d.B;
+  } else if (d.off_motion >= 0 && i >= d.off_motion && i < d.off_motion + d.n_motion) {
+    const int q = i - d.off_motion;
+    if (d.motion == MOTION_HAND_EYE) {
+      local = 6 + q; base = 0; na = d.views(); sa = 1;
+    } else {
+      const int chain = (d.motion == MOTION_ROLLING && q >= 6 * d.F) ? 1 : 0, qq = q - chain * 6 * d.F, f = qq / 6;
+      if (f >= d.f0 && f < d.f0 + d.Fl) { local = 6 + 6 * chain + qq % 6; base = (f - d.f0) * CB; na = d.C; sa = d.B; nb = d.B; sb = 1; }
+    }
+  } else if (d.off_cameras >= 0 && i >= d.off_cameras && i < d.off_cameras + d.C * (5 + d.ND)) {
+    const int q = i - d.off_cameras, c = q / (5 + d.ND), qq = q % (5 + d.ND);
+    const int lq = qq < 4 ? qq : qq - 1;
+    const bool masked = d.cam_kmask != nullptr && ((d.cam_kmask[c] >> lq) & 1u);
+    if (qq != 4 && !masked && d.KI > 0) { local = npc + lq; base = c * d.B; na = d.Fl; sa = CB; nb = d.B; sb = 1; }
+  }
+  double sum = 0.0;
+  if (local >= 0) {
+    const int total = na * nb;
+    for (int e = lane; e < total; e += 64) {
+      const int a = e / nb, b_ = e - a * nb;
+      sum += part[(size_t)(base + a * sa + b_ * sb) * part_stride + local];
+    }
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) {
+    const double val = dscale[i] * sum - beta * vold[i];
+    vout[i] = val;
+    nrm[i] = val * val;
+  }
+}
+
+// v <- v_raw * inv_alpha;  hbar <- c_hbar hbar + h;  x <- x + c_x hbar;  h <- c_h h + v;  nrm[i] = x[i]^2
+// (lsmr.py: "Update h, h_hat, x" with the normalisation of v folded in)
+__global__ __launch_bounds__(256) void k_lsmr_update(int n, double inv_alpha, double c_hbar, double c_x, double c_h,
+                                                     double* __restrict__ v, double* __restrict__ hbar, double* __restrict__ x,
+                                                     double* __restrict__ h, double* __restrict__ nrm) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double vi = v[i] * inv_alpha;
+  v[i] = vi;
+  const double hb = c_hbar * hbar[i] + h[i];
+  hbar[i] = hb;
+  const double xi = x[i] + c_x * hb;
+  x[i] = xi;
+  h[i] = c_h * h[i] + vi;
+  nrm[i] = xi * xi;
+}
+
+// out[0] = sum a[i] b[i] (one workgroup, fixed order); out[1] = sum a[i]^2, out[2] = sum b[i]^2 when three != 0
+__global__ __launch_bounds__(1024) void k_dot(size_t n, const double* __restrict__ a, const double* __restrict__ b,
+                                               double* __restrict__ out, int three) {
+  __shared__ double scratch[16];
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  for (size_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const double x = a[i], y = b ? b[i] : 1.0;
+    s0 += x * y;
+    s1 += x * x;
+    s2 += y * y;
+  }
+  const double t0 = block_reduce<false>(s0, scratch);
+  const double t1 = block_reduce<false>(s1, scratch);
+  const double t2 = block_reduce<false>(s2, scratch);
+  if (threadIdx.x == 0) {
+    out[0] = t0;
+    if (three) { out[1] = t1; out[2] = t2; }
+  }
+}
+
+// y[i] = a * x[i] (+ y0 copy helpers of the driver)
+__global__ __launch_bounds__(256) void k_scale_to(int n, double a, const double* x, double* y) {   // (x may be y)
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = a * x[i];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Frame-sharded handles: the messages of the trust-region iteration.  No n-vector crosses the ranks: every
 // message is a handful of per-rank partial sums or the SHARED entries of [g | diag], independent of the number of frames.
 // Per-rank partials travel as "gather by sum": rank r writes its values into block r of a zeroed buffer, the all-reduce adds

@@ -57,11 +57,13 @@ MCBA_HD void tr_minimize_quadratic_1d(double a, double b, double lb, double ub, 
 }
 
 // damping of the Gauss-Newton step from the Cauchy step (trf.py:338-340, build_quadratic_1d + minimize_quadratic_1d)
-MCBA_HD double tr_reg_term(double q00, double gh2, double Delta) {
+// floor: the exact normal-equation solve needs a positive definite reduced system (no pose is fixed: gauge null space);
+// scipy's LSMR branch takes the value as it is (floor = 0)
+MCBA_HD double tr_reg_term(double q00, double gh2, double Delta, double floor = TR_REG_FLOOR) {
   double tmin, ag_value;
   tr_minimize_quadratic_1d(0.5 * q00, -gh2, 0.0, Delta / sqrt(gh2), &tmin, &ag_value);
   const double reg_term = -ag_value / (Delta * Delta);
-  return reg_term > TR_REG_FLOOR ? reg_term : TR_REG_FLOOR;
+  return reg_term > floor ? reg_term : floor;
 }
 
 // real roots of a polynomial of degree <= 4 (coefficients highest power first); Durand-Kerner + Newton polish
@@ -146,9 +148,11 @@ MCBA_HD void tr_solve_2d(const double B[3] /*b00,b01,b11*/, const double g[2], d
 // 2-D subspace model in an orthonormal basis [e0 e1] = [g_h gn] Cm of span{g_h, gn} (Gram-Schmidt on the Gram matrix);
 // the quadratic forms with gn follow from (H_h + reg I) gn = g_h:  g_h^T H_h gn = |g_h|^2 - reg g_h.gn,
 // gn^T H_h gn = g_h.gn - reg |gn|^2.  S is the TrSlot block: reads TR_Q00, TR_REG, TR_D00..TR_D11; writes BS, GS0, CM.
-MCBA_HD void tr_subspace(double* S) {
+// (explicit = true: gn is an INEXACT solution -- LSMR -- and the forms g_h^T H_h gn, gn^T H_h gn are supplied by the caller,
+//  computed from the products J_h g_h, J_h gn like scipy's B_S = (J_h S)^T (J_h S), trf.py:484-487)
+MCBA_HD void tr_subspace(double* S, bool explicit_forms = false, double Q01_in = 0.0, double Q11_in = 0.0) {
   const double reg = S[TR_REG], d00 = S[TR_D00], d01 = S[TR_D01], d11 = S[TR_D11];
-  const double Q00 = S[TR_Q00], Q01 = d00 - reg * d01, Q11 = d01 - reg * d11;
+  const double Q00 = S[TR_Q00], Q01 = explicit_forms ? Q01_in : d00 - reg * d01, Q11 = explicit_forms ? Q11_in : d01 - reg * d11;
   const double n0 = sqrt(d00);
   const double proj = d01 / d00;
   const double nw2 = d11 - proj * d01;

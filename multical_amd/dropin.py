@@ -30,12 +30,17 @@ def _format_row(it, nfev, cost, red, step, opt):
 def bundle_adjust(self, tolerance=1e-4, f_scale=1.0, max_iterations=100, loss='linear'):
   """Replacement body of multical.optimization.calibration.Calibration.bundle_adjust (same signature): the native solver
   (mcba_solve).  Ends at the converged optimum -- at or below the reference's end point."""
+  return _bundle_adjust_device(self, tolerance, f_scale, max_iterations, loss, 'exact')
+
+
+def _bundle_adjust_device(self, tolerance, f_scale, max_iterations, loss, _tr_solver):
   import logging
   log = logging.getLogger("calibration")        # multical/io/logging.py:11
   rows = []
   with Handle(lower(self)) as h:
     h.set_log(lambda *a: rows.append(_format_row(*a)))
-    res = h.solve(self.param_vec, tolerance=tolerance, f_scale=f_scale, max_iterations=max_iterations, loss=loss)
+    res = h.solve(self.param_vec, tolerance=tolerance, f_scale=f_scale, max_iterations=max_iterations, loss=loss,
+                  tr_solver=_tr_solver)
   log.info(_HEADER)
   for r in rows:
     log.info(r)
@@ -63,7 +68,14 @@ def bundle_adjust_scipy(self, tolerance=1e-4, f_scale=1.0, max_iterations=100, l
   return self.with_param_vec(res.x)
 
 
-MODES = {"native": bundle_adjust, "scipy": bundle_adjust_scipy}
+def bundle_adjust_lsmr(self, tolerance=1e-4, f_scale=1.0, max_iterations=100, loss='linear'):
+  """Replacement body of Calibration.bundle_adjust: mcba_solve with scipy's OWN trust-region step (tr_solver = lsmr) -- scipy's
+  TRF driver and its LSMR restated line by line, the two Jacobian products as HIP kernels: the reference's trajectory and end
+  point like `bundle_adjust_scipy`, everything on the device."""
+  return _bundle_adjust_device(self, tolerance, f_scale, max_iterations, loss, 'lsmr')
+
+
+MODES = {"native": bundle_adjust, "scipy": bundle_adjust_scipy, "lsmr": bundle_adjust_lsmr}
 
 
 def _reprojection_tables(self):
@@ -115,4 +127,6 @@ def install_from_env():
     return install()
   if backend in ("hip-scipy", "hip_scipy"):
     return install(mode="scipy")
+  if backend in ("hip-lsmr", "hip_lsmr"):
+    return install(mode="lsmr")
   return None
