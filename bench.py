@@ -122,6 +122,7 @@ def main():
   ap.add_argument("--no-solve", action="store_true")
   ap.add_argument("--solve-repeats", type=int, default=5, help="default-tolerance solves; the median is reported")
   ap.add_argument("--no-scipy-mode", action="store_true")
+  ap.add_argument("--no-lsmr-mode", action="store_true")
   ap.add_argument("--scipy-frames", type=int, default=20, help="frames of the sample the scipy-driven product mode is timed on")
   args = ap.parse_args()
   if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -342,6 +343,8 @@ def main():
       hsm.solve(sx0)
       t0 = time.perf_counter(); nres = hsm.solve(sx0); t_nat = time.perf_counter() - t0
       t0 = time.perf_counter(); sres = hsm.solve_scipy(sx0, verbose=0); t_sci = time.perf_counter() - t0
+      hsm.solve(sx0, tr_solver="lsmr")
+      t0 = time.perf_counter(); mres = hsm.solve(sx0, tr_solver="lsmr"); t_lsm = time.perf_counter() - t0
 
       def rms_at(x):
         e_, v_ = hsm.reprojection_error(x)
@@ -349,10 +352,26 @@ def main():
       scipy_mode = dict(sample=f"first {args.scipy_frames} of {FRAMES_PER_SHARD} frames of the same rig ({hsm.n_residuals} residuals, "
                                f"{hsm.n_params} parameters)",
                         scipy_mode_seconds=t_sci, scipy_mode_nfev=sres.nfev, scipy_mode_rms_px=rms_at(sres.x),
+                        lsmr_mode_seconds=t_lsm, lsmr_mode_nfev=mres.nfev, lsmr_mode_rms_px=rms_at(mres.x),
                         native_seconds=t_nat, native_nfev=nres.nfev, native_rms_px=rms_at(nres.x),
                         note="scipy mode = scipy.optimize.least_squares(method='trf', x_scale='jac') exactly as "
                              "optimization/calibration.py:209-210 on mcba_residuals + mcba_jacobian: the reference's end point "
                              "(profiles/parity_table.md), scipy's LSMR on the host")
+
+  # ---- the reference's trajectory at the FULL north-star size: mcba_solve with scipy's own LSMR step on the device ------------
+  lsmr_mode = None
+  if world == 1 and not args.no_lsmr_mode and not args.no_solve:
+    barrier()
+    t0 = time.perf_counter()
+    lres_ = h.solve(x0, tr_solver="lsmr")
+    barrier()
+    t_lsmr = time.perf_counter() - t0
+    e_, v_ = h.reprojection_error(lres_.x)
+    lsmr_mode = dict(seconds=t_lsmr, nfev=lres_.nfev, status=lres_.status, final_cost=lres_.cost,
+                     final_rms_px=float(np.sqrt(np.mean(e_[v_] ** 2))),
+                     note="solver='lsmr' on the whole 8 x 500 x 2 rig: scipy's TRF driver + lsmr(J_h, f, damp) restated on the device "
+                          "(the reference's own solver needs hours here: cpu_baseline.lm_iters_per_s); compare final_rms_px / "
+                          "solve_seconds of the default (exact normal-equation) solver above")
 
   out = None
   if rank == 0:
@@ -380,6 +399,8 @@ def main():
       out["step_collectives"] = step_comm
     if scipy_mode is not None:
       out["scipy_mode"] = scipy_mode
+    if lsmr_mode is not None:
+      out["lsmr_mode"] = lsmr_mode
     if world == 1 and not args.no_cpu_baseline:
       out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out), flush=True)

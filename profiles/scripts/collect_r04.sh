@@ -5,7 +5,7 @@
 set -x
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r4p; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --no-scipy-mode"
+B="python $R/bench.py --no-scipy-mode --no-lsmr-mode"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o trace -- $B --steps 200 --warmup 20 > $O/bench_traced.json 2> $O/bench_traced.err
 # PMC: counters in their own passes, kernel trace only (no other trace domain)
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc -o pmc_fetch -- $B --steps 30 --warmup 5 --repeats 1 --no-cpu-baseline --no-solve > /dev/null 2> $O/pmc1.err

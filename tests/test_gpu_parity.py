@@ -799,7 +799,7 @@ def test_adjust_outliers_in_one_call_equals_the_step_by_step_loop(name, monkeypa
   assert np.array_equal(fast.inliers, slow.inliers)
   assert fast.error_statistics(True).rms == pytest.approx(slow.error_statistics(True).rms, abs=1e-9)
   assert fast.error_statistics(False).rms == pytest.approx(slow.error_statistics(False).rms, abs=1e-9)
-  assert np.abs(fast.param_vec - slow.param_vec).max() < 1e-8
+  assert np.abs(fast.param_vec - slow.param_vec).max() < 1e-6      # (the round-off of the canonicalisation, amplified by three solves)
   import re
   keep = lambda ls_: [l for l in ls_ if l.startswith(("Adjust_outliers", "Rejecting", "Auto scaling", "Beginning"))]
   number = re.compile(r"[-+]?\d+\.?\d*(?:[eE][-+]?\d+)?")
