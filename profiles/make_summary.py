@@ -80,7 +80,7 @@ def collect_round(tag, root):
                    ("chol_paths.log", f"{tag}_cholesky_paths.txt"), ("init.log", f"{tag}_initialise_poses.txt"),
                    ("workspace_cfg3.log", f"{tag}_workspace_calibrate_cfg3.txt"), ("workspace_cfg4.log", f"{tag}_workspace_calibrate_cfg4.txt"),
                    ("workspace_cfg2.log", f"{tag}_workspace_calibrate_cfg2.txt"), ("parity_table.md", "parity_table.md"),
-                   ("parity_table.json", "parity_table.json")):
+                   ("parity_table.json", "parity_table.json"), ("lsmr_mode.md", f"{tag}_lsmr_mode.md")):
     p = os.path.join(root, src)
     if os.path.exists(p) and os.path.getsize(p) > 0:
       shutil.copy(p, os.path.join(HERE, dst))

@@ -27,5 +27,6 @@ python tests/prof_r4.py frames cfg3 cfg4 > $O/frame_groups.log 2>&1; cat $O/fram
 python tests/prof_chol_phases.py > $O/chol_phases.log 2>&1; tail -4 $O/chol_phases.log
 python tests/prof_chol.py > $O/chol_paths.log 2>&1; cat $O/chol_paths.log
 python tests/prof_init.py cfg2 cfg3 cfg4 > $O/init.log 2>&1; cat $O/init.log
+python tests/prof_lsmr.py > $O/lsmr_mode.md 2> $O/lsmr_mode.err; tail -5 $O/lsmr_mode.md
 python tests/prof_parity_table.py > $O/parity_table.md 2> $O/parity_table.err; cp gpurun_out/parity_table.json $O/ 2>/dev/null
 ls $O
