@@ -308,6 +308,8 @@ struct mcba_handle_s {
   int nchunk = 1;
   // solver state
   DevBuf<double> x, xnew, scale_inv, dsc, gh, gn, scal, costpart, Lf, W, yf, P, sbuf, ps;
+  DevBuf<double> ls_state;                // solver = "lsmr": scalar state of the running LSMR solve (mcba_lsmr.h)
+  unsigned long long ls_call = 0;         // ... and the number of the solve (tag of its progress word, h_pub_seq[1])
   DevBuf<double> scale_inv2, dsc2, gh2;   // scaling of a trial point, computed speculatively (mcba_solve) and swapped in on acceptance
   DevBuf<int32_t> info;
   double* h_scal = nullptr;   // pinned
@@ -728,7 +730,7 @@ double host_sum(const double* p, int n) {   // fixed order: the result does not 
 
 bool g_force_blocked_chol = false;   // test hooks: the multi-workgroup kernels / the panel kernels at any size
 bool g_force_panel2_chol = false;
-long long* g_chol_prof = nullptr;    // device buffer of 8 phase stamps (mcba_debug_chol, blocked == 4 / 7)
+long long* g_chol_prof = nullptr;    // device buffer of 8 phase stamps (mcba_debug_chol, blocked == 4 / 7 / 9)
 
 // (S + reg I) p = rhs for buf = [S (ns x ns) | rhs (ns)]; S is overwritten by its Cholesky factor.  Three paths by size:
 //   ns + 1 <= 160    k_chol_blk     one workgroup, the lower triangle resident in LDS as 16 x 16 tiles
@@ -1181,7 +1183,8 @@ int32_t mcba_create(const mcba_problem* p, void* hip_stream, mcba_handle* out) {
   h->h_gbuf_bytes = (2 * (size_t)d.n + 2) * sizeof(double);
   h->h_scal = (double*)pinned_alloc(h->h_scal_bytes);
   h->h_pub_seq = (unsigned long long*)pinned_alloc(64);
-  *h->h_pub_seq = 0;
+  h->h_pub_seq[0] = 0;
+  h->h_pub_seq[1] = 0;   // progress word of LSMR solves (tagged with the call number: lsmr_solve)
   h->h_x = (double*)pinned_alloc(h->h_x_bytes);
   h->h_gbuf = (double*)pinned_alloc(h->h_gbuf_bytes);
   HIP_OK(hipEventCreate(&h->ev0));
@@ -1869,20 +1872,15 @@ int32_t mcba_debug_pipe_probe(int32_t iters, double* ms_out) {
 
 namespace {
 
-// scipy.sparse.linalg._isolve.lsmr._sym_ortho
-void sym_ortho(double a, double b, double& c, double& s, double& r) {
-  auto sign = [](double v) { return v > 0 ? 1.0 : (v < 0 ? -1.0 : 0.0); };
-  if (b == 0) { c = sign(a); s = 0; r = std::fabs(a); }
-  else if (a == 0) { c = 0; s = sign(b); r = std::fabs(b); }
-  else if (std::fabs(b) > std::fabs(a)) { const double tau = a / b; s = sign(b) / std::sqrt(1 + tau * tau); c = s * tau; r = b / s; }
-  else { const double tau = b / a; c = sign(a) / std::sqrt(1 + tau * tau); s = c * tau; r = a / c; }
-}
-
 struct LsmrOps {
   mcba_handle_s* h;
   int nblk;            // persistent single-wave workgroups of the two Jacobian products
   int part_stride;
   size_t m;
+  int gather_grid() const {   // one wavefront per entry outside the per-frame pose block + one per frame (k_lsmr_gather)
+    const int nfe = lsmr_gather_frame_entries(h->d);
+    return h->d.n - nfe + (nfe > 0 ? h->d.Fl : 0);
+  }
   double fetch1(const double* dev) {
     double v = 0.0;
     HIP_OK(hipMemcpyAsync(h->h_scal, dev, sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -1896,17 +1894,31 @@ struct LsmrOps {
   }
   // u <- J_h v - alpha u (mode 0) | f (mode 1) | J_h v (mode 2); returns |u|^2
   double jv(int mode, const double* vin, double alpha, double* u) {
-    h->ops->lsmr_jv(h->d, h->t, h->stream, h->view_first.p, mode, h->dsc.p, vin, alpha, u, h->ls_partial.p, nblk);
+    h->ops->lsmr_jv(h->d, h->t, h->stream, h->view_first.p, mode, h->dsc.p, vin, alpha, u, h->ls_partial.p, nblk, nullptr);
     check_launch("k_lsmr_jv");
     return fold(h->ls_partial.p, nblk);
   }
   // vout <- D J^T (u inv_beta) - beta vold (u normalised in place); returns |vout|^2
   double jtu(double* u, double inv_beta, double beta, const double* vold, double* vout) {
-    h->ops->lsmr_jtu(h->d, h->t, h->stream, h->view_first.p, inv_beta, u, h->ls_part.p, part_stride, nblk);
-    hipLaunchKernelGGL(k_lsmr_gather, dim3(h->d.n), dim3(64), 0, h->stream, h->d, (const double*)h->ls_part.p, part_stride,
-                       (const double*)h->dsc.p, beta, vold, vout, h->ls_nrm.p);
+    h->ops->lsmr_jtu(h->d, h->t, h->stream, h->view_first.p, inv_beta, u, h->ls_part.p, part_stride, nblk, nullptr);
+    hipLaunchKernelGGL(k_lsmr_gather, dim3(gather_grid()), dim3(64), 0, h->stream, h->d, (const double*)h->ls_part.p, part_stride,
+                       (const double*)h->dsc.p, beta, vold, vout, h->ls_nrm.p, (const double*)nullptr);
     check_launch("k_lsmr_jtu / k_lsmr_gather");
     return fold(h->ls_nrm.p, h->d.n);
+  }
+  // one iteration of the device-resident solve (mcba_lsmr.h): six launches, every scalar read from the state `ls`
+  void iteration(double* ls, double* u, double* v, double* vraw, unsigned long long call) {
+    const Dims& d = h->d;
+    const int nvb = (d.n + 255) / 256;
+    h->ops->lsmr_jv(d, h->t, h->stream, h->view_first.p, 0, h->dsc.p, v, 0.0, u, h->ls_partial.p, nblk, ls);
+    hipLaunchKernelGGL(k_lsmr_scal_a, dim3(1), dim3(1024), 0, h->stream, ls, (const double*)h->ls_partial.p, nblk,
+                       (const double*)h->ls_nrm.p, d.n, call, h->h_pub_seq + 1);
+    h->ops->lsmr_jtu(d, h->t, h->stream, h->view_first.p, 0.0, u, h->ls_part.p, part_stride, nblk, ls);
+    hipLaunchKernelGGL(k_lsmr_gather, dim3(gather_grid()), dim3(64), 0, h->stream, d, (const double*)h->ls_part.p, part_stride,
+                       (const double*)h->dsc.p, 0.0, (const double*)v, vraw, h->ls_nrm.p, (const double*)ls);
+    hipLaunchKernelGGL(k_lsmr_scal_b, dim3(1), dim3(1024), 0, h->stream, ls, (const double*)h->ls_nrm.p, d.n);
+    hipLaunchKernelGGL(k_lsmr_update, dim3(nvb), dim3(256), 0, h->stream, d.n, 1.0, 0.0, 0.0, 0.0, vraw, h->ls_hbar.p, h->ls_x.p,
+                       h->ls_h.p, h->ls_nrm.p, (const double*)ls);
   }
 };
 
@@ -1917,7 +1929,6 @@ int lsmr_solve(LsmrOps& op, double damp, int* istop_out) {
   mcba_handle_s* h = op.h;
   const Dims& d = h->d;
   const int n = d.n;
-  const double atol = 1e-6, btol = 1e-6, conlim = 1e8;
   const long long maxiter = std::min<long long>((long long)op.m, (long long)(h->ext2int.empty() ? n : h->n_ext));
   const int nvb = (n + 255) / 256;
   double* u = h->ls_u.p;
@@ -1934,75 +1945,59 @@ int lsmr_solve(LsmrOps& op, double damp, int* istop_out) {
   }
   if (alpha > 0) hipLaunchKernelGGL(k_scale_to, dim3(nvb), dim3(256), 0, h->stream, n, 1.0 / alpha, (const double*)v, v);
   HIP_OK(hipMemcpyAsync(h->ls_h.p, v, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-  int itn = 0, istop = 0;
-  double zetabar = alpha * beta, alphabar = alpha, rho = 1, rhobar = 1, cbar = 1, sbar = 0;
-  double betadd = beta, betad = 0, rhodold = 1, tautildeold = 0, thetatilde = 0, zeta = 0, dd = 0;
-  double normA2 = alpha * alpha, maxrbar = 0, minrbar = 1e+100, normA = std::sqrt(normA2), condA = 1, normx = 0;
-  const double ctol = conlim > 0 ? 1 / conlim : 0;
-  double normr = beta, normar = alpha * beta;
-  if (normar == 0 || normb == 0) {   // x = 0 is the exact solution
+  if (alpha * beta == 0 || normb == 0) {   // x = 0 is the exact solution (lsmr.py:292-296)
     *istop_out = 0;
     if (v != h->ls_v.p) std::swap(h->ls_v.p, h->ls_vraw.p);
     return 0;
   }
-  while (itn < maxiter) {
-    ++itn;
-    beta = std::sqrt(op.jv(0, v, alpha, u));                      // u = A v - alpha u
-    double inv_alpha = 1.0;
-    if (beta > 0) {
-      alpha = std::sqrt(op.jtu(u, 1.0 / beta, beta, v, vraw));    // v = A^T u - beta v
-      std::swap(v, vraw);
-      if (alpha > 0) inv_alpha = 1.0 / alpha;
+  // The iteration itself runs from a state block in HBM (mcba_lsmr.h): the host only ENQUEUES iterations, a bounded number
+  // ahead of the progress word that k_lsmr_scal_a writes to pinned memory, until that word reports a stopping reason.  (The
+  // first version fetched beta, alpha and |x| to the host in every iteration: three synchronisations of ~75 us.)  Kernels
+  // enqueued behind the stop are empty launches; the call id in the word tells them from those of the next solve.
+  if (h->ls_state.n < (size_t)LS_NSLOTS) h->ls_state.alloc(LS_NSLOTS, true);
+  double* ls = h->ls_state.p;
+  const unsigned long long call = (++h->ls_call) & 0xffffffull;
+  hipLaunchKernelGGL(k_lsmr_init, dim3(1), dim3(64), 0, h->stream, ls, alpha, beta, damp, normb, (double)maxiter);
+  check_launch("k_lsmr_init");
+  constexpr long long LOOKAHEAD = 6;
+  long long enqueued = 0, done = 0;
+  int istop = 0;
+  double t_wait = 0.0;
+  int spins = 0;
+  unsigned long long seen = 0;
+  while (true) {
+    const unsigned long long w = __atomic_load_n(h->h_pub_seq + 1, __ATOMIC_ACQUIRE);
+    if ((w >> 40) == call) {
+      seen = w;
+      const long long dn = (long long)(w & 0xffffffffull);
+      if (dn != done) { done = dn; t_wait = 0.0; spins = 0; }
+      istop = (int)((w >> 32) & 0xff);
+      if (istop != 0) break;
     }
-    double chat, shat, alphahat;
-    sym_ortho(alphabar, damp, chat, shat, alphahat);
-    const double rhoold = rho;
-    double c, sn;
-    sym_ortho(alphahat, beta, c, sn, rho);
-    const double thetanew = sn * alpha;
-    alphabar = c * alpha;
-    const double rhobarold = rhobar, zetaold = zeta;
-    const double thetabar = sbar * rho, rhotemp = cbar * rho;
-    sym_ortho(cbar * rho, thetanew, cbar, sbar, rhobar);
-    zeta = cbar * zetabar;
-    zetabar = -sbar * zetabar;
-    hipLaunchKernelGGL(k_lsmr_update, dim3(nvb), dim3(256), 0, h->stream, n, inv_alpha, -(thetabar * rho / (rhoold * rhobarold)),
-                       zeta / (rho * rhobar), -(thetanew / rho), v, h->ls_hbar.p, h->ls_x.p, h->ls_h.p, h->ls_nrm.p);
-    const double betaacute = chat * betadd, betacheck = -shat * betadd;
-    const double betahat = c * betaacute;
-    betadd = -sn * betaacute;
-    const double thetatildeold = thetatilde;
-    double ctildeold, stildeold, rhotildeold;
-    sym_ortho(rhodold, thetabar, ctildeold, stildeold, rhotildeold);
-    thetatilde = stildeold * rhobar;
-    rhodold = ctildeold * rhobar;
-    betad = -stildeold * betad + ctildeold * betahat;
-    tautildeold = (zetaold - thetatildeold * tautildeold) / rhotildeold;
-    const double taud = (zeta - thetatilde * tautildeold) / rhodold;
-    dd = dd + betacheck * betacheck;
-    normr = std::sqrt(dd + (betad - taud) * (betad - taud) + betadd * betadd);
-    normA2 = normA2 + beta * beta;
-    normA = std::sqrt(normA2);
-    normA2 = normA2 + alpha * alpha;
-    maxrbar = std::max(maxrbar, rhobarold);
-    if (itn > 1) minrbar = std::min(minrbar, rhobarold);
-    condA = std::max(maxrbar, rhotemp) / std::min(minrbar, rhotemp);
-    normar = std::fabs(zetabar);
-    normx = std::sqrt(op.fold(h->ls_nrm.p, n));
-    const double test1 = normr / normb;
-    const double test2 = (normA * normr) != 0 ? normar / (normA * normr) : INFINITY;
-    const double test3 = 1 / condA;
-    const double t1 = test1 / (1 + normA * normx / normb);
-    const double rtol = btol + atol * normA * normx / normb;
-    if (itn >= maxiter) istop = 7;
-    if (1 + test3 <= 1) istop = 6;
-    if (1 + test2 <= 1) istop = 5;
-    if (1 + t1 <= 1) istop = 4;
-    if (test3 <= ctol) istop = 3;
-    if (test2 <= atol) istop = 2;
-    if (test1 <= rtol) istop = 1;
-    if (istop > 0) break;
+    if (enqueued - done < LOOKAHEAD && enqueued <= maxiter) {   // (iteration maxiter + 1 carries the tests of iteration maxiter)
+      op.iteration(ls, u, v, vraw, call);
+      std::swap(v, vraw);
+      ++enqueued;
+      if ((enqueued & 15) == 0) check_launch("lsmr iteration");
+      t_wait = 0.0;
+      spins = 0;
+      continue;
+    }
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+    if ((++spins & 1023) == 0) {
+      const double now = now_seconds();
+      if (t_wait == 0.0) t_wait = now;
+      else if (now - t_wait > 0.05) {   // a failed launch must not hang the caller: everything enqueued has run after this
+        HIP_OK(hipStreamSynchronize(h->stream));
+        const unsigned long long w2 = __atomic_load_n(h->h_pub_seq + 1, __ATOMIC_ACQUIRE);
+        REQUIRE((w2 >> 40) == call && w2 != seen, "the LSMR iteration on the device made no progress");
+        t_wait = 0.0;
+      }
+    }
   }
+  const int itn = (int)done;
   if (v != h->ls_v.p) std::swap(h->ls_v.p, h->ls_vraw.p);   // (the handle's buffers keep their roles for the next call)
   *istop_out = istop;
   return itn;

@@ -103,44 +103,44 @@ void points(const Dims& d, const Tables& t, hipStream_t s, int nq, double* Hss, 
 
 template <int MOTION, bool OPTK>
 void jv2(const Dims& d, const Tables& t, hipStream_t s, const int32_t* first, int mode, const double* dscale, const double* v,
-         double alpha, double* u, double* partial, int nblk) {
+         double alpha, double* u, double* partial, int nblk, const double* ls) {
   if (d.loss != 0)
-    hipLaunchKernelGGL((k_lsmr_jv<ND_, FISH_, MOTION, OPTK, true>), dim3(nblk), dim3(64), 0, s, d, t, first, mode, dscale, v, alpha, u, partial);
+    hipLaunchKernelGGL((k_lsmr_jv<ND_, FISH_, MOTION, OPTK, true>), dim3(nblk), dim3(64), 0, s, d, t, first, mode, dscale, v, alpha, u, partial, ls);
   else
-    hipLaunchKernelGGL((k_lsmr_jv<ND_, FISH_, MOTION, OPTK, false>), dim3(nblk), dim3(64), 0, s, d, t, first, mode, dscale, v, alpha, u, partial);
+    hipLaunchKernelGGL((k_lsmr_jv<ND_, FISH_, MOTION, OPTK, false>), dim3(nblk), dim3(64), 0, s, d, t, first, mode, dscale, v, alpha, u, partial, ls);
 }
 template <int MOTION>
 void jv1(const Dims& d, const Tables& t, hipStream_t s, const int32_t* first, int mode, const double* dscale, const double* v,
-         double alpha, double* u, double* partial, int nblk) {
-  if (d.KI > 0) jv2<MOTION, true>(d, t, s, first, mode, dscale, v, alpha, u, partial, nblk);
-  else jv2<MOTION, false>(d, t, s, first, mode, dscale, v, alpha, u, partial, nblk);
+         double alpha, double* u, double* partial, int nblk, const double* ls) {
+  if (d.KI > 0) jv2<MOTION, true>(d, t, s, first, mode, dscale, v, alpha, u, partial, nblk, ls);
+  else jv2<MOTION, false>(d, t, s, first, mode, dscale, v, alpha, u, partial, nblk, ls);
 }
 void lsmr_jv(const Dims& d, const Tables& t, hipStream_t s, const int32_t* first, int mode, const double* dscale, const double* v,
-             double alpha, double* u, double* partial, int nblk) {
-  if (d.motion == MOTION_STATIC) jv1<MOTION_STATIC>(d, t, s, first, mode, dscale, v, alpha, u, partial, nblk);
-  else if (d.motion == MOTION_ROLLING) jv1<MOTION_ROLLING>(d, t, s, first, mode, dscale, v, alpha, u, partial, nblk);
-  else jv1<MOTION_HAND_EYE>(d, t, s, first, mode, dscale, v, alpha, u, partial, nblk);
+             double alpha, double* u, double* partial, int nblk, const double* ls) {
+  if (d.motion == MOTION_STATIC) jv1<MOTION_STATIC>(d, t, s, first, mode, dscale, v, alpha, u, partial, nblk, ls);
+  else if (d.motion == MOTION_ROLLING) jv1<MOTION_ROLLING>(d, t, s, first, mode, dscale, v, alpha, u, partial, nblk, ls);
+  else jv1<MOTION_HAND_EYE>(d, t, s, first, mode, dscale, v, alpha, u, partial, nblk, ls);
 }
 
 template <int MOTION, bool OPTK>
 void jtu2(const Dims& d, const Tables& t, hipStream_t s, const int32_t* first, double inv_beta, double* u, double* part,
-          int part_stride, int nblk) {
+          int part_stride, int nblk, const double* ls) {
   if (d.loss != 0)
-    hipLaunchKernelGGL((k_lsmr_jtu<ND_, FISH_, MOTION, OPTK, true>), dim3(nblk), dim3(64), 0, s, d, t, first, inv_beta, u, part, part_stride);
+    hipLaunchKernelGGL((k_lsmr_jtu<ND_, FISH_, MOTION, OPTK, true>), dim3(nblk), dim3(64), 0, s, d, t, first, inv_beta, u, part, part_stride, ls);
   else
-    hipLaunchKernelGGL((k_lsmr_jtu<ND_, FISH_, MOTION, OPTK, false>), dim3(nblk), dim3(64), 0, s, d, t, first, inv_beta, u, part, part_stride);
+    hipLaunchKernelGGL((k_lsmr_jtu<ND_, FISH_, MOTION, OPTK, false>), dim3(nblk), dim3(64), 0, s, d, t, first, inv_beta, u, part, part_stride, ls);
 }
 template <int MOTION>
 void jtu1(const Dims& d, const Tables& t, hipStream_t s, const int32_t* first, double inv_beta, double* u, double* part,
-          int part_stride, int nblk) {
-  if (d.KI > 0) jtu2<MOTION, true>(d, t, s, first, inv_beta, u, part, part_stride, nblk);
-  else jtu2<MOTION, false>(d, t, s, first, inv_beta, u, part, part_stride, nblk);
+          int part_stride, int nblk, const double* ls) {
+  if (d.KI > 0) jtu2<MOTION, true>(d, t, s, first, inv_beta, u, part, part_stride, nblk, ls);
+  else jtu2<MOTION, false>(d, t, s, first, inv_beta, u, part, part_stride, nblk, ls);
 }
 void lsmr_jtu(const Dims& d, const Tables& t, hipStream_t s, const int32_t* first, double inv_beta, double* u, double* part,
-              int part_stride, int nblk) {
-  if (d.motion == MOTION_STATIC) jtu1<MOTION_STATIC>(d, t, s, first, inv_beta, u, part, part_stride, nblk);
-  else if (d.motion == MOTION_ROLLING) jtu1<MOTION_ROLLING>(d, t, s, first, inv_beta, u, part, part_stride, nblk);
-  else jtu1<MOTION_HAND_EYE>(d, t, s, first, inv_beta, u, part, part_stride, nblk);
+              int part_stride, int nblk, const double* ls) {
+  if (d.motion == MOTION_STATIC) jtu1<MOTION_STATIC>(d, t, s, first, inv_beta, u, part, part_stride, nblk, ls);
+  else if (d.motion == MOTION_ROLLING) jtu1<MOTION_ROLLING>(d, t, s, first, inv_beta, u, part, part_stride, nblk, ls);
+  else jtu1<MOTION_HAND_EYE>(d, t, s, first, inv_beta, u, part, part_stride, nblk, ls);
 }
 
 const CamOps OPS = {residual, project_model, cost, jacobian, linearize, points, lsmr_jv, lsmr_jtu};

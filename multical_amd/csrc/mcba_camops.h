@@ -20,11 +20,12 @@ struct CamOps {
   void (*linearize)(const Dims&, const Tables&, hipStream_t, double* rec, const uint16_t* tri, bool mfma, int epoch,
                     const double* x, double* za, int na, double* zb, int nb);
   void (*points)(const Dims&, const Tables&, hipStream_t, int n_points, double* Hss, double* Hfs, double* g);
-  // solver = "lsmr": u <- J_h v - alpha u (mode 0) / u <- f (mode 1), and the per-view partials of J_h^T (u inv_beta)
+  // solver = "lsmr": u <- J_h v - alpha u (mode 0) / u <- f (mode 1), and the per-view partials of J_h^T (u inv_beta);
+  // ls != nullptr: alpha / inv_beta and the stop flag come from the device-resident state of the solve (mcba_lsmr.h)
   void (*lsmr_jv)(const Dims&, const Tables&, hipStream_t, const int32_t* first, int mode, const double* dscale, const double* v,
-                  double alpha, double* u, double* partial, int nblk);
+                  double alpha, double* u, double* partial, int nblk, const double* ls);
   void (*lsmr_jtu)(const Dims&, const Tables&, hipStream_t, const int32_t* first, double inv_beta, double* u, double* part,
-                   int part_stride, int nblk);
+                   int part_stride, int nblk, const double* ls);
 };
 
 const CamOps* cam_ops_pin4();

@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include "mcba_view.h"
+#include "mcba_lsmr.h"
 
 namespace mcba {
 
@@ -432,13 +433,18 @@ __global__ __launch_bounds__(64) void k_cost(Dims d, Tables t, double* __restric
 template <int ND, int FISH, int MOTION, bool OPTK, bool ROBUST>
 __global__ __launch_bounds__(64) void k_lsmr_jv(Dims d, Tables t, const int32_t* __restrict__ first, int mode,
                                                 const double* __restrict__ dscale, const double* __restrict__ vin, double alpha,
-                                                double* __restrict__ u, double* __restrict__ partial) {
+                                                double* __restrict__ u, double* __restrict__ partial,
+                                                const double* __restrict__ ls = nullptr) {
   constexpr bool ROLL = MOTION == MOTION_ROLLING;
   constexpr int DE = ROLL ? 12 : 6, NPB = MOTION == MOTION_STATIC ? 3 : 4, NPC = 6 * NPB, KI = OPTK ? 4 + ND : 0;
   constexpr int NV = DE + KI + 1;
   __shared__ uint16_t pidx[LIN_MAX_POINTS];
   __shared__ double vp[NPC], wl[DE + KI + 1];
   const int lane = threadIdx.x;
+  if (ls != nullptr) {   // iteration of a device-resident solve (mcba_lsmr.h): alpha from the state, nothing to do once it stopped
+    if (ls[LS_ISTOP] != 0.0) return;
+    alpha = ls[LS_ALPHA];
+  }
   const int n_active = t.active_views[0];
   double acc = 0.0;
   for (int vi = blockIdx.x; vi < n_active; vi += gridDim.x) {
@@ -516,13 +522,18 @@ __global__ __launch_bounds__(64) void k_lsmr_jv(Dims d, Tables t, const int32_t*
 // per view: part[v][0 .. NPC + KI) = [That^T sum_p E_p^T u_p | sum_p K_p^T u_p] with u <- u * inv_beta (normalised in place)
 template <int ND, int FISH, int MOTION, bool OPTK, bool ROBUST>
 __global__ __launch_bounds__(64) void k_lsmr_jtu(Dims d, Tables t, const int32_t* __restrict__ first, double inv_beta,
-                                                 double* __restrict__ u, double* __restrict__ part, int part_stride) {
+                                                 double* __restrict__ u, double* __restrict__ part, int part_stride,
+                                                 const double* __restrict__ ls = nullptr) {
   constexpr bool ROLL = MOTION == MOTION_ROLLING;
   constexpr int DE = ROLL ? 12 : 6, NPB = MOTION == MOTION_STATIC ? 3 : 4, NPC = 6 * NPB, KI = OPTK ? 4 + ND : 0;
   constexpr int NV = DE + KI + 1, NS = DE + KI;
   __shared__ uint16_t pidx[LIN_MAX_POINTS];
   __shared__ double sl[NS];
   const int lane = threadIdx.x;
+  if (ls != nullptr) {
+    if (ls[LS_ISTOP] != 0.0 || ls[LS_SKIPV] != 0.0) return;
+    inv_beta = ls[LS_INV_BETA];
+  }
   const int n_active = t.active_views[0];
   for (int vi = blockIdx.x; vi < n_active; vi += gridDim.x) {
     const int v = t.active_views[1 + vi];

@@ -1286,6 +1286,47 @@ __device__ __forceinline__ void chol_tile_syrk(const double* __restrict__ Xa, co
   for (int r = 0; r < 4; ++r) Cm[(lg + 4 * r) * CTL + li] = acc[r];
 }
 
+// forward-substituted right-hand side = row ns of the factored matrix; then the blocked back substitution on ONE wavefront with
+// the inverted diagonal tiles: p_k = L_kk^-T z_k, z_j -= L_kj^T p_k for the blocks above
+__device__ __forceinline__ void chol_blk_backsub(int ns, int nb, const double* __restrict__ Lb, const double* __restrict__ Li,
+                                                 double* __restrict__ yv, double* __restrict__ ps, int lane) {
+  const int li = lane & 15, lg = lane >> 4;
+  const int by = ns / CT, ry = ns % CT;
+  for (int e = lane; e < nb * CT; e += 64) {
+    const int bj = e / CT, c = e % CT;
+    yv[e] = (e < ns && bj <= by) ? Lb[(size_t)(by * (by + 1) / 2 + bj) * CTS + ry * CTL + c] : 0.0;
+  }
+  lds_fence();
+  const int nbc = (ns + CT - 1) / CT;
+  for (int kb = nbc - 1; kb >= 0; --kb) {
+    double p;
+    {   // p_k = L_kk^-T z_k as a mat-vec with the inverted tile: lane (c, q) sums the rows i = q, q + 4, .. of column c
+      const double* Xk = Li + (size_t)kb * CTS;
+      double s4[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s4[r] = Xk[(lg + 4 * r) * CTL + li] * yv[CT * kb + lg + 4 * r];
+      p = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+      p = fold32(p, p);
+      p = fold16(p, p);                        // every lane (c, *) holds p_c
+      if (lane < CT && CT * kb + li < ns) ps[CT * kb + li] = p;
+    }
+    if (kb > 0) {   // z_j -= L_kj^T p_k for the blocks above; p_r as scalars
+      double pr[CT];
+#pragma unroll
+      for (int r = 0; r < CT; ++r) pr[r] = lane_bcast(p, r);
+      for (int e = lane; e < CT * kb; e += 64) {
+        const int bj = e / CT, c = e % CT;
+        const double* Lt = Lb + (size_t)(kb * (kb + 1) / 2 + bj) * CTS;
+        double sp[4] = {yv[e], 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < CT; ++r) sp[r & 3] -= Lt[r * CTL + c] * pr[r];
+        yv[e] = (sp[0] + sp[1]) + (sp[2] + sp[3]);
+      }
+      lds_fence();
+    }
+  }
+}
+
 __global__ __launch_bounds__(CHOL_BLK_THREADS) void k_chol_blk(int ns, double reg, const double* __restrict__ buf,
                                                                double* __restrict__ ps, int* __restrict__ info,
                                                                long long* __restrict__ prof) {
@@ -1297,47 +1338,49 @@ __global__ __launch_bounds__(CHOL_BLK_THREADS) void k_chol_blk(int ns, double re
   double* yv = Li + (size_t)nb * CTS;          // forward-substituted right-hand side, updated by the back substitution
   double* pv = yv + nb * CT;                   // solution
   double* dvv = pv + nb * CT;                  // 1 / L_jj
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int badcol = 0;                              // wave 0: first non-positive pivot (1-based)
-  long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tc = 0;   // phase stamps (prof != nullptr): load, a0, b, c + a, back
+  long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tc = 0;   // phase stamps (prof != nullptr): -, a0 || load, b, c + a, back, load of D_0
   if (prof) tc = clock64();
 #define CHOL_STAMP(i) if (prof) { const long long now = clock64(); tp[i] += now - tc; tc = now; }
-  {   // load: two tiles per pass, thread (r, c) of each; padding rows / columns continue the matrix with the identity
-    const int r = (tid >> 4) & 15, c = tid & 15, half = __builtin_amdgcn_readfirstlane(tid >> 8);
-    constexpr int UN = 23;   // 2 x 23 tiles per pass: the 45 tiles of ns = 140 in ONE round trip
-    for (int t0 = 0; t0 < ntile; t0 += 2 * UN) {
-      double v[UN];
-      // (bi, bj) of the pass's first tile once, then stepped by two tiles: wave-uniform integers (the per-element form with
-      //  a square root per tile cost more issue slots than the loads: 17 k cycles for 92 KB)
-      const int tile0 = t0 + half;
-      int bi = (int)((sqrtf(8.0f * (float)tile0 + 1.0f) - 1.0f) * 0.5f);
-      bi += ((bi + 1) * (bi + 2) / 2 <= tile0) ? 1 : 0;
-      bi -= (bi * (bi + 1) / 2 > tile0) ? 1 : 0;
-      bi = __builtin_amdgcn_readfirstlane(bi);
-      int bj = tile0 - bi * (bi + 1) / 2;
-#pragma unroll
-      for (int u = 0; u < UN; ++u) {
-        const int tile = t0 + 2 * u + half;
-        const int gi = CT * bi + r, gj = CT * bj + c;
-        const bool in = tile < ntile && gi < n1 && gj < ns && gj <= gi;
-        v[u] = masked_load(buf, (size_t)gi * ns + gj, in) + (in ? ((gi == gj) ? reg : 0.0) : ((gi == gj) ? 1.0 : 0.0));
-        bj += 2;
-        while (bj > bi) { bj -= bi + 1; ++bi; }
-      }
-#pragma unroll
-      for (int u = 0; u < UN; ++u) {
-        const int tile = t0 + 2 * u + half;
-        if (tile < ntile) Lb[(size_t)tile * CTS + r * CTL + c] = v[u];
-      }
-      if (t0 == 0) { CHOL_STAMP(5) } else { CHOL_STAMP(6) }
-    }
-  }
-  __syncthreads();
-  CHOL_STAMP(0)
   const int li = lane & 15, lg = lane >> 4;
+  {   // load: whole tiles per wavefront, lane (row lg + 4 q, column li); padding rows / columns continue the matrix with the
+      // identity.  Wave 0 fetches only the first diagonal tile and factors it while the other seven wavefronts fetch the rest
+      // (round 4: the first pivot chain, 4.2 k cycles, used to start behind a barrier after the whole load, ~8 k cycles of
+      // mostly latency).
+    constexpr int MAXT = (CHOL_BLK_MAX_N1 / CT) * (CHOL_BLK_MAX_N1 / CT + 1) / 2;   // 55 tiles
+    constexpr int PER = (MAXT - 1 + NW - 2) / (NW - 1);                             // <= 8 tiles per loading wavefront
+    double v[PER][4];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int tile = wave == 0 ? (u == 0 ? 0 : ntile) : 1 + (wave - 1) + (NW - 1) * u;
+      int bi = 0;
+      while ((bi + 1) * (bi + 2) / 2 <= tile) ++bi;
+      const int bj = tile - bi * (bi + 1) / 2;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int gi = CT * bi + lg + 4 * q, gj = CT * bj + li;
+        const bool in = tile < ntile && gi < n1 && gj < ns && gj <= gi;
+        v[u][q] = masked_load(buf, (size_t)gi * ns + gj, in) + (in ? ((gi == gj) ? reg : 0.0) : ((gi == gj) ? 1.0 : 0.0));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int tile = wave == 0 ? (u == 0 ? 0 : ntile) : 1 + (wave - 1) + (NW - 1) * u;
+      if (tile < ntile) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Lb[(size_t)tile * CTS + (lg + 4 * q) * CTL + li] = v[u][q];
+      }
+    }
+    CHOL_STAMP(5)
+  }
   // (the panels are solved with L itself and 1 / L_jj; the INVERSES of the diagonal tiles, which only the back substitution
   //  uses, are formed one block column late by a wavefront with slack: off the critical path)
-  if (wave == 0 && ns > 0) chol_tile_factor_noinv(Lb, dvv, min(CT, ns), 0, lane, badcol);
+  if (wave == 0 && ns > 0) {
+    lds_fence();
+    CHOL_STAMP(0)
+    chol_tile_factor_noinv(Lb, dvv, min(CT, ns), 0, lane, badcol);
+  }
   __syncthreads();
   CHOL_STAMP(1)
   for (int k = 0; k < nb; ++k) {
@@ -1382,41 +1425,7 @@ __global__ __launch_bounds__(CHOL_BLK_THREADS) void k_chol_blk(int ns, double re
     CHOL_STAMP(3)
   }
   if (wave == 0) {
-    // forward-substituted right-hand side = row ns; then the blocked back substitution, wave 0 only
-    const int by = ns / CT, ry = ns % CT;
-    for (int e = lane; e < nb * CT; e += 64) {
-      const int bj = e / CT, c = e % CT;
-      yv[e] = (e < ns && bj <= by) ? Lb[(size_t)(by * (by + 1) / 2 + bj) * CTS + ry * CTL + c] : 0.0;
-    }
-    lds_fence();
-    const int nbc = (ns + CT - 1) / CT;
-    for (int kb = nbc - 1; kb >= 0; --kb) {
-      double p;
-      {   // p_k = L_kk^-T z_k as a mat-vec with the inverted tile: lane (c, q) sums the rows i = q, q + 4, .. of column c
-        const double* Xk = Li + (size_t)kb * CTS;
-        double s4[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) s4[r] = Xk[(lg + 4 * r) * CTL + li] * yv[CT * kb + lg + 4 * r];
-        p = (s4[0] + s4[1]) + (s4[2] + s4[3]);
-        p = fold32(p, p);
-        p = fold16(p, p);                        // every lane (c, *) holds p_c
-        if (lane < CT && CT * kb + li < ns) ps[CT * kb + li] = p;
-      }
-      if (kb > 0) {   // z_j -= L_kj^T p_k for the blocks above; p_r as scalars
-        double pr[CT];
-#pragma unroll
-        for (int r = 0; r < CT; ++r) pr[r] = lane_bcast(p, r);
-        for (int e = lane; e < CT * kb; e += 64) {
-          const int bj = e / CT, c = e % CT;
-          const double* Lt = Lb + (size_t)(kb * (kb + 1) / 2 + bj) * CTS;
-          double sp[4] = {yv[e], 0.0, 0.0, 0.0};
-#pragma unroll
-          for (int r = 0; r < CT; ++r) sp[r & 3] -= Lt[r * CTL + c] * pr[r];
-          yv[e] = (sp[0] + sp[1]) + (sp[2] + sp[3]);
-        }
-        lds_fence();
-      }
-    }
+    chol_blk_backsub(ns, nb, Lb, Li, yv, ps, lane);
     CHOL_STAMP(4)
     if (lane == 0) {
       info[0] = badcol;
@@ -2136,13 +2145,64 @@ __global__ __launch_bounds__(64) void k_fold_partials(double* __restrict__ part,
 // J_h^T u (k_lsmr_jtu) to the n entries of the vector, and the vector updates of the LSMR iteration.
 // ---------------------------------------------------------------------------------------------------------------
 // vout[i] = dscale[i] * (sum over the views that contain parameter i of part[view][local index]) - beta * vold[i];
-// one wavefront per entry, fixed summation order; nrm[i] = vout[i]^2 (folded afterwards)
+// nrm[i] = vout[i]^2 (folded afterwards).  Fixed summation order: "lane L adds the views L, L + 64, ..; wave_sum".
+//   workgroups [0, n - nfe):       one wavefront per entry outside the per-frame pose block (camera poses, board poses, intrinsics,
+//                                  the hand-eye pair: sums over up to all views)
+//   workgroups [n - nfe, .. + Fl): one wavefront per FRAME for its 6 / 12 pose entries (sums over the C x B views of the frame):
+//                                  16 lanes per entry -- as one wavefront per entry these were 6 000 of the launch's 6 140
+//                                  workgroups at the north-star rig (26.6 us; lsmr_gather_frame_entries gives the count).  The
+//                                  four accumulators of a lane are the lanes L, L + 16, L + 32, L + 48 of the order above.
+__host__ __device__ inline int lsmr_gather_frame_entries(const Dims& d) {
+  return (d.off_motion >= 0 && d.motion != MOTION_HAND_EYE) ? d.n_motion : 0;
+}
 __global__ __launch_bounds__(64) void k_lsmr_gather(Dims d, const double* __restrict__ part, int part_stride,
                                                     const double* __restrict__ dscale, double beta, const double* __restrict__ vold,
-                                                    double* __restrict__ vout, double* __restrict__ nrm) {
-  const int i = blockIdx.x, lane = threadIdx.x;
-  if (i >= d.n) return;
+                                                    double* __restrict__ vout, double* __restrict__ nrm,
+                                                    const double* __restrict__ ls = nullptr) {
+  const int lane = threadIdx.x;
+  const int nfe = lsmr_gather_frame_entries(d), ngen = d.n - nfe;
+  bool skip = false;
+  if (ls != nullptr) {   // device-resident solve: beta from the state; beta == 0 leaves v as it is
+    if (ls[LS_ISTOP] != 0.0) return;
+    skip = ls[LS_SKIPV] != 0.0;
+    beta = ls[LS_BETA];
+  }
   const int CB = d.C * d.B, npc = 6 * d.NPB;
+  if ((int)blockIdx.x >= ngen) {
+    const int fl = (int)blockIdx.x - ngen;
+    if (fl >= d.Fl) return;
+    const int DFm = d.motion == MOTION_ROLLING ? 12 : 6, g = lane >> 4, l16 = lane & 15;
+    for (int e = g; e < DFm; e += 4) {                  // entry e of the frame: chain e / 6, component e % 6
+      const int chain = e / 6, i = d.off_motion + chain * 6 * d.F + 6 * (d.f0 + fl) + e % 6;
+      if (skip) {
+        if (l16 == 0) vout[i] = vold[i];
+        continue;
+      }
+      double s4[4] = {0.0, 0.0, 0.0, 0.0};
+      const double* src = part + (size_t)fl * CB * part_stride + 6 + e;
+      for (int w0 = 0; w0 < CB; w0 += 64)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int vw = w0 + 16 * k + l16;
+          if (vw < CB) s4[k] += src[(size_t)vw * part_stride];
+        }
+      double sum = (s4[0] + s4[2]) + (s4[1] + s4[3]);
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) sum += __shfl_down(sum, off, 16);
+      if (l16 == 0) {
+        const double val = dscale[i] * sum - beta * vold[i];
+        vout[i] = val;
+        nrm[i] = val * val;
+      }
+    }
+    return;
+  }
+  const int i = nfe > 0 && (int)blockIdx.x >= d.off_motion ? (int)blockIdx.x + nfe : (int)blockIdx.x;
+  if (i >= d.n) return;
+  if (skip) {
+    if (lane == 0) vout[i] = vold[i];
+    return;
+  }
   int base = 0, na = 0, sa = 0, nb = 1, sb = 0, local = -1;
   if (d.off_campose >= 0 && i >= d.off_campose && i < d.off_campose + 6 * d.C) {
     const int q = i - d.off_campose, c = q / 6;
@@ -2152,12 +2212,7 @@ __global__ __launch_bounds__(64) void k_lsmr_gather(Dims d, const double* __rest
     local = 6 * (d.NPB - 1) + q % 6; base = b; na = d.Fl; sa = CB; nb = d.C; sb = d.B;
   } else if (d.off_motion >= 0 && i >= d.off_motion && i < d.off_motion + d.n_motion) {
     const int q = i - d.off_motion;
-    if (d.motion == MOTION_HAND_EYE) {
-      local = 6 + q; base = 0; na = d.views(); sa = 1;
-    } else {
-      const int chain = (d.motion == MOTION_ROLLING && q >= 6 * d.F) ? 1 : 0, qq = q - chain * 6 * d.F, f = qq / 6;
-      if (f >= d.f0 && f < d.f0 + d.Fl) { local = 6 + 6 * chain + qq % 6; base = (f - d.f0) * CB; na = d.C; sa = d.B; nb = d.B; sb = 1; }
-    }
+    if (d.motion == MOTION_HAND_EYE) { local = 6 + q; base = 0; na = d.views(); sa = 1; }
   } else if (d.off_cameras >= 0 && i >= d.off_cameras && i < d.off_cameras + d.C * (5 + d.ND)) {
     const int q = i - d.off_cameras, c = q / (5 + d.ND), qq = q % (5 + d.ND);
     const int lq = qq < 4 ? qq : qq - 1;
@@ -2166,10 +2221,20 @@ __global__ __launch_bounds__(64) void k_lsmr_gather(Dims d, const double* __rest
   }
   double sum = 0.0;
   if (local >= 0) {
+    // lane L adds the parts L, L + 64, .. IN THAT ORDER, but eight loads are in flight at a time: the parts were written by other
+    // XCDs a kernel ago, and one dependent round trip per part made this kernel 26 us at 1 000 parts per camera entry
     const int total = na * nb;
-    for (int e = lane; e < total; e += 64) {
-      const int a = e / nb, b_ = e - a * nb;
-      sum += part[(size_t)(base + a * sa + b_ * sb) * part_stride + local];
+    constexpr int UNR = 8;
+    for (int e0 = lane; e0 < total; e0 += 64 * UNR) {
+      double v[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int e = e0 + 64 * u, a = e / nb, b_ = e - a * nb;
+        v[u] = e < total ? part[(size_t)(base + a * sa + b_ * sb) * part_stride + local] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u)
+        if (e0 + 64 * u < total) sum += v[u];
     }
   }
   sum = wave_sum(sum);
@@ -2184,9 +2249,14 @@ __global__ __launch_bounds__(64) void k_lsmr_gather(Dims d, const double* __rest
 // (lsmr.py: "Update h, h_hat, x" with the normalisation of v folded in)
 __global__ __launch_bounds__(256) void k_lsmr_update(int n, double inv_alpha, double c_hbar, double c_x, double c_h,
                                                      double* __restrict__ v, double* __restrict__ hbar, double* __restrict__ x,
-                                                     double* __restrict__ h, double* __restrict__ nrm) {
+                                                     double* __restrict__ h, double* __restrict__ nrm,
+                                                     const double* __restrict__ ls = nullptr) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (ls != nullptr) {
+    if (ls[LS_ISTOP] != 0.0) return;
+    inv_alpha = ls[LS_INV_ALPHA]; c_hbar = ls[LS_C_HBAR]; c_x = ls[LS_C_X]; c_h = ls[LS_C_H];
+  }
   const double vi = v[i] * inv_alpha;
   v[i] = vi;
   const double hb = c_hbar * hbar[i] + h[i];
@@ -2215,6 +2285,45 @@ __global__ __launch_bounds__(1024) void k_dot(size_t n, const double* __restrict
     out[0] = t0;
     if (three) { out[1] = t1; out[2] = t2; }
   }
+}
+
+// The scalar side of a device-resident LSMR solve (mcba_lsmr.h), two launches of ONE workgroup per iteration:
+//   k_lsmr_scal_a behind k_lsmr_jv:     |x|^2 of the PREVIOUS iteration's update -> its stopping tests; |u|^2 -> beta
+//   k_lsmr_scal_b behind k_lsmr_gather: |v|^2 -> alpha, the plane rotations, the coefficients of k_lsmr_update
+// Sums in the order of k_dot (thread t adds the entries t, t + 1024, ..; waves, then the wave totals in order).  The stopping
+// tests of an iteration run after the NEXT k_lsmr_jv: that product is wasted once per solve and every kernel behind a stop is
+// an empty launch, in exchange for one scalar launch less per iteration.  Progress goes to a word in pinned host memory.
+__device__ __forceinline__ double lsmr_fold(const double* __restrict__ a, int n, double* scratch) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += a[i] * 1.0;
+  return block_reduce<false>(s, scratch);
+}
+__global__ __launch_bounds__(64) void k_lsmr_init(double* __restrict__ ls, double alpha, double beta, double damp, double normb,
+                                                  double maxiter) {
+  if (threadIdx.x == 0) lsmr_state_init(ls, alpha, beta, damp, normb, maxiter);
+}
+__global__ __launch_bounds__(1024) void k_lsmr_scal_a(double* __restrict__ ls, const double* __restrict__ upart, int nblk,
+                                                      const double* __restrict__ xsq, int n, unsigned long long call,
+                                                      unsigned long long* host_word) {
+  __shared__ double scratch[16];
+  if (ls[LS_ISTOP] != 0.0) return;
+  const bool test = ls[LS_ITN] > 0.0;
+  const double u2 = lsmr_fold(upart, nblk, scratch);
+  const double x2 = test ? lsmr_fold(xsq, n, scratch) : 0.0;
+  if (threadIdx.x == 0) {
+    const int istop = test ? lsmr_state_test(ls, x2) : 0;
+    if (istop != 0) ls[LS_ISTOP] = (double)istop;
+    else lsmr_state_beta(ls, u2);
+    // (relaxed: the host reads nothing but the word itself -- a system-scope RELEASE here would first write back the 12 MB of u that
+    //  k_lsmr_jv has just left in L2)
+    __hip_atomic_store(host_word, lsmr_progress_word(call, istop, (long long)ls[LS_ITN]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+__global__ __launch_bounds__(1024) void k_lsmr_scal_b(double* __restrict__ ls, const double* __restrict__ vsq, int n) {
+  __shared__ double scratch[16];
+  if (ls[LS_ISTOP] != 0.0) return;
+  const double v2 = lsmr_fold(vsq, n, scratch);
+  if (threadIdx.x == 0) lsmr_state_rotate(ls, v2);
 }
 
 // y[i] = a * x[i] (+ y0 copy helpers of the driver)

@@ -48,6 +48,13 @@ for name in SMALL + BIG:
     t_n = time.time() - t0
     h.set_log(None)
     rms_n = rms_of(h, nat.x)
+    try:      # L: scipy's TRF + LSMR step restated on the device (not for boards=True)
+      t0 = time.time()
+      lsm = h.solve(g["x0"], tolerance=kw.get("tolerance", 1e-4), loss=loss, f_scale=f_scale, max_iterations=kw.get("max_iterations", 100),
+                    tr_solver="lsmr")
+      t_l, rms_l = time.time() - t0, rms_of(h, lsm.x)
+    except Exception:
+      lsm, t_l, rms_l = None, float("nan"), float("nan")
   if name in TABLES:
     tables[name] = (str(g["ba_log"]), log, nat)
   ref = float(g["ba_rms"])
@@ -55,14 +62,16 @@ for name in SMALL + BIG:
   # physical size of the end-point differences: both solutions against the reference's raw end point, in a common gauge
   c_ref = c.with_param_vec(g["ba_x_raw"])
   d_b, d_n = gauge.parameter_deltas(c.with_param_vec(res.x), c_ref), gauge.parameter_deltas(c.with_param_vec(nat.x), c_ref)
+  d_l = dict(gauge.parameter_deltas(c.with_param_vec(lsm.x), c_ref)) if lsm is not None else None
   # ... and all three against the TRUTH that generated the synthetic observations (0.2 px noise, 1 % gross outliers)
   c_truth = calibration.from_rig(rig, 'truth')
-  t_r, t_b, t_n = (dict(gauge.parameter_deltas(q, c_truth)) for q in (c_ref, c.with_param_vec(res.x), c.with_param_vec(nat.x)))
-  rows.append(dict(name=name, truth_ref=t_r, truth_b=t_b, truth_n=t_n, ref=ref, ref_nfev=int(g["ba_nfev"]), spread=float(np.abs(pert - ref).max()), sigma=float(pert.std()),
+  tr_r, tr_b, tr_n = (dict(gauge.parameter_deltas(q, c_truth)) for q in (c_ref, c.with_param_vec(res.x), c.with_param_vec(nat.x)))
+  rows.append(dict(name=name, truth_ref=tr_r, truth_b=tr_b, truth_n=tr_n, ref=ref, ref_nfev=int(g["ba_nfev"]), spread=float(np.abs(pert - ref).max()), sigma=float(pert.std()),
                    n_pert=int(pert.size), tight=float(g["ba_tight_rms"]) if "ba_tight_rms" in g else float("nan"),
                    rms_b=rms_b, nfev_b=int(res.nfev), status_b=int(res.status), rms_n=rms_n, nfev_n=int(nat.nfev),
                    status_n=int(nat.status), ref_status=int(g["ba_status"]), loss=loss, seconds_b=t_b, seconds_n=t_n,
-                   delta_b=dict(d_b), delta_n=dict(d_n)))
+                   delta_b=dict(d_b), delta_n=dict(d_n), delta_l=d_l, rms_l=rms_l, seconds_l=t_l,
+                   nfev_l=int(lsm.nfev) if lsm is not None else -1, status_l=int(lsm.status) if lsm is not None else -100))
   print(f"# {name} done ({t_b:.1f} s scipy-driven, {t_n * 1e3:.1f} ms native)", file=sys.stderr, flush=True)
 
 print("# Parity table: final reprojection RMS (px) at the reference's default tolerance (ftol = 1e-4, max_nfev = 100)\n")
@@ -71,14 +80,17 @@ print("perturbed reference run - RMS of the reference run| over N re-runs of the
 print("residual function (oracle/make_pert.py): the resolution to which the reference's end point is defined.  `converged` =")
 print("optimum of the reference's residual function (tight polish).  B = the product's scipy mode (`solver=\"scipy\"`,")
 print("`dropin.install(mode=\"scipy\")`): the reference's own scipy driver on the HIP `fun` + analytic `jac`; N = the native HIP")
-print("solver (`solver=\"native\"`).  |d| columns are |RMS - reference RMS|.\n")
-print("| fixture | loss | reference RMS | nfev | spread (max) | spread (sigma) | N runs | converged RMS | B: RMS | B: nfev | B: \\|d\\| | B within 1e-6 px | N: RMS | N: nfev | N: \\|d\\| | N within 1e-6 px | B: s | N: ms |")
-print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
+print("solver (`solver=\"native\"`); L = `solver=\"lsmr\"`: scipy's TRF driver and its LSMR trust-region step restated on the device")
+print("(`mcba_options.tr_solver = MCBA_TR_LSMR`; not for `boards=True`).  |d| columns are |RMS - reference RMS|.\n")
+print("| fixture | loss | reference RMS | nfev | spread (max) | spread (sigma) | N runs | converged RMS | B: RMS | B: nfev | B: \\|d\\| | B within 1e-6 px | N: RMS | N: nfev | N: \\|d\\| | N within 1e-6 px | L: RMS | L: nfev | L: status (ref) | L: \\|d\\| | L within max(1e-6, spread) | B: s | N: ms | L: ms |")
+print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
 for r in rows:
   db, dn = abs(r["rms_b"] - r["ref"]), abs(r["rms_n"] - r["ref"])
   print(f"| {r['name']} | {r['loss']} | {r['ref']:.9f} | {r['ref_nfev']} | {r['spread']:.1e} | {r['sigma']:.1e} | {r['n_pert']} | {r['tight']:.9f} | "
         f"{r['rms_b']:.9f} | {r['nfev_b']} | {db:.1e} | {'yes' if db <= 1e-6 else 'no'} | {r['rms_n']:.9f} | {r['nfev_n']} | {dn:.1e} | "
-        f"{'yes' if dn <= 1e-6 else 'no'} | {r['seconds_b']:.2f} | {r['seconds_n'] * 1e3:.1f} |")
+        f"{'yes' if dn <= 1e-6 else 'no'} | {r['rms_l']:.9f} | {r['nfev_l']} | {r['status_l']} ({r['ref_status']}) | {abs(r['rms_l'] - r['ref']):.1e} | "
+        f"{'yes' if abs(r['rms_l'] - r['ref']) <= max(1e-6, r['spread']) else 'no'} | {r['seconds_b']:.2f} | {r['seconds_n'] * 1e3:.1f} | "
+        f"{r['seconds_l'] * 1e3:.1f} |")
 
 print("\n## Parameter-space size of the end-point differences\n")
 print("Both HIP routes against the reference's own end point (`ba_x_raw`), after moving every solution to the gauge \"first valid")
@@ -90,7 +102,9 @@ print("1 m from the cameras).\n")
 print("| fixture | route | \\|df\\|/f | \\|dc\\| px | \\|ddist\\| | camera deg | camera t | frame deg | frame t | board deg | board t |")
 print("|---|---|---|---|---|---|---|---|---|---|---|")
 for r in rows:
-  for route, d in (("B scipy mode", r["delta_b"]), ("N native", r["delta_n"])):
+  for route, d in (("B scipy mode", r["delta_b"]), ("L lsmr", r["delta_l"]), ("N native", r["delta_n"])):
+    if d is None:
+      continue
     print(f"| {r['name']} | {route} | {d['focal_rel']:.1e} | {d['principal_px']:.1e} | {d['dist_abs']:.1e} | {d['camera_deg']:.1e} | "
           f"{d['camera_t']:.1e} | {d['frame_deg']:.1e} | {d['frame_t']:.1e} | {d['board_deg']:.1e} | {d['board_t']:.1e} |")
 

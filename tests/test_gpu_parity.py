@@ -509,7 +509,9 @@ def test_adjust_board_rolling_and_handeye_blocks():
                                         (333, 1), (1500, 1),
                                         # 6: the multi-launch panel kernels k_cholp_* (automatic for 160 < ns + 1 <= 1024)
                                         (5, 6), (16, 6), (17, 6), (47, 6), (48, 6), (49, 6), (140, 6), (286, 6), (288, 6),
-                                        (400, 6), (1023, 6), (1023, 0)])
+                                        (400, 6), (1023, 6), (1023, 0),
+                                        (1, 0), (15, 0), (17, 0), (33, 0), (64, 0), (96, 0), (127, 0), (128, 0), (143, 0), (144, 0),
+                                        (150, 0)])
 def test_device_cholesky_paths(ns, blocked):
   """The three Cholesky paths of the reduced system vs numpy: LDS-resident tiles (0, ns + 1 <= 160), multi-launch panel
   kernels (6; automatic up to ns + 1 = 1024), multi-workgroup kernels (1; automatic beyond)."""
