@@ -87,7 +87,8 @@ typedef struct mcba_problem {
   int32_t n_boards;             /* B */
   int32_t n_points;             /* P = max points per board (tables.stack_boards, tables.py:385-394) */
 
-  const double*  points;        /* [C,F,B,P,2] point_table.points, widened to double by the caller      */
+  const double*  points;        /* [C,F,B,P,2] point_table.points as float64, or NULL when points_f32   */
+                                /* (last member) carries the table                                     */
   const uint8_t* point_valid;   /* [C,F,B,P]   point_table.valid                                       */
   const uint8_t* inlier_mask;   /* [C,F,B,P]   Calibration.inlier_mask, or NULL -> inliers = valid     */
 
@@ -117,6 +118,11 @@ typedef struct mcba_problem {
   const uint8_t* camera_fisheye;/* [C] 1 = CameraFisheye (camera_fisheye.py:28), 0 = Camera, or NULL: every camera is of  */
                                 /* `camera_model`.  A rig may MIX the two families (the reference holds independent     */
                                 /* objects, parameters.py:54-85); camera_n_dist is then required unless all carry 4.    */
+  const float* points_f32;      /* [C,F,B,P,2] point_table.points as float32 -- the dtype the reference's table has in  */
+                                /* use: fill_sparse keeps `values.dtype` (tables.py:15-17) and cv2 detects float32      */
+                                /* corners.  Uploaded as it is (half the bytes) and widened on the device, exactly as   */
+                                /* numpy promotes it in `reprojected.points - point_table.points`.  Exactly one of      */
+                                /* points / points_f32 is non-NULL.                                                     */
 } mcba_problem;
 
 typedef struct mcba_options {          /* scipy.optimize.least_squares arguments used at calibration.py:209-210 */

@@ -34,6 +34,7 @@ class Problem(C.Structure):
     ("frame_begin", C.c_int32), ("frame_end", C.c_int32),
     ("camera_n_dist", c_int32_p),
     ("camera_fisheye", c_uint8_p),
+    ("points_f32", C.POINTER(C.c_float)),
   ]
 
 

@@ -52,7 +52,11 @@ def lower(calib):
   C_, F, B, P = calib.point_table.valid.shape
   p = SimpleNamespace()
   p.shape = (C_, F, B, P)
-  p.points = _f64(points)                                     # float32 detections are widened exactly
+  # float32 detections (cv2's corner dtype, which the reference's table keeps: tables.py:15-17) go up as they are and are
+  # widened on the device -- exactly, as numpy promotes them in `reprojected.points - point_table.points`
+  points = np.asarray(points)
+  p.points_f32 = np.ascontiguousarray(points) if points.dtype == np.float32 else None
+  p.points = None if p.points_f32 is not None else _f64(points)
   p.point_valid = _u8(calib.point_table.valid)
   p.inlier_mask = None if calib.inlier_mask is None else _u8(calib.inlier_mask)
   p.board_sizes = np.ascontiguousarray(np.array([b.num_points for b in calib.boards], dtype=np.int32))
@@ -108,7 +112,8 @@ def _to_struct(p, frame_range=None):
   s = Problem()
   s.version = _lib.MCBA_VERSION
   s.n_cameras, s.n_frames, s.n_boards, s.n_points = C_, F, B, P
-  s.points = _ptr(p.points, C.c_double)
+  s.points = None if p.points is None else _ptr(p.points, C.c_double)
+  s.points_f32 = None if getattr(p, "points_f32", None) is None else _ptr(p.points_f32, C.c_float)
   s.point_valid = _ptr(p.point_valid, C.c_uint8)
   s.inlier_mask = None if p.inlier_mask is None else _ptr(p.inlier_mask, C.c_uint8)
   s.board_sizes = _ptr(p.board_sizes, C.c_int32)

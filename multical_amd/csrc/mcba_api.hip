@@ -426,7 +426,7 @@ void build_inliers(mcba_handle_s* h, const uint8_t* mask_ref) {
     if (mask_ref != nullptr) {
       if (h->raw_mask.n < (size_t)d.slots()) h->raw_mask.alloc((size_t)d.slots(), false);
       upload_shard_slabs(h, h->raw_mask.p, mask_ref, 1);
-      hipLaunchKernelGGL(k_lower_view, dim3(d.views()), dim3(64), 0, h->stream, d, (const double2*)nullptr,
+      hipLaunchKernelGGL(k_lower_view, dim3(d.views()), dim3(64), 0, h->stream, d, (const double2*)nullptr, (const float2*)nullptr,
                          (const uint8_t*)h->raw_mask.p, (const uint8_t*)h->raw_mask.p, h->cam_valid.p, h->frame_valid.p,
                          h->board_valid.p, h->board_off.p, (double2*)nullptr, (uint8_t*)nullptr, (uint8_t*)nullptr,
                          h->inlier.p, h->view_count.p, (int32_t*)nullptr);
@@ -1072,12 +1072,18 @@ int32_t mcba_create(const mcba_problem* p, void* hip_stream, mcba_handle* out) {
   h->board_valid.upload(std::vector<uint8_t>(p->board_valid, p->board_valid + d.B));
   {
     DevBuf<double2> raw_pts;
+    DevBuf<float2> raw_pts32;        // (a float32 table goes up as it is: half the bytes of the largest upload)
     DevBuf<uint8_t> raw_valid, view_e_unused;
     DevBuf<int32_t> view_ecount;
-    raw_pts.alloc(nslot, false);
     raw_valid.alloc(nslot, false);
     view_ecount.alloc((size_t)d.views(), false);
-    upload_shard_slabs(h.get(), raw_pts.p, p->points, sizeof(double2));
+    if (p->points) {
+      raw_pts.alloc(nslot, false);
+      upload_shard_slabs(h.get(), raw_pts.p, p->points, sizeof(double2));
+    } else {
+      raw_pts32.alloc(nslot, false);
+      upload_shard_slabs(h.get(), raw_pts32.p, p->points_f32, sizeof(float2));
+    }
     upload_shard_slabs(h.get(), raw_valid.p, p->point_valid, 1);
     if (p->inlier_mask) {
       h->raw_mask.alloc(nslot, false);
@@ -1085,7 +1091,7 @@ int32_t mcba_create(const mcba_problem* p, void* hip_stream, mcba_handle* out) {
     }
     if (d.views() > 0) {
       hipLaunchKernelGGL(k_lower_view, dim3(d.views()), dim3(64), 0, h->stream, d, (const double2*)raw_pts.p,
-                         (const uint8_t*)raw_valid.p, (const uint8_t*)(p->inlier_mask ? h->raw_mask.p : nullptr),
+                         (const float2*)raw_pts32.p, (const uint8_t*)raw_valid.p, (const uint8_t*)(p->inlier_mask ? h->raw_mask.p : nullptr),
                          h->cam_valid.p, h->frame_valid.p, h->board_valid.p, h->board_off.p, h->obs.p, h->valid_fm.p,
                          h->evalid.p, h->inlier.p, h->view_count.p, view_ecount.p);
     }

@@ -141,7 +141,8 @@ inline void lower_dims(const mcba_problem* p, HostProblem& hp) {
   MCBA_REQUIRE(p != nullptr, "null problem");
   MCBA_REQUIRE(p->version == MCBA_VERSION, "mcba_problem.version mismatch");
   MCBA_REQUIRE(p->n_cameras > 0 && p->n_frames > 0 && p->n_boards > 0 && p->n_points > 0, "empty problem");
-  MCBA_REQUIRE(p->points && p->point_valid && p->board_sizes && p->camera_valid && p->frame_valid && p->board_valid &&
+  MCBA_REQUIRE((p->points != nullptr) != (p->points_f32 != nullptr), "exactly one of points / points_f32 must be given");
+  MCBA_REQUIRE(p->point_valid && p->board_sizes && p->camera_valid && p->frame_valid && p->board_valid &&
                    p->x_full && p->image_heights && p->fix_aspect,
                "null array in mcba_problem");
   MCBA_REQUIRE(p->motion >= 0 && p->motion <= 2, "unknown motion model");
@@ -332,8 +333,8 @@ inline void lower_problem(const mcba_problem* p, HostProblem& hp) {
           const size_t r0 = (((size_t)c * d.F + d.f0 + fl) * d.B + b) * d.P;
           const size_t s0 = (((size_t)fl * d.C + c) * d.B + b) * d.P;
           for (int q = 0; q < d.P; ++q) {
-            obs[s0 + q].x = p->points[2 * (r0 + q)];
-            obs[s0 + q].y = p->points[2 * (r0 + q) + 1];
+            obs[s0 + q].x = p->points ? p->points[2 * (r0 + q)] : (double)p->points_f32[2 * (r0 + q)];
+            obs[s0 + q].y = p->points ? p->points[2 * (r0 + q) + 1] : (double)p->points_f32[2 * (r0 + q) + 1];
             ev[s0 + q] = hp.evalid_ref[r0 + q];
           }
         }

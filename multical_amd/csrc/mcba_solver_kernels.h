@@ -2712,6 +2712,7 @@ __global__ __launch_bounds__(AV_THREADS) void k_active_scatter(int nviews, const
 // ---------------------------------------------------------------------------------------------------------------
 // one wavefront per view v (frame-major) of the shard; raw slabs are [C][Fl][B][P]
 __global__ __launch_bounds__(64) void k_lower_view(Dims d, const double2* __restrict__ pts_raw,
+                                                   const float2* __restrict__ pts_raw32 /* the table as float32, or null */,
                                                    const uint8_t* __restrict__ pvalid_raw,
                                                    const uint8_t* __restrict__ mask_raw /* or null: inliers = valid */,
                                                    const uint8_t* __restrict__ cam_valid, const uint8_t* __restrict__ frame_valid,
@@ -2733,6 +2734,10 @@ __global__ __launch_bounds__(64) void k_lower_view(Dims d, const double2* __rest
       ev = vv && q < nb;
       in = mask_raw != nullptr ? mask_raw[r0 + q] != 0 : vv;
       if (pts_raw != nullptr) obs[s0 + q] = pts_raw[r0 + q];
+      else if (pts_raw32 != nullptr) {
+        const float2 w = pts_raw32[r0 + q];
+        obs[s0 + q] = make_double2((double)w.x, (double)w.y);
+      }
       if (valid_fm != nullptr) { valid_fm[s0 + q] = vv ? 1 : 0; evalid[s0 + q] = ev ? 1 : 0; }
       inlier[s0 + q] = in ? 1 : 0;
     }

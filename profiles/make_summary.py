@@ -79,7 +79,8 @@ def collect_round(tag, root):
                    ("frame_groups.log", f"{tag}_frame_groups.txt"), ("chol_phases.log", f"{tag}_cholesky_phases.txt"),
                    ("chol_paths.log", f"{tag}_cholesky_paths.txt"), ("init.log", f"{tag}_initialise_poses.txt"),
                    ("workspace_cfg3.log", f"{tag}_workspace_calibrate_cfg3.txt"), ("workspace_cfg4.log", f"{tag}_workspace_calibrate_cfg4.txt"),
-                   ("workspace_cfg2.log", f"{tag}_workspace_calibrate_cfg2.txt"), ("parity_table.md", "parity_table.md"),
+                   ("workspace_cfg2.log", f"{tag}_workspace_calibrate_cfg2.txt"),
+                   ("workspace_cfg3_f32.log", f"{tag}_workspace_calibrate_cfg3_float32.txt"), ("parity_table.md", "parity_table.md"),
                    ("parity_table.json", "parity_table.json"), ("lsmr_mode.md", f"{tag}_lsmr_mode.md")):
     p = os.path.join(root, src)
     if os.path.exists(p) and os.path.getsize(p) > 0:

@@ -22,6 +22,7 @@ python bench.py > $O/bench.json 2> $O/bench.err
 tail -c 300 $O/bench.json
 python tests/prof_linearize.py > $O/lin_phases.log 2>&1; tail -12 $O/lin_phases.log
 for CFG in cfg3 cfg4 cfg2; do MCBA_TIMING=1 python tests/prof_workspace.py $CFG > $O/workspace_$CFG.log 2>&1; grep "calibrate ms" $O/workspace_$CFG.log; done
+MCBA_TIMING=1 python tests/prof_workspace.py cfg3 --float32 > $O/workspace_cfg3_f32.log 2>&1; grep "calibrate ms" $O/workspace_cfg3_f32.log
 python tests/prof_lin_cfgs.py cfg2 cfg3 cfg4 cfg5 > $O/lin_cfgs.log 2>&1; cat $O/lin_cfgs.log
 python tests/prof_r4.py frames cfg3 cfg4 > $O/frame_groups.log 2>&1; cat $O/frame_groups.log
 python tests/prof_chol_phases.py > $O/chol_phases.log 2>&1; tail -4 $O/chol_phases.log

@@ -3,7 +3,12 @@ import sys, time, cProfile, pstats, io
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 from multical_amd import synthetic, calibration, Workspace
 name = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
-rig = synthetic.make_rig(name); c = calibration.from_rig(rig)
+rig = synthetic.make_rig(name)
+if "--float32" in sys.argv:      # corners as cv2 detects them and as the reference's point table keeps them (tables.py:15-17)
+  import numpy as np
+  rig.points = rig.points.astype(np.float32)
+  print("point table: float32")
+c = calibration.from_rig(rig)
 ws = Workspace(c); ws.calibrate(cameras=rig.optimize["cameras"], camera_poses=rig.optimize["camera_poses"])
 calibration.handle_cache.clear()
 ws = Workspace(c)

@@ -571,6 +571,15 @@ def test_handle_cache_sees_a_changed_validity_mask_and_float32_tables():
     cm = mirror(rg)
     ocm = restate.from_rig(rg)
     assert np.abs(cm.residuals() - ocm.evaluate(cm.param_vec)).max() < 1e-9
+  # a float32 table goes up as float32 (mcba_problem.points_f32) and is widened on the device: the same bits as the
+  # widened copy uploaded as float64
+  rg = synthetic.make_rig("tiny_rolling", seed=5)
+  p32 = rg.points.astype(np.float32)
+  rg.points = p32
+  r32 = mirror(rg).residuals()
+  rg.points = p32.astype(np.float64)
+  r64 = mirror(rg).residuals()
+  assert r32.size == r64.size and np.array_equal(r32, r64)
 
 
 @pytest.mark.parametrize("switch", ["MCBA_FUSED=0", "MCBA_ASM_STAGE_KB=4", "MCBA_FUSED=0,MCBA_TMAT_GLOBAL=1",
