@@ -288,6 +288,15 @@ int32_t mcba_dense_hessian(mcba_handle h, double* H);
 int32_t mcba_align_poses_robust(int32_t n_problems, const int64_t* offsets, const double* A, const double* B,
                                 const uint8_t* mask, double threshold, int32_t invert, double* out, uint8_t* out_valid,
                                 uint8_t* inliers);
+/* The same batch with the pairs given as INDICES into pose tables: entry k of a problem is the pair
+ * (table_a[index_a[k]], table_b[index_b[k]]), the tables hold n_a / n_b poses (row-major 4x4; table_a == table_b is one upload).
+ * tables.estimate_relative_poses (tables.py:207-227) aligns `np.take(table, i, axis)` with `np.take(table, j, axis)` for
+ * every pair of its spanning tree: the pose table [C,F,B] goes up ONCE and the pair lists as 32-bit indices, instead of two
+ * gathered copies of it per pair.                                                                                      */
+int32_t mcba_align_poses_indexed(int32_t n_problems, const int64_t* offsets, const double* table_a, int64_t n_a,
+                                 const int32_t* index_a, const double* table_b, int64_t n_b, const int32_t* index_b,
+                                 const uint8_t* mask, double threshold, int32_t invert, double* out, uint8_t* out_valid,
+                                 uint8_t* inliers);
 
 /* --- solve -------------------------------------------------------------------------------------------------- */
 /* Trust-region least squares: replaces scipy.optimize.least_squares(method='trf', x_scale='jac', jac_sparsity=S,

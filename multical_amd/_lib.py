@@ -83,6 +83,8 @@ SYMBOLS = [
   ("mcba_project_model", C.c_int32, [H, c_double_p, C.c_int32, c_double_p]),
   ("mcba_align_poses_robust", C.c_int32, [C.c_int32, C.POINTER(C.c_int64), c_double_p, c_double_p, c_uint8_p, C.c_double,
                                           C.c_int32, c_double_p, c_uint8_p, c_uint8_p]),
+  ("mcba_align_poses_indexed", C.c_int32, [C.c_int32, C.POINTER(C.c_int64), c_double_p, C.c_int64, c_int32_p, c_double_p, C.c_int64,
+                                           c_int32_p, c_uint8_p, C.c_double, C.c_int32, c_double_p, c_uint8_p, c_uint8_p]),
   ("mcba_error_stats", C.c_int32, [H, c_double_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), c_double_p,
                                    C.POINTER(C.c_int64), c_double_p]),
   ("mcba_error_count", C.c_int32, [H, C.c_int32, C.POINTER(C.c_int64)]),

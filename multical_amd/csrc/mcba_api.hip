@@ -1532,13 +1532,15 @@ int32_t mcba_project(mcba_handle h, const double* x, double* projected) {
 
 /* matrix.align_transforms_robust (transform/matrix.py:140-153) for a BATCH of problems on the device: the numeric core of
  * tables.estimate_transform (tables.py:153-176) and tables.relative_between_n (tables.py:334-345).  No handle: the
- * initialisation runs before a Calibration exists.                                                                     */
-int32_t mcba_align_poses_robust(int32_t n_problems, const int64_t* offsets, const double* A, const double* B,
-                                const uint8_t* mask, double threshold, int32_t invert, double* out, uint8_t* out_valid,
-                                uint8_t* inliers) {
-  API_BEGIN
+ * initialisation runs before a Calibration exists.  nA / nB = poses in A / B (ia, ib == nullptr: one per entry).
+ * The stream and every buffer of a call are parked in the resource cache and taken back by the next call of the same
+ * shape (an initialisation makes three calls; created and freed anew they cost 18 of its 32 ms at 16 x 1000 x 5). */
+namespace {
+void align_poses(int32_t n_problems, const int64_t* offsets, const double* A, int64_t nA, const int32_t* ia, const double* B,
+                 int64_t nB, const int32_t* ib, const uint8_t* mask, double threshold, int32_t invert, double* out,
+                 uint8_t* out_valid, uint8_t* inliers) {
   REQUIRE(n_problems >= 0 && offsets && A && B && out && out_valid, "bad argument");
-  if (n_problems == 0) return 0;
+  if (n_problems == 0) return;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
     throw Error("no HIP device: the mcba back-end is GPU-only (there is no CPU fallback)");
@@ -1550,21 +1552,49 @@ int32_t mcba_align_poses_robust(int32_t n_problems, const int64_t* offsets, cons
   }
   REQUIRE(offsets[0] == 0 && total >= 0, "offsets must start at 0");
   REQUIRE(nmax < (1ll << 24), "more than 2^24 pose pairs in one alignment problem");
-  hipStream_t st = nullptr;
-  HIP_OK(hipStreamCreate(&st));
-  struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } guard{st};
+  REQUIRE((ia == nullptr) == (ib == nullptr), "both index lists or none");
+  if (ia != nullptr) {
+    REQUIRE(nA > 0 && nB > 0 && nA < (1ll << 31) && nB < (1ll << 31), "bad pose table size");
+    for (int64_t k = 0; k < total; ++k)
+      REQUIRE(ia[k] >= 0 && ia[k] < nA && ib[k] >= 0 && ib[k] < nB, "pose index out of range");
+  }
+  const bool timing = getenv("MCBA_TIMING") != nullptr;
+  const double t0 = now_seconds();
+  hipStream_t st = resource_cache().take_stream();
+  if (st == nullptr) HIP_OK(hipStreamCreate(&st));
+  struct StreamGuard {     // the stream goes back to the resource cache (it is idle: every path below synchronises or throws)
+    hipStream_t s;
+    ~StreamGuard() {
+      if (!resource_cache().park_stream(s)) (void)hipStreamDestroy(s);
+    }
+  } guard{st};
   g_fill_stream = st;
-  DevBuf<long long> d_off;
+  {
+  struct ParkReset { ~ParkReset() { g_park_on_release = false; } } park_reset;   // (declared first: runs after the buffers went)
+  DevBuf<long long> d_off, d_prof;
   DevBuf<double> dA, dB, d_out, d_f64;
   DevBuf<uint8_t> d_mask, d_valid, d_inl;
   DevBuf<int> d_i32;
-  d_off.upload(std::vector<long long>(offsets, offsets + n_problems + 1));
+  DevBuf<int32_t> d_ia, d_ib;
+  d_off.alloc((size_t)n_problems + 1, false);
+  {
+    static_assert(sizeof(long long) == sizeof(int64_t), "offsets are copied as they are");
+    HIP_OK(hipMemcpyAsync(d_off.p, offsets, ((size_t)n_problems + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
+  }
   const size_t tot = (size_t)std::max<int64_t>(total, 1);
-  dA.alloc(16 * tot, false);
-  dB.alloc(16 * tot, false);
+  const size_t cntA = ia ? (size_t)nA : tot, cntB = ib ? (size_t)nB : tot;
+  dA.alloc(16 * cntA, false);
+  const bool same_table = ia != nullptr && A == B && nA == nB;
+  if (!same_table) dB.alloc(16 * cntB, false);
   if (total > 0) {
-    HIP_OK(hipMemcpyAsync(dA.p, A, 16 * (size_t)total * sizeof(double), hipMemcpyHostToDevice, st));
-    HIP_OK(hipMemcpyAsync(dB.p, B, 16 * (size_t)total * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(dA.p, A, 16 * (ia ? (size_t)nA : (size_t)total) * sizeof(double), hipMemcpyHostToDevice, st));
+    if (!same_table) HIP_OK(hipMemcpyAsync(dB.p, B, 16 * (ib ? (size_t)nB : (size_t)total) * sizeof(double), hipMemcpyHostToDevice, st));
+    if (ia != nullptr) {
+      d_ia.alloc(tot, false);
+      d_ib.alloc(tot, false);
+      HIP_OK(hipMemcpyAsync(d_ia.p, ia, (size_t)total * sizeof(int32_t), hipMemcpyHostToDevice, st));
+      HIP_OK(hipMemcpyAsync(d_ib.p, ib, (size_t)total * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    }
   }
   if (mask) {
     d_mask.alloc(tot, false);
@@ -1590,7 +1620,6 @@ int32_t mcba_align_poses_robust(int32_t n_problems, const int64_t* offsets, cons
   sc.parent = sc.rep_b + np_ * per;
   sc.list = sc.parent + np_ * per;
   sc.live = sc.list + np_ * per;
-  DevBuf<long long> d_prof;
   static const bool align_prof = getenv("MCBA_ALIGN_PROF") != nullptr;
   sc.prof = nullptr;
   if (align_prof) {
@@ -1605,14 +1634,19 @@ int32_t mcba_align_poses_robust(int32_t n_problems, const int64_t* offsets, cons
   const size_t lds = align_lds_bytes(lds_cap);
   // (a per-DEVICE attribute: set on every call, it costs nothing next to the copies)
   HIP_OK(hipFuncSetAttribute((const void*)k_align_robust, hipFuncAttributeMaxDynamicSharedMemorySize, (int)align_lds_bytes(ALIGN_LDS_CAP)));
-  hipLaunchKernelGGL(k_align_robust, dim3(n_problems), dim3(ALIGN_THREADS), lds, st, d_off.p, dA.p, dB.p,
-                     (const uint8_t*)(mask ? d_mask.p : nullptr), threshold, (int)invert, (long long)per, sc, d_out.p,
-                     d_valid.p, d_inl.p, lds_cap);
+  const double t1 = now_seconds();
+  hipLaunchKernelGGL(k_align_robust, dim3(n_problems), dim3(ALIGN_THREADS), lds, st, d_off.p, dA.p,
+                     (const double*)(same_table ? dA.p : dB.p), (const int32_t*)(ia ? d_ia.p : nullptr),
+                     (const int32_t*)(ib ? d_ib.p : nullptr), (const uint8_t*)(mask ? d_mask.p : nullptr), threshold, (int)invert,
+                     (long long)per, sc, d_out.p, d_valid.p, d_inl.p, lds_cap);
   check_launch("k_align_robust");
   HIP_OK(hipMemcpyAsync(out, d_out.p, 16 * (size_t)n_problems * sizeof(double), hipMemcpyDeviceToHost, st));
   HIP_OK(hipMemcpyAsync(out_valid, d_valid.p, (size_t)n_problems, hipMemcpyDeviceToHost, st));
   if (inliers && total > 0) HIP_OK(hipMemcpyAsync(inliers, d_inl.p, (size_t)total, hipMemcpyDeviceToHost, st));
   HIP_OK(hipStreamSynchronize(st));
+  if (timing)
+    fprintf(stderr, "[align_poses] %d problems, %lld entries: buffers + uploads %.2f ms, kernel + downloads %.2f ms\n", n_problems,
+            (long long)total, (t1 - t0) * 1e3, (now_seconds() - t1) * 1e3);
   if (align_prof) {   // phase cycles of the largest problem
     std::vector<long long> hp(np_ * 32);
     HIP_OK(hipMemcpy(hp.data(), d_prof.p, hp.size() * sizeof(long long), hipMemcpyDeviceToHost));
@@ -1626,6 +1660,26 @@ int32_t mcba_align_poses_robust(int32_t n_problems, const int64_t* offsets, cons
         fprintf(stderr, "[k_align_robust] problem %d (n = %lld) pass %d %-18s %10lld\n", big,
                 (long long)(offsets[big + 1] - offsets[big]), pass, names[k], hp[(size_t)big * 32 + 16 * pass + k]);
   }
+  g_park_on_release = true;   // regular end: the buffers of this scope are parked for the next call of the same shape
+  }
+}
+}  // namespace
+
+int32_t mcba_align_poses_robust(int32_t n_problems, const int64_t* offsets, const double* A, const double* B,
+                                const uint8_t* mask, double threshold, int32_t invert, double* out, uint8_t* out_valid,
+                                uint8_t* inliers) {
+  API_BEGIN
+  align_poses(n_problems, offsets, A, 0, nullptr, B, 0, nullptr, mask, threshold, invert, out, out_valid, inliers);
+  API_END
+}
+
+int32_t mcba_align_poses_indexed(int32_t n_problems, const int64_t* offsets, const double* table_a, int64_t n_a,
+                                 const int32_t* index_a, const double* table_b, int64_t n_b, const int32_t* index_b,
+                                 const uint8_t* mask, double threshold, int32_t invert, double* out, uint8_t* out_valid,
+                                 uint8_t* inliers) {
+  API_BEGIN
+  REQUIRE(index_a && index_b, "null index list");
+  align_poses(n_problems, offsets, table_a, n_a, index_a, table_b, n_b, index_b, mask, threshold, invert, out, out_valid, inliers);
   API_END
 }
 

@@ -371,8 +371,11 @@ __device__ __forceinline__ void rtvec_to_matrix4(const double* v, double* R, dou
 //   invert != 0: relative_between_inv (tables.py:334-335): the inputs are inverted and so is the result.
 //   out[p] = the aligned transform (identity when the problem has no masked entry -> out_valid[p] = 0);
 //   inliers (or null) = the entries that passed the outlier test.
+//   ia / ib (or null): entry k of the problem is the pair (A[ia[e0 + k]], B[ib[e0 + k]]) of two pose TABLES instead of
+//   (A[e0 + k], B[e0 + k]) -- mcba_align_poses_indexed: the pose table goes up once, the pair lists as 32-bit indices.
 __global__ __launch_bounds__(ALIGN_THREADS) void k_align_robust(const long long* __restrict__ off, const double* __restrict__ A,
-                                                                const double* __restrict__ B, const uint8_t* __restrict__ mask,
+                                                                const double* __restrict__ B, const int32_t* __restrict__ ia,
+                                                                const int32_t* __restrict__ ib, const uint8_t* __restrict__ mask,
                                                                 double threshold, int invert, long long scratch_stride,
                                                                 AlignScratch base, double* __restrict__ out,
                                                                 uint8_t* __restrict__ out_valid, uint8_t* __restrict__ inliers,
@@ -389,12 +392,10 @@ __global__ __launch_bounds__(ALIGN_THREADS) void k_align_robust(const long long*
     s.vec += 6 * o; s.cen += 6 * o; s.err += o; s.hgt += o; s.nd += o; s.size += o; s.chain += o; s.rep_a += o; s.rep_b += o;
     s.parent += o; s.list += o; s.live += o;
   }
-  const double* Ap = A + 16 * e0;
-  const double* Bp = B + 16 * e0;
   const uint8_t* mp = mask ? mask + e0 : nullptr;
   auto load_pair = [&](int k, double* Ra, double* ta, double* Rb, double* tb) {
-    se3_load(Ap + 16 * (size_t)k, Ra, ta);
-    se3_load(Bp + 16 * (size_t)k, Rb, tb);
+    se3_load(A + 16 * (size_t)(ia != nullptr ? (long long)ia[e0 + k] : e0 + k), Ra, ta);
+    se3_load(B + 16 * (size_t)(ib != nullptr ? (long long)ib[e0 + k] : e0 + k), Rb, tb);
     if (invert) {
       double Ri[9], ti[3];
       se3_inv(Ra, ta, Ri, ti);

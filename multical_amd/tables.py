@@ -56,6 +56,34 @@ def align_transforms_robust_ragged(A, B, sizes, mask=None, threshold=1.5, invert
   return out, valid.astype(bool), inl[:total].astype(bool)
 
 
+def align_transforms_robust_indexed(table, index_a, index_b, sizes, mask=None, threshold=1.5, invert=False):
+  """The same device batch with the pairs given as indices into ONE pose table [N, 4, 4] (mcba_align_poses_indexed): entry k is
+  the pair (table[index_a[k]], table[index_b[k]]).  Returns (transforms [P,4,4], valid [P] bool, inlier flags [total] bool)."""
+  lib = _lib.load()
+  sizes = np.asarray(sizes, dtype=np.int64).reshape(-1)
+  P = int(sizes.size)
+  if P == 0:
+    return np.zeros((0, 4, 4)), np.zeros(0, dtype=bool), np.zeros(0, dtype=bool)
+  offsets = np.ascontiguousarray(np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64))
+  total = int(offsets[-1])
+  table = _f64(table).reshape(-1, 4, 4)
+  ia = np.ascontiguousarray(np.asarray(index_a).reshape(-1), dtype=np.int32) if total else np.zeros(1, dtype=np.int32)
+  ib = np.ascontiguousarray(np.asarray(index_b).reshape(-1), dtype=np.int32) if total else np.zeros(1, dtype=np.int32)
+  assert ia.size == max(total, 1) and ib.size == max(total, 1) and table.shape[0] > 0
+  if mask is not None:
+    mask = np.ascontiguousarray(np.asarray(mask).astype(np.uint8).reshape(-1)) if total else np.zeros(1, dtype=np.uint8)
+  out = np.empty((P, 4, 4))
+  valid = np.empty(P, dtype=np.uint8)
+  inl = np.empty(max(total, 1), dtype=np.uint8)
+  dp, up, ip = C.POINTER(C.c_double), C.POINTER(C.c_uint8), C.POINTER(C.c_int32)
+  tp = table.ctypes.data_as(dp)
+  check(lib.mcba_align_poses_indexed(P, offsets.ctypes.data_as(C.POINTER(C.c_int64)), tp, table.shape[0], ia.ctypes.data_as(ip), tp,
+                                     table.shape[0], ib.ctypes.data_as(ip), None if mask is None else mask.ctypes.data_as(up),
+                                     float(threshold), 1 if invert else 0, out.ctypes.data_as(dp), valid.ctypes.data_as(up),
+                                     inl.ctypes.data_as(up)))
+  return out, valid.astype(bool), inl[:total].astype(bool)
+
+
 def align_transforms_robust_batch(problems, threshold=1.5, invert=False):
   """problems: list of (m1 [n,4,4], m2 [n,4,4], mask [n] bool or None).  Returns (transforms [P,4,4], valid [P] bool,
   list of inlier masks) -- per problem exactly matrix.align_transforms_robust(m1, m2, valid=mask, threshold)
@@ -78,12 +106,24 @@ def align_transforms_robust_batch(problems, threshold=1.5, invert=False):
 
 # ---- host control logic on [n, n] matrices (tables.py:134-148, graph.py:7-33) -------------------------------------------
 def pattern_overlaps(table, axis=0):
+  """tables.py:134-148: overlaps[i, j] = sum over the entries both i and j see of min(num_points).  The reference sums
+  `has_pose.astype(float32) * weight` per pair; the terms are integers, so the float32 sum is EXACT (independent of its order)
+  while it stays below 2^24 -- then one row of min() per index replaces the n (n - 1) / 2 np.take pairs (6 ms at 16 cameras x 1000
+  frames x 5 boards); larger sums keep the reference's expression."""
   n = table.valid.shape[axis]
+  V = np.moveaxis(np.asarray(table.valid), axis, 0).reshape(n, -1)
+  W = np.moveaxis(np.asarray(table.num_points), axis, 0).reshape(n, -1)
+  Wv = np.where(V, W, 0).astype(np.int64)          # min(w_i, w_j) over the common entries = min of the masked weights
   overlaps = np.zeros([n, n])
+  if n > 0 and int(Wv.sum(axis=1).max(initial=0)) < (1 << 24):
+    for i in range(n):
+      overlaps[i] = np.minimum(Wv[i][None], Wv).sum(axis=1)
+    np.fill_diagonal(overlaps, 0.0)
+    return overlaps
   for i in range(n):
     for j in range(i + 1, n):
-      has_pose = np.take(table.valid, i, axis=axis) & np.take(table.valid, j, axis=axis)
-      weight = np.minimum(np.take(table.num_points, i, axis=axis), np.take(table.num_points, j, axis=axis))
+      has_pose = V[i] & V[j]
+      weight = np.minimum(W[i], W[j])
       overlaps[i, j] = overlaps[j, i] = np.sum(has_pose.astype(np.float32) * weight)
   return overlaps
 
@@ -106,29 +146,45 @@ def select_pairs(overlaps, hop_penalty=0.8):
   return master, pairs
 
 
-def inverse(table):
-  """tables.inverse (tables.py:229-230 use): the poses are rigid transforms, so the inverse is (R^T | -R^T t) -- the closed
-  form agrees with the reference's np.linalg.inv to the last bits (1e-16) and costs a tenth (80 000 4x4 LU inverses: 6 ms
-  each of the five calls of an initialisation)."""
-  m = np.asarray(table.poses, dtype=np.float64)
-  Rt = np.swapaxes(m[..., :3, :3], -1, -2)
-  out = np.zeros_like(m)
-  out[..., :3, :3] = Rt
-  out[..., :3, 3] = -np.einsum('...ij,...j->...i', Rt, m[..., :3, 3])
+def inverse_poses(m):
+  """(R | t) -> (R^T | -R^T t): the closed form agrees with the reference's np.linalg.inv (tables.py:229-230 use) to the last
+  bits (1e-16) and costs a tenth of it."""
+  m = np.asarray(m, dtype=np.float64)
+  out = np.zeros(m.shape)
+  out[..., :3, :3] = np.swapaxes(m[..., :3, :3], -1, -2)
+  t = m[..., :3, 3]
+  out[..., :3, 3] = -((m[..., 0, :3] * t[..., 0:1] + m[..., 1, :3] * t[..., 1:2]) + m[..., 2, :3] * t[..., 2:3])
   out[..., 3, 3] = 1.0
-  return table._extend(poses=out)
+  return out
 
 
-def estimate_relative_poses(table, axis=0, hop_penalty=0.9):
-  """tables.py:207-227: all pair alignments of the spanning tree in one device batch."""
+def inverse(table):
+  """tables.inverse (tables.py:229-230 use)."""
+  return table._extend(poses=inverse_poses(table.poses))
+
+
+def estimate_relative_poses(table, axis=0, hop_penalty=0.9, of_inverse=False):
+  """tables.py:207-227: all pair alignments of the spanning tree in one device batch.
+  of_inverse: the result for `inverse(table)` without forming that table -- the device inverts the gathered entries as it loads
+  them (`invert`: relative_between_inv semantics, inputs AND result inverted) and the handful of results is inverted back here
+  (the closed-form inverse of all 80 000 poses of a 16 x 1000 x 5 table was a third of the host time of an initialisation)."""
   n = table.valid.shape[axis]
   master, pairs = select_pairs(pattern_overlaps(table, axis=axis), hop_penalty)
-  problems = []
-  for parent, child in pairs:
-    ti_p, tj_p = np.take(table.poses, parent, axis=axis), np.take(table.poses, child, axis=axis)
-    valid = (np.take(table.valid, parent, axis=axis) & np.take(table.valid, child, axis=axis)).ravel()
-    problems.append((ti_p.reshape(-1, 4, 4), tj_p.reshape(-1, 4, 4), valid))
-  ts, ok, _ = align_transforms_robust_batch(problems)
+  if pairs:
+    # the pose table goes to the device as it is and the batch [pairs x entries] as two lists of indices into it (per-pair np.take
+    # + a concatenation of the problems were three host copies of every side, 10 ms at 15 pairs x 5 000 entries, and 19 MB of
+    # upload where the table has 10)
+    shape3 = np.asarray(table.valid).shape
+    idx = np.moveaxis(np.arange(int(np.prod(shape3)), dtype=np.int32).reshape(shape3), axis, 0).reshape(n, -1)
+    V = np.moveaxis(np.asarray(table.valid), axis, 0).reshape(n, -1)
+    par = np.fromiter((p for p, _ in pairs), dtype=np.intp, count=len(pairs))
+    chi = np.fromiter((c for _, c in pairs), dtype=np.intp, count=len(pairs))
+    ts, ok, _ = align_transforms_robust_indexed(table.poses, idx[par], idx[chi], np.full(len(pairs), V.shape[1], dtype=np.int64),
+                                                (V[par] & V[chi]).reshape(-1), invert=of_inverse)
+    if of_inverse:
+      ts = inverse_poses(ts)
+  else:
+    ts, ok = np.zeros((0, 4, 4)), np.zeros(0, dtype=bool)
   pose_dict = {master: np.eye(4)}
   for (parent, child), t, good in zip(pairs, ts, ok):
     if not good:
@@ -147,7 +203,7 @@ def estimate_relative_poses(table, axis=0, hop_penalty=0.9):
 
 def estimate_relative_poses_inv(table, axis=2, hop_penalty=0.9):
   """tables.py:229-230."""
-  return inverse(estimate_relative_poses(inverse(table), axis=axis, hop_penalty=hop_penalty))
+  return inverse(estimate_relative_poses(table, axis=axis, hop_penalty=hop_penalty, of_inverse=True))
 
 
 def relative_between_n(table1, table2, axis=0, inv=False):
@@ -170,12 +226,21 @@ def initialise_poses(pose_table, camera_poses=None):
     camera = Table.create(poses=np.asarray(camera_poses, dtype=np.float64), valid=np.ones(len(camera_poses), dtype=bool))
   board = estimate_relative_poses_inv(pose_table, axis=2)
   binv = inverse(board)
-  # cam @ rig @ board = pose  ->  cam @ rig = board_relative = pose @ board^-1
-  board_relative = Table.create(poses=pose_table.poses @ binv.poses[None, None],
-                                valid=pose_table.valid & binv.valid[None, None])
-  expanded = Table.create(poses=np.broadcast_to(camera.poses[:, None, None], board_relative.poses.shape),
-                          valid=np.broadcast_to(camera.valid[:, None, None], board_relative.valid.shape))
-  times = relative_between_n(expanded, board_relative, axis=1, inv=True)
+  # cam @ rig @ board = pose  ->  cam @ rig = board_relative = pose @ board^-1, then one alignment per frame between the camera
+  # poses (expanded over frames and boards, tables.py:366-372) and board_relative over the entries valid in both:
+  # `relative_between_n(expanded, board_relative, axis=1, inv=True)`.  Only those entries are ever read, so only they are formed
+  # (the two full [C, F, B, 4, 4] tables, the broadcast copy and two boolean selections were 14 ms of host time at 16 x 1000 x 5,
+  # where 15 455 of the 80 000 entries take part), in the order the reference's selection gives them: (frame | camera, board).
+  poses = np.asarray(pose_table.poses, dtype=np.float64)
+  C_, F, B = poses.shape[:3]
+  v = (np.asarray(pose_table.valid) & binv.valid[None, None] & np.asarray(camera.valid)[:, None, None])
+  vf = np.moveaxis(v, 1, 0).reshape(F, C_ * B)
+  f_idx, e_idx = np.nonzero(vf)
+  c_idx, b_idx = e_idx // B, e_idx % B
+  p1 = np.asarray(camera.poses, dtype=np.float64)[c_idx]
+  p2 = poses[c_idx, f_idx, b_idx] @ binv.poses[b_idx]
+  rig, rig_valid, _ = align_transforms_robust_ragged(p1, p2, vf.sum(axis=1), None, invert=True)
+  times = Table.create(poses=rig, valid=rig_valid)
   return struct(times=times, camera=camera, board=board)
 
 

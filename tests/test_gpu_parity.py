@@ -721,6 +721,25 @@ def test_align_transforms_robust_batch_edge_cases():
     assert np.abs(o - want).max() < 1e-9
 
 
+def test_align_poses_indexed_equals_the_gathered_batch():
+  """mcba_align_poses_indexed (pairs as indices into one pose table) against mcba_align_poses_robust on the gathered copies:
+  the same bits, with and without mask / inversion, for problems of different sizes (one of them empty)."""
+  from multical_amd import tables as mtables
+  rng = np.random.default_rng(17)
+  table = synthetic.to_matrix(np.concatenate([rng.normal(0, 0.4, (300, 3)), rng.normal(0, 1.0, (300, 3))], axis=1))
+  sizes = np.array([40, 0, 7, 120, 1, 33])
+  total = int(sizes.sum())
+  ia, ib = rng.integers(0, 300, total), rng.integers(0, 300, total)
+  for mask in (None, rng.random(total) < 0.8):
+    for invert in (False, True):
+      o1, v1, i1 = mtables.align_transforms_robust_indexed(table, ia, ib, sizes, mask, invert=invert)
+      o2, v2, i2 = mtables.align_transforms_robust_ragged(table[ia], table[ib], sizes, mask, invert=invert)
+      assert np.array_equal(v1, v2) and np.array_equal(i1, i2) and np.array_equal(o1, o2)
+      assert not v1[1] and v1[0]
+  with pytest.raises(Exception, match="out of range"):
+    mtables.align_transforms_robust_indexed(table, np.full(total, 300), ib, sizes)
+
+
 def test_align_transforms_robust_with_duplicated_poses():
   """Exact duplicates among the relative poses (repeated or noise-free detections) give zero-height merges that TIE at
   the dendrogram cut: scipy's fcluster(maxclust) applies every merge up to the threshold height, so fewer than t flat
