@@ -2676,10 +2676,19 @@ int32_t mcba_adjust_outliers(mcba_handle h, double* x_inout, const mcba_options*
     *out = st.n > 0 ? st.quantiles[0] : 0.0;
     return 0;
   };
+  const bool timing = getenv("MCBA_TIMING") != nullptr;
+  double tt = now_seconds();
+  auto lap = [&](const char* what, int i) {
+    if (!timing) return;
+    const double now = now_seconds();
+    fprintf(stderr, "[mcba_adjust_outliers] round %d %-8s %.3f ms\n", i, what, (now - tt) * 1e3);
+    tt = now;
+  };
   for (int i = 0; i < num_adjustments; ++i) {
     mcba_round_report& r = rounds[i];
     memset(&r, 0, sizeof(r));
     if (int32_t rc = report(r)) return rc;
+    lap("report", i);
     mcba_options o = *opt;
     r.f_scale = opt->f_scale;
     if (scale_factor >= 0.0) {
@@ -2695,10 +2704,13 @@ int32_t mcba_adjust_outliers(mcba_handle h, double* x_inout, const mcba_options*
       r.threshold = qv * outlier_factor;
       if (int32_t rc = mcba_reject_outliers(h, x_inout, r.threshold, &r.n_kept, &r.n_valid)) return rc;
     }
+    lap("reject", i);
     if (int32_t rc = mcba_solve(h, x_inout, &o, &r.solve)) return rc;
+    lap("solve", i);
   }
   memset(&rounds[num_adjustments], 0, sizeof(mcba_round_report));
   if (int32_t rc = report(rounds[num_adjustments])) return rc;
+  lap("report", num_adjustments);
   if (inliers_out) {
     if (int32_t rc = mcba_get_inliers(h, inliers_out)) return rc;
   }
