@@ -2560,9 +2560,11 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
 /* errors of Calibration.reprojection_error (inliers_only = 0) / reprojection_inliers (1) reduced ON THE DEVICE:
  * n = number of masked points, sum_sq = sum of squared errors, values[i] = exact order statistic of rank ranks[i]
  * (0-based, ascending) found by radix select -- the inputs numpy.quantile needs (calibration.py:37-40,304-310).       */
-int32_t mcba_error_stats(mcba_handle h, const double* x, int32_t inliers_only, int32_t n_ranks, const int64_t* ranks,
-                         double* values, int64_t* n_out, double* sum_sq) {
-  API_BEGIN
+namespace {
+// inlier_sums (may be null; single handles with n_ranks > 0 only): {sum of squares, count} of the INLIERS as well, from the same
+// error pass and behind the same synchronisation (the report of the outlier loop asks for both: mcba_adjust_outliers)
+void error_stats_impl(mcba_handle h, const double* x, int32_t inliers_only, int32_t n_ranks, const int64_t* ranks,
+                      double* values, int64_t* n_out, double* sum_sq, double* inlier_sums) {
   REQUIRE(h && x && n_out && sum_sq, "null argument");
   REQUIRE(n_ranks == 0 || (ranks && values), "null argument");
   g_fill_stream = h->stream;
@@ -2576,10 +2578,16 @@ int32_t mcba_error_stats(mcba_handle h, const double* x, int32_t inliers_only, i
   call_allreduce(h, h->scal.p, 2, 0);
   int64_t n;
   const bool count_known = !h->allreduce;   // single handle: the counts are host-side facts (mcba_error_count)
+  REQUIRE(inlier_sums == nullptr || (count_known && n_ranks > 0), "internal: inlier sums ride with a selection on a single handle");
   if (count_known && n_ranks > 0) {
     // one synchronisation for the whole call: the sums come down behind the selection passes
     n = inliers_only ? h->n_inliers : h->n_evalid;
-    HIP_OK(hipMemcpyAsync(h->h_scal, h->scal.p, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (inlier_sums != nullptr) {
+      hipLaunchKernelGGL(k_err_sums, dim3(grid), dim3(256), 0, h->stream, h->err_fm.p, h->evalid.p, (const uint8_t*)h->inlier.p,
+                         d.slots(), h->costpart.p);
+      hipLaunchKernelGGL(k_sum2, dim3(1), dim3(256), 0, h->stream, h->costpart.p, grid, h->scal.p + 2);
+    }
+    HIP_OK(hipMemcpyAsync(h->h_scal, h->scal.p, 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   } else {
     fetch_scalars(h, 2);
     n = (int64_t)h->h_scal[1];
@@ -2607,6 +2615,17 @@ int32_t mcba_error_stats(mcba_handle h, const double* x, int32_t inliers_only, i
   *sum_sq = h->h_scal[0];                     // (select_ranks_multi synchronised the stream)
   REQUIRE(!count_known || n_ranks == 0 || (int64_t)h->h_scal[1] == n, "inlier count out of sync with the device table");
   *n_out = n;
+  if (inlier_sums != nullptr) {
+    inlier_sums[0] = h->h_scal[2];
+    inlier_sums[1] = h->h_scal[3];
+  }
+}
+}  // namespace
+
+int32_t mcba_error_stats(mcba_handle h, const double* x, int32_t inliers_only, int32_t n_ranks, const int64_t* ranks,
+                         double* values, int64_t* n_out, double* sum_sq) {
+  API_BEGIN
+  error_stats_impl(h, x, inliers_only, n_ranks, ranks, values, n_out, sum_sq, nullptr);
   API_END
 }
 
@@ -2614,8 +2633,10 @@ namespace {
 // numpy.quantile(errors, q) (default method 'linear') from exact order statistics: virtual index (n - 1) q, its floor / ceil
 // ranks by radix select on the device, numpy's _lerp on the host (numpy/lib/_function_base_impl.py)
 struct ErrorStats { int64_t n = 0; double sum_sq = 0.0; std::vector<double> quantiles; };
-int32_t error_stats_with_quantiles(mcba_handle h, const double* x, int inliers_only, const std::vector<double>& q, ErrorStats& out) {
+int32_t error_stats_with_quantiles(mcba_handle h, const double* x, int inliers_only, const std::vector<double>& q, ErrorStats& out,
+                                   ErrorStats* inl_out = nullptr) {
   out.quantiles.assign(q.size(), 0.0);
+  if (inl_out != nullptr) inl_out->n = -1;      // (-1: not delivered -- the caller asks again)
   int64_t n = 0;
   if (int32_t rc = mcba_error_count(h, inliers_only, &n)) return rc;
   double ssq = 0.0;
@@ -2634,7 +2655,18 @@ int32_t error_stats_with_quantiles(mcba_handle h, const double* x, int inliers_o
     ranks[2 * i + 1] = std::min<int64_t>((int64_t)fl + 1, n - 1);
     gamma[i] = virt - fl;
   }
-  if (int32_t rc = mcba_error_stats(h, x, inliers_only, (int32_t)ranks.size(), ranks.data(), vals.data(), &n, &ssq)) return rc;
+  double isums[2] = {0.0, 0.0};
+  const bool with_inl = inl_out != nullptr && !h->allreduce;
+  try {
+    error_stats_impl(h, x, inliers_only, (int32_t)ranks.size(), ranks.data(), vals.data(), &n, &ssq, with_inl ? isums : nullptr);
+  } catch (const std::exception& e) {
+    g_error = e.what();
+    return 1;
+  }
+  if (with_inl) {
+    inl_out->sum_sq = isums[0];
+    inl_out->n = (int64_t)isums[1];
+  }
   out.sum_sq = ssq;
   for (size_t i = 0; i < q.size(); ++i) {
     const double a = vals[2 * i], b = vals[2 * i + 1], diff = b - a;
@@ -2660,8 +2692,9 @@ int32_t mcba_adjust_outliers(mcba_handle h, double* x_inout, const mcba_options*
   const std::vector<double> five = {0.0, 0.25, 0.5, 0.75, 1.0};
   auto report = [&](mcba_round_report& r) -> int32_t {
     ErrorStats all, inl;
-    if (int32_t rc = error_stats_with_quantiles(h, x_inout, 0, five, all)) return rc;
-    if (int32_t rc = error_stats_with_quantiles(h, x_inout, 1, {}, inl)) return rc;
+    if (int32_t rc = error_stats_with_quantiles(h, x_inout, 0, five, all, &inl)) return rc;    // (one pass, one synchronisation)
+    if (inl.n < 0)
+      if (int32_t rc = error_stats_with_quantiles(h, x_inout, 1, {}, inl)) return rc;
     r.n_all = all.n; r.n_inliers = inl.n;
     r.rms_all = all.n > 0 ? std::sqrt(all.sum_sq / (double)all.n) : 0.0;
     r.rms_inliers = inl.n > 0 ? std::sqrt(inl.sum_sq / (double)inl.n) : 0.0;
