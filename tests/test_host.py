@@ -58,6 +58,15 @@ def test_lowering_layout():
   assert n.value == p.x_full.size
   # enable flags follow `optimize[k] is True` (calibration.py:160)
   assert lower(c.enable(cameras=False)).n_params == p.n_params - C_ * 10
+  # a float32 point table (the reference's dtype: tables.py:15-17) is handed over as it is, a float64 one as float64
+  st = _to_struct(p)
+  assert p.points is not None and p.points_f32 is None and bool(st.points) and not bool(st.points_f32)
+  rig.points = rig.points.astype(np.float32)
+  p32 = lower(mirror(rig))
+  st32 = _to_struct(p32)
+  assert p32.points is None and p32.points_f32.dtype == np.float32 and p32.points_f32.flags.c_contiguous
+  assert not bool(st32.points) and bool(st32.points_f32)
+  assert _lib.load().mcba_full_size(ctypes.byref(st32), ctypes.byref(n)) == 0 and n.value == p.x_full.size
 
 
 def test_pickle_holds_only_constructor_fields():
