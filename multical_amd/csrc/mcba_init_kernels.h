@@ -114,9 +114,62 @@ __device__ __forceinline__ void block_argmin(double& v, int& idx, double* sv, in
     if (sv[w] < v || (sv[w] == v && si[w] < idx)) { v = sv[w]; idx = si[w]; }
 }
 
+// k-th smallest (0-based) of the n NON-NEGATIVE doubles v[0..n) (merge heights, errors: their IEEE bit patterns order like the
+// values); every thread of the block takes part and gets the value.  Small sets are RANKED (n^2 / threads comparisons, two
+// barriers); large ones go through a radix select on the bit patterns, eight 8-bit passes with a 256-bin histogram in LDS
+// (ranking 16 000 values is 2.6e8 comparisons on one compute unit -- it was 82 M cycles of the quartile in round 2 and
+// 0.8 M cycles of every dendrogram cut until round 4; the eight passes cost a 26-entry problem more than its clustering).
+constexpr int KTH_RANK_MAX = 2048;
+__device__ double block_kth_smallest(const double* v, int n, int k, double* sv /* shared, [>= 1] */) {
+  __shared__ unsigned int r_hist[256];
+  __shared__ unsigned long long r_prefix;
+  __shared__ int r_rank;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  __syncthreads();                                       // (v may have been written by other threads just now)
+  if (n <= KTH_RANK_MAX) {
+    for (int i = tid; i < n; i += nthr) {
+      const double vi = v[i];
+      int rank = 0;
+      for (int q = 0; q < n; ++q) {
+        const double vq = v[q];
+        rank += (vq < vi || (vq == vi && q < i)) ? 1 : 0;
+      }
+      if (rank == k) sv[0] = vi;                         // (ranks are a permutation: exactly one writer)
+    }
+    __syncthreads();
+    const double r = sv[0];
+    __syncthreads();
+    return r;
+  }
+  if (tid == 0) { r_prefix = 0ull; r_rank = k; }
+  for (int shift = 56; shift >= 0; shift -= 8) {
+    if (tid < 256) r_hist[tid] = 0u;
+    __syncthreads();
+    const unsigned long long pre = r_prefix;
+    for (int i = tid; i < n; i += nthr) {
+      const unsigned long long key = (unsigned long long)__double_as_longlong(v[i]);
+      const bool match = shift == 56 || (key >> (shift + 8)) == (pre >> (shift + 8));
+      if (match) atomicAdd(&r_hist[(unsigned)(key >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int r = r_rank, dgt = 0;
+      while (dgt < 255 && r >= (int)r_hist[dgt]) { r -= (int)r_hist[dgt]; ++dgt; }
+      r_rank = r;
+      r_prefix = pre | ((unsigned long long)dgt << shift);
+    }
+    __syncthreads();
+  }
+  const double r = __longlong_as_double((long long)r_prefix);
+  __syncthreads();
+  return r;
+}
+
 // robust mean of the n 6-vectors vec[0..n) (transform/common.py:6-21) -> out[6]; every thread of the block takes part
+constexpr int ALIGN_TILE = 1024;      // live centroids per LDS tile of the nearest-neighbour scans (56 B each)
 __device__ void robust_mean_block(int n, const AlignScratch& s, double* out /* shared [6] */, double* sv, int* si,
-                                  int* s_int /* shared [4] */, long long* prof = nullptr /* [16] phase cycles of this pass */) {
+                                  int* s_int /* shared [4] */, long long* prof = nullptr /* [16] phase cycles of this pass */,
+                                  double* tile = nullptr /* LDS, 56 B x ALIGN_TILE, when the state lives in memory */) {
   long long tprof = prof ? clock64() : 0;
 #define RM_STAMP(k) if (prof != nullptr && threadIdx.x == 0) { const long long now = clock64(); prof[k] += now - tprof; tprof = now; }
   const int tid = threadIdx.x, nthr = blockDim.x;
@@ -206,32 +259,61 @@ __device__ void robust_mean_block(int n, const AlignScratch& s, double* out /* s
         }
         __syncthreads();
         const int nlive = s_nlive;
-        for (int li = tid; li < nlive; li += nthr) {
-          const int i = live[li];
-          double cx[6];
-          for (int j = 0; j < 6; ++j) cx[j] = s.cen[6 * i + j];
-          const double nx = (double)s.size[i];
+        // The candidates of a scan are the SAME for every thread.  With the clustering state in memory (more selected entries
+        // than the dynamic LDS holds) every candidate was three dependent round trips per wavefront -- live[lc] -> size / centroid
+        // -- per wavefront.  Round 4: the live centroids stream through the idle dynamic LDS in tiles of ALIGN_TILE, loaded by all
+        // threads at once and read as LDS broadcasts (-7 % at the 5 000- and 16 000-entry pair problems of a 16 x 1000 x 5 table).
+        // What bounds a scan is its arithmetic, ~45 FP64-pipe instructions per candidate with every lane busy: keeping the weights
+        // n_c / (n_x + n_c) of the sizes 1 .. 4 in registers instead of dividing per candidate changed nothing (measured).
+        for (int lbase = 0; lbase < nlive; lbase += nthr) {
+          const int li = lbase + tid;
+          const bool active = li < nlive;
+          const int i = active ? live[li] : -1;
+          double cx[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+          if (active)
+            for (int j = 0; j < 6; ++j) cx[j] = s.cen[6 * i + j];
+          const double nx = active ? (double)s.size[i] : 1.0;
           // the candidates are compared on  d^2 n_c / (n_x + n_c)  -- the Ward distance squared without the factor 2 n_x that
           // is common to the scan: the same order as the distances (the square root and the factor are monotone), one division
           // and no square root per candidate; the height sqrt(2 n_x n_c / (n_x + n_c) d^2) is formed once, for the winner,
           // with the expression of the chain algorithm (bit-symmetric in the pair)
           double bkey = INFINITY, bd2 = 0.0;
           int bi = -1, bn = 1;
-          for (int lc = 0; lc < nlive; ++lc) {       // ascending slots: the first minimum is the lowest index
-            const int c = live[lc];
-            if (c == i) continue;
-            const int nci = s.size[c];
+          auto candidate = [&](int c_any, int n_any, const double* cc) {      // (every lane looks at the SAME candidate)
+            const int c = __builtin_amdgcn_readfirstlane(c_any), nci = __builtin_amdgcn_readfirstlane(n_any);
             double d2 = 0.0;
             for (int j = 0; j < 6; ++j) {
-              const double dl = cx[j] - s.cen[6 * c + j];
+              const double dl = cx[j] - cc[j];
               d2 += dl * dl;
             }
             const double ni = (double)nci, key = d2 * ni / (nx + ni);
-            if (key < bkey) { bkey = key; bi = c; bd2 = d2; bn = nci; }
+            if (c != i && key < bkey) { bkey = key; bi = c; bd2 = d2; bn = nci; }
+          };
+          if (tile != nullptr) {
+            int* tile_c = reinterpret_cast<int*>(tile + 6 * (size_t)ALIGN_TILE);     // [ALIGN_TILE] slot | [ALIGN_TILE] size
+            for (int t0 = 0; t0 < nlive; t0 += ALIGN_TILE) {
+              const int nt = min(ALIGN_TILE, nlive - t0);
+              __syncthreads();                       // (the previous tile has been read by everyone)
+              for (int k = tid; k < nt; k += nthr) {
+                const int c = live[t0 + k];
+                tile_c[k] = c;
+                tile_c[ALIGN_TILE + k] = s.size[c];
+                for (int j = 0; j < 6; ++j) tile[6 * k + j] = s.cen[6 * c + j];
+              }
+              __syncthreads();
+              for (int k = 0; k < nt; ++k) candidate(tile_c[k], tile_c[ALIGN_TILE + k], tile + 6 * k);   // ascending slots
+            }
+          } else if (__builtin_amdgcn_readfirstlane(lbase + (tid & ~63)) < nlive) {   // (wave-uniform: the wave owns a cluster)
+            for (int lc = 0; lc < nlive; ++lc) {     // ascending slots: the first minimum is the lowest index
+              const int c = __builtin_amdgcn_readfirstlane(live[lc]);
+              candidate(c, s.size[c], s.cen + 6 * (size_t)c);
+            }
           }
-          nn[i] = bi;
-          const double ni = (double)bn;
-          nd[i] = sqrt(2.0 * nx * ni / (nx + ni) * bd2);
+          if (active) {
+            nn[i] = bi;
+            const double ni = (double)bn;
+            nd[i] = sqrt(2.0 * nx * ni / (nx + ni) * bd2);
+          }
         }
         __syncthreads();
         // reciprocal pairs owned by this thread (cluster i < its partner), found for 64 of its entries at a time: a merge only
@@ -284,22 +366,12 @@ __device__ void robust_mean_block(int n, const AlignScratch& s, double* out /* s
     // tie with it are applied too -- exact duplicates among the relative poses (noise-free or repeated detections) give
     // zero-height merges, and the flat clusters then hold fewer than t_clust groups, exactly as in the reference.
     const int nm = n - 1, keep = n - t_clust;
-    for (int k = tid; k < nm; k += nthr) {
-      const double hk = s.hgt[k];
-      int rank = 0;
-      for (int q = 0; q < nm; ++q) {
-        const double hq = s.hgt[q];
-        rank += (hq < hk || (hq == hk && q < k)) ? 1 : 0;
-      }
-      if (rank == keep - 1) sv[0] = hk;      // (ranks are a permutation: exactly one writer)
-    }
-    __syncthreads();
+    const double thr = block_kth_smallest(s.hgt, nm, keep - 1, sv);
     {
       // Every slot dies at most once (a merge moves the cluster of the smaller slot into the larger one), so the applied
       // merges form a forest of "dies into" links that can be written in parallel; the flat cluster of a point is the slot
       // its links end in.  (The first version ran a union-find without path compression on ONE thread: 37 M cycles for
       // 1300 points, more than the clustering itself.)
-      const double thr = sv[0];
       for (int k = tid; k < nm; k += nthr)
         if (s.hgt[k] <= thr) s.parent[s.rep_a[k]] = s.rep_b[k];
     }
@@ -326,14 +398,30 @@ __device__ void robust_mean_block(int n, const AlignScratch& s, double* out /* s
     atomicMin(&s.chain[r], i);
   }
   __syncthreads();
-  if (tid == 0) {
-    int best = -1, bestc = 0, bestm = 0x7fffffff;
-    for (int i = 0; i < n; ++i) {
-      const int c = s.size[i], mm = s.chain[i];
-      if (c > bestc || (c == bestc && c > 0 && mm < bestm)) { bestc = c; best = i; bestm = mm; }
+  {   // (one thread walking n slots of memory was 0.7 ms of a 16 000-entry problem: block-wide maximum of (count, -smallest member))
+    unsigned long long bestk = 0ull;
+    for (int i = tid; i < n; i += nthr) {
+      const int c = s.size[i];
+      if (c > 0) {
+        const unsigned long long key = ((unsigned long long)(unsigned)c << 32) | (unsigned long long)(0x7fffffffu - (unsigned)s.chain[i]);
+        bestk = key > bestk ? key : bestk;
+      }
     }
-    s_int[0] = best;
-    s_int[1] = bestc;
+    for (int off = 32; off > 0; off >>= 1) {
+      const unsigned long long o = __shfl_down(bestk, off, 64);
+      bestk = o > bestk ? o : bestk;
+    }
+    __shared__ unsigned long long s_best[ALIGN_THREADS / 64];
+    __syncthreads();
+    if ((tid & 63) == 0) s_best[tid >> 6] = bestk;
+    __syncthreads();
+    if (tid == 0) {
+      unsigned long long b = 0ull;
+      for (int w = 0; w < (nthr >> 6); ++w) b = s_best[w] > b ? s_best[w] : b;
+      const int bestc = (int)(b >> 32), bestm = (int)(0x7fffffffu - (unsigned)(b & 0xffffffffull));
+      s_int[0] = bestc > 0 ? s.list[bestm] : -1;      // the slot that holds the cluster of its smallest member
+      s_int[1] = bestc;
+    }
   }
   __syncthreads();
   {                   // mean of the most common cluster (numpy adds the rows in index order; here: fixed tree, ~1e-16 apart)
@@ -467,7 +555,8 @@ __global__ __launch_bounds__(ALIGN_THREADS) void k_align_robust(const long long*
         sl.live = ib + 6 * (size_t)lds_cap;
       }
       ALIGN_STAMP(1)
-      robust_mean_block(cnt, sl, mean6, sv, si, s_int, s.prof ? s.prof + (size_t)p * 32 + 16 * pass : nullptr);
+      robust_mean_block(cnt, sl, mean6, sv, si, s_int, s.prof ? s.prof + (size_t)p * 32 + 16 * pass : nullptr,
+                        cnt > lds_cap && lds_cap * 92 >= ALIGN_TILE * 56 ? align_lds : nullptr);
       ALIGN_STAMP(2)
     }
     if (tid == 0) rtvec_to_matrix4(mean6, Rm, tm);
@@ -489,38 +578,10 @@ __global__ __launch_bounds__(ALIGN_THREADS) void k_align_robust(const long long*
       const double virt = (double)(n - 1) * 0.75;
       const int lo = (int)floor(virt), hi = min(lo + 1, n - 1);
       const double gamma = virt - floor(virt);
-      // the two order statistics by RADIX SELECT on the bit patterns (errors are non-negative: the IEEE bits order like the
-      // values): eight 8-bit passes per statistic, a 256-bin histogram in LDS.  (Ranking every error against every other
-      // was n^2 = 2.6e8 comparisons on ONE compute unit for the 16 000 entries of a board pair: 82 M cycles, more than both
-      // clusterings together.)
-      __shared__ unsigned int r_hist[256];
-      __shared__ unsigned long long r_prefix;
-      __shared__ int r_rank;
-      for (int which = 0; which < 2; ++which) {
-        if (tid == 0) { r_prefix = 0ull; r_rank = which == 0 ? lo : hi; }
-        for (int shift = 56; shift >= 0; shift -= 8) {
-          if (tid < 256) r_hist[tid] = 0u;
-          __syncthreads();
-          const unsigned long long pre = r_prefix;
-          for (int k = tid; k < n; k += nthr) {
-            const unsigned long long key = (unsigned long long)__double_as_longlong(s.err[k]);
-            const bool match = shift == 56 || (key >> (shift + 8)) == (pre >> (shift + 8));
-            if (match) atomicAdd(&r_hist[(unsigned)(key >> shift) & 255u], 1u);
-          }
-          __syncthreads();
-          if (tid == 0) {
-            int r = r_rank, dgt = 0;
-            while (dgt < 255 && r >= (int)r_hist[dgt]) { r -= (int)r_hist[dgt]; ++dgt; }
-            r_rank = r;
-            r_prefix = pre | ((unsigned long long)dgt << shift);
-          }
-          __syncthreads();
-        }
-        if (tid == 0) sv[which] = __longlong_as_double((long long)r_prefix);
-        __syncthreads();
-      }
-      __syncthreads();
-      const double a = sv[0], b = sv[1], diff = b - a;
+      // the two order statistics (block_kth_smallest: ranking for small problems, radix select on the bit patterns for large ones)
+      const double a = block_kth_smallest(s.err, n, lo, sv);
+      const double b = block_kth_smallest(s.err, n, hi, sv);
+      const double diff = b - a;
       const double uq = gamma >= 0.5 ? b - diff * (1.0 - gamma) : a + diff * gamma;   // numpy _lerp
       __syncthreads();
       for (int k = tid; k < n; k += nthr) {

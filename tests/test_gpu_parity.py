@@ -704,7 +704,7 @@ def test_align_transforms_robust_batch_edge_cases():
     return synthetic.to_matrix(np.concatenate([rng.normal(0, sigma, (n, 3)), rng.normal(0, 1.0, (n, 3))], axis=1))
   T = synthetic.to_matrix(np.array([0.3, -0.2, 0.5, 0.1, 0.2, -0.4]))
   problems = []
-  for n in (1, 2, 3, 9, 10, 11, 29, 30, 31, 200):
+  for n in (1, 2, 3, 9, 10, 11, 29, 30, 31, 200, 2600):     # (2600: ranking -> radix select, clustering state in memory + LDS tiles)
     a = poses(n, 0.5)
     b = synthetic.perturb(T @ a, rng, 1e-3, 1e-3)
     if n > 8:
