@@ -10,6 +10,7 @@
 //     Jacobian is computed exactly from the analytic normal equations (Schur elimination of the per-frame pose blocks
 //     + dense Cholesky of the reduced system), all on the GPU.  Only 2x2 algebra and control flow run on the host.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <algorithm>
 #include <dlfcn.h>
 #include <chrono>
@@ -1635,6 +1636,88 @@ void align_poses(int32_t n_problems, const int64_t* offsets, const double* A, in
   // (a per-DEVICE attribute: set on every call, it costs nothing next to the copies)
   HIP_OK(hipFuncSetAttribute((const void*)k_align_robust, hipFuncAttributeMaxDynamicSharedMemorySize, (int)align_lds_bytes(ALIGN_LDS_CAP)));
   const double t1 = now_seconds();
+  static const bool no_staged = getenv("MCBA_ALIGN_MONOLITHIC") != nullptr;
+  if (nmax > ALIGN_STAGED_MIN && n_problems <= 4096 && !align_prof && !no_staged) {
+    // large problems: the rounds of the clustering as separate launches, the scans spread over the chip (k_align_stage_*)
+    DevBuf<AlignStage> d_stage;
+    DevBuf<int> d_done, d_pi;
+    DevBuf<double> d_pf;
+    d_stage.alloc(np_, true);
+    d_done.alloc(2, true);
+    d_pf.alloc(2 * np_ * ALIGN_SCAN_Z * per, false);     // partial winners of the split scans: key | d^2
+    d_pi.alloc(2 * np_ * ALIGN_SCAN_Z * per + 2 * np_ * per, false);     // slot | size; + changed | work list
+    unsigned long long* h_prog = (unsigned long long*)pinned_alloc(64);
+    struct PinGuard { unsigned long long* p; ~PinGuard() { pinned_free(p, 64); } } pin_guard{h_prog};
+    static std::atomic<unsigned long long> call_counter{0};
+    AlignArgs a;
+    a.off = d_off.p; a.A = dA.p; a.B = same_table ? dA.p : dB.p; a.ia = ia ? d_ia.p : nullptr; a.ib = ib ? d_ib.p : nullptr;
+    a.mask = mask ? d_mask.p : nullptr; a.threshold = threshold; a.invert = (int)invert; a.scratch_stride = (long long)per;
+    a.base = sc; a.out = d_out.p; a.out_valid = d_valid.p; a.inliers = d_inl.p; a.st = d_stage.p; a.done_count = d_done.p;
+    a.host_progress = h_prog;
+    a.pkey = d_pf.p; a.pd2 = d_pf.p + np_ * ALIGN_SCAN_Z * per; a.pidx = d_pi.p; a.pn = d_pi.p + np_ * ALIGN_SCAN_Z * per;
+    a.changed = d_pi.p + 2 * np_ * ALIGN_SCAN_Z * per; a.work = a.changed + np_ * per;
+    const int scan_y = (int)std::max<int64_t>(1, std::min<int64_t>(64, (nmax + 255) / 256));
+    for (int pass = 0; pass < 2; ++pass) {
+      const unsigned long long call = (++call_counter) & 0xffffull;
+      *h_prog = 0ull;
+      HIP_OK(hipMemsetAsync(d_done.p, 0, sizeof(int), st));
+      hipLaunchKernelGGL(k_align_stage_pre, dim3(n_problems), dim3(ALIGN_THREADS), 0, st, a, pass);
+      check_launch("k_align_stage_pre");
+      // rounds: enqueued a few ahead of the progress word [call | problems whose clustering ended | round] that block 0 of every
+      // merge kernel stores (kernels of finished problems return at once; at most nmax rounds can be needed)
+      constexpr int LOOKAHEAD = 8;
+      int enqueued = 0, seen_round = 0, spins = 0;
+      double t_wait = 0.0;
+      while (true) {
+        const unsigned long long w = __atomic_load_n(h_prog, __ATOMIC_ACQUIRE);
+        if ((w >> 48) == call) {
+          const int rd = (int)(w & 0xffffffull);
+          if (rd != seen_round) { seen_round = rd; t_wait = 0.0; spins = 0; }
+          if ((int)((w >> 24) & 0xffffffull) >= n_problems) break;
+        }
+        if (enqueued - seen_round < LOOKAHEAD && enqueued <= nmax + 1) {
+          hipLaunchKernelGGL(k_align_stage_scan, dim3(n_problems, scan_y, ALIGN_SCAN_Z), dim3(256), 0, st, a);
+          ++enqueued;
+          hipLaunchKernelGGL(k_align_stage_merge, dim3(n_problems), dim3(ALIGN_THREADS), 0, st, a, call, enqueued);
+          if ((enqueued & 15) == 0) check_launch("k_align_stage rounds");
+          t_wait = 0.0;
+          spins = 0;
+          continue;
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+        if ((++spins & 1023) == 0) {
+          const double now = now_seconds();
+          if (t_wait == 0.0) t_wait = now;
+          else if (now - t_wait > 0.05) {   // (a failed launch must not hang the caller)
+            HIP_OK(hipStreamSynchronize(st));
+            const unsigned long long w2 = __atomic_load_n(h_prog, __ATOMIC_ACQUIRE);
+            REQUIRE((w2 >> 48) == call && ((int)(w2 & 0xffffffull) != seen_round || (int)((w2 >> 24) & 0xffffffull) >= n_problems),
+                    "the staged alignment made no progress");
+            t_wait = 0.0;
+          }
+        }
+      }
+      hipLaunchKernelGGL(k_align_stage_post, dim3(n_problems), dim3(ALIGN_THREADS), 0, st, a, pass);
+      check_launch("k_align_stage_post");
+    }
+    HIP_OK(hipMemcpyAsync(out, d_out.p, 16 * (size_t)n_problems * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(out_valid, d_valid.p, (size_t)n_problems, hipMemcpyDeviceToHost, st));
+    if (inliers && total > 0) HIP_OK(hipMemcpyAsync(inliers, d_inl.p, (size_t)total, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    if (timing) {
+      std::vector<AlignStage> hs(np_);
+      HIP_OK(hipMemcpy(hs.data(), d_stage.p, np_ * sizeof(AlignStage), hipMemcpyDeviceToHost));
+      long long sl = 0, sw = 0, rd = 0;
+      for (const AlignStage& q : hs) { sl += q.sum_live; sw += q.sum_work; rd = std::max<long long>(rd, q.rounds); }
+      fprintf(stderr, "[align_poses] %d problems, %lld entries (staged): buffers + uploads %.2f ms, kernels + downloads %.2f ms; "
+              "rounds of the last pass <= %lld, clusters alive / scanning summed over rounds %lld / %lld\n",
+              n_problems, (long long)total, (t1 - t0) * 1e3, (now_seconds() - t1) * 1e3, rd, sl, sw);
+    }
+    g_park_on_release = true;
+    return;
+  }
   hipLaunchKernelGGL(k_align_robust, dim3(n_problems), dim3(ALIGN_THREADS), lds, st, d_off.p, dA.p,
                      (const double*)(same_table ? dA.p : dB.p), (const int32_t*)(ia ? d_ia.p : nullptr),
                      (const int32_t*)(ib ? d_ib.p : nullptr), (const uint8_t*)(mask ? d_mask.p : nullptr), threshold, (int)invert,
