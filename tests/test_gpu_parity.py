@@ -751,7 +751,8 @@ def test_align_transforms_robust_with_duplicated_poses():
     return synthetic.to_matrix(np.concatenate([rng.normal(0, sigma, (n, 3)), rng.normal(0, 1.0, (n, 3))], axis=1))
   T = synthetic.to_matrix(np.array([0.3, -0.2, 0.5, 0.1, 0.2, -0.4]))
   problems = []
-  for groups, reps, extra in ((4, 2, 0), (6, 3, 2), (3, 8, 5), (10, 4, 0), (1, 12, 3)):
+  # (the last case is large enough for the staged kernels: nearest-neighbour caching and split scans with exact ties)
+  for groups, reps, extra in ((4, 2, 0), (6, 3, 2), (3, 8, 5), (10, 4, 0), (1, 12, 3), (280, 8, 100)):
     a0 = poses(groups, 0.5)
     b0 = synthetic.perturb(T @ a0, rng, 2e-3, 2e-3)
     a = np.concatenate([np.repeat(a0, reps, axis=0), poses(extra, 0.5)])
