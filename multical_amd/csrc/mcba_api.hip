@@ -1637,7 +1637,10 @@ void align_poses(int32_t n_problems, const int64_t* offsets, const double* A, in
   HIP_OK(hipFuncSetAttribute((const void*)k_align_robust, hipFuncAttributeMaxDynamicSharedMemorySize, (int)align_lds_bytes(ALIGN_LDS_CAP)));
   const double t1 = now_seconds();
   static const bool no_staged = getenv("MCBA_ALIGN_MONOLITHIC") != nullptr;
-  if (nmax > ALIGN_STAGED_MIN && n_problems <= 4096 && !align_prof && !no_staged) {
+  // (the partial winners of the split scans take 24 B x ALIGN_SCAN_Z per entry and problem: batches beyond 4 M entries x problems
+  //  -- 1.6 GB of them -- stay with the one-workgroup kernel)
+  if (nmax > ALIGN_STAGED_MIN && n_problems <= 4096 && (size_t)n_problems * (size_t)nmax <= ((size_t)1 << 22) && !align_prof &&
+      !no_staged) {
     // large problems: the rounds of the clustering as separate launches, the scans spread over the chip (k_align_stage_*)
     DevBuf<AlignStage> d_stage;
     DevBuf<int> d_done, d_pi;
