@@ -214,3 +214,48 @@ def test_parameter_deltas_are_gauge_invariant():
                          cameras=cameras)
     d = gauge.parameter_deltas(c, changed)
     assert abs(d.camera_deg - 0.01) < 1e-9 and abs(d.focal_rel - 1e-3 / 1.001) < 1e-12
+
+
+@pytest.mark.parametrize("name,frames,seed", [("tiny_rolling", None, 5), ("cfg4", 12, 5), ("cfg5", 20, 9)])
+def test_initialise_poses_host_logic_with_the_oracle_as_the_device(name, frames, seed):
+  """multical_amd.tables.initialise_poses with both device entry points replaced by the oracle's align_transforms_robust (per
+  problem, on the CPU): what is tested is everything AROUND the kernels -- overlaps, spanning tree, the pair lists as indices into
+  the pose table, `invert` instead of an inverted table for the board stage, the per-frame gather of the entries that take part,
+  chaining and the final inverses -- against the oracle's restatement of tables.initialise_poses (bit-identical to the reference:
+  test_oracle_vs_reference)."""
+  from multical_amd import tables as mtables
+  from multical_amd.structs import Table
+  from oracle import restate_init
+
+  def ragged(A, B, sizes, mask=None, threshold=1.5, invert=False):
+    sizes = np.asarray(sizes, dtype=np.int64).reshape(-1)
+    A, B = np.asarray(A, dtype=np.float64).reshape(-1, 4, 4), np.asarray(B, dtype=np.float64).reshape(-1, 4, 4)
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    m = np.ones(int(off[-1]), dtype=bool) if mask is None else np.asarray(mask).astype(bool).reshape(-1)
+    out = np.broadcast_to(np.eye(4), (sizes.size, 4, 4)).copy()
+    valid = np.zeros(sizes.size, dtype=bool)
+    inl = np.zeros(int(off[-1]), dtype=bool)
+    for p in range(sizes.size):
+      sl = slice(int(off[p]), int(off[p + 1]))
+      if m[sl].any():
+        a, b = (np.linalg.inv(A[sl]), np.linalg.inv(B[sl])) if invert else (A[sl], B[sl])    # relative_between_inv: tables.py:334-335
+        t, il = restate_init.align_transforms_robust(a, b, valid=m[sl], threshold=threshold)
+        out[p], valid[p], inl[sl] = (np.linalg.inv(t) if invert else t), True, il
+    return out, valid, inl
+
+  def indexed(table, ia, ib, sizes, mask=None, threshold=1.5, invert=False):
+    t = np.asarray(table, dtype=np.float64).reshape(-1, 4, 4)
+    return ragged(t[np.asarray(ia).reshape(-1)], t[np.asarray(ib).reshape(-1)], sizes, mask, threshold, invert)
+
+  saved = mtables.align_transforms_robust_ragged, mtables.align_transforms_robust_indexed
+  mtables.align_transforms_robust_ragged, mtables.align_transforms_robust_indexed = ragged, indexed
+  try:
+    rig = synthetic.make_rig(name, frames=frames)
+    pt = synthetic.make_pose_table(rig, seed=seed)
+    got = mtables.initialise_poses(Table.create(poses=pt["poses"], valid=pt["valid"], num_points=pt["num_points"]))
+  finally:
+    mtables.align_transforms_robust_ragged, mtables.align_transforms_robust_indexed = saved
+  want = restate_init.initialise_poses(restate_init.table(pt["poses"], pt["valid"]), pt["num_points"])
+  for k in ("camera", "board", "times"):
+    assert np.array_equal(got[k].valid, want[k]["valid"]), k
+    assert np.abs(got[k].poses - want[k]["poses"]).max() < 1e-9, (k, np.abs(got[k].poses - want[k]["poses"]).max())
