@@ -740,6 +740,37 @@ def test_align_poses_indexed_equals_the_gathered_batch():
     mtables.align_transforms_robust_indexed(table, np.full(total, 300), ib, sizes)
 
 
+def test_staged_alignment_batch_with_degenerate_members():
+  """A batch whose largest problem sends it through the staged kernels (k_align_stage_*: more than 2 048 entries) together with
+  an empty problem, a single pair, a fully masked one and small ones: every member against the oracle."""
+  from multical_amd import tables as mtables
+  from oracle import restate_init
+  rng = np.random.default_rng(23)
+  def poses(n, sigma):
+    return synthetic.to_matrix(np.concatenate([rng.normal(0, sigma, (n, 3)), rng.normal(0, 1.0, (n, 3))], axis=1))
+  T = synthetic.to_matrix(np.array([-0.2, 0.1, 0.4, 0.3, -0.1, 0.2]))
+  problems = []
+  for n, masked in ((2500, False), (0, False), (1, False), (7, False), (40, True), (300, False)):
+    a = poses(n, 0.5)
+    b = synthetic.perturb(T @ a, rng, 1e-3, 1e-3) if n else a
+    if n > 8:
+      b[::9] = poses(len(b[::9]), 1.0)
+    mask = (np.zeros(n, dtype=bool) if masked else rng.random(n) < 0.9) if n > 1 else None
+    problems.append((a, b, mask))
+  for invert in (False, True):
+    out, valid, inl = mtables.align_transforms_robust_batch(problems, invert=invert)
+    for k, ((a, b, m), o, il) in enumerate(zip(problems, out, inl)):
+      if len(a) == 0 or (m is not None and not m.any()):
+        assert not valid[k] and np.array_equal(o, np.eye(4)) and not il.any()
+        continue
+      aa, bb = (np.linalg.inv(a), np.linalg.inv(b)) if invert else (a, b)
+      want, want_inl = restate_init.align_transforms_robust(aa, bb, valid=m)
+      if invert:
+        want = np.linalg.inv(want)
+      assert valid[k] and np.array_equal(il, want_inl), k
+      assert np.abs(o - want).max() < 1e-9, (k, invert)
+
+
 def test_align_transforms_robust_with_duplicated_poses():
   """Exact duplicates among the relative poses (repeated or noise-free detections) give zero-height merges that TIE at
   the dendrogram cut: scipy's fcluster(maxclust) applies every merge up to the threshold height, so fewer than t flat
