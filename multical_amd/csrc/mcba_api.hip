@@ -2459,14 +2459,14 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
         hipLaunchKernelGGL(k_vec_scale_q00, dim3(sl.nvb + q00_blocks), dim3(256), 0, h->stream, d, h->x.p, h->g(), h->diag(),
                            h->scale_inv.p, h->scale_inv.p, h->dsc.p, h->gh.p, first ? 1 : 0, h->scal.p + sl.vs, h->costcount(),
                            h->scal.p + TR_COST, sl.nvb, h->Hss.p, h->Hfs.p, h->Hff.p, h->scal.p + sl.q00p);
-      if (h->allreduce) {   // message 2: [|g|_inf, |g_h|^2, |x scale|^2, curvature] of every rank, 4 doubles each
+      if (h->allreduce && !scaled) {   // message 2: [|g|_inf, |g_h|^2, |x scale|^2, curvature] of every rank, 4 doubles each
         hipLaunchKernelGGL(k_shard_fold2, dim3(1), dim3(64), 0, h->stream, h->scal.p + sl.vs, sl.nvb, h->scal.p + sl.q00p,
                            q00_blocks, d.shard_rank, d.shard_world, h->scal.p + sl.shard2);
         call_allreduce(h, h->scal.p + sl.shard2, (size_t)4 * d.shard_world, 0);
-      }
+      }          // (scaled: message 2 of this point went out speculatively, behind its linearisation)
       // (the fold of the k_vec_scale / k_q00 partials and the damping: head of the first kernel of the solve)
       // (scaled ahead: the partials were folded behind it by k_fold_tr -- [mx | gg | xs] is a k_vec_scale block of its own, q one value)
-      const TrRegPartials trp = scaled ? TrRegPartials{h->scal.p + sl.fold, 1, h->scal.p + sl.fold + 3, 1, 0, Delta}
+      const TrRegPartials trp = scaled && !h->allreduce ? TrRegPartials{h->scal.p + sl.fold, 1, h->scal.p + sl.fold + 3, 1, 0, Delta}
                               : h->allreduce ? TrRegPartials{h->scal.p + sl.shard2, d.shard_world, h->scal.p + sl.shard2 + 3 * d.shard_world,
                                                              d.shard_world, first ? 1 : 0, Delta}
                                        : TrRegPartials{h->scal.p + sl.vs, sl.nvb, h->scal.p + sl.q00p, q00_blocks, first ? 1 : 0, Delta};
@@ -2523,6 +2523,20 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
         fetch_scalars_begin(h, trial_fetch_end);
       }
       if (merged_trial_cost) trial_cost_values = 1;
+      if (h->allreduce && merged_trial_cost && !spec_accept_off) {
+        // Frame-sharded speculation (round 4): the scaling and the curvature of x_new and their message -- [|g|_inf, |g_h|^2,
+        // |x scale|^2, curvature] per rank -- go out BEHIND the copy the host decides on, into the second buffer set: every rank
+        // takes the same decision from the same all-reduced cost, so the sequence of collectives stays the same on all of them;
+        // an accepted step finds message 2 of its point done (the host used to wait for message 1 before it enqueued it), a
+        // rejected one has wasted 4 W doubles.
+        hipLaunchKernelGGL(k_vec_scale_q00, dim3(sl.nvb + q00_blocks), dim3(256), 0, h->stream, d, h->xnew.p, h->g(), h->diag(),
+                           h->scale_inv.p, h->scale_inv2.p, h->dsc2.p, h->gh2.p, 0, h->scal.p + sl.vs, h->costcount(),
+                           h->scal.p + TR_COST, sl.nvb, h->Hss.p, h->Hfs.p, h->Hff.p, h->scal.p + sl.q00p);
+        hipLaunchKernelGGL(k_shard_fold2, dim3(1), dim3(64), 0, h->stream, h->scal.p + sl.vs, sl.nvb, h->scal.p + sl.q00p,
+                           q00_blocks, d.shard_rank, d.shard_world, h->scal.p + sl.shard2);
+        call_allreduce(h, h->scal.p + sl.shard2, (size_t)4 * d.shard_world, 0);
+        spec_scaled = true;
+      }
       mark("iteration enqueued");
       if (side_cost && publish) publish_scalars_end(h, h->stream2);
       else fetch_scalars_end(h);

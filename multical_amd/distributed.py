@@ -5,7 +5,8 @@ frame, and everything else is a sum -- so a rank keeps only its contiguous frame
 its GPU and the solver exchanges just the reduced quantities per iteration:
 
     shared entries of [g | diag] + cost + step norms    2 n_s + 6 doubles   after every linearisation
-    norms + Cauchy curvature, per rank                  4 W doubles         once per iteration
+    norms + Cauchy curvature, per rank                  4 W doubles         once per trial point (speculatively, right behind
+                                                                            the linearisation's message: a rejected step wastes it)
     Schur complement + right-hand side                  n_s^2 + n_s         once per iteration
     dots of the 2-D subspace, per rank (+ pivot flag)   3 W + 1 doubles     once per iteration
     trial cost + step norms                             4 doubles           per RETRY after a rejected step only

@@ -167,6 +167,11 @@ def test_sharded_solve_two_ranks_one_gpu(name, empty_last, frames, tmp_path):
     assert body[i - 1] == M2                                   # norms + curvature right before the Schur system
     assert body[i + 1] == M4                                   # dots right behind the back substitution
     assert body[i + 2] == G, sizes                             # speculative linearisation: trial cost + step norms ride along
+  # round 4: message 2 of a TRIAL point goes out speculatively right behind its linearisation's message -- also behind that of a
+  # step which is then rejected (the retry's 4-double message follows it), where the host used to decide first
+  for i, v in enumerate(body[:-1]):
+    if v == G and G not in (M2, 4):
+      assert body[i + 1] == M2, (i, sizes)
   retries = sum(1 for v in body if v == 4) if 4 not in (M2, M4) else None
   if retries is not None:
     assert retries == res.nfev - 1 - len(at)                   # one 4-double message per RETRY only
