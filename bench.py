@@ -300,15 +300,18 @@ def main():
       barrier()
       solves.append((time.perf_counter() - t0, res.nfev))
     t_solve, nfev_med = sorted(solves)[len(solves) // 2]
-    if world > 1:
-      h.allreduce_stats(reset=True)
     rng = np.random.default_rng(1)
     x1 = x0 + 1e-3 * rng.normal(size=x0.size)
-    barrier()
-    t0 = time.perf_counter()
-    lres = h.solve(x1, tolerance=1e-15, xtol=1e-15, gtol=1e-15, max_iterations=41)
-    barrier()
-    t_long = time.perf_counter() - t0
+    longs = []
+    for _ in range(3):           # (median of three: one 0.25 ms hiccup in a 3 ms solve moved a single sample from 134 to 145 us)
+      if world > 1:
+        h.allreduce_stats(reset=True)
+      barrier()
+      t0 = time.perf_counter()
+      lres = h.solve(x1, tolerance=1e-15, xtol=1e-15, gtol=1e-15, max_iterations=41)
+      barrier()
+      longs.append(time.perf_counter() - t0)
+    t_long = sorted(longs)[1]
     e, v = h.reprojection_error(res.x)
     sq = torch.tensor([float((e[v] ** 2).sum()), float(v.sum())], dtype=torch.float64, device="cuda")
     if world > 1:
