@@ -15,12 +15,19 @@ step    : ONE fused residual+Jacobian evaluation reduced to the normal equations
 workload: BASELINE.json configs[2], the rig the north star quotes the metric on: 8 cameras x 500 frames x 2 boards
           (charuco_16x22 + aprilgrid_9x9), rolling-shutter motion model, intrinsics + extrinsics optimised, synthetic
           data (multical_amd.synthetic, seed 3).  Inputs are resident in HBM before the timed region.
-scaling : `value` is WEAK scaling -- every rank owns a 500-frame shard of one 8 x (500 N) x 2 rig (frame sharding, SURVEY
-          8(e)) and `value` counts shard evaluations (N per pass), so at N = 1 it is exactly evaluations/s of the
-          north-star rig.  For N > 1 the same line also carries `strong_scaling`: the FIXED 8 x 500 x 2 rig of the north
-          star split over the N ranks (500 / N frames each), evaluations/s of that one rig -- the wording of
-          BASELINE.json's north star.  At 62 frames per GPU k_linearize is latency-bound, so the strong number is the
-          harder one; both are measured in the same run with the same timing protocol.
+scaling : `value` is evaluations/s of ONE FIXED rig -- BASELINE.json's north star: "on a synthetic 8-cam x 500-frame x 2-board
+          rig reported at 1/2/4/8 GPUs".  For N > 1 that rig is frame-sharded over the N ranks (500 / N frames each)
+          and every evaluation ends with the all-reduce of the shared [g | diag | cost]: STRONG scaling (`"scaling": "strong"`).
+          At 62 frames per GPU k_linearize is latency-bound and ~23 us of fixed-cost kernels + the collective do not shrink, so
+          the curve is Amdahl-limited (README).  The same line carries `weak_scaling` for N > 1: every rank owns a full
+          500-frame shard of one 8 x (500 N) x 2 rig, shard evaluations/s of the whole job.
+          --config cfg4 measures BASELINE configs[3] (16 cameras x 1000 frames x 5 cube faces, "frame-sharded across 8 x MI355X")
+          with the same protocol.
+parity  : `parity_route` = the solver that REPRODUCES THE REFERENCE'S END POINT (solver = "lsmr", the product default): whole-solve
+          seconds, nfev / status, LM iterations/s, final RMS and its distance from the END POINT OF THE UNMODIFIED REFERENCE on this
+          very rig (tests/golden/cfg3_endpoint.npz: Calibration.bundle_adjust() run to completion on one host core,
+          oracle/make_endpoint.py), beside the reference's measured wall time.  `lm_iters_per_s` / `lm_long_solve` belong to the
+          exact-step solver (solver = "native"), which ends at the converged optimum instead.
 """
 import argparse
 import json
@@ -36,7 +43,30 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_PEAK_TFLOPS = 78.6    # MI355X FP64 matrix (= vector) peak: 256 CUs x 4 SIMDs x 32 flop/clk x 2.4 GHz (AMD spec;
                            # the guide's table stops at bf16/fp8 -- v_mfma_f64_16x16x4 measured at 64 cycles agrees)
-FRAMES_PER_SHARD = 500
+RIGS = {   # BASELINE.json configs[2] (the north-star rig) and configs[3]
+  "cfg3": dict(frames=500, label="BASELINE configs[2]: 8 cameras x 500 frames x 2 boards (charuco_16x22 + aprilgrid_9x9), "
+                                 "rolling-shutter motion, intrinsics+extrinsics"),
+  "cfg4": dict(frames=1000, label="BASELINE configs[3]: 16 cameras x 1000 frames x 5 boards (cube_10x10 faces), static frames, "
+                                  "intrinsics+extrinsics"),
+}
+FRAMES_PER_SHARD = 500     # (cpu_baseline: the north-star rig)
+
+
+def reference_endpoint(config):
+  """END POINT of the unmodified reference on this rig at its stated size (committed fixture; oracle/make_endpoint.py)."""
+  path = os.path.join(ROOT, "tests", "golden", f"{config}_endpoint.npz")
+  if not os.path.exists(path):
+    return None
+  g = np.load(path, allow_pickle=False)
+  out = dict(rms_px=float(g["ba_rms"]), cost=float(g["ba_cost"]), nfev=int(g["ba_nfev"]), njev=int(g["ba_njev"]),
+             status=int(g["ba_status"]), seconds=float(g["ba_seconds"]), evaluate_calls=int(g["ba_evaluate_calls"]),
+             peak_rss_gb=float(g["ba_peak_rss_gb"]), host=json.loads(str(g["host"])),
+             source=f"tests/golden/{config}_endpoint.npz: Calibration.bundle_adjust() of the unmodified reference, one core of the build "
+                    "container (8 vCPU Xeon 2.1 GHz), measured -- not extrapolated")
+  if "ba_pert_rms" in g:
+    out["spread_px"] = float(np.abs(g["ba_pert_rms"] - g["ba_rms"]).max())
+    out["spread_runs"] = int(g["ba_pert_rms"].size)
+  return out
 
 
 def cpu_baseline(n_frames_sample=25):
@@ -118,11 +148,16 @@ def main():
   ap.add_argument("--steps", type=int, default=200)
   ap.add_argument("--warmup", type=int, default=20)
   ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; the median is reported")
+  ap.add_argument("--config", choices=sorted(RIGS), default="cfg3", help="cfg3 = BASELINE configs[2] (north star), cfg4 = configs[3]")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-solve", action="store_true")
   ap.add_argument("--solve-repeats", type=int, default=5, help="default-tolerance solves; the median is reported")
   ap.add_argument("--no-scipy-mode", action="store_true")
-  ap.add_argument("--no-lsmr-mode", action="store_true")
+  ap.add_argument("--no-lsmr-mode", action="store_true", help="skip `parity_route` (the solver = \"lsmr\" solve of the rig)")
+  ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the weak-scaling measurement")
+  ap.add_argument("--require-native-rccl", action="store_true",
+                  help="N > 1: exit non-zero when the library's own RCCL communicator cannot be used (default: fall back to the "
+                       "torch.distributed hook, loudly, and say so in the JSON line)")
   ap.add_argument("--scipy-frames", type=int, default=20, help="frames of the sample the scipy-driven product mode is timed on")
   args = ap.parse_args()
   if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -138,14 +173,19 @@ def main():
   rank = int(os.environ.get("RANK", "0"))
   local_rank = int(os.environ.get("LOCAL_RANK", "0"))
   assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+  say = lambda msg: sys.stderr.write(f"[bench rank {rank}/{world}] {msg}\n")
   if not torch.cuda.is_available():
     # the product is HIP-only: there is no CPU path to fall back to, and the bench must not pretend otherwise
-    sys.stderr.write(f"[bench rank {rank}/{world}] no HIP device visible: the mcba back-end is GPU-only\n")
+    say("no HIP device visible: the mcba back-end is GPU-only")
     sys.exit(3)
   # MCBA_BENCH_BACKEND=gloo is a test hook: it lets the N > 1 code path run with several ranks on ONE GPU (all-reduces
   # staged through the host); the measured configuration is always nccl (= RCCL over xGMI), one GPU per rank
   backend = os.environ.get("MCBA_BENCH_BACKEND", "nccl")
-  device_index = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
+  n_dev = torch.cuda.device_count()
+  if world > 1 and backend == "nccl" and n_dev < world:
+    say(f"{world} ranks but only {n_dev} visible GPU(s): ranks would SHARE a device -- refusing to measure that")
+    sys.exit(4)
+  device_index = local_rank % max(n_dev, 1) if backend != "nccl" else local_rank
   torch.cuda.set_device(device_index)
   if world > 1:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -153,26 +193,57 @@ def main():
       dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
     else:
       dist.init_process_group(backend)
+  if world > 1 and backend == "nccl":     # one GPU per rank, checked: every rank reports the PCI bus id of its device
+    ids = [None] * world
+    dist.all_gather_object(ids, torch.cuda.get_device_properties(device_index).pci_bus_id
+                           if hasattr(torch.cuda.get_device_properties(device_index), "pci_bus_id") else f"index{device_index}")
+    if len(set(ids)) != world:
+      say(f"ranks share a device: {ids}")
+      sys.exit(4)
 
-  # ---- synthetic workload: this rank's 500-frame shard of the 8 x (500 N) x 2 rolling-shutter rig -------------
-  F_total = FRAMES_PER_SHARD * world
-  shard = (rank * FRAMES_PER_SHARD, (rank + 1) * FRAMES_PER_SHARD)
-  rig = synthetic.make_rig("cfg3", frames=F_total, obs_frames=shard)
-  calib = calibration.from_rig(rig)
-  x0 = calib.param_vec
+  rigdef = RIGS[args.config]
+  F_rig = rigdef["frames"]
   tstream = torch.cuda.Stream()    # kernels and RCCL collectives share this (non-default) stream
-  h = Handle(lower(calib), frame_range=shard if world > 1 else None, stream=tstream.cuda_stream)
-  native = False
+  rccl_version = Handle.rccl_version()
+  native_flags = []
+
+  def make_handle(frames_total, shard):
+    """this rank's frame shard [shard) of one rig of `frames_total` frames (a single rank owns the whole rig)"""
+    rig_ = synthetic.make_rig(args.config, frames=frames_total, obs_frames=shard if world > 1 else None)
+    calib_ = calibration.from_rig(rig_)
+    h_ = Handle(lower(calib_), frame_range=shard if world > 1 else None, stream=tstream.cuda_stream)
+    native_ = False
+    if world > 1:
+      # reductions: the library's own RCCL communicator (in-place ncclAllReduce on the handle's stream); the
+      # torch.distributed hook is the fallback (gloo test hook, or if the native initialisation fails on any rank)
+      if backend == "nccl" and os.environ.get("MCBA_NO_NATIVE_RCCL", "0") != "1":
+        native_ = mdist.init_native_allreduce(h_, rank, world)
+        if not native_:
+          say("NATIVE RCCL INITIALISATION FAILED -- falling back to the torch.distributed all-reduce hook "
+              "(~50 us of host time per reduction); the JSON line says so")
+          if args.require_native_rccl:
+            sys.exit(5)
+      if not native_:
+        h_.set_allreduce(mdist.make_allreduce_hook(stream=tstream))
+      h_.set_shard_rank(rank, world)
+    native_flags.append(native_)
+    return rig_, calib_, h_, native_
+
+  # ---- the workload: the FIXED rig of the north star; N > 1: this rank's frames of it ---------------------------
+  shards = mdist.frame_shards(F_rig, world)
+  shard = shards[rank]
+  rig, calib, h, native = make_handle(F_rig, shard)
+  x0 = calib.param_vec
+  say(f"device {device_index} ({h.device_info().split(':')[0]}), frames [{shard[0]}, {shard[1]}) of {F_rig}, "
+      f"native_rccl={'true' if native else 'false'}, rccl={rccl_version}, backend={backend if world > 1 else 'none'}")
+  n_slots_local = int(np.prod(rig.valid.shape[0:1] + (shard[1] - shard[0],) + rig.valid.shape[2:]))
+  n_obs_local = h.n_residuals // 2
   if world > 1:
-    # reductions: the library's own RCCL communicator (in-place ncclAllReduce on the handle's stream); the
-    # torch.distributed hook is the fallback (gloo test hook, or if the native initialisation fails on any rank)
-    if backend == "nccl" and os.environ.get("MCBA_NO_NATIVE_RCCL", "0") != "1":
-      native = mdist.init_native_allreduce(h, rank, world)
-    if not native:
-      h.set_allreduce(mdist.make_allreduce_hook(stream=tstream))
-    h.set_shard_rank(rank, world)
-  n_slots = int(np.prod(rig.valid.shape[0:1] + (FRAMES_PER_SHARD,) + rig.valid.shape[2:]))
-  n_obs = h.n_residuals // 2
+    tot = torch.tensor([n_slots_local, n_obs_local], dtype=torch.float64, device="cuda")
+    dist.all_reduce(tot)
+    n_slots, n_obs = int(tot[0].item()), int(tot[1].item())
+  else:
+    n_slots, n_obs = n_slots_local, n_obs_local
 
   def barrier():
     if world > 1:
@@ -191,7 +262,7 @@ def main():
   check(h.lib.mcba_normal_equations(h.h, _ptr(xbuf, C.c_double), C.byref(opt), C.byref(cost), None, None))
 
   def step():
-    # tables + k_tmat + k_linearize + assembly (+ all-reduce), enqueued on the handle's stream; no host transfer
+    # tables + k_linearize + assembly (+ all-reduce), enqueued on the handle's stream; no host transfer
     check(h.lib.mcba_normal_equations_device(h.h, C.byref(opt)))
 
   def step_host():
@@ -224,39 +295,33 @@ def main():
   region_times = []
   dt = timed(step, region_times)
   ms_per_step = dt / args.steps * 1e3
-  value = world * args.steps / dt                       # shard evaluations per second, whole job
+  value = args.steps / dt                               # evaluations per second of the ONE fixed rig, whole job
 
-  # ---- strong scaling (N > 1): the FIXED 8 x 500 x 2 rig of the north star, 500 / N frames per rank ---------------
-  strong = None
-  if world > 1:
-    sshards = mdist.frame_shards(FRAMES_PER_SHARD, world)
-    srig = synthetic.make_rig("cfg3", frames=FRAMES_PER_SHARD, obs_frames=sshards[rank])
-    scalib = calibration.from_rig(srig)
-    hs = Handle(lower(scalib), frame_range=sshards[rank], stream=tstream.cuda_stream)
-    snative = False
-    if backend == "nccl" and os.environ.get("MCBA_NO_NATIVE_RCCL", "0") != "1":
-      snative = mdist.init_native_allreduce(hs, rank, world)
-    if not snative:
-      hs.set_allreduce(mdist.make_allreduce_hook(stream=tstream))
-    hs.set_shard_rank(rank, world)
-    sx = np.ascontiguousarray(scalib.param_vec)
-    check(hs.lib.mcba_normal_equations(hs.h, _ptr(sx, C.c_double), C.byref(opt), C.byref(cost), None, None))
-    sdt = timed(lambda: check(hs.lib.mcba_normal_equations_device(hs.h, C.byref(opt))))
-    strong = dict(value=args.steps / sdt, unit="evals/s of the fixed 8 x 500 x 2 rig", ms_per_step=sdt / args.steps * 1e3,
-                  frames_per_gpu=[b - a for a, b in sshards], scaling="strong",
-                  note="one rig, frame-sharded over all ranks; every evaluation ends with the all-reduce of [g | diag | cost]")
-    hs.close()
+  # ---- weak scaling (N > 1): every rank owns a full F_rig-frame shard of one N-times-longer rig --------------------
+  weak = None
+  if world > 1 and not args.no_weak:
+    wshard = (rank * F_rig, (rank + 1) * F_rig)
+    wrig, wcalib, hw, wnative = make_handle(F_rig * world, wshard)
+    wx = np.ascontiguousarray(wcalib.param_vec)
+    check(hw.lib.mcba_normal_equations(hw.h, _ptr(wx, C.c_double), C.byref(opt), C.byref(cost), None, None))
+    wdt = timed(lambda: check(hw.lib.mcba_normal_equations_device(hw.h, C.byref(opt))))
+    weak = dict(value=world * args.steps / wdt, unit=f"shard evaluations/s (one {F_rig}-frame shard per GPU)", ms_per_step=wdt / args.steps * 1e3,
+                frames_per_gpu=F_rig, scaling="weak", native_rccl=bool(wnative),
+                note=f"{world} frame shards of one {rig.valid.shape[0]} x {F_rig * world} x {rig.valid.shape[2]} rig; every evaluation ends "
+                     "with the all-reduce of the shared [g | diag | cost]")
+    hw.close()
   # PCIe-inclusive variant (never `value`): every evaluation enters and leaves through the host boundary
   host_ms_per_step = timed(step_host) / args.steps * 1e3
 
-  # ---- dominant kernel: k_linearize, HIP events on the handle's stream --------------------------------------------
+  # ---- dominant kernel: k_linearize, HIP events on the handle's stream (this rank's shard) --------------------------
   lin_ms = h.time_linearize(x0, repeats=50)
   res_ms = h.time_residuals(x0, repeats=50)
-  alg_bytes = 17 * n_slots + 16 * n_obs                  # observed xy + mask per slot, residual per obs
+  alg_bytes = 17 * n_slots_local + 16 * n_obs_local      # observed xy + mask per slot, residual per obs
   achieved = alg_bytes / (lin_ms * 1e-3) / 1e9
   d = h.problem
   NV = (12 if d.motion == 1 else 6) + (4 + d.n_dist if d.optimize & 8 else 0) + 1
-  alg_flops = n_obs * (2 * NV * (NV + 1) + 420 + (260 if d.motion == 1 else 0))
+  flops_per_obs = 2 * NV * (NV + 1) + 420 + (260 if d.motion == 1 else 0)
+  alg_flops = n_obs_local * flops_per_obs
   # The fused pass is FP64-bound (~23 flop per algorithmic byte against a ridge of ~10 flop/B), so the
   # roofline that bounds k_linearize is the FP64 matrix/vector peak; the HBM view of the same launch is kept alongside.
   tflops = alg_flops / (lin_ms * 1e-3) / 1e12
@@ -273,7 +338,7 @@ def main():
   # committed rocprofv3 passes of the same command is quoted and labelled as such (profiles/hbm_traffic.json: separate
   # --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction)
   traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-  if os.path.exists(traffic_file):
+  if os.path.exists(traffic_file) and world == 1 and args.config == "cfg3":
     try:
       tj = json.load(open(traffic_file))
       roofline["traffic"] = tj.get("k_linearize_bytes_per_launch")
@@ -287,11 +352,20 @@ def main():
     except Exception:
       pass
 
+  def global_rms(hh, x):
+    e, v = hh.reprojection_error(x)
+    sq = torch.tensor([float((e[v] ** 2).sum()), float(v.sum())], dtype=torch.float64, device="cuda")
+    if world > 1:
+      dist.all_reduce(sq)
+    return float(torch.sqrt(sq[0] / sq[1]).item())
+
   # ---- LM iterations/s and final RMS: one full bundle adjustment of the same problem (not part of `value`) --------
   extra = {}
+  ref_end = reference_endpoint(args.config)
   if not args.no_solve:
-    # the default solve of the rig (scipy's defaults: ftol 1e-4), repeated: median of the repeats; and a LONG solve (tight
-    # tolerances, fixed number of trial steps from a perturbed start) whose per-trial-step time is the steady-state figure
+    # the default-tolerance solve of the rig with the EXACT-step solver (scipy's defaults: ftol 1e-4), repeated: median of the
+    # repeats; and a LONG solve (tight tolerances, fixed number of trial steps from a perturbed start) whose per-trial-step time is
+    # the steady-state figure
     solves = []
     for _ in range(max(1, args.solve_repeats)):
       barrier()
@@ -312,16 +386,13 @@ def main():
       barrier()
       longs.append(time.perf_counter() - t0)
     t_long = sorted(longs)[1]
-    e, v = h.reprojection_error(res.x)
-    sq = torch.tensor([float((e[v] ** 2).sum()), float(v.sum())], dtype=torch.float64, device="cuda")
-    if world > 1:
-      dist.all_reduce(sq)
-    extra = dict(lm_iters_per_s=(nfev_med - 1) / t_solve, lm_trial_steps=res.nfev - 1, lm_linearizations=res.njev,
+    native_rms = global_rms(h, res.x)
+    extra = dict(lm_solver="native (exact Schur / Cholesky steps: the converged optimum, NOT the reference's end point -- see parity_route)",
+                 lm_iters_per_s=(nfev_med - 1) / t_solve, lm_trial_steps=res.nfev - 1, lm_linearizations=res.njev,
                  solve_seconds=t_solve, solve_seconds_all=[t for t, _ in solves], solve_status=res.status,
                  lm_long_solve=dict(trial_steps=lres.nfev - 1, seconds=t_long, us_per_trial_step=t_long / max(lres.nfev - 1, 1) * 1e6,
                                     iters_per_s=max(lres.nfev - 1, 1) / t_long),
-                 final_rms_px=float(torch.sqrt(sq[0] / sq[1]).item()), final_cost=res.cost,
-                 initial_cost=res.initial_cost)
+                 final_rms_px=native_rms, final_cost=res.cost, initial_cost=res.initial_cost)
     if world > 1:
       calls, doubles, sizes = h.allreduce_stats(reset=True)
       extra["lm_long_solve"]["allreduce"] = dict(calls=calls, bytes=8 * doubles, calls_per_trial_step=calls / max(lres.nfev - 1, 1),
@@ -336,9 +407,47 @@ def main():
     calls, doubles, sizes = h.allreduce_stats(reset=True)
     step_comm = dict(allreduce_calls=calls, allreduce_bytes=8 * doubles, message_doubles=[abs(s) for s in sizes])
 
+  # ---- PARITY ROUTE: the solver that reproduces the reference's END POINT, on the whole rig (single GPU or frame-sharded) -----
+  parity_route = None
+  if not args.no_lsmr_mode and not args.no_solve:
+    h.solve(x0, tr_solver="lsmr")                                   # warm-up (buffers, first-use allocations)
+    runs = []
+    for _ in range(3):
+      barrier()
+      t0 = time.perf_counter()
+      pres = h.solve(x0, tr_solver="lsmr")
+      barrier()
+      runs.append(time.perf_counter() - t0)
+    t_par = sorted(runs)[1]
+    itn = h.lsmr_iterations()
+    prms = global_rms(h, pres.x)
+    parity_route = dict(solver="lsmr", seconds=t_par, seconds_all=runs, nfev=pres.nfev, njev=pres.njev, status=pres.status,
+                        lm_iters_per_s=(pres.nfev - 1) / t_par, lsmr_iterations=itn, us_per_lsmr_iteration=t_par / max(itn, 1) * 1e6,
+                        final_cost=pres.cost, final_rms_px=prms,
+                        note="solver='lsmr' (the product default) on the whole rig: scipy's TRF driver + lsmr(J_h, f, damp) restated on the "
+                             "device; us_per_lsmr_iteration = whole solve / LSMR iterations (linearisations and trial evaluations included)")
+    if ref_end is not None:
+      parity_route.update(reference_rms_px=ref_end["rms_px"], abs_delta_px=abs(prms - ref_end["rms_px"]),
+                          reference_nfev=ref_end["nfev"], reference_status=ref_end["status"], reference_cost=ref_end["cost"],
+                          reference_spread_px=ref_end.get("spread_px"), reference_spread_runs=ref_end.get("spread_runs"),
+                          reference_seconds=ref_end["seconds"], speedup_vs_reference=ref_end["seconds"] / t_par,
+                          within_tolerance=bool(abs(prms - ref_end["rms_px"]) <= max(1e-6, ref_end.get("spread_px") or 0.0)
+                                                and pres.nfev == ref_end["nfev"] and pres.status == ref_end["status"]),
+                          reference_source=ref_end["source"])
+      if "final_rms_px" in extra:
+        extra["native_abs_delta_px"] = abs(extra["final_rms_px"] - ref_end["rms_px"])
+    # the product kernel of the route: J v and J^T u of one LSMR iteration
+    parity_route["lsmr_iteration"] = dict(flops_per_observation=4 * (2 * (NV - 1)) + flops_per_obs - 2 * NV * (NV + 1),
+                                          note="per observation and iteration: the analytic row pair (forward model + derivatives, "
+                                               "as in k_linearize without the V^T V accumulation) + 2 x 2 x (NV - 1) multiply-adds for "
+                                               "J v and J^T u")
+    fl = parity_route["lsmr_iteration"]["flops_per_observation"] * n_obs_local
+    parity_route["lsmr_iteration"].update(us=parity_route["us_per_lsmr_iteration"],
+                                          fp64_frac=fl / (parity_route["us_per_lsmr_iteration"] * 1e-6) / 1e12 / FP64_PEAK_TFLOPS)
+
   # ---- the reference's own solver on the device functions (product mode solver="scipy"), beside the native solve -----
   scipy_mode = None
-  if world == 1 and not args.no_scipy_mode:
+  if world == 1 and not args.no_scipy_mode and args.config == "cfg3":
     srig = synthetic.make_rig("cfg3", frames=args.scipy_frames)
     sc = calibration.from_rig(srig)
     with Handle(lower(sc)) as hsm:
@@ -352,7 +461,7 @@ def main():
       def rms_at(x):
         e_, v_ = hsm.reprojection_error(x)
         return float(np.sqrt(np.mean(e_[v_] ** 2)))
-      scipy_mode = dict(sample=f"first {args.scipy_frames} of {FRAMES_PER_SHARD} frames of the same rig ({hsm.n_residuals} residuals, "
+      scipy_mode = dict(sample=f"first {args.scipy_frames} of {F_rig} frames of the same rig ({hsm.n_residuals} residuals, "
                                f"{hsm.n_params} parameters)",
                         scipy_mode_seconds=t_sci, scipy_mode_nfev=sres.nfev, scipy_mode_rms_px=rms_at(sres.x),
                         lsmr_mode_seconds=t_lsm, lsmr_mode_nfev=mres.nfev, lsmr_mode_rms_px=rms_at(mres.x),
@@ -361,51 +470,46 @@ def main():
                              "optimization/calibration.py:209-210 on mcba_residuals + mcba_jacobian: the reference's end point "
                              "(profiles/parity_table.md), scipy's LSMR on the host")
 
-  # ---- the reference's trajectory at the FULL north-star size: mcba_solve with scipy's own LSMR step on the device ------------
-  lsmr_mode = None
-  if world == 1 and not args.no_lsmr_mode and not args.no_solve:
-    barrier()
-    t0 = time.perf_counter()
-    lres_ = h.solve(x0, tr_solver="lsmr")
-    barrier()
-    t_lsmr = time.perf_counter() - t0
-    e_, v_ = h.reprojection_error(lres_.x)
-    lsmr_mode = dict(seconds=t_lsmr, nfev=lres_.nfev, status=lres_.status, final_cost=lres_.cost,
-                     final_rms_px=float(np.sqrt(np.mean(e_[v_] ** 2))),
-                     note="solver='lsmr' on the whole 8 x 500 x 2 rig: scipy's TRF driver + lsmr(J_h, f, damp) restated on the device "
-                          "(the reference's own solver needs hours here: cpu_baseline.lm_iters_per_s); compare final_rms_px / "
-                          "solve_seconds of the default (exact normal-equation) solver above")
-
   out = None
   if rank == 0:
+    C_, B_ = rig.valid.shape[0], rig.valid.shape[2]
+    par = "single GPU"
+    if world > 1:
+      par = (f"ONE {C_} x {F_rig} x {B_} rig frame-sharded x{world} ({[b - a for a, b in shards]} frames per GPU), " +
+             ("native RCCL all-reduce (librccl %d)" % rccl_version if native else f"torch.distributed ({backend}) all-reduce hook"))
     out = dict(metric="residual+Jacobian evals/sec", value=value, unit="evals/s", n_gpus=world, steps=args.steps,
-               warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling="weak", vs_baseline=None,
-               dtype="f64", data="synthetic",
-               config=dict(workload=f"BASELINE configs[2]: 8 cameras x {FRAMES_PER_SHARD} frames x 2 boards per GPU "
-                                    f"(charuco_16x22 + aprilgrid_9x9), rolling-shutter motion, intrinsics+extrinsics; "
-                                    f"{world} frame shard(s) of one 8 x {F_total} x 2 rig",
-                           n_params=int(h.n_params), n_slots_per_gpu=n_slots, n_observations_per_gpu=int(n_obs),
+               warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling="strong",
+               vs_baseline=None, dtype="f64", data="synthetic",
+               config=dict(workload=f"{rigdef['label']}; the whole rig on {world} GPU(s)",
+                           n_params=int(h.n_params), n_slots=n_slots, n_observations=int(n_obs),
                            observation_fill=float(n_obs) / n_slots,   # evals/s is linear in observations, not in slots
-                           parallelism=(f"frame-sharded x{world}, " + ("native RCCL all-reduce" if native else
-                                        f"torch.distributed ({backend}) all-reduce hook")) if world > 1 else "single GPU",
+                           parallelism=par, native_rccl=bool(native) if world > 1 else None, rccl_version=rccl_version,
                            device=h.device_info()),
                obs_per_s=value * float(n_obs),            # observations linearised per second, whole job
-               step_roofline_frac=alg_flops / (ms_per_step * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,   # the STEP (all kernels of an
-               # evaluation + launch gaps), not just the dominant kernel, against the FP64 peak
+               step_roofline_frac=n_obs * flops_per_obs / (ms_per_step * 1e-3) / 1e12 / (FP64_PEAK_TFLOPS * world),   # the STEP
+               # (all kernels of an evaluation + launch gaps + collective), not just the dominant kernel, against the FP64 peak of N GPUs
                timed_regions_ms=[t * 1e3 for t in region_times], repeats=len(region_times),
-               host_boundary=dict(ms_per_step=host_ms_per_step, evals_per_s=world * 1e3 / host_ms_per_step,
+               host_boundary=dict(ms_per_step=host_ms_per_step, evals_per_s=1e3 / host_ms_per_step,
                                   note="same evaluation with x uploaded and the cost downloaded on every call"),
                roofline=roofline, **extra)
-    if strong is not None:
-      out["strong_scaling"] = strong
+    if parity_route is not None:
+      out["parity_route"] = parity_route
+    if weak is not None:
+      out["weak_scaling"] = weak
     if step_comm is not None:
       out["step_collectives"] = step_comm
     if scipy_mode is not None:
       out["scipy_mode"] = scipy_mode
-    if lsmr_mode is not None:
-      out["lsmr_mode"] = lsmr_mode
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and args.config == "cfg3":
       out["cpu_baseline"] = cpu_baseline()
+      if ref_end is not None:
+        # the REAL reference, run to completion on this rig (build container): njev Jacobians (= residual+Jacobian evaluations by
+        # SURVEY 8(d)'s counting convention) and nfev - 1 trial steps in `seconds` of one core
+        out["cpu_baseline"]["reference_measured"] = dict(
+          seconds=ref_end["seconds"], nfev=ref_end["nfev"], njev=ref_end["njev"], evaluate_calls=ref_end["evaluate_calls"],
+          evals_per_s=ref_end["njev"] / ref_end["seconds"], lm_iters_per_s=(ref_end["nfev"] - 1) / ref_end["seconds"],
+          peak_rss_gb=ref_end["peak_rss_gb"], final_rms_px=ref_end["rms_px"], cores=1, kind="reference", host=ref_end["host"],
+          source=ref_end["source"])
     print(json.dumps(out), flush=True)
   h.close()
   if world > 1:

@@ -134,7 +134,10 @@ typedef struct mcba_options {          /* scipy.optimize.least_squares arguments
   double f_scale;               /* scipy `f_scale` (soft margin of the robust loss)                     */
   int32_t verbose;              /* 2: per-iteration rows are delivered to the log callback              */
   int32_t tr_solver;            /* MCBA_TR_EXACT (0): exact Schur / Cholesky steps; MCBA_TR_LSMR (1): scipy's own step,     */
-                                /* gn_h = lsmr(J_h, f, damp) (trf.py:481), with the Jacobian products on the device         */
+                                /* gn_h = lsmr(J_h, f, damp) (trf.py:481), with the Jacobian products on the device.        */
+                                /* (Until round 3 this field was `reserved`: ZERO-INITIALISE the struct -- an uninitialised */
+                                /* value is rejected with "unknown trust-region solver".  MCBA_TR_LSMR is what reproduces   */
+                                /* the reference's end point; the Python drop-in selects it by default.)                     */
 } mcba_options;
 
 typedef struct mcba_result {           /* scipy OptimizeResult fields the caller needs                    */
@@ -205,6 +208,9 @@ int32_t mcba_set_allreduce(mcba_handle h, mcba_allreduce_fn fn, void* ctx);
 int32_t mcba_rccl_unique_id(uint8_t* id_out /*[128]*/);
 int32_t mcba_rccl_init(mcba_handle h, const uint8_t* id /*[128]*/, int32_t rank, int32_t world);
 int32_t mcba_rccl_shutdown(mcba_handle h);
+/* version of the librccl the native path binds (ncclGetVersion: major * 10000 + minor * 100 + patch; 0 = library not found or
+ * its ABI refused) -- reported per rank by bench.py                                                                     */
+int32_t mcba_rccl_version(int32_t* version_out);
 /* exactly one rank of a sharded problem is the root: it contributes the replicated (shared) right-hand side to the
  * reduced system.  Default: root.  Ranks other than 0 call this with 0.                                          */
 int32_t mcba_set_shard_root(mcba_handle h, int32_t is_root);

@@ -102,6 +102,7 @@ SYMBOLS = [
   ("mcba_rccl_unique_id", C.c_int32, [C.POINTER(C.c_uint8)]),
   ("mcba_rccl_init", C.c_int32, [H, C.POINTER(C.c_uint8), C.c_int32, C.c_int32]),
   ("mcba_rccl_shutdown", C.c_int32, [H]),
+  ("mcba_rccl_version", C.c_int32, [C.POINTER(C.c_int32)]),
   ("mcba_set_mfma", C.c_int32, [H, C.c_int32]),
   ("mcba_debug_set_lin_grid", C.c_int32, [H, C.c_int32]),
   ("mcba_debug_set_frame_groups", C.c_int32, [H, C.c_int32]),
@@ -112,6 +113,8 @@ SYMBOLS = [
   ("mcba_debug_mfma_probe", C.c_int32, [c_double_p, c_double_p]),
   ("mcba_debug_chol", C.c_int32, [H, C.c_int32, c_double_p, c_double_p, C.c_double, C.c_int32, c_double_p]),
   ("mcba_debug_linearize_profile", C.c_int32, [H, c_double_p, C.POINTER(C.c_longlong)]),
+  ("mcba_debug_lsmr_products", C.c_int32, [H, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]),
+  ("mcba_debug_lsmr_info", C.c_int32, [H, C.POINTER(C.c_int64)]),
 ]
 
 _lib = None

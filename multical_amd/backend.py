@@ -464,6 +464,13 @@ class Handle(object):
     buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
     check(self.lib.mcba_rccl_init(self.h, buf, int(rank), int(world)))
 
+  @staticmethod
+  def rccl_version():
+    """ncclGetVersion of the librccl the native path binds (0: not available)."""
+    v = C.c_int32()
+    check(_lib.load().mcba_rccl_version(C.byref(v)))
+    return int(v.value)
+
   def rccl_shutdown(self):
     check(self.lib.mcba_rccl_shutdown(self.h))
 
@@ -480,6 +487,30 @@ class Handle(object):
                            nfev=res.nfev, njev=res.njev, status=res.status, iterations=res.iterations,
                            message=STATUS_MESSAGES.get(res.status, ""), solve_seconds=res.solve_seconds,
                            linearize_seconds=res.linearize_seconds, success=res.status > 0)
+
+  def lsmr_products(self, x, v=None, u=None):
+    """(J(x) v, J(x)^T u) through the matrix-free kernels the lsmr mode iterates with (mcba_debug_lsmr_products; unscaled columns,
+    linear loss, reference residual order) -- test hook: compare with `jacobian(x) @ v` / `jacobian(x).T @ u`."""
+    x = self._x(x)
+    jv = jtu = None
+    pv = pu = pjv = pjtu = None
+    if v is not None:
+      v = self._x(v)
+      jv = np.empty(self.n_residuals)
+      pv, pjv = _ptr(v, C.c_double), _ptr(jv, C.c_double)
+    if u is not None:
+      u = _f64(u)
+      assert u.shape == (self.n_residuals,)
+      jtu = np.empty(self.n_params)
+      pu, pjtu = _ptr(u, C.c_double), _ptr(jtu, C.c_double)
+    check(self.lib.mcba_debug_lsmr_products(self.h, _ptr(x, C.c_double), pv, pu, pjv, pjtu))
+    return jv, jtu
+
+  def lsmr_iterations(self):
+    """LSMR iterations of the last `solve(tr_solver='lsmr')` on this handle."""
+    n = C.c_int64()
+    check(self.lib.mcba_debug_lsmr_info(self.h, C.byref(n)))
+    return int(n.value)
 
   def solve_scipy(self, x0, tolerance=1e-4, f_scale=1.0, max_iterations=100, loss='linear', verbose=2):
     """The reference's OWN solver call (optimization/calibration.py:209-210) with the device functions plugged in:

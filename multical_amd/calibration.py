@@ -48,17 +48,18 @@ class LogWriter(object):
     return LogWriter(logging.INFO, ignore_newline)
 
 
-# Which solver `Calibration.bundle_adjust` uses (both run residuals and Jacobian on the MI355X):
-#   "native"  mcba_solve: trust-region driver with exact Schur / Cholesky steps, everything on the device.  Ends at the
-#             CONVERGED optimum (at or below the reference's end point).
+# Which solver `Calibration.bundle_adjust` uses (all run residuals and Jacobian on the MI355X):
+#   "lsmr"    DEFAULT.  mcba_solve with scipy's OWN trust-region step on the device (tr_solver = lsmr): gn_h = lsmr(J_h, f, damp) with
+#             the two Jacobian products as HIP kernels and scipy's driver restated line by line -- the reference's trajectory and
+#             END POINT (within max(1e-6 px, the reference's own reproducibility), identical nfev / status), without the
+#             host-side LSMR (an hour of one core at the north-star rig).
+#   "native"  mcba_solve: trust-region driver with exact Schur / Cholesky steps, everything on the device, ~100 x faster than
+#             "lsmr".  Ends at the CONVERGED optimum (at or below the reference's cost) -- NOT at the reference's end point: on
+#             weakly determined rigs the principal point ends tens of pixels away from the reference's (profiles/parity_table.md).
 #   "scipy"   the reference's own call scipy.optimize.least_squares(method='trf', x_scale='jac', ...) on mcba_residuals +
-#             mcba_jacobian (Handle.solve_scipy): the reference's trajectory and END POINT (1e-6 px, identical nfev / status
-#             wherever the reference reproduces itself to that level), at the price of scipy's host-side LSMR.
-#   "lsmr"    mcba_solve with scipy's OWN trust-region step on the device (tr_solver = lsmr): gn_h = lsmr(J_h, f, damp) with the
-#             two Jacobian products as HIP kernels and scipy's driver restated line by line -- the reference's trajectory and
-#             end point like "scipy", without the host-side LSMR (hours at the north-star rig).
-SOLVERS = ("native", "scipy", "lsmr")
-_default_solver = [os.environ.get("MULTICAL_AMD_SOLVER", "native").lower()]
+#             mcba_jacobian (Handle.solve_scipy): the reference's end point as well, at the price of scipy's host-side LSMR.
+SOLVERS = ("lsmr", "native", "scipy")
+_default_solver = [os.environ.get("MULTICAL_AMD_SOLVER", "lsmr").lower()]
 
 
 def set_solver(name):
@@ -166,6 +167,11 @@ class _HandleCache(object):
       if e["handle"] is handle:
         e["mask"] = mask
 
+  def invalidate_inliers(self, handle):
+    """a library call that rewrites the device mask (mcba_reject_outliers, mcba_adjust_outliers) FAILED part-way: the
+    device mask is unknown, so the next lookup must upload its own (a fresh token never compares equal)."""
+    self.note_inliers(handle, _UNKNOWN_MASK)
+
   def clear(self):
     for e in self.entries:
       e["handle"].close()
@@ -176,6 +182,7 @@ def parameters_order():
   return ["camera_poses", "board_poses", "motion", "cameras", "boards"]
 
 
+_UNKNOWN_MASK = np.zeros(0, dtype=np.uint8)   # token of "the device mask is in an unknown state"
 handle_cache = _HandleCache()
 
 
@@ -307,7 +314,7 @@ class Calibration(parameters.Parameters):
                     xtol=1e-8, gtol=1e-8, solver=None):
     """Non-linear least squares on point reprojection error, solved on the GPU.
 
-    Keeps the reference's signature and semantics.  solver = "native" (mcba_solve; default, see `set_solver`): the iteration
+    Keeps the reference's signature and semantics.  solver = "lsmr" (default, see `set_solver`) / "native" (mcba_solve): the iteration
     table scipy prints with verbose=2 is emitted in the same format through the "calibration" logger (calibration.py:208,
     io/logging.py:53-68).  solver = "scipy": the reference's own `least_squares` call on the device residuals + analytic
     Jacobian (`Handle.solve_scipy`), scipy's own table redirected to the logger exactly as calibration.py:208 does."""
@@ -366,8 +373,12 @@ class Calibration(parameters.Parameters):
   def reject_outliers(self, threshold):
     """calibration.py:240-252, evaluated on the device; only the new mask (uint8) comes back."""
     h = self._handle()
-    n_in, n_valid = h.reject_outliers(self.param_vec, threshold)
-    inliers = h.get_inliers()
+    try:
+      n_in, n_valid = h.reject_outliers(self.param_vec, threshold)
+      inliers = h.get_inliers()
+    except BaseException:
+      handle_cache.invalidate_inliers(h)
+      raise
     num_outliers = n_valid - n_in
     inlier_percent = 100.0 * n_in / max(n_valid, 1)
     info(f"Rejecting {num_outliers} outliers with error > {threshold:.2f} pixels, "
@@ -394,6 +405,9 @@ class Calibration(parameters.Parameters):
         outlier=None if select_outliers is None else (select_outliers.quantile, select_outliers.factor),
         scale=None if select_scale is None else (select_scale.quantile, select_scale.factor),
         tr_solver="lsmr" if get_solver() == "lsmr" else "exact", **kwargs)
+    except BaseException:
+      handle_cache.invalidate_inliers(h)   # a rejection may already have rewritten the device mask
+      raise
     finally:
       h.set_log(None)
     tables, cur = [], None                      # the iteration rows of every solve (a solve starts with iteration 0)

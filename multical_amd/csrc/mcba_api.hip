@@ -56,6 +56,21 @@ struct Error : std::runtime_error {
 
 thread_local hipStream_t g_fill_stream = nullptr;   // stream of the running API call (see DevBuf::alloc)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to the (function, device) pair, not to a handle: keep a process-wide
+// high-water mark per pair and only ever RAISE it, so that a second live handle with a smaller requirement cannot lower the
+// limit under the first one (two handles stay alive in the Python-side cache).
+static void raise_dynamic_lds(const void* fn, int device, size_t bytes) {
+  static std::mutex m;
+  static std::map<std::pair<const void*, int>, size_t> set;
+  if (bytes <= 48 * 1024) return;   // the default limit
+  std::lock_guard<std::mutex> lock(m);
+  size_t& cur = set[{fn, device}];
+  if (bytes <= cur) return;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) throw std::runtime_error(std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed: ") + hipGetErrorString(e));
+  cur = bytes;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Process-wide cache of the resources a handle owns.  A Workspace.calibrate creates one handle per Calibration and
 // destroys it afterwards: ~50 hipMalloc / hipFree pairs, four pinned host buffers and a stream cost more than the three
@@ -273,10 +288,8 @@ struct mcba_handle_s {
   bool shard_root = true;
   DevBuf<double> comm;   // frame-sharded handles: [g_s | diag_s | cost, count | step norms] of the linearisation's message
   // solver "lsmr": m-vectors u (bidiagonalisation), J_h g_h, J_h gn; per-view partials of J_h^T u; n-vectors v, v_raw, h, hbar, x
-  DevBuf<double> ls_u, ls_ua, ls_ub, ls_part, ls_v, ls_vraw, ls_h, ls_hbar, ls_x, ls_nrm, ls_partial, ls_out;
+  DevBuf<double> ls_u, ls_ua, ls_ub, ls_part, ls_v, ls_vraw, ls_h, ls_hbar, ls_x, ls_nrm, ls_partial, ls_out, ls_bpart, ls_comm;
   ScalLayout sl;
-  size_t asm_lds_set = 48 * 1024;
-  size_t chol_lds3_set = 0, chol_lds5_set = 0;
   DevBuf<double> chol_linv;   // inverted diagonal tiles of the panel kernels (k_cholp_back)
   int lin_grid = 0;          // 0 = automatic (see lin2), > 0 = forced number of persistent workgroups (debug)
 
@@ -309,6 +322,7 @@ struct mcba_handle_s {
   int nchunk = 1;
   // solver state
   DevBuf<double> x, xnew, scale_inv, dsc, gh, gn, scal, costpart, Lf, W, yf, P, sbuf, ps;
+  long long lsmr_iterations_last = 0;     // LSMR iterations of the last solve_lsmr (mcba_debug_lsmr_info)
   DevBuf<double> ls_state;                // solver = "lsmr": scalar state of the running LSMR solve (mcba_lsmr.h)
   unsigned long long ls_call = 0;         // ... and the number of the solve (tag of its progress word, h_pub_seq[1])
   DevBuf<double> scale_inv2, dsc2, gh2;   // scaling of a trial point, computed speculatively (mcba_solve) and swapped in on acceptance
@@ -526,7 +540,7 @@ int call_allreduce(mcba_handle_s* h, double* buf, size_t count, int op) {
   if (!h->allreduce) return 0;
   ++h->ar_calls;
   h->ar_doubles += (int64_t)count;
-  if (h->ar_trace.size() < 4096) h->ar_trace.push_back(op == 0 ? (int64_t)count : -(int64_t)count);
+  if (h->ar_trace.size() < (1u << 18)) h->ar_trace.push_back(op == 0 ? (int64_t)count : -(int64_t)count);
   const int rc = h->allreduce(h->allreduce_ctx, buf, count, op, (void*)h->stream);
   if (rc != 0) throw Error("all-reduce hook failed with code " + std::to_string(rc));
   return 0;
@@ -614,10 +628,7 @@ void launch_assemble(mcba_handle_s* h, unsigned long long publish_seq = 0, int c
   const size_t stage_bytes = std::min<size_t>((size_t)stage_kb * 1024, ASM_LDS_MAX - fixed);
   const int gviews = nfb ? std::max(1, std::min(cb, (int)(stage_bytes / ((size_t)ne * 8)))) : 1;
   const size_t lds = nfb ? (size_t)gviews * ne * sizeof(double) + fixed : 0;
-  if (lds > h->asm_lds_set) {
-    HIP_OK(hipFuncSetAttribute((const void*)k_assemble, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    h->asm_lds_set = lds;
-  }
+  raise_dynamic_lds((const void*)k_assemble, h->device, lds);
   // (timed apart at cfg3: frame blocks alone 10.0 us, chunk sums alone 6.9 us, together 12.4 us)
   hipLaunchKernelGGL(k_assemble, dim3(nfb + d.C * d.B * h->nchunk), dim3(ASM_THREADS), lds, h->stream, d, h->t, h->rec.p, nfb, h->nchunk, gviews,
                      h->ftab.p, h->nftab, h->Hff.p, h->Hfs.p, h->g(), h->diag(), h->partial.p);
@@ -742,10 +753,7 @@ long long* g_chol_prof = nullptr;    // device buffer of 8 phase stamps (mcba_de
 void launch_chol(mcba_handle_s* h, int ns, double reg, double* buf, double* ps) {
   if (ns + 1 <= CHOL_BLK_MAX_N1 && !g_force_blocked_chol && !g_force_panel2_chol) {
     const size_t lds_blk = chol_blk_lds_bytes(ns);
-    if (lds_blk > h->chol_lds3_set) {
-      HIP_OK(hipFuncSetAttribute((const void*)k_chol_blk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_blk));
-      h->chol_lds3_set = lds_blk;
-    }
+    raise_dynamic_lds((const void*)k_chol_blk, h->device, lds_blk);
     hipLaunchKernelGGL(k_chol_blk, dim3(1), dim3(CHOL_BLK_THREADS), lds_blk, h->stream, ns, reg, buf, ps, h->info.p, g_chol_prof);
     return;
   }
@@ -756,10 +764,7 @@ void launch_chol(mcba_handle_s* h, int ns, double reg, double* buf, double* ps) 
     for (int kt0 = 0; kt0 < nbc;) {
       const int wt = cholp_panel_tiles(ns, kt0);
       const size_t lds = cholp_lds_bytes(ns, kt0, wt);
-      if (lds > h->chol_lds5_set) {
-        HIP_OK(hipFuncSetAttribute((const void*)k_cholp_panel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        h->chol_lds5_set = lds;
-      }
+      raise_dynamic_lds((const void*)k_cholp_panel, h->device, lds);
       hipLaunchKernelGGL(k_cholp_panel, dim3(1), dim3(CHOLP_THREADS), lds, h->stream, ns, kt0, wt, reg, buf, h->chol_linv.p,
                          h->info.p, g_chol_prof);
       const int k1 = kt0 + wt, m = nb - k1, nt = m * (m + 1) / 2;
@@ -1294,6 +1299,7 @@ int32_t mcba_rccl_unique_id(uint8_t* id_out) {
 int32_t mcba_rccl_init(mcba_handle h, const uint8_t* id_in, int32_t rank, int32_t world) {
   API_BEGIN
   REQUIRE(h && id_in && world >= 1 && rank >= 0 && rank < world, "bad argument");
+  REQUIRE(world <= SHARD_MAX_WORLD, "at most 64 ranks");   // (before anything is installed on the handle)
   const RcclApi& api = rccl_api();
   REQUIRE(api.ok, "librccl could not be loaded");
   REQUIRE(h->rccl_comm == nullptr, "communicator already initialised");
@@ -1328,10 +1334,17 @@ int32_t mcba_rccl_init(mcba_handle h, const uint8_t* id_in, int32_t rank, int32_
   }
   h->allreduce = rccl_allreduce_native;
   h->allreduce_ctx = h;
-  REQUIRE(world <= SHARD_MAX_WORLD, "at most 64 ranks");
   h->d.shard_rank = rank;
   h->d.shard_world = world;
   h->shard_root = rank == 0;
+  API_END
+}
+
+int32_t mcba_rccl_version(int32_t* version_out) {
+  API_BEGIN
+  REQUIRE(version_out, "null argument");
+  const RcclApi& api = rccl_api();
+  *version_out = api.ok ? api.version : 0;
   API_END
 }
 
@@ -2023,46 +2036,81 @@ struct LsmrOps {
   int nblk;            // persistent single-wave workgroups of the two Jacobian products
   int part_stride;
   size_t m;
+  bool sharded() const { return h->allreduce != nullptr; }
+  double* bpart() const { return h->d.off_boards >= 0 ? h->ls_bpart.p : nullptr; }   // boards=True: jp^T u per observation
+  LsmrGatherExtra extra() const { return LsmrGatherExtra{h->obs_index.p, h->board_off.p, bpart(), sharded() ? 1 : 0}; }
   int gather_grid() const {   // one wavefront per entry outside the per-frame pose block + one per frame (k_lsmr_gather)
     const int nfe = lsmr_gather_frame_entries(h->d);
     return h->d.n - nfe + (nfe > 0 ? h->d.Fl : 0);
   }
-  double fetch1(const double* dev) {
-    double v = 0.0;
-    HIP_OK(hipMemcpyAsync(h->h_scal, dev, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  // `count` doubles at `dev`: summed over the ranks of a frame-sharded problem (in place), then copied to the host
+  void fetch_sum(double* dev, int count, double* out) {
+    if (sharded()) call_allreduce(h, dev, (size_t)count, 0);
+    HIP_OK(hipMemcpyAsync(h->h_scal, dev, count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     sync(h);
-    v = h->h_scal[0];
-    return v;
+    for (int k = 0; k < count; ++k) out[k] = h->h_scal[k];
   }
   double fold(double* part, int n) {   // sum of n partials (fixed order), one double back to the host
     hipLaunchKernelGGL(k_dot, dim3(1), dim3(1024), 0, h->stream, (size_t)n, (const double*)part, (const double*)nullptr, h->ls_out.p, 0);
-    return fetch1(h->ls_out.p);
+    double v = 0.0;
+    fetch_sum(h->ls_out.p, 1, &v);
+    return v;
   }
-  // u <- J_h v - alpha u (mode 0) | f (mode 1) | J_h v (mode 2); returns |u|^2
+  // u <- J_h v - alpha u (mode 0) | f (mode 1) | J_h v (mode 2); returns |u|^2 (over all ranks)
   double jv(int mode, const double* vin, double alpha, double* u) {
     h->ops->lsmr_jv(h->d, h->t, h->stream, h->view_first.p, mode, h->dsc.p, vin, alpha, u, h->ls_partial.p, nblk, nullptr);
     check_launch("k_lsmr_jv");
     return fold(h->ls_partial.p, nblk);
   }
+  // the per-view partials of k_lsmr_jtu -> vout = D J^T u - beta vold, nrm[i] = (weighted) vout[i]^2.  Frame-sharded: the
+  // shared entries are a sum over the ranks -- ONE all-reduce of ns doubles (k_lsmr_shard_pack / _finish).
+  void gather(double beta, const double* vold, double* vout, const double* ls) {
+    const Dims& d = h->d;
+    hipLaunchKernelGGL(k_lsmr_gather, dim3(gather_grid()), dim3(64), 0, h->stream, d, (const double*)h->ls_part.p, part_stride,
+                       (const double*)h->dsc.p, beta, vold, vout, h->ls_nrm.p, ls, extra());
+    if (sharded()) {
+      const int ns = std::max(d.ns, 1);
+      if (h->ls_comm.n < (size_t)ns) h->ls_comm.alloc((size_t)ns, true);
+      hipLaunchKernelGGL(k_lsmr_shard_pack, dim3((ns + 255) / 256), dim3(256), 0, h->stream, d, (const double*)vout, h->ls_comm.p);
+      call_allreduce(h, h->ls_comm.p, (size_t)d.ns, 0);
+      hipLaunchKernelGGL(k_lsmr_shard_finish, dim3((d.n + 255) / 256), dim3(256), 0, h->stream, d, (const double*)h->ls_comm.p,
+                         (const double*)h->dsc.p, beta, vold, vout, h->ls_nrm.p, ls);
+    }
+    check_launch("k_lsmr_gather");
+  }
   // vout <- D J^T (u inv_beta) - beta vold (u normalised in place); returns |vout|^2
   double jtu(double* u, double inv_beta, double beta, const double* vold, double* vout) {
-    h->ops->lsmr_jtu(h->d, h->t, h->stream, h->view_first.p, inv_beta, u, h->ls_part.p, part_stride, nblk, nullptr);
-    hipLaunchKernelGGL(k_lsmr_gather, dim3(gather_grid()), dim3(64), 0, h->stream, h->d, (const double*)h->ls_part.p, part_stride,
-                       (const double*)h->dsc.p, beta, vold, vout, h->ls_nrm.p, (const double*)nullptr);
-    check_launch("k_lsmr_jtu / k_lsmr_gather");
+    h->ops->lsmr_jtu(h->d, h->t, h->stream, h->view_first.p, inv_beta, u, h->ls_part.p, part_stride, bpart(), nblk, nullptr);
+    gather(beta, vold, vout, nullptr);
     return fold(h->ls_nrm.p, h->d.n);
   }
   // one iteration of the device-resident solve (mcba_lsmr.h): six launches, every scalar read from the state `ls`
+  // (frame-sharded: + three small all-reduces -- [|u|^2, |x|^2] (2 doubles), the shared sums of J^T u (ns), |v|^2 (1))
   void iteration(double* ls, double* u, double* v, double* vraw, unsigned long long call) {
     const Dims& d = h->d;
     const int nvb = (d.n + 255) / 256;
     h->ops->lsmr_jv(d, h->t, h->stream, h->view_first.p, 0, h->dsc.p, v, 0.0, u, h->ls_partial.p, nblk, ls);
-    hipLaunchKernelGGL(k_lsmr_scal_a, dim3(1), dim3(1024), 0, h->stream, ls, (const double*)h->ls_partial.p, nblk,
-                       (const double*)h->ls_nrm.p, d.n, call, h->h_pub_seq + 1);
-    h->ops->lsmr_jtu(d, h->t, h->stream, h->view_first.p, 0.0, u, h->ls_part.p, part_stride, nblk, ls);
-    hipLaunchKernelGGL(k_lsmr_gather, dim3(gather_grid()), dim3(64), 0, h->stream, d, (const double*)h->ls_part.p, part_stride,
-                       (const double*)h->dsc.p, 0.0, (const double*)v, vraw, h->ls_nrm.p, (const double*)ls);
-    hipLaunchKernelGGL(k_lsmr_scal_b, dim3(1), dim3(1024), 0, h->stream, ls, (const double*)h->ls_nrm.p, d.n);
+    if (sharded()) {
+      double* two = h->ls_out.p + 4;
+      hipLaunchKernelGGL(k_lsmr_shard_fold_a, dim3(1), dim3(1024), 0, h->stream, d, (const double*)h->ls_partial.p, nblk,
+                         (const double*)h->ls_nrm.p, two);
+      call_allreduce(h, two, 2, 0);
+      hipLaunchKernelGGL(k_lsmr_scal_a, dim3(1), dim3(1024), 0, h->stream, ls, (const double*)two, 1, (const double*)(two + 1), 1,
+                         call, h->h_pub_seq + 1);
+    } else {
+      hipLaunchKernelGGL(k_lsmr_scal_a, dim3(1), dim3(1024), 0, h->stream, ls, (const double*)h->ls_partial.p, nblk,
+                         (const double*)h->ls_nrm.p, d.n, call, h->h_pub_seq + 1);
+    }
+    h->ops->lsmr_jtu(d, h->t, h->stream, h->view_first.p, 0.0, u, h->ls_part.p, part_stride, bpart(), nblk, ls);
+    gather(0.0, v, vraw, ls);
+    if (sharded()) {
+      double* one = h->ls_out.p + 6;
+      hipLaunchKernelGGL(k_dot, dim3(1), dim3(1024), 0, h->stream, (size_t)d.n, (const double*)h->ls_nrm.p, (const double*)nullptr, one, 0);
+      call_allreduce(h, one, 1, 0);
+      hipLaunchKernelGGL(k_lsmr_scal_b, dim3(1), dim3(1024), 0, h->stream, ls, (const double*)one, 1);
+    } else {
+      hipLaunchKernelGGL(k_lsmr_scal_b, dim3(1), dim3(1024), 0, h->stream, ls, (const double*)h->ls_nrm.p, d.n);
+    }
     hipLaunchKernelGGL(k_lsmr_update, dim3(nvb), dim3(256), 0, h->stream, d.n, 1.0, 0.0, 0.0, 0.0, vraw, h->ls_hbar.p, h->ls_x.p,
                        h->ls_h.p, h->ls_nrm.p, (const double*)ls);
   }
@@ -2106,6 +2154,7 @@ int lsmr_solve(LsmrOps& op, double damp, int* istop_out) {
   hipLaunchKernelGGL(k_lsmr_init, dim3(1), dim3(64), 0, h->stream, ls, alpha, beta, damp, normb, (double)maxiter);
   check_launch("k_lsmr_init");
   constexpr long long LOOKAHEAD = 6;
+  const bool lockstep = op.sharded();
   long long enqueued = 0, done = 0;
   int istop = 0;
   double t_wait = 0.0;
@@ -2120,7 +2169,12 @@ int lsmr_solve(LsmrOps& op, double damp, int* istop_out) {
       istop = (int)((w >> 32) & 0xff);
       if (istop != 0) break;
     }
-    if (enqueued - done < LOOKAHEAD && enqueued <= maxiter) {   // (iteration maxiter + 1 carries the tests of iteration maxiter)
+    // Frame-sharded: every rank must enqueue the SAME number of iterations (each carries three collectives), so an iteration is
+    // only enqueued once the word of the previous one (its k_lsmr_scal_a: completed = enqueued - 1, not stopped) has arrived --
+    // the state is computed from all-reduced sums and is bit-identical on all ranks, hence so is the decision.
+    const bool may_enqueue = lockstep ? (enqueued == 0 || ((seen >> 40) == call && done == enqueued - 1))
+                                      : (enqueued - done < LOOKAHEAD);
+    if (may_enqueue && enqueued <= maxiter) {   // (iteration maxiter + 1 carries the tests of iteration maxiter)
       op.iteration(ls, u, v, vraw, call);
       std::swap(v, vraw);
       ++enqueued;
@@ -2151,6 +2205,25 @@ int lsmr_solve(LsmrOps& op, double damp, int* istop_out) {
 
 }  // namespace
 
+// g, diag, cost at dx (device) + every table the two products read (view chains, That); timing: events around k_linearize
+static void lsmr_linearize(mcba_handle_s* h, const double* dx, bool timing = false) {
+  const Dims& d = h->d;
+  if (timing) HIP_OK(hipEventRecord(h->ev0, h->stream));
+  launch_linearize(h, dx);
+  if (timing) HIP_OK(hipEventRecord(h->ev1, h->stream));
+  launch_assemble(h);
+  const int nvw = d.views() * (d.motion == MOTION_ROLLING ? 2 : 1);
+  if (nvw > 0) hipLaunchKernelGGL(k_views, dim3((nvw + 127) / 128), dim3(128), 0, h->stream, d, h->t);
+  const int nb_views = std::max((d.views() + TMV - 1) / TMV, 1);
+  if (tmat_local_poses(d) <= TM_LOCAL_POSES)
+    hipLaunchKernelGGL(k_tmat<true>, dim3(nb_views), dim3(TM_THREADS), 0, h->stream, d, h->t, (double*)nullptr, 0, (double*)nullptr, 0,
+                       (const double*)nullptr, nb_views);
+  else
+    hipLaunchKernelGGL(k_tmat<false>, dim3(nb_views), dim3(TM_THREADS), 0, h->stream, d, h->t, (double*)nullptr, 0, (double*)nullptr, 0,
+                       (const double*)nullptr, nb_views);
+  check_launch("linearisation");
+}
+
 /* scipy.optimize.least_squares(method='trf', tr_solver='lsmr', x_scale='jac') -- the reference's solver (calibration.py:209-210;
  * scipy picks 'lsmr' for a sparse Jacobian) -- with every product on the device: opt->tr_solver == MCBA_TR_LSMR.  The driver is
  * scipy's trf_no_bounds line by line (trf.py:401-560): Jacobian scaling, Cauchy regularisation, gn_h = lsmr(J_h, f, damp), the
@@ -2159,8 +2232,8 @@ int lsmr_solve(LsmrOps& op, double damp, int* istop_out) {
 static void solve_lsmr(mcba_handle h, double* x_inout, const mcba_options* opt, mcba_result* result) {
   const double t_start = now_seconds();
   const Dims& d = h->d;
-  if (h->allreduce) throw Error("the lsmr trust-region solver is not available for frame-sharded handles");
-  if (d.off_boards >= 0) throw Error("the lsmr trust-region solver does not cover adjusted board points (boards=True)");
+  if (h->allreduce && d.shard_world <= 0)
+    throw Error("frame-sharded handle without a rank: call mcba_set_shard_rank (or mcba_rccl_init)");
   const ScalLayout& sl = h->sl;
   const double ftol = opt->ftol, xtol = opt->xtol, gtol = opt->gtol;
   const int max_nfev = opt->max_nfev > 0 ? opt->max_nfev : d.n * 100;
@@ -2177,23 +2250,19 @@ static void solve_lsmr(mcba_handle h, double* x_inout, const mcba_options* opt, 
   for (DevBuf<double>* b : {&h->ls_v, &h->ls_vraw, &h->ls_h, &h->ls_hbar, &h->ls_x, &h->ls_nrm})
     if (b->n < (size_t)d.n) b->alloc((size_t)d.n, true);
   if (h->ls_partial.n < (size_t)op.nblk) h->ls_partial.alloc((size_t)op.nblk, false);
-  if (h->ls_out.n < 4) h->ls_out.alloc(4, false);
+  if (h->ls_out.n < 8) h->ls_out.alloc(8, false);
+  if (d.off_boards >= 0) {   // boards=True: jp^T u per observation + the residual index of every slot (k_lsmr_gather)
+    if (h->ls_bpart.n < std::max<size_t>(3 * (size_t)h->n_inliers, 3)) h->ls_bpart.alloc(std::max<size_t>(3 * (size_t)h->n_inliers, 3), false);
+    ensure_obs_index(h);
+  }
 
   upload_x(h, x_inout, h->x.p);
   float lin_ms_total = 0.f;
+  bool lin_timed = false;
   auto linearize = [&](const double* dx) {   // g, diag, cost at dx + every table the two products read (view chains, That)
-    launch_linearize(h, dx);
-    launch_assemble(h);
-    const int nvw = d.views() * (d.motion == MOTION_ROLLING ? 2 : 1);
-    if (nvw > 0) hipLaunchKernelGGL(k_views, dim3((nvw + 127) / 128), dim3(128), 0, h->stream, d, h->t);
-    const int nb_views = std::max((d.views() + TMV - 1) / TMV, 1);
-    if (tmat_local_poses(d) <= TM_LOCAL_POSES)
-      hipLaunchKernelGGL(k_tmat<true>, dim3(nb_views), dim3(TM_THREADS), 0, h->stream, d, h->t, (double*)nullptr, 0, (double*)nullptr, 0,
-                         (const double*)nullptr, nb_views);
-    else
-      hipLaunchKernelGGL(k_tmat<false>, dim3(nb_views), dim3(TM_THREADS), 0, h->stream, d, h->t, (double*)nullptr, 0, (double*)nullptr, 0,
-                         (const double*)nullptr, nb_views);
-    check_launch("linearisation");
+    const bool timing = !lin_timed;          // (only the first linearisation is timed: see mcba_solve)
+    lin_timed = true;
+    lsmr_linearize(h, dx, timing);
   };
   const int prep_blocks = (d.n_pose + d.C + d.B * d.P + 255) / 256;
   const int cost_grid = h->cost_blocks;
@@ -2205,12 +2274,24 @@ static void solve_lsmr(mcba_handle h, double* x_inout, const mcba_options* opt, 
   while (true) {
     hipLaunchKernelGGL(k_vec_scale, dim3(sl.nvb), dim3(256), 0, h->stream, d, h->x.p, h->g(), h->diag(), h->scale_inv.p, h->dsc.p,
                        h->gh.p, first ? 1 : 0, h->scal.p + sl.vs, h->costcount(), h->scal.p + TR_COST);
+    if (h->allreduce) {   // the norms of the iterate, per rank ("gathered by summation", like message 2 of the exact solver)
+      hipLaunchKernelGGL(k_shard_fold2, dim3(1), dim3(64), 0, h->stream, h->scal.p + sl.vs, sl.nvb, (const double*)nullptr, 0,
+                         d.shard_rank, d.shard_world, h->scal.p + sl.shard2);
+      call_allreduce(h, h->scal.p + sl.shard2, (size_t)4 * d.shard_world, 0);
+      HIP_OK(hipMemcpyAsync(h->h_scal + sl.shard2, h->scal.p + sl.shard2, 4 * d.shard_world * sizeof(double),
+                            hipMemcpyDeviceToHost, h->stream));
+    }
     fetch_scalars(h, sl.q00p);
+    if (lin_timed && lin_ms_total == 0.f) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) lin_ms_total = ms;
+    }
     double mx = 0, gg = 0, xs = 0;
-    for (int blk = 0; blk < sl.nvb; ++blk) {
-      mx = std::max(mx, S[sl.vs + 3 * blk]);
-      gg += S[sl.vs + 3 * blk + 1];
-      xs += S[sl.vs + 3 * blk + 2];
+    const int nfold = h->allreduce ? d.shard_world : sl.nvb, at = h->allreduce ? sl.shard2 : sl.vs;
+    for (int blk = 0; blk < nfold; ++blk) {
+      mx = std::max(mx, S[at + 3 * blk]);
+      gg += S[at + 3 * blk + 1];
+      xs += S[at + 3 * blk + 2];
     }
     g_norm = mx;
     if (first) {
@@ -2236,13 +2317,19 @@ static void solve_lsmr(mcba_handle h, double* x_inout, const mcba_options* opt, 
               itn, istop);
     HIP_OK(hipMemcpyAsync(h->gn.p, h->ls_x.p, (size_t)d.n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     op.jv(2, h->gn.p, 0.0, h->ls_ub.p);
+    // [Jg.Jgn | Jg.Jg | Jgn.Jgn] over the m rows and [g_h.gn | g_h.g_h | gn.gn] over the n entries (reordered below); frame-sharded:
+    // per-rank partials (every parameter entry counted once: k_dot_weighted), summed by ONE all-reduce of 6 doubles
     hipLaunchKernelGGL(k_dot, dim3(1), dim3(1024), 0, h->stream, m, (const double*)h->ls_ua.p, (const double*)h->ls_ub.p, h->ls_out.p, 1);
-    hipLaunchKernelGGL(k_dot, dim3(1), dim3(1024), 0, h->stream, (size_t)d.n, (const double*)h->gh.p, (const double*)h->gn.p,
-                       h->scal.p + TR_D00, 1);   // [g_h.gn | g_h.g_h | gn.gn] -> reordered below
-    double q3[3], d3[3];
-    HIP_OK(hipMemcpyAsync(q3, h->ls_out.p, sizeof(q3), hipMemcpyDeviceToHost, h->stream));
-    HIP_OK(hipMemcpyAsync(d3, h->scal.p + TR_D00, sizeof(d3), hipMemcpyDeviceToHost, h->stream));
-    sync(h);
+    if (h->allreduce)
+      hipLaunchKernelGGL(k_dot_weighted, dim3(1), dim3(1024), 0, h->stream, d, (const double*)h->gh.p, (const double*)h->gn.p,
+                         h->ls_out.p + 3, 1);
+    else
+      hipLaunchKernelGGL(k_dot, dim3(1), dim3(1024), 0, h->stream, (size_t)d.n, (const double*)h->gh.p, (const double*)h->gn.p,
+                         h->ls_out.p + 3, 1);
+    double q6[6];
+    op.fetch_sum(h->ls_out.p, 6, q6);
+    const double* q3 = q6;
+    const double* d3 = q6 + 3;
     S[TR_REG] = reg_term;
     S[TR_Q00] = q3[1];
     S[TR_D00] = d3[1]; S[TR_D01] = d3[0]; S[TR_D11] = d3[2];
@@ -2256,12 +2343,21 @@ static void solve_lsmr(mcba_handle h, double* x_inout, const mcba_options* opt, 
       hipLaunchKernelGGL(k_vec_step, dim3(sl.nvb + prep_blocks), dim3(256), 0, h->stream, d, h->t, h->x.p, h->dsc.p, h->gh.p, h->gn.p,
                          S[TR_ALPHA], S[TR_BETA], h->xnew.p, h->scal.p + sl.step, (double*)nullptr, h->scal.p + sl.dotp, 0, sl.nvb,
                          (double*)nullptr, (double*)nullptr);
-      h->ops->cost(d, h->t, h->stream, h->scal.p + sl.costp, cost_grid);
-      fetch_scalars(h, sl.costp + cost_grid - sl.step, sl.step);
+      h->ops->cost(d, h->t, h->stream, h->scal.p + sl.costp, cost_grid);   // (an empty shard writes partial[0] = 0)
+      if (h->allreduce) {   // [trial cost | step norms] of this rank, 4 doubles, summed over the ranks
+        if (h->comm.n < 4) h->comm.alloc(4, false);
+        hipLaunchKernelGGL(k_shard_trial_pack, dim3(1), dim3(64), 0, h->stream, h->scal.p + sl.costp, cost_grid, h->scal.p + sl.step,
+                           sl.nvb, h->comm.p);
+        call_allreduce(h, h->comm.p, 4, 0);
+        hipLaunchKernelGGL(k_shard_trial_unpack, dim3(1), dim3(256), 0, h->stream, h->comm.p, h->scal.p + sl.costp,
+                           h->scal.p + sl.step, sl.nvb);
+      }
+      const int cost_values = h->allreduce ? 1 : cost_grid;
+      fetch_scalars(h, sl.costp + cost_values - sl.step, sl.step);
       double s3[3] = {0, 0, 0};
       for (int blk = 0; blk < sl.nvb; ++blk)
         for (int k = 0; k < 3; ++k) s3[k] += S[sl.step + 3 * blk + k];
-      cost_new = host_sum(S + sl.costp, cost_grid);
+      cost_new = host_sum(S + sl.costp, cost_values);
       const double predicted = S[TR_PRED];
       ++nfev;
       const double step_h_norm = std::sqrt(s3[0]);
@@ -2292,9 +2388,11 @@ static void solve_lsmr(mcba_handle h, double* x_inout, const mcba_options* opt, 
   if (getenv("MCBA_SOLVE_TRACE") != nullptr)
     fprintf(stderr, "[mcba_solve lsmr] %d trial steps, %lld LSMR iterations, %.3f ms\n", nfev - 1, lsmr_iterations,
             (now_seconds() - t_start) * 1e3);
+  gather_frame_entries(h, h->x.p);   // (frame-sharded: every rank returns the complete x; ONE n_motion message per solve)
   HIP_OK(hipMemcpyAsync(h->h_x, h->x.p, (size_t)d.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   sync(h);
   to_caller(h, x_inout, h->h_x);
+  h->lsmr_iterations_last = lsmr_iterations;
   if (result) {
     result->cost = cost;
     result->initial_cost = initial_cost;
@@ -2304,8 +2402,65 @@ static void solve_lsmr(mcba_handle h, double* x_inout, const mcba_options* opt, 
     result->status = status;
     result->iterations = iteration;
     result->solve_seconds = now_seconds() - t_start;
-    result->linearize_seconds = lin_ms_total * 1e-3;
+    result->linearize_seconds = lin_ms_total * 1e-3;   // (the first linearisation, as mcba_solve reports it)
   }
+}
+
+/* test hook (mcba_debug.h): the two matrix-free products of the lsmr mode at x WITHOUT column scaling, through the very kernels
+ * the solver iterates with (k_lsmr_jv / k_lsmr_jtu / k_lsmr_gather): jv_out[m] = J(x) v in the reference's residual order,
+ * jtu_out[n] = J(x)^T u.  Either pair may be NULL.  Linear loss (J of `evaluate` itself, as mcba_jacobian returns it).      */
+int32_t mcba_debug_lsmr_products(mcba_handle h, const double* x, const double* v, const double* u, double* jv_out, double* jtu_out) {
+  API_BEGIN
+  REQUIRE(h && x, "null argument");
+  REQUIRE((v == nullptr) == (jv_out == nullptr) && (u == nullptr) == (jtu_out == nullptr), "v / jv_out and u / jtu_out come in pairs");
+  g_fill_stream = h->stream;
+  set_loss(h, nullptr);
+  const Dims& d = h->d;
+  ensure_view_first(h);
+  const size_t m = 2 * (size_t)h->n_inliers;
+  const int NL = 6 * d.NPB + d.KI;
+  LsmrOps op{h, std::max(1, std::min(2048, d.views())), (NL + 1) & ~1, m};
+  for (DevBuf<double>* b : {&h->ls_u, &h->ls_ua})
+    if (b->n < std::max<size_t>(m, 2)) b->alloc(std::max<size_t>(m, 2), false);
+  if (h->ls_part.n < (size_t)std::max(d.views(), 1) * op.part_stride) h->ls_part.alloc((size_t)std::max(d.views(), 1) * op.part_stride, true);
+  else HIP_OK(hipMemsetAsync(h->ls_part.p, 0, h->ls_part.n * sizeof(double), h->stream));
+  for (DevBuf<double>* b : {&h->ls_v, &h->ls_vraw, &h->ls_nrm})
+    if (b->n < (size_t)d.n) b->alloc((size_t)d.n, true);
+  if (h->ls_partial.n < (size_t)op.nblk) h->ls_partial.alloc((size_t)op.nblk, false);
+  if (h->ls_out.n < 8) h->ls_out.alloc(8, false);
+  if (d.off_boards >= 0) {
+    if (h->ls_bpart.n < std::max<size_t>(3 * (size_t)h->n_inliers, 3)) h->ls_bpart.alloc(std::max<size_t>(3 * (size_t)h->n_inliers, 3), false);
+    ensure_obs_index(h);
+  }
+  upload_x(h, x, h->x.p);
+  sync(h);   // (h_x is reused for v below)
+  lsmr_linearize(h, h->x.p);
+  std::vector<double> ones((size_t)d.n, 1.0);
+  HIP_OK(hipMemcpyAsync(h->dsc.p, ones.data(), (size_t)d.n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  sync(h);
+  if (v != nullptr) {
+    upload_x(h, v, h->ls_v.p);
+    op.jv(2, h->ls_v.p, 0.0, h->ls_u.p);
+    HIP_OK(hipMemcpyAsync(jv_out, h->ls_u.p, m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    sync(h);
+  }
+  if (u != nullptr) {
+    HIP_OK(hipMemcpyAsync(h->ls_ua.p, u, m * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_OK(hipMemsetAsync(h->ls_v.p, 0, (size_t)d.n * sizeof(double), h->stream));
+    op.jtu(h->ls_ua.p, 1.0, 0.0, h->ls_v.p, h->ls_vraw.p);
+    HIP_OK(hipMemcpyAsync(h->h_x, h->ls_vraw.p, (size_t)d.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    sync(h);
+    to_caller(h, jtu_out, h->h_x);
+  }
+  API_END
+}
+
+/* LSMR iterations of the last solve with tr_solver = MCBA_TR_LSMR on this handle */
+int32_t mcba_debug_lsmr_info(mcba_handle h, int64_t* lsmr_iterations) {
+  API_BEGIN
+  REQUIRE(h && lsmr_iterations, "null argument");
+  *lsmr_iterations = h->lsmr_iterations_last;
+  API_END
 }
 
 int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba_result* result) {

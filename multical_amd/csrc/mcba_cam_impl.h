@@ -124,23 +124,23 @@ void lsmr_jv(const Dims& d, const Tables& t, hipStream_t s, const int32_t* first
 
 template <int MOTION, bool OPTK>
 void jtu2(const Dims& d, const Tables& t, hipStream_t s, const int32_t* first, double inv_beta, double* u, double* part,
-          int part_stride, int nblk, const double* ls) {
+          int part_stride, double* bpart, int nblk, const double* ls) {
   if (d.loss != 0)
-    hipLaunchKernelGGL((k_lsmr_jtu<ND_, FISH_, MOTION, OPTK, true>), dim3(nblk), dim3(64), 0, s, d, t, first, inv_beta, u, part, part_stride, ls);
+    hipLaunchKernelGGL((k_lsmr_jtu<ND_, FISH_, MOTION, OPTK, true>), dim3(nblk), dim3(64), 0, s, d, t, first, inv_beta, u, part, part_stride, bpart, ls);
   else
-    hipLaunchKernelGGL((k_lsmr_jtu<ND_, FISH_, MOTION, OPTK, false>), dim3(nblk), dim3(64), 0, s, d, t, first, inv_beta, u, part, part_stride, ls);
+    hipLaunchKernelGGL((k_lsmr_jtu<ND_, FISH_, MOTION, OPTK, false>), dim3(nblk), dim3(64), 0, s, d, t, first, inv_beta, u, part, part_stride, bpart, ls);
 }
 template <int MOTION>
 void jtu1(const Dims& d, const Tables& t, hipStream_t s, const int32_t* first, double inv_beta, double* u, double* part,
-          int part_stride, int nblk, const double* ls) {
-  if (d.KI > 0) jtu2<MOTION, true>(d, t, s, first, inv_beta, u, part, part_stride, nblk, ls);
-  else jtu2<MOTION, false>(d, t, s, first, inv_beta, u, part, part_stride, nblk, ls);
+          int part_stride, double* bpart, int nblk, const double* ls) {
+  if (d.KI > 0) jtu2<MOTION, true>(d, t, s, first, inv_beta, u, part, part_stride, bpart, nblk, ls);
+  else jtu2<MOTION, false>(d, t, s, first, inv_beta, u, part, part_stride, bpart, nblk, ls);
 }
 void lsmr_jtu(const Dims& d, const Tables& t, hipStream_t s, const int32_t* first, double inv_beta, double* u, double* part,
-              int part_stride, int nblk, const double* ls) {
-  if (d.motion == MOTION_STATIC) jtu1<MOTION_STATIC>(d, t, s, first, inv_beta, u, part, part_stride, nblk, ls);
-  else if (d.motion == MOTION_ROLLING) jtu1<MOTION_ROLLING>(d, t, s, first, inv_beta, u, part, part_stride, nblk, ls);
-  else jtu1<MOTION_HAND_EYE>(d, t, s, first, inv_beta, u, part, part_stride, nblk, ls);
+              int part_stride, double* bpart, int nblk, const double* ls) {
+  if (d.motion == MOTION_STATIC) jtu1<MOTION_STATIC>(d, t, s, first, inv_beta, u, part, part_stride, bpart, nblk, ls);
+  else if (d.motion == MOTION_ROLLING) jtu1<MOTION_ROLLING>(d, t, s, first, inv_beta, u, part, part_stride, bpart, nblk, ls);
+  else jtu1<MOTION_HAND_EYE>(d, t, s, first, inv_beta, u, part, part_stride, bpart, nblk, ls);
 }
 
 const CamOps OPS = {residual, project_model, cost, jacobian, linearize, points, lsmr_jv, lsmr_jtu};

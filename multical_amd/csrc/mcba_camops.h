@@ -24,8 +24,9 @@ struct CamOps {
   // ls != nullptr: alpha / inv_beta and the stop flag come from the device-resident state of the solve (mcba_lsmr.h)
   void (*lsmr_jv)(const Dims&, const Tables&, hipStream_t, const int32_t* first, int mode, const double* dscale, const double* v,
                   double alpha, double* u, double* partial, int nblk, const double* ls);
+  // bpart != nullptr (boards=True): + jp^T u of every observation, 3 doubles in the residual order (k_lsmr_gather sums them per point)
   void (*lsmr_jtu)(const Dims&, const Tables&, hipStream_t, const int32_t* first, double inv_beta, double* u, double* part,
-                   int part_stride, int nblk, const double* ls);
+                   int part_stride, double* bpart, int nblk, const double* ls);
 };
 
 const CamOps* cam_ops_pin4();

@@ -34,6 +34,13 @@ int32_t mcba_debug_chol(mcba_handle h, int32_t ns, const double* S, const double
 /* one v_mfma_f64_16x16x4_f64 on V = [A | B] (4 x 32, row-major): out[16][16] = A^T B (operand-layout self-test)     */
 int32_t mcba_debug_mfma_probe(const double* V, double* out);
 
+/* the matrix-free Jacobian products of the lsmr mode (k_lsmr_jv / k_lsmr_jtu / k_lsmr_gather) at x, unscaled columns, linear
+ * loss: jv_out[m] = J(x) v (reference residual order), jtu_out[n] = J(x)^T u; either pair may be NULL (tests compare them with
+ * mcba_jacobian)                                                                                                      */
+int32_t mcba_debug_lsmr_products(mcba_handle h, const double* x, const double* v, const double* u, double* jv_out, double* jtu_out);
+/* LSMR iterations taken by the last mcba_solve with tr_solver = MCBA_TR_LSMR on this handle                           */
+int32_t mcba_debug_lsmr_info(mcba_handle h, int64_t* lsmr_iterations);
+
 #ifdef __cplusplus
 }
 #endif

@@ -492,6 +492,15 @@ __global__ __launch_bounds__(64) void k_lsmr_jv(Dims d, Tables t, const int32_t*
           double2 old;
           old.x = old.y = 0.0;
           if (mode == 0) old = reinterpret_cast<const double2*>(u)[out0 + i];
+          double bterm[2] = {0.0, 0.0};
+          if (mode != 1 && d.off_boards >= 0) {   // adjusted board points (boards=True): + jp . (D v)[point], jp = rs A R_view
+            const int gq = d.off_boards + 3 * (t.board_off[b] + p);
+            double w3[3];
+            board_point_direction<ROLL>(t, v, ps.tr, dscale[gq] * vin[gq], dscale[gq + 1] * vin[gq + 1], dscale[gq + 2] * vin[gq + 2], w3);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+              bterm[a] = ps.rs[a] * (ps.A[3 * a] * w3[0] + ps.A[3 * a + 1] * w3[1] + ps.A[3 * a + 2] * w3[2]);
+          }
 #pragma unroll
           for (int a = 0; a < 2; ++a) {
             double row[NV];
@@ -501,6 +510,7 @@ __global__ __launch_bounds__(64) void k_lsmr_jv(Dims d, Tables t, const int32_t*
               val = 0.0;
 #pragma unroll
               for (int k = 0; k < DE + KI; ++k) val += row[k] * wl[k];
+              val += bterm[a];
               val -= alpha * (a == 0 ? old.x : old.y);
             } else {
               val = row[NV - 1];
@@ -523,7 +533,7 @@ __global__ __launch_bounds__(64) void k_lsmr_jv(Dims d, Tables t, const int32_t*
 template <int ND, int FISH, int MOTION, bool OPTK, bool ROBUST>
 __global__ __launch_bounds__(64) void k_lsmr_jtu(Dims d, Tables t, const int32_t* __restrict__ first, double inv_beta,
                                                  double* __restrict__ u, double* __restrict__ part, int part_stride,
-                                                 const double* __restrict__ ls = nullptr) {
+                                                 double* __restrict__ bpart, const double* __restrict__ ls = nullptr) {
   constexpr bool ROLL = MOTION == MOTION_ROLLING;
   constexpr int DE = ROLL ? 12 : 6, NPB = MOTION == MOTION_STATIC ? 3 : 4, NPC = 6 * NPB, KI = OPTK ? 4 + ND : 0;
   constexpr int NV = DE + KI + 1, NS = DE + KI;
@@ -567,6 +577,14 @@ __global__ __launch_bounds__(64) void k_lsmr_jtu(Dims d, Tables t, const int32_t
           uu.x *= inv_beta;
           uu.y *= inv_beta;
           reinterpret_cast<double2*>(u)[out0 + i] = uu;
+          if (bpart != nullptr) {   // boards=True: jp^T u of this observation (3 doubles, residual order), summed per point by k_lsmr_gather
+            double q3[3], w3[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) q3[k] = ps.rs[0] * uu.x * ps.A[k] + ps.rs[1] * uu.y * ps.A[3 + k];
+            board_point_adjoint<ROLL>(t, v, ps.tr, q3, w3);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) bpart[3 * (out0 + i) + k] = w3[k];
+          }
 #pragma unroll
           for (int a = 0; a < 2; ++a) {
             double row[NV];

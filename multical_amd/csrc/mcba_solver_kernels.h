@@ -2155,10 +2155,20 @@ __global__ __launch_bounds__(64) void k_fold_partials(double* __restrict__ part,
 __host__ __device__ inline int lsmr_gather_frame_entries(const Dims& d) {
   return (d.off_motion >= 0 && d.motion != MOTION_HAND_EYE) ? d.n_motion : 0;
 }
+//   boards=True: entry (point q, coordinate k) of the board-point block sums bpart[3 idx + k] over the inlier observations of the
+//                point (all frames x cameras of its board; idx = the observation's residual index, obs_index)
+//   frame-sharded handles (raw_shared): the SHARED entries are left as the rank's raw sum -- they are all-reduced and finished
+//                by k_lsmr_shard_finish; the entries of the own frames are final
+struct LsmrGatherExtra {
+  const int32_t* obs_index;
+  const int32_t* board_off;
+  const double* bpart;
+  int raw_shared;
+};
 __global__ __launch_bounds__(64) void k_lsmr_gather(Dims d, const double* __restrict__ part, int part_stride,
                                                     const double* __restrict__ dscale, double beta, const double* __restrict__ vold,
                                                     double* __restrict__ vout, double* __restrict__ nrm,
-                                                    const double* __restrict__ ls = nullptr) {
+                                                    const double* __restrict__ ls, LsmrGatherExtra ex) {
   const int lane = threadIdx.x;
   const int nfe = lsmr_gather_frame_entries(d), ngen = d.n - nfe;
   bool skip = false;
@@ -2199,8 +2209,27 @@ __global__ __launch_bounds__(64) void k_lsmr_gather(Dims d, const double* __rest
   }
   const int i = nfe > 0 && (int)blockIdx.x >= d.off_motion ? (int)blockIdx.x + nfe : (int)blockIdx.x;
   if (i >= d.n) return;
-  if (skip) {
+  if (skip && !ex.raw_shared) {
     if (lane == 0) vout[i] = vold[i];
+    return;
+  }
+  if (d.off_boards >= 0 && i >= d.off_boards) {   // adjusted board point: sum over the observations of the point
+    const int q = (i - d.off_boards) / 3, k = (i - d.off_boards) % 3;
+    int b = 0;
+    while (q >= ex.board_off[b + 1]) ++b;
+    const int p = q - ex.board_off[b], total = d.Fl * d.C;
+    double sum = 0.0;
+    for (int e = lane; e < total; e += 64) {   // e = fl C + c: the frame-major views of board b
+      const int idx = ex.obs_index[((size_t)e * d.B + b) * d.P + p];
+      if (idx >= 0) sum += ex.bpart[3 * (size_t)idx + k];
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) {
+      if (ex.raw_shared) { vout[i] = sum; return; }
+      const double val = dscale[i] * sum - beta * vold[i];
+      vout[i] = val;
+      nrm[i] = val * val;
+    }
     return;
   }
   int base = 0, na = 0, sa = 0, nb = 1, sb = 0, local = -1;
@@ -2239,10 +2268,70 @@ __global__ __launch_bounds__(64) void k_lsmr_gather(Dims d, const double* __rest
   }
   sum = wave_sum(sum);
   if (lane == 0) {
+    if (ex.raw_shared) { vout[i] = sum; return; }
     const double val = dscale[i] * sum - beta * vold[i];
     vout[i] = val;
     nrm[i] = val * val;
   }
+}
+
+// Frame-sharded LSMR: J_h^T u is a sum over views, so its SHARED entries are a sum over the ranks -- one all-reduce
+// of ns doubles per product; the entries of a rank's own frames are complete.  comm[s] = raw sum of shared entry s.
+__global__ __launch_bounds__(256) void k_lsmr_shard_pack(Dims d, const double* __restrict__ vraw, double* __restrict__ comm) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < d.ns) comm[s] = vraw[d.shared_to_x(s)];
+}
+// after the all-reduce: the shared entries are finished exactly as k_lsmr_gather finishes them on a single GPU
+// (val = dscale sum - beta vold), and nrm[i] = weight_i val_i^2 for EVERY entry (own frames 1, foreign frames 0, shared entries
+// on rank 0 only), so that the sum of the ranks' folds is |v|^2
+__global__ __launch_bounds__(256) void k_lsmr_shard_finish(Dims d, const double* __restrict__ comm, const double* __restrict__ dscale,
+                                                           double beta, const double* __restrict__ vold, double* __restrict__ vout,
+                                                           double* __restrict__ nrm, const double* __restrict__ ls) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.n) return;
+  bool skip = false;
+  if (ls != nullptr) {
+    if (ls[LS_ISTOP] != 0.0) return;
+    skip = ls[LS_SKIPV] != 0.0;
+    beta = ls[LS_BETA];
+  }
+  const int s = d.x_to_shared(i);
+  double val = vout[i];
+  if (s >= 0) {
+    val = skip ? vold[i] : dscale[i] * comm[s] - beta * vold[i];
+    vout[i] = val;
+  }
+  nrm[i] = d.entry_weight(i) * (val * val);
+}
+// one double per rank for a sum over all ranks: out[0] = sum_i weight_i a[i] (b == nullptr) or sum_i weight_i a[i] b[i]
+__global__ __launch_bounds__(1024) void k_dot_weighted(Dims d, const double* __restrict__ a, const double* __restrict__ b,
+                                                       double* __restrict__ out, int three) {
+  __shared__ double scratch[16];
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  for (int i = threadIdx.x; i < d.n; i += blockDim.x) {
+    const double w = d.entry_weight(i), x = a[i], y = b ? b[i] : 1.0;
+    s0 += w * (x * y);
+    s1 += w * (x * x);
+    s2 += w * (y * y);
+  }
+  const double t0 = block_reduce<false>(s0, scratch);
+  const double t1 = block_reduce<false>(s1, scratch);
+  const double t2 = block_reduce<false>(s2, scratch);
+  if (threadIdx.x == 0) {
+    out[0] = t0;
+    if (three) { out[1] = t1; out[2] = t2; }
+  }
+}
+// [ |u|^2 partial of this rank, |x|^2 partial of this rank ] in front of k_lsmr_scal_a (folded in k_dot's order)
+__global__ __launch_bounds__(1024) void k_lsmr_shard_fold_a(Dims d, const double* __restrict__ upart, int nblk,
+                                                            const double* __restrict__ xsq, double* __restrict__ out) {
+  __shared__ double scratch[16];
+  double s0 = 0.0, s1 = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += blockDim.x) s0 += upart[i];
+  for (int i = threadIdx.x; i < d.n; i += blockDim.x) s1 += d.entry_weight(i) * xsq[i];
+  const double t0 = block_reduce<false>(s0, scratch);
+  const double t1 = block_reduce<false>(s1, scratch);
+  if (threadIdx.x == 0) { out[0] = t0; out[1] = t1; }
 }
 
 // v <- v_raw * inv_alpha;  hbar <- c_hbar hbar + h;  x <- x + c_x hbar;  h <- c_h h + v;  nrm[i] = x[i]^2

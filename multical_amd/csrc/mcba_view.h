@@ -445,6 +445,35 @@ MCBA_HD double point_rows(const Dims& d, const Tables& t, int v, int c, int b, i
   return rho;
 }
 
+// The board-point block of a row pair (boards=True) is jp = rs A R with R = the view's rotation at the observation's scan time
+// (rolling shutter: (1 - t) R_start + t R_end), see point_rows.  The matrix-free products of the LSMR mode need
+//   R w   (J_h v:   jp . w = rs A . (R w))      and      R^T q   (J_h^T u:  jp^T u = R^T (sum_a rs_a u_a A_a)).
+template <bool ROLL>
+MCBA_HD void board_point_direction(const Tables& t, int v, double tr, double w0, double w1, double w2, double* out /*[3]*/) {
+  const double* V = t.view + (size_t)v * (VIEW_STRIDE * (ROLL ? 2 : 1));
+  for (int i = 0; i < 3; ++i) {
+    double r[3];
+    for (int k = 0; k < 3; ++k) {
+      r[k] = V[3 * i + k];
+      if constexpr (ROLL) r[k] = (1.0 - tr) * r[k] + tr * V[VIEW_STRIDE + 3 * i + k];
+    }
+    out[i] = r[0] * w0 + r[1] * w1 + r[2] * w2;
+  }
+}
+template <bool ROLL>
+MCBA_HD void board_point_adjoint(const Tables& t, int v, double tr, const double* q /*[3]*/, double* out /*[3]*/) {
+  const double* V = t.view + (size_t)v * (VIEW_STRIDE * (ROLL ? 2 : 1));
+  for (int k = 0; k < 3; ++k) {
+    double sum = 0.0;
+    for (int i = 0; i < 3; ++i) {
+      double rik = V[3 * i + k];
+      if constexpr (ROLL) rik = (1.0 - tr) * rik + tr * V[VIEW_STRIDE + 3 * i + k];
+      sum += q[i] * rik;
+    }
+    out[k] = sum;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // table preparation (bodies of k_prep / k_views)
 // ---------------------------------------------------------------------------------------------------------------

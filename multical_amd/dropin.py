@@ -2,8 +2,14 @@
 the MI355X back-end while keeping every other line of multical untouched.
 
     import multical_amd.dropin as dropin
-    dropin.install()              # native solver; or set MULTICAL_BACKEND=hip and call dropin.install_from_env()
-    dropin.install(mode="scipy")  # the reference's own scipy driver on the device fun + jac (MULTICAL_BACKEND=hip-scipy)
+    dropin.install()                # mode="lsmr": the reference's own trajectory and END POINT, everything on the device;
+                                    # or set MULTICAL_BACKEND=hip and call dropin.install_from_env()
+    dropin.install(mode="native")   # exact Schur / Cholesky steps: the converged optimum, ~100 x faster (MULTICAL_BACKEND=hip-native)
+    dropin.install(mode="scipy")    # the reference's own scipy driver on the device fun + jac (MULTICAL_BACKEND=hip-scipy)
+
+The DEFAULT reproduces the reference's answer (final RMS within max(1e-6 px, the reference's own reproducibility), identical
+nfev / status); `native` does NOT -- it walks the same valley further down and may end tens of pixels of principal point away
+from the reference's end point on weakly determined rigs (profiles/parity_table.md).
 
 After `install()`, `Workspace.calibrate` (workspace.py:228-247), `Calibration.adjust_outliers` (calibration.py:254-268)
 and `HandEyeCalibration.bundle_adjust` (optimization/hand_eye.py:73-75) reach the GPU through the unchanged call chain.
@@ -28,8 +34,16 @@ def _format_row(it, nfev, cost, red, step, opt):
 
 
 def bundle_adjust(self, tolerance=1e-4, f_scale=1.0, max_iterations=100, loss='linear'):
-  """Replacement body of multical.optimization.calibration.Calibration.bundle_adjust (same signature): the native solver
-  (mcba_solve).  Ends at the converged optimum -- at or below the reference's end point."""
+  """Replacement body of multical.optimization.calibration.Calibration.bundle_adjust (same signature), the DEFAULT of install():
+  mcba_solve with scipy's OWN trust-region step (tr_solver = lsmr) -- scipy's TRF driver and its LSMR restated line by line, the
+  two Jacobian products as HIP kernels: the reference's trajectory and END POINT, everything on the device."""
+  return _bundle_adjust_device(self, tolerance, f_scale, max_iterations, loss, 'lsmr')
+
+
+def bundle_adjust_native(self, tolerance=1e-4, f_scale=1.0, max_iterations=100, loss='linear'):
+  """Opt-in replacement body (install(mode="native")): exact regularised Gauss-Newton steps from the Schur-reduced normal
+  equations.  Ends at the CONVERGED optimum -- at or below the reference's cost, NOT at the reference's end point
+  (DESIGN.md section 2)."""
   return _bundle_adjust_device(self, tolerance, f_scale, max_iterations, loss, 'exact')
 
 
@@ -68,14 +82,10 @@ def bundle_adjust_scipy(self, tolerance=1e-4, f_scale=1.0, max_iterations=100, l
   return self.with_param_vec(res.x)
 
 
-def bundle_adjust_lsmr(self, tolerance=1e-4, f_scale=1.0, max_iterations=100, loss='linear'):
-  """Replacement body of Calibration.bundle_adjust: mcba_solve with scipy's OWN trust-region step (tr_solver = lsmr) -- scipy's
-  TRF driver and its LSMR restated line by line, the two Jacobian products as HIP kernels: the reference's trajectory and end
-  point like `bundle_adjust_scipy`, everything on the device."""
-  return _bundle_adjust_device(self, tolerance, f_scale, max_iterations, loss, 'lsmr')
+bundle_adjust_lsmr = bundle_adjust     # (round-4 name)
 
 
-MODES = {"native": bundle_adjust, "scipy": bundle_adjust_scipy, "lsmr": bundle_adjust_lsmr}
+MODES = {"lsmr": bundle_adjust, "native": bundle_adjust_native, "scipy": bundle_adjust_scipy}
 
 
 def _reprojection_tables(self):
@@ -84,10 +94,11 @@ def _reprojection_tables(self):
     return h.reprojection_error(self.param_vec)
 
 
-def install(calibration_module=None, patch_errors=False, mode="native"):
+def install(calibration_module=None, patch_errors=False, mode="lsmr"):
   """Patch `Calibration.bundle_adjust` of multical (or of the given module object).  Returns the patched class.
-  mode = "native": mcba_solve (fast; converged optimum).  mode = "scipy": the reference's own scipy driver on the device
-  residuals + analytic Jacobian (the reference's end point to 1e-6 px).
+  mode = "lsmr" (default): mcba_solve with scipy's TRF + LSMR step on the device -- the reference's end point.
+  mode = "native": mcba_solve with exact steps (fastest; the converged optimum, not the reference's end point).
+  mode = "scipy": the reference's own scipy driver on the device residuals + analytic Jacobian (host-side LSMR).
   patch_errors=True additionally evaluates `reprojection_error` / `reject_outliers` on the device."""
   if mode not in MODES:
     raise ValueError(f"unknown mode {mode!r}, options are {sorted(MODES)}")
@@ -120,13 +131,13 @@ def uninstall(calibration_module=None):
 
 
 def install_from_env():
-  """MULTICAL_BACKEND=hip -> install() (native solver); MULTICAL_BACKEND=hip-scipy -> install(mode="scipy"); anything else
-  keeps the reference's scipy path untouched."""
-  backend = os.environ.get("MULTICAL_BACKEND", "scipy").lower()
-  if backend == "hip":
+  """MULTICAL_BACKEND=hip (or hip-lsmr) -> install(): the reference's end point on the device; hip-native -> install(mode="native");
+  hip-scipy -> install(mode="scipy"); anything else keeps the reference's scipy path untouched."""
+  backend = os.environ.get("MULTICAL_BACKEND", "scipy").lower().replace("_", "-")
+  if backend in ("hip", "hip-lsmr"):
     return install()
-  if backend in ("hip-scipy", "hip_scipy"):
+  if backend == "hip-native":
+    return install(mode="native")
+  if backend == "hip-scipy":
     return install(mode="scipy")
-  if backend in ("hip-lsmr", "hip_lsmr"):
-    return install(mode="lsmr")
   return None

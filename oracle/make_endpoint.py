@@ -1,0 +1,180 @@
+"""TEST INFRASTRUCTURE: END POINTS of the unmodified reference at the BASELINE configurations' STATED sizes.
+
+    PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_endpoint cfg3 ba          # Calibration.bundle_adjust()
+    PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_endpoint cfg3 ao          # adjust_outliers as Workspace.calibrate drives it
+    PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_endpoint cfg3 pert 100 101   # self-sensitivity re-runs (seeds)
+    PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_endpoint merge cfg3       # parts -> tests/golden/cfg3_endpoint.npz
+
+Runs `Calibration.bundle_adjust` (/root/reference/multical/optimization/calibration.py:199-212) and
+`Calibration.adjust_outliers` (:254-268, arguments of workspace.py:228-247) of the real reference (oracle/refload.py) on the
+seeded synthetic rig of a BASELINE configuration at full size -- hours of one host core -- and records what the reference
+returned, scipy's iteration table, the number of `evaluate` calls, wall time and peak memory, all MEASURED (BASELINE.md only
+extrapolated them).  The rig is regenerated from its seed on the test side (checksums of the observation table are stored).
+"""
+import io
+import os
+import sys
+import json
+import time
+import resource
+import logging
+
+import numpy as np
+
+from multical_amd import synthetic
+from . import build_reference
+from .make_golden import _Spy, PERT_SIGMA, GOLDEN_DIR
+
+PART_DIR = os.path.join(GOLDEN_DIR, "_parts")
+
+
+def _rig(cfg):
+  rig = synthetic.make_rig(cfg)
+  calib, ref = build_reference.reference_calibration(rig)
+  head = dict(config=np.array(cfg), shape=np.array(rig.valid.shape), points_sum=np.array(rig.points.sum()),
+              points_abs_sum=np.array(np.abs(rig.points).sum()), valid_count=np.array(int(rig.valid.sum())))
+  return rig, calib, ref, head
+
+
+class _Count(object):
+  """Counts `Calibration.with_param_vec` calls (= calls of the reference's `evaluate` closure)."""
+
+  def __init__(self, ref):
+    self.cls = ref.optimization_calibration.Calibration
+    self.n = 0
+
+  def __enter__(self):
+    self.real = self.cls.with_param_vec
+    outer = self
+
+    def counted(this, x):
+      outer.n += 1
+      return outer.real(this, x)
+    self.cls.with_param_vec = counted
+    return self
+
+  def __exit__(self, *a):
+    self.cls.with_param_vec = self.real
+
+
+def _log():
+  log = io.StringIO()
+  handler = logging.StreamHandler(log)
+  logger = logging.getLogger("calibration")
+  logger.addHandler(handler)
+  logger.setLevel(logging.INFO)
+  logger.propagate = False
+  return log
+
+
+def _save(cfg, stage, out):
+  os.makedirs(PART_DIR, exist_ok=True)
+  path = os.path.join(PART_DIR, f"{cfg}_{stage}.npz")
+  np.savez_compressed(path, **out)
+  print(f"[{time.strftime('%H:%M:%S')}] {cfg} {stage} -> {path}", flush=True)
+
+
+def run_ba(cfg):
+  rig, calib, ref, out = _rig(cfg)
+  error_stats = ref.optimization_calibration.error_stats
+  log = _log()
+  out["x0"] = calib.param_vec
+  t0 = time.time()
+  with _Spy() as spy, _Count(ref) as cnt:
+    ba = calib.bundle_adjust()
+    res = spy.results[-1]
+  out["ba_seconds"] = time.time() - t0
+  out["ba_evaluate_calls"] = cnt.n
+  out["ba_peak_rss_gb"] = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2 ** 20
+  out["ba_x"], out["ba_x_raw"] = ba.param_vec, res.x
+  out["ba_cost"], out["ba_optimality"] = res.cost, res.optimality
+  out["ba_nfev"], out["ba_njev"], out["ba_status"] = res.nfev, res.njev, res.status
+  es = error_stats(ba.reprojection_error)
+  out["ba_rms"], out["ba_quantiles"] = es.rms, np.asarray(es.quantiles)
+  out["ba_log"] = np.array(log.getvalue())
+  out["host"] = np.array(json.dumps(dict(cpu_count=os.cpu_count(), numpy=np.__version__,
+                                         scipy=__import__("scipy").__version__)))
+  print(log.getvalue(), flush=True)
+  print(f"{cfg} ba: rms {float(out['ba_rms']):.9f} nfev {res.nfev} status {res.status} {out['ba_seconds']:.0f} s "
+        f"{cnt.n} evaluate calls, peak {out['ba_peak_rss_gb']:.1f} GB", flush=True)
+  _save(cfg, "ba", out)
+
+
+def run_ao(cfg):
+  rig, calib, ref, out = _rig(cfg)
+  error_stats = ref.optimization_calibration.error_stats
+  select_threshold = ref.optimization_calibration.select_threshold
+  log = _log()
+  t0 = time.time()
+  with _Spy() as spy, _Count(ref) as cnt:
+    ao = calib.adjust_outliers(num_adjustments=3, select_outliers=select_threshold(quantile=0.75, factor=5.0),
+                               select_scale=None, loss='linear', tolerance=1e-4)
+    results = list(spy.results)
+  out["ao_seconds"] = time.time() - t0
+  out["ao_evaluate_calls"] = cnt.n
+  out["ao_peak_rss_gb"] = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2 ** 20
+  out["ao_x"], out["ao_x_raw"] = ao.param_vec, results[-1].x
+  out["ao_inliers_packed"] = np.packbits(ao.inliers.ravel())
+  out["ao_rms"] = error_stats(ao.reprojection_error).rms
+  out["ao_rms_inliers"] = error_stats(ao.reprojection_inliers).rms
+  out["ao_nfev"] = np.array([r.nfev for r in results])
+  out["ao_status"] = np.array([r.status for r in results])
+  out["ao_cost"] = np.array([r.cost for r in results])
+  out["ao_log"] = np.array(log.getvalue())
+  print(log.getvalue(), flush=True)
+  print(f"{cfg} ao: rms {float(out['ao_rms']):.9f} inliers {float(out['ao_rms_inliers']):.9f} nfev {out['ao_nfev']} "
+        f"{out['ao_seconds']:.0f} s", flush=True)
+  _save(cfg, "ao", out)
+
+
+def run_pert(cfg, seeds):
+  """The reference's own reproducibility at this size: the same call with N(0, 1e-12 px) added to its residual function
+  (oracle/make_golden.py explains why that moves the end point)."""
+  rig, calib, ref, out = _rig(cfg)
+  error_stats = ref.optimization_calibration.error_stats
+  for s in seeds:
+    t0 = time.time()
+    with _Spy(PERT_SIGMA, seed=s) as spy:
+      bp = calib.bundle_adjust()
+      res = spy.results[-1]
+    part = dict(out, seed=s, rms=error_stats(bp.reprojection_error).rms, nfev=res.nfev, status=res.status,
+                cost=res.cost, x_raw=res.x, seconds=time.time() - t0)
+    print(f"{cfg} pert {s}: rms {float(part['rms']):.9f} nfev {res.nfev} status {res.status} {part['seconds']:.0f} s", flush=True)
+    _save(cfg, f"pert{s}", part)
+
+
+def merge(cfg):
+  import glob
+  out = {}
+  for stage in ("ba", "ao"):
+    p = os.path.join(PART_DIR, f"{cfg}_{stage}.npz")
+    if os.path.exists(p):
+      out.update({k: v for k, v in np.load(p).items()})
+  perts = sorted(glob.glob(os.path.join(PART_DIR, f"{cfg}_pert*.npz")))
+  if perts:
+    ps = [np.load(p) for p in perts]
+    out["ba_pert_seed"] = np.array([int(p["seed"]) for p in ps])
+    out["ba_pert_rms"] = np.array([float(p["rms"]) for p in ps])
+    out["ba_pert_nfev"] = np.array([int(p["nfev"]) for p in ps])
+    out["ba_pert_status"] = np.array([int(p["status"]) for p in ps])
+    out["ba_pert_cost"] = np.array([float(p["cost"]) for p in ps])
+  path = os.path.join(GOLDEN_DIR, f"{cfg}_endpoint.npz")
+  np.savez_compressed(path, **out)
+  print(f"{cfg}: {sorted(out)} -> {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+if __name__ == "__main__":
+  sys.dont_write_bytecode = True
+  if sys.argv[1] == "merge":
+    for c in sys.argv[2:]:
+      merge(c)
+  else:
+    cfg, stage = sys.argv[1], sys.argv[2]
+    if stage == "ba":
+      run_ba(cfg)
+    elif stage == "ao":
+      run_ao(cfg)
+    elif stage == "pert":
+      run_pert(cfg, [int(s) for s in sys.argv[3:]])
+    else:
+      raise SystemExit(f"unknown stage {stage}")

@@ -178,6 +178,82 @@ def test_sharded_solve_two_ranks_one_gpu(name, empty_last, frames, tmp_path):
   assert body.count(G) >= int(sh["njev"])                      # (+ one per re-linearisation after a rejected step)
 
 
+def _gpu_lsmr_worker(rank, world, port, name, out, empty_last=False, boards=False):
+  sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+  import torch
+  import torch.distributed as dist
+  os.environ["MASTER_ADDR"] = "127.0.0.1"
+  os.environ["MASTER_PORT"] = str(port)
+  torch.cuda.set_device(0)
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  g, rig = load_golden(name)
+  c = mirror(rig)
+  x0 = c.param_vec
+  F = rig.valid.shape[1]
+  h = mdist.sharded_handle(c, shards=[(0, F)] + [(F, F)] * (world - 1) if empty_last else None)
+  h.allreduce_stats(reset=True)
+  res = h.solve(x0, tr_solver="lsmr")
+  ar_calls, ar_doubles, ar_sizes = h.allreduce_stats(reset=True, cap=1 << 20)
+  lsmr_itn = h.lsmr_iterations()
+  e, v = h.reprojection_error(res.x)
+  sq = torch.tensor([float((e[v] ** 2).sum()), float(v.sum())], dtype=torch.float64)
+  dist.all_reduce(sq)
+  xs = [None] * world
+  dist.all_gather_object(xs, res.x)
+  if rank == 0:
+    np.savez(out, x=res.x, nfev=res.nfev, status=res.status, final_cost=res.cost, rms=float(np.sqrt(sq[0] / sq[1])),
+             ar_sizes=np.array(ar_sizes), njev=res.njev, lsmr_itn=lsmr_itn, x_equal=all(np.array_equal(xs[0], xr) for xr in xs))
+  h.close()
+  dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,empty_last", [("cfg1", False), ("tiny_rolling", False), ("tiny_handeye", False), ("tiny_boards", False),
+                                             ("cfg1", True)])
+def test_sharded_lsmr_solve_two_ranks_one_gpu(name, empty_last, tmp_path):
+  """solver = "lsmr" on a frame-sharded problem: J v is local, J^T u is a sum over views -- ONE all-reduce of the
+  ns shared entries per product, plus the scalar norms.  Two ranks on one GPU (gloo) must take the single handle's trust-region
+  trajectory (nfev, status) and land on its end point to the resolution LSMR-truncated steps are defined to; every rank returns
+  the same x; the sequence of collectives per LSMR iteration is [2 | ns | 1] and nothing grows with the number of frames."""
+  import torch.multiprocessing as mp
+  from multical_amd.backend import Handle
+  out = str(tmp_path / "sharded_lsmr.npz")
+  world = 2
+  mp.spawn(_gpu_lsmr_worker, args=(world, _free_port(), name, out, empty_last), nprocs=world, join=True)
+  sh = np.load(out)
+  g, rig = load_golden(name)
+  c = mirror(rig)
+  with Handle(c) as h:
+    res = h.solve(c.param_vec, tr_solver="lsmr")
+    itn = h.lsmr_iterations()
+    e, v = h.reprojection_error(res.x)
+  rms = float(np.sqrt(np.mean(e[v] ** 2)))
+  spread = float(np.abs(g["ba_pert_rms"] - g["ba_rms"]).max())
+  assert bool(sh["x_equal"])
+  assert int(sh["status"]) == res.status
+  if name in ("cfg1", "tiny_handeye"):          # reference end point defined to < 1e-6 px: same trajectory, same end point
+    assert int(sh["nfev"]) == res.nfev
+    assert abs(float(sh["rms"]) - rms) <= 1e-6
+    assert float(sh["final_cost"]) == pytest.approx(res.cost, rel=1e-6)
+  else:                                         # (two shards sum in another order: the end point moves inside the reference's spread)
+    assert abs(int(sh["nfev"]) - res.nfev) <= 2
+    assert abs(float(sh["rms"]) - rms) <= max(1e-6, 3 * spread)
+  # ---- collectives, in issue order --------------------------------------------------------------------------------
+  sizes = [int(v) for v in sh["ar_sizes"]]
+  n = res.x.size
+  F = rig.valid.shape[1]
+  n_motion = {"static": 6, "rolling": 12}.get(rig.cfg["motion"], 0) * F
+  ns = n - n_motion
+  G = 2 * ns + 6
+  allowed = {G, 4 * world, 1, 2, ns, 6, 4} | ({n_motion} if n_motion else set())
+  assert set(sizes) <= allowed, sorted(set(sizes) - allowed)
+  # every LSMR iteration: [|u|^2, |x|^2] -> shared sums of J^T u -> |v|^2
+  triples = sum(1 for i in range(len(sizes) - 2) if sizes[i] == 2 and sizes[i + 1] == ns and sizes[i + 2] == 1)
+  assert triples >= int(sh["lsmr_itn"]) and triples <= int(sh["lsmr_itn"]) + 2 * res.nfev   # (+ the wasted product per solve)
+  assert sizes.count(ns) <= triples + 2 * res.nfev + 2
+  assert abs(int(sh["lsmr_itn"]) - itn) <= max(3, itn // 20)
+
+
 def _rccl_single_rank_worker(rank, out_path):
   import numpy as np
   from multical_amd.backend import Handle
@@ -286,17 +362,35 @@ def test_bench_self_launches_its_ranks_and_fails_loudly_without_a_gpu():
 @pytest.mark.gpu
 def test_bench_two_ranks_on_one_gpu():
   """The N > 1 path of bench.py end to end, self-launched (no torchrun on the command line): two ranks share the one
-  GPU of the test box with host-staged gloo all-reduces.  The JSON line must carry the weak-scaling value, the strong-
-  scaling object of the fixed 8 x 500 x 2 rig and the contract's fields."""
+  GPU of the test box with host-staged gloo all-reduces.  `value` must be evaluations/s of the FIXED 8 x 500 x 2 rig of the north
+  star (250 frames per rank, "scaling": "strong"), the weak-scaling figure rides along, and `parity_route` -- the lsmr solve of
+  the frame-sharded rig -- lands on the committed end point of the unmodified reference."""
   import json
   r = _run_bench({"MCBA_BENCH_BACKEND": "gloo"}, "--gpus", "2", "--steps", "5", "--warmup", "2", "--repeats", "2",
                  "--no-cpu-baseline")
   assert r.returncode == 0, r.stderr[-3000:]
+  assert "[bench rank 0/2]" in r.stderr and "[bench rank 1/2]" in r.stderr and "native_rccl=false" in r.stderr
   line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
   out = json.loads(line)
-  assert out["n_gpus"] == 2 and out["steps"] == 5 and out["warmup"] == 2 and out["scaling"] == "weak"
+  assert out["n_gpus"] == 2 and out["steps"] == 5 and out["warmup"] == 2 and out["scaling"] == "strong"
   assert out["metric"] == "residual+Jacobian evals/sec" and out["dtype"] == "f64" and out["value"] > 0
-  assert out["strong_scaling"]["frames_per_gpu"] == [250, 250] and out["strong_scaling"]["value"] > 0
-  assert "gloo" in out["config"]["parallelism"]
+  assert out["config"]["n_observations"] == 763957 and out["config"]["native_rccl"] is False
+  assert "[250, 250]" in out["config"]["parallelism"] and "gloo" in out["config"]["parallelism"]
+  assert out["weak_scaling"]["frames_per_gpu"] == 500 and out["weak_scaling"]["value"] > 0
   assert out["roofline"]["frac"] > 0 and out["obs_per_s"] > 0 and 0 < out["step_roofline_frac"] < 1
   assert 2.5 < out["final_rms_px"] < 3.5                     # 1 % gross outliers stay in: ~3 px (single GPU: 3.03)
+  pr = out["parity_route"]
+  assert pr["solver"] == "lsmr" and pr["nfev"] == pr["reference_nfev"] and pr["status"] == pr["reference_status"]
+  assert pr["abs_delta_px"] <= max(1e-6, 3 * (pr["reference_spread_px"] or 0.0)), pr
+
+
+def test_bench_refuses_ranks_that_share_a_device(monkeypatch):
+  """backend nccl with more ranks than visible GPUs = ranks silently sharing a device: bench.py must exit non-zero (no JSON line).
+  Runs wherever fewer than two GPUs are visible (build box: 0 -> the GPU-only exit; single-GPU test box: the sharing exit)."""
+  import torch
+  if torch.cuda.device_count() >= 2:
+    pytest.skip("two GPUs visible")
+  r = _run_bench({}, "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-solve")
+  assert r.returncode != 0
+  assert "refusing to measure" in r.stderr or "GPU-only" in r.stderr, r.stderr[-2000:]
+  assert not r.stdout.strip().startswith("{")

@@ -66,6 +66,18 @@ def test_install_from_env(monkeypatch):
   finally:
     dropin.uninstall()
   assert refcal.Calibration.bundle_adjust is original
+  monkeypatch.setenv("MULTICAL_BACKEND", "hip-native")
+  try:
+    assert dropin.install_from_env() is refcal.Calibration
+    assert refcal.Calibration.bundle_adjust is dropin.bundle_adjust_native
+  finally:
+    dropin.uninstall()
+  monkeypatch.setenv("MULTICAL_BACKEND", "hip-lsmr")
+  try:
+    assert dropin.install_from_env() is refcal.Calibration
+    assert refcal.Calibration.bundle_adjust is dropin.bundle_adjust      # the default: the reference's end point
+  finally:
+    dropin.uninstall()
   monkeypatch.setenv("MULTICAL_BACKEND", "hip-scipy")
   try:
     assert dropin.install_from_env() is refcal.Calibration
@@ -155,10 +167,15 @@ class _HandEyeCalibration(object):
 
 
 @pytest.mark.gpu
-def test_dropin_runs_the_reference_call_chains_on_the_gpu():
+@pytest.mark.parametrize("mode", ["lsmr", "native"])
+def test_dropin_runs_the_reference_call_chains_on_the_gpu(mode):
+  """install() (default mode "lsmr": the reference's end point) and install(mode="native") (exact steps: the converged optimum)
+  on fixtures whose reference end point and converged optimum agree to 1e-6 px."""
   mod = types.SimpleNamespace(Calibration=_PlainCalibration)
   try:
-    assert dropin.install(calibration_module=mod) is _PlainCalibration
+    assert (dropin.install(calibration_module=mod) if mode == "lsmr" else
+            dropin.install(calibration_module=mod, mode=mode)) is _PlainCalibration
+    assert _PlainCalibration.bundle_adjust is (dropin.bundle_adjust if mode == "lsmr" else dropin.bundle_adjust_native)
     # Calibration.bundle_adjust + adjust_outliers (what Workspace.calibrate drives) against the cfg1 reference golden
     g, rig = load_golden("cfg1")
     c = _as_plain(mirror(rig))
@@ -180,7 +197,8 @@ def test_dropin_runs_the_reference_call_chains_on_the_gpu():
     assert abs(calibration.error_stats(he2.calib.reprojection_error).rms - float(g["ba_rms"])) < 1e-6
     he3 = he.adjust_outliers(num_adjustments=3, select_outliers=calibration.select_threshold(0.75, 5.0))
     assert np.array_equal(he3.calib.inliers, g["ao_inliers"])
-    assert abs(calibration.error_stats(he3.calib.reprojection_inliers).rms - float(g["ao_tight_rms_inliers"])) < 1e-6
+    assert abs(calibration.error_stats(he3.calib.reprojection_inliers).rms -
+               float(g["ao_tight_rms_inliers" if mode == "native" else "ao_rms_inliers"])) < 1e-6
   finally:
     dropin.uninstall(calibration_module=mod)
   with pytest.raises(AssertionError, match="un-patched"):

@@ -1,0 +1,138 @@
+"""GPU (MI355X): the lsmr mode (mcba_options.tr_solver = MCBA_TR_LSMR) below and above the solver level.
+
+  * kernel level: the matrix-free products J v / J^T u of k_lsmr_jv / k_lsmr_jtu / k_lsmr_gather against the analytic Jacobian
+    mcba_jacobian returns (itself pinned to the reference's finite differences and to 3-point differences of the oracle:
+    tests/test_gpu_parity.py, tests/test_gpu_protocol.py), on every motion / camera model and with boards=True;
+  * END POINTS of the unmodified reference at the BASELINE configurations' STATED sizes (tests/golden/cfg*_endpoint.npz,
+    oracle/make_endpoint.py: hours of one host core each): solver = "lsmr" reproduces them with identical nfev / status.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from multical_amd import synthetic, calibration
+from multical_amd.backend import Handle
+from util import load_golden, mirror, GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+PRODUCT_CASES = ["tiny", "tiny_rolling", "tiny_fisheye", "tiny_handeye", "tiny_rational", "tiny_thin_prism", "tiny_tilted",
+                 "tiny_edge", "tiny_fixintr", "tiny_pin4", "tiny_boards", "tiny_bigboard", "tiny_fishmix", "tiny_fishmix5", "cfg1"]
+
+
+@pytest.mark.parametrize("name", PRODUCT_CASES)
+def test_lsmr_products_against_the_jacobian(name):
+  """J v and J^T u of the lsmr mode's kernels = h.jacobian(x) @ v and .T @ u to rounding (1e-12 of sum |J_ij| |v_j|): the row
+  pairs, the That chain of the pose blocks, the per-view reduction, the gather over the views of every parameter (incl. the
+  board-point block of boards=True and invalid / ragged blocks, whose columns must come back exactly zero)."""
+  g, rig = load_golden(name)
+  c = mirror(rig)
+  rng = np.random.default_rng(5)
+  for x in (c.param_vec, c.param_vec + 1e-3 * rng.normal(size=c.param_vec.size)):
+    with Handle(c) as h:
+      J = h.jacobian(x)
+      v = rng.normal(size=h.n_params)
+      u = rng.normal(size=h.n_residuals)
+      jv, jtu = h.lsmr_products(x, v, u)
+      jv_only, _ = h.lsmr_products(x, v, None)
+      _, jtu_only = h.lsmr_products(x, None, u)
+    A = abs(J)
+    assert np.abs(jv - J @ v).max() <= 1e-12 * (A @ np.abs(v)).max()
+    scale = A.T @ np.abs(u)
+    assert np.abs(jtu - J.T @ u).max() <= 1e-12 * scale.max()
+    assert np.all(jtu[scale == 0] == 0)                   # structurally zero columns (skew, invalid poses, fix_aspect)
+    assert np.array_equal(jv, jv_only) and np.array_equal(jtu, jtu_only)
+
+
+def test_lsmr_products_after_an_outlier_rejection():
+  """the products follow the CURRENT inlier set (view lists, residual order, obs_index of the board-point gather)"""
+  g, rig = load_golden("tiny_boards")
+  c = mirror(rig)
+  x = c.param_vec
+  rng = np.random.default_rng(6)
+  with Handle(c) as h:
+    e, valid = h.reprojection_error(x)
+    h.reject_outliers(x, float(np.quantile(e[valid.astype(bool)], 0.9)))
+    J = h.jacobian(x)
+    assert J.shape[0] == h.n_residuals < g["r0"].size
+    v, u = rng.normal(size=h.n_params), rng.normal(size=h.n_residuals)
+    jv, jtu = h.lsmr_products(x, v, u)
+  A = abs(J)
+  assert np.abs(jv - J @ v).max() <= 1e-12 * (A @ np.abs(v)).max()
+  assert np.abs(jtu - J.T @ u).max() <= 1e-12 * (A.T @ np.abs(u)).max()
+
+
+def test_lsmr_mode_with_adjusted_board_points():
+  """boards=True (board/charuco.py:112-117, sparsity calibration.py:188-190) under the lsmr mode: the reference's end point of
+  `tiny_boards` within the reference's own spread, like every other fixture of test_device_lsmr_mode_*."""
+  g, rig = load_golden("tiny_boards")
+  with Handle(mirror(rig)) as h:
+    res = h.solve(g["x0"], tr_solver="lsmr")
+    e, v = h.reprojection_error(res.x)
+    assert h.lsmr_iterations() > 0
+  rms = float(np.sqrt(np.mean(e[v.astype(bool)] ** 2)))
+  ref, spread = float(g["ba_rms"]), float(np.abs(g["ba_pert_rms"] - g["ba_rms"]).max())
+  assert abs(rms - ref) <= max(1e-6, 3 * spread), (rms - ref, spread, res.nfev, int(g["ba_nfev"]))
+  assert res.nfev <= 2 * int(g["ba_nfev"]) + 5
+
+
+def load_endpoint(cfg):
+  path = os.path.join(GOLDEN, f"{cfg}_endpoint.npz")
+  if not os.path.exists(path):
+    pytest.skip(f"{path} not generated (oracle/make_endpoint.py)")
+  g = dict(np.load(path, allow_pickle=False))
+  rig = synthetic.make_rig(str(g["config"]))
+  assert tuple(g["shape"]) == rig.valid.shape and int(g["valid_count"]) == int(rig.valid.sum())
+  assert float(g["points_sum"]) == pytest.approx(float(rig.points.sum()), rel=1e-13)
+  return g, rig
+
+
+def endpoint_spread(g):
+  return float(np.abs(g["ba_pert_rms"] - g["ba_rms"]).max()) if "ba_pert_rms" in g else 0.0
+
+
+@pytest.mark.parametrize("cfg", ["cfg3", "cfg5", "cfg4"])
+def test_lsmr_mode_reproduces_the_reference_end_point_at_full_size(cfg, record_property):
+  """BASELINE configs[2] (8 x 500 x 2 rolling shutter: the rig bench.py measures), configs[4] (6 x 400 x 5 fisheye) and configs[3]
+  (16 x 1000 x 5) AT THEIR STATED SIZE: the unmodified reference's `Calibration.bundle_adjust()` end point (final RMS, nfev,
+  status, cost) is reproduced by solver = "lsmr" within max(1e-6 px, the reference's own spread under 1e-12 px perturbations);
+  the exact-step default solver's distance from that end point is reported beside it."""
+  g, rig = load_endpoint(cfg)
+  c = mirror(rig)
+  assert np.array_equal(c.param_vec, g["x0"])
+  out, res = c.bundle_adjust(solver="lsmr", return_result=True)
+  rms = calibration.error_stats(out.reprojection_error).rms
+  spread = endpoint_spread(g)
+  native, nres = c.bundle_adjust(solver="native", return_result=True)
+  rms_native = calibration.error_stats(native.reprojection_error).rms
+  record_property("lsmr_minus_reference_px", rms - float(g["ba_rms"]))
+  record_property("native_minus_reference_px", rms_native - float(g["ba_rms"]))
+  record_property("reference_spread_px", spread)
+  print(f"{cfg}: reference {float(g['ba_rms']):.9f} px (nfev {int(g['ba_nfev'])}, {float(g['ba_seconds']):.0f} s on one core), "
+        f"lsmr {rms - float(g['ba_rms']):+.2e} px in {res.solve_seconds * 1e3:.1f} ms, native {rms_native - float(g['ba_rms']):+.2e} px "
+        f"in {nres.solve_seconds * 1e3:.2f} ms, reference spread {spread:.1e}")
+  assert abs(rms - float(g["ba_rms"])) <= max(1e-6, spread), (cfg, rms - float(g["ba_rms"]), spread)
+  assert res.nfev == int(g["ba_nfev"]) and res.status == int(g["ba_status"])
+  assert res.cost == pytest.approx(float(g["ba_cost"]), rel=2e-6)
+  # the exact solver ends at or below the reference's cost (converged optimum of the same function), never above its end point
+  assert rms_native <= float(g["ba_rms"]) + max(1e-6, spread)
+
+
+@pytest.mark.parametrize("cfg", ["cfg3", "cfg5"])
+def test_workspace_calibrate_at_full_size_against_the_reference(cfg):
+  """Workspace.calibrate's outlier loop (workspace.py:228-247 -> calibration.py:254-268) at the stated size under solver="lsmr":
+  the reference's inlier mask after three rounds, bit for bit, and its inlier RMS."""
+  from multical_amd import Workspace
+  g, rig = load_endpoint(cfg)
+  if "ao_inliers_packed" not in g:
+    pytest.skip("adjust_outliers end point of the reference not generated")
+  prev = calibration.set_solver("lsmr")
+  try:
+    ao = Workspace(mirror(rig)).calibrate(cameras=rig.optimize["cameras"], camera_poses=rig.optimize["camera_poses"])
+  finally:
+    calibration.set_solver(prev)
+  ref_mask = np.unpackbits(g["ao_inliers_packed"])[:rig.valid.size].reshape(rig.valid.shape).astype(bool)
+  diff = int(np.sum(ao.inliers != ref_mask))
+  assert diff <= 2, diff        # (an observation whose error sits within rounding of the threshold may flip)
+  assert abs(ao.error_statistics(True).rms - float(g["ao_rms_inliers"])) <= max(1e-6, endpoint_spread(g))

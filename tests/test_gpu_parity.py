@@ -17,6 +17,15 @@ from util import SMALL_CASES, ALL_CASES, load_golden, mirror, oracle, golden_jac
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _exact_step_solver():
+  """This module pins the properties of the EXACT-step solver (solver = "native": converged optima, fused outlier loop, timing
+  paths) unless a test names another one; the product default is "lsmr" (tests/test_gpu_lsmr.py, test_device_lsmr_mode_*)."""
+  prev = calibration.set_solver("native")
+  yield
+  calibration.set_solver(prev)
+
+
 def rms_of(h, x):
   e, v = h.reprojection_error(x)
   return float(np.sqrt(np.mean(e[v] ** 2)))

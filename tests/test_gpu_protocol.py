@@ -32,6 +32,15 @@ from util import load_golden, mirror, oracle, rel_col_error, GOLDEN
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _exact_step_solver():
+  """This module pins the properties of the EXACT-step solver (solver = "native": converged optima, fused outlier loop, timing
+  paths) unless a test names another one; the product default is "lsmr" (tests/test_gpu_lsmr.py, test_device_lsmr_mode_*)."""
+  prev = calibration.set_solver("native")
+  yield
+  calibration.set_solver(prev)
+
 PROTOCOL_CASES = ["tiny", "tiny_rolling", "tiny_fisheye", "tiny_handeye", "tiny_rational", "tiny_thin_prism",
                   "tiny_tilted", "tiny_edge", "tiny_fixintr", "tiny_pin4", "cfg1", "tiny_softl1", "tiny_huber",
                   "tiny_boards", "tiny_bigboard", "tiny_fishmix"]
@@ -400,7 +409,7 @@ def test_device_lsmr_mode_reproduces_the_reference_end_point(name):
   assert res.cost == pytest.approx(float(g["ba_cost"]), rel=2e-6)
 
 
-@pytest.mark.parametrize("name", [n for n in PROTOCOL_CASES if n not in B_TIGHT and n != "tiny_boards"])
+@pytest.mark.parametrize("name", [n for n in PROTOCOL_CASES if n not in B_TIGHT])
 def test_device_lsmr_mode_within_the_references_own_spread(name):
   """the fixtures whose reference end point moves by 1e-5 ... 1e-3 px under 1e-12 px perturbations of its own residual
   function: the device LSMR mode lands inside that spread (like the scipy mode), never on the far side of the valley the
@@ -417,19 +426,23 @@ def test_device_lsmr_mode_within_the_references_own_spread(name):
 
 
 def test_device_lsmr_mode_through_the_dropin_and_workspace():
-  """dropin.install(mode="lsmr") and set_solver("lsmr"): the reference-shaped call chains land on the reference's END points."""
+  """dropin.install() / the default solver of the mirror (both "lsmr"): the reference-shaped call chains land on the reference's
+  END points."""
   import types
   from multical_amd import dropin, Workspace
   from test_dropin import _PlainCalibration, _as_plain
   g, rig = load_golden("cfg1")
   mod = types.SimpleNamespace(Calibration=_PlainCalibration)
   try:
-    dropin.install(calibration_module=mod, mode="lsmr")
+    dropin.install(calibration_module=mod)
+    assert _PlainCalibration.bundle_adjust is dropin.bundle_adjust is dropin.MODES["lsmr"]
     out = _as_plain(mirror(rig)).bundle_adjust()
     assert abs(calibration.error_stats(out.reprojection_error).rms - float(g["ba_rms"])) < 1e-6
   finally:
     dropin.uninstall(calibration_module=mod)
-  prev = calibration.set_solver("lsmr")
+  import os
+  assert os.environ.get("MULTICAL_AMD_SOLVER") is None
+  prev = calibration.set_solver("lsmr")     # (this module's fixture selected "native")
   try:
     ao = Workspace(mirror(rig)).calibrate(cameras=rig.optimize["cameras"], camera_poses=rig.optimize["camera_poses"])
   finally:

@@ -259,3 +259,68 @@ def test_initialise_poses_host_logic_with_the_oracle_as_the_device(name, frames,
   for k in ("camera", "board", "times"):
     assert np.array_equal(got[k].valid, want[k]["valid"]), k
     assert np.abs(got[k].poses - want[k]["poses"]).max() < 1e-9, (k, np.abs(got[k].poses - want[k]["poses"]).max())
+
+
+def test_the_default_solver_is_the_one_that_reproduces_the_reference():
+  """`dropin.install()`, MULTICAL_BACKEND=hip and the mirror's `bundle_adjust()` select "lsmr" (scipy's TRF
+  + LSMR step on the device: the reference's END POINT); the exact-step solver is the opt-in "native" mode."""
+  import inspect
+  from multical_amd import dropin
+  assert os.environ.get("MULTICAL_AMD_SOLVER") is None and calibration.get_solver() == "lsmr"
+  assert calibration.SOLVERS[0] == "lsmr" and set(calibration.SOLVERS) == {"lsmr", "native", "scipy"}
+  assert inspect.signature(dropin.install).parameters["mode"].default == "lsmr"
+  assert dropin.MODES["lsmr"] is dropin.bundle_adjust and dropin.MODES["native"] is dropin.bundle_adjust_native
+  sig = lambda f: list(inspect.signature(f).parameters)
+  assert sig(dropin.bundle_adjust) == sig(dropin.bundle_adjust_native) == sig(dropin.bundle_adjust_scipy) == \
+      ["self", "tolerance", "f_scale", "max_iterations", "loss"]          # calibration.py:199
+
+
+def test_handle_cache_forgets_the_device_mask_when_a_mutating_call_fails():
+  """mcba_reject_outliers / mcba_adjust_outliers rewrite the device inlier mask; when the call raises
+  after that, the cache may not keep believing that the device still holds the Calibration's mask."""
+  g, rig = load_golden("tiny")
+  c = mirror(rig)
+  uploads = []
+
+  class FakeHandle(object):
+    h = 1
+    problem = None
+
+    def set_inliers(self, mask):
+      uploads.append(None if mask is None else mask.copy())
+
+    def reject_outliers(self, x, threshold):
+      raise RuntimeError("device failure after the mask was rewritten")
+
+    def adjust_outliers(self, *a, **k):
+      raise RuntimeError("solver failure after a rejection")
+
+    def set_log(self, fn):
+      pass
+
+    def close(self):
+      pass
+
+  cache = calibration.handle_cache
+  cache.clear()
+  prob = lower(c)
+  c._mcba_problem = prob
+  fake = FakeHandle()
+  fake.problem = prob
+  real_handle = calibration.Handle
+  calibration.Handle = lambda prob_: fake
+  try:
+    assert c._handle() is fake and uploads == []
+    with pytest.raises(RuntimeError, match="mask was rewritten"):
+      c.reject_outliers(1.0)
+    assert c._handle() is fake and len(uploads) == 1 and uploads[0] is None      # re-synchronised: inlier_mask is None here
+    masked = c.copy(inlier_mask=c.valid.copy())
+    masked._mcba_problem = lower(masked)
+    assert masked._handle() is fake and len(uploads) == 2
+    with pytest.raises(RuntimeError, match="after a rejection"):
+      masked.adjust_outliers(num_adjustments=1, select_outliers=calibration.select_threshold(0.75, 5.0))
+    assert masked._handle() is fake and len(uploads) == 3 and np.array_equal(uploads[2], masked.inlier_mask)
+    assert masked._handle() is fake and len(uploads) == 3                      # ... and the token is valid again afterwards
+  finally:
+    calibration.Handle = real_handle
+    cache.entries = []
