@@ -115,6 +115,8 @@ SYMBOLS = [
   ("mcba_debug_linearize_profile", C.c_int32, [H, c_double_p, C.POINTER(C.c_longlong)]),
   ("mcba_debug_lsmr_products", C.c_int32, [H, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]),
   ("mcba_debug_lsmr_info", C.c_int32, [H, C.POINTER(C.c_int64)]),
+  ("mcba_debug_set_lsmr_fused", C.c_int32, [H, C.c_int32]),
+  ("mcba_debug_set_switch", C.c_int32, [C.c_char_p, C.c_char_p]),
 ]
 
 _lib = None
@@ -141,6 +143,14 @@ def load():
     fn.argtypes = argtypes
   _lib = lib
   return lib
+
+
+def set_switch(name, value):
+  """Experiment / path-forcing switch of the library (mcba_debug_set_switch): tests and profiling scripts only; process-wide, before
+  the first Handle.  The product library does not read these from the environment."""
+  rc = load().mcba_debug_set_switch(name.encode(), str(value).encode())
+  if rc != 0:
+    raise RuntimeError(load().mcba_last_error().decode("utf-8", "replace"))
 
 
 class McbaError(RuntimeError):

@@ -506,6 +506,10 @@ class Handle(object):
     check(self.lib.mcba_debug_lsmr_products(self.h, _ptr(x, C.c_double), pv, pu, pjv, pjtu))
     return jv, jtu
 
+  def set_lsmr_fused(self, on):
+    """A/B switch of the LSMR iteration: True (default) = three launches (k_lsmr_fused), False = the six-launch form."""
+    check(self.lib.mcba_debug_set_lsmr_fused(self.h, 1 if on else 0))
+
   def lsmr_iterations(self):
     """LSMR iterations of the last `solve(tr_solver='lsmr')` on this handle."""
     n = C.c_int64()

@@ -24,7 +24,9 @@ SOURCES = ["mcba_api.hip", "mcba_cam_pin4.hip", "mcba_cam_pin5.hip", "mcba_cam_p
            "mcba_cam_pin14.hip", "mcba_cam_fish4.hip", "mcba_cam_mix14.hip"]
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "mcba.h")]
 FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-Wall", "-Wno-unused-function"] + \
-        os.environ.get("MCBA_EXTRA_FLAGS", "").split()
+        (["-DMCBA_ENV_SWITCHES=1"] if VARIANT else []) + os.environ.get("MCBA_EXTRA_FLAGS", "").split()
+# (-DMCBA_ENV_SWITCHES: only VARIANT builds read the MCBA_* experiment switches from the environment; the product library takes
+#  them through mcba_debug_set_switch alone -- csrc/mcba_api.hip: dbg_switch)
 
 
 def hipcc():

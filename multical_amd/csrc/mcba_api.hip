@@ -56,6 +56,31 @@ struct Error : std::runtime_error {
 
 thread_local hipStream_t g_fill_stream = nullptr;   // stream of the running API call (see DevBuf::alloc)
 
+// Experiment / path-forcing switches (A/B variants of kernels, forcing the code paths of very large rigs on small fixtures,
+// solver traces).  The PRODUCT library does not read them from the environment: it behaves the same in every process.  Tests
+// and the profiling scripts set them through mcba_debug_set_switch (mcba_debug.h) BEFORE the first handle is created (most are
+// latched on first use); a library built with -DMCBA_ENV_SWITCHES (python -m multical_amd.build with MCBA_BUILD_VARIANT set)
+// reads the environment as well.  Environment variables the product does honour: MCBA_NO_MFMA (validation accumulate),
+// MCBA_CACHE_MB (parked device memory), MCBA_TIMING (host-phase timing lines), and MCBA_NO_NATIVE_RCCL on the Python side.
+static std::map<std::string, std::string>& dbg_switch_table() {
+  static std::map<std::string, std::string> t;
+  return t;
+}
+static std::mutex g_dbg_switch_mutex;
+static const char* dbg_switch(const char* name) {
+  {
+    std::lock_guard<std::mutex> lock(g_dbg_switch_mutex);
+    auto& t = dbg_switch_table();
+    auto it = t.find(name);
+    if (it != t.end()) return it->second.c_str();   // (entries are never erased: the pointer stays valid)
+  }
+#if defined(MCBA_ENV_SWITCHES)
+  return getenv(name);
+#else
+  return nullptr;
+#endif
+}
+
 // hipFuncAttributeMaxDynamicSharedMemorySize belongs to the (function, device) pair, not to a handle: keep a process-wide
 // high-water mark per pair and only ever RAISE it, so that a second live handle with a smaller requirement cannot lower the
 // limit under the first one (two handles stay alive in the Python-side cache).
@@ -288,7 +313,8 @@ struct mcba_handle_s {
   bool shard_root = true;
   DevBuf<double> comm;   // frame-sharded handles: [g_s | diag_s | cost, count | step norms] of the linearisation's message
   // solver "lsmr": m-vectors u (bidiagonalisation), J_h g_h, J_h gn; per-view partials of J_h^T u; n-vectors v, v_raw, h, hbar, x
-  DevBuf<double> ls_u, ls_ua, ls_ub, ls_part, ls_v, ls_vraw, ls_h, ls_hbar, ls_x, ls_nrm, ls_partial, ls_out, ls_bpart, ls_comm;
+  DevBuf<double> ls_u, ls_ua, ls_ub, ls_part, ls_v, ls_vraw, ls_h, ls_hbar, ls_x, ls_nrm, ls_partial, ls_out, ls_bpart, ls_comm, ls_xpart;
+  bool lsmr_fused = true;                 // LSMR iteration in three launches (k_lsmr_fused); false: the six-launch form of round 4 (A/B, tests)
   ScalLayout sl;
   DevBuf<double> chol_linv;   // inverted diagonal tiles of the panel kernels (k_cholp_back)
   int lin_grid = 0;          // 0 = automatic (see lin2), > 0 = forced number of persistent workgroups (debug)
@@ -558,7 +584,7 @@ void check_launch(const char* what) {
 
 // MCBA_FUSED=0 forces the table form (k_tmat + k_linearize); default: the table-fed fused form wherever it applies
 bool linearize_table_form() {
-  static const bool table = getenv("MCBA_FUSED") != nullptr && atoi(getenv("MCBA_FUSED")) == 0;
+  static const bool table = dbg_switch("MCBA_FUSED") != nullptr && atoi(dbg_switch("MCBA_FUSED")) == 0;
   return table;
 }
 
@@ -586,7 +612,7 @@ void launch_linearize(mcba_handle_s* h, const double* dx) {
   }
   const int nb_views = std::max((d.views() + TMV - 1) / TMV, 1);
   // (MCBA_TMAT_GLOBAL=1 forces the path of rigs too large for the workgroup-local pose table: tests)
-  static const bool force_global = getenv("MCBA_TMAT_GLOBAL") != nullptr && getenv("MCBA_TMAT_GLOBAL")[0] == '1';
+  static const bool force_global = dbg_switch("MCBA_TMAT_GLOBAL") != nullptr && dbg_switch("MCBA_TMAT_GLOBAL")[0] == '1';
   const bool local = tmat_local_poses(d) <= TM_LOCAL_POSES && !force_global;
   if (dx != nullptr && !local) {   // unusual shape (cameras + boards exceed the workgroup-local pose table): separate table pass
     eval_pose_tables(h, dx);
@@ -618,7 +644,7 @@ void launch_assemble(mcba_handle_s* h, unsigned long long publish_seq = 0, int c
   // frame blocks stage the record entries they sum in LDS, `gviews` records at a time (all C B views of the frame when they
   // fit the budget: 43.8 KB at the north-star rig)
   // (clamped to what a workgroup may ask for by default: 64 KB of dynamic LDS minus the kernel's static tables)
-  static const int stage_kb = getenv("MCBA_ASM_STAGE_KB") ? std::min(60, std::max(4, atoi(getenv("MCBA_ASM_STAGE_KB")))) : 44;
+  static const int stage_kb = dbg_switch("MCBA_ASM_STAGE_KB") ? std::min(60, std::max(4, atoi(dbg_switch("MCBA_ASM_STAGE_KB")))) : 44;
   const int ne = frame_entries(d), cb = d.C * d.B;
   // staging slots: as many non-empty views of a frame as the budget holds (all C B when they fit); a frame with more active
   // views than slots takes several passes
@@ -636,7 +662,7 @@ void launch_assemble(mcba_handle_s* h, unsigned long long publish_seq = 0, int c
   {
     const int npair = d.C * d.B, pg = std::min(npair, 16);
     // MCBA_SHARED_FINAL_BIG=1 forces the many-pairs kernel (tests)
-    static const bool force_big = getenv("MCBA_SHARED_FINAL_BIG") != nullptr && getenv("MCBA_SHARED_FINAL_BIG")[0] == '1';
+    static const bool force_big = dbg_switch("MCBA_SHARED_FINAL_BIG") != nullptr && dbg_switch("MCBA_SHARED_FINAL_BIG")[0] == '1';
     if (npair <= SHARED_FINAL_MAX_PAIRS && !force_big)   // pair sums in LDS
       hipLaunchKernelGGL(k_shared_final, dim3((d.rec_size + 2 + 63) / 64), dim3(64 * pg), (size_t)npair * 64 * sizeof(double),
                          h->stream, d, h->partial.p, h->nchunk, h->tri.p, h->Hss.p, h->g(), h->diag(), h->costcount(),
@@ -816,7 +842,7 @@ struct TrRegPartials { const double* vs; int nvb; const double* q; int nq; int f
 // (reduced systems of nine tile columns or more: below that the blocks are mostly padding -- 6.9 against 4.5 us at 4 x 200 x 1;
 //  MCBA_SYRK3=1 forces it for every size)
 static bool syrk3_enabled(const mcba_handle_s* h) {
-  static const char* env = getenv("MCBA_SYRK3");
+  static const char* env = dbg_switch("MCBA_SYRK3");
   if (env != nullptr && env[0] == '0') return false;
   return h->use_mfma && (h->ntile >= 9 || (env != nullptr && env[0] == '1'));
 }
@@ -1154,7 +1180,7 @@ int32_t mcba_create(const mcba_problem* p, void* hip_stream, mcba_handle* out) {
   // chunk sums of the shared part: about 512 (pair, chunk) workgroups in k_assemble; k_shared_final reads C B nchunk
   // partial records per entry, so many pairs get fewer chunks
   {
-    const char* e = getenv("MCBA_NCHUNK_TARGET");   // tuning knob: (pair, chunk) workgroups aimed at
+    const char* e = dbg_switch("MCBA_NCHUNK_TARGET");   // tuning knob: (pair, chunk) workgroups aimed at
     const int target = e ? std::max(1, atoi(e)) : 256;   // measured at cfg3: 256 -> 114.4 us / step, 512 -> 113.1, 1024 -> 119.3
     h->nchunk = std::max(1, std::min(std::min(64, (d.Fl + 7) / 8), std::max(4, target / std::max(1, d.C * d.B))));
   }
@@ -1183,7 +1209,7 @@ int32_t mcba_create(const mcba_problem* p, void* hip_stream, mcba_handle* out) {
     } else {
       while (ks < 64 && nt2 * ks < 1024 && K / (ks * 2) >= 32) ks *= 2;
     }
-    if (const char* e = getenv("MCBA_KSPLIT")) ks = std::max(1, std::min(64, atoi(e)));   // (experiments)
+    if (const char* e = dbg_switch("MCBA_KSPLIT")) ks = std::max(1, std::min(64, atoi(e)));   // (experiments)
     h->ksplit = ks;
     h->P.alloc((size_t)ks * nt2 * 256);
   }
@@ -1634,7 +1660,7 @@ void align_poses(int32_t n_problems, const int64_t* offsets, const double* A, in
   sc.parent = sc.rep_b + np_ * per;
   sc.list = sc.parent + np_ * per;
   sc.live = sc.list + np_ * per;
-  static const bool align_prof = getenv("MCBA_ALIGN_PROF") != nullptr;
+  static const bool align_prof = dbg_switch("MCBA_ALIGN_PROF") != nullptr;
   sc.prof = nullptr;
   if (align_prof) {
     d_prof.alloc(np_ * 32);
@@ -1649,7 +1675,7 @@ void align_poses(int32_t n_problems, const int64_t* offsets, const double* A, in
   // (a per-DEVICE attribute: set on every call, it costs nothing next to the copies)
   HIP_OK(hipFuncSetAttribute((const void*)k_align_robust, hipFuncAttributeMaxDynamicSharedMemorySize, (int)align_lds_bytes(ALIGN_LDS_CAP)));
   const double t1 = now_seconds();
-  static const bool no_staged = getenv("MCBA_ALIGN_MONOLITHIC") != nullptr;
+  static const bool no_staged = dbg_switch("MCBA_ALIGN_MONOLITHIC") != nullptr;
   // (the partial winners of the split scans take 24 B x ALIGN_SCAN_Z per entry and problem: batches beyond 4 M entries x problems
   //  -- 1.6 GB of them -- stay with the one-workgroup kernel)
   if (nmax > ALIGN_STAGED_MIN && n_problems <= 4096 && (size_t)n_problems * (size_t)nmax <= ((size_t)1 << 22) && !align_prof &&
@@ -2011,8 +2037,8 @@ int32_t mcba_debug_pipe_probe(int32_t iters, double* ms_out) {
   HIP_OK(hipEventCreate(&e0));
   HIP_OK(hipEventCreate(&e1));
   // (MCBA_PROBE_THREADS / MCBA_PROBE_BLOCKS: other occupancies, e.g. 256 threads = one wavefront per SIMD)
-  const int thr = getenv("MCBA_PROBE_THREADS") ? atoi(getenv("MCBA_PROBE_THREADS")) : 512;
-  const int blk = getenv("MCBA_PROBE_BLOCKS") ? atoi(getenv("MCBA_PROBE_BLOCKS")) : 256;
+  const int thr = dbg_switch("MCBA_PROBE_THREADS") ? atoi(dbg_switch("MCBA_PROBE_THREADS")) : 512;
+  const int blk = dbg_switch("MCBA_PROBE_BLOCKS") ? atoi(dbg_switch("MCBA_PROBE_BLOCKS")) : 256;
   REQUIRE(thr >= 64 && thr <= 512 && thr % 64 == 0 && blk > 0, "bad probe shape");
   for (int mode = 0; mode < 3; ++mode) {
     hipLaunchKernelGGL(k_pipe_probe, dim3(blk), dim3(thr), 0, 0, mode, 16, sink.p);   // warm-up
@@ -2035,7 +2061,8 @@ struct LsmrOps {
   mcba_handle_s* h;
   int nblk;            // persistent single-wave workgroups of the two Jacobian products
   int part_stride;
-  size_t m;
+  size_t m;            // residuals of THIS handle (its frame shard)
+  size_t m_global = 0; // residuals of the whole problem (frame-sharded: summed over the ranks): scipy's maxiter = min(m, n)
   bool sharded() const { return h->allreduce != nullptr; }
   double* bpart() const { return h->d.off_boards >= 0 ? h->ls_bpart.p : nullptr; }   // boards=True: jp^T u per observation
   LsmrGatherExtra extra() const { return LsmrGatherExtra{h->obs_index.p, h->board_off.p, bpart(), sharded() ? 1 : 0}; }
@@ -2114,6 +2141,42 @@ struct LsmrOps {
     hipLaunchKernelGGL(k_lsmr_update, dim3(nvb), dim3(256), 0, h->stream, d.n, 1.0, 0.0, 0.0, 0.0, vraw, h->ls_hbar.p, h->ls_x.p,
                        h->ls_h.p, h->ls_nrm.p, (const double*)ls);
   }
+  // Round 5: the same iteration in THREE launches -- k_lsmr_fused (both products from one evaluation of the analytic rows),
+  // k_lsmr_gather2 (+ beta, stopping tests), k_lsmr_update2 (+ alpha, rotations); state double-buffered A -> B -> A
+  // (mcba_solver_kernels.h).  Frame-sharded: the same three collectives as above between them.
+  void iteration_fused(double* lsA, double* lsB, double* u, double* v, double* vraw, unsigned long long call) {
+    const Dims& d = h->d;
+    const int nvb = (d.n + LSG_THREADS - 1) / LSG_THREADS;
+    h->ops->lsmr_fused(d, h->t, h->stream, h->view_first.p, h->dsc.p, v, u, h->ls_partial.p, h->ls_part.p, part_stride, bpart(), nblk, lsA);
+    const double* upart = h->ls_partial.p;
+    const double* xpart = h->ls_xpart.p;
+    int nu = nblk, nx = nvb;
+    if (sharded()) {
+      double* two = h->ls_out.p + 4;
+      hipLaunchKernelGGL(k_lsmr_shard_fold_a2, dim3(1), dim3(LSG_THREADS), 0, h->stream, upart, nu, xpart, nx, two);
+      call_allreduce(h, two, 2, 0);
+      upart = two; nu = 1; xpart = two + 1; nx = 1;
+    }
+    hipLaunchKernelGGL(k_lsmr_gather2, dim3((gather_grid() + LSG_THREADS / 64 - 1) / (LSG_THREADS / 64)), dim3(LSG_THREADS), 0, h->stream, d,
+                       (const double*)h->ls_part.p, part_stride, (const double*)h->dsc.p, (const double*)v, vraw, h->ls_nrm.p,
+                       (const double*)lsA, lsB, upart, nu, xpart, nx, call, h->h_pub_seq + 1, extra());
+    const double* vpart = h->ls_nrm.p;
+    int nv = d.n;
+    if (sharded()) {
+      const int ns = std::max(d.ns, 1);
+      if (h->ls_comm.n < (size_t)ns) h->ls_comm.alloc((size_t)ns, true);
+      hipLaunchKernelGGL(k_lsmr_shard_pack, dim3((ns + 255) / 256), dim3(256), 0, h->stream, d, (const double*)vraw, h->ls_comm.p);
+      call_allreduce(h, h->ls_comm.p, (size_t)d.ns, 0);
+      hipLaunchKernelGGL(k_lsmr_shard_finish, dim3((d.n + 255) / 256), dim3(256), 0, h->stream, d, (const double*)h->ls_comm.p,
+                         (const double*)h->dsc.p, 0.0, (const double*)v, vraw, h->ls_nrm.p, (const double*)lsB, 1);
+      double* one = h->ls_out.p + 6;
+      hipLaunchKernelGGL(k_dot, dim3(1), dim3(1024), 0, h->stream, (size_t)d.n, (const double*)h->ls_nrm.p, (const double*)nullptr, one, 0);
+      call_allreduce(h, one, 1, 0);
+      vpart = one; nv = 1;
+    }
+    hipLaunchKernelGGL(k_lsmr_update2, dim3(nvb), dim3(LSG_THREADS), 0, h->stream, d, (const double*)lsB, lsA, vpart, nv, vraw, h->ls_hbar.p,
+                       h->ls_x.p, h->ls_h.p, h->ls_xpart.p);
+  }
 };
 
 // scipy.sparse.linalg.lsmr(J_h, f, damp, atol = btol = 1e-6, conlim = 1e8, maxiter = min(m, n)) -- the call of trf.py:481 --
@@ -2123,7 +2186,7 @@ int lsmr_solve(LsmrOps& op, double damp, int* istop_out) {
   mcba_handle_s* h = op.h;
   const Dims& d = h->d;
   const int n = d.n;
-  const long long maxiter = std::min<long long>((long long)op.m, (long long)(h->ext2int.empty() ? n : h->n_ext));
+  const long long maxiter = std::min<long long>((long long)(op.m_global ? op.m_global : op.m), (long long)(h->ext2int.empty() ? n : h->n_ext));
   const int nvb = (n + 255) / 256;
   double* u = h->ls_u.p;
   double* v = h->ls_v.p;
@@ -2148,7 +2211,8 @@ int lsmr_solve(LsmrOps& op, double damp, int* istop_out) {
   // ahead of the progress word that k_lsmr_scal_a writes to pinned memory, until that word reports a stopping reason.  (The
   // first version fetched beta, alpha and |x| to the host in every iteration: three synchronisations of ~75 us.)  Kernels
   // enqueued behind the stop are empty launches; the call id in the word tells them from those of the next solve.
-  if (h->ls_state.n < (size_t)LS_NSLOTS) h->ls_state.alloc(LS_NSLOTS, true);
+  if (h->ls_state.n < (size_t)2 * LS_NSLOTS) h->ls_state.alloc((size_t)2 * LS_NSLOTS, true);   // [A | B] (fused iteration)
+  if (h->ls_xpart.n < (size_t)nvb + 1) h->ls_xpart.alloc((size_t)nvb + 1, true);
   double* ls = h->ls_state.p;
   const unsigned long long call = (++h->ls_call) & 0xffffffull;
   hipLaunchKernelGGL(k_lsmr_init, dim3(1), dim3(64), 0, h->stream, ls, alpha, beta, damp, normb, (double)maxiter);
@@ -2175,7 +2239,8 @@ int lsmr_solve(LsmrOps& op, double damp, int* istop_out) {
     const bool may_enqueue = lockstep ? (enqueued == 0 || ((seen >> 40) == call && done == enqueued - 1))
                                       : (enqueued - done < LOOKAHEAD);
     if (may_enqueue && enqueued <= maxiter) {   // (iteration maxiter + 1 carries the tests of iteration maxiter)
-      op.iteration(ls, u, v, vraw, call);
+      if (h->lsmr_fused) op.iteration_fused(ls, ls + LS_NSLOTS, u, v, vraw, call);
+      else op.iteration(ls, u, v, vraw, call);
       std::swap(v, vraw);
       ++enqueued;
       if ((enqueued & 15) == 0) check_launch("lsmr iteration");
@@ -2298,6 +2363,9 @@ static void solve_lsmr(mcba_handle h, double* x_inout, const mcba_options* opt, 
       cost = S[TR_COST];
       initial_cost = cost;
       if (!std::isfinite(cost)) throw Error("Residuals are not finite in the initial point.");   // scipy least_squares.py:844-845
+      // (frame-sharded: the observation count of the linearisation is all-reduced with the cost -- the SAME maxiter on every rank,
+      //  whatever its own shard holds; an empty shard must not stop enqueuing iterations and their collectives early)
+      op.m_global = h->allreduce ? 2 * (size_t)std::llround(S[TR_COUNT]) : m;
       Delta = std::sqrt(xs);
       if (Delta == 0) Delta = 1.0;
       first = false;
@@ -2312,7 +2380,7 @@ static void solve_lsmr(mcba_handle h, double* x_inout, const mcba_options* opt, 
     int istop = 0;
     const int itn = lsmr_solve(op, std::sqrt(reg_term), &istop);
     lsmr_iterations += itn;
-    if (getenv("MCBA_SOLVE_TRACE") != nullptr)
+    if (dbg_switch("MCBA_SOLVE_TRACE") != nullptr)
       fprintf(stderr, "[mcba_solve lsmr] iteration %d: Delta %.17g reg_term %.17g -> lsmr itn %d istop %d\n", iteration, Delta, reg_term,
               itn, istop);
     HIP_OK(hipMemcpyAsync(h->gn.p, h->ls_x.p, (size_t)d.n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
@@ -2385,7 +2453,7 @@ static void solve_lsmr(mcba_handle h, double* x_inout, const mcba_options* opt, 
     ++iteration;
   }
   if (status == -100) status = 0;
-  if (getenv("MCBA_SOLVE_TRACE") != nullptr)
+  if (dbg_switch("MCBA_SOLVE_TRACE") != nullptr)
     fprintf(stderr, "[mcba_solve lsmr] %d trial steps, %lld LSMR iterations, %.3f ms\n", nfev - 1, lsmr_iterations,
             (now_seconds() - t_start) * 1e3);
   gather_frame_entries(h, h->x.p);   // (frame-sharded: every rank returns the complete x; ONE n_motion message per solve)
@@ -2455,6 +2523,26 @@ int32_t mcba_debug_lsmr_products(mcba_handle h, const double* x, const double* v
   API_END
 }
 
+/* experiment / path-forcing switch `name` = `value` (see dbg_switch); value == NULL removes nothing -- set "" to override an
+ * environment value of a variant build.  Process-wide; call before the first mcba_create.                                  */
+int32_t mcba_debug_set_switch(const char* name, const char* value) {
+  API_BEGIN
+  REQUIRE(name && value && strncmp(name, "MCBA_", 5) == 0, "bad switch");
+  std::lock_guard<std::mutex> lock(g_dbg_switch_mutex);
+  auto& t = dbg_switch_table();
+  if (t.find(name) == t.end()) t[name] = value;
+  else REQUIRE(t[name] == value, "a switch can be set once per process (most are latched on first use)");
+  API_END
+}
+
+/* 1 (default): the three-launch LSMR iteration (k_lsmr_fused / k_lsmr_gather2 / k_lsmr_update2); 0: the six-launch form (A/B) */
+int32_t mcba_debug_set_lsmr_fused(mcba_handle h, int32_t on) {
+  API_BEGIN
+  REQUIRE(h, "null handle");
+  h->lsmr_fused = on != 0;
+  API_END
+}
+
 /* LSMR iterations of the last solve with tr_solver = MCBA_TR_LSMR on this handle */
 int32_t mcba_debug_lsmr_info(mcba_handle h, int64_t* lsmr_iterations) {
   API_BEGIN
@@ -2488,7 +2576,7 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
   // same algebra (mcba_trmath.h) only for the retries after a rejected step.
   double* S = h->h_scal;   // host copy of the scalar block scal[0 .. TR_NSLOTS)
 
-  static const bool trace = getenv("MCBA_SOLVE_TRACE") != nullptr;   // host wall clock of the driver's stages (stderr)
+  static const bool trace = dbg_switch("MCBA_SOLVE_TRACE") != nullptr;   // host wall clock of the driver's stages (stderr)
   auto mark = [&](const char* what) {
     if (trace) fprintf(stderr, "[mcba_solve] %8.3f ms  %s\n", (now_seconds() - t_start) * 1e3, what);
   };
@@ -2545,9 +2633,9 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
                          h->scal.p + sl.step, sl.nvb);
     }
   };
-  static const bool merge_off = getenv("MCBA_NO_MERGED_TRIAL_COST") != nullptr && getenv("MCBA_NO_MERGED_TRIAL_COST")[0] == '1';
+  static const bool merge_off = dbg_switch("MCBA_NO_MERGED_TRIAL_COST") != nullptr && dbg_switch("MCBA_NO_MERGED_TRIAL_COST")[0] == '1';
   // (MCBA_FORCE_MERGED_TRIAL_COST=1: experiment -- a single GPU takes the trial cost from the speculative linearisation as well)
-  static const bool merge_force = getenv("MCBA_FORCE_MERGED_TRIAL_COST") != nullptr && getenv("MCBA_FORCE_MERGED_TRIAL_COST")[0] == '1';
+  static const bool merge_force = dbg_switch("MCBA_FORCE_MERGED_TRIAL_COST") != nullptr && dbg_switch("MCBA_FORCE_MERGED_TRIAL_COST")[0] == '1';
   const bool merged_trial_cost = (h->allreduce != nullptr || merge_force) && !merge_off;
   auto fold_trial = [&](double* step_h2, double* step2, double* x2, int n_cost) {   // after a fetch that covers [sl.step, ...)
     double s3[3] = {0, 0, 0};
@@ -2570,8 +2658,8 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
   // form: k_linearize is not slowed by a concurrent k_cost (58 -> 49 us), no event packet between k_vec_step and
   // k_linearize (7 us), no copy.  MCBA_SPEC_ACCEPT=0 restores the side-stream form.
   // (blocks of the curvature sums: every k_schur_frame workgroup folds their partials -- MCBA_Q00_BLOCKS for experiments)
-  static const int q00_blocks = getenv("MCBA_Q00_BLOCKS") ? std::max(1, std::min(Q00_BLOCKS, atoi(getenv("MCBA_Q00_BLOCKS")))) : Q00_BLOCKS;
-  static const bool spec_accept_off = getenv("MCBA_SPEC_ACCEPT") != nullptr && getenv("MCBA_SPEC_ACCEPT")[0] == '0';
+  static const int q00_blocks = dbg_switch("MCBA_Q00_BLOCKS") ? std::max(1, std::min(Q00_BLOCKS, atoi(dbg_switch("MCBA_Q00_BLOCKS")))) : Q00_BLOCKS;
+  static const bool spec_accept_off = dbg_switch("MCBA_SPEC_ACCEPT") != nullptr && dbg_switch("MCBA_SPEC_ACCEPT")[0] == '0';
   // (k_fold_tr behind the speculative scaling: measured neutral against letting every k_schur_frame workgroup fold the
   //  72 + 512 partials itself -- 135.3 vs 136.1 us per trial step at the north-star rig, round 4 -- kept)
   bool scaled_ahead = false;     // the scaling / curvature of h->x are already in place (computed speculatively, swapped in)
@@ -2588,7 +2676,7 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
     bool spec_lin = false, spec_scaled = false;
     // ---- enqueue: gradient scaling, Cauchy curvature (+ on a single GPU the whole step and its trial evaluation) ----
     // k_vec_scale also forwards {cost, count} of the linearisation into scal[TR_COST, TR_COUNT]
-    static const bool split_q00 = getenv("MCBA_SPLIT_Q00") != nullptr && getenv("MCBA_SPLIT_Q00")[0] == '1';
+    static const bool split_q00 = dbg_switch("MCBA_SPLIT_Q00") != nullptr && dbg_switch("MCBA_SPLIT_Q00")[0] == '1';
     const bool scaled = scaled_ahead;   // (k_vec_scale's partials of this very point are in scal[sl.vs ..) already)
     scaled_ahead = false;
     if (scaled) {
@@ -2630,9 +2718,9 @@ int32_t mcba_solve(mcba_handle h, double* x_inout, const mcba_options* opt, mcba
       // that the tail of k_vec_step wrote, so k_cost + the scalar copy go to a side stream and run BESIDE k_linearize (13 us
       // of every iteration's critical path at the north-star rig); the host still decides on the trial cost alone.
       const bool spec_tables_ready = !linearize_table_form() && d.off_boards < 0 && h->use_mfma;
-      static const bool side_off = getenv("MCBA_NO_SIDE_COST") != nullptr && getenv("MCBA_NO_SIDE_COST")[0] == '1';
+      static const bool side_off = dbg_switch("MCBA_NO_SIDE_COST") != nullptr && dbg_switch("MCBA_NO_SIDE_COST")[0] == '1';
       const bool side_cost = !h->allreduce && spec_tables_ready && !side_off && !merged_trial_cost;
-      static const bool publish = !(getenv("MCBA_NO_PUBLISH") != nullptr && getenv("MCBA_NO_PUBLISH")[0] == '1');
+      static const bool publish = !(dbg_switch("MCBA_NO_PUBLISH") != nullptr && dbg_switch("MCBA_NO_PUBLISH")[0] == '1');
       const bool spec_accept = side_cost && !spec_accept_off;
       if (spec_accept) {   // (see the declaration of scaled_ahead)
         enqueue_trial(0.0, 0.0, h->scal.p, false, true);

@@ -143,7 +143,28 @@ void lsmr_jtu(const Dims& d, const Tables& t, hipStream_t s, const int32_t* firs
   else jtu1<MOTION_HAND_EYE>(d, t, s, first, inv_beta, u, part, part_stride, bpart, nblk, ls);
 }
 
-const CamOps OPS = {residual, project_model, cost, jacobian, linearize, points, lsmr_jv, lsmr_jtu};
+template <int MOTION, bool OPTK>
+void fus2(const Dims& d, const Tables& t, hipStream_t s, const int32_t* first, const double* dscale, const double* v, double* u,
+          double* partial, double* part, int part_stride, double* bpart, int nblk, const double* ls) {
+  if (d.loss != 0)
+    hipLaunchKernelGGL((k_lsmr_fused<ND_, FISH_, MOTION, OPTK, true>), dim3(nblk), dim3(64), 0, s, d, t, first, dscale, v, u, partial, part, part_stride, bpart, ls);
+  else
+    hipLaunchKernelGGL((k_lsmr_fused<ND_, FISH_, MOTION, OPTK, false>), dim3(nblk), dim3(64), 0, s, d, t, first, dscale, v, u, partial, part, part_stride, bpart, ls);
+}
+template <int MOTION>
+void fus1(const Dims& d, const Tables& t, hipStream_t s, const int32_t* first, const double* dscale, const double* v, double* u,
+          double* partial, double* part, int part_stride, double* bpart, int nblk, const double* ls) {
+  if (d.KI > 0) fus2<MOTION, true>(d, t, s, first, dscale, v, u, partial, part, part_stride, bpart, nblk, ls);
+  else fus2<MOTION, false>(d, t, s, first, dscale, v, u, partial, part, part_stride, bpart, nblk, ls);
+}
+void lsmr_fused(const Dims& d, const Tables& t, hipStream_t s, const int32_t* first, const double* dscale, const double* v, double* u,
+                double* partial, double* part, int part_stride, double* bpart, int nblk, const double* ls) {
+  if (d.motion == MOTION_STATIC) fus1<MOTION_STATIC>(d, t, s, first, dscale, v, u, partial, part, part_stride, bpart, nblk, ls);
+  else if (d.motion == MOTION_ROLLING) fus1<MOTION_ROLLING>(d, t, s, first, dscale, v, u, partial, part, part_stride, bpart, nblk, ls);
+  else fus1<MOTION_HAND_EYE>(d, t, s, first, dscale, v, u, partial, part, part_stride, bpart, nblk, ls);
+}
+
+const CamOps OPS = {residual, project_model, cost, jacobian, linearize, points, lsmr_jv, lsmr_jtu, lsmr_fused};
 
 }  // namespace
 

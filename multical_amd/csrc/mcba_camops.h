@@ -27,6 +27,9 @@ struct CamOps {
   // bpart != nullptr (boards=True): + jp^T u of every observation, 3 doubles in the residual order (k_lsmr_gather sums them per point)
   void (*lsmr_jtu)(const Dims&, const Tables&, hipStream_t, const int32_t* first, double inv_beta, double* u, double* part,
                    int part_stride, double* bpart, int nblk, const double* ls);
+  // both products of an LSMR iteration in one pass (k_lsmr_fused): uhat <- J_h v - alpha uhat_old / beta_old, per-view J_h^T uhat
+  void (*lsmr_fused)(const Dims&, const Tables&, hipStream_t, const int32_t* first, const double* dscale, const double* v, double* u,
+                     double* partial, double* part, int part_stride, double* bpart, int nblk, const double* ls);
 };
 
 const CamOps* cam_ops_pin4();

@@ -38,6 +38,11 @@ int32_t mcba_debug_mfma_probe(const double* V, double* out);
  * loss: jv_out[m] = J(x) v (reference residual order), jtu_out[n] = J(x)^T u; either pair may be NULL (tests compare them with
  * mcba_jacobian)                                                                                                      */
 int32_t mcba_debug_lsmr_products(mcba_handle h, const double* x, const double* v, const double* u, double* jv_out, double* jtu_out);
+/* experiment / path-forcing switches (formerly MCBA_* environment variables: the product library no longer reads those, a
+ * MCBA_BUILD_VARIANT build does): process-wide, once per name, before the first mcba_create                               */
+int32_t mcba_debug_set_switch(const char* name, const char* value);
+/* 1 (default): three-launch LSMR iteration (both Jacobian products from one evaluation of the rows); 0: the six-launch form  */
+int32_t mcba_debug_set_lsmr_fused(mcba_handle h, int32_t on);
 /* LSMR iterations taken by the last mcba_solve with tr_solver = MCBA_TR_LSMR on this handle                           */
 int32_t mcba_debug_lsmr_info(mcba_handle h, int64_t* lsmr_iterations);
 

@@ -117,6 +117,56 @@ __device__ __forceinline__ double block_reduce(double v, double* scratch /*[16]*
   return r;
 }
 
+// N per-lane partial sums -> N wave totals in ~N/2 + N/4 + N/8 .. lane exchanges instead of 6 N (wave_sum per value): a butterfly
+// that halves the number of live registers while it halves the lanes left to add.  fold32 / fold16 pair the values up over
+// the lane halves / the 16-lane rows, the remaining four steps (lane distance 8, 4, 2, 1) pair the registers with a select +
+// __shfl_xor until one is left.  Lane L then holds the total of value
+//     many_index(L) = b5 + 2 b4 + 4 b3 + 8 b2 + 16 b1        (b_k = bit k of L)
+// provided many_writer<N>(L): the lane bits that took part in no register pairing are zero (those lanes hold copies).
+// (index map verified by symbolic simulation of exactly these steps: profiles/scripts/sim_wave_reduce_many.py)
+template <int NREG, int S>
+struct ManyStep {
+  static __device__ __forceinline__ void run(double* q, int lane) {
+    if constexpr (S >= 1) {
+      if constexpr (NREG == 1) {
+        q[0] += __shfl_xor(q[0], S, 64);
+        ManyStep<1, S / 2>::run(q, lane);
+      } else {
+        constexpr int H = (NREG + 1) / 2;
+        const bool up = (lane & S) != 0;
+#pragma unroll
+        for (int i = 0; i < H; ++i) {
+          const double a = q[2 * i], b = (2 * i + 1 < NREG) ? q[2 * i + 1] : 0.0;
+          const double keep = up ? b : a, send = up ? a : b;
+          q[i] = keep + __shfl_xor(send, S, 64);
+        }
+        ManyStep<H, S / 2>::run(q, lane);
+      }
+    }
+  }
+};
+template <int N>
+__device__ __forceinline__ double wave_reduce_many(const double (&v)[N], int lane) {
+  static_assert(N >= 1 && N <= 32, "at most 32 values");
+  constexpr int NP = (N + 3) / 4 * 4;
+  double r[NP / 2], q[NP / 4];
+#pragma unroll
+  for (int i = 0; i < NP / 2; ++i) r[i] = fold32(2 * i < N ? v[2 * i] : 0.0, 2 * i + 1 < N ? v[2 * i + 1] : 0.0);
+#pragma unroll
+  for (int i = 0; i < NP / 4; ++i) q[i] = fold16(r[2 * i], r[2 * i + 1]);
+  ManyStep<NP / 4, 8>::run(q, lane);
+  return q[0];
+}
+__device__ __forceinline__ int many_index(int lane) {
+  return ((lane >> 5) & 1) | (((lane >> 4) & 1) << 1) | (((lane >> 3) & 1) << 2) | (((lane >> 2) & 1) << 3) | (((lane >> 1) & 1) << 4);
+}
+template <int N>
+__device__ __forceinline__ bool many_writer(int lane) {
+  constexpr int R = ((N + 3) / 4 * 4) / 4;   // registers after fold16; pairing steps: distance 8 if R > 1, 4 if R > 2, 2 if R > 4
+  constexpr int unused = 1 | (R > 4 ? 0 : 2) | (R > 2 ? 0 : 4) | (R > 1 ? 0 : 8);
+  return (lane & unused) == 0 && many_index(lane) < N;
+}
+
 // (Fusing the "sum the per-block partials" launch into the producing kernel with the threadfence + ticket-counter idiom
 //  was measured and rejected on this chip: an agent-scope release is an L2 write-back on a multi-XCD part and ~75 ns per
 //  same-address atomic serialises 500-1000 tickets into 40-90 us.  Single-GPU solves copy the partials to the host with
@@ -616,6 +666,135 @@ __global__ __launch_bounds__(64) void k_lsmr_jtu(Dims d, Tables t, const int32_t
     }
     lds_fence();
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_lsmr_fused: BOTH products of a Golub-Kahan step in ONE pass over the observations (round 5; k_lsmr_jv + k_lsmr_jtu
+// evaluated the analytic row pair of every observation twice per LSMR iteration):
+//     uhat <- J_h v - alpha (uhat_old inv_beta_old)          stored UN-normalised; beta = |uhat| is known after the pass
+//     part[view] <- [That^T sum_p E_p^T uhat_p | sum_p K_p^T uhat_p]      (k_lsmr_gather2 applies 1 / beta to the sums)
+// alpha, inv_beta_old and the stop flag come from the device-resident state `ls` (mcba_lsmr.h).  Element for element the
+// arithmetic of uhat is that of k_lsmr_jv on the normalised u that k_lsmr_jtu used to store (u = uhat * inv_beta is formed
+// on the fly with the same rounding).  The NS per-lane sums of a view are reduced with wave_reduce_many (one butterfly for
+// all of them instead of NS wave_sums).  partial[blockIdx.x] = sum of squares of what this workgroup wrote.
+// ---------------------------------------------------------------------------------------------------------------
+template <int ND, int FISH, int MOTION, bool OPTK, bool ROBUST>
+__global__ __launch_bounds__(64) void k_lsmr_fused(Dims d, Tables t, const int32_t* __restrict__ first,
+                                                   const double* __restrict__ dscale, const double* __restrict__ vin,
+                                                   double* __restrict__ u, double* __restrict__ partial,
+                                                   double* __restrict__ part, int part_stride, double* __restrict__ bpart,
+                                                   const double* __restrict__ ls) {
+  constexpr bool ROLL = MOTION == MOTION_ROLLING;
+  constexpr int DE = ROLL ? 12 : 6, NPB = MOTION == MOTION_STATIC ? 3 : 4, NPC = 6 * NPB, KI = OPTK ? 4 + ND : 0;
+  constexpr int NV = DE + KI + 1, NS = DE + KI;
+  __shared__ uint16_t pidx[LIN_MAX_POINTS];
+  __shared__ double vp[NPC], wl[NS], sl[NS];
+  const int lane = threadIdx.x;
+  if (ls[LS_ISTOP] != 0.0) return;
+  const double alpha = ls[LS_ALPHA], inv_beta_old = ls[LS_INV_BETA];
+  const int n_active = t.active_views[0];
+  double acc = 0.0;
+  for (int vi = blockIdx.x; vi < n_active; vi += gridDim.x) {
+    const int v = t.active_views[1 + vi];
+    if (v < 0) continue;
+    const int b = v % d.B, c = (v / d.B) % d.C, f = d.f0 + v / (d.B * d.C);
+    // the view's scaled local parameter vector, then w = That vp
+    if (lane < NPC + KI) {
+      const int xi = local_to_x(d, f, c, b, lane);
+      const double val = xi >= 0 ? dscale[xi] * vin[xi] : 0.0;
+      if (lane < NPC) vp[lane] = val; else wl[DE + lane - NPC] = val;
+    }
+    lds_fence();
+    if (lane < DE) {
+      const double* Tm = t.tmat + (size_t)v * (DE * NPC) + lane * NPC;
+      double sum = 0.0;
+#pragma unroll
+      for (int j = 0; j < NPC; ++j) sum += Tm[j] * vp[j];
+      wl[lane] = sum;
+    }
+    lds_fence();
+    double sums[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) sums[k] = 0.0;
+    size_t out0 = (size_t)first[v];
+    constexpr int NPB64 = LIN_MAX_POINTS / 64;
+    for (int seg0 = 0; seg0 < d.P; seg0 += LIN_MAX_POINTS) {
+      uint8_t inb[NPB64];
+#pragma unroll
+      for (int k = 0; k < NPB64; ++k) inb[k] = masked_load_row(t.inlier + (size_t)v * d.P, seg0 + k * 64 + lane, d.P);
+      int count = 0;
+#pragma unroll
+      for (int k = 0; k < NPB64; ++k) {
+        const bool in = inb[k] != 0;
+        const unsigned long long m = __ballot(in);
+        if (in) pidx[count + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(seg0 + k * 64 + lane);
+        count += __popcll(m);
+      }
+      lds_fence();
+      for (int base = 0; base < count; base += 64) {
+        const int i = base + lane;
+        if (i < count) {
+          const int p = pidx[i];
+          PointState<ND, ROLL> ps;
+          point_state<ND, FISH, ROLL, ROBUST>(d, t, v, c, b, p, t.obs[(size_t)v * d.P + p], ps);
+          double2 old = reinterpret_cast<const double2*>(u)[out0 + i];
+          old.x *= inv_beta_old;      // (the normalised u of the previous step, rounded as k_lsmr_jtu stored it)
+          old.y *= inv_beta_old;
+          double bterm[2] = {0.0, 0.0};
+          if (d.off_boards >= 0) {   // adjusted board points: + jp . (D v)[point]
+            const int gq = d.off_boards + 3 * (t.board_off[b] + p);
+            double w3[3];
+            board_point_direction<ROLL>(t, v, ps.tr, dscale[gq] * vin[gq], dscale[gq + 1] * vin[gq + 1], dscale[gq + 2] * vin[gq + 2], w3);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+              bterm[a] = ps.rs[a] * (ps.A[3 * a] * w3[0] + ps.A[3 * a + 1] * w3[1] + ps.A[3 * a + 2] * w3[2]);
+          }
+          double2 o;
+#pragma unroll
+          for (int a = 0; a < 2; ++a) {
+            double row[NV];
+            point_row<ND, ROLL, OPTK>(ps, a, row);
+            double val = 0.0;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) val += row[k] * wl[k];
+            val += bterm[a];
+            val -= alpha * (a == 0 ? old.x : old.y);
+#pragma unroll
+            for (int k = 0; k < NS; ++k) sums[k] += row[k] * val;
+            if (a == 0) o.x = val; else o.y = val;
+          }
+          reinterpret_cast<double2*>(u)[out0 + i] = o;
+          acc += o.x * o.x + o.y * o.y;
+          if (bpart != nullptr) {   // boards=True: jp^T uhat of this observation (summed per point by the gather)
+            double q3[3], w3[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) q3[k] = ps.rs[0] * o.x * ps.A[k] + ps.rs[1] * o.y * ps.A[3 + k];
+            board_point_adjoint<ROLL>(t, v, ps.tr, q3, w3);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) bpart[3 * (out0 + i) + k] = w3[k];
+          }
+        }
+      }
+      out0 += (size_t)count;
+      lds_fence();
+    }
+    const double tot = wave_reduce_many<NS>(sums, lane);
+    if (many_writer<NS>(lane)) sl[many_index(lane)] = tot;
+    lds_fence();
+    double* out = part + (size_t)v * part_stride;
+    if (lane < NPC) {
+      const double* Tm = t.tmat + (size_t)v * (DE * NPC);
+      double sum = 0.0;
+#pragma unroll
+      for (int a = 0; a < DE; ++a) sum += Tm[a * NPC + lane] * sl[a];
+      out[lane] = sum;
+    } else if (lane < NPC + KI) {
+      out[lane] = sl[DE + lane - NPC];
+    }
+    lds_fence();
+  }
+  const double tot = wave_sum(acc);
+  if (lane == 0) partial[blockIdx.x] = tot;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

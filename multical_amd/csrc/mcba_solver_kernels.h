@@ -2286,19 +2286,22 @@ __global__ __launch_bounds__(256) void k_lsmr_shard_pack(Dims d, const double* _
 // on rank 0 only), so that the sum of the ranks' folds is |v|^2
 __global__ __launch_bounds__(256) void k_lsmr_shard_finish(Dims d, const double* __restrict__ comm, const double* __restrict__ dscale,
                                                            double beta, const double* __restrict__ vold, double* __restrict__ vout,
-                                                           double* __restrict__ nrm, const double* __restrict__ ls) {
+                                                           double* __restrict__ nrm, const double* __restrict__ ls,
+                                                           int unnormalised = 0) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= d.n) return;
   bool skip = false;
+  double inv_beta = 1.0;
   if (ls != nullptr) {
     if (ls[LS_ISTOP] != 0.0) return;
     skip = ls[LS_SKIPV] != 0.0;
     beta = ls[LS_BETA];
+    if (unnormalised) inv_beta = ls[LS_INV_BETA];   // (k_lsmr_fused leaves sums of the un-normalised uhat)
   }
   const int s = d.x_to_shared(i);
   double val = vout[i];
   if (s >= 0) {
-    val = skip ? vold[i] : dscale[i] * comm[s] - beta * vold[i];
+    val = skip ? vold[i] : dscale[i] * (unnormalised ? comm[s] * inv_beta : comm[s]) - beta * vold[i];
     vout[i] = val;
   }
   nrm[i] = d.entry_weight(i) * (val * val);
@@ -2354,6 +2357,199 @@ __global__ __launch_bounds__(256) void k_lsmr_update(int n, double inv_alpha, do
   x[i] = xi;
   h[i] = c_h * h[i] + vi;
   nrm[i] = xi * xi;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Round 5: the LSMR iteration in THREE launches (k_lsmr_fused -> k_lsmr_gather2 -> k_lsmr_update2) instead of six.  The two
+// single-workgroup scalar kernels are gone: every workgroup of the consuming kernel folds the (few) partial sums itself, in
+// the same fixed order, and runs the scalar recurrence redundantly -- no atomics, no "last block" tickets (rejected on this
+// multi-XCD part, see mcba_kernels.h), bit-identical scalars in every workgroup.  Workgroup 0 publishes the state.  The state
+// is double-buffered so that a workgroup that is late never reads what workgroup 0 has already advanced:
+//     k_lsmr_fused    reads A (alpha, 1 / beta_old, stop flag)
+//     k_lsmr_gather2  reads A, |uhat|^2 partials, |x|^2 partials -> stopping tests of the previous iteration, beta; writes B
+//     k_lsmr_update2  reads B, |v|^2 values -> alpha, plane rotations, update coefficients; writes A
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int LSG_THREADS = 256;
+__device__ __forceinline__ double lsmr_fold256(const double* __restrict__ a, int n, double* scratch) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += LSG_THREADS) s += a[i];
+  const double t = block_reduce<false>(s, scratch);
+  __shared__ double bc;
+  if (threadIdx.x == 0) bc = t;
+  __syncthreads();
+  const double r = bc;
+  __syncthreads();
+  return r;   // the same value in every thread
+}
+
+// vout[i] = dscale[i] * (inv_beta * sum over the views that contain parameter i of part[view][local]) - beta * vold[i];
+// nrm[i] = vout[i]^2.  Head: beta and the stopping tests (see above).  Tasks, one wavefront each (4 per workgroup): the
+// entries outside the per-frame pose block, then one per frame (k_lsmr_gather's two kinds of workgroups).
+__global__ __launch_bounds__(LSG_THREADS) void k_lsmr_gather2(Dims d, const double* __restrict__ part, int part_stride,
+                                                              const double* __restrict__ dscale, const double* __restrict__ vold,
+                                                              double* __restrict__ vout, double* __restrict__ nrm,
+                                                              const double* __restrict__ lsA, double* __restrict__ lsB,
+                                                              const double* __restrict__ upart, int nu,
+                                                              const double* __restrict__ xpart, int nx, unsigned long long call,
+                                                              unsigned long long* host_word, LsmrGatherExtra ex) {
+  __shared__ double scratch[16];
+  __shared__ double head[4];
+  if (lsA[LS_ISTOP] != 0.0) return;
+  const double u2 = lsmr_fold256(upart, nu, scratch);
+  const double x2 = lsmr_fold256(xpart, nx, scratch);
+  if (threadIdx.x == 0) {
+    double L[LS_NSLOTS];
+    for (int k = 0; k < LS_NSLOTS; ++k) L[k] = lsA[k];
+    const int istop = L[LS_ITN] > 0.0 ? lsmr_state_test(L, x2) : 0;
+    if (istop != 0) L[LS_ISTOP] = (double)istop;
+    else lsmr_state_beta(L, u2);
+    head[0] = L[LS_BETA]; head[1] = L[LS_INV_BETA]; head[2] = L[LS_SKIPV]; head[3] = L[LS_ISTOP];
+    if (blockIdx.x == 0) {
+      for (int k = 0; k < LS_NSLOTS; ++k) lsB[k] = L[k];
+      __hip_atomic_store(host_word, lsmr_progress_word(call, istop, (long long)L[LS_ITN]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  __syncthreads();
+  if (head[3] != 0.0) return;
+  const double beta = head[0], inv_beta = head[1];
+  const bool skip = head[2] != 0.0;
+  const int lane = threadIdx.x & 63;
+  const int nfe = lsmr_gather_frame_entries(d), ngen = d.n - nfe;
+  const int task = (int)blockIdx.x * (LSG_THREADS / 64) + (threadIdx.x >> 6);
+  const int CB = d.C * d.B, npc = 6 * d.NPB;
+  if (task >= ngen) {
+    const int fl = task - ngen;
+    if (fl >= d.Fl || nfe == 0) return;
+    const int DFm = d.motion == MOTION_ROLLING ? 12 : 6, g = lane >> 4, l16 = lane & 15;
+    for (int e = g; e < DFm; e += 4) {                  // entry e of the frame: chain e / 6, component e % 6
+      const int chain = e / 6, i = d.off_motion + chain * 6 * d.F + 6 * (d.f0 + fl) + e % 6;
+      if (skip) {
+        if (l16 == 0) vout[i] = vold[i];
+        continue;
+      }
+      double s4[4] = {0.0, 0.0, 0.0, 0.0};
+      const double* src = part + (size_t)fl * CB * part_stride + 6 + e;
+      for (int w0 = 0; w0 < CB; w0 += 64)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int vw = w0 + 16 * k + l16;
+          if (vw < CB) s4[k] += src[(size_t)vw * part_stride];
+        }
+      double sum = (s4[0] + s4[2]) + (s4[1] + s4[3]);
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) sum += __shfl_down(sum, off, 16);
+      if (l16 == 0) {
+        const double val = dscale[i] * (sum * inv_beta) - beta * vold[i];
+        vout[i] = val;
+        nrm[i] = val * val;
+      }
+    }
+    return;
+  }
+  const int i = nfe > 0 && task >= d.off_motion ? task + nfe : task;
+  if (i >= d.n) return;
+  if (skip && !ex.raw_shared) {
+    if (lane == 0) vout[i] = vold[i];
+    return;
+  }
+  double sum = 0.0;
+  if (d.off_boards >= 0 && i >= d.off_boards) {   // adjusted board point: sum over the observations of the point
+    const int q = (i - d.off_boards) / 3, k = (i - d.off_boards) % 3;
+    int b = 0;
+    while (q >= ex.board_off[b + 1]) ++b;
+    const int p = q - ex.board_off[b], total = d.Fl * d.C;
+    for (int e = lane; e < total; e += 64) {
+      const int idx = ex.obs_index[((size_t)e * d.B + b) * d.P + p];
+      if (idx >= 0) sum += ex.bpart[3 * (size_t)idx + k];
+    }
+  } else {
+    int base = 0, na = 0, sa = 0, nb = 1, sb = 0, local = -1;
+    if (d.off_campose >= 0 && i >= d.off_campose && i < d.off_campose + 6 * d.C) {
+      const int q = i - d.off_campose, c = q / 6;
+      local = q % 6; base = c * d.B; na = d.Fl; sa = CB; nb = d.B; sb = 1;
+    } else if (d.off_boardpose >= 0 && i >= d.off_boardpose && i < d.off_boardpose + 6 * d.B) {
+      const int q = i - d.off_boardpose, b = q / 6;
+      local = 6 * (d.NPB - 1) + q % 6; base = b; na = d.Fl; sa = CB; nb = d.C; sb = d.B;
+    } else if (d.off_motion >= 0 && i >= d.off_motion && i < d.off_motion + d.n_motion) {
+      const int q = i - d.off_motion;
+      if (d.motion == MOTION_HAND_EYE) { local = 6 + q; base = 0; na = d.views(); sa = 1; }
+    } else if (d.off_cameras >= 0 && i >= d.off_cameras && i < d.off_cameras + d.C * (5 + d.ND)) {
+      const int q = i - d.off_cameras, c = q / (5 + d.ND), qq = q % (5 + d.ND);
+      const int lq = qq < 4 ? qq : qq - 1;
+      const bool masked = d.cam_kmask != nullptr && ((d.cam_kmask[c] >> lq) & 1u);
+      if (qq != 4 && !masked && d.KI > 0) { local = npc + lq; base = c * d.B; na = d.Fl; sa = CB; nb = d.B; sb = 1; }
+    }
+    if (local >= 0) {
+      const int total = na * nb;
+      constexpr int UNR = 8;
+      for (int e0 = lane; e0 < total; e0 += 64 * UNR) {
+        double v[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const int e = e0 + 64 * u, a = e / nb, b_ = e - a * nb;
+          v[u] = e < total ? part[(size_t)(base + a * sa + b_ * sb) * part_stride + local] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+          if (e0 + 64 * u < total) sum += v[u];
+      }
+    }
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) {
+    if (ex.raw_shared) { vout[i] = sum; return; }       // (frame-sharded: summed over the ranks, finished by k_lsmr_shard_finish)
+    const double val = dscale[i] * (sum * inv_beta) - beta * vold[i];
+    vout[i] = val;
+    nrm[i] = val * val;
+  }
+}
+
+// head: |v|^2 (vpart[0 .. nv)) -> alpha, the plane rotations and the coefficients of the update (lsmr_state_rotate); state B -> A.
+// body: v <- v_raw / alpha;  hbar <- c_hbar hbar + h;  x <- x + c_x hbar;  h <- c_h h + v;  xpart[workgroup] = sum_i w_i x_i^2
+// (w = 1; frame-sharded: entry_weight, so that the ranks' partials add up to |x|^2)
+__global__ __launch_bounds__(LSG_THREADS) void k_lsmr_update2(Dims d, const double* __restrict__ lsB, double* __restrict__ lsA,
+                                                              const double* __restrict__ vpart, int nv, double* __restrict__ v,
+                                                              double* __restrict__ hbar, double* __restrict__ x, double* __restrict__ h,
+                                                              double* __restrict__ xpart) {
+  __shared__ double scratch[16];
+  __shared__ double head[5];
+  if (lsB[LS_ISTOP] != 0.0) {   // stopped by the tests in front of this update: hand the flag on, leave x as it is
+    if (blockIdx.x == 0 && threadIdx.x == 0) lsA[LS_ISTOP] = lsB[LS_ISTOP];
+    return;
+  }
+  const double v2 = lsmr_fold256(vpart, nv, scratch);
+  if (threadIdx.x == 0) {
+    double L[LS_NSLOTS];
+    for (int k = 0; k < LS_NSLOTS; ++k) L[k] = lsB[k];
+    lsmr_state_rotate(L, v2);
+    head[0] = L[LS_INV_ALPHA]; head[1] = L[LS_C_HBAR]; head[2] = L[LS_C_X]; head[3] = L[LS_C_H];
+    if (blockIdx.x == 0)
+      for (int k = 0; k < LS_NSLOTS; ++k) lsA[k] = L[k];
+  }
+  __syncthreads();
+  const double inv_alpha = head[0], c_hbar = head[1], c_x = head[2], c_h = head[3];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double sq = 0.0;
+  if (i < d.n) {
+    const double vi = v[i] * inv_alpha;
+    v[i] = vi;
+    const double hb = c_hbar * hbar[i] + h[i];
+    hbar[i] = hb;
+    const double xi = x[i] + c_x * hb;
+    x[i] = xi;
+    h[i] = c_h * h[i] + vi;
+    sq = d.entry_weight(i) * (xi * xi);
+  }
+  const double tot = block_reduce<false>(sq, scratch);
+  if (threadIdx.x == 0) xpart[blockIdx.x] = tot;
+}
+
+// frame-sharded form of the fused iteration: [ |uhat|^2 partial of this rank, |x|^2 partial of this rank ] (plain sums of partials)
+__global__ __launch_bounds__(LSG_THREADS) void k_lsmr_shard_fold_a2(const double* __restrict__ upart, int nu,
+                                                                   const double* __restrict__ xpart, int nx, double* __restrict__ out) {
+  __shared__ double scratch[16];
+  const double a = lsmr_fold256(upart, nu, scratch), b = lsmr_fold256(xpart, nx, scratch);
+  if (threadIdx.x == 0) { out[0] = a; out[1] = b; }
 }
 
 // out[0] = sum a[i] b[i] (one workgroup, fixed order); out[1] = sum a[i]^2, out[2] = sum b[i]^2 when three != 0

@@ -245,18 +245,24 @@ def initialise_poses(pose_table, camera_poses=None):
 
 
 def make_point_table(detections, boards):
-  """tables.py:68-81: ragged per-image detections (corners [k, 2], ids [k]) -> dense table [C, F, B, P] (+ mask)."""
+  """tables.py:68-81: ragged per-image detections (corners [k, 2], ids [k]) -> dense table [C, F, B, P] (+ mask).
+
+  dtype: the reference fills one array per image with `values.dtype` (fill_sparse, tables.py:15-21) and stacks them
+  (make_nd_table -> Table.stack -> np.stack), so the table carries numpy's PROMOTION of all per-image corner dtypes: float32
+  when every detection is float32 (cv2.aruco), float64 as soon as one image contributes float64 corners -- e.g. an empty
+  detection built as np.zeros([0, 2]).  One scatter for the whole table instead of one per image."""
   num_points = int(np.max([b.num_points for b in boards]))
   C_, F, B = len(detections), len(detections[0]), len(detections[0][0])
-  points = np.zeros((C_, F, B, num_points, 2), dtype=np.asarray(detections[0][0][0].corners).dtype
-                    if np.asarray(detections[0][0][0].corners).size else np.float32)
-  valid = np.zeros((C_, F, B, num_points), dtype=bool)
-  for c in range(C_):
-    for f in range(F):
-      for b in range(B):
-        d = detections[c][f][b]
-        ids = np.asarray(d.ids, dtype=np.int64).reshape(-1)
-        if ids.size:
-          points[c, f, b, ids] = np.asarray(d.corners).reshape(-1, 2)
-          valid[c, f, b, ids] = True
-  return Table.create(points=points, valid=valid)
+  flat = [detections[c][f][b] for c in range(C_) for f in range(F) for b in range(B)]
+  corners = [np.asarray(d.corners) for d in flat]
+  ids = [np.asarray(d.ids, dtype=np.int64).reshape(-1) for d in flat]
+  dtype = np.result_type(*[a.dtype for a in corners])
+  counts = np.array([i.size for i in ids], dtype=np.int64)
+  points = np.zeros((C_ * F * B, num_points, 2), dtype=dtype)
+  valid = np.zeros((C_ * F * B, num_points), dtype=bool)
+  if counts.sum() > 0:
+    image = np.repeat(np.arange(C_ * F * B), counts)
+    point = np.concatenate(ids)
+    points[image, point] = np.concatenate([a.reshape(-1, 2) for a, i in zip(corners, ids) if i.size]).astype(dtype, copy=False)
+    valid[image, point] = True
+  return Table.create(points=points.reshape(C_, F, B, num_points, 2), valid=valid.reshape(C_, F, B, num_points))

@@ -36,7 +36,7 @@ def first(pattern):
 
 
 def timeline(trace_csv, out_path, cfg):
-  """consecutive kernels of two LM iterations from the kernel trace of tests/prof_cfg.py (start / end relative to the first)"""
+  """consecutive kernels of two LM iterations from the kernel trace of profiles/scripts/prof_cfg.py (start / end relative to the first)"""
   rows = []
   with open(trace_csv) as f:
     for r in csv.DictReader(f):
@@ -50,7 +50,7 @@ def timeline(trace_csv, out_path, cfg):
   i1 = chol[min(len(chol) - 1, len(chol) // 2 + 2)]
   t0 = rows[i0][0]
   with open(out_path, "w") as out:
-    out.write(f"rocprofv3 --kernel-trace of tests/prof_cfg.py {cfg} (long solve): consecutive kernels of two LM iterations, MI355X, HEAD\n\n")
+    out.write(f"rocprofv3 --kernel-trace of profiles/scripts/prof_cfg.py {cfg} (long solve): consecutive kernels of two LM iterations, MI355X, HEAD\n\n")
     for s, e, name, q in rows[i0:i1 + 1]:
       out.write("%-34s queue %s  start %8.1f end %8.1f us  (%5.1f)\n" % (name[:34], q, (s - t0) / 1e3, (e - t0) / 1e3, (e - s) / 1e3))
     out.write("\niteration period: %.1f us\n" % ((rows[i1][0] - rows[i0][0]) / 2e3))

@@ -2,7 +2,7 @@
 R=$GRAFT_REPO_ROOT; TAG=$1; CFG=$2; shift 2
 O=$R/gpurun_out/ks; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-env "$@" PYTHONPATH=$R:$R/tests rocprofv3 --kernel-trace --stats --output-format csv -d $O/$TAG -o solve -- python $R/tests/prof_cfg.py $CFG > $O/$TAG.log 2>&1
+env "$@" PYTHONPATH=$R:$R/tests rocprofv3 --kernel-trace --stats --output-format csv -d $O/$TAG -o solve -- python $R/profiles/scripts/prof_cfg.py $CFG > $O/$TAG.log 2>&1
 python - <<PY
 import csv, glob
 f = glob.glob("$O/$TAG/**/solve_kernel_stats.csv", recursive=True)[0]

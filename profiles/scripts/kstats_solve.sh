@@ -1,7 +1,7 @@
 # per-kernel average durations of the solver loop: bash profiles/scripts/kstats_solve.sh <tag> [cfg]
 R=$GRAFT_REPO_ROOT; T=$1; CFG=${2:-cfg3}; O=$R/gpurun_out/kss_$T; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-PYTHONPATH=$R:$R/tests rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o trace -- python $R/tests/prof_cfg.py $CFG > $O/solve.log 2>&1
+PYTHONPATH=$R:$R/tests rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o trace -- python $R/profiles/scripts/prof_cfg.py $CFG > $O/solve.log 2>&1
 grep "^$CFG" $O/solve.log
 python - <<PY
 import csv, glob

@@ -1,0 +1,28 @@
+"""The LSMR iteration of the parity route at the north-star rig: three-launch form (k_lsmr_fused) against the six-launch form of
+round 4, same handle, same solve.   python profiles/scripts/prof_lsmr_iter.py [cfg3|cfg4|cfg5 ...]
+(under `rocprofv3 --kernel-trace --stats` the per-kernel times of both forms land in one trace)"""
+import sys, time, json
+import numpy as np
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+from multical_amd import synthetic, calibration
+from multical_amd.backend import Handle
+
+for cfg in (sys.argv[1:] or ["cfg3"]):
+  rig = synthetic.make_rig(cfg)
+  c = calibration.from_rig(rig)
+  x0 = c.param_vec
+  with Handle(c) as h:
+    out = {}
+    for fused in (True, False, True):
+      h.set_lsmr_fused(fused)
+      h.solve(x0, tr_solver="lsmr")
+      ts = []
+      for _ in range(3):
+        t0 = time.perf_counter(); r = h.solve(x0, tr_solver="lsmr"); ts.append(time.perf_counter() - t0)
+      t = sorted(ts)[1]
+      itn = h.lsmr_iterations()
+      e, v = h.reprojection_error(r.x)
+      out["fused" if fused else "six_launch"] = dict(seconds=t, nfev=r.nfev, status=r.status, lsmr_iterations=itn,
+                                                      us_per_lsmr_iteration=t / max(itn, 1) * 1e6, cost=r.cost,
+                                                      rms_px=float(np.sqrt(np.mean(e[v] ** 2))))
+    print(cfg, json.dumps(out), flush=True)

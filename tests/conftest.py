@@ -18,6 +18,13 @@ def pytest_configure(config):
 def pytest_collection_modifyitems(config, items):
   from oracle import refload
   skip_ref = pytest.mark.skip(reason="/root/reference not present (GPU box)")
+  try:
+    import pytest_timeout  # noqa: F401 -- a test that hangs (a deadlocked collective of a multi-rank test) must fail, not stall the box
+    limit = pytest.mark.timeout(900)
+  except ImportError:
+    limit = None
   for item in items:
     if "needs_reference" in item.keywords and not refload.available():
       item.add_marker(skip_ref)
+    if limit is not None and item.get_closest_marker("timeout") is None:
+      item.add_marker(limit)

@@ -595,7 +595,7 @@ def test_handle_cache_sees_a_changed_validity_mask_and_float32_tables():
                                     "MCBA_NCHUNK_TARGET=1024", "MCBA_SHARED_FINAL_BIG=1", "MCBA_SYRK3=1", "MCBA_SPLIT_Q00=1", "MCBA_SPEC_ACCEPT=0", "MCBA_SPEC_ACCEPT=0,MCBA_NO_PUBLISH=1"])
 def test_alternative_linearisation_paths_match_the_default(switch):
   """Paths of the evaluation that the fixtures do not reach by themselves, each forced with its switch in a subprocess
-  (the switches are read once per process); all must reproduce the normal equations of the default form to round-off,
+  (mcba_debug_set_switch, once per process -- the product library reads no MCBA_* experiment switch from the environment); all must reproduce the normal equations of the default form to round-off,
   for every motion model, and the same solve:
     (default)                 table-fed fused form: pose entries from the pose table (k_prep / k_vec_step), chains and That
                               in k_linearize (no k_tmat, no That table)
@@ -606,10 +606,13 @@ def test_alternative_linearisation_paths_match_the_default(switch):
     MCBA_NCHUNK_TARGET=1024   more chunk sums than the default split of the shared part"""
   import os, subprocess, sys, json
   code = r'''
-import sys, json, numpy as np
+import sys, json, os, numpy as np
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 from util import load_golden, mirror
 from multical_amd.backend import Handle
+from multical_amd import _lib
+for kv in filter(None, os.environ.get("TEST_SWITCHES", "").split(",")):
+  _lib.set_switch(*kv.split("="))
 out = {}
 for name in ["tiny", "tiny_rolling", "tiny_handeye", "tiny_fisheye", "tiny_edge", "tiny_pin4", "cfg1", "tiny_tilted"]:
   g, rig = load_golden(name)
@@ -623,9 +626,8 @@ print("RESULT" + json.dumps(out))
 '''
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
   res = {}
-  sw = dict(kv.split("=") for kv in switch.split(","))
-  base = {k: v for k, v in os.environ.items() if k not in sw}
-  for fused, env in (("0", base), ("1", dict(base, **sw))):
+  base = {k: v for k, v in os.environ.items() if not k.startswith("MCBA_") and k != "TEST_SWITCHES"}
+  for fused, env in (("0", base), ("1", dict(base, TEST_SWITCHES=switch))):
     p = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     res[fused] = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT")][0][6:])

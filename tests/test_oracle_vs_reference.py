@@ -110,3 +110,42 @@ def test_initialise_poses_restatement_is_bit_identical_to_reference(name, frames
   for k, rk in [("camera", want.camera), ("board", want.board), ("times", want.times)]:
     assert np.array_equal(np.asarray(rk.valid), got[k]["valid"]), k
     assert np.array_equal(np.asarray(rk.poses), got[k]["poses"]), k
+
+
+@pytest.mark.parametrize("empty_dtype", [np.float32, np.float64])
+def test_make_point_table_equals_the_reference(empty_dtype):
+  """tables.make_point_table (tables.py:12-20,68-81) on ragged float32 detections with empty images: same points, same mask and
+  the SAME dtype as the reference's fill_sparse + Table.stack -- float32 when every image is float32, float64 as soon as one
+  (e.g. an empty detection built as float64 zeros) is not."""
+  from oracle import refload
+  from multical_amd import tables as mtables
+  refload.load()
+  import multical.tables as rtables
+  from structs.struct import struct
+  rng = np.random.default_rng(11)
+  C, F, B = 3, 5, 2
+  sizes = [81, 324]
+  boards = [struct(num_points=n) for n in sizes]
+  dets = []
+  for c in range(C):
+    cam = []
+    for f in range(F):
+      frame = []
+      for b in range(B):
+        k = 0 if (c + f + b) % 4 == 0 else int(rng.integers(1, sizes[b]))
+        ids = np.sort(rng.choice(sizes[b], size=k, replace=False)).astype(np.int32)
+        if k == 0:
+          corners = np.zeros([0, 2], dtype=empty_dtype)
+        else:
+          corners = rng.uniform(0, 2000, size=(k, 2)).astype(np.float32)
+        frame.append(struct(corners=corners, ids=ids))
+      cam.append(frame)
+    dets.append(cam)
+  ref = rtables.make_point_table(dets, boards)
+  got = mtables.make_point_table(dets, boards)
+  assert got.points.dtype == ref.points.dtype == (np.float32 if empty_dtype == np.float32 else np.float64)
+  assert got.points.shape == ref.points.shape == (C, F, B, 324, 2)
+  assert np.array_equal(got.points, ref.points) and np.array_equal(got.valid, ref.valid)
+  assert got.valid.dtype == ref.valid.dtype == bool
+  # the float32 table goes to the device as it is and is widened there exactly as numpy widens it (mcba_problem.points_f32)
+  assert np.array_equal(got.points.astype(np.float64), np.asarray(ref.points, dtype=np.float64))
