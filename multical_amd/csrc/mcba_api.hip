@@ -2062,6 +2062,7 @@ struct LsmrOps {
   int nblk;            // persistent single-wave workgroups of the two Jacobian products
   int part_stride;
   size_t m;            // residuals of THIS handle (its frame shard)
+  bool trace = false;  // MCBA_SOLVE_TRACE (debug switch): per-solve lines on stderr
   size_t m_global = 0; // residuals of the whole problem (frame-sharded: summed over the ranks): scipy's maxiter = min(m, n)
   bool sharded() const { return h->allreduce != nullptr; }
   double* bpart() const { return h->d.off_boards >= 0 ? h->ls_bpart.p : nullptr; }   // boards=True: jp^T u per observation
@@ -2263,6 +2264,9 @@ int lsmr_solve(LsmrOps& op, double damp, int* istop_out) {
     }
   }
   const int itn = (int)done;
+  if (op.trace)
+    fprintf(stderr, "[lsmr_solve rank %d/%d] call %llu: normb %.17g alpha %.17g beta %.17g damp %.17g maxiter %lld -> enqueued %lld done %lld istop %d\n",
+            d.shard_rank, d.shard_world, call, normb, alpha, beta, damp, maxiter, enqueued, done, istop);
   if (v != h->ls_v.p) std::swap(h->ls_v.p, h->ls_vraw.p);   // (the handle's buffers keep their roles for the next call)
   *istop_out = istop;
   return itn;
@@ -2321,6 +2325,18 @@ static void solve_lsmr(mcba_handle h, double* x_inout, const mcba_options* opt, 
     ensure_obs_index(h);
   }
 
+  // residuals of the WHOLE problem (scipy's maxiter = min(m, n) must be the same number on every rank of a frame-sharded solve,
+  // whatever the rank's own shard holds -- an empty shard included): one 1-double all-reduce per solve
+  size_t m_global = m;
+  if (h->allreduce) {
+    const double mine = (double)m;
+    double all = 0.0;
+    HIP_OK(hipMemcpyAsync(h->ls_out.p, &mine, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    op.fetch_sum(h->ls_out.p, 1, &all);
+    m_global = (size_t)std::llround(all);
+  }
+  const bool trace = dbg_switch("MCBA_SOLVE_TRACE") != nullptr;
+  op.trace = trace;
   upload_x(h, x_inout, h->x.p);
   float lin_ms_total = 0.f;
   bool lin_timed = false;
@@ -2365,7 +2381,7 @@ static void solve_lsmr(mcba_handle h, double* x_inout, const mcba_options* opt, 
       if (!std::isfinite(cost)) throw Error("Residuals are not finite in the initial point.");   // scipy least_squares.py:844-845
       // (frame-sharded: the observation count of the linearisation is all-reduced with the cost -- the SAME maxiter on every rank,
       //  whatever its own shard holds; an empty shard must not stop enqueuing iterations and their collectives early)
-      op.m_global = h->allreduce ? 2 * (size_t)std::llround(S[TR_COUNT]) : m;
+      op.m_global = m_global;
       Delta = std::sqrt(xs);
       if (Delta == 0) Delta = 1.0;
       first = false;
@@ -2380,9 +2396,9 @@ static void solve_lsmr(mcba_handle h, double* x_inout, const mcba_options* opt, 
     int istop = 0;
     const int itn = lsmr_solve(op, std::sqrt(reg_term), &istop);
     lsmr_iterations += itn;
-    if (dbg_switch("MCBA_SOLVE_TRACE") != nullptr)
-      fprintf(stderr, "[mcba_solve lsmr] iteration %d: Delta %.17g reg_term %.17g -> lsmr itn %d istop %d\n", iteration, Delta, reg_term,
-              itn, istop);
+    if (trace)
+      fprintf(stderr, "[mcba_solve lsmr rank %d/%d] iteration %d: cost %.17g Q00 %.17g gg %.17g Delta %.17g reg_term %.17g m %zu -> lsmr itn %d istop %d\n",
+              d.shard_rank, d.shard_world, iteration, cost, Q00, gg, Delta, reg_term, op.m_global, itn, istop);
     HIP_OK(hipMemcpyAsync(h->gn.p, h->ls_x.p, (size_t)d.n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     op.jv(2, h->gn.p, 0.0, h->ls_ub.p);
     // [Jg.Jgn | Jg.Jg | Jgn.Jgn] over the m rows and [g_h.gn | g_h.g_h | gn.gn] over the n entries (reordered below); frame-sharded:
@@ -2453,9 +2469,9 @@ static void solve_lsmr(mcba_handle h, double* x_inout, const mcba_options* opt, 
     ++iteration;
   }
   if (status == -100) status = 0;
-  if (dbg_switch("MCBA_SOLVE_TRACE") != nullptr)
-    fprintf(stderr, "[mcba_solve lsmr] %d trial steps, %lld LSMR iterations, %.3f ms\n", nfev - 1, lsmr_iterations,
-            (now_seconds() - t_start) * 1e3);
+  if (trace)
+    fprintf(stderr, "[mcba_solve lsmr rank %d/%d] %d trial steps, %lld LSMR iterations, status %d, %.3f ms\n", d.shard_rank, d.shard_world,
+            nfev - 1, lsmr_iterations, status, (now_seconds() - t_start) * 1e3);
   gather_frame_entries(h, h->x.p);   // (frame-sharded: every rank returns the complete x; ONE n_motion message per solve)
   HIP_OK(hipMemcpyAsync(h->h_x, h->x.p, (size_t)d.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   sync(h);

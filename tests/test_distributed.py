@@ -187,7 +187,9 @@ def _gpu_lsmr_worker(rank, world, port, name, out, empty_last=False, boards=Fals
   os.environ["MASTER_ADDR"] = "127.0.0.1"
   os.environ["MASTER_PORT"] = str(port)
   torch.cuda.set_device(0)
-  dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=180))
+  dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=60))
+  from multical_amd import _lib
+  _lib.set_switch("MCBA_SOLVE_TRACE", "1")       # per-rank solver lines on stderr: shown when the test fails
   g, rig = load_golden(name)
   c = mirror(rig)
   x0 = c.param_vec

@@ -114,7 +114,8 @@ def test_lsmr_mode_reproduces_the_reference_end_point_at_full_size(cfg, record_p
         f"in {nres.solve_seconds * 1e3:.2f} ms, reference spread {spread:.1e}")
   assert abs(rms - float(g["ba_rms"])) <= max(1e-6, spread), (cfg, rms - float(g["ba_rms"]), spread)
   assert res.nfev == int(g["ba_nfev"]) and res.status == int(g["ba_status"])
-  assert res.cost == pytest.approx(float(g["ba_cost"]), rel=2e-6)
+  cost_spread = float(np.abs(g["ba_pert_cost"] - g["ba_cost"]).max()) if "ba_pert_cost" in g else 0.0
+  assert abs(res.cost - float(g["ba_cost"])) <= max(2e-6 * float(g["ba_cost"]), cost_spread), (res.cost, float(g["ba_cost"]), cost_spread)
   # the exact solver ends at or below the reference's cost (converged optimum of the same function), never above its end point
   assert rms_native <= float(g["ba_rms"]) + max(1e-6, spread)
 
