@@ -1,6 +1,6 @@
 """TEST INFRASTRUCTURE: widen the reference's SELF-SENSITIVITY sample of the golden fixtures.
 
-    PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_pert [--n 10] [--jobs 6] [case ...]
+    PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_pert [--n 10] [--jobs 6] [--ba-only] [case ...]
 
 tests/golden/*.npz hold, per case, the end points of the unmodified reference re-run with N(0, 1e-12 px) noise added to
 its residual function (`ba_pert_*`, `ao_pert_*`, written by oracle/make_golden.py with 3 runs per call).  Three samples
@@ -33,7 +33,7 @@ def _rig_of(name):
   return rig, ba_kwargs, mg.AO_KWARGS.get(name, {}), run_ao
 
 
-def run(name, n_pert):
+def run(name, n_pert, ba_only=False):
   import logging
   logging.getLogger("calibration").setLevel(logging.ERROR)
   path = os.path.join(mg.GOLDEN_DIR, f"{name}.npz")
@@ -64,7 +64,7 @@ def run(name, n_pert):
   g["ba_pert_rms"] = np.array([p[0] for p in pert])
   g["ba_pert_nfev"] = np.array([p[1] for p in pert])
   g["ba_pert_cost"] = np.array([p[2] for p in pert])
-  if run_ao and "ao_rms" in g:
+  if run_ao and "ao_rms" in g and not ba_only:
     ao_inl = g["ao_inliers"] if "ao_inliers" in g else np.unpackbits(g["ao_inliers_packed"])[:rig.valid.size].reshape(rig.valid.shape).astype(bool)
     pert = []
     for k in range(n_pert):
@@ -91,10 +91,11 @@ def run(name, n_pert):
 
 
 def main(argv):
-  n_pert, jobs, names = 10, 1, []
+  n_pert, jobs, names, ba_only = 10, 1, [], False
   it = iter(argv)
   for a in it:
     if a == "--n": n_pert = int(next(it))
+    elif a == "--ba-only": ba_only = True      # widen only the bundle_adjust sample (the adjust_outliers sample stays as stored)
     elif a == "--jobs": jobs = int(next(it))
     else: names.append(a)
   names = names or (list(mg.CASES) + list(mg.BIG_CASES))
@@ -121,7 +122,7 @@ def main(argv):
       import time
       time.sleep(1.0)
   else:
-    rows = [run(nm, n_pert) for nm in names]
+    rows = [run(nm, n_pert, ba_only) for nm in names]
   root = os.path.dirname(mg.GOLDEN_DIR.rstrip("/"))
   out = os.path.join(os.path.dirname(root), "profiles", "parity_reference_spread.json")
   if rows:
