@@ -506,9 +506,10 @@ class Handle(object):
     check(self.lib.mcba_debug_lsmr_products(self.h, _ptr(x, C.c_double), pv, pu, pjv, pjtu))
     return jv, jtu
 
-  def set_lsmr_fused(self, on):
-    """A/B switch of the LSMR iteration: True (default) = three launches (k_lsmr_fused), False = the six-launch form."""
-    check(self.lib.mcba_debug_set_lsmr_fused(self.h, 1 if on else 0))
+  def set_lsmr_fused(self, mode):
+    """A/B switch of the LSMR iteration: 2 (default) = two launches (k_lsmr_fused2 / k_lsmr_gather3), 1 = three (k_lsmr_fused /
+    k_lsmr_gather2 / k_lsmr_update2), 0 = the six-launch form of round 4."""
+    check(self.lib.mcba_debug_set_lsmr_fused(self.h, int(mode)))
 
   def lsmr_iterations(self):
     """LSMR iterations of the last `solve(tr_solver='lsmr')` on this handle."""

@@ -313,8 +313,8 @@ struct mcba_handle_s {
   bool shard_root = true;
   DevBuf<double> comm;   // frame-sharded handles: [g_s | diag_s | cost, count | step norms] of the linearisation's message
   // solver "lsmr": m-vectors u (bidiagonalisation), J_h g_h, J_h gn; per-view partials of J_h^T u; n-vectors v, v_raw, h, hbar, x
-  DevBuf<double> ls_u, ls_ua, ls_ub, ls_part, ls_v, ls_vraw, ls_h, ls_hbar, ls_x, ls_nrm, ls_partial, ls_out, ls_bpart, ls_comm, ls_xpart;
-  bool lsmr_fused = true;                 // LSMR iteration in three launches (k_lsmr_fused); false: the six-launch form of round 4 (A/B, tests)
+  DevBuf<double> ls_u, ls_ua, ls_ub, ls_part, ls_v, ls_vraw, ls_h, ls_hbar, ls_x, ls_nrm, ls_partial, ls_out, ls_bpart, ls_comm, ls_xpart, ls_vpart;
+  int lsmr_fused = 2;                     // LSMR iteration: 2 = two launches (k_lsmr_fused2 / k_lsmr_gather3), 1 = three (k_lsmr_fused), 0 = the six-launch form of round 4 (A/B, tests)
   ScalLayout sl;
   DevBuf<double> chol_linv;   // inverted diagonal tiles of the panel kernels (k_cholp_back)
   int lin_grid = 0;          // 0 = automatic (see lin2), > 0 = forced number of persistent workgroups (debug)
@@ -2178,6 +2178,42 @@ struct LsmrOps {
     hipLaunchKernelGGL(k_lsmr_update2, dim3(nvb), dim3(LSG_THREADS), 0, h->stream, d, (const double*)lsB, lsA, vpart, nv, vraw, h->ls_hbar.p,
                        h->ls_x.p, h->ls_h.p, h->ls_xpart.p);
   }
+  // ... and in TWO launches: k_lsmr_fused2 carries the rotation + vector update of the previous step in its head, k_lsmr_gather3
+  // folds its partials in a fifth wavefront beside the sums.  v is kept un-normalised (v = v_raw / alpha, alpha in the state).
+  // State: k_lsmr_fused2 reads s0 (written by the gather / the initialisation) and writes s1; the gather reads s1 and writes s0.
+  int gather3_grid() const { return (gather_grid() + 3) / 4; }
+  void iteration_fused2(double* s0, double* s1, double* u, double* v, double* vraw, unsigned long long call, bool first_iteration) {
+    const Dims& d = h->d;
+    const double* vpart = h->ls_vpart.p;
+    int nv = gather3_grid();
+    if (sharded()) { vpart = h->ls_out.p + 6; nv = 1; }     // (|v_raw|^2 summed over the ranks by the previous iteration)
+    (void)first_iteration;                                   // (state slot LS_PENDING = 0: the head of the first product has nothing to rotate)
+    h->ops->lsmr_fused2(d, h->t, h->stream, h->view_first.p, h->dsc.p, v, u, h->ls_partial.p, h->ls_xpart.p, h->ls_part.p, part_stride,
+                        bpart(), nblk, s0, s1, vpart, nv, h->ls_hbar.p, h->ls_x.p, h->ls_h.p);
+    const double* upart = h->ls_partial.p;
+    const double* xpart = h->ls_xpart.p;
+    int nu = nblk, nx = nblk;
+    if (sharded()) {
+      double* two = h->ls_out.p + 4;
+      hipLaunchKernelGGL(k_lsmr_shard_fold_a2, dim3(1), dim3(LSG_THREADS), 0, h->stream, upart, nu, xpart, nx, two);
+      call_allreduce(h, two, 2, 0);
+      upart = two; nu = 1; xpart = two + 1; nx = 1;
+    }
+    hipLaunchKernelGGL(k_lsmr_gather3, dim3(gather3_grid()), dim3(LSG3_THREADS), 0, h->stream, d, (const double*)h->ls_part.p, part_stride,
+                       (const double*)h->dsc.p, (const double*)v, vraw, h->ls_nrm.p, h->ls_vpart.p, (const double*)s1, s0, upart, nu, xpart, nx,
+                       call, h->h_pub_seq + 1, extra());
+    if (sharded()) {
+      const int ns = std::max(d.ns, 1);
+      if (h->ls_comm.n < (size_t)ns) h->ls_comm.alloc((size_t)ns, true);
+      hipLaunchKernelGGL(k_lsmr_shard_pack, dim3((ns + 255) / 256), dim3(256), 0, h->stream, d, (const double*)vraw, h->ls_comm.p);
+      call_allreduce(h, h->ls_comm.p, (size_t)d.ns, 0);
+      hipLaunchKernelGGL(k_lsmr_shard_finish, dim3((d.n + 255) / 256), dim3(256), 0, h->stream, d, (const double*)h->ls_comm.p,
+                         (const double*)h->dsc.p, 0.0, (const double*)v, vraw, h->ls_nrm.p, (const double*)s0, 2);
+      double* one = h->ls_out.p + 6;
+      hipLaunchKernelGGL(k_dot, dim3(1), dim3(1024), 0, h->stream, (size_t)d.n, (const double*)h->ls_nrm.p, (const double*)nullptr, one, 0);
+      call_allreduce(h, one, 1, 0);
+    }
+  }
 };
 
 // scipy.sparse.linalg.lsmr(J_h, f, damp, atol = btol = 1e-6, conlim = 1e8, maxiter = min(m, n)) -- the call of trf.py:481 --
@@ -2213,7 +2249,8 @@ int lsmr_solve(LsmrOps& op, double damp, int* istop_out) {
   // first version fetched beta, alpha and |x| to the host in every iteration: three synchronisations of ~75 us.)  Kernels
   // enqueued behind the stop are empty launches; the call id in the word tells them from those of the next solve.
   if (h->ls_state.n < (size_t)2 * LS_NSLOTS) h->ls_state.alloc((size_t)2 * LS_NSLOTS, true);   // [A | B] (fused iteration)
-  if (h->ls_xpart.n < (size_t)nvb + 1) h->ls_xpart.alloc((size_t)nvb + 1, true);
+  if (h->ls_xpart.n < (size_t)std::max(nvb, op.nblk) + 1) h->ls_xpart.alloc((size_t)std::max(nvb, op.nblk) + 1, true);
+  if (h->ls_vpart.n < (size_t)op.gather3_grid() + 1) h->ls_vpart.alloc((size_t)op.gather3_grid() + 1, true);
   double* ls = h->ls_state.p;
   const unsigned long long call = (++h->ls_call) & 0xffffffull;
   hipLaunchKernelGGL(k_lsmr_init, dim3(1), dim3(64), 0, h->stream, ls, alpha, beta, damp, normb, (double)maxiter);
@@ -2240,7 +2277,8 @@ int lsmr_solve(LsmrOps& op, double damp, int* istop_out) {
     const bool may_enqueue = lockstep ? (enqueued == 0 || ((seen >> 40) == call && done == enqueued - 1))
                                       : (enqueued - done < LOOKAHEAD);
     if (may_enqueue && enqueued <= maxiter) {   // (iteration maxiter + 1 carries the tests of iteration maxiter)
-      if (h->lsmr_fused) op.iteration_fused(ls, ls + LS_NSLOTS, u, v, vraw, call);
+      if (h->lsmr_fused == 2) op.iteration_fused2(ls, ls + LS_NSLOTS, u, v, vraw, call, enqueued == 0);
+      else if (h->lsmr_fused == 1) op.iteration_fused(ls, ls + LS_NSLOTS, u, v, vraw, call);
       else op.iteration(ls, u, v, vraw, call);
       std::swap(v, vraw);
       ++enqueued;
@@ -2555,7 +2593,8 @@ int32_t mcba_debug_set_switch(const char* name, const char* value) {
 int32_t mcba_debug_set_lsmr_fused(mcba_handle h, int32_t on) {
   API_BEGIN
   REQUIRE(h, "null handle");
-  h->lsmr_fused = on != 0;
+  REQUIRE(on >= 0 && on <= 2, "0 = six launches, 1 = three, 2 = two");
+  h->lsmr_fused = on;
   API_END
 }
 

@@ -164,7 +164,33 @@ void lsmr_fused(const Dims& d, const Tables& t, hipStream_t s, const int32_t* fi
   else fus1<MOTION_HAND_EYE>(d, t, s, first, dscale, v, u, partial, part, part_stride, bpart, nblk, ls);
 }
 
-const CamOps OPS = {residual, project_model, cost, jacobian, linearize, points, lsmr_jv, lsmr_jtu, lsmr_fused};
+#define MCBA_F2_ARGS const Dims& d, const Tables& t, hipStream_t s, const int32_t* first, const double* dscale, const double* v, double* u, \
+                     double* partial, double* xpart, double* part, int part_stride, double* bpart, int nblk, const double* lsIn, \
+                     double* lsOut, const double* vpart, int nv, double* hbar, double* x, double* h
+#define MCBA_F2_PASS d, t, s, first, dscale, v, u, partial, xpart, part, part_stride, bpart, nblk, lsIn, lsOut, vpart, nv, hbar, x, h
+template <int MOTION, bool OPTK>
+void fus22(MCBA_F2_ARGS) {
+  if (d.loss != 0)
+    hipLaunchKernelGGL((k_lsmr_fused2<ND_, FISH_, MOTION, OPTK, true>), dim3(nblk), dim3(64), 0, s, d, t, first, dscale, v, u, partial, xpart, part,
+                       part_stride, bpart, lsIn, lsOut, vpart, nv, hbar, x, h);
+  else
+    hipLaunchKernelGGL((k_lsmr_fused2<ND_, FISH_, MOTION, OPTK, false>), dim3(nblk), dim3(64), 0, s, d, t, first, dscale, v, u, partial, xpart, part,
+                       part_stride, bpart, lsIn, lsOut, vpart, nv, hbar, x, h);
+}
+template <int MOTION>
+void fus21(MCBA_F2_ARGS) {
+  if (d.KI > 0) fus22<MOTION, true>(MCBA_F2_PASS);
+  else fus22<MOTION, false>(MCBA_F2_PASS);
+}
+void lsmr_fused2(MCBA_F2_ARGS) {
+  if (d.motion == MOTION_STATIC) fus21<MOTION_STATIC>(MCBA_F2_PASS);
+  else if (d.motion == MOTION_ROLLING) fus21<MOTION_ROLLING>(MCBA_F2_PASS);
+  else fus21<MOTION_HAND_EYE>(MCBA_F2_PASS);
+}
+#undef MCBA_F2_ARGS
+#undef MCBA_F2_PASS
+
+const CamOps OPS = {residual, project_model, cost, jacobian, linearize, points, lsmr_jv, lsmr_jtu, lsmr_fused, lsmr_fused2};
 
 }  // namespace
 

@@ -30,6 +30,10 @@ struct CamOps {
   // both products of an LSMR iteration in one pass (k_lsmr_fused): uhat <- J_h v - alpha uhat_old / beta_old, per-view J_h^T uhat
   void (*lsmr_fused)(const Dims&, const Tables&, hipStream_t, const int32_t* first, const double* dscale, const double* v, double* u,
                      double* partial, double* part, int part_stride, double* bpart, int nblk, const double* ls);
+  // k_lsmr_fused + the rotation / vector update of the previous step in its head (two-launch iteration)
+  void (*lsmr_fused2)(const Dims&, const Tables&, hipStream_t, const int32_t* first, const double* dscale, const double* v, double* u,
+                      double* partial, double* xpart, double* part, int part_stride, double* bpart, int nblk, const double* lsIn,
+                      double* lsOut, const double* vpart, int nv, double* hbar, double* x, double* h);
 };
 
 const CamOps* cam_ops_pin4();

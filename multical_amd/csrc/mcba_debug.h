@@ -41,7 +41,8 @@ int32_t mcba_debug_lsmr_products(mcba_handle h, const double* x, const double* v
 /* experiment / path-forcing switches (formerly MCBA_* environment variables: the product library no longer reads those, a
  * MCBA_BUILD_VARIANT build does): process-wide, once per name, before the first mcba_create                               */
 int32_t mcba_debug_set_switch(const char* name, const char* value);
-/* 1 (default): three-launch LSMR iteration (both Jacobian products from one evaluation of the rows); 0: the six-launch form  */
+/* LSMR iteration: 2 (default) = two launches (k_lsmr_fused2: both Jacobian products from one evaluation of the rows + the scalar
+ * recurrence / vector update of the previous step in its head; k_lsmr_gather3), 1 = three launches, 0 = the six-launch form    */
 int32_t mcba_debug_set_lsmr_fused(mcba_handle h, int32_t on);
 /* LSMR iterations taken by the last mcba_solve with tr_solver = MCBA_TR_LSMR on this handle                           */
 int32_t mcba_debug_lsmr_info(mcba_handle h, int64_t* lsmr_iterations);

@@ -798,6 +798,173 @@ __global__ __launch_bounds__(64) void k_lsmr_fused(Dims d, Tables t, const int32
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// k_lsmr_fused2: k_lsmr_fused + the scalar recurrence and the vector update of the PREVIOUS Golub-Kahan step in its head, so that
+// an LSMR iteration is TWO launches (k_lsmr_fused2 -> k_lsmr_gather3).  Every workgroup (one wavefront), redundantly and with
+// bit-identical results: fold the |v_raw|^2 partials of the last gather -> alpha, the plane rotations and the update
+// coefficients (lsmr_state_rotate); workgroup 0 publishes the state (in: lsIn, written by the gather; out: lsOut -- double
+// buffer, see k_lsmr_gather3).  v is never stored normalised: v = v_raw / alpha is formed where it is read.  The vector update
+// h_bar, x, h (n entries) is spread over the workgroups, 64 entries each; xpart[workgroup] = its part of |x|^2.
+// ---------------------------------------------------------------------------------------------------------------
+template <int ND, int FISH, int MOTION, bool OPTK, bool ROBUST>
+__global__ __launch_bounds__(64) void k_lsmr_fused2(Dims d, Tables t, const int32_t* __restrict__ first,
+                                                    const double* __restrict__ dscale, const double* __restrict__ vin,
+                                                    double* __restrict__ u, double* __restrict__ partial, double* __restrict__ xpart,
+                                                    double* __restrict__ part, int part_stride, double* __restrict__ bpart,
+                                                    const double* __restrict__ lsIn, double* __restrict__ lsOut,
+                                                    const double* __restrict__ vpart, int nv, double* __restrict__ hbar,
+                                                    double* __restrict__ xv, double* __restrict__ hv) {
+  constexpr bool ROLL = MOTION == MOTION_ROLLING;
+  constexpr int DE = ROLL ? 12 : 6, NPB = MOTION == MOTION_STATIC ? 3 : 4, NPC = 6 * NPB, KI = OPTK ? 4 + ND : 0;
+  constexpr int NV = DE + KI + 1, NS = DE + KI;
+  __shared__ uint16_t pidx[LIN_MAX_POINTS];
+  __shared__ double vp[NPC], wl[NS], sl[NS];
+  const int lane = threadIdx.x;
+  if (lsIn[LS_ISTOP] != 0.0) {   // stopped by the tests of the last gather: hand the flag on, leave x as it is
+    if (blockIdx.x == 0 && lane == 0) lsOut[LS_ISTOP] = lsIn[LS_ISTOP];
+    return;
+  }
+  double alpha, inv_alpha, inv_beta_old;
+  {
+    // ---- head: rotation + vector update of the step whose v_raw the last gather produced --------------------------------
+    double L[LS_NSLOTS];
+#pragma unroll
+    for (int k = 0; k < LS_NSLOTS; ++k) L[k] = lsIn[k];
+    const bool pending = L[LS_PENDING] != 0.0;
+    double xsq = 0.0;
+    if (pending) {
+      double s = 0.0;
+      for (int i = lane; i < nv; i += 64) s += vpart[i];
+      s = wave_sum(s);
+      const double v2 = __shfl(s, 0, 64);
+      lsmr_state_rotate(L, v2);
+      L[LS_PENDING] = 0.0;
+      const double ia = L[LS_INV_ALPHA], c_hbar = L[LS_C_HBAR], c_x = L[LS_C_X], c_h = L[LS_C_H];
+      for (int i = blockIdx.x * 64 + lane; i < d.n; i += gridDim.x * 64) {
+        const double vi = vin[i] * ia;
+        const double hb = c_hbar * hbar[i] + hv[i];
+        hbar[i] = hb;
+        const double xi = xv[i] + c_x * hb;
+        xv[i] = xi;
+        hv[i] = c_h * hv[i] + vi;
+        xsq += d.entry_weight(i) * (xi * xi);
+      }
+    }
+    xsq = wave_sum(xsq);
+    if (lane == 0) xpart[blockIdx.x] = xsq;
+    if (blockIdx.x == 0 && lane == 0) {
+#pragma unroll
+      for (int k = 0; k < LS_NSLOTS; ++k) lsOut[k] = L[k];
+    }
+    alpha = L[LS_ALPHA];
+    inv_alpha = L[LS_INV_ALPHA];
+    inv_beta_old = L[LS_INV_BETA];
+  }
+  const int n_active = t.active_views[0];
+  double acc = 0.0;
+  for (int vi = blockIdx.x; vi < n_active; vi += gridDim.x) {
+    const int v = t.active_views[1 + vi];
+    if (v < 0) continue;
+    const int b = v % d.B, c = (v / d.B) % d.C, f = d.f0 + v / (d.B * d.C);
+    if (lane < NPC + KI) {
+      const int xi = local_to_x(d, f, c, b, lane);
+      const double val = xi >= 0 ? dscale[xi] * (vin[xi] * inv_alpha) : 0.0;
+      if (lane < NPC) vp[lane] = val; else wl[DE + lane - NPC] = val;
+    }
+    lds_fence();
+    if (lane < DE) {
+      const double* Tm = t.tmat + (size_t)v * (DE * NPC) + lane * NPC;
+      double sum = 0.0;
+#pragma unroll
+      for (int j = 0; j < NPC; ++j) sum += Tm[j] * vp[j];
+      wl[lane] = sum;
+    }
+    lds_fence();
+    double sums[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) sums[k] = 0.0;
+    size_t out0 = (size_t)first[v];
+    constexpr int NPB64 = LIN_MAX_POINTS / 64;
+    for (int seg0 = 0; seg0 < d.P; seg0 += LIN_MAX_POINTS) {
+      uint8_t inb[NPB64];
+#pragma unroll
+      for (int k = 0; k < NPB64; ++k) inb[k] = masked_load_row(t.inlier + (size_t)v * d.P, seg0 + k * 64 + lane, d.P);
+      int count = 0;
+#pragma unroll
+      for (int k = 0; k < NPB64; ++k) {
+        const bool in = inb[k] != 0;
+        const unsigned long long m = __ballot(in);
+        if (in) pidx[count + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(seg0 + k * 64 + lane);
+        count += __popcll(m);
+      }
+      lds_fence();
+      for (int base = 0; base < count; base += 64) {
+        const int i = base + lane;
+        if (i < count) {
+          const int p = pidx[i];
+          PointState<ND, ROLL> ps;
+          point_state<ND, FISH, ROLL, ROBUST>(d, t, v, c, b, p, t.obs[(size_t)v * d.P + p], ps);
+          double2 old = reinterpret_cast<const double2*>(u)[out0 + i];
+          old.x *= inv_beta_old;
+          old.y *= inv_beta_old;
+          double bterm[2] = {0.0, 0.0};
+          if (d.off_boards >= 0) {
+            const int gq = d.off_boards + 3 * (t.board_off[b] + p);
+            double w3[3];
+            board_point_direction<ROLL>(t, v, ps.tr, dscale[gq] * (vin[gq] * inv_alpha), dscale[gq + 1] * (vin[gq + 1] * inv_alpha),
+                                        dscale[gq + 2] * (vin[gq + 2] * inv_alpha), w3);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+              bterm[a] = ps.rs[a] * (ps.A[3 * a] * w3[0] + ps.A[3 * a + 1] * w3[1] + ps.A[3 * a + 2] * w3[2]);
+          }
+          double2 o;
+#pragma unroll
+          for (int a = 0; a < 2; ++a) {
+            double row[NV];
+            point_row<ND, ROLL, OPTK>(ps, a, row);
+            double val = 0.0;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) val += row[k] * wl[k];
+            val += bterm[a];
+            val -= alpha * (a == 0 ? old.x : old.y);
+#pragma unroll
+            for (int k = 0; k < NS; ++k) sums[k] += row[k] * val;
+            if (a == 0) o.x = val; else o.y = val;
+          }
+          reinterpret_cast<double2*>(u)[out0 + i] = o;
+          acc += o.x * o.x + o.y * o.y;
+          if (bpart != nullptr) {
+            double q3[3], w3[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) q3[k] = ps.rs[0] * o.x * ps.A[k] + ps.rs[1] * o.y * ps.A[3 + k];
+            board_point_adjoint<ROLL>(t, v, ps.tr, q3, w3);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) bpart[3 * (out0 + i) + k] = w3[k];
+          }
+        }
+      }
+      out0 += (size_t)count;
+      lds_fence();
+    }
+    const double tot = wave_reduce_many<NS>(sums, lane);
+    if (many_writer<NS>(lane)) sl[many_index(lane)] = tot;
+    lds_fence();
+    double* out = part + (size_t)v * part_stride;
+    if (lane < NPC) {
+      const double* Tm = t.tmat + (size_t)v * (DE * NPC);
+      double sum = 0.0;
+#pragma unroll
+      for (int a = 0; a < DE; ++a) sum += Tm[a * NPC + lane] * sl[a];
+      out[lane] = sum;
+    } else if (lane < NPC + KI) {
+      out[lane] = sl[DE + lane - NPC];
+    }
+    lds_fence();
+  }
+  const double tot = wave_sum(acc);
+  if (lane == 0) partial[blockIdx.x] = tot;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // k_jacobian: analytic Jacobian rows in the column order of Calibration.sparsity_matrix
 //             (optimization/calibration.py:173-196).  One thread per inlier observation (not a hot path).
 // ---------------------------------------------------------------------------------------------------------------

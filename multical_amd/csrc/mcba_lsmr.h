@@ -13,6 +13,7 @@ enum LsmrSlot : int {
   LS_ISTOP, LS_ITN, LS_MAXITER, LS_DAMP, LS_NORMB,
   LS_ZETABAR, LS_ALPHABAR, LS_RHO, LS_RHOBAR, LS_CBAR, LS_SBAR, LS_BETADD, LS_BETAD, LS_RHODOLD, LS_TAUTILDEOLD, LS_THETATILDE,
   LS_ZETA, LS_DD, LS_NORMA2, LS_MAXRBAR, LS_MINRBAR, LS_NORMR, LS_NORMA, LS_CONDA, LS_NORMAR,
+  LS_PENDING,                  // two-launch iteration: a new v_raw (and its |.|^2 partials) waits for its rotation + vector update
   LS_NSLOTS
 };
 

@@ -2291,17 +2291,19 @@ __global__ __launch_bounds__(256) void k_lsmr_shard_finish(Dims d, const double*
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= d.n) return;
   bool skip = false;
-  double inv_beta = 1.0;
+  double inv_beta = 1.0, inv_alpha = 1.0;
   if (ls != nullptr) {
     if (ls[LS_ISTOP] != 0.0) return;
     skip = ls[LS_SKIPV] != 0.0;
     beta = ls[LS_BETA];
     if (unnormalised) inv_beta = ls[LS_INV_BETA];   // (k_lsmr_fused leaves sums of the un-normalised uhat)
+    if (unnormalised == 2) inv_alpha = ls[LS_INV_ALPHA];   // (two-launch iteration: v_old is v_raw of the last step, v = v_raw / alpha)
   }
   const int s = d.x_to_shared(i);
   double val = vout[i];
   if (s >= 0) {
-    val = skip ? vold[i] : dscale[i] * (unnormalised ? comm[s] * inv_beta : comm[s]) - beta * vold[i];
+    const double vn = unnormalised == 2 ? vold[i] * inv_alpha : vold[i];
+    val = skip ? vn : dscale[i] * (unnormalised ? comm[s] * inv_beta : comm[s]) - beta * vn;
     vout[i] = val;
   }
   nrm[i] = d.entry_weight(i) * (val * val);
@@ -2502,6 +2504,166 @@ __global__ __launch_bounds__(LSG_THREADS) void k_lsmr_gather2(Dims d, const doub
     vout[i] = val;
     nrm[i] = val * val;
   }
+}
+
+// Two-launch iteration (k_lsmr_fused2 -> k_lsmr_gather3): the gather of k_lsmr_gather2 with
+//   * a FIFTH wavefront per workgroup that does the head (fold of the |uhat|^2 and |x|^2 partials, stopping tests, beta) WHILE the
+//     four task wavefronts form their sums over the per-view partials -- the sums do not depend on beta; one barrier, then the
+//     finish  v_raw[i] = D_i (sum / beta) - beta (v_old[i] / alpha)   (v is kept un-normalised: 1 / alpha comes from the state);
+//   * per-workgroup partials of |v_raw|^2 (vpart[workgroup]) for the head of the next k_lsmr_fused2 instead of n squares.
+// State: in = lsIn (written by k_lsmr_fused2), out = lsOut.
+constexpr int LSG3_THREADS = 320;
+__global__ __launch_bounds__(LSG3_THREADS) void k_lsmr_gather3(Dims d, const double* __restrict__ part, int part_stride,
+                                                               const double* __restrict__ dscale, const double* __restrict__ vold,
+                                                               double* __restrict__ vout, double* __restrict__ nrm,
+                                                               double* __restrict__ vpart,
+                                                               const double* __restrict__ lsIn, double* __restrict__ lsOut,
+                                                               const double* __restrict__ upart, int nu,
+                                                               const double* __restrict__ xpart, int nx, unsigned long long call,
+                                                               unsigned long long* host_word, LsmrGatherExtra ex) {
+  __shared__ double head[5];
+  __shared__ double wsq[4];
+  if (lsIn[LS_ISTOP] != 0.0) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nfe = lsmr_gather_frame_entries(d), ngen = d.n - nfe;
+  const int CB = d.C * d.B, npc = 6 * d.NPB;
+  const int task = (int)blockIdx.x * 4 + wave;
+  // ---- phase 1: sums (task wavefronts) || head (fifth wavefront) ------------------------------------------------------------
+  double sum = 0.0, fsum[3] = {0.0, 0.0, 0.0};
+  int kind = 0, gi = -1;   // kind 1: general entry gi (lane 0 finishes it); kind 2: frame task (lanes with l16 == 0, entries g, g + 4, g + 8)
+  const int DFm = d.motion == MOTION_ROLLING ? 12 : 6, g16 = lane >> 4, l16 = lane & 15;
+  int fl = -1;
+  if (wave == 4) {
+    double su = 0.0, sx = 0.0;
+    for (int i = lane; i < nu; i += 64) su += upart[i];
+    for (int i = lane; i < nx; i += 64) sx += xpart[i];
+    su = wave_sum(su);
+    sx = wave_sum(sx);
+    const double u2 = __shfl(su, 0, 64), x2 = __shfl(sx, 0, 64);
+    double L[LS_NSLOTS];
+#pragma unroll
+    for (int k = 0; k < LS_NSLOTS; ++k) L[k] = lsIn[k];
+    const int istop = L[LS_ITN] > 0.0 ? lsmr_state_test(L, x2) : 0;
+    if (istop != 0) L[LS_ISTOP] = (double)istop;
+    else lsmr_state_beta(L, u2);
+    L[LS_PENDING] = 1.0;
+    if (lane == 0) {
+      head[0] = L[LS_BETA]; head[1] = L[LS_INV_BETA]; head[2] = L[LS_SKIPV]; head[3] = L[LS_ISTOP]; head[4] = L[LS_INV_ALPHA];
+      if (blockIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < LS_NSLOTS; ++k) lsOut[k] = L[k];
+        __hip_atomic_store(host_word, lsmr_progress_word(call, istop, (long long)L[LS_ITN]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  } else if (task >= ngen) {
+    fl = task - ngen;
+    if (fl < d.Fl && nfe > 0) {
+      kind = 2;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int e = g16 + 4 * q;
+        if (e < DFm) {
+          double s4[4] = {0.0, 0.0, 0.0, 0.0};
+          const double* src = part + (size_t)fl * CB * part_stride + 6 + e;
+          for (int w0 = 0; w0 < CB; w0 += 64)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const int vw = w0 + 16 * k + l16;
+              if (vw < CB) s4[k] += src[(size_t)vw * part_stride];
+            }
+          double sq = (s4[0] + s4[2]) + (s4[1] + s4[3]);
+#pragma unroll
+          for (int off = 8; off > 0; off >>= 1) sq += __shfl_down(sq, off, 16);
+          fsum[q] = sq;
+        }
+      }
+    }
+  } else {
+    const int i = nfe > 0 && task >= d.off_motion ? task + nfe : task;
+    if (i < d.n) {
+      kind = 1;
+      gi = i;
+      if (d.off_boards >= 0 && i >= d.off_boards) {   // adjusted board point: sum over the observations of the point
+        const int q = (i - d.off_boards) / 3, k = (i - d.off_boards) % 3;
+        int b = 0;
+        while (q >= ex.board_off[b + 1]) ++b;
+        const int p = q - ex.board_off[b], total = d.Fl * d.C;
+        for (int e = lane; e < total; e += 64) {
+          const int idx = ex.obs_index[((size_t)e * d.B + b) * d.P + p];
+          if (idx >= 0) sum += ex.bpart[3 * (size_t)idx + k];
+        }
+      } else {
+        int base = 0, na = 0, sa = 0, nb = 1, sb = 0, local = -1;
+        if (d.off_campose >= 0 && i >= d.off_campose && i < d.off_campose + 6 * d.C) {
+          const int q = i - d.off_campose, c = q / 6;
+          local = q % 6; base = c * d.B; na = d.Fl; sa = CB; nb = d.B; sb = 1;
+        } else if (d.off_boardpose >= 0 && i >= d.off_boardpose && i < d.off_boardpose + 6 * d.B) {
+          const int q = i - d.off_boardpose, b = q / 6;
+          local = 6 * (d.NPB - 1) + q % 6; base = b; na = d.Fl; sa = CB; nb = d.C; sb = d.B;
+        } else if (d.off_motion >= 0 && i >= d.off_motion && i < d.off_motion + d.n_motion) {
+          const int q = i - d.off_motion;
+          if (d.motion == MOTION_HAND_EYE) { local = 6 + q; base = 0; na = d.views(); sa = 1; }
+        } else if (d.off_cameras >= 0 && i >= d.off_cameras && i < d.off_cameras + d.C * (5 + d.ND)) {
+          const int q = i - d.off_cameras, c = q / (5 + d.ND), qq = q % (5 + d.ND);
+          const int lq = qq < 4 ? qq : qq - 1;
+          const bool masked = d.cam_kmask != nullptr && ((d.cam_kmask[c] >> lq) & 1u);
+          if (qq != 4 && !masked && d.KI > 0) { local = npc + lq; base = c * d.B; na = d.Fl; sa = CB; nb = d.B; sb = 1; }
+        }
+        if (local >= 0) {
+          const int total = na * nb;
+          constexpr int UNR = 8;
+          for (int e0 = lane; e0 < total; e0 += 64 * UNR) {
+            double v[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+              const int e = e0 + 64 * u, a = e / nb, b_ = e - a * nb;
+              v[u] = e < total ? part[(size_t)(base + a * sa + b_ * sb) * part_stride + local] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u)
+              if (e0 + 64 * u < total) sum += v[u];
+          }
+        }
+      }
+      sum = wave_sum(sum);
+    }
+  }
+  __syncthreads();
+  if (head[3] != 0.0) return;
+  // ---- phase 2: finish with beta ------------------------------------------------------------------------------------------------
+  const double beta = head[0], inv_beta = head[1], inv_alpha = head[4];
+  const bool skip = head[2] != 0.0;
+  double vsq = 0.0;
+  if (kind == 2) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int e = g16 + 4 * q;
+      if (e < DFm && l16 == 0) {
+        const int chain = e / 6, i = d.off_motion + chain * 6 * d.F + 6 * (d.f0 + fl) + e % 6;
+        const double vn = vold[i] * inv_alpha;
+        const double val = skip ? vn : dscale[i] * (fsum[q] * inv_beta) - beta * vn;
+        vout[i] = val;
+        nrm[i] = val * val;
+        vsq += val * val;
+      }
+    }
+  } else if (kind == 1 && lane == 0) {
+    if (ex.raw_shared) {
+      vout[gi] = sum;          // (frame-sharded: summed over the ranks, finished by k_lsmr_shard_finish)
+    } else {
+      const double vn = vold[gi] * inv_alpha;
+      const double val = skip ? vn : dscale[gi] * (sum * inv_beta) - beta * vn;
+      vout[gi] = val;
+      nrm[gi] = val * val;
+      vsq = val * val;
+    }
+  }
+  if (wave < 4) {
+    vsq = wave_sum(vsq);
+    if (lane == 0) wsq[wave] = vsq;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) vpart[blockIdx.x] = (wsq[0] + wsq[1]) + (wsq[2] + wsq[3]);
 }
 
 // head: |v|^2 (vpart[0 .. nv)) -> alpha, the plane rotations and the coefficients of the update (lsmr_state_rotate); state B -> A.

@@ -1,5 +1,5 @@
-"""The LSMR iteration of the parity route at the north-star rig: three-launch form (k_lsmr_fused) against the six-launch form of
-round 4, same handle, same solve.   python profiles/scripts/prof_lsmr_iter.py [cfg3|cfg4|cfg5 ...]
+"""The LSMR iteration of the parity route at the north-star rig: two-launch form (k_lsmr_fused2 / k_lsmr_gather3), three-launch form
+(k_lsmr_fused) and the six-launch form of round 4, same handle, same solve.   python profiles/scripts/prof_lsmr_iter.py [cfg3|cfg4|cfg5 ...]
 (under `rocprofv3 --kernel-trace --stats` the per-kernel times of both forms land in one trace)"""
 import sys, time, json
 import numpy as np
@@ -13,7 +13,7 @@ for cfg in (sys.argv[1:] or ["cfg3"]):
   x0 = c.param_vec
   with Handle(c) as h:
     out = {}
-    for fused in (True, False, True):
+    for fused in (2, 1, 0, 2):
       h.set_lsmr_fused(fused)
       h.solve(x0, tr_solver="lsmr")
       ts = []
@@ -22,7 +22,7 @@ for cfg in (sys.argv[1:] or ["cfg3"]):
       t = sorted(ts)[1]
       itn = h.lsmr_iterations()
       e, v = h.reprojection_error(r.x)
-      out["fused" if fused else "six_launch"] = dict(seconds=t, nfev=r.nfev, status=r.status, lsmr_iterations=itn,
+      out[{2: "two_launch", 1: "three_launch", 0: "six_launch"}[fused]] = dict(seconds=t, nfev=r.nfev, status=r.status, lsmr_iterations=itn,
                                                       us_per_lsmr_iteration=t / max(itn, 1) * 1e6, cost=r.cost,
                                                       rms_px=float(np.sqrt(np.mean(e[v] ** 2))))
     print(cfg, json.dumps(out), flush=True)

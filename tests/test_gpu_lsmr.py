@@ -137,3 +137,26 @@ def test_workspace_calibrate_at_full_size_against_the_reference(cfg):
   diff = int(np.sum(ao.inliers != ref_mask))
   assert diff <= 2, diff        # (an observation whose error sits within rounding of the threshold may flip)
   assert abs(ao.error_statistics(True).rms - float(g["ao_rms_inliers"])) <= max(1e-6, endpoint_spread(g))
+
+
+@pytest.mark.parametrize("name", ["cfg1", "tiny_handeye", "tiny_rolling", "tiny_fisheye", "tiny_boards", "tiny_edge", "tiny_fishmix"])
+def test_lsmr_iteration_forms_agree(name):
+  """The LSMR iteration exists in three forms -- two launches (default: k_lsmr_fused2 / k_lsmr_gather3), three (k_lsmr_fused) and the
+  six launches of round 4 (one kernel per product + two scalar kernels): the same recurrences with different summation orders.
+  They must take the same trust-region trajectory wherever the reference's end point is defined to 1e-6 px, and stay inside the
+  reference's own spread elsewhere."""
+  g, rig = load_golden(name)
+  spread = float(np.abs(g["ba_pert_rms"] - g["ba_rms"]).max())
+  out = {}
+  with Handle(mirror(rig)) as h:
+    for mode in (0, 1, 2):
+      h.set_lsmr_fused(mode)
+      res = h.solve(g["x0"], tr_solver="lsmr")
+      e, v = h.reprojection_error(res.x)
+      out[mode] = (res.nfev, res.status, float(np.sqrt(np.mean(e[v] ** 2))), h.lsmr_iterations())
+  ref = float(g["ba_rms"])
+  for mode in (0, 1, 2):
+    assert abs(out[mode][2] - ref) <= max(1e-6, 3 * spread), (name, mode, out)
+  if spread < 3e-7:
+    assert out[0][:2] == out[1][:2] == out[2][:2] == (int(g["ba_nfev"]), int(g["ba_status"])), (name, out)
+    assert max(abs(out[m][2] - out[0][2]) for m in (1, 2)) <= 1e-6, (name, out)
