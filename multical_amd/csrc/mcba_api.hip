@@ -2181,7 +2181,7 @@ struct LsmrOps {
   // ... and in TWO launches: k_lsmr_fused2 carries the rotation + vector update of the previous step in its head, k_lsmr_gather3
   // folds its partials in a fifth wavefront beside the sums.  v is kept un-normalised (v = v_raw / alpha, alpha in the state).
   // State: k_lsmr_fused2 reads s0 (written by the gather / the initialisation) and writes s1; the gather reads s1 and writes s0.
-  int gather3_grid() const { return (gather_grid() + 3) / 4; }
+  int gather3_grid() const { return (gather_grid() + 3) / 4 + 1; }   // (+ the publisher workgroup, which has no tasks)
   void iteration_fused2(double* s0, double* s1, double* u, double* v, double* vraw, unsigned long long call, bool first_iteration) {
     const Dims& d = h->d;
     const double* vpart = h->ls_vpart.p;
@@ -2192,7 +2192,8 @@ struct LsmrOps {
                         bpart(), nblk, s0, s1, vpart, nv, h->ls_hbar.p, h->ls_x.p, h->ls_h.p);
     const double* upart = h->ls_partial.p;
     const double* xpart = h->ls_xpart.p;
-    int nu = nblk, nx = nblk;
+    // (the vector update is spread 64 entries per workgroup: only the first ceil(n / 64) workgroups hold a part of |x|^2)
+    int nu = nblk, nx = std::max(1, std::min(nblk, (d.n + 63) / 64));
     if (sharded()) {
       double* two = h->ls_out.p + 4;
       hipLaunchKernelGGL(k_lsmr_shard_fold_a2, dim3(1), dim3(LSG_THREADS), 0, h->stream, upart, nu, xpart, nx, two);
@@ -2349,7 +2350,9 @@ static void solve_lsmr(mcba_handle h, double* x_inout, const mcba_options* opt, 
   ensure_view_first(h);
   const size_t m = 2 * (size_t)h->n_inliers;
   const int NL = 6 * d.NPB + d.KI;
-  LsmrOps op{h, std::max(1, std::min(2048, d.views())), (NL + 1) & ~1, m};
+  // (persistent single-wave workgroups of the product kernels; MCBA_LSMR_GRID: debug switch for grid experiments)
+  static const int lsmr_grid = dbg_switch("MCBA_LSMR_GRID") ? std::max(64, atoi(dbg_switch("MCBA_LSMR_GRID"))) : 2048;
+  LsmrOps op{h, std::max(1, std::min(lsmr_grid, d.views())), (NL + 1) & ~1, m};
   for (DevBuf<double>* b : {&h->ls_u, &h->ls_ua, &h->ls_ub})
     if (b->n < std::max<size_t>(m, 2)) b->alloc(std::max<size_t>(m, 2), false);
   if (h->ls_part.n < (size_t)std::max(d.views(), 1) * op.part_stride) h->ls_part.alloc((size_t)std::max(d.views(), 1) * op.part_stride, true);

@@ -167,6 +167,25 @@ __device__ __forceinline__ bool many_writer(int lane) {
   return (lane & unused) == 0 && many_index(lane) < N;
 }
 
+// sum of a[0 .. n) over the lanes of ONE wavefront (lane L adds L, L + 64, ..), B loads in flight per lane: a plain
+// "for (i = lane; i < n; i += 64) s += a[i]" waits for every load before it issues the next -- 32 dependent round trips of
+// ~0.7 us for 2048 partials, which is what made the heads of the first fused LSMR kernels cost 6 - 10 us (round 5 trace).
+// n >= 1.  Result in every lane.
+template <int B>
+__device__ __forceinline__ double wave_fold_batched(const double* __restrict__ a, int n, int lane) {
+  double s = 0.0;
+  for (int i0 = lane; i0 < n; i0 += 64 * B) {
+    double v[B];
+#pragma unroll
+    for (int k = 0; k < B; ++k) v[k] = a[min(i0 + 64 * k, n - 1)];   // (clamped index: unconditional, independent loads)
+#pragma unroll
+    for (int k = 0; k < B; ++k)
+      if (i0 + 64 * k < n) s += v[k];
+  }
+  s = wave_sum(s);
+  return __shfl(s, 0, 64);
+}
+
 // (Fusing the "sum the per-block partials" launch into the producing kernel with the threadfence + ticket-counter idiom
 //  was measured and rejected on this chip: an agent-scope release is an L2 write-back on a multi-XCD part and ~75 ns per
 //  same-address atomic serialises 500-1000 tickets into 40-90 us.  Single-GPU solves copy the partials to the host with
@@ -799,11 +818,11 @@ __global__ __launch_bounds__(64) void k_lsmr_fused(Dims d, Tables t, const int32
 
 // ---------------------------------------------------------------------------------------------------------------
 // k_lsmr_fused2: k_lsmr_fused + the scalar recurrence and the vector update of the PREVIOUS Golub-Kahan step in its head, so that
-// an LSMR iteration is TWO launches (k_lsmr_fused2 -> k_lsmr_gather3).  Every workgroup (one wavefront), redundantly and with
-// bit-identical results: fold the |v_raw|^2 partials of the last gather -> alpha, the plane rotations and the update
-// coefficients (lsmr_state_rotate); workgroup 0 publishes the state (in: lsIn, written by the gather; out: lsOut -- double
-// buffer, see k_lsmr_gather3).  v is never stored normalised: v = v_raw / alpha is formed where it is read.  The vector update
-// h_bar, x, h (n entries) is spread over the workgroups, 64 entries each; xpart[workgroup] = its part of |x|^2.
+// an LSMR iteration is TWO launches (k_lsmr_fused2 -> k_lsmr_gather3).  Every workgroup (one wavefront) folds the |v_raw|^2
+// partials of the last gather and forms alpha and 1 / alpha (redundantly, bit-identical); the plane rotations, the update
+// coefficients (lsmr_state_rotate) and the vector update h_bar, x, h run in the TAIL of the workgroups that own a 64-entry slice
+// of the vectors, xpart[slice] = its part of |x|^2, and the last workgroup publishes the state (in: lsIn, written by the gather;
+// out: lsOut -- double buffer, see k_lsmr_gather3).  v is never stored normalised: v = v_raw / alpha is formed where it is read.
 // ---------------------------------------------------------------------------------------------------------------
 template <int ND, int FISH, int MOTION, bool OPTK, bool ROBUST>
 __global__ __launch_bounds__(64) void k_lsmr_fused2(Dims d, Tables t, const int32_t* __restrict__ first,
@@ -819,45 +838,25 @@ __global__ __launch_bounds__(64) void k_lsmr_fused2(Dims d, Tables t, const int3
   __shared__ uint16_t pidx[LIN_MAX_POINTS];
   __shared__ double vp[NPC], wl[NS], sl[NS];
   const int lane = threadIdx.x;
+  const int last = (int)gridDim.x - 1;
   if (lsIn[LS_ISTOP] != 0.0) {   // stopped by the tests of the last gather: hand the flag on, leave x as it is
-    if (blockIdx.x == 0 && lane == 0) lsOut[LS_ISTOP] = lsIn[LS_ISTOP];
+    if ((int)blockIdx.x == last && lane == 0) lsOut[LS_ISTOP] = lsIn[LS_ISTOP];
     return;
   }
-  double alpha, inv_alpha, inv_beta_old;
-  {
-    // ---- head: rotation + vector update of the step whose v_raw the last gather produced --------------------------------
-    double L[LS_NSLOTS];
-#pragma unroll
-    for (int k = 0; k < LS_NSLOTS; ++k) L[k] = lsIn[k];
-    const bool pending = L[LS_PENDING] != 0.0;
-    double xsq = 0.0;
-    if (pending) {
-      double s = 0.0;
-      for (int i = lane; i < nv; i += 64) s += vpart[i];
-      s = wave_sum(s);
-      const double v2 = __shfl(s, 0, 64);
-      lsmr_state_rotate(L, v2);
-      L[LS_PENDING] = 0.0;
-      const double ia = L[LS_INV_ALPHA], c_hbar = L[LS_C_HBAR], c_x = L[LS_C_X], c_h = L[LS_C_H];
-      for (int i = blockIdx.x * 64 + lane; i < d.n; i += gridDim.x * 64) {
-        const double vi = vin[i] * ia;
-        const double hb = c_hbar * hbar[i] + hv[i];
-        hbar[i] = hb;
-        const double xi = xv[i] + c_x * hb;
-        xv[i] = xi;
-        hv[i] = c_h * hv[i] + vi;
-        xsq += d.entry_weight(i) * (xi * xi);
-      }
+  // ---- head: ONLY what the product needs -- alpha and 1 / alpha, the first two operations of lsmr_state_rotate -- in every
+  // workgroup; the rest of the recurrence, the vector update and the state go to the TAIL of the workgroups that own a slice of
+  // the vectors (the last ones of the grid: the active-view list is largest-first, so they hold the lightest views).  The full
+  // recurrence in the head of every workgroup was 6 us on the critical path of the launch (round 5 trace).
+  const bool pending = lsIn[LS_PENDING] != 0.0;
+  double alpha = lsIn[LS_ALPHA], inv_alpha = lsIn[LS_INV_ALPHA], v2 = 0.0;
+  const double inv_beta_old = lsIn[LS_INV_BETA];
+  if (pending) {
+    v2 = wave_fold_batched<4>(vpart, nv, lane);
+    inv_alpha = 1.0;
+    if (lsIn[LS_SKIPV] == 0.0) {   // (lsmr_state_rotate: the same two operations, the same rounding)
+      alpha = sqrt(v2);
+      if (alpha > 0) inv_alpha = 1.0 / alpha;
     }
-    xsq = wave_sum(xsq);
-    if (lane == 0) xpart[blockIdx.x] = xsq;
-    if (blockIdx.x == 0 && lane == 0) {
-#pragma unroll
-      for (int k = 0; k < LS_NSLOTS; ++k) lsOut[k] = L[k];
-    }
-    alpha = L[LS_ALPHA];
-    inv_alpha = L[LS_INV_ALPHA];
-    inv_beta_old = L[LS_INV_BETA];
   }
   const int n_active = t.active_views[0];
   double acc = 0.0;
@@ -962,6 +961,35 @@ __global__ __launch_bounds__(64) void k_lsmr_fused2(Dims d, Tables t, const int3
   }
   const double tot = wave_sum(acc);
   if (lane == 0) partial[blockIdx.x] = tot;
+  // ---- tail (slice owners): rotation, vector update h_bar, x, h of slice j = entries j 64 + lane (+ multiples of 64 gridDim), the
+  // slice's part of |x|^2; the last workgroup publishes the state
+  const int j = last - (int)blockIdx.x;
+  if (j * 64 < d.n || j == 0) {
+    double L[LS_NSLOTS];
+#pragma unroll
+    for (int k = 0; k < LS_NSLOTS; ++k) L[k] = lsIn[k];
+    double xsq = 0.0;
+    if (pending) {
+      lsmr_state_rotate(L, v2);
+      L[LS_PENDING] = 0.0;
+      const double ia = L[LS_INV_ALPHA], c_hbar = L[LS_C_HBAR], c_x = L[LS_C_X], c_h = L[LS_C_H];
+      for (int i = j * 64 + lane; i < d.n; i += gridDim.x * 64) {
+        const double vi = vin[i] * ia;
+        const double hb = c_hbar * hbar[i] + hv[i];
+        hbar[i] = hb;
+        const double xi = xv[i] + c_x * hb;
+        xv[i] = xi;
+        hv[i] = c_h * hv[i] + vi;
+        xsq += d.entry_weight(i) * (xi * xi);
+      }
+    }
+    xsq = wave_sum(xsq);
+    if (lane == 0) xpart[j] = xsq;
+    if (j == 0 && lane == 0) {
+#pragma unroll
+      for (int k = 0; k < LS_NSLOTS; ++k) lsOut[k] = L[k];
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -2374,7 +2374,15 @@ __global__ __launch_bounds__(256) void k_lsmr_update(int n, double inv_alpha, do
 constexpr int LSG_THREADS = 256;
 __device__ __forceinline__ double lsmr_fold256(const double* __restrict__ a, int n, double* scratch) {
   double s = 0.0;
-  for (int i = threadIdx.x; i < n; i += LSG_THREADS) s += a[i];
+  constexpr int FB = 8;   // loads in flight per thread (see wave_fold_batched)
+  for (int i0 = threadIdx.x; i0 < n; i0 += LSG_THREADS * FB) {
+    double v[FB];
+#pragma unroll
+    for (int k = 0; k < FB; ++k) v[k] = a[min(i0 + LSG_THREADS * k, n - 1)];
+#pragma unroll
+    for (int k = 0; k < FB; ++k)
+      if (i0 + LSG_THREADS * k < n) s += v[k];
+  }
   const double t = block_reduce<false>(s, scratch);
   __shared__ double bc;
   if (threadIdx.x == 0) bc = t;
@@ -2507,9 +2515,11 @@ __global__ __launch_bounds__(LSG_THREADS) void k_lsmr_gather2(Dims d, const doub
 }
 
 // Two-launch iteration (k_lsmr_fused2 -> k_lsmr_gather3): the gather of k_lsmr_gather2 with
-//   * a FIFTH wavefront per workgroup that does the head (fold of the |uhat|^2 and |x|^2 partials, stopping tests, beta) WHILE the
-//     four task wavefronts form their sums over the per-view partials -- the sums do not depend on beta; one barrier, then the
-//     finish  v_raw[i] = D_i (sum / beta) - beta (v_old[i] / alpha)   (v is kept un-normalised: 1 / alpha comes from the state);
+//   * a FIFTH wavefront per workgroup that folds the |uhat|^2 partials into beta WHILE the four task wavefronts form their sums
+//     over the per-view partials -- the sums do not depend on beta; one barrier, then the finish
+//     v_raw[i] = D_i (sum / beta) - beta (v_old[i] / alpha)   (v is kept un-normalised: 1 / alpha comes from the state);
+//   * the stopping tests of the previous iteration (|x|^2 partials, lsmr_state_test) and the state only in ONE extra workgroup
+//     that has no tasks (the last one): nobody waits for them inside the kernel;
 //   * per-workgroup partials of |v_raw|^2 (vpart[workgroup]) for the head of the next k_lsmr_fused2 instead of n squares.
 // State: in = lsIn (written by k_lsmr_fused2), out = lsOut.
 constexpr int LSG3_THREADS = 320;
@@ -2528,28 +2538,31 @@ __global__ __launch_bounds__(LSG3_THREADS) void k_lsmr_gather3(Dims d, const dou
   const int nfe = lsmr_gather_frame_entries(d), ngen = d.n - nfe;
   const int CB = d.C * d.B, npc = 6 * d.NPB;
   const int task = (int)blockIdx.x * 4 + wave;
+  const bool publisher = blockIdx.x == gridDim.x - 1;   // one extra workgroup without tasks: stopping tests + state (off the others' path)
   // ---- phase 1: sums (task wavefronts) || head (fifth wavefront) ------------------------------------------------------------
   double sum = 0.0, fsum[3] = {0.0, 0.0, 0.0};
   int kind = 0, gi = -1;   // kind 1: general entry gi (lane 0 finishes it); kind 2: frame task (lanes with l16 == 0, entries g, g + 4, g + 8)
   const int DFm = d.motion == MOTION_ROLLING ? 12 : 6, g16 = lane >> 4, l16 = lane & 15;
   int fl = -1;
   if (wave == 4) {
-    double su = 0.0, sx = 0.0;
-    for (int i = lane; i < nu; i += 64) su += upart[i];
-    for (int i = lane; i < nx; i += 64) sx += xpart[i];
-    su = wave_sum(su);
-    sx = wave_sum(sx);
-    const double u2 = __shfl(su, 0, 64), x2 = __shfl(sx, 0, 64);
-    double L[LS_NSLOTS];
-#pragma unroll
-    for (int k = 0; k < LS_NSLOTS; ++k) L[k] = lsIn[k];
-    const int istop = L[LS_ITN] > 0.0 ? lsmr_state_test(L, x2) : 0;
-    if (istop != 0) L[LS_ISTOP] = (double)istop;
-    else lsmr_state_beta(L, u2);
-    L[LS_PENDING] = 1.0;
+    // every workgroup: beta = |uhat| and 1 / beta (lsmr_state_beta), nothing else -- the tasks do not wait for the stopping tests
+    // (what a stopped iteration writes is never read: the next k_lsmr_fused2 returns on the flag)
+    const double inv_alpha_cur = lsIn[LS_INV_ALPHA];
+    const double u2 = wave_fold_batched<16>(upart, nu, lane);
+    const double beta = sqrt(u2);
     if (lane == 0) {
-      head[0] = L[LS_BETA]; head[1] = L[LS_INV_BETA]; head[2] = L[LS_SKIPV]; head[3] = L[LS_ISTOP]; head[4] = L[LS_INV_ALPHA];
-      if (blockIdx.x == 0) {
+      head[0] = beta; head[1] = beta > 0 ? 1.0 / beta : 1.0; head[2] = beta > 0 ? 0.0 : 1.0; head[3] = 0.0; head[4] = inv_alpha_cur;
+    }
+    if (publisher) {
+      double L[LS_NSLOTS];
+#pragma unroll
+      for (int k = 0; k < LS_NSLOTS; ++k) L[k] = lsIn[k];
+      const double x2 = wave_fold_batched<4>(xpart, nx, lane);
+      const int istop = L[LS_ITN] > 0.0 ? lsmr_state_test(L, x2) : 0;
+      if (istop != 0) L[LS_ISTOP] = (double)istop;
+      else lsmr_state_beta(L, u2);
+      L[LS_PENDING] = 1.0;
+      if (lane == 0) {
 #pragma unroll
         for (int k = 0; k < LS_NSLOTS; ++k) lsOut[k] = L[k];
         __hip_atomic_store(host_word, lsmr_progress_word(call, istop, (long long)L[LS_ITN]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -2611,7 +2624,7 @@ __global__ __launch_bounds__(LSG3_THREADS) void k_lsmr_gather3(Dims d, const dou
         }
         if (local >= 0) {
           const int total = na * nb;
-          constexpr int UNR = 8;
+          constexpr int UNR = 16;   // (a board-pose entry sums Fl C parts -- 4000 at the north-star rig: 16 loads in flight per lane = 4 round trips)
           for (int e0 = lane; e0 < total; e0 += 64 * UNR) {
             double v[UNR];
 #pragma unroll
@@ -2628,8 +2641,21 @@ __global__ __launch_bounds__(LSG3_THREADS) void k_lsmr_gather3(Dims d, const dou
       sum = wave_sum(sum);
     }
   }
+  // (what the finish reads besides beta is requested in front of the barrier: one round trip less behind it)
+  double pvo[3] = {0.0, 0.0, 0.0}, pds[3] = {0.0, 0.0, 0.0};
+  if (kind == 2) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int e = min(g16 + 4 * q, DFm - 1);
+      const int chain = e / 6, i = d.off_motion + chain * 6 * d.F + 6 * (d.f0 + fl) + e % 6;
+      pvo[q] = vold[i];
+      pds[q] = dscale[i];
+    }
+  } else if (kind == 1) {
+    pvo[0] = vold[gi];
+    pds[0] = dscale[gi];
+  }
   __syncthreads();
-  if (head[3] != 0.0) return;
   // ---- phase 2: finish with beta ------------------------------------------------------------------------------------------------
   const double beta = head[0], inv_beta = head[1], inv_alpha = head[4];
   const bool skip = head[2] != 0.0;
@@ -2640,8 +2666,8 @@ __global__ __launch_bounds__(LSG3_THREADS) void k_lsmr_gather3(Dims d, const dou
       const int e = g16 + 4 * q;
       if (e < DFm && l16 == 0) {
         const int chain = e / 6, i = d.off_motion + chain * 6 * d.F + 6 * (d.f0 + fl) + e % 6;
-        const double vn = vold[i] * inv_alpha;
-        const double val = skip ? vn : dscale[i] * (fsum[q] * inv_beta) - beta * vn;
+        const double vn = pvo[q] * inv_alpha;
+        const double val = skip ? vn : pds[q] * (fsum[q] * inv_beta) - beta * vn;
         vout[i] = val;
         nrm[i] = val * val;
         vsq += val * val;
@@ -2651,8 +2677,8 @@ __global__ __launch_bounds__(LSG3_THREADS) void k_lsmr_gather3(Dims d, const dou
     if (ex.raw_shared) {
       vout[gi] = sum;          // (frame-sharded: summed over the ranks, finished by k_lsmr_shard_finish)
     } else {
-      const double vn = vold[gi] * inv_alpha;
-      const double val = skip ? vn : dscale[gi] * (sum * inv_beta) - beta * vn;
+      const double vn = pvo[0] * inv_alpha;
+      const double val = skip ? vn : pds[0] * (sum * inv_beta) - beta * vn;
       vout[gi] = val;
       nrm[gi] = val * val;
       vsq = val * val;
