@@ -75,6 +75,26 @@ def collect_round(tag, root):
         out.setdefault(k, {}).update(d)
   if out:
     json.dump(out, open(os.path.join(HERE, f"{tag}_solve_pmc.json"), "w"), indent=1, sort_keys=True)
+  # round 5: the LSMR iteration of the default solver (kernel statistics of the three forms, PMC averages of its kernels)
+  st = first(os.path.join(root, "lsmr_trace", "**", "lsmr_kernel_stats.csv"))
+  if st:
+    shutil.copy(st, os.path.join(HERE, f"{tag}_lsmr_kernel_stats.csv"))
+  out = {}
+  for c in ("FETCH_SIZE", "WRITE_SIZE", "valu"):
+    f = first(os.path.join(root, f"lsmr_pmc_{c}", "**", "*_counter_collection.csv"))
+    if f:
+      for k, d in pmc_averages(f).items():
+        if "lsmr" in k:
+          out.setdefault(k, {}).update(d)
+  if out:
+    json.dump(out, open(os.path.join(HERE, f"{tag}_lsmr_pmc.json"), "w"), indent=1, sort_keys=True)
+  for src, dst in (("lsmr_iteration.log", f"{tag}_lsmr_iteration.txt"), ("bench_cfg4.json", f"{tag}_bench_cfg4.json"),
+                   ("workspace_lsmr_cfg3.log", f"{tag}_workspace_calibrate_lsmr_cfg3.txt"),
+                   ("workspace_lsmr_cfg4.log", f"{tag}_workspace_calibrate_lsmr_cfg4.txt"),
+                   ("workspace_lsmr_cfg2.log", f"{tag}_workspace_calibrate_lsmr_cfg2.txt")):
+    p = os.path.join(root, src)
+    if os.path.exists(p) and os.path.getsize(p) > 0:
+      shutil.copy(p, os.path.join(HERE, dst))
   for src, dst in (("bench.json", f"{tag}_bench.json"), ("lin_phases.log", f"{tag}_linearize_phases.txt"), ("lin_cfgs.log", f"{tag}_linearize_configs.txt"),
                    ("frame_groups.log", f"{tag}_frame_groups.txt"), ("chol_phases.log", f"{tag}_cholesky_phases.txt"),
                    ("chol_paths.log", f"{tag}_cholesky_paths.txt"), ("init.log", f"{tag}_initialise_poses.txt"),

@@ -1,0 +1,35 @@
+# Round-5 evidence, ALL of it from the commit that is checked out:  bash profiles/scripts/collect_r05.sh   (on the GPU box)
+# Raw rocprofv3 output goes to gpurun_out/r5p (scratch); `python profiles/make_summary.py r05 gpurun_out/r5p` condenses it into the
+# tracked profiles/r05_* files: kernel statistics of the bench (evaluation step) and of the LSMR iteration in its three forms, PMC
+# averages of every kernel of both, the native solver's LM timeline, Workspace.calibrate under both solvers, the lsmr-mode table.
+set -x
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r5p; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+export PYTHONPATH=$R:$R/tests
+B="python $R/bench.py --no-scipy-mode --no-lsmr-mode"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o trace -- $B --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_traced.json 2> $O/bench_traced.err
+# PMC: counters in their own passes, kernel trace only (no other trace domain)
+timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc -o pmc_fetch -- $B --steps 30 --warmup 5 --repeats 1 --no-cpu-baseline --no-solve > /dev/null 2> $O/pmc1.err
+timeout 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc -o pmc_write -- $B --steps 30 --warmup 5 --repeats 1 --no-cpu-baseline --no-solve > /dev/null 2> $O/pmc2.err
+timeout 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU --kernel-trace --output-format csv -d $O/pmc -o pmc_mfma -- $B --steps 30 --warmup 5 --repeats 1 --no-cpu-baseline --no-solve > /dev/null 2> $O/pmc3.err
+# the LSMR iteration (default solver): kernel trace of the three forms + PMC of the kernels
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/lsmr_trace -o lsmr -- python $R/profiles/scripts/prof_lsmr_iter.py cfg3 > $O/lsmr_traced.log 2>&1
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/lsmr_pmc_$C -o pmc -- python $R/profiles/scripts/prof_lsmr_iter.py cfg3 > $O/lsmr_pmc_$C.log 2>&1
+done
+timeout 200 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU --kernel-trace --output-format csv -d $O/lsmr_pmc_valu -o pmc -- python $R/profiles/scripts/prof_lsmr_iter.py cfg3 > $O/lsmr_pmc_valu.log 2>&1
+for CFG in cfg3 cfg4; do
+  timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/solve_$CFG -o solve -- python $R/profiles/scripts/prof_cfg.py $CFG > $O/solve_$CFG.log 2>&1
+done
+cd $R
+timeout 120 python profiles/scripts/prof_lsmr_iter.py cfg3 cfg4 cfg5 cfg2 > $O/lsmr_iteration.log 2>&1; cut -c1-400 $O/lsmr_iteration.log
+timeout 400 python bench.py > $O/bench.json 2> $O/bench.err
+tail -c 300 $O/bench.json
+timeout 200 python bench.py --config cfg4 --no-cpu-baseline --no-scipy-mode > $O/bench_cfg4.json 2> $O/bench_cfg4.err
+for CFG in cfg3 cfg4 cfg2; do
+  MCBA_TIMING=1 timeout 100 python profiles/scripts/prof_workspace.py $CFG --solver native > $O/workspace_$CFG.log 2>&1; grep "calibrate ms" $O/workspace_$CFG.log
+  timeout 100 python profiles/scripts/prof_workspace.py $CFG --solver lsmr > $O/workspace_lsmr_$CFG.log 2>&1; grep "calibrate ms" $O/workspace_lsmr_$CFG.log
+done
+LSMR_NO_SCIPY=1 timeout 300 python profiles/scripts/prof_lsmr.py > $O/lsmr_mode.md 2> $O/lsmr_mode.err; tail -5 $O/lsmr_mode.md
+timeout 500 python profiles/scripts/prof_parity_table.py > $O/parity_table.md 2> $O/parity_table.err; cp gpurun_out/parity_table.json $O/ 2>/dev/null
+ls $O

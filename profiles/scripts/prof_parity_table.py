@@ -48,7 +48,7 @@ for name in SMALL + BIG:
     t_n = time.time() - t0
     h.set_log(None)
     rms_n = rms_of(h, nat.x)
-    try:      # L: scipy's TRF + LSMR step restated on the device (not for boards=True)
+    try:      # L: scipy TRF + LSMR step restated on the device
       t0 = time.time()
       lsm = h.solve(g["x0"], tolerance=kw.get("tolerance", 1e-4), loss=loss, f_scale=f_scale, max_iterations=kw.get("max_iterations", 100),
                     tr_solver="lsmr")
@@ -81,7 +81,7 @@ print("residual function (oracle/make_pert.py): the resolution to which the refe
 print("optimum of the reference's residual function (tight polish).  B = the product's scipy mode (`solver=\"scipy\"`,")
 print("`dropin.install(mode=\"scipy\")`): the reference's own scipy driver on the HIP `fun` + analytic `jac`; N = the native HIP")
 print("solver (`solver=\"native\"`); L = `solver=\"lsmr\"`: scipy's TRF driver and its LSMR trust-region step restated on the device")
-print("(`mcba_options.tr_solver = MCBA_TR_LSMR`; not for `boards=True`).  |d| columns are |RMS - reference RMS|.\n")
+print("(`mcba_options.tr_solver = MCBA_TR_LSMR`: the product DEFAULT since round 5).  |d| columns are |RMS - reference RMS|.\n")
 print("| fixture | loss | reference RMS | nfev | spread (max) | spread (sigma) | N runs | converged RMS | B: RMS | B: nfev | B: \\|d\\| | B within 1e-6 px | N: RMS | N: nfev | N: \\|d\\| | N within 1e-6 px | L: RMS | L: nfev | L: status (ref) | L: \\|d\\| | L within max(1e-6, spread) | B: s | N: ms | L: ms |")
 print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
 for r in rows:

@@ -8,6 +8,9 @@ if "--float32" in sys.argv:      # corners as cv2 detects them and as the refere
   import numpy as np
   rig.points = rig.points.astype(np.float32)
   print("point table: float32")
+if "--solver" in sys.argv:      # "lsmr" (the product default: the reference's end point) or "native" (exact steps)
+  calibration.set_solver(sys.argv[sys.argv.index("--solver") + 1])
+print("solver:", calibration.get_solver())
 c = calibration.from_rig(rig)
 ws = Workspace(c); ws.calibrate(cameras=rig.optimize["cameras"], camera_poses=rig.optimize["camera_poses"])
 calibration.handle_cache.clear()
