@@ -297,8 +297,61 @@ def main():
   ms_per_step = dt / args.steps * 1e3
   value = args.steps / dt                               # evaluations per second of the ONE fixed rig, whole job
 
+  # ---- everything below adds detail to the line; `value` above is the contract's number -------------------------------------
+  # N > 1 runs code that has never executed on more than one GPU (native RCCL with several ranks, the frame-sharded solvers over
+  # xGMI): a WATCHDOG makes sure a hang there cannot cost the measurement -- past the deadline rank 0 prints the line with the
+  # sections that did finish (marked "incomplete") and every rank leaves.
+  weak = parity_route = step_comm = scipy_mode = roofline = host_ms_per_step = None
+  extra = {}
+  n_flops_obs = [None]
+
+  def assemble(incomplete=None):
+    C_, B_ = rig.valid.shape[0], rig.valid.shape[2]
+    par = "single GPU"
+    if world > 1:
+      par = (f"ONE {C_} x {F_rig} x {B_} rig frame-sharded x{world} ({[b - a for a, b in shards]} frames per GPU), " +
+             ("native RCCL all-reduce (librccl %d)" % rccl_version if native else f"torch.distributed ({backend}) all-reduce hook"))
+    o = dict(metric="residual+Jacobian evals/sec", value=value, unit="evals/s", n_gpus=world, steps=args.steps,
+             warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling="strong",
+             vs_baseline=None, dtype="f64", data="synthetic",
+             config=dict(workload=f"{rigdef['label']}; the whole rig on {world} GPU(s)",
+                         n_params=int(h.n_params), n_slots=n_slots, n_observations=int(n_obs),
+                         observation_fill=float(n_obs) / n_slots,   # evals/s is linear in observations, not in slots
+                         parallelism=par, native_rccl=bool(native) if world > 1 else None, rccl_version=rccl_version,
+                         device=h.device_info()),
+             obs_per_s=value * float(n_obs),            # observations linearised per second, whole job
+             timed_regions_ms=[t * 1e3 for t in region_times], repeats=len(region_times))
+    if n_flops_obs[0] is not None:   # the STEP (all kernels of an evaluation + launch gaps + collective) against the FP64 peak of N GPUs
+      o["step_roofline_frac"] = n_obs * n_flops_obs[0] / (ms_per_step * 1e-3) / 1e12 / (FP64_PEAK_TFLOPS * world)
+    if host_ms_per_step is not None:
+      o["host_boundary"] = dict(ms_per_step=host_ms_per_step, evals_per_s=1e3 / host_ms_per_step,
+                                note="same evaluation with x uploaded and the cost downloaded on every call")
+    if roofline is not None:
+      o["roofline"] = roofline
+    o.update(extra)
+    for key, val in (("parity_route", parity_route), ("weak_scaling", weak), ("step_collectives", step_comm), ("scipy_mode", scipy_mode)):
+      if val is not None:
+        o[key] = val
+    if incomplete:
+      o["incomplete"] = incomplete
+    return o
+
+  watchdog = None
+  if world > 1:
+    import threading
+    deadline_s = float(os.environ.get("MCBA_BENCH_DEADLINE_S", "420"))
+
+    def expire():
+      say(f"WATCHDOG: sections after the timed region did not finish within {deadline_s:.0f} s -- printing what exists and leaving")
+      if rank == 0:
+        print(json.dumps(assemble(f"watchdog after {deadline_s:.0f} s: a multi-GPU section hung; `value` and the listed sections are complete")),
+              flush=True)
+      os._exit(0 if rank == 0 else 7)
+    watchdog = threading.Timer(deadline_s, expire)
+    watchdog.daemon = True
+    watchdog.start()
+
   # ---- weak scaling (N > 1): every rank owns a full F_rig-frame shard of one N-times-longer rig --------------------
-  weak = None
   if world > 1 and not args.no_weak:
     wshard = (rank * F_rig, (rank + 1) * F_rig)
     wrig, wcalib, hw, wnative = make_handle(F_rig * world, wshard)
@@ -321,6 +374,7 @@ def main():
   d = h.problem
   NV = (12 if d.motion == 1 else 6) + (4 + d.n_dist if d.optimize & 8 else 0) + 1
   flops_per_obs = 2 * NV * (NV + 1) + 420 + (260 if d.motion == 1 else 0)
+  n_flops_obs[0] = flops_per_obs
   alg_flops = n_obs_local * flops_per_obs
   # The fused pass is FP64-bound (~23 flop per algorithmic byte against a ridge of ~10 flop/B), so the
   # roofline that bounds k_linearize is the FP64 matrix/vector peak; the HBM view of the same launch is kept alongside.
@@ -360,7 +414,6 @@ def main():
     return float(torch.sqrt(sq[0] / sq[1]).item())
 
   # ---- LM iterations/s and final RMS: one full bundle adjustment of the same problem (not part of `value`) --------
-  extra = {}
   ref_end = reference_endpoint(args.config)
   if not args.no_solve:
     # the default-tolerance solve of the rig with the EXACT-step solver (scipy's defaults: ftol 1e-4), repeated: median of the
@@ -399,7 +452,6 @@ def main():
                                                  bytes_per_trial_step=8 * doubles / max(lres.nfev - 1, 1),
                                                  message_doubles=sorted(set(abs(s) for s in sizes)))
   # collectives of ONE evaluation step (N > 1)
-  step_comm = None
   if world > 1:
     h.allreduce_stats(reset=True)
     step()
@@ -408,7 +460,6 @@ def main():
     step_comm = dict(allreduce_calls=calls, allreduce_bytes=8 * doubles, message_doubles=[abs(s) for s in sizes])
 
   # ---- PARITY ROUTE: the solver that reproduces the reference's END POINT, on the whole rig (single GPU or frame-sharded) -----
-  parity_route = None
   if not args.no_lsmr_mode and not args.no_solve:
     h.solve(x0, tr_solver="lsmr")                                   # warm-up (buffers, first-use allocations)
     runs = []
@@ -446,7 +497,6 @@ def main():
                                           fp64_frac=fl / (parity_route["us_per_lsmr_iteration"] * 1e-6) / 1e12 / FP64_PEAK_TFLOPS)
 
   # ---- the reference's own solver on the device functions (product mode solver="scipy"), beside the native solve -----
-  scipy_mode = None
   if world == 1 and not args.no_scipy_mode and args.config == "cfg3":
     srig = synthetic.make_rig("cfg3", frames=args.scipy_frames)
     sc = calibration.from_rig(srig)
@@ -470,36 +520,11 @@ def main():
                              "optimization/calibration.py:209-210 on mcba_residuals + mcba_jacobian: the reference's end point "
                              "(profiles/parity_table.md), scipy's LSMR on the host")
 
+  if watchdog is not None:
+    watchdog.cancel()
   out = None
   if rank == 0:
-    C_, B_ = rig.valid.shape[0], rig.valid.shape[2]
-    par = "single GPU"
-    if world > 1:
-      par = (f"ONE {C_} x {F_rig} x {B_} rig frame-sharded x{world} ({[b - a for a, b in shards]} frames per GPU), " +
-             ("native RCCL all-reduce (librccl %d)" % rccl_version if native else f"torch.distributed ({backend}) all-reduce hook"))
-    out = dict(metric="residual+Jacobian evals/sec", value=value, unit="evals/s", n_gpus=world, steps=args.steps,
-               warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling="strong",
-               vs_baseline=None, dtype="f64", data="synthetic",
-               config=dict(workload=f"{rigdef['label']}; the whole rig on {world} GPU(s)",
-                           n_params=int(h.n_params), n_slots=n_slots, n_observations=int(n_obs),
-                           observation_fill=float(n_obs) / n_slots,   # evals/s is linear in observations, not in slots
-                           parallelism=par, native_rccl=bool(native) if world > 1 else None, rccl_version=rccl_version,
-                           device=h.device_info()),
-               obs_per_s=value * float(n_obs),            # observations linearised per second, whole job
-               step_roofline_frac=n_obs * flops_per_obs / (ms_per_step * 1e-3) / 1e12 / (FP64_PEAK_TFLOPS * world),   # the STEP
-               # (all kernels of an evaluation + launch gaps + collective), not just the dominant kernel, against the FP64 peak of N GPUs
-               timed_regions_ms=[t * 1e3 for t in region_times], repeats=len(region_times),
-               host_boundary=dict(ms_per_step=host_ms_per_step, evals_per_s=1e3 / host_ms_per_step,
-                                  note="same evaluation with x uploaded and the cost downloaded on every call"),
-               roofline=roofline, **extra)
-    if parity_route is not None:
-      out["parity_route"] = parity_route
-    if weak is not None:
-      out["weak_scaling"] = weak
-    if step_comm is not None:
-      out["step_collectives"] = step_comm
-    if scipy_mode is not None:
-      out["scipy_mode"] = scipy_mode
+    out = assemble()
     if world == 1 and not args.no_cpu_baseline and args.config == "cfg3":
       out["cpu_baseline"] = cpu_baseline()
       if ref_end is not None:

@@ -32,4 +32,8 @@ for CFG in cfg3 cfg4 cfg2; do
 done
 LSMR_NO_SCIPY=1 timeout 300 python profiles/scripts/prof_lsmr.py > $O/lsmr_mode.md 2> $O/lsmr_mode.err; tail -5 $O/lsmr_mode.md
 timeout 500 python profiles/scripts/prof_parity_table.py > $O/parity_table.md 2> $O/parity_table.err; cp gpurun_out/parity_table.json $O/ 2>/dev/null
-ls $O
+# condense ON THE BOX (gpurun copies back at most 64 MiB: the raw kernel traces are ~30 MB each) and keep only the summaries
+python profiles/make_summary.py r05 $O > $O/make_summary.log 2>&1
+mkdir -p $R/gpurun_out/r05 && cp profiles/r05_* profiles/hbm_traffic.json profiles/parity_table.md profiles/parity_table.json $R/gpurun_out/r05/ 2>/dev/null
+find $O -name "*_kernel_trace.csv" -delete; find $O -name "*_counter_collection.csv" -delete; find $O -name "*.db" -delete
+du -sh $R/gpurun_out; ls $R/gpurun_out/r05
