@@ -2537,8 +2537,10 @@ __global__ __launch_bounds__(LSG3_THREADS) void k_lsmr_gather3(Dims d, const dou
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nfe = lsmr_gather_frame_entries(d), ngen = d.n - nfe;
   const int CB = d.C * d.B, npc = 6 * d.NPB;
-  const int task = (int)blockIdx.x * 4 + wave;
+  // tasks are dealt round-robin over the workgroups (task = wave * (workgroups - 1) + workgroup): the heavy ones -- the entries
+  // outside the frame block come first and sum over hundreds to thousands of views -- land in different workgroups / CUs
   const bool publisher = blockIdx.x == gridDim.x - 1;   // one extra workgroup without tasks: stopping tests + state (off the others' path)
+  const int task = publisher ? 0x3fffffff : wave * ((int)gridDim.x - 1) + (int)blockIdx.x;
   // ---- phase 1: sums (task wavefronts) || head (fifth wavefront) ------------------------------------------------------------
   double sum = 0.0, fsum[3] = {0.0, 0.0, 0.0};
   int kind = 0, gi = -1;   // kind 1: general entry gi (lane 0 finishes it); kind 2: frame task (lanes with l16 == 0, entries g, g + 4, g + 8)
@@ -2624,7 +2626,7 @@ __global__ __launch_bounds__(LSG3_THREADS) void k_lsmr_gather3(Dims d, const dou
         }
         if (local >= 0) {
           const int total = na * nb;
-          constexpr int UNR = 16;   // (a board-pose entry sums Fl C parts -- 4000 at the north-star rig: 16 loads in flight per lane = 4 round trips)
+          constexpr int UNR = 8;
           for (int e0 = lane; e0 < total; e0 += 64 * UNR) {
             double v[UNR];
 #pragma unroll
