@@ -293,6 +293,46 @@ def test_native_rccl_single_rank_communicator(tmp_path):
   assert np.abs(r["x"] - r["x_ref"]).max() < 1e-7
 
 
+def _rccl_one_gpu_worker(rank, world, port, out):
+  sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+  import faulthandler
+  faulthandler.dump_traceback_later(150, exit=True)
+  import torch
+  import torch.distributed as dist
+  os.environ["MASTER_ADDR"] = "127.0.0.1"
+  os.environ["MASTER_PORT"] = str(port)
+  torch.cuda.set_device(0)                  # BOTH ranks on the one GPU of the test box
+  dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=60))
+  g, rig = load_golden("cfg1")
+  c = mirror(rig)
+  h = mdist.sharded_handle(c, native=True)  # asks for the library's own RCCL communicator; falls back to the hook if any rank fails
+  res = h.solve(c.param_vec)
+  if rank == 0:
+    np.savez(out, native=bool(h.native_allreduce), nfev=res.nfev, status=res.status, cost=res.cost)
+  h.close()
+  dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_native_rccl_with_two_ranks_on_one_gpu_falls_back_or_works(tmp_path):
+  """The native RCCL path has only ever run with ONE rank (one GPU per test box).  Two ranks on the SAME device: RCCL (NCCL 2.x ABI)
+  refuses a communicator whose ranks share a GPU ("duplicate GPU"), so `init_native_allreduce` must report failure on EVERY rank
+  (MIN over the success flags) and the handle must fall back to the torch.distributed hook -- the solve still matches the single
+  handle.  Should a future RCCL accept it, the native path must produce the same solve.  Either way: no hang, no silent divergence."""
+  import torch.multiprocessing as mp
+  from multical_amd.backend import Handle
+  out = str(tmp_path / "rccl_one_gpu.npz")
+  mp.spawn(_rccl_one_gpu_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+  sh = np.load(out)
+  g, rig = load_golden("cfg1")
+  c = mirror(rig)
+  with Handle(c) as h:
+    res = h.solve(c.param_vec)
+  print("native RCCL with two ranks on one device:", "accepted" if bool(sh["native"]) else "refused -> torch.distributed hook")
+  assert int(sh["nfev"]) == res.nfev and int(sh["status"]) == res.status
+  assert float(sh["cost"]) == pytest.approx(res.cost, rel=1e-10)
+
+
 def _rccl_world_worker(rank, world, port, name, out):
   sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
   import torch
