@@ -120,7 +120,7 @@ def test_lsmr_mode_reproduces_the_reference_end_point_at_full_size(cfg, record_p
   assert rms_native <= float(g["ba_rms"]) + max(1e-6, spread)
 
 
-@pytest.mark.parametrize("cfg", ["cfg3", "cfg5"])
+@pytest.mark.parametrize("cfg", ["cfg3", "cfg5", "cfg4"])
 def test_workspace_calibrate_at_full_size_against_the_reference(cfg):
   """Workspace.calibrate's outlier loop (workspace.py:228-247 -> calibration.py:254-268) at the stated size under solver="lsmr":
   the reference's inlier mask after three rounds, bit for bit, and its inlier RMS."""
