@@ -864,6 +864,11 @@ __global__ __launch_bounds__(64) void k_lsmr_fused2(Dims d, Tables t, const int3
     const int v = t.active_views[1 + vi];
     if (v < 0) continue;
     const int b = v % d.B, c = (v / d.B) % d.C, f = d.f0 + v / (d.B * d.C);
+    constexpr int NPB64 = LIN_MAX_POINTS / 64;
+    // the mask bytes of the first segment are requested in front of the parameter staging: one round trip for both
+    uint8_t inb[NPB64];
+#pragma unroll
+    for (int k = 0; k < NPB64; ++k) inb[k] = masked_load_row(t.inlier + (size_t)v * d.P, k * 64 + lane, d.P);
     if (lane < NPC + KI) {
       const int xi = local_to_x(d, f, c, b, lane);
       const double val = xi >= 0 ? dscale[xi] * (vin[xi] * inv_alpha) : 0.0;
@@ -882,11 +887,11 @@ __global__ __launch_bounds__(64) void k_lsmr_fused2(Dims d, Tables t, const int3
 #pragma unroll
     for (int k = 0; k < NS; ++k) sums[k] = 0.0;
     size_t out0 = (size_t)first[v];
-    constexpr int NPB64 = LIN_MAX_POINTS / 64;
     for (int seg0 = 0; seg0 < d.P; seg0 += LIN_MAX_POINTS) {
-      uint8_t inb[NPB64];
+      if (seg0 > 0) {
 #pragma unroll
-      for (int k = 0; k < NPB64; ++k) inb[k] = masked_load_row(t.inlier + (size_t)v * d.P, seg0 + k * 64 + lane, d.P);
+        for (int k = 0; k < NPB64; ++k) inb[k] = masked_load_row(t.inlier + (size_t)v * d.P, seg0 + k * 64 + lane, d.P);
+      }
       int count = 0;
 #pragma unroll
       for (int k = 0; k < NPB64; ++k) {
@@ -896,13 +901,26 @@ __global__ __launch_bounds__(64) void k_lsmr_fused2(Dims d, Tables t, const int3
         count += __popcll(m);
       }
       lds_fence();
+      // observation, board point and old uhat of the NEXT chunk are requested before the current one is evaluated (as in k_cost)
+      int p_cur = lane < count ? pidx[lane] : 0;
+      double2 ob_cur = t.obs[(size_t)v * d.P + p_cur];
+      double X_cur[3], X_nxt[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) X_cur[k] = t.board_points[3 * (size_t)(b * d.P + p_cur) + k];
+      const size_t o0 = count > 0 ? out0 : 0;   // (a segment without inliers behind the last residual must not read past the vector)
+      double2 old_cur = reinterpret_cast<const double2*>(u)[o0 + (lane < count ? lane : 0)];
       for (int base = 0; base < count; base += 64) {
-        const int i = base + lane;
+        const int i = base + lane, inx = i + 64;
+        const int p_nxt = inx < count ? pidx[inx] : p_cur;
+        const double2 ob_nxt = t.obs[(size_t)v * d.P + p_nxt];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) X_nxt[k] = t.board_points[3 * (size_t)(b * d.P + p_nxt) + k];
+        const double2 old_nxt = reinterpret_cast<const double2*>(u)[o0 + (inx < count ? inx : 0)];
         if (i < count) {
-          const int p = pidx[i];
+          const int p = p_cur;
           PointState<ND, ROLL> ps;
-          point_state<ND, FISH, ROLL, ROBUST>(d, t, v, c, b, p, t.obs[(size_t)v * d.P + p], ps);
-          double2 old = reinterpret_cast<const double2*>(u)[out0 + i];
+          point_state<ND, FISH, ROLL, ROBUST>(d, t, v, c, b, p, ob_cur, ps, X_cur);
+          double2 old = old_cur;
           old.x *= inv_beta_old;
           old.y *= inv_beta_old;
           double bterm[2] = {0.0, 0.0};
@@ -940,6 +958,11 @@ __global__ __launch_bounds__(64) void k_lsmr_fused2(Dims d, Tables t, const int3
             for (int k = 0; k < 3; ++k) bpart[3 * (out0 + i) + k] = w3[k];
           }
         }
+        p_cur = p_nxt;
+        ob_cur = ob_nxt;
+        old_cur = old_nxt;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) X_cur[k] = X_nxt[k];
       }
       out0 += (size_t)count;
       lds_fence();
