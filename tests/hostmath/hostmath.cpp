@@ -7,6 +7,7 @@
 // no CPU path.  Built by __graft_entry__.build() into tests/hostmath/_build/libmcba_hostmath.so.
 #include <cmath>
 #include <cstring>
+#include <stdexcept>
 #include <string>
 #include <vector>
 #include "../../multical_amd/csrc/mcba_lower.h"
@@ -115,6 +116,86 @@ void jacobian_t(Host& h, int row_nnz, double* vals, int32_t* cols) {
       for (int k = 0; k < 3; ++k) { o0[pos] = jp[k]; o1[pos] = jp[3 + k]; oc[pos] = base + k; ++pos; }
     }
   }
+}
+
+// The matrix-free Jacobian products of the lsmr mode, serially, with the device functions the kernels use (k_lsmr_jv / k_lsmr_jtu /
+// k_lsmr_fused*): per view w = That (v restricted to the view's pose blocks) | v_K, per observation  J v = row . w + jp . v_point,
+// and the adjoint  J^T u = That^T sum_p E_p^T u_p | sum_p K_p^T u_p | jp^T u  scattered through local_to_x.  Unscaled columns.
+template <int ND, int FISH, bool ROLL, bool OPTK>
+void lsmr_products_t(Host& h, const double* vin, const double* uin, double* jv, double* jtu) {
+  const Dims& d = h.hp.d;
+  constexpr int DE = ROLL ? 12 : 6, KI = OPTK ? 4 + ND : 0, NV = DE + KI + 1, NS = DE + KI;
+  const int NPC = 6 * d.NPB;
+  for (int i = 0; i < d.n; ++i) jtu[i] = 0.0;
+  Dims dl = d;
+  dl.loss = 0;
+  for (int v = 0; v < d.views(); ++v) {
+    const int b = v % d.B, c = (v / d.B) % d.C, fl = v / (d.B * d.C), f = d.f0 + fl;
+    double That[12][24], wl[NS], sums[NS];
+    for (int j = 0; j < NPC; ++j) {
+      double col[12];
+      view_column(d, h.t, f, c, b, j, col);
+      for (int a = 0; a < DE; ++a) That[a][j] = col[a];
+    }
+    for (int a = 0; a < DE; ++a) {
+      double s = 0.0;
+      for (int j = 0; j < NPC; ++j) {
+        const int xi = local_to_x(d, f, c, b, j);
+        if (xi >= 0) s += That[a][j] * vin[xi];
+      }
+      wl[a] = s;
+    }
+    for (int q = 0; q < KI; ++q) {
+      const int xi = local_to_x(d, f, c, b, NPC + q);
+      wl[DE + q] = xi >= 0 ? vin[xi] : 0.0;
+    }
+    for (int k = 0; k < NS; ++k) sums[k] = 0.0;
+    for (int p = 0; p < d.P; ++p) {
+      const size_t s = (size_t)v * d.P + p;
+      const int idx = h.t.obs_index[s];
+      if (idx < 0) continue;
+      PointState<ND, ROLL> ps;
+      point_state<ND, FISH, ROLL, false>(dl, h.t, v, c, b, p, h.t.obs[s], ps);
+      double bterm[2] = {0.0, 0.0};
+      const int gq = d.off_boards >= 0 ? d.off_boards + 3 * (h.t.board_off[b] + p) : -1;
+      if (gq >= 0) {
+        double w3[3];
+        board_point_direction<ROLL>(h.t, v, ps.tr, vin[gq], vin[gq + 1], vin[gq + 2], w3);
+        for (int a = 0; a < 2; ++a) bterm[a] = ps.rs[a] * (ps.A[3 * a] * w3[0] + ps.A[3 * a + 1] * w3[1] + ps.A[3 * a + 2] * w3[2]);
+      }
+      double uu[2] = {uin[2 * idx], uin[2 * idx + 1]};
+      for (int a = 0; a < 2; ++a) {
+        double row[NV];
+        point_row<ND, ROLL, OPTK>(ps, a, row);
+        double val = 0.0;
+        for (int k = 0; k < NS; ++k) val += row[k] * wl[k];
+        jv[2 * idx + a] = val + bterm[a];
+        for (int k = 0; k < NS; ++k) sums[k] += row[k] * uu[a];
+      }
+      if (gq >= 0) {
+        double q3[3], w3[3];
+        for (int k = 0; k < 3; ++k) q3[k] = ps.rs[0] * uu[0] * ps.A[k] + ps.rs[1] * uu[1] * ps.A[3 + k];
+        board_point_adjoint<ROLL>(h.t, v, ps.tr, q3, w3);
+        for (int k = 0; k < 3; ++k) jtu[gq + k] += w3[k];
+      }
+    }
+    for (int j = 0; j < NPC; ++j) {
+      const int xi = local_to_x(d, f, c, b, j);
+      if (xi < 0) continue;
+      double s = 0.0;
+      for (int a = 0; a < DE; ++a) s += That[a][j] * sums[a];
+      jtu[xi] += s;
+    }
+    for (int q = 0; q < KI; ++q) {
+      const int xi = local_to_x(d, f, c, b, NPC + q);
+      if (xi >= 0) jtu[xi] += sums[DE + q];
+    }
+  }
+}
+template <int ND, int FISH, bool ROLL>
+void lsmr_products_k(Host& h, const double* vin, const double* uin, double* jv, double* jtu) {
+  if (h.hp.d.KI > 0) lsmr_products_t<ND, FISH, ROLL, true>(h, vin, uin, jv, jtu);
+  else lsmr_products_t<ND, FISH, ROLL, false>(h, vin, uin, jv, jtu);
 }
 
 // per-view S = V^T V, M = That^T S That, scattered into dense H / g  (the kernels' algebra, serial)
@@ -253,6 +334,15 @@ int32_t hm_normal_equations(const mcba_problem* p, const double* x, int32_t loss
       for (size_t j = 0; j < ne; ++j) H[i * ne + j] = Hi[(size_t)h.hp.ext2int[i] * n + h.hp.ext2int[j]];
     }
   }
+  HM_END
+}
+
+// J(x) v and J(x)^T u through the matrix-free factorisation of the lsmr mode (uniform rigs: caller's layout = internal layout)
+int32_t hm_lsmr_products(const mcba_problem* p, const double* x, const double* v, const double* u, double* jv, double* jtu) {
+  HM_BEGIN
+  Host h; h.init(p); h.eval_tables(x);
+  if (!h.hp.ext2int.empty()) throw std::runtime_error("hm_lsmr_products: uniform camera blocks only");
+  DISPATCH_CAM(lsmr_products_k, h, v, u, jv, jtu);
   HM_END
 }
 

@@ -83,3 +83,11 @@ class HostMath(object):
     _check(lib().hm_normal_equations(C.byref(self.struct), _ptr(x, C.c_double), _lib.LOSSES[loss], C.c_double(f_scale),
                                      _ptr(H, C.c_double), _ptr(g, C.c_double), C.byref(cost)))
     return H, g, cost.value
+
+  def lsmr_products(self, x, v, u):
+    """(J v, J^T u) through the matrix-free factorisation the lsmr mode's kernels use (device functions, serial)."""
+    x, v, u = _f64(x), _f64(v), _f64(u)
+    jv, jtu = np.zeros(self.m), np.zeros(self.n)
+    _check(lib().hm_lsmr_products(C.byref(self.struct), _ptr(x, C.c_double), _ptr(v, C.c_double), _ptr(u, C.c_double),
+                                  _ptr(jv, C.c_double), _ptr(jtu, C.c_double)))
+    return jv, jtu

@@ -324,3 +324,24 @@ def test_handle_cache_forgets_the_device_mask_when_a_mutating_call_fails():
   finally:
     calibration.Handle = real_handle
     cache.entries = []
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_rolling", "tiny_fisheye", "tiny_handeye", "tiny_tilted", "tiny_edge", "tiny_fixintr",
+                                  "tiny_pin4", "tiny_boards", "tiny_bigboard"])
+def test_device_math_lsmr_products_match_the_jacobian(name):
+  """The matrix-free factorisation the lsmr mode's kernels use (J v = E (That v_pose) + K v_K + jp v_point and its adjoint, built from
+  point_state / point_row / view_column / board_point_direction / board_point_adjoint / local_to_x) compiled for the host, against the
+  Jacobian of the same device functions -- which test_device_math_jacobian_* pin to the reference's finite differences.  The GPU
+  test of the kernels themselves is tests/test_gpu_lsmr.py::test_lsmr_products_against_the_jacobian."""
+  g, rig = load_golden(name)
+  hm = HostMath(mirror(rig))
+  rng = np.random.default_rng(3)
+  x = g["x0"] + 1e-3 * rng.normal(size=g["x0"].size)
+  J = hm.jacobian(x)
+  v, u = rng.normal(size=hm.n), rng.normal(size=hm.m)
+  jv, jtu = hm.lsmr_products(x, v, u)
+  A = abs(J)
+  assert np.abs(jv - J @ v).max() <= 1e-12 * (A @ np.abs(v)).max()
+  scale = A.T @ np.abs(u)
+  assert np.abs(jtu - J.T @ u).max() <= 1e-12 * scale.max()
+  assert np.all(jtu[scale == 0] == 0)
