@@ -160,3 +160,21 @@ def test_lsmr_iteration_forms_agree(name):
   if spread < 3e-7:
     assert out[0][:2] == out[1][:2] == out[2][:2] == (int(g["ba_nfev"]), int(g["ba_status"])), (name, out)
     assert max(abs(out[m][2] - out[0][2]) for m in (1, 2)) <= 1e-6, (name, out)
+
+
+@pytest.mark.parametrize("name", ["tiny_rolling", "tiny_boards", "cfg1"])
+def test_lsmr_solve_is_bit_repeatable(name):
+  """No atomics and no order-dependent reductions anywhere in the lsmr route: every workgroup folds partial sums in a fixed order
+  and the scalar recurrences are bit-identical in all of them, so two solves of the same problem return the SAME bits -- also
+  across handles -- although thousands of LSMR iterations amplify any rounding difference to the 1e-6 px level."""
+  g, rig = load_golden(name)
+  c = mirror(rig)
+  xs, its = [], []
+  for _ in range(2):
+    with Handle(c) as h:
+      for _ in range(2):
+        res = h.solve(g["x0"], tr_solver="lsmr")
+        xs.append(res.x)
+        its.append((res.nfev, res.status, h.lsmr_iterations(), res.cost))
+  assert all(np.array_equal(xs[0], x) for x in xs[1:]), [float(np.abs(xs[0] - x).max()) for x in xs[1:]]
+  assert all(it == its[0] for it in its), its
