@@ -492,6 +492,19 @@ def main():
                                           note="per observation and iteration: the analytic row pair (forward model + derivatives, "
                                                "as in k_linearize without the V^T V accumulation) + 2 x 2 x (NV - 1) multiply-adds for "
                                                "J v and J^T u")
+    if world == 1:
+      # the dominant kernel of THIS route, timed live with HIP events on the handle's stream like `roofline` above: the product kernel
+      # of an LSMR iteration (both Jacobian products from one evaluation of the analytic rows) + the gather behind it
+      f_ms, g_ms = h.time_lsmr_iteration(x0, repeats=50)
+      fl_it = parity_route["lsmr_iteration"]["flops_per_observation"] * n_obs_local
+      by_it = 48 * n_obs_local + n_slots_local        # observation in, uhat in + out (16 B each) per observation, mask byte per slot
+      parity_route["roofline"] = dict(bound="fp64-valu", kernel="k_lsmr_fused2", achieved=fl_it / (f_ms * 1e-3) / 1e12, peak=FP64_PEAK_TFLOPS,
+                                      unit="TFLOP/s", frac=fl_it / (f_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, launch_ms=f_ms,
+                                      gather_launch_ms=g_ms, algorithmic_flops=fl_it, algorithmic_bytes=by_it,
+                                      hbm=dict(achieved=by_it / (f_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                                               frac=by_it / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS),
+                                      traffic=None, traffic_source="profiles/r05_lsmr_pmc.json (FETCH_SIZE x2 + WRITE_SIZE of the committed "
+                                                                   "rocprofv3 passes): 59 MB per launch")
     fl = parity_route["lsmr_iteration"]["flops_per_observation"] * n_obs_local
     parity_route["lsmr_iteration"].update(us=parity_route["us_per_lsmr_iteration"],
                                           fp64_frac=fl / (parity_route["us_per_lsmr_iteration"] * 1e-6) / 1e12 / FP64_PEAK_TFLOPS)

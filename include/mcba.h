@@ -321,6 +321,9 @@ int32_t mcba_allreduce_stats(mcba_handle h, int32_t reset, int64_t* calls, int64
 int32_t mcba_time_linearize(mcba_handle h, const double* x, const mcba_options* opt, int32_t repeats,
                             double* avg_ms);
 int32_t mcba_time_residuals(mcba_handle h, const double* x, int32_t repeats, double* avg_ms);
+/* ... and of the two kernels of one LSMR iteration of the default solver (tr_solver = MCBA_TR_LSMR): ms[0] = the product kernel
+ * (J_h v and J_h^T u from one evaluation of the analytic rows), ms[1] = the gather; bench.py: parity_route.roofline             */
+int32_t mcba_time_lsmr_iteration(mcba_handle h, const double* x, int32_t repeats, double* ms /*[2]*/);
 
 #ifdef __cplusplus
 }

@@ -99,6 +99,7 @@ SYMBOLS = [
   ("mcba_solve", C.c_int32, [H, c_double_p, C.POINTER(Options), C.POINTER(Result)]),
   ("mcba_time_linearize", C.c_int32, [H, c_double_p, C.POINTER(Options), C.c_int32, c_double_p]),
   ("mcba_time_residuals", C.c_int32, [H, c_double_p, C.c_int32, c_double_p]),
+  ("mcba_time_lsmr_iteration", C.c_int32, [H, c_double_p, C.c_int32, c_double_p]),
   ("mcba_rccl_unique_id", C.c_int32, [C.POINTER(C.c_uint8)]),
   ("mcba_rccl_init", C.c_int32, [H, C.POINTER(C.c_uint8), C.c_int32, C.c_int32]),
   ("mcba_rccl_shutdown", C.c_int32, [H]),

@@ -559,6 +559,13 @@ class Handle(object):
     check(self.lib.mcba_time_linearize(self.h, _ptr(x, C.c_double), C.byref(opt), int(repeats), C.byref(ms)))
     return ms.value
 
+  def time_lsmr_iteration(self, x, repeats=50):
+    """(ms of k_lsmr_fused2, ms of k_lsmr_gather3): the two launches of one LSMR iteration of the default solver, HIP events."""
+    x = self._x(x)
+    ms = np.zeros(2)
+    check(self.lib.mcba_time_lsmr_iteration(self.h, _ptr(x, C.c_double), repeats, _ptr(ms, C.c_double)))
+    return float(ms[0]), float(ms[1])
+
   def time_residuals(self, x, repeats=20):
     x = self._x(x)
     ms = C.c_double()

@@ -3237,6 +3237,74 @@ int32_t mcba_time_linearize(mcba_handle h, const double* x, const mcba_options* 
   API_END
 }
 
+/* average launch duration (HIP events on the handle's stream) of the two kernels of an LSMR iteration of the default solver at x:
+ * ms[0] = k_lsmr_fused2 (both Jacobian products of a Golub-Kahan step), ms[1] = k_lsmr_gather3 -- the live numbers behind
+ * bench.py's `parity_route.roofline`.  Single (unsharded) handles; linear loss.                                                  */
+int32_t mcba_time_lsmr_iteration(mcba_handle h, const double* x, int32_t repeats, double* ms /*[2]*/) {
+  API_BEGIN
+  REQUIRE(h && x && ms && repeats > 0, "bad argument");
+  REQUIRE(h->allreduce == nullptr, "single handles only");
+  g_fill_stream = h->stream;
+  set_loss(h, nullptr);
+  const Dims& d = h->d;
+  ensure_view_first(h);
+  const size_t m = 2 * (size_t)h->n_inliers;
+  const int NL = 6 * d.NPB + d.KI;
+  LsmrOps op{h, std::max(1, std::min(2048, d.views())), (NL + 1) & ~1, m};
+  if (h->ls_u.n < std::max<size_t>(m, 2)) h->ls_u.alloc(std::max<size_t>(m, 2), true);
+  if (h->ls_part.n < (size_t)std::max(d.views(), 1) * op.part_stride) h->ls_part.alloc((size_t)std::max(d.views(), 1) * op.part_stride, true);
+  for (DevBuf<double>* b : {&h->ls_v, &h->ls_vraw, &h->ls_h, &h->ls_hbar, &h->ls_x, &h->ls_nrm})
+    if (b->n < (size_t)d.n) b->alloc((size_t)d.n, true);
+  if (h->ls_partial.n < (size_t)op.nblk) h->ls_partial.alloc((size_t)op.nblk, false);
+  if (h->ls_out.n < 8) h->ls_out.alloc(8, false);
+  if (h->ls_state.n < (size_t)2 * LS_NSLOTS) h->ls_state.alloc((size_t)2 * LS_NSLOTS, true);
+  if (h->ls_xpart.n < (size_t)op.nblk + 1) h->ls_xpart.alloc((size_t)op.nblk + 1, true);
+  if (h->ls_vpart.n < (size_t)op.gather3_grid() + 1) h->ls_vpart.alloc((size_t)op.gather3_grid() + 1, true);
+  if (d.off_boards >= 0) {
+    if (h->ls_bpart.n < std::max<size_t>(3 * (size_t)h->n_inliers, 3)) h->ls_bpart.alloc(std::max<size_t>(3 * (size_t)h->n_inliers, 3), false);
+    ensure_obs_index(h);
+  }
+  upload_x(h, x, h->x.p);
+  sync(h);
+  lsmr_linearize(h, h->x.p);
+  std::vector<double> ones((size_t)d.n, 1.0);
+  HIP_OK(hipMemcpyAsync(h->dsc.p, ones.data(), (size_t)d.n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_OK(hipMemcpyAsync(h->ls_v.p, ones.data(), (size_t)d.n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  double* s0 = h->ls_state.p;
+  double* s1 = s0 + LS_NSLOTS;
+  hipLaunchKernelGGL(k_lsmr_init, dim3(1), dim3(64), 0, h->stream, s0, 1.0, 1.0, 0.0, 1.0, 1e9);   // (no pending rotation: the product alone)
+  sync(h);
+  auto product = [&]() {
+    h->ops->lsmr_fused2(d, h->t, h->stream, h->view_first.p, h->dsc.p, h->ls_v.p, h->ls_u.p, h->ls_partial.p, h->ls_xpart.p, h->ls_part.p,
+                        op.part_stride, op.bpart(), op.nblk, s0, s1, h->ls_vpart.p, op.gather3_grid(), h->ls_hbar.p, h->ls_x.p, h->ls_h.p);
+  };
+  auto gather = [&]() {   // (writes its state to the spare half of s1's buffer is not possible: a scratch copy keeps s0 untouched)
+    hipLaunchKernelGGL(k_lsmr_gather3, dim3(op.gather3_grid()), dim3(LSG3_THREADS), 0, h->stream, d, (const double*)h->ls_part.p, op.part_stride,
+                       (const double*)h->dsc.p, (const double*)h->ls_v.p, h->ls_vraw.p, h->ls_nrm.p, h->ls_vpart.p, (const double*)s1, h->ls_out.p,
+                       (const double*)h->ls_partial.p, op.nblk, (const double*)h->ls_xpart.p, std::max(1, std::min(op.nblk, (d.n + 63) / 64)),
+                       0ull, h->h_pub_seq + 1, op.extra());
+  };
+  if (h->ls_out.n < (size_t)LS_NSLOTS + 8) h->ls_out.alloc((size_t)LS_NSLOTS + 8, false);   // (scratch state of the timed gather)
+  product();
+  gather();
+  sync(h);
+  float t = 0.f;
+  HIP_OK(hipEventRecord(h->ev0, h->stream));
+  for (int i = 0; i < repeats; ++i) product();
+  HIP_OK(hipEventRecord(h->ev1, h->stream));
+  sync(h);
+  HIP_OK(hipEventElapsedTime(&t, h->ev0, h->ev1));
+  ms[0] = t / repeats;
+  HIP_OK(hipEventRecord(h->ev0, h->stream));
+  for (int i = 0; i < repeats; ++i) gather();
+  HIP_OK(hipEventRecord(h->ev1, h->stream));
+  sync(h);
+  HIP_OK(hipEventElapsedTime(&t, h->ev0, h->ev1));
+  ms[1] = t / repeats;
+  h->h_pub_seq[1] = 0;   // (the timed gathers published progress words of call 0: forget them)
+  API_END
+}
+
 int32_t mcba_time_residuals(mcba_handle h, const double* x, int32_t repeats, double* avg_ms) {
   API_BEGIN
   REQUIRE(h && x && avg_ms && repeats > 0, "bad argument");
