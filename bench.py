@@ -503,8 +503,18 @@ def main():
                                       gather_launch_ms=g_ms, algorithmic_flops=fl_it, algorithmic_bytes=by_it,
                                       hbm=dict(achieved=by_it / (f_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                                                frac=by_it / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS),
-                                      traffic=None, traffic_source="profiles/r05_lsmr_pmc.json (FETCH_SIZE x2 + WRITE_SIZE of the committed "
-                                                                   "rocprofv3 passes): 59 MB per launch")
+                                      traffic=None)
+      pmc_file = os.path.join(ROOT, "profiles", "r05_lsmr_pmc.json")     # (PMC counters cannot be read inside an un-profiled run)
+      if os.path.exists(pmc_file) and args.config == "cfg3":
+        try:
+          pj = json.load(open(pmc_file))
+          k2 = [k for k in pj if "k_lsmr_fused2" in k]
+          if k2 and "FETCH_SIZE" in pj[k2[0]] and "WRITE_SIZE" in pj[k2[0]]:
+            parity_route["roofline"]["traffic"] = 2 * pj[k2[0]]["FETCH_SIZE"] * 1024 + pj[k2[0]]["WRITE_SIZE"] * 1024
+            parity_route["roofline"]["traffic_source"] = ("profiles/r05_lsmr_pmc.json: separate --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                                          "profiles/scripts/collect_r05.sh, gfx950 x2 read correction; not measured in this run")
+        except Exception:
+          pass
     fl = parity_route["lsmr_iteration"]["flops_per_observation"] * n_obs_local
     parity_route["lsmr_iteration"].update(us=parity_route["us_per_lsmr_iteration"],
                                           fp64_frac=fl / (parity_route["us_per_lsmr_iteration"] * 1e-6) / 1e12 / FP64_PEAK_TFLOPS)
