@@ -506,6 +506,14 @@ class Handle(object):
     check(self.lib.mcba_debug_lsmr_products(self.h, _ptr(x, C.c_double), pv, pu, pjv, pjtu))
     return jv, jtu
 
+  def lsmr_fused_products(self, x, v):
+    """(J(x) v, J(x)^T J(x) v) through k_lsmr_fused2 + k_lsmr_gather3, the two kernels of the default solver's LSMR iteration
+    (mcba_debug_lsmr_fused_products) -- test hook."""
+    x, v = self._x(x), self._x(v)
+    jv, w = np.empty(self.n_residuals), np.empty(self.n_params)
+    check(self.lib.mcba_debug_lsmr_fused_products(self.h, _ptr(x, C.c_double), _ptr(v, C.c_double), _ptr(jv, C.c_double), _ptr(w, C.c_double)))
+    return jv, w
+
   def set_lsmr_fused(self, mode):
     """A/B switch of the LSMR iteration: 2 (default) = two launches (k_lsmr_fused2 / k_lsmr_gather3), 1 = three (k_lsmr_fused /
     k_lsmr_gather2 / k_lsmr_update2), 0 = the six-launch form of round 4."""

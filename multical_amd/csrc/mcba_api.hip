@@ -3237,6 +3237,68 @@ int32_t mcba_time_linearize(mcba_handle h, const double* x, const mcba_options* 
   API_END
 }
 
+/* test hook (mcba_debug.h): one Golub-Kahan step through the kernels the default solver ITERATES with -- k_lsmr_fused2 (uhat = J v with
+ * alpha = 0, and the per-view partials of J^T uhat from the same pass) and k_lsmr_gather3 (v_raw = J^T uhat / beta - beta v, beta = |uhat|)
+ * -- at x, unscaled columns, linear loss: jv_out[m] = J(x) v, jtjv_out[n] = J(x)^T J(x) v (recovered as (v_raw + beta v) beta).  */
+int32_t mcba_debug_lsmr_fused_products(mcba_handle h, const double* x, const double* v, double* jv_out, double* jtjv_out) {
+  API_BEGIN
+  REQUIRE(h && x && v && jv_out && jtjv_out, "null argument");
+  REQUIRE(h->allreduce == nullptr, "single handles only");
+  g_fill_stream = h->stream;
+  set_loss(h, nullptr);
+  const Dims& d = h->d;
+  ensure_view_first(h);
+  const size_t m = 2 * (size_t)h->n_inliers;
+  const int NL = 6 * d.NPB + d.KI;
+  LsmrOps op{h, std::max(1, std::min(2048, d.views())), (NL + 1) & ~1, m};
+  if (h->ls_u.n < std::max<size_t>(m, 2)) h->ls_u.alloc(std::max<size_t>(m, 2), true);
+  if (h->ls_part.n < (size_t)std::max(d.views(), 1) * op.part_stride) h->ls_part.alloc((size_t)std::max(d.views(), 1) * op.part_stride, true);
+  for (DevBuf<double>* b : {&h->ls_v, &h->ls_vraw, &h->ls_h, &h->ls_hbar, &h->ls_x, &h->ls_nrm})
+    if (b->n < (size_t)d.n) b->alloc((size_t)d.n, true);
+  if (h->ls_partial.n < (size_t)op.nblk) h->ls_partial.alloc((size_t)op.nblk, false);
+  if (h->ls_out.n < (size_t)LS_NSLOTS + 8) h->ls_out.alloc((size_t)LS_NSLOTS + 8, false);
+  if (h->ls_state.n < (size_t)2 * LS_NSLOTS) h->ls_state.alloc((size_t)2 * LS_NSLOTS, true);
+  if (h->ls_xpart.n < (size_t)op.nblk + 1) h->ls_xpart.alloc((size_t)op.nblk + 1, true);
+  if (h->ls_vpart.n < (size_t)op.gather3_grid() + 1) h->ls_vpart.alloc((size_t)op.gather3_grid() + 1, true);
+  if (d.off_boards >= 0) {
+    if (h->ls_bpart.n < std::max<size_t>(3 * (size_t)h->n_inliers, 3)) h->ls_bpart.alloc(std::max<size_t>(3 * (size_t)h->n_inliers, 3), false);
+    ensure_obs_index(h);
+  }
+  upload_x(h, x, h->x.p);
+  sync(h);
+  lsmr_linearize(h, h->x.p);
+  std::vector<double> ones((size_t)d.n, 1.0);
+  HIP_OK(hipMemcpyAsync(h->dsc.p, ones.data(), (size_t)d.n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  sync(h);
+  upload_x(h, v, h->ls_v.p);                                   // (internal layout; padded coefficients zero)
+  HIP_OK(hipMemsetAsync(h->ls_u.p, 0, std::max<size_t>(m, 2) * sizeof(double), h->stream));
+  double* s0 = h->ls_state.p;
+  double* s1 = s0 + LS_NSLOTS;
+  hipLaunchKernelGGL(k_lsmr_init, dim3(1), dim3(64), 0, h->stream, s0, /*alpha*/ 0.0, /*beta*/ 1.0, 0.0, 1.0, 1e9);
+  h->ops->lsmr_fused2(d, h->t, h->stream, h->view_first.p, h->dsc.p, h->ls_v.p, h->ls_u.p, h->ls_partial.p, h->ls_xpart.p, h->ls_part.p,
+                      op.part_stride, op.bpart(), op.nblk, s0, s1, h->ls_vpart.p, op.gather3_grid(), h->ls_hbar.p, h->ls_x.p, h->ls_h.p);
+  hipLaunchKernelGGL(k_lsmr_gather3, dim3(op.gather3_grid()), dim3(LSG3_THREADS), 0, h->stream, d, (const double*)h->ls_part.p, op.part_stride,
+                     (const double*)h->dsc.p, (const double*)h->ls_v.p, h->ls_vraw.p, h->ls_nrm.p, h->ls_vpart.p, (const double*)s1, h->ls_out.p,
+                     (const double*)h->ls_partial.p, op.nblk, (const double*)h->ls_xpart.p, std::max(1, std::min(op.nblk, (d.n + 63) / 64)),
+                     0ull, h->h_pub_seq + 1, op.extra());
+  check_launch("k_lsmr_fused2 / k_lsmr_gather3");
+  HIP_OK(hipMemcpyAsync(jv_out, h->ls_u.p, m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  std::vector<double> vraw((size_t)d.n), vint((size_t)d.n);
+  HIP_OK(hipMemcpyAsync(vraw.data(), h->ls_vraw.p, (size_t)d.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipMemcpyAsync(vint.data(), h->ls_v.p, (size_t)d.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  double beta = 0.0;   // the gather's own beta = |uhat| (published with its state): the recovery below is then exact in the zero columns
+  HIP_OK(hipMemcpyAsync(&beta, h->ls_out.p + LS_BETA, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  sync(h);
+  h->h_pub_seq[1] = 0;
+  for (int i = 0; i < d.n; ++i) {
+#pragma clang fp contract(off)      // (beta v must be rounded as the kernel rounded it before it is added back)
+    const double bv = beta * vint[i];
+    h->h_x[i] = (vraw[i] + bv) * beta;
+  }
+  to_caller(h, jtjv_out, h->h_x);
+  API_END
+}
+
 /* average launch duration (HIP events on the handle's stream) of the two kernels of an LSMR iteration of the default solver at x:
  * ms[0] = k_lsmr_fused2 (both Jacobian products of a Golub-Kahan step), ms[1] = k_lsmr_gather3 -- the live numbers behind
  * bench.py's `parity_route.roofline`.  Single (unsharded) handles; linear loss.                                                  */

@@ -44,6 +44,9 @@ int32_t mcba_debug_set_switch(const char* name, const char* value);
 /* LSMR iteration: 2 (default) = two launches (k_lsmr_fused2: both Jacobian products from one evaluation of the rows + the scalar
  * recurrence / vector update of the previous step in its head; k_lsmr_gather3), 1 = three launches, 0 = the six-launch form    */
 int32_t mcba_debug_set_lsmr_fused(mcba_handle h, int32_t on);
+/* ... and through the kernels the default solver iterates with (k_lsmr_fused2 + k_lsmr_gather3, one Golub-Kahan step with alpha = 0):
+ * jv_out[m] = J(x) v, jtjv_out[n] = J(x)^T J(x) v                                                                               */
+int32_t mcba_debug_lsmr_fused_products(mcba_handle h, const double* x, const double* v, double* jv_out, double* jtjv_out);
 /* LSMR iterations taken by the last mcba_solve with tr_solver = MCBA_TR_LSMR on this handle                           */
 int32_t mcba_debug_lsmr_info(mcba_handle h, int64_t* lsmr_iterations);
 

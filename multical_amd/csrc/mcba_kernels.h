@@ -834,7 +834,7 @@ __global__ __launch_bounds__(64) void k_lsmr_fused2(Dims d, Tables t, const int3
                                                     double* __restrict__ xv, double* __restrict__ hv) {
   constexpr bool ROLL = MOTION == MOTION_ROLLING;
   constexpr int DE = ROLL ? 12 : 6, NPB = MOTION == MOTION_STATIC ? 3 : 4, NPC = 6 * NPB, KI = OPTK ? 4 + ND : 0;
-  constexpr int NV = DE + KI + 1, NS = DE + KI;
+  constexpr int NS = DE + KI;
   __shared__ uint16_t pidx[LIN_MAX_POINTS];
   __shared__ double vp[NPC], wl[NS], sl[NS];
   const int lane = threadIdx.x;
@@ -933,19 +933,57 @@ __global__ __launch_bounds__(64) void k_lsmr_fused2(Dims d, Tables t, const int3
             for (int a = 0; a < 2; ++a)
               bterm[a] = ps.rs[a] * (ps.A[3 * a] * w3[0] + ps.A[3 * a + 1] * w3[1] + ps.A[3 * a + 2] * w3[2]);
           }
+          // The row pair is never formed: with E_a = [X x a_a | a_a] (base_row) the product is  E_a . w = a_a . (w_t + w_r x X)  and
+          // the adjoint  sum_a E_a^T c_a = [X x q | q],  q = sum_a c_a a_a  -- two cross products each way instead of 2 x 2 x 12
+          // multiply-adds with 24 row entries (rolling shutter: y and q are blended with the scan time).  K_a stays a plain dot.
+          constexpr int KIA = 4 + ND;
+          double y[3];
+          {
+            const double ys0 = wl[3] + (wl[1] * ps.Xs[2] - wl[2] * ps.Xs[1]);
+            const double ys1 = wl[4] + (wl[2] * ps.Xs[0] - wl[0] * ps.Xs[2]);
+            const double ys2 = wl[5] + (wl[0] * ps.Xs[1] - wl[1] * ps.Xs[0]);
+            if constexpr (ROLL) {
+              const double ye0 = wl[9] + (wl[7] * ps.Xe[2] - wl[8] * ps.Xe[1]);
+              const double ye1 = wl[10] + (wl[8] * ps.Xe[0] - wl[6] * ps.Xe[2]);
+              const double ye2 = wl[11] + (wl[6] * ps.Xe[1] - wl[7] * ps.Xe[0]);
+              const double ts = 1.0 - ps.tr;
+              y[0] = ts * ys0 + ps.tr * ye0; y[1] = ts * ys1 + ps.tr * ye1; y[2] = ts * ys2 + ps.tr * ye2;
+            } else {
+              y[0] = ys0; y[1] = ys1; y[2] = ys2;
+            }
+          }
+          double cv[2];   // c_a = rs_a uhat_a
           double2 o;
 #pragma unroll
           for (int a = 0; a < 2; ++a) {
-            double row[NV];
-            point_row<ND, ROLL, OPTK>(ps, a, row);
-            double val = 0.0;
+            double dot = ps.A[3 * a] * y[0] + ps.A[3 * a + 1] * y[1] + ps.A[3 * a + 2] * y[2];
+            if constexpr (OPTK) {
 #pragma unroll
-            for (int k = 0; k < NS; ++k) val += row[k] * wl[k];
+              for (int k = 0; k < KI; ++k) dot += ps.Kc[a * KIA + k] * wl[DE + k];
+            }
+            double val = ps.rs[a] * dot;
             val += bterm[a];
             val -= alpha * (a == 0 ? old.x : old.y);
-#pragma unroll
-            for (int k = 0; k < NS; ++k) sums[k] += row[k] * val;
+            cv[a] = ps.rs[a] * val;
             if (a == 0) o.x = val; else o.y = val;
+          }
+          {
+            const double q0 = cv[0] * ps.A[0] + cv[1] * ps.A[3], q1 = cv[0] * ps.A[1] + cv[1] * ps.A[4], q2 = cv[0] * ps.A[2] + cv[1] * ps.A[5];
+            const double ws = ROLL ? 1.0 - ps.tr : 1.0;
+            sums[0] += ws * (ps.Xs[1] * q2 - ps.Xs[2] * q1);
+            sums[1] += ws * (ps.Xs[2] * q0 - ps.Xs[0] * q2);
+            sums[2] += ws * (ps.Xs[0] * q1 - ps.Xs[1] * q0);
+            sums[3] += ws * q0; sums[4] += ws * q1; sums[5] += ws * q2;
+            if constexpr (ROLL) {
+              sums[6] += ps.tr * (ps.Xe[1] * q2 - ps.Xe[2] * q1);
+              sums[7] += ps.tr * (ps.Xe[2] * q0 - ps.Xe[0] * q2);
+              sums[8] += ps.tr * (ps.Xe[0] * q1 - ps.Xe[1] * q0);
+              sums[9] += ps.tr * q0; sums[10] += ps.tr * q1; sums[11] += ps.tr * q2;
+            }
+            if constexpr (OPTK) {
+#pragma unroll
+              for (int k = 0; k < KI; ++k) sums[DE + k] += cv[0] * ps.Kc[k] + cv[1] * ps.Kc[KIA + k];
+            }
           }
           reinterpret_cast<double2*>(u)[out0 + i] = o;
           acc += o.x * o.x + o.y * o.y;

@@ -45,6 +45,28 @@ def test_lsmr_products_against_the_jacobian(name):
     assert np.array_equal(jv, jv_only) and np.array_equal(jtu, jtu_only)
 
 
+@pytest.mark.parametrize("name", PRODUCT_CASES)
+def test_lsmr_two_launch_kernels_against_the_jacobian(name):
+  """The kernels the DEFAULT solver iterates with -- k_lsmr_fused2 (both products of a Golub-Kahan step from one evaluation of the
+  analytic rows) and k_lsmr_gather3 -- against the analytic Jacobian: J v to 1e-12, J^T (J v) to 1e-11 (of sum |J^T| |J v|)."""
+  g, rig = load_golden(name)
+  c = mirror(rig)
+  rng = np.random.default_rng(8)
+  x = c.param_vec + 1e-3 * rng.normal(size=c.param_vec.size)
+  with Handle(c) as h:
+    J = h.jacobian(x)
+    v = rng.normal(size=h.n_params)
+    jv, w = h.lsmr_fused_products(x, v)
+    jv2, w2 = h.lsmr_fused_products(x, v)
+  A = abs(J)
+  ref = J @ v
+  assert np.abs(jv - ref).max() <= 1e-12 * (A @ np.abs(v)).max()
+  scale = A.T @ np.abs(ref)
+  assert np.abs(w - J.T @ ref).max() <= 1e-11 * scale.max()
+  assert np.all(w[scale == 0] == 0)
+  assert np.array_equal(jv, jv2) and np.array_equal(w, w2)          # deterministic
+
+
 def test_lsmr_products_after_an_outlier_rejection():
   """the products follow the CURRENT inlier set (view lists, residual order, obs_index of the board-point gather)"""
   g, rig = load_golden("tiny_boards")
