@@ -313,7 +313,7 @@ struct mcba_handle_s {
   bool shard_root = true;
   DevBuf<double> comm;   // frame-sharded handles: [g_s | diag_s | cost, count | step norms] of the linearisation's message
   // solver "lsmr": m-vectors u (bidiagonalisation), J_h g_h, J_h gn; per-view partials of J_h^T u; n-vectors v, v_raw, h, hbar, x
-  DevBuf<double> ls_u, ls_ua, ls_ub, ls_part, ls_v, ls_vraw, ls_h, ls_hbar, ls_x, ls_nrm, ls_partial, ls_out, ls_bpart, ls_comm, ls_xpart, ls_vpart;
+  DevBuf<double> ls_u, ls_ua, ls_ub, ls_part, ls_v, ls_vraw, ls_h, ls_hbar, ls_x, ls_nrm, ls_partial, ls_out, ls_bpart, ls_comm, ls_xpart, ls_vpart, ls_part2;
   int lsmr_fused = 2;                     // LSMR iteration: 2 = two launches (k_lsmr_fused2 / k_lsmr_gather3), 1 = three (k_lsmr_fused), 0 = the six-launch form of round 4 (A/B, tests)
   ScalLayout sl;
   DevBuf<double> chol_linv;   // inverted diagonal tiles of the panel kernels (k_cholp_back)
@@ -2182,13 +2182,19 @@ struct LsmrOps {
   // folds its partials in a fifth wavefront beside the sums.  v is kept un-normalised (v = v_raw / alpha, alpha in the state).
   // State: k_lsmr_fused2 reads s0 (written by the gather / the initialisation) and writes s1; the gather reads s1 and writes s0.
   int gather3_grid() const { return (gather_grid() + 3) / 4 + 1; }   // (+ the publisher workgroup, which has no tasks)
+  // per-view partials of the two-launch iteration in the TRANSPOSED layout (lsmr_part_index); views without inliers stay zero
+  void ensure_part2(bool clear) {
+    const size_t need = (size_t)std::max(h->d.views(), 1) * (size_t)(6 * h->d.NPB + h->d.KI);
+    if (h->ls_part2.n < need) h->ls_part2.alloc(need, true);
+    else if (clear) HIP_OK(hipMemsetAsync(h->ls_part2.p, 0, h->ls_part2.n * sizeof(double), h->stream));
+  }
   void iteration_fused2(double* s0, double* s1, double* u, double* v, double* vraw, unsigned long long call, bool first_iteration) {
     const Dims& d = h->d;
     const double* vpart = h->ls_vpart.p;
     int nv = gather3_grid();
     if (sharded()) { vpart = h->ls_out.p + 6; nv = 1; }     // (|v_raw|^2 summed over the ranks by the previous iteration)
     (void)first_iteration;                                   // (state slot LS_PENDING = 0: the head of the first product has nothing to rotate)
-    h->ops->lsmr_fused2(d, h->t, h->stream, h->view_first.p, h->dsc.p, v, u, h->ls_partial.p, h->ls_xpart.p, h->ls_part.p, part_stride,
+    h->ops->lsmr_fused2(d, h->t, h->stream, h->view_first.p, h->dsc.p, v, u, h->ls_partial.p, h->ls_xpart.p, h->ls_part2.p, part_stride,
                         bpart(), nblk, s0, s1, vpart, nv, h->ls_hbar.p, h->ls_x.p, h->ls_h.p);
     const double* upart = h->ls_partial.p;
     const double* xpart = h->ls_xpart.p;
@@ -2200,7 +2206,7 @@ struct LsmrOps {
       call_allreduce(h, two, 2, 0);
       upart = two; nu = 1; xpart = two + 1; nx = 1;
     }
-    hipLaunchKernelGGL(k_lsmr_gather3, dim3(gather3_grid()), dim3(LSG3_THREADS), 0, h->stream, d, (const double*)h->ls_part.p, part_stride,
+    hipLaunchKernelGGL(k_lsmr_gather3, dim3(gather3_grid()), dim3(LSG3_THREADS), 0, h->stream, d, (const double*)h->ls_part2.p, part_stride,
                        (const double*)h->dsc.p, (const double*)v, vraw, h->ls_nrm.p, h->ls_vpart.p, (const double*)s1, s0, upart, nu, xpart, nx,
                        call, h->h_pub_seq + 1, extra());
     if (sharded()) {
@@ -2361,6 +2367,7 @@ static void solve_lsmr(mcba_handle h, double* x_inout, const mcba_options* opt, 
     if (b->n < (size_t)d.n) b->alloc((size_t)d.n, true);
   if (h->ls_partial.n < (size_t)op.nblk) h->ls_partial.alloc((size_t)op.nblk, false);
   if (h->ls_out.n < 8) h->ls_out.alloc(8, false);
+  op.ensure_part2(true);
   if (d.off_boards >= 0) {   // boards=True: jp^T u per observation + the residual index of every slot (k_lsmr_gather)
     if (h->ls_bpart.n < std::max<size_t>(3 * (size_t)h->n_inliers, 3)) h->ls_bpart.alloc(std::max<size_t>(3 * (size_t)h->n_inliers, 3), false);
     ensure_obs_index(h);
@@ -3274,10 +3281,11 @@ int32_t mcba_debug_lsmr_fused_products(mcba_handle h, const double* x, const dou
   HIP_OK(hipMemsetAsync(h->ls_u.p, 0, std::max<size_t>(m, 2) * sizeof(double), h->stream));
   double* s0 = h->ls_state.p;
   double* s1 = s0 + LS_NSLOTS;
+  op.ensure_part2(true);
   hipLaunchKernelGGL(k_lsmr_init, dim3(1), dim3(64), 0, h->stream, s0, /*alpha*/ 0.0, /*beta*/ 1.0, 0.0, 1.0, 1e9);
-  h->ops->lsmr_fused2(d, h->t, h->stream, h->view_first.p, h->dsc.p, h->ls_v.p, h->ls_u.p, h->ls_partial.p, h->ls_xpart.p, h->ls_part.p,
+  h->ops->lsmr_fused2(d, h->t, h->stream, h->view_first.p, h->dsc.p, h->ls_v.p, h->ls_u.p, h->ls_partial.p, h->ls_xpart.p, h->ls_part2.p,
                       op.part_stride, op.bpart(), op.nblk, s0, s1, h->ls_vpart.p, op.gather3_grid(), h->ls_hbar.p, h->ls_x.p, h->ls_h.p);
-  hipLaunchKernelGGL(k_lsmr_gather3, dim3(op.gather3_grid()), dim3(LSG3_THREADS), 0, h->stream, d, (const double*)h->ls_part.p, op.part_stride,
+  hipLaunchKernelGGL(k_lsmr_gather3, dim3(op.gather3_grid()), dim3(LSG3_THREADS), 0, h->stream, d, (const double*)h->ls_part2.p, op.part_stride,
                      (const double*)h->dsc.p, (const double*)h->ls_v.p, h->ls_vraw.p, h->ls_nrm.p, h->ls_vpart.p, (const double*)s1, h->ls_out.p,
                      (const double*)h->ls_partial.p, op.nblk, (const double*)h->ls_xpart.p, std::max(1, std::min(op.nblk, (d.n + 63) / 64)),
                      0ull, h->h_pub_seq + 1, op.extra());
@@ -3334,14 +3342,15 @@ int32_t mcba_time_lsmr_iteration(mcba_handle h, const double* x, int32_t repeats
   HIP_OK(hipMemcpyAsync(h->ls_v.p, ones.data(), (size_t)d.n * sizeof(double), hipMemcpyHostToDevice, h->stream));
   double* s0 = h->ls_state.p;
   double* s1 = s0 + LS_NSLOTS;
+  op.ensure_part2(true);
   hipLaunchKernelGGL(k_lsmr_init, dim3(1), dim3(64), 0, h->stream, s0, 1.0, 1.0, 0.0, 1.0, 1e9);   // (no pending rotation: the product alone)
   sync(h);
   auto product = [&]() {
-    h->ops->lsmr_fused2(d, h->t, h->stream, h->view_first.p, h->dsc.p, h->ls_v.p, h->ls_u.p, h->ls_partial.p, h->ls_xpart.p, h->ls_part.p,
+    h->ops->lsmr_fused2(d, h->t, h->stream, h->view_first.p, h->dsc.p, h->ls_v.p, h->ls_u.p, h->ls_partial.p, h->ls_xpart.p, h->ls_part2.p,
                         op.part_stride, op.bpart(), op.nblk, s0, s1, h->ls_vpart.p, op.gather3_grid(), h->ls_hbar.p, h->ls_x.p, h->ls_h.p);
   };
   auto gather = [&]() {   // (writes its state to the spare half of s1's buffer is not possible: a scratch copy keeps s0 untouched)
-    hipLaunchKernelGGL(k_lsmr_gather3, dim3(op.gather3_grid()), dim3(LSG3_THREADS), 0, h->stream, d, (const double*)h->ls_part.p, op.part_stride,
+    hipLaunchKernelGGL(k_lsmr_gather3, dim3(op.gather3_grid()), dim3(LSG3_THREADS), 0, h->stream, d, (const double*)h->ls_part2.p, op.part_stride,
                        (const double*)h->dsc.p, (const double*)h->ls_v.p, h->ls_vraw.p, h->ls_nrm.p, h->ls_vpart.p, (const double*)s1, h->ls_out.p,
                        (const double*)h->ls_partial.p, op.nblk, (const double*)h->ls_xpart.p, std::max(1, std::min(op.nblk, (d.n + 63) / 64)),
                        0ull, h->h_pub_seq + 1, op.extra());

@@ -1021,14 +1021,14 @@ __global__ __launch_bounds__(64) void k_lsmr_fused2(Dims d, Tables t, const int3
     const double tot = wave_reduce_many<NS>(sums, lane);
     if (many_writer<NS>(lane)) sl[many_index(lane)] = tot;
     lds_fence();
-    double* out = part + (size_t)v * part_stride;
+    // (transposed layout, lsmr_part_index: the gather then sums contiguous runs)
     if (lane < NPC) {
       double sum = 0.0;
 #pragma unroll
       for (int a = 0; a < DE; ++a) sum += TmS[a * NPC + lane] * sl[a];
-      out[lane] = sum;
+      part[lsmr_part_index(d, v, lane)] = sum;
     } else if (lane < NPC + KI) {
-      out[lane] = sl[DE + lane - NPC];
+      part[lsmr_part_index(d, v, lane)] = sl[DE + lane - NPC];
     }
     lds_fence();
   }

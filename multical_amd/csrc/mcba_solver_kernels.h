@@ -2536,7 +2536,8 @@ __global__ __launch_bounds__(LSG3_THREADS) void k_lsmr_gather3(Dims d, const dou
   if (lsIn[LS_ISTOP] != 0.0) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nfe = lsmr_gather_frame_entries(d), ngen = d.n - nfe;
-  const int CB = d.C * d.B, npc = 6 * d.NPB;
+  const int CB = d.C * d.B;
+  (void)part_stride;   // (transposed layout: lsmr_part_index)
   // tasks are dealt round-robin over the workgroups (task = wave * (workgroups - 1) + workgroup): the heavy ones -- the entries
   // outside the frame block come first and sum over hundreds to thousands of views -- land in different workgroups / CUs
   const bool publisher = blockIdx.x == gridDim.x - 1;   // one extra workgroup without tasks: stopping tests + state (off the others' path)
@@ -2579,12 +2580,12 @@ __global__ __launch_bounds__(LSG3_THREADS) void k_lsmr_gather3(Dims d, const dou
         const int e = g16 + 4 * q;
         if (e < DFm) {
           double s4[4] = {0.0, 0.0, 0.0, 0.0};
-          const double* src = part + (size_t)fl * CB * part_stride + 6 + e;
+          const double* src = part + lsmr_part_motion(d) + ((size_t)fl * DFm + e) * CB;      // (contiguous: lsmr_part_index)
           for (int w0 = 0; w0 < CB; w0 += 64)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
               const int vw = w0 + 16 * k + l16;
-              if (vw < CB) s4[k] += src[(size_t)vw * part_stride];
+              if (vw < CB) s4[k] += src[vw];
             }
           double sq = (s4[0] + s4[2]) + (s4[1] + s4[3]);
 #pragma unroll
@@ -2608,32 +2609,30 @@ __global__ __launch_bounds__(LSG3_THREADS) void k_lsmr_gather3(Dims d, const dou
           if (idx >= 0) sum += ex.bpart[3 * (size_t)idx + k];
         }
       } else {
-        int base = 0, na = 0, sa = 0, nb = 1, sb = 0, local = -1;
+        // the contiguous run of the entry in the transposed layout (lsmr_part_index)
+        const double* run = nullptr;
+        int total = 0;
         if (d.off_campose >= 0 && i >= d.off_campose && i < d.off_campose + 6 * d.C) {
-          const int q = i - d.off_campose, c = q / 6;
-          local = q % 6; base = c * d.B; na = d.Fl; sa = CB; nb = d.B; sb = 1;
+          const int q = i - d.off_campose;
+          run = part + lsmr_part_cam(d, q / 6, q % 6); total = d.Fl * d.B;
         } else if (d.off_boardpose >= 0 && i >= d.off_boardpose && i < d.off_boardpose + 6 * d.B) {
-          const int q = i - d.off_boardpose, b = q / 6;
-          local = 6 * (d.NPB - 1) + q % 6; base = b; na = d.Fl; sa = CB; nb = d.C; sb = d.B;
+          const int q = i - d.off_boardpose;
+          run = part + lsmr_part_board(d, q / 6, q % 6); total = d.Fl * d.C;
         } else if (d.off_motion >= 0 && i >= d.off_motion && i < d.off_motion + d.n_motion) {
           const int q = i - d.off_motion;
-          if (d.motion == MOTION_HAND_EYE) { local = 6 + q; base = 0; na = d.views(); sa = 1; }
+          if (d.motion == MOTION_HAND_EYE) { run = part + lsmr_part_motion(d) + (size_t)q * d.views(); total = d.views(); }
         } else if (d.off_cameras >= 0 && i >= d.off_cameras && i < d.off_cameras + d.C * (5 + d.ND)) {
           const int q = i - d.off_cameras, c = q / (5 + d.ND), qq = q % (5 + d.ND);
           const int lq = qq < 4 ? qq : qq - 1;
           const bool masked = d.cam_kmask != nullptr && ((d.cam_kmask[c] >> lq) & 1u);
-          if (qq != 4 && !masked && d.KI > 0) { local = npc + lq; base = c * d.B; na = d.Fl; sa = CB; nb = d.B; sb = 1; }
+          if (qq != 4 && !masked && d.KI > 0) { run = part + lsmr_part_cam(d, c, 6 + lq); total = d.Fl * d.B; }
         }
-        if (local >= 0) {
-          const int total = na * nb;
+        if (run != nullptr) {
           constexpr int UNR = 8;
           for (int e0 = lane; e0 < total; e0 += 64 * UNR) {
             double v[UNR];
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-              const int e = e0 + 64 * u, a = e / nb, b_ = e - a * nb;
-              v[u] = e < total ? part[(size_t)(base + a * sa + b_ * sb) * part_stride + local] : 0.0;
-            }
+            for (int u = 0; u < UNR; ++u) v[u] = run[min(e0 + 64 * u, total - 1)];
 #pragma unroll
             for (int u = 0; u < UNR; ++u)
               if (e0 + 64 * u < total) sum += v[u];

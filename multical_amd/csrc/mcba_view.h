@@ -356,7 +356,29 @@ MCBA_HD int local_to_x(const Dims& d, int f, int c, int b, int i) {
   return d.off_cameras + c * (5 + d.ND) + (q < 4 ? q : q + 1);   // skip the skew slot (camera.py:153)
 }
 
-// is local parameter i an ELIMINATED per-frame parameter?
+// Layout of the per-view partials of J_h^T uhat in the two-launch LSMR iteration (k_lsmr_fused2 writes, k_lsmr_gather3 sums): TRANSPOSED
+// so that the views an x entry sums over are ONE contiguous run (the [view][local] layout of k_lsmr_jtu made every addend a cache
+// line of its own: 4 000 lines for a board-pose entry at the north-star rig).  Segments, v = (fl C + c) B + b frame-major:
+//   camera c, entry l_c in [0, 6 + KI) (pose | intrinsics):  [(c (6 + KI) + l_c) Fl B + fl B + b]
+//   board b, entry l_b in [0, 6):                            [(b 6 + l_b) Fl C + fl C + c]
+//   frame fl, entry e in [0, DFm) (static 6, rolling 12):    [(fl DFm + e) C B + c B + b]      hand-eye entry q in [0, 12): [q views + v]
+// local = index in the view's parameter vector: [0, 6) camera pose | [6, NPC - 6) motion | [NPC - 6, NPC) board pose | [NPC, NPC + KI)
+MCBA_HD size_t lsmr_part_cam(const Dims& d, int c, int lc) { return (size_t)(c * (6 + d.KI) + lc) * ((size_t)d.Fl * d.B); }
+MCBA_HD size_t lsmr_part_board(const Dims& d, int b, int lb) {
+  return (size_t)d.C * (6 + d.KI) * d.Fl * d.B + (size_t)(b * 6 + lb) * ((size_t)d.Fl * d.C);
+}
+MCBA_HD size_t lsmr_part_motion(const Dims& d) { return (size_t)d.views() * (6 + d.KI) + (size_t)d.views() * 6; }
+MCBA_HD size_t lsmr_part_index(const Dims& d, int v, int local) {
+  const int npc = 6 * d.NPB, b = v % d.B, c = (v / d.B) % d.C, fl = v / (d.B * d.C);
+  if (local < 6) return lsmr_part_cam(d, c, local) + (size_t)fl * d.B + b;
+  if (local >= npc) return lsmr_part_cam(d, c, 6 + local - npc) + (size_t)fl * d.B + b;
+  if (local >= npc - 6) return lsmr_part_board(d, b, local - (npc - 6)) + (size_t)fl * d.C + c;
+  const int e = local - 6, DFm = npc - 12;
+  if (d.motion == MOTION_HAND_EYE) return lsmr_part_motion(d) + (size_t)e * d.views() + v;
+  return lsmr_part_motion(d) + ((size_t)fl * DFm + e) * ((size_t)d.C * d.B) + (size_t)c * d.B + b;
+}
+
+// is local parameter i an ELIMINATED per-frame parameter?// is local parameter i an ELIMINATED per-frame parameter?
 MCBA_HD bool local_is_frame(const Dims& d, int i) {
   if (d.DF == 0) return false;
   return i >= 6 && i < 6 + d.DF;
