@@ -200,3 +200,22 @@ def test_lsmr_solve_is_bit_repeatable(name):
         its.append((res.nfev, res.status, h.lsmr_iterations(), res.cost))
   assert all(np.array_equal(xs[0], x) for x in xs[1:]), [float(np.abs(xs[0] - x).max()) for x in xs[1:]]
   assert all(it == its[0] for it in its), its
+
+
+@pytest.mark.parametrize("name", ["tiny_autoscale", "tiny_autoscale_huber", "tiny", "tiny_rolling", "tiny_handeye", "tiny_edge"])
+def test_workspace_calibrate_under_the_default_solver(name):
+  """Workspace.calibrate (workspace.py:228-247: enable -> 3 x {report, auto-scale, reject, bundle_adjust} -> report) under the DEFAULT
+  solver -- robust losses with `auto_scale` included -- against the reference's own run of the same loop: the inlier mask after three
+  rounds (up to the mask differences the reference's own perturbed re-runs show) and the inlier RMS within the reference's spread."""
+  import json
+  from multical_amd import Workspace
+  g, rig = load_golden(name)
+  kw = json.loads(str(g["ao_kwargs_json"])) if "ao_kwargs_json" in g else {}
+  assert calibration.get_solver() == "lsmr"
+  out = Workspace(mirror(rig)).calibrate(cameras=rig.optimize["cameras"], camera_poses=rig.optimize["camera_poses"],
+                                         loss=kw.get("loss", "linear"), auto_scale=kw.get("auto_scale", None))
+  allowed = int(g["ao_pert_mask_diff"].max()) if "ao_pert_mask_diff" in g else 0
+  assert int((out.inliers != g["ao_inliers"]).sum()) <= allowed, (int((out.inliers != g["ao_inliers"]).sum()), allowed)
+  spread = float(np.abs(g["ao_pert_rms_inliers"] - g["ao_rms_inliers"]).max())
+  rms_inl = out.error_statistics(True).rms
+  assert abs(rms_inl - float(g["ao_rms_inliers"])) <= max(1e-6, 3 * spread), (rms_inl, float(g["ao_rms_inliers"]), spread)
