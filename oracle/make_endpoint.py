@@ -2,6 +2,7 @@
 
     PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_endpoint cfg3 ba          # Calibration.bundle_adjust()
     PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_endpoint cfg3 ao          # adjust_outliers as Workspace.calibrate drives it
+    PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_endpoint cfg3 aor         # ... with loss='soft_l1', auto_scale=2.0
     PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_endpoint cfg3 pert 100 101   # self-sensitivity re-runs (seeds)
     PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_endpoint merge cfg3       # parts -> tests/golden/cfg3_endpoint.npz
 
@@ -127,6 +128,53 @@ def run_ao(cfg):
   _save(cfg, "ao", out)
 
 
+def run_ao_robust(cfg, loss='soft_l1', auto_scale=2.0):
+  """Workspace.calibrate(loss=..., auto_scale=...) (workspace.py:239-244): the outlier loop with a robust loss whose soft margin is
+  re-derived from the error quantile in every round (calibration.py:259-266)."""
+  rig, calib, ref, out = _rig(cfg)
+  error_stats = ref.optimization_calibration.error_stats
+  select_threshold = ref.optimization_calibration.select_threshold
+  log = _log()
+  t0 = time.time()
+  with _Spy() as spy:
+    ao = calib.adjust_outliers(num_adjustments=3, select_outliers=select_threshold(quantile=0.75, factor=5.0),
+                               select_scale=select_threshold(quantile=0.75, factor=auto_scale), loss=loss, tolerance=1e-4)
+    results = list(spy.results)
+  out["aor_kwargs_json"] = np.array(json.dumps(dict(loss=loss, auto_scale=auto_scale)))
+  out["aor_seconds"] = time.time() - t0
+  out["aor_x"], out["aor_x_raw"] = ao.param_vec, results[-1].x
+  out["aor_inliers_packed"] = np.packbits(ao.inliers.ravel())
+  out["aor_rms"] = error_stats(ao.reprojection_error).rms
+  out["aor_rms_inliers"] = error_stats(ao.reprojection_inliers).rms
+  out["aor_nfev"] = np.array([r.nfev for r in results])
+  out["aor_status"] = np.array([r.status for r in results])
+  out["aor_cost"] = np.array([r.cost for r in results])
+  out["aor_log"] = np.array(log.getvalue())
+  print(log.getvalue(), flush=True)
+  print(f"{cfg} ao {loss} auto_scale {auto_scale}: rms {float(out['aor_rms']):.9f} inliers {float(out['aor_rms_inliers']):.9f} "
+        f"nfev {out['aor_nfev']} status {out['aor_status']} {out['aor_seconds']:.0f} s", flush=True)
+  _save(cfg, "aor", out)
+
+
+def run_aor_pert(cfg, seeds, loss='soft_l1', auto_scale=2.0):
+  """the reference's own reproducibility of the robust outlier loop: `aor` repeated with N(0, 1e-12 px) on its residual function"""
+  rig, calib, ref, out = _rig(cfg)
+  error_stats = ref.optimization_calibration.error_stats
+  select_threshold = ref.optimization_calibration.select_threshold
+  base = np.load(os.path.join(PART_DIR, f"{cfg}_aor.npz"))
+  base_mask = np.unpackbits(base["aor_inliers_packed"])[:rig.valid.size].reshape(rig.valid.shape).astype(bool)
+  for s in seeds:
+    t0 = time.time()
+    with _Spy(PERT_SIGMA, seed=s) as spy:
+      ap = calib.adjust_outliers(num_adjustments=3, select_outliers=select_threshold(quantile=0.75, factor=5.0),
+                                 select_scale=select_threshold(quantile=0.75, factor=auto_scale), loss=loss, tolerance=1e-4)
+      nfev = [r.nfev for r in spy.results]
+    part = dict(out, seed=s, rms=error_stats(ap.reprojection_error).rms, rms_inliers=error_stats(ap.reprojection_inliers).rms,
+                mask_diff=int(np.sum(ap.inliers != base_mask)), nfev=np.array(nfev), seconds=time.time() - t0)
+    print(f"{cfg} aor pert {s}: inliers rms {float(part['rms_inliers']):.9f} mask diff {part['mask_diff']} nfev {nfev} {part['seconds']:.0f} s", flush=True)
+    _save(cfg, f"aorpert{s}", part)
+
+
 def run_pert(cfg, seeds):
   """The reference's own reproducibility at this size: the same call with N(0, 1e-12 px) added to its residual function
   (oracle/make_golden.py explains why that moves the end point)."""
@@ -146,10 +194,15 @@ def run_pert(cfg, seeds):
 def merge(cfg):
   import glob
   out = {}
-  for stage in ("ba", "ao"):
+  for stage in ("ba", "ao", "aor"):
     p = os.path.join(PART_DIR, f"{cfg}_{stage}.npz")
     if os.path.exists(p):
       out.update({k: v for k, v in np.load(p).items()})
+  aps = sorted(glob.glob(os.path.join(PART_DIR, f"{cfg}_aorpert*.npz")))
+  if aps and "aor_rms_inliers" in out:
+    ps = [np.load(p) for p in aps]
+    out["aor_pert_rms_inliers"] = np.array([float(p["rms_inliers"]) for p in ps])
+    out["aor_pert_mask_diff"] = np.array([int(p["mask_diff"]) for p in ps])
   perts = sorted(glob.glob(os.path.join(PART_DIR, f"{cfg}_pert*.npz")))
   if perts:
     ps = [np.load(p) for p in perts]
@@ -174,6 +227,10 @@ if __name__ == "__main__":
       run_ba(cfg)
     elif stage == "ao":
       run_ao(cfg)
+    elif stage == "aor":
+      run_ao_robust(cfg)
+    elif stage == "aorpert":
+      run_aor_pert(cfg, [int(s) for s in sys.argv[3:]])
     elif stage == "pert":
       run_pert(cfg, [int(s) for s in sys.argv[3:]])
     else:

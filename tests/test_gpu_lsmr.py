@@ -219,3 +219,25 @@ def test_workspace_calibrate_under_the_default_solver(name):
   spread = float(np.abs(g["ao_pert_rms_inliers"] - g["ao_rms_inliers"]).max())
   rms_inl = out.error_statistics(True).rms
   assert abs(rms_inl - float(g["ao_rms_inliers"])) <= max(1e-6, 3 * spread), (rms_inl, float(g["ao_rms_inliers"]), spread)
+
+
+@pytest.mark.parametrize("cfg", ["cfg5", "cfg3"])
+def test_workspace_calibrate_with_a_robust_loss_at_full_size(cfg):
+  """Workspace.calibrate(loss='soft_l1', auto_scale=2.0) (workspace.py:239-244: the soft margin re-derived from the error quantile in
+  every round) at the stated size under the default solver, against the unmodified reference's run of the same loop."""
+  import json
+  from multical_amd import Workspace
+  g, rig = load_endpoint(cfg)
+  if "aor_inliers_packed" not in g:
+    pytest.skip("robust outlier loop of the reference not generated (oracle/make_endpoint.py aor)")
+  kw = json.loads(str(g["aor_kwargs_json"]))
+  out = Workspace(mirror(rig)).calibrate(cameras=rig.optimize["cameras"], camera_poses=rig.optimize["camera_poses"],
+                                         loss=kw["loss"], auto_scale=kw["auto_scale"])
+  ref_mask = np.unpackbits(g["aor_inliers_packed"])[:rig.valid.size].reshape(rig.valid.shape).astype(bool)
+  allowed = 2 + (int(g["aor_pert_mask_diff"].max()) if "aor_pert_mask_diff" in g else 0)
+  assert int(np.sum(out.inliers != ref_mask)) <= allowed
+  spread = float(np.abs(g["aor_pert_rms_inliers"] - g["aor_rms_inliers"]).max()) if "aor_pert_rms_inliers" in g else 0.0
+  rms_inl = out.error_statistics(True).rms
+  print(f"{cfg}: reference inlier RMS {float(g['aor_rms_inliers']):.9f} (nfev {g['aor_nfev']}, {float(g['aor_seconds']):.0f} s), "
+        f"here {rms_inl - float(g['aor_rms_inliers']):+.2e}, reference spread {spread:.1e}")
+  assert abs(rms_inl - float(g["aor_rms_inliers"])) <= max(1e-5, 3 * spread)
