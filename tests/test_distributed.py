@@ -73,6 +73,57 @@ def test_sharded_normal_equations_sum_gloo(name, tmp_path):
   assert red[-1] == hm.m                                           # shards partition the residual vector
 
 
+def _cpu_lsmr_worker(rank, world, port, name, out):
+  sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+  import torch
+  import torch.distributed as dist
+  from hostmath_lib import HostMath
+  os.environ["MASTER_ADDR"] = "127.0.0.1"
+  os.environ["MASTER_PORT"] = str(port)
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  g, rig = load_golden(name)
+  c = mirror(rig)
+  F = rig.valid.shape[1]
+  f0, f1 = mdist.frame_shards(F, world, c.inliers.sum(axis=(0, 2, 3)).astype(float))[rank]
+  hm = HostMath(c, frame_range=(f0, f1))
+  rng = np.random.default_rng(12)                      # the same v, u on every rank
+  x = g["x0"] + 1e-3 * rng.normal(size=g["x0"].size)
+  v = rng.normal(size=g["x0"].size)
+  u = rng.normal(size=g["r0"].size)
+  # rows of this shard in the reference's residual order (C-order over (c, f, b, p) restricted to the inliers)
+  frame_of_row = np.repeat(np.nonzero(c.inliers)[1], 2)
+  mine = (frame_of_row >= f0) & (frame_of_row < f1)
+  assert mine.sum() == hm.m
+  jv_local, jtu_local = hm.lsmr_products(x, v, u[mine])
+  # J v: every row is computed by the rank that owns its frame -- no collective; J^T u: a sum over views, i.e. over the ranks
+  jv = np.zeros(u.size)
+  jv[mine] = jv_local
+  tj, tt = torch.from_numpy(jv), torch.from_numpy(jtu_local.copy())
+  dist.all_reduce(tj)                                   # (an all-gather written as a sum of disjoint supports)
+  dist.all_reduce(tt)                                   # the GPU path reduces the SHARED entries only; the frame entries stay with the owner
+  if rank == 0:
+    np.savez(out, jv=tj.numpy(), jtu=tt.numpy(), x=x, v=v, u=u)
+  dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["tiny_rolling", "tiny_boards", "cfg1"])
+def test_sharded_lsmr_products_sum_gloo(name, tmp_path):
+  """The decomposition the frame-sharded lsmr mode rests on, with the product's device functions on the CPU and a world-size-2 gloo
+  group: J v is local to the owner of a frame, J^T u is the sum of the ranks' partial products (shared entries: a sum over all ranks,
+  frame entries: non-zero on the owner only).  (The device kernels themselves: test_sharded_lsmr_solve_two_ranks_one_gpu.)"""
+  import torch.multiprocessing as mp
+  from hostmath_lib import HostMath
+  out = str(tmp_path / "lsmr_products.npz")
+  mp.spawn(_cpu_lsmr_worker, args=(2, _free_port(), name, out), nprocs=2, join=True)
+  r = np.load(out)
+  g, rig = load_golden(name)
+  hm = HostMath(mirror(rig))
+  J = hm.jacobian(r["x"])
+  A = abs(J)
+  assert np.abs(r["jv"] - J @ r["v"]).max() <= 1e-12 * (A @ np.abs(r["v"])).max()
+  assert np.abs(r["jtu"] - J.T @ r["u"]).max() <= 1e-12 * (A.T @ np.abs(r["u"])).max()
+
+
 def _gpu_worker(rank, world, port, name, out, empty_last=False, frames=None):
   sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
   import torch
