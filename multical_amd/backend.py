@@ -519,6 +519,39 @@ class Handle(object):
     k_lsmr_gather2 / k_lsmr_update2), 0 = the six-launch form of round 4."""
     check(self.lib.mcba_debug_set_lsmr_fused(self.h, int(mode)))
 
+  def lsmr_solve(self, x, damp, scale=None, loss='linear', f_scale=1.0):
+    """ONE call of the device's LSMR solve (mcba_debug_lsmr_solve) on the linearisation at x: returns (gn_h, scale, info) with
+    info = dict(istop, itn, normr, normar, normA, condA, normx, normb) -- scipy's `lsmr` return tuple -- test hook.  scale = None:
+    scipy's Jacobian scaling of a first iterate; else the column scaling d to use (J_h = J diag(d))."""
+    x = self._x(x)
+    scale_in = None if scale is None else self._x(scale)
+    gn, scale, out = np.empty(self.n_params), np.empty(self.n_params), np.empty(8)
+    opt = make_options(loss=loss, f_scale=f_scale)
+    check(self.lib.mcba_debug_lsmr_solve(self.h, _ptr(x, C.c_double), C.byref(opt), C.c_double(damp),
+                                         None if scale_in is None else _ptr(scale_in, C.c_double), _ptr(gn, C.c_double),
+                                         _ptr(scale, C.c_double), _ptr(out, C.c_double)))
+    keys = ("istop", "itn", "normr", "normar", "normA", "condA", "normx", "normb")
+    info = {k: (int(v) if k in ("istop", "itn") else float(v)) for k, v in zip(keys, out)}
+    return gn, scale, info
+
+  def set_lsmr_trace(self, scalars=True):
+    """ask the next lsmr-mode solves for normr .. normx of every LSMR call (lsmr_trace) -- test / profiling hook"""
+    check(self.lib.mcba_debug_set_lsmr_trace(self.h, 1 if scalars else 0))
+
+  def lsmr_trace(self):
+    """The LSMR calls of the last `solve(tr_solver='lsmr')`: a list of dicts (iteration, damp, Delta, istop, itn, normr, normar,
+    normA, condA, normx); the last five are NaN unless set_lsmr_trace() preceded the solve."""
+    n = C.c_int32()
+    check(self.lib.mcba_debug_lsmr_trace(self.h, 0, None, C.byref(n)))
+    rows = np.zeros((max(n.value, 1), 10))
+    check(self.lib.mcba_debug_lsmr_trace(self.h, n.value, _ptr(rows, C.c_double), C.byref(n)))
+    keys = ("iteration", "damp", "Delta", "istop", "itn", "normr", "normar", "normA", "condA", "normx")
+    return [{k: (int(v) if k in ("iteration", "istop", "itn") else float(v)) for k, v in zip(keys, r)} for r in rows[:n.value]]
+
+  def set_lsmr_grid(self, grid):
+    """persistent workgroups of the LSMR product kernels (default 2048): only the summation order changes -- experiment hook"""
+    check(self.lib.mcba_debug_set_lsmr_grid(self.h, int(grid)))
+
   def lsmr_iterations(self):
     """LSMR iterations of the last `solve(tr_solver='lsmr')` on this handle."""
     n = C.c_int64()

@@ -349,6 +349,12 @@ struct mcba_handle_s {
   // solver state
   DevBuf<double> x, xnew, scale_inv, dsc, gh, gn, scal, costpart, Lf, W, yf, P, sbuf, ps;
   long long lsmr_iterations_last = 0;     // LSMR iterations of the last solve_lsmr (mcba_debug_lsmr_info)
+  int lsmr_grid = 2048;                   // persistent single-wave workgroups of the LSMR product kernels (mcba_debug_set_lsmr_grid: grid experiments)
+  // one row per LSMR call of the last solve_lsmr (mcba_debug_lsmr_trace): scipy's return tuple of `lsmr` beside the trust-region
+  // quantities the call was made with
+  struct LsmrCall { double tr_iteration, damp, Delta, istop, itn, normr, normar, normA, condA, normx; };
+  std::vector<LsmrCall> lsmr_trace;
+  bool lsmr_trace_scalars = false;        // also fetch normr .. normx of every call from the state block (one small copy + wait per call)
   DevBuf<double> ls_state;                // solver = "lsmr": scalar state of the running LSMR solve (mcba_lsmr.h)
   unsigned long long ls_call = 0;         // ... and the number of the solve (tag of its progress word, h_pub_seq[1])
   DevBuf<double> scale_inv2, dsc2, gh2;   // scaling of a trial point, computed speculatively (mcba_solve) and swapped in on acceptance
@@ -2223,6 +2229,52 @@ struct LsmrOps {
   }
 };
 
+// every buffer the lsmr route needs on this handle (solve_lsmr, the debug and the timing entry points); idempotent
+static LsmrOps lsmr_setup(mcba_handle_s* h) {
+  const Dims& d = h->d;
+  ensure_view_first(h);
+  const size_t m = 2 * (size_t)h->n_inliers;
+  const int NL = 6 * d.NPB + d.KI;
+  LsmrOps op{h, std::max(1, std::min(h->lsmr_grid, d.views())), (NL + 1) & ~1, m};
+  for (DevBuf<double>* b : {&h->ls_u, &h->ls_ua, &h->ls_ub})
+    if (b->n < std::max<size_t>(m, 2)) b->alloc(std::max<size_t>(m, 2), false);
+  if (h->ls_part.n < (size_t)std::max(d.views(), 1) * op.part_stride) h->ls_part.alloc((size_t)std::max(d.views(), 1) * op.part_stride, true);
+  else HIP_OK(hipMemsetAsync(h->ls_part.p, 0, h->ls_part.n * sizeof(double), h->stream));
+  for (DevBuf<double>* b : {&h->ls_v, &h->ls_vraw, &h->ls_h, &h->ls_hbar, &h->ls_x, &h->ls_nrm})
+    if (b->n < (size_t)d.n) b->alloc((size_t)d.n, true);
+  if (h->ls_partial.n < (size_t)op.nblk) h->ls_partial.alloc((size_t)op.nblk, false);
+  if (h->ls_out.n < (size_t)LS_NSLOTS + 8) h->ls_out.alloc((size_t)LS_NSLOTS + 8, false);
+  if (h->ls_state.n < (size_t)2 * LS_NSLOTS) h->ls_state.alloc((size_t)2 * LS_NSLOTS, true);   // [A | B] (fused iterations)
+  const size_t nvb = (size_t)(d.n + 255) / 256;
+  if (h->ls_xpart.n < std::max(nvb, (size_t)op.nblk) + 1) h->ls_xpart.alloc(std::max(nvb, (size_t)op.nblk) + 1, true);
+  if (h->ls_vpart.n < (size_t)op.gather3_grid() + 1) h->ls_vpart.alloc((size_t)op.gather3_grid() + 1, true);
+  op.ensure_part2(true);
+  if (d.off_boards >= 0) {   // boards=True: jp^T u per observation + the residual index of every slot (k_lsmr_gather)
+    if (h->ls_bpart.n < std::max<size_t>(3 * (size_t)h->n_inliers, 3)) h->ls_bpart.alloc(std::max<size_t>(3 * (size_t)h->n_inliers, 3), false);
+    ensure_obs_index(h);
+  }
+  return op;
+}
+
+// normr, normar, normA, condA, normx of the finished lsmr_solve from its state block (a copy + a wait: debug / trace only)
+void lsmr_fetch_scalars(mcba_handle_s* h, mcba_handle_s::LsmrCall& c);
+
+// the state block that holds the end of the last lsmr_solve (where the stopping tests of each iteration form write it)
+const double* lsmr_final_state(const mcba_handle_s* h) {
+  return h->lsmr_fused == 1 ? h->ls_state.p + LS_NSLOTS : h->ls_state.p;
+}
+
+void lsmr_fetch_scalars(mcba_handle_s* h, mcba_handle_s::LsmrCall& c) {
+  double L[LS_NSLOTS];
+  HIP_OK(hipMemcpyAsync(L, lsmr_final_state(h), sizeof(L), hipMemcpyDeviceToHost, h->stream));
+  sync(h);
+  if (c.itn == 0) {   // (x = 0 returned from the prologue: the state was never initialised for this call)
+    c.normr = c.normar = c.normA = c.condA = c.normx = std::numeric_limits<double>::quiet_NaN();
+    return;
+  }
+  c.normr = L[LS_NORMR]; c.normar = L[LS_NORMAR]; c.normA = L[LS_NORMA]; c.condA = L[LS_CONDA]; c.normx = std::sqrt(L[LS_X2]);
+}
+
 // scipy.sparse.linalg.lsmr(J_h, f, damp, atol = btol = 1e-6, conlim = 1e8, maxiter = min(m, n)) -- the call of trf.py:481 --
 // with the two products on the device and the scalar recurrences (lsmr.py:300-420, transcribed in order) on the host.
 // The solution is left in h->ls_x; returns the number of iterations, *istop_out = scipy's stopping reason.
@@ -2353,25 +2405,11 @@ static void solve_lsmr(mcba_handle h, double* x_inout, const mcba_options* opt, 
   const int max_nfev = opt->max_nfev > 0 ? opt->max_nfev : d.n * 100;
   const double NaN = std::numeric_limits<double>::quiet_NaN();
   double* S = h->h_scal;
-  ensure_view_first(h);
-  const size_t m = 2 * (size_t)h->n_inliers;
-  const int NL = 6 * d.NPB + d.KI;
-  // (persistent single-wave workgroups of the product kernels; MCBA_LSMR_GRID: debug switch for grid experiments)
-  static const int lsmr_grid = dbg_switch("MCBA_LSMR_GRID") ? std::max(64, atoi(dbg_switch("MCBA_LSMR_GRID"))) : 2048;
-  LsmrOps op{h, std::max(1, std::min(lsmr_grid, d.views())), (NL + 1) & ~1, m};
-  for (DevBuf<double>* b : {&h->ls_u, &h->ls_ua, &h->ls_ub})
-    if (b->n < std::max<size_t>(m, 2)) b->alloc(std::max<size_t>(m, 2), false);
-  if (h->ls_part.n < (size_t)std::max(d.views(), 1) * op.part_stride) h->ls_part.alloc((size_t)std::max(d.views(), 1) * op.part_stride, true);
-  else HIP_OK(hipMemsetAsync(h->ls_part.p, 0, h->ls_part.n * sizeof(double), h->stream));
-  for (DevBuf<double>* b : {&h->ls_v, &h->ls_vraw, &h->ls_h, &h->ls_hbar, &h->ls_x, &h->ls_nrm})
-    if (b->n < (size_t)d.n) b->alloc((size_t)d.n, true);
-  if (h->ls_partial.n < (size_t)op.nblk) h->ls_partial.alloc((size_t)op.nblk, false);
-  if (h->ls_out.n < 8) h->ls_out.alloc(8, false);
-  op.ensure_part2(true);
-  if (d.off_boards >= 0) {   // boards=True: jp^T u per observation + the residual index of every slot (k_lsmr_gather)
-    if (h->ls_bpart.n < std::max<size_t>(3 * (size_t)h->n_inliers, 3)) h->ls_bpart.alloc(std::max<size_t>(3 * (size_t)h->n_inliers, 3), false);
-    ensure_obs_index(h);
-  }
+  // (persistent single-wave workgroups of the product kernels: h->lsmr_grid, default 2048; MCBA_LSMR_GRID: process-wide debug switch)
+  if (const char* gsw = dbg_switch("MCBA_LSMR_GRID")) h->lsmr_grid = std::max(64, atoi(gsw));
+  LsmrOps op = lsmr_setup(h);
+  const size_t m = op.m;
+  h->lsmr_trace.clear();
 
   // residuals of the WHOLE problem (scipy's maxiter = min(m, n) must be the same number on every rank of a frame-sharded solve,
   // whatever the rank's own shard holds -- an empty shard included): one 1-double all-reduce per solve
@@ -2444,6 +2482,8 @@ static void solve_lsmr(mcba_handle h, double* x_inout, const mcba_options* opt, 
     int istop = 0;
     const int itn = lsmr_solve(op, std::sqrt(reg_term), &istop);
     lsmr_iterations += itn;
+    h->lsmr_trace.push_back({(double)iteration, std::sqrt(reg_term), Delta, (double)istop, (double)itn, NaN, NaN, NaN, NaN, NaN});
+    if (h->lsmr_trace_scalars) lsmr_fetch_scalars(h, h->lsmr_trace.back());
     if (trace)
       fprintf(stderr, "[mcba_solve lsmr rank %d/%d] iteration %d: cost %.17g Q00 %.17g gg %.17g Delta %.17g reg_term %.17g m %zu -> lsmr itn %d istop %d\n",
               d.shard_rank, d.shard_world, iteration, cost, Q00, gg, Delta, reg_term, op.m_global, itn, istop);
@@ -2548,22 +2588,8 @@ int32_t mcba_debug_lsmr_products(mcba_handle h, const double* x, const double* v
   g_fill_stream = h->stream;
   set_loss(h, nullptr);
   const Dims& d = h->d;
-  ensure_view_first(h);
-  const size_t m = 2 * (size_t)h->n_inliers;
-  const int NL = 6 * d.NPB + d.KI;
-  LsmrOps op{h, std::max(1, std::min(2048, d.views())), (NL + 1) & ~1, m};
-  for (DevBuf<double>* b : {&h->ls_u, &h->ls_ua})
-    if (b->n < std::max<size_t>(m, 2)) b->alloc(std::max<size_t>(m, 2), false);
-  if (h->ls_part.n < (size_t)std::max(d.views(), 1) * op.part_stride) h->ls_part.alloc((size_t)std::max(d.views(), 1) * op.part_stride, true);
-  else HIP_OK(hipMemsetAsync(h->ls_part.p, 0, h->ls_part.n * sizeof(double), h->stream));
-  for (DevBuf<double>* b : {&h->ls_v, &h->ls_vraw, &h->ls_nrm})
-    if (b->n < (size_t)d.n) b->alloc((size_t)d.n, true);
-  if (h->ls_partial.n < (size_t)op.nblk) h->ls_partial.alloc((size_t)op.nblk, false);
-  if (h->ls_out.n < 8) h->ls_out.alloc(8, false);
-  if (d.off_boards >= 0) {
-    if (h->ls_bpart.n < std::max<size_t>(3 * (size_t)h->n_inliers, 3)) h->ls_bpart.alloc(std::max<size_t>(3 * (size_t)h->n_inliers, 3), false);
-    ensure_obs_index(h);
-  }
+  LsmrOps op = lsmr_setup(h);
+  const size_t m = op.m;
   upload_x(h, x, h->x.p);
   sync(h);   // (h_x is reused for v below)
   lsmr_linearize(h, h->x.p);
@@ -2599,12 +2625,91 @@ int32_t mcba_debug_set_switch(const char* name, const char* value) {
   API_END
 }
 
-/* 1 (default): the three-launch LSMR iteration (k_lsmr_fused / k_lsmr_gather2 / k_lsmr_update2); 0: the six-launch form (A/B) */
+/* 2 (default): the two-launch LSMR iteration (k_lsmr_fused2 / k_lsmr_gather3); 1: three launches (k_lsmr_fused / k_lsmr_gather2 /
+ * k_lsmr_update2); 0: the six-launch form of round 4 (A/B runs, test_lsmr_iteration_forms_agree) */
 int32_t mcba_debug_set_lsmr_fused(mcba_handle h, int32_t on) {
   API_BEGIN
   REQUIRE(h, "null handle");
   REQUIRE(on >= 0 && on <= 2, "0 = six launches, 1 = three, 2 = two");
   h->lsmr_fused = on;
+  API_END
+}
+
+/* test hook (mcba_debug.h): ONE call of the device's LSMR solve -- scipy.sparse.linalg.lsmr(J_h, f, damp, atol = btol = 1e-6), the
+ * call of scipy/optimize/_lsq/trf.py:481 -- on the linearisation at x with scipy's Jacobian scaling of a FIRST iterate
+ * (compute_jac_scale without a previous scale), through lsmr_solve itself (whichever iteration form the handle is set to).
+ * scale_in (may be NULL) replaces that scaling (a later iterate: scipy keeps the running maximum of the column norms).
+ * gn_h_out[n] = the solution, scale_out[n] = d (J_h = J diag(d)), out[8] = scipy's return tuple {istop, itn, normr, normar, normA,
+ * condA, normx} + normb.                                                                                                       */
+int32_t mcba_debug_lsmr_solve(mcba_handle h, const double* x, const mcba_options* opt, double damp, const double* scale_in,
+                              double* gn_h_out, double* scale_out, double* out) {
+  API_BEGIN
+  REQUIRE(h && x && gn_h_out && out, "null argument");
+  REQUIRE(h->allreduce == nullptr, "single handles only");
+  REQUIRE(damp >= 0, "damp must not be negative");
+  g_fill_stream = h->stream;
+  set_loss(h, opt);
+  const Dims& d = h->d;
+  const ScalLayout& sl = h->sl;
+  LsmrOps op = lsmr_setup(h);
+  upload_x(h, x, h->x.p);
+  sync(h);   // (h_x is reused below)
+  lsmr_linearize(h, h->x.p);
+  hipLaunchKernelGGL(k_vec_scale, dim3(sl.nvb), dim3(256), 0, h->stream, d, h->x.p, h->g(), h->diag(), h->scale_inv.p, h->dsc.p, h->gh.p, 1,
+                     h->scal.p + sl.vs, h->costcount(), h->scal.p + TR_COST);
+  if (scale_in != nullptr) {   // the scaling of a LATER iterate (scipy keeps the running maximum of the column norms: common.py:606-611)
+    sync(h);
+    upload_x(h, scale_in, h->dsc.p);
+    sync(h);
+  }
+  int istop = 0;
+  const int itn = lsmr_solve(op, damp, &istop);
+  mcba_handle_s::LsmrCall c{0.0, damp, 0.0, (double)istop, (double)itn, 0, 0, 0, 0, 0};
+  lsmr_fetch_scalars(h, c);
+  double normb = 0.0;
+  HIP_OK(hipMemcpyAsync(&normb, lsmr_final_state(h) + LS_NORMB, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipMemcpyAsync(h->h_x, h->ls_x.p, (size_t)d.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  sync(h);
+  to_caller(h, gn_h_out, h->h_x);
+  if (scale_out != nullptr) {
+    HIP_OK(hipMemcpyAsync(h->h_x, h->dsc.p, (size_t)d.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    sync(h);
+    to_caller(h, scale_out, h->h_x);
+  }
+  out[0] = c.istop; out[1] = c.itn; out[2] = c.normr; out[3] = c.normar; out[4] = c.normA; out[5] = c.condA; out[6] = c.normx;
+  out[7] = itn > 0 ? normb : std::numeric_limits<double>::quiet_NaN();
+  API_END
+}
+
+/* one row per LSMR call of the last mcba_solve with tr_solver = MCBA_TR_LSMR on this handle, 10 doubles each: {trust-region iteration,
+ * damp, Delta, istop, itn, normr, normar, normA, condA, normx}; the last five are NaN unless mcba_debug_set_lsmr_trace(h, 1) asked
+ * for them BEFORE the solve (one small copy + wait per call).  rows may be NULL (count only); at most cap rows are written.        */
+int32_t mcba_debug_lsmr_trace(mcba_handle h, int32_t cap, double* rows, int32_t* n_rows) {
+  API_BEGIN
+  REQUIRE(h && n_rows, "null argument");
+  *n_rows = (int32_t)h->lsmr_trace.size();
+  if (rows != nullptr)
+    for (int i = 0; i < std::min<int>(cap, *n_rows); ++i) {
+      const auto& c = h->lsmr_trace[(size_t)i];
+      const double r[10] = {c.tr_iteration, c.damp, c.Delta, c.istop, c.itn, c.normr, c.normar, c.normA, c.condA, c.normx};
+      memcpy(rows + 10 * (size_t)i, r, sizeof(r));
+    }
+  API_END
+}
+
+int32_t mcba_debug_set_lsmr_trace(mcba_handle h, int32_t scalars) {
+  API_BEGIN
+  REQUIRE(h, "null handle");
+  h->lsmr_trace_scalars = scalars != 0;
+  API_END
+}
+
+/* persistent single-wave workgroups of the LSMR product kernels on this handle (default 2048; >= 64): changes only the order in
+ * which partial sums are folded -- the summation-order experiment of profiles/r06_lsmr_sign.* */
+int32_t mcba_debug_set_lsmr_grid(mcba_handle h, int32_t grid) {
+  API_BEGIN
+  REQUIRE(h && grid >= 64 && grid <= 65536, "bad grid");
+  h->lsmr_grid = grid;
   API_END
 }
 
@@ -3254,23 +3359,8 @@ int32_t mcba_debug_lsmr_fused_products(mcba_handle h, const double* x, const dou
   g_fill_stream = h->stream;
   set_loss(h, nullptr);
   const Dims& d = h->d;
-  ensure_view_first(h);
-  const size_t m = 2 * (size_t)h->n_inliers;
-  const int NL = 6 * d.NPB + d.KI;
-  LsmrOps op{h, std::max(1, std::min(2048, d.views())), (NL + 1) & ~1, m};
-  if (h->ls_u.n < std::max<size_t>(m, 2)) h->ls_u.alloc(std::max<size_t>(m, 2), true);
-  if (h->ls_part.n < (size_t)std::max(d.views(), 1) * op.part_stride) h->ls_part.alloc((size_t)std::max(d.views(), 1) * op.part_stride, true);
-  for (DevBuf<double>* b : {&h->ls_v, &h->ls_vraw, &h->ls_h, &h->ls_hbar, &h->ls_x, &h->ls_nrm})
-    if (b->n < (size_t)d.n) b->alloc((size_t)d.n, true);
-  if (h->ls_partial.n < (size_t)op.nblk) h->ls_partial.alloc((size_t)op.nblk, false);
-  if (h->ls_out.n < (size_t)LS_NSLOTS + 8) h->ls_out.alloc((size_t)LS_NSLOTS + 8, false);
-  if (h->ls_state.n < (size_t)2 * LS_NSLOTS) h->ls_state.alloc((size_t)2 * LS_NSLOTS, true);
-  if (h->ls_xpart.n < (size_t)op.nblk + 1) h->ls_xpart.alloc((size_t)op.nblk + 1, true);
-  if (h->ls_vpart.n < (size_t)op.gather3_grid() + 1) h->ls_vpart.alloc((size_t)op.gather3_grid() + 1, true);
-  if (d.off_boards >= 0) {
-    if (h->ls_bpart.n < std::max<size_t>(3 * (size_t)h->n_inliers, 3)) h->ls_bpart.alloc(std::max<size_t>(3 * (size_t)h->n_inliers, 3), false);
-    ensure_obs_index(h);
-  }
+  LsmrOps op = lsmr_setup(h);
+  const size_t m = op.m;
   upload_x(h, x, h->x.p);
   sync(h);
   lsmr_linearize(h, h->x.p);
@@ -3317,23 +3407,7 @@ int32_t mcba_time_lsmr_iteration(mcba_handle h, const double* x, int32_t repeats
   g_fill_stream = h->stream;
   set_loss(h, nullptr);
   const Dims& d = h->d;
-  ensure_view_first(h);
-  const size_t m = 2 * (size_t)h->n_inliers;
-  const int NL = 6 * d.NPB + d.KI;
-  LsmrOps op{h, std::max(1, std::min(2048, d.views())), (NL + 1) & ~1, m};
-  if (h->ls_u.n < std::max<size_t>(m, 2)) h->ls_u.alloc(std::max<size_t>(m, 2), true);
-  if (h->ls_part.n < (size_t)std::max(d.views(), 1) * op.part_stride) h->ls_part.alloc((size_t)std::max(d.views(), 1) * op.part_stride, true);
-  for (DevBuf<double>* b : {&h->ls_v, &h->ls_vraw, &h->ls_h, &h->ls_hbar, &h->ls_x, &h->ls_nrm})
-    if (b->n < (size_t)d.n) b->alloc((size_t)d.n, true);
-  if (h->ls_partial.n < (size_t)op.nblk) h->ls_partial.alloc((size_t)op.nblk, false);
-  if (h->ls_out.n < 8) h->ls_out.alloc(8, false);
-  if (h->ls_state.n < (size_t)2 * LS_NSLOTS) h->ls_state.alloc((size_t)2 * LS_NSLOTS, true);
-  if (h->ls_xpart.n < (size_t)op.nblk + 1) h->ls_xpart.alloc((size_t)op.nblk + 1, true);
-  if (h->ls_vpart.n < (size_t)op.gather3_grid() + 1) h->ls_vpart.alloc((size_t)op.gather3_grid() + 1, true);
-  if (d.off_boards >= 0) {
-    if (h->ls_bpart.n < std::max<size_t>(3 * (size_t)h->n_inliers, 3)) h->ls_bpart.alloc(std::max<size_t>(3 * (size_t)h->n_inliers, 3), false);
-    ensure_obs_index(h);
-  }
+  LsmrOps op = lsmr_setup(h);
   upload_x(h, x, h->x.p);
   sync(h);
   lsmr_linearize(h, h->x.p);
@@ -3355,7 +3429,6 @@ int32_t mcba_time_lsmr_iteration(mcba_handle h, const double* x, int32_t repeats
                        (const double*)h->ls_partial.p, op.nblk, (const double*)h->ls_xpart.p, std::max(1, std::min(op.nblk, (d.n + 63) / 64)),
                        0ull, h->h_pub_seq + 1, op.extra());
   };
-  if (h->ls_out.n < (size_t)LS_NSLOTS + 8) h->ls_out.alloc((size_t)LS_NSLOTS + 8, false);   // (scratch state of the timed gather)
   product();
   gather();
   sync(h);

@@ -5,7 +5,13 @@
 // Every expression is evaluated in scipy's order WITHOUT contraction into fused multiply-adds (the iteration amplifies rounding
 // differences: tests/test_oracle.py::test_scipys_lsmr_step_is_not_reproducible_beyond_rounding_noise).
 #pragma once
+#include <math.h>
+#if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
+#define LSMR_HD __host__ __device__ inline
+#else
+#define LSMR_HD inline   // (tests/hostmath: the same source under g++, which never contracts on plain x86-64)
+#endif
 
 enum LsmrSlot : int {
   LS_ALPHA = 0, LS_BETA, LS_INV_BETA, LS_INV_ALPHA, LS_C_HBAR, LS_C_X, LS_C_H,   // read by the vector kernels
@@ -14,16 +20,17 @@ enum LsmrSlot : int {
   LS_ZETABAR, LS_ALPHABAR, LS_RHO, LS_RHOBAR, LS_CBAR, LS_SBAR, LS_BETADD, LS_BETAD, LS_RHODOLD, LS_TAUTILDEOLD, LS_THETATILDE,
   LS_ZETA, LS_DD, LS_NORMA2, LS_MAXRBAR, LS_MINRBAR, LS_NORMR, LS_NORMA, LS_CONDA, LS_NORMAR,
   LS_PENDING,                  // two-launch iteration: a new v_raw (and its |.|^2 partials) waits for its rotation + vector update
+  LS_X2,                       // |x|^2 the last stopping tests saw (normx of scipy's return tuple: mcba_debug_lsmr_solve, the call trace)
   LS_NSLOTS
 };
 
 // progress word of a solve in pinned host memory: [call id : 24 | istop : 8 | completed iterations : 32]
-__host__ __device__ inline unsigned long long lsmr_progress_word(unsigned long long call, int istop, long long itn) {
+LSMR_HD unsigned long long lsmr_progress_word(unsigned long long call, int istop, long long itn) {
   return ((call & 0xffffffull) << 40) | ((unsigned long long)(istop & 0xff) << 32) | (unsigned long long)(itn & 0xffffffffll);
 }
 
 // lsmr.py:_sym_ortho
-__host__ __device__ inline void lsmr_sym_ortho(double a, double b, double& c, double& s, double& r) {
+LSMR_HD void lsmr_sym_ortho(double a, double b, double& c, double& s, double& r) {
 #pragma clang fp contract(off)
   const double sa = a > 0 ? 1.0 : (a < 0 ? -1.0 : 0.0), sb = b > 0 ? 1.0 : (b < 0 ? -1.0 : 0.0);
   if (b == 0) { c = sa; s = 0; r = fabs(a); }
@@ -33,7 +40,7 @@ __host__ __device__ inline void lsmr_sym_ortho(double a, double b, double& c, do
 }
 
 // state in front of the first iteration (lsmr.py:262-298); alpha, beta, normb come from the two products of the prologue
-__host__ __device__ inline void lsmr_state_init(double* L, double alpha, double beta, double damp, double normb, double maxiter) {
+LSMR_HD void lsmr_state_init(double* L, double alpha, double beta, double damp, double normb, double maxiter) {
 #pragma clang fp contract(off)
   for (int i = 0; i < LS_NSLOTS; ++i) L[i] = 0.0;
   L[LS_ALPHA] = alpha; L[LS_BETA] = beta; L[LS_INV_ALPHA] = 1.0; L[LS_INV_BETA] = 1.0;
@@ -45,7 +52,7 @@ __host__ __device__ inline void lsmr_state_init(double* L, double alpha, double 
 }
 
 // u = A v - alpha u is formed: beta = |u| (lsmr.py:316-318)
-__host__ __device__ inline void lsmr_state_beta(double* L, double u2) {
+LSMR_HD void lsmr_state_beta(double* L, double u2) {
 #pragma clang fp contract(off)
   const double beta = sqrt(u2);
   L[LS_BETA] = beta;
@@ -55,7 +62,7 @@ __host__ __device__ inline void lsmr_state_beta(double* L, double u2) {
 
 // v = A^T u - beta v is formed (v2 = its squared norm): alpha, the rotations and the coefficients of the vector update
 // (lsmr.py:320-389)
-__host__ __device__ inline void lsmr_state_rotate(double* L, double v2) {
+LSMR_HD void lsmr_state_rotate(double* L, double v2) {
 #pragma clang fp contract(off)
   const double itn = L[LS_ITN] + 1.0;
   L[LS_ITN] = itn;
@@ -114,7 +121,7 @@ __host__ __device__ inline void lsmr_state_rotate(double* L, double v2) {
 
 // x is updated (x2 = |x|^2): the stopping tests of the iteration (lsmr.py:391-420, atol = btol = 1e-6, conlim = 1e8: the call of
 // scipy/optimize/_lsq/trf.py:481); returns scipy's istop, 0 = carry on
-__host__ __device__ inline int lsmr_state_test(const double* L, double x2) {
+LSMR_HD int lsmr_state_test(const double* L, double x2) {
 #pragma clang fp contract(off)
   const double atol = 1e-6, btol = 1e-6, ctol = 1 / 1e8;
   const double normx = sqrt(x2), normr = L[LS_NORMR], normA = L[LS_NORMA], normb = L[LS_NORMB], normar = L[LS_NORMAR];

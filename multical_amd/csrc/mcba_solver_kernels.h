@@ -2411,6 +2411,7 @@ __global__ __launch_bounds__(LSG_THREADS) void k_lsmr_gather2(Dims d, const doub
     double L[LS_NSLOTS];
     for (int k = 0; k < LS_NSLOTS; ++k) L[k] = lsA[k];
     const int istop = L[LS_ITN] > 0.0 ? lsmr_state_test(L, x2) : 0;
+    L[LS_X2] = x2;
     if (istop != 0) L[LS_ISTOP] = (double)istop;
     else lsmr_state_beta(L, u2);
     head[0] = L[LS_BETA]; head[1] = L[LS_INV_BETA]; head[2] = L[LS_SKIPV]; head[3] = L[LS_ISTOP];
@@ -2562,6 +2563,7 @@ __global__ __launch_bounds__(LSG3_THREADS) void k_lsmr_gather3(Dims d, const dou
       for (int k = 0; k < LS_NSLOTS; ++k) L[k] = lsIn[k];
       const double x2 = wave_fold_batched<4>(xpart, nx, lane);
       const int istop = L[LS_ITN] > 0.0 ? lsmr_state_test(L, x2) : 0;
+      L[LS_X2] = x2;
       if (istop != 0) L[LS_ISTOP] = (double)istop;
       else lsmr_state_beta(L, u2);
       L[LS_PENDING] = 1.0;
@@ -2786,6 +2788,7 @@ __global__ __launch_bounds__(1024) void k_lsmr_scal_a(double* __restrict__ ls, c
   const double x2 = test ? lsmr_fold(xsq, n, scratch) : 0.0;
   if (threadIdx.x == 0) {
     const int istop = test ? lsmr_state_test(ls, x2) : 0;
+    ls[LS_X2] = x2;
     if (istop != 0) ls[LS_ISTOP] = (double)istop;
     else lsmr_state_beta(ls, u2);
     // (relaxed: the host reads nothing but the word itself -- a system-scope RELEASE here would first write back the 12 MB of u that

@@ -12,6 +12,7 @@
 #include <vector>
 #include "../../multical_amd/csrc/mcba_lower.h"
 #include "../../multical_amd/csrc/mcba_view.h"
+#include "../../multical_amd/csrc/mcba_lsmr.h"
 
 using namespace mcba;
 
@@ -344,6 +345,25 @@ int32_t hm_lsmr_products(const mcba_problem* p, const double* x, const double* v
   if (!h.hp.ext2int.empty()) throw std::runtime_error("hm_lsmr_products: uniform camera blocks only");
   DISPATCH_CAM(lsmr_products_k, h, v, u, jv, jtu);
   HM_END
+}
+
+// the scalar recurrences of the device-resident LSMR solve (csrc/mcba_lsmr.h), one call each: the state block L has
+// hm_lsmr_nslots() doubles
+int32_t hm_lsmr_nslots() { return LS_NSLOTS; }
+void hm_lsmr_state_init(double* L, double alpha, double beta, double damp, double normb, double maxiter) {
+  lsmr_state_init(L, alpha, beta, damp, normb, maxiter);
+}
+void hm_lsmr_state_beta(double* L, double u2) { lsmr_state_beta(L, u2); }
+void hm_lsmr_state_rotate(double* L, double v2) { lsmr_state_rotate(L, v2); }
+int32_t hm_lsmr_state_test(const double* L, double x2) { return lsmr_state_test(L, x2); }
+int32_t hm_lsmr_slot(const char* name) {
+  static const char* names[] = {"alpha", "beta", "inv_beta", "inv_alpha", "c_hbar", "c_x", "c_h", "skipv", "istop", "itn", "maxiter", "damp",
+                                "normb", "zetabar", "alphabar", "rho", "rhobar", "cbar", "sbar", "betadd", "betad", "rhodold", "tautildeold",
+                                "thetatilde", "zeta", "dd", "norma2", "maxrbar", "minrbar", "normr", "norma", "conda", "normar", "pending", "x2"};
+  static_assert(sizeof(names) / sizeof(names[0]) == LS_NSLOTS, "slot names out of date");
+  for (int i = 0; i < LS_NSLOTS; ++i)
+    if (std::strcmp(names[i], name) == 0) return i;
+  return -1;
 }
 
 }  // extern "C"
