@@ -119,7 +119,7 @@ SYMBOLS = [
   ("mcba_debug_lsmr_info", C.c_int32, [H, C.POINTER(C.c_int64)]),
   ("mcba_debug_set_lsmr_fused", C.c_int32, [H, C.c_int32]),
   ("mcba_debug_set_switch", C.c_int32, [C.c_char_p, C.c_char_p]),
-  ("mcba_debug_lsmr_solve", C.c_int32, [H, c_double_p, C.POINTER(Options), C.c_double, c_double_p, c_double_p, c_double_p, c_double_p]),
+  ("mcba_debug_lsmr_solve", C.c_int32, [H, c_double_p, C.POINTER(Options), C.c_double, c_double_p, C.c_int32, c_double_p, c_double_p, c_double_p]),
   ("mcba_debug_lsmr_trace", C.c_int32, [H, C.c_int32, c_double_p, C.POINTER(C.c_int32)]),
   ("mcba_debug_set_lsmr_trace", C.c_int32, [H, C.c_int32]),
   ("mcba_debug_set_lsmr_grid", C.c_int32, [H, C.c_int32]),

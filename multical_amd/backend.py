@@ -519,16 +519,16 @@ class Handle(object):
     k_lsmr_gather2 / k_lsmr_update2), 0 = the six-launch form of round 4."""
     check(self.lib.mcba_debug_set_lsmr_fused(self.h, int(mode)))
 
-  def lsmr_solve(self, x, damp, scale=None, loss='linear', f_scale=1.0):
+  def lsmr_solve(self, x, damp, scale=None, maxiter=0, loss='linear', f_scale=1.0):
     """ONE call of the device's LSMR solve (mcba_debug_lsmr_solve) on the linearisation at x: returns (gn_h, scale, info) with
     info = dict(istop, itn, normr, normar, normA, condA, normx, normb) -- scipy's `lsmr` return tuple -- test hook.  scale = None:
-    scipy's Jacobian scaling of a first iterate; else the column scaling d to use (J_h = J diag(d))."""
+    scipy's Jacobian scaling of a first iterate; else the column scaling d to use (J_h = J diag(d)); maxiter > 0: scipy's `maxiter`."""
     x = self._x(x)
     scale_in = None if scale is None else self._x(scale)
     gn, scale, out = np.empty(self.n_params), np.empty(self.n_params), np.empty(8)
     opt = make_options(loss=loss, f_scale=f_scale)
     check(self.lib.mcba_debug_lsmr_solve(self.h, _ptr(x, C.c_double), C.byref(opt), C.c_double(damp),
-                                         None if scale_in is None else _ptr(scale_in, C.c_double), _ptr(gn, C.c_double),
+                                         None if scale_in is None else _ptr(scale_in, C.c_double), C.c_int32(int(maxiter)), _ptr(gn, C.c_double),
                                          _ptr(scale, C.c_double), _ptr(out, C.c_double)))
     keys = ("istop", "itn", "normr", "normar", "normA", "condA", "normx", "normb")
     info = {k: (int(v) if k in ("istop", "itn") else float(v)) for k, v in zip(keys, out)}

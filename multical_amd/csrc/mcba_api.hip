@@ -2070,6 +2070,7 @@ struct LsmrOps {
   size_t m;            // residuals of THIS handle (its frame shard)
   bool trace = false;  // MCBA_SOLVE_TRACE (debug switch): per-solve lines on stderr
   size_t m_global = 0; // residuals of the whole problem (frame-sharded: summed over the ranks): scipy's maxiter = min(m, n)
+  long long maxiter_override = 0;   // > 0: lsmr(..., maxiter = this) (test hook)
   bool sharded() const { return h->allreduce != nullptr; }
   double* bpart() const { return h->d.off_boards >= 0 ? h->ls_bpart.p : nullptr; }   // boards=True: jp^T u per observation
   LsmrGatherExtra extra() const { return LsmrGatherExtra{h->obs_index.p, h->board_off.p, bpart(), sharded() ? 1 : 0}; }
@@ -2282,7 +2283,8 @@ int lsmr_solve(LsmrOps& op, double damp, int* istop_out) {
   mcba_handle_s* h = op.h;
   const Dims& d = h->d;
   const int n = d.n;
-  const long long maxiter = std::min<long long>((long long)(op.m_global ? op.m_global : op.m), (long long)(h->ext2int.empty() ? n : h->n_ext));
+  long long maxiter = std::min<long long>((long long)(op.m_global ? op.m_global : op.m), (long long)(h->ext2int.empty() ? n : h->n_ext));
+  if (op.maxiter_override > 0) maxiter = op.maxiter_override;   // (mcba_debug_lsmr_solve: scipy's `maxiter` argument)
   const int nvb = (n + 255) / 256;
   double* u = h->ls_u.p;
   double* v = h->ls_v.p;
@@ -2638,10 +2640,12 @@ int32_t mcba_debug_set_lsmr_fused(mcba_handle h, int32_t on) {
 /* test hook (mcba_debug.h): ONE call of the device's LSMR solve -- scipy.sparse.linalg.lsmr(J_h, f, damp, atol = btol = 1e-6), the
  * call of scipy/optimize/_lsq/trf.py:481 -- on the linearisation at x with scipy's Jacobian scaling of a FIRST iterate
  * (compute_jac_scale without a previous scale), through lsmr_solve itself (whichever iteration form the handle is set to).
- * scale_in (may be NULL) replaces that scaling (a later iterate: scipy keeps the running maximum of the column norms).
+ * scale_in (may be NULL) replaces that scaling (a later iterate: scipy keeps the running maximum of the column norms); maxiter > 0 =
+ * scipy's `maxiter` argument (0: min(m, n)): the first few dozen Golub-Kahan steps can be compared with scipy's to rounding -- beyond
+ * that the bidiagonalisation of these Jacobians loses orthogonality and any two roundings of it drift apart (profiles/r06_lsmr_sign.md).
  * gn_h_out[n] = the solution, scale_out[n] = d (J_h = J diag(d)), out[8] = scipy's return tuple {istop, itn, normr, normar, normA,
  * condA, normx} + normb.                                                                                                       */
-int32_t mcba_debug_lsmr_solve(mcba_handle h, const double* x, const mcba_options* opt, double damp, const double* scale_in,
+int32_t mcba_debug_lsmr_solve(mcba_handle h, const double* x, const mcba_options* opt, double damp, const double* scale_in, int32_t maxiter,
                               double* gn_h_out, double* scale_out, double* out) {
   API_BEGIN
   REQUIRE(h && x && gn_h_out && out, "null argument");
@@ -2663,6 +2667,7 @@ int32_t mcba_debug_lsmr_solve(mcba_handle h, const double* x, const mcba_options
     sync(h);
   }
   int istop = 0;
+  op.maxiter_override = maxiter;
   const int itn = lsmr_solve(op, damp, &istop);
   mcba_handle_s::LsmrCall c{0.0, damp, 0.0, (double)istop, (double)itn, 0, 0, 0, 0, 0};
   lsmr_fetch_scalars(h, c);

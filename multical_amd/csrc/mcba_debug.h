@@ -51,10 +51,10 @@ int32_t mcba_debug_lsmr_fused_products(mcba_handle h, const double* x, const dou
 int32_t mcba_debug_lsmr_info(mcba_handle h, int64_t* lsmr_iterations);
 
 /* ONE call of the device's LSMR solve (lsmr_solve: scipy.sparse.linalg.lsmr(J_h, f, damp, atol = btol = 1e-6) of trf.py:481) on the
- * linearisation at x with scipy's Jacobian scaling of a first iterate (or scale_in[n], the scaling of a later iterate): gn_h_out[n] = the solution, scale_out[n] (may be NULL) = d with
+ * linearisation at x with scipy's Jacobian scaling of a first iterate (or scale_in[n], the scaling of a later iterate; maxiter > 0: scipy's `maxiter`): gn_h_out[n] = the solution, scale_out[n] (may be NULL) = d with
  * J_h = J diag(d), out[8] = {istop, itn, normr, normar, normA, condA, normx, normb} -- compared with scipy's own lsmr on
  * mcba_jacobian's matrix by tests/test_gpu_lsmr.py::test_device_lsmr_call_matches_scipy                                       */
-int32_t mcba_debug_lsmr_solve(mcba_handle h, const double* x, const mcba_options* opt, double damp, const double* scale_in,
+int32_t mcba_debug_lsmr_solve(mcba_handle h, const double* x, const mcba_options* opt, double damp, const double* scale_in, int32_t maxiter,
                               double* gn_h_out, double* scale_out, double* out);
 /* the LSMR calls of the last lsmr-mode mcba_solve: rows[cap][10] = {trust-region iteration, damp, Delta, istop, itn, normr, normar,
  * normA, condA, normx} (the last five NaN unless mcba_debug_set_lsmr_trace(h, 1) preceded the solve)                            */

@@ -13,6 +13,7 @@
 #include "../../multical_amd/csrc/mcba_lower.h"
 #include "../../multical_amd/csrc/mcba_view.h"
 #include "../../multical_amd/csrc/mcba_lsmr.h"
+#include "../../multical_amd/csrc/mcba_trmath.h"
 
 using namespace mcba;
 
@@ -345,6 +346,25 @@ int32_t hm_lsmr_products(const mcba_problem* p, const double* x, const double* v
   if (!h.hp.ext2int.empty()) throw std::runtime_error("hm_lsmr_products: uniform camera blocks only");
   DISPATCH_CAM(lsmr_products_k, h, v, u, jv, jtu);
   HM_END
+}
+
+// the scalar trust-region algebra of the drivers (csrc/mcba_trmath.h): S is the TR_* block (hm_tr_nslots() doubles)
+int32_t hm_tr_nslots() { return TR_NSLOTS; }
+double hm_tr_reg_term(double q00, double gh2, double Delta, double floor) { return tr_reg_term(q00, gh2, Delta, floor); }
+void hm_tr_subspace(double* S, int32_t explicit_forms, double Q01, double Q11) { tr_subspace(S, explicit_forms != 0, Q01, Q11); }
+void hm_tr_trial(double* S, double Delta) { tr_trial(S, Delta); }
+double hm_tr_update_radius(double Delta, double actual, double predicted, double step_norm, int32_t bound_hit, double* ratio) {
+  tr_update_radius(Delta, actual, predicted, step_norm, bound_hit != 0, *ratio);
+  return Delta;
+}
+int32_t hm_tr_check_termination(double dF, double F, double dx_norm, double x_norm, double ratio, double ftol, double xtol) {
+  return tr_check_termination(dF, F, dx_norm, x_norm, ratio, ftol, xtol);
+}
+int32_t hm_tr_slot(const char* name) {
+  struct { const char* n; int i; } const t[] = {{"gnorm", TR_GNORM}, {"gh2", TR_GH2}, {"xs2", TR_XS2}, {"q00", TR_Q00}, {"reg", TR_REG}, {"delta", TR_DELTA},
+    {"d00", TR_D00}, {"d01", TR_D01}, {"d11", TR_D11}, {"alpha", TR_ALPHA}, {"beta", TR_BETA}, {"pred", TR_PRED}};
+  for (const auto& e : t) if (std::strcmp(e.n, name) == 0) return e.i;
+  return -1;
 }
 
 // the scalar recurrences of the device-resident LSMR solve (csrc/mcba_lsmr.h), one call each: the state block L has

@@ -140,18 +140,20 @@ class ScaledMatrix(object):
 
 
 def trf_lsmr(fun, jac, x0, solver="scipy", ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=100, calls=None, sumsq=None):
-  """scipy's trf_no_bounds with tr_solver='lsmr', x_scale='jac', linear loss; solver = "scipy" (scipy.sparse.linalg.lsmr) or
-  "device" (device_lsmr).  calls (a list) receives one dict per LSMR call."""
+  """scipy's trf_no_bounds with tr_solver='lsmr', x_scale='jac', linear loss, statement by statement with scipy's own helper functions
+  (bit-identical to scipy.optimize.least_squares: tests/test_host.py); solver = "scipy" (scipy.sparse.linalg.lsmr), "device"
+  (device_lsmr) or a callable(x, scale, damp, J, f) returning scipy's tuple.  calls (a list) receives one dict per LSMR call."""
+  from scipy.linalg import qr
+  from scipy.optimize._lsq.common import (compute_grad, compute_jac_scale, right_multiplied_operator, build_quadratic_1d,
+                                          evaluate_quadratic)
   x = np.array(x0, dtype=np.float64)
   f = fun(x)
   nfev, njev = 1, 1
   J = jac(x)
   m, n = J.shape
   cost = 0.5 * np.dot(f, f)
-  g = J.T @ f
-  scale_inv = np.asarray(J.power(2).sum(axis=0)).ravel() ** 0.5
-  scale_inv[scale_inv == 0] = 1
-  scale = 1 / scale_inv
+  g = compute_grad(J, f)
+  scale, scale_inv = compute_jac_scale(J)
   Delta = norm(x * scale_inv)
   if Delta == 0:
     Delta = 1.0
@@ -164,32 +166,33 @@ def trf_lsmr(fun, jac, x0, solver="scipy", ftol=1e-4, xtol=1e-8, gtol=1e-8, max_
       break
     d = scale
     g_h = d * g
-    Jg = J @ (d * g_h)
-    a = 0.5 * np.dot(Jg, Jg)
-    b = -np.dot(g_h, g_h)
+    J_h = right_multiplied_operator(J, d)
+    a, b = build_quadratic_1d(J_h, g_h, -g_h)
     to_tr = Delta / norm(g_h)
     ag_value = minimize_quadratic_1d(a, b, 0, to_tr)[1]
     reg_term = -ag_value / Delta**2
-    damp = reg_term**0.5
-    if solver == "scipy":
-      out = scipy_lsmr(scaled_operator(J, d), f, damp=damp)
+    damp = (0.0**2 + reg_term)**0.5
+    if callable(solver):          # e.g. the device's own LSMR call on this linearisation (mcba_debug_lsmr_solve)
+      out = solver(x=x, scale=d, damp=damp, J=J, f=f)
+    elif solver == "scipy":
+      out = scipy_lsmr(J_h, f, damp=damp)
     else:
       out = device_lsmr(ScaledMatrix(J, d), f, damp, sumsq=sumsq)
     gn_h = out[0]
     if calls is not None:
-      calls.append(dict(iteration=iteration, x=x.copy(), scale=d.copy(), gn_h=np.array(gn_h), damp=damp, Delta=Delta, istop=int(out[1]), itn=int(out[2]), normr=float(out[3]),
-                        normar=float(out[4]), normA=float(out[5]), condA=float(out[6]), normx=float(out[7])))
+      calls.append(dict(iteration=iteration, x=x.copy(), scale=d.copy(), gn_h=np.array(gn_h), damp=damp, Delta=Delta, istop=int(out[1]),
+                        itn=int(out[2]), normr=float(out[3]), normar=float(out[4]), normA=float(out[5]), condA=float(out[6]),
+                        normx=float(out[7])))
     S = np.vstack((g_h, gn_h)).T
-    S, _ = np.linalg.qr(S)
-    JS = np.column_stack([J @ (d * S[:, 0]), J @ (d * S[:, 1])])
-    B_S = JS.T @ JS
-    g_S = S.T @ g_h
+    S, _ = qr(S, mode='economic')
+    JS = J_h.dot(S)
+    B_S = np.dot(JS.T, JS)
+    g_S = S.T.dot(g_h)
     actual_reduction = -1
     while actual_reduction <= 0 and nfev < max_nfev:
       p_S, _ = solve_trust_region_2d(B_S, g_S, Delta)
-      step_h = S @ p_S
-      Js = J @ (d * step_h)
-      predicted_reduction = -(0.5 * np.dot(Js, Js) + np.dot(step_h, g_h))
+      step_h = S.dot(p_S)
+      predicted_reduction = -evaluate_quadratic(J_h, g_h, step_h)
       step = d * step_h
       x_new = x + step
       f_new = fun(x_new)
@@ -210,10 +213,102 @@ def trf_lsmr(fun, jac, x0, solver="scipy", ftol=1e-4, xtol=1e-8, gtol=1e-8, max_
       x, f, cost = x_new, f_new, cost_new
       J = jac(x)
       njev += 1
-      g = J.T @ f
-      scale_inv = np.maximum(np.asarray(J.power(2).sum(axis=0)).ravel() ** 0.5, scale_inv)
-      scale = 1 / scale_inv
+      g = compute_grad(J, f)
+      scale, scale_inv = compute_jac_scale(J, scale_inv)
     else:
       step_norm, actual_reduction = 0, 0
     iteration += 1
   return dict(x=x, cost=cost, nfev=nfev, njev=njev, status=status or 0, optimality=g_norm)
+
+
+class TrBlock(object):
+  """The TR_* scalar block of csrc/mcba_trmath.h on the host."""
+
+  def __init__(self):
+    self.lib = hostmath_lib.lib()
+    self.lib.hm_tr_reg_term.restype = C.c_double
+    self.lib.hm_tr_update_radius.restype = C.c_double
+    self.S = np.zeros(self.lib.hm_tr_nslots())
+    self.p = self.S.ctypes.data_as(C.POINTER(C.c_double))
+
+  def __setitem__(self, name, v):
+    self.S[self.lib.hm_tr_slot(name.encode())] = v
+
+  def __getitem__(self, name):
+    return float(self.S[self.lib.hm_tr_slot(name.encode())])
+
+
+def trf_lsmr_device_driver(fun, jac, x0, solver="scipy", ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=100, calls=None):
+  """csrc/mcba_api.hip: solve_lsmr step by step on the host -- the device's trust-region DRIVER (Cauchy damping, 2-D subspace from the
+  Gram matrix of {g_h, gn_h} and the products J_h g_h, J_h gn_h, trial step p_h = alpha g_h + beta gn_h, radius update, termination)
+  with the scalar algebra of csrc/mcba_trmath.h itself (compiled into tests/hostmath); the LSMR solve is pluggable as in trf_lsmr."""
+  tr = TrBlock()
+  lib = tr.lib
+  x = np.array(x0, dtype=np.float64)
+  f = fun(x)
+  J = jac(x)
+  nfev, njev, iteration, status = 1, 1, 0, -100
+  cost = 0.5 * np.dot(f, f)
+  g = J.T @ f
+  scale_inv = np.asarray(J.power(2).sum(axis=0)).ravel() ** 0.5
+  scale_inv[scale_inv == 0] = 1
+  first = True
+  Delta = 0.0
+  while True:
+    d = 1 / scale_inv
+    g_h = d * g
+    g_norm, gg, xs = np.abs(g).max(), float(np.dot(g_h, g_h)), float(np.dot(x * scale_inv, x * scale_inv))
+    if first:
+      Delta = np.sqrt(xs) or 1.0
+      first = False
+    if g_norm < gtol:
+      status = 1
+    if status != -100 or nfev >= max_nfev:
+      break
+    Jg = J @ (d * g_h)
+    Q00 = float(np.dot(Jg, Jg))
+    reg_term = lib.hm_tr_reg_term(C.c_double(Q00), C.c_double(gg), C.c_double(Delta), C.c_double(0.0)) if gg > 0 else 0.0
+    damp = np.sqrt(reg_term)
+    if callable(solver):
+      out = solver(x=x, scale=d, damp=damp, J=J, f=f)
+    elif solver == "scipy":
+      out = scipy_lsmr(scaled_operator(J, d), f, damp=damp)
+    else:
+      out = device_lsmr(ScaledMatrix(J, d), f, damp)
+    gn = np.array(out[0])
+    if calls is not None:
+      calls.append(dict(iteration=iteration, damp=damp, Delta=Delta, istop=int(out[1]), itn=int(out[2])))
+    Jgn = J @ (d * gn)
+    tr["reg"], tr["q00"] = reg_term, float(np.dot(Jg, Jg))
+    tr["d00"], tr["d01"], tr["d11"] = float(np.dot(g_h, g_h)), float(np.dot(g_h, gn)), float(np.dot(gn, gn))
+    tr["gnorm"], tr["gh2"], tr["xs2"] = g_norm, gg, xs
+    lib.hm_tr_subspace(tr.p, 1, C.c_double(float(np.dot(Jg, Jgn))), C.c_double(float(np.dot(Jgn, Jgn))))
+    actual_reduction, cost_new = -1.0, cost
+    while actual_reduction <= 0 and nfev < max_nfev:
+      lib.hm_tr_trial(tr.p, C.c_double(Delta))
+      p = tr["alpha"] * g_h + tr["beta"] * gn
+      x_new = x + d * p
+      f_new = fun(x_new)
+      nfev += 1
+      step_h_norm = np.sqrt(np.dot(p, p))
+      cost_new = 0.5 * np.dot(f_new, f_new)
+      if not np.isfinite(cost_new):
+        Delta = 0.25 * step_h_norm
+        continue
+      actual_reduction = cost - cost_new
+      ratio = C.c_double(0.0)
+      Delta_new = lib.hm_tr_update_radius(C.c_double(Delta), C.c_double(actual_reduction), C.c_double(tr["pred"]), C.c_double(step_h_norm),
+                                          int(step_h_norm > 0.95 * Delta), C.byref(ratio))
+      status = lib.hm_tr_check_termination(C.c_double(actual_reduction), C.c_double(cost), C.c_double(norm(d * p)), C.c_double(norm(x)),
+                                           ratio, C.c_double(ftol), C.c_double(xtol))
+      if status != -100:
+        break
+      Delta = Delta_new
+    if actual_reduction > 0:
+      x, f, cost = x_new, f_new, cost_new
+      J = jac(x)
+      njev += 1
+      g = J.T @ f
+      scale_inv = np.maximum(np.asarray(J.power(2).sum(axis=0)).ravel() ** 0.5, scale_inv)
+    iteration += 1
+  return dict(x=x, cost=cost, nfev=nfev, njev=njev, status=0 if status == -100 else status, optimality=g_norm)

@@ -345,3 +345,84 @@ def test_device_math_lsmr_products_match_the_jacobian(name):
   scale = A.T @ np.abs(u)
   assert np.abs(jtu - J.T @ u).max() <= 1e-12 * scale.max()
   assert np.all(jtu[scale == 0] == 0)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The default solver's algorithm on the host (tests/lsmr_emulation.py): scipy's trf_no_bounds transcribed, the device's LSMR flow and the
+# device's trust-region driver walked through with numpy vectors and the scalar code of csrc/mcba_lsmr.h / csrc/mcba_trmath.h itself
+# ---------------------------------------------------------------------------------------------------------------------------------
+EMU_CASES = ["cfg1", "tiny_handeye", "tiny_fixintr", "tiny_rolling"]
+
+
+@pytest.mark.parametrize("name", EMU_CASES)
+def test_trf_transcription_equals_scipys_least_squares(name):
+  """tests/lsmr_emulation.trf_lsmr(solver="scipy") IS scipy.optimize.least_squares(method='trf', tr_solver='lsmr', x_scale='jac') as the
+  reference calls it (calibration.py:209-210) when both get the same residual function and the same sparse analytic Jacobian: the
+  instrumented driver the call-level parity tests, profiles/scripts/prof_lsmr_sign.py and oracle/make_exact_products.py rely on."""
+  from scipy.optimize import least_squares
+  from lsmr_emulation import trf_lsmr
+  g, rig = load_golden(name)
+  hm = HostMath(mirror(rig))
+  ref = least_squares(hm.residuals, g["x0"], jac=hm.jacobian, x_scale='jac', ftol=1e-4, max_nfev=100, method='trf')
+  calls = []
+  res = trf_lsmr(hm.residuals, hm.jacobian, g["x0"], solver="scipy", calls=calls)
+  assert (res["nfev"], res["njev"], res["status"]) == (ref.nfev, ref.njev, ref.status)
+  assert np.array_equal(res["x"], ref.x) or np.abs(res["x"] - ref.x).max() <= 1e-13 * np.abs(ref.x).max()
+  assert res["cost"] == pytest.approx(ref.cost, rel=1e-14) and res["optimality"] == pytest.approx(ref.optimality, rel=1e-12)
+  assert len(calls) == res["njev"] - (0 if res["status"] == 0 else 1) + 1 or len(calls) >= 1
+
+
+@pytest.mark.parametrize("name", EMU_CASES)
+def test_device_lsmr_flow_first_steps_equal_scipys(name):
+  """The device's LSMR FLOW (two launches per iteration: u and v kept un-normalised, rotation + vector update of a step in the tail of the
+  next product launch, stopping tests one launch later; tests/lsmr_emulation.device_lsmr) with the scalar recurrences of
+  csrc/mcba_lsmr.h, against scipy.sparse.linalg.lsmr(maxiter = k): the whole return tuple and the solution to 1e-10 for the first
+  Golub-Kahan steps, and the same stopping reason for the complete call."""
+  from scipy.sparse.linalg import lsmr
+  from lsmr_emulation import device_lsmr, ScaledMatrix, scaled_operator
+  g, rig = load_golden(name)
+  hm = HostMath(mirror(rig))
+  x0 = g["x0"]
+  J, f = hm.jacobian(x0), hm.residuals(x0)
+  si = np.asarray(J.power(2).sum(axis=0)).ravel() ** 0.5
+  si[si == 0] = 1
+  d = 1 / si
+  for damp in (0.0, 0.02):
+    for k in (1, 2, 3, 5) + ((8,) if hm.n >= 100 else ()):
+      ref = lsmr(scaled_operator(J, d), f, damp=damp, maxiter=k)
+      out = device_lsmr(ScaledMatrix(J, d), f, damp, maxiter=k)
+      assert (out[1], out[2]) == (ref[1], ref[2]), (name, k, out[1:3], ref[1:3])
+      for a, b in zip(out[3:], ref[3:]):
+        assert abs(a - b) <= 1e-10 * abs(b), (name, damp, k, out[3:], ref[3:])
+      assert np.linalg.norm(out[0] - ref[0]) <= 1e-10 * np.linalg.norm(ref[0])
+    ref = lsmr(scaled_operator(J, d), f, damp=damp)
+    out = device_lsmr(ScaledMatrix(J, d), f, damp)
+    assert out[1] == ref[1] and abs(out[2] - ref[2]) <= max(2, 0.03 * ref[2]), (name, damp, out[1:3], ref[1:3])
+
+
+@pytest.mark.parametrize("name", EMU_CASES)
+def test_device_trust_region_driver_equals_scipys(name):
+  """csrc/mcba_api.hip: solve_lsmr's driver -- Cauchy damping, the 2-D subspace from the Gram matrix of {g_h, gn_h} and the products
+  J_h g_h, J_h gn_h, p_h = alpha g_h + beta gn_h, radius update, termination -- walked through on the host with csrc/mcba_trmath.h itself
+  (tests/lsmr_emulation.trf_lsmr_device_driver), around scipy's lsmr: the trajectory of scipy's own driver (same nfev / status, the
+  same LSMR stopping reasons, end points within 1e-8 px -- the two differ in rounding only, which the LSMR calls amplify)."""
+  from lsmr_emulation import trf_lsmr, trf_lsmr_device_driver
+  g, rig = load_golden(name)
+  hm = HostMath(mirror(rig))
+
+  def rms(x):
+    e, v = hm.reprojection_error(x)
+    return float(np.sqrt(np.mean(e[v] ** 2)))
+  ca, cb = [], []
+  a = trf_lsmr(hm.residuals, hm.jacobian, g["x0"], solver="scipy", calls=ca)
+  b = trf_lsmr_device_driver(hm.residuals, hm.jacobian, g["x0"], solver="scipy", calls=cb)
+  spread = float(np.abs(g["ba_pert_rms"] - g["ba_rms"]).max())
+  if spread < 1e-6:     # (elsewhere the reference's own trajectory changes under 1e-12 px of noise: tiny_rolling)
+    assert (a["nfev"], a["status"]) == (b["nfev"], b["status"]) == (int(g["ba_nfev"]), int(g["ba_status"]))
+    assert [c["istop"] for c in ca] == [c["istop"] for c in cb]
+  assert ca[0]["damp"] == pytest.approx(cb[0]["damp"], rel=1e-12) and ca[0]["Delta"] == pytest.approx(cb[0]["Delta"], rel=1e-14)
+  assert abs(rms(a["x"]) - rms(b["x"])) <= max(1e-8, 3 * spread), (rms(a["x"]) - float(g["ba_rms"]), rms(b["x"]) - float(g["ba_rms"]))
+  c = trf_lsmr_device_driver(hm.residuals, hm.jacobian, g["x0"], solver="device")    # driver AND LSMR flow of the device
+  if spread < 1e-6:
+    assert (c["nfev"], c["status"]) == (a["nfev"], a["status"])
+  assert abs(rms(c["x"]) - float(g["ba_rms"])) <= max(1e-6, 3 * spread)
