@@ -123,6 +123,7 @@ SYMBOLS = [
   ("mcba_debug_lsmr_trace", C.c_int32, [H, C.c_int32, c_double_p, C.POINTER(C.c_int32)]),
   ("mcba_debug_set_lsmr_trace", C.c_int32, [H, C.c_int32]),
   ("mcba_debug_set_lsmr_grid", C.c_int32, [H, C.c_int32]),
+  ("mcba_debug_set_allreduce_trace", C.c_int32, [H, C.c_int32]),
 ]
 
 _lib = None

@@ -548,6 +548,10 @@ class Handle(object):
     keys = ("iteration", "damp", "Delta", "istop", "itn", "normr", "normar", "normA", "condA", "normx")
     return [{k: (int(v) if k in ("iteration", "istop", "itn") else float(v)) for k, v in zip(keys, r)} for r in rows[:n.value]]
 
+  def set_allreduce_trace(self, cap):
+    """how many collective sizes allreduce_stats() keeps (default 4096) -- the collective-sequence tests record whole lsmr solves"""
+    check(self.lib.mcba_debug_set_allreduce_trace(self.h, int(cap)))
+
   def set_lsmr_grid(self, grid):
     """persistent workgroups of the LSMR product kernels (default 2048): only the summation order changes -- experiment hook"""
     check(self.lib.mcba_debug_set_lsmr_grid(self.h, int(grid)))

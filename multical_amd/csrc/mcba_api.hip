@@ -384,6 +384,7 @@ struct mcba_handle_s {
   // sizes of the first calls in issue order (the sequence the world-2 tests assert)
   int64_t ar_calls = 0, ar_doubles = 0;
   std::vector<int64_t> ar_trace;
+  size_t ar_trace_cap = 4096;   // sizes kept for mcba_allreduce_stats (a long-lived handle must not grow; tests raise it: mcba_debug_set_allreduce_trace)
   void* rccl_comm = nullptr;   // ncclComm_t of the native all-reduce path (mcba_rccl_init)
   mcba_log_fn log = nullptr;
   void* log_ctx = nullptr;
@@ -572,7 +573,7 @@ int call_allreduce(mcba_handle_s* h, double* buf, size_t count, int op) {
   if (!h->allreduce) return 0;
   ++h->ar_calls;
   h->ar_doubles += (int64_t)count;
-  if (h->ar_trace.size() < (1u << 18)) h->ar_trace.push_back(op == 0 ? (int64_t)count : -(int64_t)count);
+  if (h->ar_trace.size() < h->ar_trace_cap) h->ar_trace.push_back(op == 0 ? (int64_t)count : -(int64_t)count);
   const int rc = h->allreduce(h->allreduce_ctx, buf, count, op, (void*)h->stream);
   if (rc != 0) throw Error("all-reduce hook failed with code " + std::to_string(rc));
   return 0;
@@ -2199,34 +2200,33 @@ struct LsmrOps {
     const Dims& d = h->d;
     const double* vpart = h->ls_vpart.p;
     int nv = gather3_grid();
-    if (sharded()) { vpart = h->ls_out.p + 6; nv = 1; }     // (|v_raw|^2 summed over the ranks by the previous iteration)
+    if (sharded()) { vpart = h->ls_out.p + 6; nv = 1; }     // (|v_raw|^2 over all ranks, formed by k_lsmr_shard_finish2 of the previous iteration)
     (void)first_iteration;                                   // (state slot LS_PENDING = 0: the head of the first product has nothing to rotate)
     h->ops->lsmr_fused2(d, h->t, h->stream, h->view_first.p, h->dsc.p, v, u, h->ls_partial.p, h->ls_xpart.p, h->ls_part2.p, part_stride,
                         bpart(), nblk, s0, s1, vpart, nv, h->ls_hbar.p, h->ls_x.p, h->ls_h.p);
-    const double* upart = h->ls_partial.p;
-    const double* xpart = h->ls_xpart.p;
     // (the vector update is spread 64 entries per workgroup: only the first ceil(n / 64) workgroups hold a part of |x|^2)
-    int nu = nblk, nx = std::max(1, std::min(nblk, (d.n + 63) / 64));
-    if (sharded()) {
-      double* two = h->ls_out.p + 4;
-      hipLaunchKernelGGL(k_lsmr_shard_fold_a2, dim3(1), dim3(LSG_THREADS), 0, h->stream, upart, nu, xpart, nx, two);
-      call_allreduce(h, two, 2, 0);
-      upart = two; nu = 1; xpart = two + 1; nx = 1;
+    const int nu = nblk, nx = std::max(1, std::min(nblk, (d.n + 63) / 64));
+    if (!sharded()) {
+      hipLaunchKernelGGL(k_lsmr_gather3, dim3(gather3_grid()), dim3(LSG3_THREADS), 0, h->stream, d, (const double*)h->ls_part2.p, part_stride,
+                         (const double*)h->dsc.p, (const double*)v, vraw, h->ls_nrm.p, h->ls_vpart.p, (const double*)s1, s0,
+                         (const double*)h->ls_partial.p, nu, (const double*)h->ls_xpart.p, nx, call, h->h_pub_seq + 1, extra());
+      return;
     }
+    // Frame-sharded: ONE collective per iteration (k_lsmr_shard_pack2 / k_lsmr_shard_finish2, mcba_solver_kernels.h).  The gather only
+    // forms raw sums (beta is not known before the message is back); message = [shared sums (ns) | |uhat|^2 | |x|^2 | a | b | c].
+    LsmrGatherExtra ex = extra();
+    ex.raw_shared = 2;
     hipLaunchKernelGGL(k_lsmr_gather3, dim3(gather3_grid()), dim3(LSG3_THREADS), 0, h->stream, d, (const double*)h->ls_part2.p, part_stride,
-                       (const double*)h->dsc.p, (const double*)v, vraw, h->ls_nrm.p, h->ls_vpart.p, (const double*)s1, s0, upart, nu, xpart, nx,
-                       call, h->h_pub_seq + 1, extra());
-    if (sharded()) {
-      const int ns = std::max(d.ns, 1);
-      if (h->ls_comm.n < (size_t)ns) h->ls_comm.alloc((size_t)ns, true);
-      hipLaunchKernelGGL(k_lsmr_shard_pack, dim3((ns + 255) / 256), dim3(256), 0, h->stream, d, (const double*)vraw, h->ls_comm.p);
-      call_allreduce(h, h->ls_comm.p, (size_t)d.ns, 0);
-      hipLaunchKernelGGL(k_lsmr_shard_finish, dim3((d.n + 255) / 256), dim3(256), 0, h->stream, d, (const double*)h->ls_comm.p,
-                         (const double*)h->dsc.p, 0.0, (const double*)v, vraw, h->ls_nrm.p, (const double*)s0, 2);
-      double* one = h->ls_out.p + 6;
-      hipLaunchKernelGGL(k_dot, dim3(1), dim3(1024), 0, h->stream, (size_t)d.n, (const double*)h->ls_nrm.p, (const double*)nullptr, one, 0);
-      call_allreduce(h, one, 1, 0);
-    }
+                       (const double*)h->dsc.p, (const double*)v, vraw, h->ls_nrm.p, h->ls_vpart.p, (const double*)s1, s0,
+                       (const double*)h->ls_partial.p, nu, (const double*)h->ls_xpart.p, nx, call, h->h_pub_seq + 1, ex);
+    const size_t msg = (size_t)d.ns + 5;
+    if (h->ls_comm.n < msg) h->ls_comm.alloc(msg, true);
+    hipLaunchKernelGGL(k_lsmr_shard_pack2, dim3(1), dim3(LSP_THREADS), 0, h->stream, d, (const double*)vraw, (const double*)v,
+                       (const double*)h->dsc.p, (const double*)s1, (const double*)h->ls_partial.p, nu, (const double*)h->ls_xpart.p, nx,
+                       h->ls_comm.p);
+    call_allreduce(h, h->ls_comm.p, msg, 0);
+    hipLaunchKernelGGL(k_lsmr_shard_finish2, dim3(1), dim3(LSP_THREADS), 0, h->stream, d, (const double*)h->ls_comm.p, (const double*)h->dsc.p,
+                       (const double*)v, vraw, (const double*)s1, s0, h->ls_out.p + 6, call, h->h_pub_seq + 1);
   }
 };
 
@@ -2317,7 +2317,16 @@ int lsmr_solve(LsmrOps& op, double damp, int* istop_out) {
   hipLaunchKernelGGL(k_lsmr_init, dim3(1), dim3(64), 0, h->stream, ls, alpha, beta, damp, normb, (double)maxiter);
   check_launch("k_lsmr_init");
   constexpr long long LOOKAHEAD = 6;
-  const bool lockstep = op.sharded();
+  // Frame-sharded: every rank must enqueue the SAME number of iterations (each carries collectives).  The default (two-launch) form
+  // enqueues in CHUNKS of LSMR_CHUNK iterations, two chunks ahead: chunk k + 1 goes out once the progress word of call k * CHUNK has
+  // arrived without a stop (calls are numbered from 1; call j publishes the tests of step j - 1).  The word is monotone and the state
+  // behind it is bit-identical on all ranks (computed from all-reduced sums by one workgroup in one order), so "was the solve stopped
+  // when call k * CHUNK published?" has ONE answer whenever a rank happens to look: with the stop at step s every rank ends up having
+  // enqueued (floor(s / CHUNK) + 2) * CHUNK calls (capped at maxiter + 1), and the collectives behind the stop stay matched -- their
+  // kernels return on the flag.  The three- and six-launch forms (A/B runs) keep the lockstep of round 5 with three collectives each.
+  constexpr long long LSMR_CHUNK = 8;
+  const bool chunked = op.sharded() && h->lsmr_fused == 2;
+  const bool lockstep = op.sharded() && !chunked;
   long long enqueued = 0, done = 0;
   int istop = 0;
   double t_wait = 0.0;
@@ -2330,14 +2339,28 @@ int lsmr_solve(LsmrOps& op, double damp, int* istop_out) {
       const long long dn = (long long)(w & 0xffffffffull);
       if (dn != done) { done = dn; t_wait = 0.0; spins = 0; }
       istop = (int)((w >> 32) & 0xff);
-      if (istop != 0) break;
+      if (istop != 0 && !chunked) break;
+    }
+    if (chunked) {
+      const bool have = (seen >> 40) == call;
+      const long long allowed = lsmr_chunk_allowed(have, istop, done, LSMR_CHUNK, maxiter + 1);
+      if (have && istop != 0 && enqueued >= allowed) break;
+      if (enqueued < allowed) {
+        op.iteration_fused2(ls, ls + LS_NSLOTS, u, v, vraw, call, enqueued == 0);
+        std::swap(v, vraw);
+        ++enqueued;
+        if ((enqueued & 15) == 0) check_launch("lsmr iteration");
+        t_wait = 0.0;
+        spins = 0;
+        continue;
+      }
     }
     // Frame-sharded: every rank must enqueue the SAME number of iterations (each carries three collectives), so an iteration is
     // only enqueued once the word of the previous one (its k_lsmr_scal_a: completed = enqueued - 1, not stopped) has arrived --
     // the state is computed from all-reduced sums and is bit-identical on all ranks, hence so is the decision.
     const bool may_enqueue = lockstep ? (enqueued == 0 || ((seen >> 40) == call && done == enqueued - 1))
                                       : (enqueued - done < LOOKAHEAD);
-    if (may_enqueue && enqueued <= maxiter) {   // (iteration maxiter + 1 carries the tests of iteration maxiter)
+    if (!chunked && may_enqueue && enqueued <= maxiter) {   // (iteration maxiter + 1 carries the tests of iteration maxiter)
       if (h->lsmr_fused == 2) op.iteration_fused2(ls, ls + LS_NSLOTS, u, v, vraw, call, enqueued == 0);
       else if (h->lsmr_fused == 1) op.iteration_fused(ls, ls + LS_NSLOTS, u, v, vraw, call);
       else op.iteration(ls, u, v, vraw, call);
@@ -2706,6 +2729,14 @@ int32_t mcba_debug_set_lsmr_trace(mcba_handle h, int32_t scalars) {
   API_BEGIN
   REQUIRE(h, "null handle");
   h->lsmr_trace_scalars = scalars != 0;
+  API_END
+}
+
+/* number of collective sizes mcba_allreduce_stats keeps (default 4096): the collective-sequence tests record whole lsmr solves */
+int32_t mcba_debug_set_allreduce_trace(mcba_handle h, int32_t cap) {
+  API_BEGIN
+  REQUIRE(h && cap >= 0 && cap <= (1 << 22), "bad cap");
+  h->ar_trace_cap = (size_t)cap;
   API_END
 }
 

@@ -29,6 +29,18 @@ LSMR_HD unsigned long long lsmr_progress_word(unsigned long long call, int istop
   return ((call & 0xffffffull) << 40) | ((unsigned long long)(istop & 0xff) << 32) | (unsigned long long)(itn & 0xffffffffll);
 }
 
+// Frame-sharded solves enqueue LSMR iterations in CHUNKS, two chunks ahead of the progress word (mcba_api.hip: lsmr_solve): calls are
+// numbered from 1, call j publishes the stopping tests of step j - 1, and chunk k + 1 (calls (k + 1) chunk + 1 .. (k + 2) chunk) goes out
+// once the word of call k * chunk has arrived WITHOUT a stop.  Given the last word a rank has seen -- have_word, istop, done = the step
+// the word reports -- this returns how many calls the rank may have enqueued in total.  The word is monotone and identical on all ranks,
+// so whenever a rank looks, the answer converges to the same number: (floor(s / chunk) + 2) * chunk for a stop at step s, capped at
+// maxiter + 1 calls (tests/test_host.py::test_chunked_enqueueing_keeps_ranks_matched).
+LSMR_HD long long lsmr_chunk_allowed(bool have_word, int istop, long long done, long long chunk, long long cap) {
+  long long allowed = 2 * chunk;                                              // chunks 0 and 1 need no word
+  if (have_word) allowed = ((istop != 0 ? done : done + 1) / chunk + 2) * chunk;   // (done + 1 = the call whose word this is)
+  return allowed < cap ? allowed : cap;
+}
+
 // lsmr.py:_sym_ortho
 LSMR_HD void lsmr_sym_ortho(double a, double b, double& c, double& s, double& r) {
 #pragma clang fp contract(off)

@@ -2548,7 +2548,13 @@ __global__ __launch_bounds__(LSG3_THREADS) void k_lsmr_gather3(Dims d, const dou
   int kind = 0, gi = -1;   // kind 1: general entry gi (lane 0 finishes it); kind 2: frame task (lanes with l16 == 0, entries g, g + 4, g + 8)
   const int DFm = d.motion == MOTION_ROLLING ? 12 : 6, g16 = lane >> 4, l16 = lane & 15;
   int fl = -1;
+  // frame-sharded, ONE collective per iteration (ex.raw_shared == 2): this kernel only forms the raw sums of EVERY entry -- beta needs
+  // |uhat|^2 over all ranks, which travels in the same message as the shared sums (k_lsmr_shard_pack2 / k_lsmr_shard_finish2)
+  const bool raw_all = ex.raw_shared == 2;
   if (wave == 4) {
+    if (raw_all) {
+      if (lane == 0) { head[0] = 0.0; head[1] = 1.0; head[2] = 0.0; head[3] = 0.0; head[4] = 1.0; }
+    } else {
     // every workgroup: beta = |uhat| and 1 / beta (lsmr_state_beta), nothing else -- the tasks do not wait for the stopping tests
     // (what a stopped iteration writes is never read: the next k_lsmr_fused2 returns on the flag)
     const double inv_alpha_cur = lsIn[LS_INV_ALPHA];
@@ -2572,6 +2578,7 @@ __global__ __launch_bounds__(LSG3_THREADS) void k_lsmr_gather3(Dims d, const dou
         for (int k = 0; k < LS_NSLOTS; ++k) lsOut[k] = L[k];
         __hip_atomic_store(host_word, lsmr_progress_word(call, istop, (long long)L[LS_ITN]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
+    }
     }
   } else if (task >= ngen) {
     fl = task - ngen;
@@ -2663,6 +2670,18 @@ __global__ __launch_bounds__(LSG3_THREADS) void k_lsmr_gather3(Dims d, const dou
   const double beta = head[0], inv_beta = head[1], inv_alpha = head[4];
   const bool skip = head[2] != 0.0;
   double vsq = 0.0;
+  if (raw_all) {
+    if (kind == 2) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int e = g16 + 4 * q;
+        if (e < DFm && l16 == 0) vout[d.off_motion + (e / 6) * 6 * d.F + 6 * (d.f0 + fl) + e % 6] = fsum[q];
+      }
+    } else if (kind == 1 && lane == 0) {
+      vout[gi] = sum;
+    }
+    return;     // (no barrier behind this point)
+  }
   if (kind == 2) {
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
@@ -2741,6 +2760,95 @@ __global__ __launch_bounds__(LSG_THREADS) void k_lsmr_shard_fold_a2(const double
   __shared__ double scratch[16];
   const double a = lsmr_fold256(upart, nu, scratch), b = lsmr_fold256(xpart, nx, scratch);
   if (threadIdx.x == 0) { out[0] = a; out[1] = b; }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Frame-sharded two-launch iteration with ONE collective per LSMR iteration (round 6).  Everything an iteration needs from the other
+// ranks is known BEFORE beta is: the raw shared sums s = sum_views J^T uhat (ns doubles), |uhat|^2 and |x|^2 (per-rank partials) and
+// three sums over the rank's OWN frame entries that give the frame part of |v_raw|^2 for any beta:
+//     v_raw_i = D_i s_i / beta - beta vn_i   =>   sum_i v_raw_i^2 = a / beta^2 - 2 b + beta^2 c,
+//     a = sum (D_i s_i)^2,  b = sum D_i s_i vn_i,  c = sum vn_i^2          (vn = v_old / alpha: the normalised v of the step)
+// message = [s (ns) | |uhat|^2 | |x|^2 | a | b | c]; after the all-reduce EVERY rank forms beta, runs the stopping tests of the previous
+// step, finishes v_raw (shared entries from the message, own frame entries from its own raw sums) and |v_raw|^2 = (shared part, summed
+// in a fixed order: bit-identical on all ranks) + (a / beta^2 - 2 b + beta^2 c) -- so the state stays bit-identical across the ranks.
+// Both kernels are ONE workgroup: n is a few thousand entries, and a single fold order is what makes the scalars rank-independent.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int LSP_THREADS = 1024;
+__global__ __launch_bounds__(LSP_THREADS) void k_lsmr_shard_pack2(Dims d, const double* __restrict__ vraw, const double* __restrict__ vold,
+                                                                   const double* __restrict__ dscale, const double* __restrict__ ls,
+                                                                   const double* __restrict__ upart, int nu,
+                                                                   const double* __restrict__ xpart, int nx, double* __restrict__ comm) {
+  __shared__ double scratch[16];
+  const int ns = d.ns;
+  if (ls[LS_ISTOP] != 0.0) {   // stopped: the message of an iteration enqueued behind the stop is never read (zeros keep it finite)
+    for (int s = threadIdx.x; s < ns + 5; s += blockDim.x) comm[s] = 0.0;
+    return;
+  }
+  const double inv_alpha = ls[LS_INV_ALPHA];
+  for (int s = threadIdx.x; s < ns; s += blockDim.x) comm[s] = vraw[d.shared_to_x(s)];
+  double u2 = 0.0, x2 = 0.0, a = 0.0, b = 0.0, c = 0.0;
+  for (int i = threadIdx.x; i < nu; i += blockDim.x) u2 += upart[i];
+  for (int i = threadIdx.x; i < nx; i += blockDim.x) x2 += xpart[i];
+  if (d.DF > 0 && d.off_motion >= 0) {
+    const int nfe = d.Fl * d.DF;     // own frame entries: local frame fl, eliminated parameter q
+    for (int k = threadIdx.x; k < nfe; k += blockDim.x) {
+      const int i = d.frame_to_x(d.f0 + k / d.DF, k % d.DF);
+      const double t = dscale[i] * vraw[i], vn = vold[i] * inv_alpha;
+      a += t * t;
+      b += t * vn;
+      c += vn * vn;
+    }
+  }
+  const double U = block_reduce<false>(u2, scratch), X = block_reduce<false>(x2, scratch);
+  const double A = block_reduce<false>(a, scratch), B = block_reduce<false>(b, scratch), Cc = block_reduce<false>(c, scratch);
+  if (threadIdx.x == 0) { comm[ns] = U; comm[ns + 1] = X; comm[ns + 2] = A; comm[ns + 3] = B; comm[ns + 4] = Cc; }
+}
+
+// state: in = lsIn (written by k_lsmr_fused2), out = lsOut; vsq[0] = |v_raw|^2 for the head of the next k_lsmr_fused2
+__global__ __launch_bounds__(LSP_THREADS) void k_lsmr_shard_finish2(Dims d, const double* __restrict__ comm, const double* __restrict__ dscale,
+                                                                     const double* __restrict__ vold, double* __restrict__ vout,
+                                                                     const double* __restrict__ lsIn, double* __restrict__ lsOut,
+                                                                     double* __restrict__ vsq, unsigned long long call,
+                                                                     unsigned long long* host_word) {
+  __shared__ double scratch[16];
+  __shared__ double head[6];
+  if (lsIn[LS_ISTOP] != 0.0) return;   // (lsOut keeps the flag the stopping iteration left there)
+  const int ns = d.ns;
+  if (threadIdx.x == 0) {
+    double L[LS_NSLOTS];
+    for (int k = 0; k < LS_NSLOTS; ++k) L[k] = lsIn[k];
+    const double u2 = comm[ns], x2 = comm[ns + 1];
+    const int istop = L[LS_ITN] > 0.0 ? lsmr_state_test(L, x2) : 0;
+    L[LS_X2] = x2;
+    if (istop != 0) L[LS_ISTOP] = (double)istop;
+    else lsmr_state_beta(L, u2);
+    L[LS_PENDING] = 1.0;
+    for (int k = 0; k < LS_NSLOTS; ++k) lsOut[k] = L[k];
+    head[0] = L[LS_BETA]; head[1] = L[LS_INV_BETA]; head[2] = L[LS_SKIPV]; head[3] = (double)istop; head[4] = L[LS_INV_ALPHA];
+    __hip_atomic_store(host_word, lsmr_progress_word(call, istop, (long long)L[LS_ITN]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __syncthreads();
+  if (head[3] != 0.0) return;
+  const double beta = head[0], inv_beta = head[1], inv_alpha = head[4];
+  const bool skip = head[2] != 0.0;
+  double sq = 0.0;
+  for (int i = threadIdx.x; i < d.n; i += blockDim.x) {
+    const int s = d.x_to_shared(i);
+    double sum;
+    if (s >= 0) sum = comm[s];
+    else if (d.entry_weight(i) != 0.0) sum = vout[i];     // own frame entry: the raw sum k_lsmr_gather3 left there
+    else continue;                                         // a frame of another rank
+    const double vn = vold[i] * inv_alpha;
+    const double val = skip ? vn : dscale[i] * (sum * inv_beta) - beta * vn;
+    vout[i] = val;
+    if (s >= 0) sq += val * val;
+  }
+  const double shared = block_reduce<false>(sq, scratch);
+  if (threadIdx.x == 0) {
+    const double a = comm[ns + 2], b = comm[ns + 3], c = comm[ns + 4];
+    const double frames = skip ? c : (a * inv_beta) * inv_beta - 2.0 * b + (beta * beta) * c;
+    vsq[0] = shared + (frames > 0.0 ? frames : 0.0);
+  }
 }
 
 // out[0] = sum a[i] b[i] (one workgroup, fixed order); out[1] = sum a[i]^2, out[2] = sum b[i]^2 when three != 0

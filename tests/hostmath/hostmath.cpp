@@ -376,6 +376,9 @@ void hm_lsmr_state_init(double* L, double alpha, double beta, double damp, doubl
 void hm_lsmr_state_beta(double* L, double u2) { lsmr_state_beta(L, u2); }
 void hm_lsmr_state_rotate(double* L, double v2) { lsmr_state_rotate(L, v2); }
 int32_t hm_lsmr_state_test(const double* L, double x2) { return lsmr_state_test(L, x2); }
+int64_t hm_lsmr_chunk_allowed(int32_t have_word, int32_t istop, int64_t done, int64_t chunk, int64_t cap) {
+  return lsmr_chunk_allowed(have_word != 0, istop, done, chunk, cap);
+}
 int32_t hm_lsmr_slot(const char* name) {
   static const char* names[] = {"alpha", "beta", "inv_beta", "inv_alpha", "c_hbar", "c_x", "c_h", "skipv", "istop", "itn", "maxiter", "damp",
                                 "normb", "zetabar", "alphabar", "rho", "rhobar", "cbar", "sbar", "betadd", "betad", "rhodold", "tautildeold",

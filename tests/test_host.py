@@ -426,3 +426,48 @@ def test_device_trust_region_driver_equals_scipys(name):
   if spread < 1e-6:
     assert (c["nfev"], c["status"]) == (a["nfev"], a["status"])
   assert abs(rms(c["x"]) - float(g["ba_rms"])) <= max(1e-6, 3 * spread)
+
+
+def test_chunked_enqueueing_keeps_ranks_matched():
+  """csrc/mcba_lsmr.h: lsmr_chunk_allowed -- the rule by which the ranks of a frame-sharded solve enqueue LSMR iterations (each carries a
+  collective) in chunks of 8, two chunks ahead of the progress word.  Simulation: R ranks poll the (monotone, rank-independent) word at
+  random moments; call j executes once EVERY rank has enqueued it and then publishes the tests of step j - 1.  For every stop step s and
+  every polling schedule all ranks end with the same number of enqueued calls -- (s // 8 + 2) * 8, capped at maxiter + 1 -- and nobody
+  waits for a call that is never enqueued (no deadlock)."""
+  import ctypes as C
+  import hostmath_lib
+  lib = hostmath_lib.lib()
+  lib.hm_lsmr_chunk_allowed.restype = C.c_int64
+  allowed = lambda have, istop, done, cap: int(lib.hm_lsmr_chunk_allowed(int(have), int(istop), C.c_int64(done), C.c_int64(8), C.c_int64(cap)))
+  rng = np.random.default_rng(3)
+  for trial in range(300):
+    R = int(rng.integers(1, 9))
+    maxiter = int(rng.integers(1, 80))
+    s = int(rng.integers(1, maxiter + 1))              # the step whose tests stop the solve (istop 7 at the latest: s = maxiter)
+    cap = maxiter + 1
+    enq = [0] * R
+    finished = [False] * R
+    seen = [None] * R                                  # last word a rank has read: (istop, done)
+    executed = 0                                       # calls the device has executed (= min over ranks of what is enqueued, in order)
+    for step in range(100000):
+      executed_possible = min(enq)
+      # the device runs ahead as far as all ranks have enqueued, but kernels behind the stop publish nothing new
+      executed = max(executed, executed_possible)
+      word = None if executed == 0 else ((2, s) if executed >= s + 1 else (0, executed - 1))
+      r = int(rng.integers(0, R))
+      if finished[r]:
+        if all(finished):
+          break
+        continue
+      if rng.random() < 0.7:
+        seen[r] = word                                 # the rank looks at the pinned word
+      have = seen[r] is not None
+      istop, done = seen[r] if have else (0, 0)
+      a = allowed(have, istop, done, cap)
+      if have and istop != 0 and enq[r] >= a:
+        finished[r] = True
+      elif enq[r] < a:
+        enq[r] += 1
+    assert all(finished), (trial, R, maxiter, s, enq)
+    expect = min((s // 8 + 2) * 8, cap)
+    assert enq == [expect] * R, (trial, R, maxiter, s, enq, expect)
