@@ -314,7 +314,8 @@ struct mcba_handle_s {
   DevBuf<double> comm;   // frame-sharded handles: [g_s | diag_s | cost, count | step norms] of the linearisation's message
   // solver "lsmr": m-vectors u (bidiagonalisation), J_h g_h, J_h gn; per-view partials of J_h^T u; n-vectors v, v_raw, h, hbar, x
   DevBuf<double> ls_u, ls_ua, ls_ub, ls_part, ls_v, ls_vraw, ls_h, ls_hbar, ls_x, ls_nrm, ls_partial, ls_out, ls_bpart, ls_comm, ls_xpart, ls_vpart, ls_part2;
-  int lsmr_fused = 2;                     // LSMR iteration: 2 = two launches (k_lsmr_fused2 / k_lsmr_gather3), 1 = three (k_lsmr_fused), 0 = the six-launch form of round 4 (A/B, tests)
+  DevBuf<double> ls_cache;                // lsmr_fused == 3: the per-observation state A, X_start, X_end, t (+ robust scales) of the current linearisation
+  int lsmr_fused = 2;                     // LSMR iteration: 3 = two launches with the per-observation state cached (experiment), 2 = two launches (k_lsmr_fused2 / k_lsmr_gather3), 1 = three (k_lsmr_fused), 0 = the six-launch form of round 4 (A/B, tests)
   ScalLayout sl;
   DevBuf<double> chol_linv;   // inverted diagonal tiles of the panel kernels (k_cholp_back)
   int lin_grid = 0;          // 0 = automatic (see lin2), > 0 = forced number of persistent workgroups (debug)
@@ -2201,9 +2202,15 @@ struct LsmrOps {
     const double* vpart = h->ls_vpart.p;
     int nv = gather3_grid();
     if (sharded()) { vpart = h->ls_out.p + 6; nv = 1; }     // (|v_raw|^2 over all ranks, formed by k_lsmr_shard_finish2 of the previous iteration)
-    (void)first_iteration;                                   // (state slot LS_PENDING = 0: the head of the first product has nothing to rotate)
+    // lsmr_fused == 3: the first iteration of a solve stores the state of every observation, the others stream it back (boards=True
+    // needs the point index of an observation: stays on the evaluating form)
+    const int cached = (h->lsmr_fused == 3 && d.off_boards < 0) ? (first_iteration ? 1 : 2) : 0;
+    if (cached == 1) {
+      const size_t need = (((size_t)h->n_inliers + 63) / 64) * 64 * (size_t)lsmr_cache_components(d.motion, d.loss) + 64;
+      if (h->ls_cache.n < need) h->ls_cache.alloc(need, false);
+    }
     h->ops->lsmr_fused2(d, h->t, h->stream, h->view_first.p, h->dsc.p, v, u, h->ls_partial.p, h->ls_xpart.p, h->ls_part2.p, part_stride,
-                        bpart(), nblk, s0, s1, vpart, nv, h->ls_hbar.p, h->ls_x.p, h->ls_h.p);
+                        bpart(), nblk, s0, s1, vpart, nv, h->ls_hbar.p, h->ls_x.p, h->ls_h.p, h->ls_cache.p, cached);
     // (the vector update is spread 64 entries per workgroup: only the first ceil(n / 64) workgroups hold a part of |x|^2)
     const int nu = nblk, nx = std::max(1, std::min(nblk, (d.n + 63) / 64));
     if (!sharded()) {
@@ -2325,7 +2332,7 @@ int lsmr_solve(LsmrOps& op, double damp, int* istop_out) {
   // enqueued (floor(s / CHUNK) + 2) * CHUNK calls (capped at maxiter + 1), and the collectives behind the stop stay matched -- their
   // kernels return on the flag.  The three- and six-launch forms (A/B runs) keep the lockstep of round 5 with three collectives each.
   constexpr long long LSMR_CHUNK = 8;
-  const bool chunked = op.sharded() && h->lsmr_fused == 2;
+  const bool chunked = op.sharded() && h->lsmr_fused >= 2;
   const bool lockstep = op.sharded() && !chunked;
   long long enqueued = 0, done = 0;
   int istop = 0;
@@ -2361,7 +2368,7 @@ int lsmr_solve(LsmrOps& op, double damp, int* istop_out) {
     const bool may_enqueue = lockstep ? (enqueued == 0 || ((seen >> 40) == call && done == enqueued - 1))
                                       : (enqueued - done < LOOKAHEAD);
     if (!chunked && may_enqueue && enqueued <= maxiter) {   // (iteration maxiter + 1 carries the tests of iteration maxiter)
-      if (h->lsmr_fused == 2) op.iteration_fused2(ls, ls + LS_NSLOTS, u, v, vraw, call, enqueued == 0);
+      if (h->lsmr_fused >= 2) op.iteration_fused2(ls, ls + LS_NSLOTS, u, v, vraw, call, enqueued == 0);
       else if (h->lsmr_fused == 1) op.iteration_fused(ls, ls + LS_NSLOTS, u, v, vraw, call);
       else op.iteration(ls, u, v, vraw, call);
       std::swap(v, vraw);
@@ -2655,7 +2662,7 @@ int32_t mcba_debug_set_switch(const char* name, const char* value) {
 int32_t mcba_debug_set_lsmr_fused(mcba_handle h, int32_t on) {
   API_BEGIN
   REQUIRE(h, "null handle");
-  REQUIRE(on >= 0 && on <= 2, "0 = six launches, 1 = three, 2 = two");
+  REQUIRE(on >= 0 && on <= 3, "0 = six launches, 1 = three, 2 = two, 3 = two with the per-observation state cached");
   h->lsmr_fused = on;
   API_END
 }
@@ -3409,8 +3416,16 @@ int32_t mcba_debug_lsmr_fused_products(mcba_handle h, const double* x, const dou
   double* s1 = s0 + LS_NSLOTS;
   op.ensure_part2(true);
   hipLaunchKernelGGL(k_lsmr_init, dim3(1), dim3(64), 0, h->stream, s0, /*alpha*/ 0.0, /*beta*/ 1.0, 0.0, 1.0, 1e9);
+  int cached = 0;
+  if (h->lsmr_fused == 3 && d.off_boards < 0) {   // the cached form: one evaluating pass fills the cache, the pass under test streams it back
+    const size_t need = (((size_t)h->n_inliers + 63) / 64) * 64 * (size_t)lsmr_cache_components(d.motion, d.loss) + 64;
+    if (h->ls_cache.n < need) h->ls_cache.alloc(need, false);
+    h->ops->lsmr_fused2(d, h->t, h->stream, h->view_first.p, h->dsc.p, h->ls_v.p, h->ls_u.p, h->ls_partial.p, h->ls_xpart.p, h->ls_part2.p,
+                        op.part_stride, op.bpart(), op.nblk, s0, s1, h->ls_vpart.p, op.gather3_grid(), h->ls_hbar.p, h->ls_x.p, h->ls_h.p, h->ls_cache.p, 1);
+    cached = 2;
+  }
   h->ops->lsmr_fused2(d, h->t, h->stream, h->view_first.p, h->dsc.p, h->ls_v.p, h->ls_u.p, h->ls_partial.p, h->ls_xpart.p, h->ls_part2.p,
-                      op.part_stride, op.bpart(), op.nblk, s0, s1, h->ls_vpart.p, op.gather3_grid(), h->ls_hbar.p, h->ls_x.p, h->ls_h.p);
+                      op.part_stride, op.bpart(), op.nblk, s0, s1, h->ls_vpart.p, op.gather3_grid(), h->ls_hbar.p, h->ls_x.p, h->ls_h.p, h->ls_cache.p, cached);
   hipLaunchKernelGGL(k_lsmr_gather3, dim3(op.gather3_grid()), dim3(LSG3_THREADS), 0, h->stream, d, (const double*)h->ls_part2.p, op.part_stride,
                      (const double*)h->dsc.p, (const double*)h->ls_v.p, h->ls_vraw.p, h->ls_nrm.p, h->ls_vpart.p, (const double*)s1, h->ls_out.p,
                      (const double*)h->ls_partial.p, op.nblk, (const double*)h->ls_xpart.p, std::max(1, std::min(op.nblk, (d.n + 63) / 64)),
@@ -3454,10 +3469,18 @@ int32_t mcba_time_lsmr_iteration(mcba_handle h, const double* x, int32_t repeats
   double* s1 = s0 + LS_NSLOTS;
   op.ensure_part2(true);
   hipLaunchKernelGGL(k_lsmr_init, dim3(1), dim3(64), 0, h->stream, s0, 1.0, 1.0, 0.0, 1.0, 1e9);   // (no pending rotation: the product alone)
+  int cached = 0;
+  if (h->lsmr_fused == 3 && d.off_boards < 0) {   // the cached form: one evaluating pass fills the cache, the pass under test streams it back
+    const size_t need = (((size_t)h->n_inliers + 63) / 64) * 64 * (size_t)lsmr_cache_components(d.motion, d.loss) + 64;
+    if (h->ls_cache.n < need) h->ls_cache.alloc(need, false);
+    h->ops->lsmr_fused2(d, h->t, h->stream, h->view_first.p, h->dsc.p, h->ls_v.p, h->ls_u.p, h->ls_partial.p, h->ls_xpart.p, h->ls_part2.p,
+                        op.part_stride, op.bpart(), op.nblk, s0, s1, h->ls_vpart.p, op.gather3_grid(), h->ls_hbar.p, h->ls_x.p, h->ls_h.p, h->ls_cache.p, 1);
+    cached = 2;
+  }
   sync(h);
   auto product = [&]() {
     h->ops->lsmr_fused2(d, h->t, h->stream, h->view_first.p, h->dsc.p, h->ls_v.p, h->ls_u.p, h->ls_partial.p, h->ls_xpart.p, h->ls_part2.p,
-                        op.part_stride, op.bpart(), op.nblk, s0, s1, h->ls_vpart.p, op.gather3_grid(), h->ls_hbar.p, h->ls_x.p, h->ls_h.p);
+                        op.part_stride, op.bpart(), op.nblk, s0, s1, h->ls_vpart.p, op.gather3_grid(), h->ls_hbar.p, h->ls_x.p, h->ls_h.p, h->ls_cache.p, cached);
   };
   auto gather = [&]() {   // (writes its state to the spare half of s1's buffer is not possible: a scratch copy keeps s0 untouched)
     hipLaunchKernelGGL(k_lsmr_gather3, dim3(op.gather3_grid()), dim3(LSG3_THREADS), 0, h->stream, d, (const double*)h->ls_part2.p, op.part_stride,

@@ -166,16 +166,23 @@ void lsmr_fused(const Dims& d, const Tables& t, hipStream_t s, const int32_t* fi
 
 #define MCBA_F2_ARGS const Dims& d, const Tables& t, hipStream_t s, const int32_t* first, const double* dscale, const double* v, double* u, \
                      double* partial, double* xpart, double* part, int part_stride, double* bpart, int nblk, const double* lsIn, \
-                     double* lsOut, const double* vpart, int nv, double* hbar, double* x, double* h
-#define MCBA_F2_PASS d, t, s, first, dscale, v, u, partial, xpart, part, part_stride, bpart, nblk, lsIn, lsOut, vpart, nv, hbar, x, h
+                     double* lsOut, const double* vpart, int nv, double* hbar, double* x, double* h, double* cache, int cached
+#define MCBA_F2_PASS d, t, s, first, dscale, v, u, partial, xpart, part, part_stride, bpart, nblk, lsIn, lsOut, vpart, nv, hbar, x, h, cache, cached
+#define MCBA_F2_LAUNCH(ROB, CA) \
+    hipLaunchKernelGGL((k_lsmr_fused2<ND_, FISH_, MOTION, OPTK, ROB, CA>), dim3(nblk), dim3(64), 0, s, d, t, first, dscale, v, u, partial, xpart, part, \
+                       part_stride, bpart, lsIn, lsOut, vpart, nv, hbar, x, h, cache)
+// cached: 0 = evaluate the state of every observation (default), 1 = ... and store it (first iteration of a cached solve), 2 = stream it back
 template <int MOTION, bool OPTK>
 void fus22(MCBA_F2_ARGS) {
-  if (d.loss != 0)
-    hipLaunchKernelGGL((k_lsmr_fused2<ND_, FISH_, MOTION, OPTK, true>), dim3(nblk), dim3(64), 0, s, d, t, first, dscale, v, u, partial, xpart, part,
-                       part_stride, bpart, lsIn, lsOut, vpart, nv, hbar, x, h);
-  else
-    hipLaunchKernelGGL((k_lsmr_fused2<ND_, FISH_, MOTION, OPTK, false>), dim3(nblk), dim3(64), 0, s, d, t, first, dscale, v, u, partial, xpart, part,
-                       part_stride, bpart, lsIn, lsOut, vpart, nv, hbar, x, h);
+  if (d.loss != 0) {
+    if (cached == 2) MCBA_F2_LAUNCH(true, 2);
+    else if (cached == 1) MCBA_F2_LAUNCH(true, 1);
+    else MCBA_F2_LAUNCH(true, 0);
+  } else {
+    if (cached == 2) MCBA_F2_LAUNCH(false, 2);
+    else if (cached == 1) MCBA_F2_LAUNCH(false, 1);
+    else MCBA_F2_LAUNCH(false, 0);
+  }
 }
 template <int MOTION>
 void fus21(MCBA_F2_ARGS) {
@@ -187,6 +194,7 @@ void lsmr_fused2(MCBA_F2_ARGS) {
   else if (d.motion == MOTION_ROLLING) fus21<MOTION_ROLLING>(MCBA_F2_PASS);
   else fus21<MOTION_HAND_EYE>(MCBA_F2_PASS);
 }
+#undef MCBA_F2_LAUNCH
 #undef MCBA_F2_ARGS
 #undef MCBA_F2_PASS
 

@@ -824,17 +824,34 @@ __global__ __launch_bounds__(64) void k_lsmr_fused(Dims d, Tables t, const int32
 // of the vectors, xpart[slice] = its part of |x|^2, and the last workgroup publishes the state (in: lsIn, written by the gather;
 // out: lsOut -- double buffer, see k_lsmr_gather3).  v is never stored normalised: v = v_raw / alpha is formed where it is read.
 // ---------------------------------------------------------------------------------------------------------------
-template <int ND, int FISH, int MOTION, bool OPTK, bool ROBUST>
+// The Jacobian is FIXED during an LSMR solve: what an observation contributes to both products is determined by its PointState --
+// A = d(u, v) / d X_cam, the camera-frame points of the start / end chain, the scan time (+ the robust row scales) -- 13 doubles
+// (rolling shutter; 9 static; + 2 robust).  CACHED = 1 stores them while it evaluates an iteration as before (the first iteration of
+// a solve), CACHED = 2 streams them back instead of reading masks / observations / board points and re-deriving the state: the
+// intrinsic columns K_c are rebuilt from X_cam by the same project_point (its A / uv halves are dead code there), everything behind the
+// state is the same source.  Layout: blocks of 64 observations in residual order, component-major inside a block (one 512-byte run
+// per component and wavefront).  mcba_debug_set_lsmr_fused(h, 3); measured in profiles/r06_lsmr_experiments.txt.
+template <bool ROLL, bool ROBUST>
+struct LsmrCacheLayout {
+  static constexpr int NC = 6 + 3 + (ROLL ? 4 : 0) + (ROBUST ? 2 : 0);
+  __host__ __device__ static size_t index(size_t gi, int k) { return (gi >> 6) * (size_t)(NC * 64) + (size_t)k * 64 + (gi & 63); }
+};
+__host__ __device__ inline int lsmr_cache_components(int motion, int loss) {
+  return 6 + 3 + (motion == MOTION_ROLLING ? 4 : 0) + (loss != 0 ? 2 : 0);
+}
+
+template <int ND, int FISH, int MOTION, bool OPTK, bool ROBUST, int CACHED>
 __global__ __launch_bounds__(64) void k_lsmr_fused2(Dims d, Tables t, const int32_t* __restrict__ first,
                                                     const double* __restrict__ dscale, const double* __restrict__ vin,
                                                     double* __restrict__ u, double* __restrict__ partial, double* __restrict__ xpart,
                                                     double* __restrict__ part, int part_stride, double* __restrict__ bpart,
                                                     const double* __restrict__ lsIn, double* __restrict__ lsOut,
                                                     const double* __restrict__ vpart, int nv, double* __restrict__ hbar,
-                                                    double* __restrict__ xv, double* __restrict__ hv) {
+                                                    double* __restrict__ xv, double* __restrict__ hv, double* __restrict__ cache) {
   constexpr bool ROLL = MOTION == MOTION_ROLLING;
   constexpr int DE = ROLL ? 12 : 6, NPB = MOTION == MOTION_STATIC ? 3 : 4, NPC = 6 * NPB, KI = OPTK ? 4 + ND : 0;
   constexpr int NS = DE + KI;
+  using CL = LsmrCacheLayout<ROLL, ROBUST>;
   __shared__ uint16_t pidx[LIN_MAX_POINTS];
   __shared__ double vp[NPC], wl[NS], sl[NS];
   __shared__ double TmS[DE * NPC];   // That of the view: requested with the masks and parameters (ONE round trip), used by both products
@@ -862,6 +879,84 @@ __global__ __launch_bounds__(64) void k_lsmr_fused2(Dims d, Tables t, const int3
   }
   const int n_active = t.active_views[0];
   double acc = 0.0;
+  double sums[NS];
+  // one observation: uhat, its part of |uhat|^2 and of the per-view sums of row^T uhat, from the state ps (shared by all three forms)
+  auto observe = [&](const PointState<ND, ROLL>& ps, double2 old, int v, int b, int p, size_t pair) {
+    old.x *= inv_beta_old;
+    old.y *= inv_beta_old;
+    double bterm[2] = {0.0, 0.0};
+    if (d.off_boards >= 0) {
+      const int gq = d.off_boards + 3 * (t.board_off[b] + p);
+      double w3[3];
+      board_point_direction<ROLL>(t, v, ps.tr, dscale[gq] * (vin[gq] * inv_alpha), dscale[gq + 1] * (vin[gq + 1] * inv_alpha),
+                                  dscale[gq + 2] * (vin[gq + 2] * inv_alpha), w3);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+        bterm[a] = ps.rs[a] * (ps.A[3 * a] * w3[0] + ps.A[3 * a + 1] * w3[1] + ps.A[3 * a + 2] * w3[2]);
+    }
+    // The row pair is never formed: with E_a = [X x a_a | a_a] (base_row) the product is  E_a . w = a_a . (w_t + w_r x X)  and
+    // the adjoint  sum_a E_a^T c_a = [X x q | q],  q = sum_a c_a a_a  -- two cross products each way instead of 2 x 2 x 12
+    // multiply-adds with 24 row entries (rolling shutter: y and q are blended with the scan time).  K_a stays a plain dot.
+    constexpr int KIA = 4 + ND;
+    double y[3];
+    {
+      const double ys0 = wl[3] + (wl[1] * ps.Xs[2] - wl[2] * ps.Xs[1]);
+      const double ys1 = wl[4] + (wl[2] * ps.Xs[0] - wl[0] * ps.Xs[2]);
+      const double ys2 = wl[5] + (wl[0] * ps.Xs[1] - wl[1] * ps.Xs[0]);
+      if constexpr (ROLL) {
+        const double ye0 = wl[9] + (wl[7] * ps.Xe[2] - wl[8] * ps.Xe[1]);
+        const double ye1 = wl[10] + (wl[8] * ps.Xe[0] - wl[6] * ps.Xe[2]);
+        const double ye2 = wl[11] + (wl[6] * ps.Xe[1] - wl[7] * ps.Xe[0]);
+        const double ts = 1.0 - ps.tr;
+        y[0] = ts * ys0 + ps.tr * ye0; y[1] = ts * ys1 + ps.tr * ye1; y[2] = ts * ys2 + ps.tr * ye2;
+      } else {
+        y[0] = ys0; y[1] = ys1; y[2] = ys2;
+      }
+    }
+    double cv[2];   // c_a = rs_a uhat_a
+    double2 o;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      double dot = ps.A[3 * a] * y[0] + ps.A[3 * a + 1] * y[1] + ps.A[3 * a + 2] * y[2];
+      if constexpr (OPTK) {
+#pragma unroll
+        for (int k = 0; k < KI; ++k) dot += ps.Kc[a * KIA + k] * wl[DE + k];
+      }
+      double val = ps.rs[a] * dot;
+      val += bterm[a];
+      val -= alpha * (a == 0 ? old.x : old.y);
+      cv[a] = ps.rs[a] * val;
+      if (a == 0) o.x = val; else o.y = val;
+    }
+    {
+      const double q0 = cv[0] * ps.A[0] + cv[1] * ps.A[3], q1 = cv[0] * ps.A[1] + cv[1] * ps.A[4], q2 = cv[0] * ps.A[2] + cv[1] * ps.A[5];
+      const double ws = ROLL ? 1.0 - ps.tr : 1.0;
+      sums[0] += ws * (ps.Xs[1] * q2 - ps.Xs[2] * q1);
+      sums[1] += ws * (ps.Xs[2] * q0 - ps.Xs[0] * q2);
+      sums[2] += ws * (ps.Xs[0] * q1 - ps.Xs[1] * q0);
+      sums[3] += ws * q0; sums[4] += ws * q1; sums[5] += ws * q2;
+      if constexpr (ROLL) {
+        sums[6] += ps.tr * (ps.Xe[1] * q2 - ps.Xe[2] * q1);
+        sums[7] += ps.tr * (ps.Xe[2] * q0 - ps.Xe[0] * q2);
+        sums[8] += ps.tr * (ps.Xe[0] * q1 - ps.Xe[1] * q0);
+        sums[9] += ps.tr * q0; sums[10] += ps.tr * q1; sums[11] += ps.tr * q2;
+      }
+      if constexpr (OPTK) {
+#pragma unroll
+        for (int k = 0; k < KI; ++k) sums[DE + k] += cv[0] * ps.Kc[k] + cv[1] * ps.Kc[KIA + k];
+      }
+    }
+    reinterpret_cast<double2*>(u)[pair] = o;
+    acc += o.x * o.x + o.y * o.y;
+    if (bpart != nullptr) {
+      double q3[3], w3[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) q3[k] = ps.rs[0] * o.x * ps.A[k] + ps.rs[1] * o.y * ps.A[3 + k];
+      board_point_adjoint<ROLL>(t, v, ps.tr, q3, w3);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) bpart[3 * pair + k] = w3[k];
+    }
+  };
   // (a boustrophedon order of the largest-first list -- odd rounds backwards, pairing large with small views -- was measured:
   //  40.3 against 39.0 us per iteration; what a workgroup spends is dominated by the per-view round trips, not by its observations)
   for (int vi = blockIdx.x; vi < n_active; vi += gridDim.x) {
@@ -871,8 +966,13 @@ __global__ __launch_bounds__(64) void k_lsmr_fused2(Dims d, Tables t, const int3
     constexpr int NPB64 = LIN_MAX_POINTS / 64;
     // the mask bytes of the first segment are requested in front of the parameter staging: one round trip for both
     uint8_t inb[NPB64];
+    int cached_count = 0;
+    if constexpr (CACHED == 2) {
+      cached_count = t.view_count[v];
+    } else {
 #pragma unroll
-    for (int k = 0; k < NPB64; ++k) inb[k] = masked_load_row(t.inlier + (size_t)v * d.P, k * 64 + lane, d.P);
+      for (int k = 0; k < NPB64; ++k) inb[k] = masked_load_row(t.inlier + (size_t)v * d.P, k * 64 + lane, d.P);
+    }
     double tl[NTL];
     {
       const double* tg = t.tmat + (size_t)v * (DE * NPC);
@@ -896,10 +996,47 @@ __global__ __launch_bounds__(64) void k_lsmr_fused2(Dims d, Tables t, const int3
       wl[lane] = sum;
     }
     lds_fence();
-    double sums[NS];
 #pragma unroll
     for (int k = 0; k < NS; ++k) sums[k] = 0.0;
     size_t out0 = (size_t)first[v];
+    if constexpr (CACHED == 2) {
+      // ---- the state of every observation comes back from the cache: no masks, no compaction, no observation / board-point reads
+      const double* cam = t.cam + (size_t)c * CAM_STRIDE;
+      for (int base = 0; base < cached_count; base += 64) {
+        const int i = base + lane;
+        const size_t gi = out0 + (size_t)(i < cached_count ? i : 0);
+        double cv_[CL::NC];
+#pragma unroll
+        for (int k = 0; k < CL::NC; ++k) cv_[k] = cache[CL::index(gi, k)];
+        const double2 old = reinterpret_cast<const double2*>(u)[gi];
+        if (i < cached_count) {
+          PointState<ND, ROLL> ps;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) ps.A[k] = cv_[k];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) ps.Xs[k] = cv_[6 + k];
+          double Xc[3];
+          if constexpr (ROLL) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) ps.Xe[k] = cv_[9 + k];
+            ps.tr = cv_[12];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) Xc[k] = ps.Xs[k] * (1.0 - ps.tr) + ps.Xe[k] * ps.tr;   // (slot_forward's blend)
+          } else {
+            ps.tr = 0.0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { ps.Xe[k] = 0.0; Xc[k] = ps.Xs[k]; }
+          }
+          if constexpr (ROBUST) { ps.rs[0] = cv_[CL::NC - 2]; ps.rs[1] = cv_[CL::NC - 1]; }
+          else { ps.rs[0] = 1.0; ps.rs[1] = 1.0; }
+          if constexpr (OPTK) {
+            double uv_[2], A_[6];
+            project_point<ND, FISH, true>(cam, cam + CAM_TILT, Xc, uv_, A_, ps.Kc);   // (only the K_c half survives)
+          }
+          observe(ps, old, v, b, /*p: the point index is only needed with boards=True, which the host keeps on form 2*/ 0, gi);
+        }
+      }
+    } else {
     for (int seg0 = 0; seg0 < d.P; seg0 += LIN_MAX_POINTS) {
       if (seg0 > 0) {
 #pragma unroll
@@ -933,81 +1070,20 @@ __global__ __launch_bounds__(64) void k_lsmr_fused2(Dims d, Tables t, const int3
           const int p = p_cur;
           PointState<ND, ROLL> ps;
           point_state<ND, FISH, ROLL, ROBUST>(d, t, v, c, b, p, ob_cur, ps, X_cur);
-          double2 old = old_cur;
-          old.x *= inv_beta_old;
-          old.y *= inv_beta_old;
-          double bterm[2] = {0.0, 0.0};
-          if (d.off_boards >= 0) {
-            const int gq = d.off_boards + 3 * (t.board_off[b] + p);
-            double w3[3];
-            board_point_direction<ROLL>(t, v, ps.tr, dscale[gq] * (vin[gq] * inv_alpha), dscale[gq + 1] * (vin[gq + 1] * inv_alpha),
-                                        dscale[gq + 2] * (vin[gq + 2] * inv_alpha), w3);
+          if constexpr (CACHED == 1) {   // the state of the observation for the cached iterations that follow
+            const size_t gi = out0 + (size_t)i;
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
-              bterm[a] = ps.rs[a] * (ps.A[3 * a] * w3[0] + ps.A[3 * a + 1] * w3[1] + ps.A[3 * a + 2] * w3[2]);
-          }
-          // The row pair is never formed: with E_a = [X x a_a | a_a] (base_row) the product is  E_a . w = a_a . (w_t + w_r x X)  and
-          // the adjoint  sum_a E_a^T c_a = [X x q | q],  q = sum_a c_a a_a  -- two cross products each way instead of 2 x 2 x 12
-          // multiply-adds with 24 row entries (rolling shutter: y and q are blended with the scan time).  K_a stays a plain dot.
-          constexpr int KIA = 4 + ND;
-          double y[3];
-          {
-            const double ys0 = wl[3] + (wl[1] * ps.Xs[2] - wl[2] * ps.Xs[1]);
-            const double ys1 = wl[4] + (wl[2] * ps.Xs[0] - wl[0] * ps.Xs[2]);
-            const double ys2 = wl[5] + (wl[0] * ps.Xs[1] - wl[1] * ps.Xs[0]);
+            for (int k = 0; k < 6; ++k) cache[CL::index(gi, k)] = ps.A[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) cache[CL::index(gi, 6 + k)] = ps.Xs[k];
             if constexpr (ROLL) {
-              const double ye0 = wl[9] + (wl[7] * ps.Xe[2] - wl[8] * ps.Xe[1]);
-              const double ye1 = wl[10] + (wl[8] * ps.Xe[0] - wl[6] * ps.Xe[2]);
-              const double ye2 = wl[11] + (wl[6] * ps.Xe[1] - wl[7] * ps.Xe[0]);
-              const double ts = 1.0 - ps.tr;
-              y[0] = ts * ys0 + ps.tr * ye0; y[1] = ts * ys1 + ps.tr * ye1; y[2] = ts * ys2 + ps.tr * ye2;
-            } else {
-              y[0] = ys0; y[1] = ys1; y[2] = ys2;
+#pragma unroll
+              for (int k = 0; k < 3; ++k) cache[CL::index(gi, 9 + k)] = ps.Xe[k];
+              cache[CL::index(gi, 12)] = ps.tr;
             }
+            if constexpr (ROBUST) { cache[CL::index(gi, CL::NC - 2)] = ps.rs[0]; cache[CL::index(gi, CL::NC - 1)] = ps.rs[1]; }
           }
-          double cv[2];   // c_a = rs_a uhat_a
-          double2 o;
-#pragma unroll
-          for (int a = 0; a < 2; ++a) {
-            double dot = ps.A[3 * a] * y[0] + ps.A[3 * a + 1] * y[1] + ps.A[3 * a + 2] * y[2];
-            if constexpr (OPTK) {
-#pragma unroll
-              for (int k = 0; k < KI; ++k) dot += ps.Kc[a * KIA + k] * wl[DE + k];
-            }
-            double val = ps.rs[a] * dot;
-            val += bterm[a];
-            val -= alpha * (a == 0 ? old.x : old.y);
-            cv[a] = ps.rs[a] * val;
-            if (a == 0) o.x = val; else o.y = val;
-          }
-          {
-            const double q0 = cv[0] * ps.A[0] + cv[1] * ps.A[3], q1 = cv[0] * ps.A[1] + cv[1] * ps.A[4], q2 = cv[0] * ps.A[2] + cv[1] * ps.A[5];
-            const double ws = ROLL ? 1.0 - ps.tr : 1.0;
-            sums[0] += ws * (ps.Xs[1] * q2 - ps.Xs[2] * q1);
-            sums[1] += ws * (ps.Xs[2] * q0 - ps.Xs[0] * q2);
-            sums[2] += ws * (ps.Xs[0] * q1 - ps.Xs[1] * q0);
-            sums[3] += ws * q0; sums[4] += ws * q1; sums[5] += ws * q2;
-            if constexpr (ROLL) {
-              sums[6] += ps.tr * (ps.Xe[1] * q2 - ps.Xe[2] * q1);
-              sums[7] += ps.tr * (ps.Xe[2] * q0 - ps.Xe[0] * q2);
-              sums[8] += ps.tr * (ps.Xe[0] * q1 - ps.Xe[1] * q0);
-              sums[9] += ps.tr * q0; sums[10] += ps.tr * q1; sums[11] += ps.tr * q2;
-            }
-            if constexpr (OPTK) {
-#pragma unroll
-              for (int k = 0; k < KI; ++k) sums[DE + k] += cv[0] * ps.Kc[k] + cv[1] * ps.Kc[KIA + k];
-            }
-          }
-          reinterpret_cast<double2*>(u)[out0 + i] = o;
-          acc += o.x * o.x + o.y * o.y;
-          if (bpart != nullptr) {
-            double q3[3], w3[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) q3[k] = ps.rs[0] * o.x * ps.A[k] + ps.rs[1] * o.y * ps.A[3 + k];
-            board_point_adjoint<ROLL>(t, v, ps.tr, q3, w3);
-#pragma unroll
-            for (int k = 0; k < 3; ++k) bpart[3 * (out0 + i) + k] = w3[k];
-          }
+          observe(ps, old_cur, v, b, p, out0 + (size_t)i);
         }
         p_cur = p_nxt;
         ob_cur = ob_nxt;
@@ -1017,6 +1093,7 @@ __global__ __launch_bounds__(64) void k_lsmr_fused2(Dims d, Tables t, const int3
       }
       out0 += (size_t)count;
       lds_fence();
+    }
     }
     const double tot = wave_reduce_many<NS>(sums, lane);
     if (many_writer<NS>(lane)) sl[many_index(lane)] = tot;

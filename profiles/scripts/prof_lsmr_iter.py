@@ -1,4 +1,5 @@
-"""The LSMR iteration of the parity route at the north-star rig: two-launch form (k_lsmr_fused2 / k_lsmr_gather3), three-launch form
+"""The LSMR iteration of the parity route at the north-star rig: two-launch form (k_lsmr_fused2 / k_lsmr_gather3), the same with the
+per-observation state cached (round 6 experiment: mcba_debug_set_lsmr_fused(h, 3)), three-launch form
 (k_lsmr_fused) and the six-launch form of round 4, same handle, same solve.   python profiles/scripts/prof_lsmr_iter.py [cfg3|cfg4|cfg5 ...]
 (under `rocprofv3 --kernel-trace --stats` the per-kernel times of both forms land in one trace)"""
 import sys, time, json
@@ -13,7 +14,7 @@ for cfg in (sys.argv[1:] or ["cfg3"]):
   x0 = c.param_vec
   with Handle(c) as h:
     out = {}
-    for fused in (2, 1, 0, 2):
+    for fused in (2, 3, 1, 0, 2):
       h.set_lsmr_fused(fused)
       h.solve(x0, tr_solver="lsmr")
       ts = []
@@ -22,7 +23,8 @@ for cfg in (sys.argv[1:] or ["cfg3"]):
       t = sorted(ts)[1]
       itn = h.lsmr_iterations()
       e, v = h.reprojection_error(r.x)
-      out[{2: "two_launch", 1: "three_launch", 0: "six_launch"}[fused]] = dict(seconds=t, nfev=r.nfev, status=r.status, lsmr_iterations=itn,
+      k_us = [1e3 * ms for ms in h.time_lsmr_iteration(x0, repeats=200)] if fused >= 2 else None
+      out[{3: "two_launch_cached_state", 2: "two_launch", 1: "three_launch", 0: "six_launch"}[fused]] = dict(product_gather_kernel_us=k_us, seconds=t, nfev=r.nfev, status=r.status, lsmr_iterations=itn,
                                                       us_per_lsmr_iteration=t / max(itn, 1) * 1e6, cost=r.cost,
                                                       rms_px=float(np.sqrt(np.mean(e[v] ** 2))))
     print(cfg, json.dumps(out), flush=True)

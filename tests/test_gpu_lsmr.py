@@ -58,6 +58,9 @@ def test_lsmr_two_launch_kernels_against_the_jacobian(name):
     v = rng.normal(size=h.n_params)
     jv, w = h.lsmr_fused_products(x, v)
     jv2, w2 = h.lsmr_fused_products(x, v)
+    h.set_lsmr_fused(3)          # the same step with the per-observation state streamed back from the cache (CACHED = 2)
+    jv3, w3 = h.lsmr_fused_products(x, v)
+  assert np.array_equal(jv, jv3) and np.array_equal(w, w3), (np.abs(jv - jv3).max(), np.abs(w - w3).max())
   A = abs(J)
   ref = J @ v
   assert np.abs(jv - ref).max() <= 1e-12 * (A @ np.abs(v)).max()
@@ -171,13 +174,18 @@ def test_lsmr_iteration_forms_agree(name):
   spread = float(np.abs(g["ba_pert_rms"] - g["ba_rms"]).max())
   out = {}
   with Handle(mirror(rig)) as h:
-    for mode in (0, 1, 2):
+    for mode in (0, 1, 2, 3):
       h.set_lsmr_fused(mode)
       res = h.solve(g["x0"], tr_solver="lsmr")
       e, v = h.reprojection_error(res.x)
       out[mode] = (res.nfev, res.status, float(np.sqrt(np.mean(e[v] ** 2))), h.lsmr_iterations())
+    xs = {}
+    for mode in (2, 3):
+      h.set_lsmr_fused(mode)
+      xs[mode] = h.solve(g["x0"], tr_solver="lsmr").x
+  assert np.array_equal(xs[2], xs[3]), np.abs(xs[2] - xs[3]).max()      # the cached-state form is the SAME arithmetic: same bits
   ref = float(g["ba_rms"])
-  for mode in (0, 1, 2):
+  for mode in (0, 1, 2, 3):
     assert abs(out[mode][2] - ref) <= max(1e-6, 3 * spread), (name, mode, out)
   if spread < 3e-7:
     assert out[0][:2] == out[1][:2] == out[2][:2] == (int(g["ba_nfev"]), int(g["ba_status"])), (name, out)
