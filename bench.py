@@ -66,17 +66,61 @@ def reference_endpoint(config):
   if "ba_pert_rms" in g:
     out["spread_px"] = float(np.abs(g["ba_pert_rms"] - g["ba_rms"]).max())
     out["spread_runs"] = int(g["ba_pert_rms"].size)
+  if "ba_tight_rms" in g:     # converged optimum of the reference's own residual function (oracle/make_endpoint.py tight)
+    out["tight_rms_px"] = float(g["ba_tight_rms"])
+    out["tight_cost"] = float(g["ba_tight_cost"])
+  xp_path = os.path.join(ROOT, "tests", "golden", "exact_products.json")
+  if os.path.exists(xp_path):   # scipy's own algorithm on the reference's residual function with 80-bit products (oracle/make_exact_products.py)
+    xp = json.load(open(xp_path)).get(config)
+    if xp and "longdouble_mean_rms" in xp:
+      out["exact_product_rms_px"] = float(xp["longdouble_mean_rms"])
+      out["exact_product_runs"] = len([r for r in xp["runs"] if r["arithmetic"] == "longdouble"])
   return out
 
 
-def cpu_baseline(n_frames_sample=25):
-  """Reference CPU path (oracle = numpy/scipy port of the reference, bit-identical to it in-container) on a bounded
-  sample of the same workload: the first `n_frames_sample` frames of the cfg3 rig.  One residual+Jacobian evaluation =
-  evaluate(x0) + scipy's grouped 2-point finite differences with the reference's sparsity (34 column groups)."""
+def cpu_baseline(n_frames_sample=25, full_jacobian=False):
+  """Reference CPU path (oracle = numpy/scipy port of the reference, bit-identical to it in-container) timed on THIS host.
+
+  One residual+Jacobian evaluation of the reference = evaluate(x0) + scipy's grouped 2-point finite differences with the reference's
+  sparsity: G + 1 `evaluate` calls for G column groups.  `value`: the port's `evaluate` timed at the FULL 500-frame rig (median of 5;
+  nothing extrapolated in the number of frames) times the G + 1 = 40 calls the unmodified reference itself made per Jacobian on this rig
+  (tests/golden/cfg3_endpoint.npz: 201 evaluate calls for nfev 5 / njev 5).  --cpu-baseline-full additionally runs ONE complete
+  finite-difference Jacobian at full size (sparsity build ~75 s + G evaluations + the sparse assembly: several minutes).  The 25-frame
+  sample of earlier rounds stays for the LSMR / trust-region figures, which need a Jacobian in memory."""
   from multical_amd import synthetic
   from oracle import restate
   from scipy.optimize._numdiff import approx_derivative, group_columns
   from scipy.sparse import csr_matrix
+  # ---- full rig: evaluate(), measured
+  rig_full = synthetic.make_rig("cfg3")
+  oc_full = restate.from_rig(rig_full)
+  xf = oc_full.param_vec
+  oc_full.evaluate(xf)
+  tev = []
+  for _ in range(5):
+    t0 = time.perf_counter()
+    f_full = oc_full.evaluate(xf)
+    tev.append(time.perf_counter() - t0)
+  t_eval_full = sorted(tev)[2]
+  ref = reference_endpoint("cfg3")
+  calls_per_jacobian = 40
+  if ref is not None and ref["njev"] > 0:   # (evaluate calls = nfev trial evaluations + 1 + njev * G  ->  G + 1 per residual+Jacobian evaluation)
+    calls_per_jacobian = (ref["evaluate_calls"] - ref["nfev"] - 1) // ref["njev"] + 1
+  full = dict(evaluate_seconds=t_eval_full, evaluate_seconds_all=tev, residuals=int(f_full.size), evaluate_calls_per_evaluation=calls_per_jacobian)
+  if full_jacobian:
+    t0 = time.perf_counter()
+    S = csr_matrix(oc_full.sparsity_matrix)
+    groups = group_columns(S)
+    t_sp = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    f0 = oc_full.evaluate(xf)
+    Jf = approx_derivative(oc_full.evaluate, xf, method='2-point', f0=f0, sparsity=(S, groups))
+    gf = Jf.T @ f0
+    full.update(jacobian_seconds=time.perf_counter() - t0, sparsity_seconds=t_sp, groups=int(groups.max()) + 1,
+                evals_per_s_measured=1.0 / (time.perf_counter() - t0))
+    del Jf, S
+  del oc_full, rig_full
+  # ---- 25-frame sample: Jacobian, LSMR iteration, trust-region iterations
   rig = synthetic.make_rig("cfg3", frames=n_frames_sample)
   oc = restate.from_rig(rig)
   x0 = oc.param_vec
@@ -84,18 +128,11 @@ def cpu_baseline(n_frames_sample=25):
   S = csr_matrix(oc.sparsity_matrix)
   groups = group_columns(S)
   t_sparsity = time.perf_counter() - t0
-  n_eval = 0
   t0 = time.perf_counter()
-  reps = 0
-  while True:
-    f0 = oc.evaluate(x0)
-    J = approx_derivative(oc.evaluate, x0, method='2-point', f0=f0, sparsity=(S, groups))
-    g = J.T @ f0                                    # the reduction the fused GPU pass also delivers
-    reps += 1
-    n_eval += 2 + int(groups.max())
-    if time.perf_counter() - t0 > 12.0 or reps >= 8:
-      break
-  dt = (time.perf_counter() - t0) / reps
+  f0 = oc.evaluate(x0)
+  J = approx_derivative(oc.evaluate, x0, method='2-point', f0=f0, sparsity=(S, groups))
+  g = J.T @ f0                                    # the reduction the fused GPU pass also delivers
+  dt = time.perf_counter() - t0
   evals_per_s_sample = 1.0 / dt
   # one LSMR iteration of the reference's linear solve = one J v and one J^T u (scipy lsmr: 2 sparse mat-vecs + O(m + n)
   # vector work); a TRF iteration runs up to min(m, n) of them (74 % of the reference's wall time)
@@ -105,24 +142,26 @@ def cpu_baseline(n_frames_sample=25):
     u = J @ v
     w = J.T @ u
   t_lsmr_iter = (time.perf_counter() - t1) / 20
-  # one complete TRF iteration of the reference on the sample (Jacobian + LSMR solve + trial evaluations): two iterations
-  # of the reference's own bundle_adjust, timed as a whole
   t1 = time.perf_counter()
   ba = oc.bundle_adjust(max_iterations=3, return_result=True)[1]
   t_ba = time.perf_counter() - t1
   lm_iters_per_s_sample = max(ba.nfev - 1, 1) / t_ba
-  scale = n_frames_sample / FRAMES_PER_SHARD         # cost is linear in the number of frames
-  return dict(value=evals_per_s_sample * scale, unit="evals/s", cores=1, kind="port",
-              sample=(f"first {n_frames_sample} of {FRAMES_PER_SHARD} frames of the same rig (m={f0.size} residuals, "
-                      f"n={x0.size}); {reps} residual+Jacobian evaluations = {n_eval} evaluate() calls "
-                      f"({int(groups.max()) + 1} FD column groups), {dt:.2f} s each, sparsity build {t_sparsity:.1f} s "
-                      f"not counted; extrapolated linearly in frames to the 500-frame rig; host has "
-                      f"{os.cpu_count()} logical cores, numpy/scipy path is single-threaded"),
-              evals_per_s_on_sample=evals_per_s_sample,
+  scale = n_frames_sample / FRAMES_PER_SHARD         # (only the LM figure below is still scaled from the sample)
+  value = 1.0 / (calls_per_jacobian * t_eval_full)
+  return dict(value=value, unit="evals/s", cores=1, kind="port",
+              sample=(f"FULL rig ({FRAMES_PER_SHARD} frames, m={full['residuals']} residuals): evaluate() of the oracle port measured at full size, "
+                      f"median of 5 = {t_eval_full:.2f} s, x {calls_per_jacobian} evaluate() calls per residual+Jacobian evaluation "
+                      f"(the reference's own count on this rig: G = {calls_per_jacobian - 1} finite-difference column groups + f0); the sparsity "
+                      f"build ({t_sparsity:.1f} s on the {n_frames_sample}-frame sample, ~75 s at full size) is not counted; host has "
+                      f"{os.cpu_count()} logical cores, the numpy/scipy path is single-threaded"),
+              full_rig=full,
+              evals_per_s_on_sample=evals_per_s_sample, sample_frames=n_frames_sample,
+              sample_extrapolated_evals_per_s=evals_per_s_sample * scale,
               lm_iters_per_s=lm_iters_per_s_sample * scale, lm_iters_per_s_on_sample=lm_iters_per_s_sample,
               lsmr_iteration_ms_on_sample=t_lsmr_iter * 1e3,
-              lm_note=(f"reference TRF on the same sample: {ba.nfev - 1} trial steps (max_nfev = 3) in {t_ba:.1f} s incl. "
-                       f"finite-difference Jacobians and LSMR; one LSMR iteration (J v + J^T u) = {t_lsmr_iter * 1e3:.1f} ms"))
+              lm_note=(f"reference TRF on the first {n_frames_sample} frames: {ba.nfev - 1} trial steps (max_nfev = 3) in {t_ba:.1f} s incl. "
+                       f"finite-difference Jacobians and LSMR, scaled linearly to {FRAMES_PER_SHARD} frames; one LSMR iteration "
+                       f"(J v + J^T u) = {t_lsmr_iter * 1e3:.1f} ms on the sample; the measured full-size figure is `reference_measured`"))
 
 
 def self_launch(args):
@@ -150,6 +189,8 @@ def main():
   ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; the median is reported")
   ap.add_argument("--config", choices=sorted(RIGS), default="cfg3", help="cfg3 = BASELINE configs[2] (north star), cfg4 = configs[3]")
   ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--cpu-baseline-full", action="store_true",
+                  help="cpu_baseline: also run ONE complete finite-difference Jacobian of the oracle port at the full rig (several minutes)")
   ap.add_argument("--no-solve", action="store_true")
   ap.add_argument("--solve-repeats", type=int, default=5, help="default-tolerance solves; the median is reported")
   ap.add_argument("--no-scipy-mode", action="store_true")
@@ -487,6 +528,22 @@ def main():
                           reference_source=ref_end["source"])
       if "final_rms_px" in extra:
         extra["native_abs_delta_px"] = abs(extra["final_rms_px"] - ref_end["rms_px"])
+      if "exact_product_rms_px" in ref_end:
+        # where scipy's OWN algorithm ends on the reference's residual function when its two sparse products are accumulated in 80-bit
+        # precision: the device's products (tree reductions) are accurate to a few ulp and land there; the reference's single run sits
+        # 1e-7 ... 2.5e-6 px above it (the footprint of sequential double accumulation in scipy.sparse: profiles/r06_lsmr_sign.md)
+        parity_route.update(exact_product_rms_px=ref_end["exact_product_rms_px"],
+                            exact_product_abs_delta_px=abs(prms - ref_end["exact_product_rms_px"]),
+                            exact_product_source="tests/golden/exact_products.json (oracle/make_exact_products.py)")
+      if "tight_rms_px" in ref_end:
+        # SURVEY 7 protocol C at the stated size: the converged optimum of the reference's residual function, reached by the exact-step
+        # solver at tight tolerance -- the sense in which the end point is defined beyond the reference's run-to-run spread
+        cres = h.solve(x0, tolerance=1e-14, xtol=1e-14, gtol=1e-14, max_iterations=400)
+        crms = global_rms(h, cres.x)
+        parity_route.update(converged_rms_px=crms, converged_reference_rms_px=ref_end["tight_rms_px"],
+                            converged_abs_delta_px=abs(crms - ref_end["tight_rms_px"]), converged_nfev=cres.nfev,
+                            converged_cost_rel=cres.cost / ref_end["tight_cost"] - 1.0,
+                            converged_source="tests/golden/%s_endpoint.npz: ba_tight_* (oracle/make_endpoint.py tight)" % args.config)
     # the product kernel of the route: J v and J^T u of one LSMR iteration
     parity_route["lsmr_iteration"] = dict(flops_per_observation=4 * (2 * (NV - 1)) + flops_per_obs - 2 * NV * (NV + 1),
                                           note="per observation and iteration: the analytic row pair (forward model + derivatives, "
@@ -504,15 +561,17 @@ def main():
                                       hbm=dict(achieved=by_it / (f_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                                                frac=by_it / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS),
                                       traffic=None)
-      pmc_file = os.path.join(ROOT, "profiles", "r05_lsmr_pmc.json")     # (PMC counters cannot be read inside an un-profiled run)
+      pmc_file = os.path.join(ROOT, "profiles", "r06_lsmr_pmc.json")     # (PMC counters cannot be read inside an un-profiled run)
+      if not os.path.exists(pmc_file):
+        pmc_file = os.path.join(ROOT, "profiles", "r05_lsmr_pmc.json")
       if os.path.exists(pmc_file) and args.config == "cfg3":
         try:
           pj = json.load(open(pmc_file))
           k2 = [k for k in pj if "k_lsmr_fused2" in k]
           if k2 and "FETCH_SIZE" in pj[k2[0]] and "WRITE_SIZE" in pj[k2[0]]:
             parity_route["roofline"]["traffic"] = 2 * pj[k2[0]]["FETCH_SIZE"] * 1024 + pj[k2[0]]["WRITE_SIZE"] * 1024
-            parity_route["roofline"]["traffic_source"] = ("profiles/r05_lsmr_pmc.json: separate --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                                                          "profiles/scripts/collect_r05.sh, gfx950 x2 read correction; not measured in this run")
+            parity_route["roofline"]["traffic_source"] = (os.path.relpath(pmc_file, ROOT) + ": separate --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                                          "(profiles/scripts/collect_r0*.sh), gfx950 x2 read correction; not measured in this run")
         except Exception:
           pass
     fl = parity_route["lsmr_iteration"]["flops_per_observation"] * n_obs_local
@@ -549,7 +608,7 @@ def main():
   if rank == 0:
     out = assemble()
     if world == 1 and not args.no_cpu_baseline and args.config == "cfg3":
-      out["cpu_baseline"] = cpu_baseline()
+      out["cpu_baseline"] = cpu_baseline(full_jacobian=args.cpu_baseline_full)
       if ref_end is not None:
         # the REAL reference, run to completion on this rig (build container): njev Jacobians (= residual+Jacobian evaluations by
         # SURVEY 8(d)'s counting convention) and nfev - 1 trial steps in `seconds` of one core

@@ -515,7 +515,8 @@ class Handle(object):
     return jv, w
 
   def set_lsmr_fused(self, mode):
-    """A/B switch of the LSMR iteration: 2 (default) = two launches (k_lsmr_fused2 / k_lsmr_gather3), 1 = three (k_lsmr_fused /
+    """A/B switch of the LSMR iteration: -1 (default) = automatic (3 on static / hand-eye rigs, 2 with rolling shutter or boards=True),
+    3 = two launches with the per-observation state cached, 2 = two launches (k_lsmr_fused2 / k_lsmr_gather3), 1 = three (k_lsmr_fused /
     k_lsmr_gather2 / k_lsmr_update2), 0 = the six-launch form of round 4."""
     check(self.lib.mcba_debug_set_lsmr_fused(self.h, int(mode)))
 

@@ -67,6 +67,9 @@ def set_solver(name):
   if name not in SOLVERS:
     raise ValueError(f"unknown solver {name!r}, options are {SOLVERS}")
   prev, _default_solver[0] = _default_solver[0], name
+  if prev != name:
+    import logging
+    logging.getLogger("calibration").info("multical_amd: bundle adjustment solver '%s' -> '%s'", prev, name)
   return prev
 
 

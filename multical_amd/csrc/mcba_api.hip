@@ -315,7 +315,12 @@ struct mcba_handle_s {
   // solver "lsmr": m-vectors u (bidiagonalisation), J_h g_h, J_h gn; per-view partials of J_h^T u; n-vectors v, v_raw, h, hbar, x
   DevBuf<double> ls_u, ls_ua, ls_ub, ls_part, ls_v, ls_vraw, ls_h, ls_hbar, ls_x, ls_nrm, ls_partial, ls_out, ls_bpart, ls_comm, ls_xpart, ls_vpart, ls_part2;
   DevBuf<double> ls_cache;                // lsmr_fused == 3: the per-observation state A, X_start, X_end, t (+ robust scales) of the current linearisation
-  int lsmr_fused = 2;                     // LSMR iteration: 3 = two launches with the per-observation state cached (experiment), 2 = two launches (k_lsmr_fused2 / k_lsmr_gather3), 1 = three (k_lsmr_fused), 0 = the six-launch form of round 4 (A/B, tests)
+  // LSMR iteration: -1 (default) = automatic: 3 for static / hand-eye rigs, 2 for rolling shutter (measured, profiles/r06_lsmr_iteration.txt:
+  // streaming the 9-double state back beats re-deriving it by 9 - 10 % per product launch, the 13 doubles of a rolling-shutter observation lose
+  // 15 %: 136 B per observation and iteration run into the memory system at 3.5 TB/s); 3 = two launches with the per-observation state cached,
+  // 2 = two launches (k_lsmr_fused2 / k_lsmr_gather3), 1 = three (k_lsmr_fused), 0 = the six-launch form of round 4 (A/B, tests)
+  int lsmr_fused_setting = -1;
+  int lsmr_fused = 2;                     // the form in force (resolved from lsmr_fused_setting by lsmr_setup)
   ScalLayout sl;
   DevBuf<double> chol_linv;   // inverted diagonal tiles of the panel kernels (k_cholp_back)
   int lin_grid = 0;          // 0 = automatic (see lin2), > 0 = forced number of persistent workgroups (debug)
@@ -2240,6 +2245,7 @@ struct LsmrOps {
 // every buffer the lsmr route needs on this handle (solve_lsmr, the debug and the timing entry points); idempotent
 static LsmrOps lsmr_setup(mcba_handle_s* h) {
   const Dims& d = h->d;
+  h->lsmr_fused = h->lsmr_fused_setting >= 0 ? h->lsmr_fused_setting : (d.motion == MOTION_ROLLING || d.off_boards >= 0 ? 2 : 3);
   ensure_view_first(h);
   const size_t m = 2 * (size_t)h->n_inliers;
   const int NL = 6 * d.NPB + d.KI;
@@ -2657,13 +2663,16 @@ int32_t mcba_debug_set_switch(const char* name, const char* value) {
   API_END
 }
 
-/* 2 (default): the two-launch LSMR iteration (k_lsmr_fused2 / k_lsmr_gather3); 1: three launches (k_lsmr_fused / k_lsmr_gather2 /
- * k_lsmr_update2); 0: the six-launch form of round 4 (A/B runs, test_lsmr_iteration_forms_agree) */
+/* -1 (default): automatic (3 for static / hand-eye rigs, 2 for rolling shutter and boards=True); 3: two launches, the per-observation
+ * state of the linearisation cached by the first iteration of a solve and streamed back by the others; 2: the two-launch LSMR iteration
+ * (k_lsmr_fused2 / k_lsmr_gather3); 1: three launches (k_lsmr_fused / k_lsmr_gather2 / k_lsmr_update2); 0: the six-launch form of
+ * round 4 (A/B runs, test_lsmr_iteration_forms_agree) */
 int32_t mcba_debug_set_lsmr_fused(mcba_handle h, int32_t on) {
   API_BEGIN
   REQUIRE(h, "null handle");
-  REQUIRE(on >= 0 && on <= 3, "0 = six launches, 1 = three, 2 = two, 3 = two with the per-observation state cached");
-  h->lsmr_fused = on;
+  REQUIRE(on >= -1 && on <= 3, "-1 = automatic, 0 = six launches, 1 = three, 2 = two, 3 = two with the per-observation state cached");
+  h->lsmr_fused_setting = on;
+  h->lsmr_fused = on >= 0 ? on : 2;
   API_END
 }
 

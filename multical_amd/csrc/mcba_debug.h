@@ -41,7 +41,8 @@ int32_t mcba_debug_lsmr_products(mcba_handle h, const double* x, const double* v
 /* experiment / path-forcing switches (formerly MCBA_* environment variables: the product library no longer reads those, a
  * MCBA_BUILD_VARIANT build does): process-wide, once per name, before the first mcba_create                               */
 int32_t mcba_debug_set_switch(const char* name, const char* value);
-/* LSMR iteration: 2 (default) = two launches (k_lsmr_fused2: both Jacobian products from one evaluation of the rows + the scalar
+/* LSMR iteration: -1 (default) = automatic: 3 on static / hand-eye rigs, 2 with rolling shutter or boards=True; 3 = two launches with the
+ * per-observation state (A, X_start, X_end, t) stored by the first iteration of a solve and streamed back by the others; 2 = two launches (k_lsmr_fused2: both Jacobian products from one evaluation of the rows + the scalar
  * recurrence / vector update of the previous step in its head; k_lsmr_gather3), 1 = three launches, 0 = the six-launch form    */
 int32_t mcba_debug_set_lsmr_fused(mcba_handle h, int32_t on);
 /* ... and through the kernels the default solver iterates with (k_lsmr_fused2 + k_lsmr_gather3, one Golub-Kahan step with alpha = 0):

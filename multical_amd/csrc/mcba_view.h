@@ -378,7 +378,7 @@ MCBA_HD size_t lsmr_part_index(const Dims& d, int v, int local) {
   return lsmr_part_motion(d) + ((size_t)fl * DFm + e) * ((size_t)d.C * d.B) + (size_t)c * d.B + b;
 }
 
-// is local parameter i an ELIMINATED per-frame parameter?// is local parameter i an ELIMINATED per-frame parameter?
+// is local parameter i an ELIMINATED per-frame parameter?
 MCBA_HD bool local_is_frame(const Dims& d, int i) {
   if (d.DF == 0) return false;
   return i >= 6 && i < 6 + d.DF;

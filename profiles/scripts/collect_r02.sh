@@ -14,6 +14,8 @@ MCBA_TIMING=1 python profiles/scripts/prof_workspace.py cfg3 > $O/workspace_cfg3
 python profiles/scripts/prof_lin_cfgs.py cfg2 cfg3 cfg4 cfg5 > $O/lin_cfgs.log 2>&1; cat $O/lin_cfgs.log
 python profiles/scripts/prof_scale.py > $O/lin_scale.log 2>&1; tail -8 $O/lin_scale.log
 python profiles/scripts/prof_init.py cfg2 cfg3 cfg4 > $O/init.log 2>&1; cat $O/init.log
+# (round 2 script, kept for the record: since round 5 the product library reads MCBA_* switches only through mcba_debug_set_switch;
+#  MCBA_FUSED is honoured by MCBA_BUILD_VARIANT builds alone)
 MCBA_FUSED=1 python bench.py --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_fused.json 2>/dev/null; grep -o '"ms_per_step": [0-9.]*' $O/bench_fused.json | head -1
 MCBA_TIMING=1 python profiles/scripts/prof_workspace.py cfg4 2>&1 | grep 'calibrate ms'
 MCBA_TIMING=1 python profiles/scripts/prof_workspace.py cfg2 2>&1 | grep 'calibrate ms'

@@ -29,10 +29,14 @@ with Handle(mirror(rig)) as h:
   print("scipy mode: nfev", rs.nfev, "cost %.12e" % rs.cost)
   for i, c in enumerate(calls):
     print("  scipy lsmr call %d: reg_term %.17g itn %d istop %d normr %.10e normar %.6e normA %.6e condA %.4e normx %.10e" % ((i,) + c))
-  os.environ["MCBA_SOLVE_TRACE"] = "1"
+  # (the product library takes experiment switches through mcba_debug_set_switch only -- not from the environment -- and latches them
+  #  on first use: the per-call (istop, itn, normr ...) of a solve now come back as values, Handle.lsmr_trace())
+  h.set_lsmr_trace(True)
   rows = []
   h.set_log(lambda *a: rows.append(a))
   rl = h.solve(g["x0"], tr_solver="lsmr")
   print("device lsmr: nfev", rl.nfev, "cost %.12e" % rl.cost)
+  for c in h.lsmr_trace():
+    print("  device lsmr call %(iteration)d: damp %(damp).17g itn %(itn)d istop %(istop)d normr %(normr).10e normar %(normar).6e normA %(normA).6e condA %(condA).4e normx %(normx).10e" % c)
   for r in rows:
     print("  ", r)

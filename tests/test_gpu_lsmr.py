@@ -56,11 +56,15 @@ def test_lsmr_two_launch_kernels_against_the_jacobian(name):
   with Handle(c) as h:
     J = h.jacobian(x)
     v = rng.normal(size=h.n_params)
+    h.set_lsmr_fused(2)          # the evaluating form (the default on rolling-shutter rigs and with boards=True)
     jv, w = h.lsmr_fused_products(x, v)
     jv2, w2 = h.lsmr_fused_products(x, v)
     h.set_lsmr_fused(3)          # the same step with the per-observation state streamed back from the cache (CACHED = 2)
     jv3, w3 = h.lsmr_fused_products(x, v)
-  assert np.array_equal(jv, jv3) and np.array_equal(w, w3), (np.abs(jv - jv3).max(), np.abs(w - w3).max())
+  if name == "tiny_bigboard":   # (a board of more than 512 points is walked in segments: the cached form deals its observations to other lanes)
+    assert np.abs(jv - jv3).max() <= 1e-13 * np.abs(jv).max() and np.abs(w - w3).max() <= 1e-12 * np.abs(w).max()
+  else:
+    assert np.array_equal(jv, jv3) and np.array_equal(w, w3), (np.abs(jv - jv3).max(), np.abs(w - w3).max())
   A = abs(J)
   ref = J @ v
   assert np.abs(jv - ref).max() <= 1e-12 * (A @ np.abs(v)).max()
