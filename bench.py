@@ -181,6 +181,108 @@ def self_launch(args):
   return subprocess.call(cmd, env=env)
 
 
+def dry_run(args):
+  """`--dry-run`: the N-rank PLUMBING of this file without a GPU -- rank / world from the launcher's environment, gloo rendezvous on the
+  loopback address, the frame-shard plan (with one EMPTY shard for N >= 3), the collective of an evaluation step with its real message
+  layout [g_shared | diag_shared | cost, count | step norms] (2 n_s + 6 doubles) and real numbers (the rank's shard evaluated by the
+  product's device functions compiled for the host: tests/hostmath, test infrastructure), the barrier + MAX-over-ranks timing of the
+  contract, the watchdog and the one JSON line of rank 0 (flagged "dry_run": true; its `value` times the CPU stand-in and measures
+  nothing).  So that the first multi-GPU run the driver manages is not also the first time this code path executes.
+  Rank 0 checks the reduced [g | diag | cost] against the unsharded evaluation."""
+  import torch
+  import torch.distributed as dist
+  sys.path.insert(0, os.path.join(ROOT, "tests"))
+  from hostmath_lib import HostMath
+  from multical_amd import synthetic, calibration
+  from multical_amd import distributed as mdist
+  world = int(os.environ.get("WORLD_SIZE", "1"))
+  rank = int(os.environ.get("RANK", "0"))
+  assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+  say = lambda msg: sys.stderr.write(f"[bench rank {rank}/{world}] {msg}\n")
+  if world > 1:
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo")
+  F = args.dry_frames
+  rig = synthetic.make_rig(args.config, frames=F)
+  calib = calibration.from_rig(rig)
+  weights = calib.inliers.sum(axis=(0, 2, 3)).astype(np.float64)
+  shards = mdist.frame_shards(F, world - 1, weights) + [(F, F)] if world >= 3 else mdist.frame_shards(F, world, weights)
+  shard = shards[rank]
+  hm = HostMath(calib, frame_range=shard if world > 1 else None)
+  x0 = calib.param_vec
+  n = x0.size
+  C_, B_ = rig.valid.shape[0], rig.valid.shape[2]
+  per = {"static": 6, "rolling": 12}.get(rig.cfg["motion"], 0)
+  off = 6 * C_ + 6 * B_
+  shared = np.ones(n, dtype=bool)
+  shared[off:off + per * F] = False
+  ns = int(shared.sum())
+  say(f"dry run: frames [{shard[0]}, {shard[1]}) of {F}, {hm.m // 2} observations, n = {n}, n_s = {ns}, backend gloo")
+
+  def barrier():
+    if world > 1:
+      dist.barrier()
+
+  sizes = []
+
+  def step():
+    H, g, cost = hm.normal_equations(x0)
+    msg = np.concatenate([g[shared], np.diag(H)[shared], [cost, hm.m // 2], np.zeros(4)])
+    if world > 1:
+      t = torch.from_numpy(msg)
+      dist.all_reduce(t)
+      sizes.append(int(t.numel()))
+    return g, np.diag(H).copy(), msg
+
+  watchdog = None
+  if world > 1:
+    import threading
+    deadline_s = float(os.environ.get("MCBA_BENCH_DEADLINE_S", "420"))
+
+    def expire():
+      say(f"WATCHDOG: the dry run did not finish within {deadline_s:.0f} s")
+      os._exit(7)
+    watchdog = threading.Timer(deadline_s, expire)
+    watchdog.daemon = True
+    watchdog.start()
+  for _ in range(args.warmup):
+    step()
+  barrier()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    g_loc, diag_loc, msg = step()
+  barrier()
+  dt = time.perf_counter() - t0
+  if world > 1:
+    tmax = torch.tensor([dt], dtype=torch.float64)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+  counts = [None] * world
+  if world > 1:
+    dist.all_gather_object(counts, hm.m // 2)
+  else:
+    counts = [hm.m // 2]
+  if watchdog is not None:
+    watchdog.cancel()
+  if rank == 0:
+    whole = HostMath(calib)
+    H, g, cost = whole.normal_equations(x0)
+    ref = np.concatenate([g[shared], np.diag(H)[shared], [cost, whole.m // 2]])
+    err = float(np.abs(msg[:2 * ns + 2] - ref).max() / np.abs(ref).max())
+    print(json.dumps(dict(metric="residual+Jacobian evals/sec", value=args.steps / dt, unit="evals/s", n_gpus=world, steps=args.steps,
+                          warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="strong", vs_baseline=None,
+                          dtype="f64", data="synthetic", dry_run=True,
+                          config=dict(workload=f"DRY RUN (no GPU): {RIGS[args.config]['label']} cut to {F} frames; the CPU stand-in of the step is "
+                                               "test infrastructure and its timing means nothing",
+                                      parallelism=f"frame-sharded x{world} ({[b - a for a, b in shards]} frames per rank), gloo all-reduce",
+                                      n_params=int(n), n_shared=ns, observations_per_rank=counts),
+                          step_collectives=dict(allreduce_calls_per_step=1 if world > 1 else 0, message_doubles=sorted(set(sizes))),
+                          reduced_message_rel_error=err)), flush=True)
+  if world > 1:
+    dist.destroy_process_group()
+  return 0
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
@@ -200,9 +302,15 @@ def main():
                   help="N > 1: exit non-zero when the library's own RCCL communicator cannot be used (default: fall back to the "
                        "torch.distributed hook, loudly, and say so in the JSON line)")
   ap.add_argument("--scipy-frames", type=int, default=20, help="frames of the sample the scipy-driven product mode is timed on")
+  ap.add_argument("--dry-run", action="store_true",
+                  help="no GPU: run the N-rank plumbing (launcher, gloo rendezvous, shard plan incl. an empty shard, the step's collective with "
+                       "its real message, barrier + MAX timing, watchdog, JSON line) with the shard evaluated by tests/hostmath on the CPU")
+  ap.add_argument("--dry-frames", type=int, default=14, help="--dry-run: frames of the (cut-down) rig")
   args = ap.parse_args()
   if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
     sys.exit(self_launch(args))
+  if args.dry_run:
+    sys.exit(dry_run(args))
 
   import torch
   import torch.distributed as dist

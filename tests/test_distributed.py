@@ -637,3 +637,27 @@ def test_one_message_lsmr_iteration_gloo_world_4(name, tmp_path):
   assert abs(objective(r["x"]) - objective(ref[0])) <= (1e-9 if ref[1] in (1, 2) else 1e-4) * objective(ref[0])
   if name == "cfg1":                                                                     # (well conditioned: the solutions coincide)
     assert np.linalg.norm(r["x"] - ref[0]) <= 1e-5 * np.linalg.norm(ref[0])
+
+
+def test_bench_dry_run_eight_ranks_gloo():
+  """`python bench.py --gpus 8 --config cfg4 --dry-run` on the GPU-less box: the launcher the driver uses, eight gloo ranks on the
+  loopback address, the frame-shard plan of BASELINE configs[3] (cut to 14 frames: seven ranks with one to three frames each, balanced by inlier count, and one EMPTY shard),
+  one all-reduce of 2 n_s + 6 doubles per step with the real message layout, barrier + MAX-over-ranks timing, the watchdog armed, ONE JSON
+  line from rank 0 -- and the reduced [g | diag | cost, count] equal to the unsharded evaluation.  (The 8-GPU run itself is the driver's.)"""
+  import json
+  r = _run_bench({}, "--gpus", "8", "--config", "cfg4", "--dry-run", "--steps", "2", "--warmup", "1", timeout=600)
+  assert r.returncode == 0, r.stderr[-3000:]
+  for k in range(8):
+    assert f"[bench rank {k}/8] dry run" in r.stderr
+  lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+  assert len(lines) == 1
+  out = json.loads(lines[0])
+  assert out["dry_run"] is True and out["n_gpus"] == 8 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "strong"
+  assert out["metric"] == "residual+Jacobian evals/sec" and out["dtype"] == "f64"
+  counts = out["config"]["observations_per_rank"]
+  assert len(counts) == 8 and counts[-1] == 0 and all(c > 0 for c in counts[:-1])
+  plan = json.loads(out["config"]["parallelism"].split("(")[1].split(" frames")[0])
+  assert len(plan) == 8 and sum(plan) == 14 and plan[-1] == 0 and min(plan[:-1]) >= 1     # balanced by inlier count; the last shard is empty
+  ns = out["config"]["n_shared"]
+  assert out["step_collectives"]["message_doubles"] == [2 * ns + 6]
+  assert out["reduced_message_rel_error"] <= 1e-12
