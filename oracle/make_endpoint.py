@@ -162,7 +162,10 @@ def run_aor_pert(cfg, seeds, loss='soft_l1', auto_scale=2.0):
   rig, calib, ref, out = _rig(cfg)
   error_stats = ref.optimization_calibration.error_stats
   select_threshold = ref.optimization_calibration.select_threshold
-  base = np.load(os.path.join(PART_DIR, f"{cfg}_aor.npz"))
+  base_path = os.path.join(PART_DIR, f"{cfg}_aor.npz")
+  if not os.path.exists(base_path):      # (parts of an earlier session are gone: the merged fixture holds the same arrays)
+    base_path = os.path.join(GOLDEN_DIR, f"{cfg}_endpoint.npz")
+  base = np.load(base_path)
   base_mask = np.unpackbits(base["aor_inliers_packed"])[:rig.valid.size].reshape(rig.valid.shape).astype(bool)
   for s in seeds:
     t0 = time.time()
@@ -278,6 +281,9 @@ def run_tight(cfg, max_iter=40):
 def merge(cfg):
   import glob
   out = {}
+  path = os.path.join(GOLDEN_DIR, f"{cfg}_endpoint.npz")
+  if os.path.exists(path):               # parts of earlier sessions are not kept: start from what the fixture already holds
+    out.update({k: v for k, v in np.load(path, allow_pickle=False).items()})
   for stage in ("ba", "ao", "aor", "tight"):
     p = os.path.join(PART_DIR, f"{cfg}_{stage}.npz")
     if os.path.exists(p):
@@ -285,8 +291,12 @@ def merge(cfg):
   aps = sorted(glob.glob(os.path.join(PART_DIR, f"{cfg}_aorpert*.npz")))
   if aps and "aor_rms_inliers" in out:
     ps = [np.load(p) for p in aps]
-    out["aor_pert_rms_inliers"] = np.array([float(p["rms_inliers"]) for p in ps])
-    out["aor_pert_mask_diff"] = np.array([int(p["mask_diff"]) for p in ps])
+    old = set(int(v) for v in out.get("aor_pert_seed", []))
+    new = [p for p in ps if int(p["seed"]) not in old]
+    out["aor_pert_seed"] = np.concatenate([np.asarray(out.get("aor_pert_seed", []), dtype=np.int64), [int(p["seed"]) for p in new]])
+    keep = len(out["aor_pert_seed"]) - len(new)
+    out["aor_pert_rms_inliers"] = np.concatenate([np.asarray(out.get("aor_pert_rms_inliers", []), dtype=np.float64)[:keep], [float(p["rms_inliers"]) for p in new]])
+    out["aor_pert_mask_diff"] = np.concatenate([np.asarray(out.get("aor_pert_mask_diff", []), dtype=np.int64)[:keep], [int(p["mask_diff"]) for p in new]])
   perts = sorted(glob.glob(os.path.join(PART_DIR, f"{cfg}_pert*.npz")))
   if perts:
     ps = [np.load(p) for p in perts]
@@ -295,7 +305,6 @@ def merge(cfg):
     out["ba_pert_nfev"] = np.array([int(p["nfev"]) for p in ps])
     out["ba_pert_status"] = np.array([int(p["status"]) for p in ps])
     out["ba_pert_cost"] = np.array([float(p["cost"]) for p in ps])
-  path = os.path.join(GOLDEN_DIR, f"{cfg}_endpoint.npz")
   np.savez_compressed(path, **out)
   print(f"{cfg}: {sorted(out)} -> {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
 

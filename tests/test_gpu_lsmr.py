@@ -164,8 +164,11 @@ def test_workspace_calibrate_at_full_size_against_the_reference(cfg):
     calibration.set_solver(prev)
   ref_mask = np.unpackbits(g["ao_inliers_packed"])[:rig.valid.size].reshape(rig.valid.shape).astype(bool)
   diff = int(np.sum(ao.inliers != ref_mask))
-  assert diff <= 2, diff        # (an observation whose error sits within rounding of the threshold may flip)
-  assert abs(ao.error_statistics(True).rms - float(g["ao_rms_inliers"])) <= max(1e-6, endpoint_spread(g))
+  drms = ao.error_statistics(True).rms - float(g["ao_rms_inliers"])
+  print(f"{cfg}: inlier mask after three rounds differs from the reference's in {diff} of {int(ref_mask.sum())} observations, "
+        f"inlier RMS {drms:+.2e} px from the reference's")
+  assert diff == 0, diff        # index-level work: the reference's mask bit for bit (measured: 0 at all three sizes)
+  assert abs(drms) <= max(1e-6, endpoint_spread(g))
 
 
 @pytest.mark.parametrize("name", ["cfg1", "tiny_handeye", "tiny_rolling", "tiny_fisheye", "tiny_boards", "tiny_edge", "tiny_fishmix"])
@@ -246,13 +249,15 @@ def test_workspace_calibrate_with_a_robust_loss_at_full_size(cfg):
   out = Workspace(mirror(rig)).calibrate(cameras=rig.optimize["cameras"], camera_poses=rig.optimize["camera_poses"],
                                          loss=kw["loss"], auto_scale=kw["auto_scale"])
   ref_mask = np.unpackbits(g["aor_inliers_packed"])[:rig.valid.size].reshape(rig.valid.shape).astype(bool)
-  allowed = 2 + (int(g["aor_pert_mask_diff"].max()) if "aor_pert_mask_diff" in g else 0)
-  assert int(np.sum(out.inliers != ref_mask)) <= allowed
+  allowed = int(g["aor_pert_mask_diff"].max()) if "aor_pert_mask_diff" in g else 0     # (what the reference's own perturbed re-runs flip)
+  diff = int(np.sum(out.inliers != ref_mask))
+  print(f"{cfg}: robust loop: inlier mask differs from the reference's in {diff} observations (reference's own re-runs: up to {allowed})")
+  assert diff <= allowed, (diff, allowed)
   spread = float(np.abs(g["aor_pert_rms_inliers"] - g["aor_rms_inliers"]).max()) if "aor_pert_rms_inliers" in g else 0.0
   rms_inl = out.error_statistics(True).rms
   print(f"{cfg}: reference inlier RMS {float(g['aor_rms_inliers']):.9f} (nfev {g['aor_nfev']}, {float(g['aor_seconds']):.0f} s), "
         f"here {rms_inl - float(g['aor_rms_inliers']):+.2e}, reference spread {spread:.1e}")
-  assert abs(rms_inl - float(g["aor_rms_inliers"])) <= max(1e-5, 3 * spread)
+  assert abs(rms_inl - float(g["aor_rms_inliers"])) <= max(1e-6, 3 * spread)
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
