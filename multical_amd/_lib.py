@@ -124,6 +124,7 @@ SYMBOLS = [
   ("mcba_debug_set_lsmr_trace", C.c_int32, [H, C.c_int32]),
   ("mcba_debug_set_lsmr_grid", C.c_int32, [H, C.c_int32]),
   ("mcba_debug_set_allreduce_trace", C.c_int32, [H, C.c_int32]),
+  ("mcba_debug_set_lsmr_masks_form", C.c_int32, [H, C.c_int32]),
 ]
 
 _lib = None

@@ -549,6 +549,11 @@ class Handle(object):
     keys = ("iteration", "damp", "Delta", "istop", "itn", "normr", "normar", "normA", "condA", "normx")
     return [{k: (int(v) if k in ("iteration", "istop", "itn") else float(v)) for k, v in zip(keys, r)} for r in rows[:n.value]]
 
+  def set_lsmr_masks_form(self, on=True):
+    """A/B switch: the LSMR product kernel reads masks / observations / board points from the frame-major tables (its form with
+    boards=True) instead of the compacted observation tables -- test / profiling hook"""
+    check(self.lib.mcba_debug_set_lsmr_masks_form(self.h, 1 if on else 0))
+
   def set_allreduce_trace(self, cap):
     """how many collective sizes allreduce_stats() keeps (default 4096) -- the collective-sequence tests record whole lsmr solves"""
     check(self.lib.mcba_debug_set_allreduce_trace(self.h, int(cap)))

@@ -314,12 +314,18 @@ struct mcba_handle_s {
   DevBuf<double> comm;   // frame-sharded handles: [g_s | diag_s | cost, count | step norms] of the linearisation's message
   // solver "lsmr": m-vectors u (bidiagonalisation), J_h g_h, J_h gn; per-view partials of J_h^T u; n-vectors v, v_raw, h, hbar, x
   DevBuf<double> ls_u, ls_ua, ls_ub, ls_part, ls_v, ls_vraw, ls_h, ls_hbar, ls_x, ls_nrm, ls_partial, ls_out, ls_bpart, ls_comm, ls_xpart, ls_vpart, ls_part2;
+  // compacted observation tables of the lsmr route (LsmrCompact; rebuilt when the inlier set changes: ensure_compact)
+  DevBuf<double2> cp_obs, cp_bxy;
+  DevBuf<double> cp_bz;
+  DevBuf<int4> cp_desc;
+  bool compact_dirty = true;
   DevBuf<double> ls_cache;                // lsmr_fused == 3: the per-observation state A, X_start, X_end, t (+ robust scales) of the current linearisation
   // LSMR iteration: -1 (default) = automatic: 3 for static / hand-eye rigs, 2 for rolling shutter (measured, profiles/r06_lsmr_iteration.txt:
   // streaming the 9-double state back beats re-deriving it by 9 - 10 % per product launch, the 13 doubles of a rolling-shutter observation lose
   // 15 %: 136 B per observation and iteration run into the memory system at 3.5 TB/s); 3 = two launches with the per-observation state cached,
   // 2 = two launches (k_lsmr_fused2 / k_lsmr_gather3), 1 = three (k_lsmr_fused), 0 = the six-launch form of round 4 (A/B, tests)
   int lsmr_fused_setting = -1;
+  bool lsmr_masks_form = false;           // debug (mcba_debug_set_lsmr_masks_form): k_lsmr_fused2 reads the frame-major tables on every rig (A/B, tests)
   int lsmr_fused = 2;                     // the form in force (resolved from lsmr_fused_setting by lsmr_setup)
   ScalLayout sl;
   DevBuf<double> chol_linv;   // inverted diagonal tiles of the panel kernels (k_cholp_back)
@@ -492,7 +498,7 @@ void build_inliers(mcba_handle_s* h, const uint8_t* mask_ref) {
   refresh_active_views(h);
   scan_views(h);
   h->out_r.alloc((size_t)std::max<int64_t>(2 * h->n_inliers, 1), false);
-  h->obs_index_dirty = true;
+  h->obs_index_dirty = true; h->compact_dirty = true;
 }
 
 void set_loss(mcba_handle_s* h, const mcba_options* opt) {
@@ -938,6 +944,24 @@ void ensure_obs_index(mcba_handle_s* h) {
   h->obs_index_dirty = false;
 }
 
+// compacted observation tables of the lsmr route for the current inlier table (the board points are constants here: boards=True keeps
+// the masks form).  Needs the board-point table, i.e. a preceding table preparation (lsmr_linearize).
+void ensure_compact(mcba_handle_s* h) {
+  if (!h->compact_dirty) return;
+  const Dims& d = h->d;
+  ensure_view_first(h);
+  const size_t n = (size_t)std::max<int64_t>(h->n_inliers, 1) + 64;
+  if (h->cp_obs.n < n) { h->cp_obs.alloc(n, false); h->cp_bxy.alloc(n, false); h->cp_bz.alloc(n, false); }
+  const size_t nv = (size_t)std::max(d.views(), 1);
+  if (h->cp_desc.n < nv) h->cp_desc.alloc(nv, false);
+  if (d.views() > 0)
+    hipLaunchKernelGGL(k_compact_views, dim3(d.views()), dim3(64), 0, h->stream, d, h->t, (const int32_t*)h->view_first.p, h->cp_obs.p, h->cp_bxy.p,
+                       h->cp_bz.p, h->cp_desc.p);
+  check_launch("k_compact_views");
+  h->compact_dirty = false;
+}
+LsmrCompact compact_tables(const mcba_handle_s* h) { return LsmrCompact{h->cp_obs.p, h->cp_bxy.p, h->cp_bz.p, h->cp_desc.p}; }
+
 void compute_errors(mcba_handle_s* h, const double* x) {
   const Dims& d = h->d;
   if (h->err_fm.n < (size_t)std::max(d.slots(), 1)) h->err_fm.alloc((size_t)std::max(d.slots(), 1));
@@ -1148,7 +1172,7 @@ int32_t mcba_create(const mcba_problem* p, void* hip_stream, mcba_handle* out) {
     h->n_inliers = h->h_totals[0];
     h->n_evalid = h->h_totals[1];
   }
-  h->obs_index_dirty = true;      // the residual ordering is built on first use (mcba_residuals / mcba_jacobian)
+  h->obs_index_dirty = true; h->compact_dirty = true;      // the residual ordering is built on first use (mcba_residuals / mcba_jacobian)
   const double tc2 = now_seconds();
   h->active_views.alloc((size_t)d.views() + 1);
   h->work_counter.alloc(2);
@@ -2207,15 +2231,17 @@ struct LsmrOps {
     const double* vpart = h->ls_vpart.p;
     int nv = gather3_grid();
     if (sharded()) { vpart = h->ls_out.p + 6; nv = 1; }     // (|v_raw|^2 over all ranks, formed by k_lsmr_shard_finish2 of the previous iteration)
-    // lsmr_fused == 3: the first iteration of a solve stores the state of every observation, the others stream it back (boards=True
-    // needs the point index of an observation: stays on the evaluating form)
-    const int cached = (h->lsmr_fused == 3 && d.off_boards < 0) ? (first_iteration ? 1 : 2) : 0;
-    if (cached == 1) {
+    // source of the observations (k_lsmr_fused2's MODE): the compacted tables, except with boards=True (masks form); lsmr_fused == 3:
+    // the first iteration of a solve also stores the state of every observation, the others stream it back
+    int mode = (d.off_boards < 0 && !h->lsmr_masks_form) ? 3 : 0;
+    if (h->lsmr_fused == 3 && mode == 3) mode = first_iteration ? 4 : 2;
+    if (mode == 4) {
       const size_t need = (((size_t)h->n_inliers + 63) / 64) * 64 * (size_t)lsmr_cache_components(d.motion, d.loss) + 64;
       if (h->ls_cache.n < need) h->ls_cache.alloc(need, false);
     }
+    if (mode != 0) ensure_compact(h);
     h->ops->lsmr_fused2(d, h->t, h->stream, h->view_first.p, h->dsc.p, v, u, h->ls_partial.p, h->ls_xpart.p, h->ls_part2.p, part_stride,
-                        bpart(), nblk, s0, s1, vpart, nv, h->ls_hbar.p, h->ls_x.p, h->ls_h.p, h->ls_cache.p, cached);
+                        bpart(), nblk, s0, s1, vpart, nv, h->ls_hbar.p, h->ls_x.p, h->ls_h.p, h->ls_cache.p, mode, compact_tables(h));
     // (the vector update is spread 64 entries per workgroup: only the first ceil(n / 64) workgroups hold a part of |x|^2)
     const int nu = nblk, nx = std::max(1, std::min(nblk, (d.n + 63) / 64));
     if (!sharded()) {
@@ -2745,6 +2771,15 @@ int32_t mcba_debug_set_lsmr_trace(mcba_handle h, int32_t scalars) {
   API_BEGIN
   REQUIRE(h, "null handle");
   h->lsmr_trace_scalars = scalars != 0;
+  API_END
+}
+
+/* 1: k_lsmr_fused2 reads masks / observations / board points from the frame-major tables on every rig (its form with boards=True and the
+ * only one until round 6) instead of the compacted tables; A/B runs and test_lsmr_observation_sources_agree */
+int32_t mcba_debug_set_lsmr_masks_form(mcba_handle h, int32_t on) {
+  API_BEGIN
+  REQUIRE(h, "null handle");
+  h->lsmr_masks_form = on != 0;
   API_END
 }
 
@@ -3346,7 +3381,7 @@ int32_t mcba_reject_outliers(mcba_handle h, const double* x, double threshold, i
   hipLaunchKernelGGL(k_sum2, dim3(1), dim3(256), 0, h->stream, h->costpart.p, grid, h->scal.p + 2);
   fetch_scalars(h, 4);
   h->n_inliers = (int64_t)h->h_scal[1];      // this shard's inliers
-  h->obs_index_dirty = true;
+  h->obs_index_dirty = true; h->compact_dirty = true;
   h->view_first_dirty = true;
   h->out_r.alloc((size_t)std::max<int64_t>(2 * h->n_inliers, 1), false);
   double tot[2] = {h->h_scal[1], h->h_scal[3]};
@@ -3425,16 +3460,18 @@ int32_t mcba_debug_lsmr_fused_products(mcba_handle h, const double* x, const dou
   double* s1 = s0 + LS_NSLOTS;
   op.ensure_part2(true);
   hipLaunchKernelGGL(k_lsmr_init, dim3(1), dim3(64), 0, h->stream, s0, /*alpha*/ 0.0, /*beta*/ 1.0, 0.0, 1.0, 1e9);
-  int cached = 0;
-  if (h->lsmr_fused == 3 && d.off_boards < 0) {   // the cached form: one evaluating pass fills the cache, the pass under test streams it back
+  int cached = (d.off_boards < 0 && !h->lsmr_masks_form) ? 3 : 0;   // (k_lsmr_fused2's MODE: compact tables unless boards=True)
+  if (cached != 0) ensure_compact(h);
+  if (h->lsmr_fused == 3 && cached == 3) {          // the cached form: one evaluating pass fills the cache, the pass under test streams it back
     const size_t need = (((size_t)h->n_inliers + 63) / 64) * 64 * (size_t)lsmr_cache_components(d.motion, d.loss) + 64;
     if (h->ls_cache.n < need) h->ls_cache.alloc(need, false);
     h->ops->lsmr_fused2(d, h->t, h->stream, h->view_first.p, h->dsc.p, h->ls_v.p, h->ls_u.p, h->ls_partial.p, h->ls_xpart.p, h->ls_part2.p,
-                        op.part_stride, op.bpart(), op.nblk, s0, s1, h->ls_vpart.p, op.gather3_grid(), h->ls_hbar.p, h->ls_x.p, h->ls_h.p, h->ls_cache.p, 1);
+                        op.part_stride, op.bpart(), op.nblk, s0, s1, h->ls_vpart.p, op.gather3_grid(), h->ls_hbar.p, h->ls_x.p, h->ls_h.p, h->ls_cache.p, 4,
+                        compact_tables(h));
     cached = 2;
   }
   h->ops->lsmr_fused2(d, h->t, h->stream, h->view_first.p, h->dsc.p, h->ls_v.p, h->ls_u.p, h->ls_partial.p, h->ls_xpart.p, h->ls_part2.p,
-                      op.part_stride, op.bpart(), op.nblk, s0, s1, h->ls_vpart.p, op.gather3_grid(), h->ls_hbar.p, h->ls_x.p, h->ls_h.p, h->ls_cache.p, cached);
+                      op.part_stride, op.bpart(), op.nblk, s0, s1, h->ls_vpart.p, op.gather3_grid(), h->ls_hbar.p, h->ls_x.p, h->ls_h.p, h->ls_cache.p, cached, compact_tables(h));
   hipLaunchKernelGGL(k_lsmr_gather3, dim3(op.gather3_grid()), dim3(LSG3_THREADS), 0, h->stream, d, (const double*)h->ls_part2.p, op.part_stride,
                      (const double*)h->dsc.p, (const double*)h->ls_v.p, h->ls_vraw.p, h->ls_nrm.p, h->ls_vpart.p, (const double*)s1, h->ls_out.p,
                      (const double*)h->ls_partial.p, op.nblk, (const double*)h->ls_xpart.p, std::max(1, std::min(op.nblk, (d.n + 63) / 64)),
@@ -3478,18 +3515,20 @@ int32_t mcba_time_lsmr_iteration(mcba_handle h, const double* x, int32_t repeats
   double* s1 = s0 + LS_NSLOTS;
   op.ensure_part2(true);
   hipLaunchKernelGGL(k_lsmr_init, dim3(1), dim3(64), 0, h->stream, s0, 1.0, 1.0, 0.0, 1.0, 1e9);   // (no pending rotation: the product alone)
-  int cached = 0;
-  if (h->lsmr_fused == 3 && d.off_boards < 0) {   // the cached form: one evaluating pass fills the cache, the pass under test streams it back
+  int cached = (d.off_boards < 0 && !h->lsmr_masks_form) ? 3 : 0;   // (k_lsmr_fused2's MODE: compact tables unless boards=True)
+  if (cached != 0) ensure_compact(h);
+  if (h->lsmr_fused == 3 && cached == 3) {          // the cached form: one evaluating pass fills the cache, the pass under test streams it back
     const size_t need = (((size_t)h->n_inliers + 63) / 64) * 64 * (size_t)lsmr_cache_components(d.motion, d.loss) + 64;
     if (h->ls_cache.n < need) h->ls_cache.alloc(need, false);
     h->ops->lsmr_fused2(d, h->t, h->stream, h->view_first.p, h->dsc.p, h->ls_v.p, h->ls_u.p, h->ls_partial.p, h->ls_xpart.p, h->ls_part2.p,
-                        op.part_stride, op.bpart(), op.nblk, s0, s1, h->ls_vpart.p, op.gather3_grid(), h->ls_hbar.p, h->ls_x.p, h->ls_h.p, h->ls_cache.p, 1);
+                        op.part_stride, op.bpart(), op.nblk, s0, s1, h->ls_vpart.p, op.gather3_grid(), h->ls_hbar.p, h->ls_x.p, h->ls_h.p, h->ls_cache.p, 4,
+                        compact_tables(h));
     cached = 2;
   }
   sync(h);
   auto product = [&]() {
     h->ops->lsmr_fused2(d, h->t, h->stream, h->view_first.p, h->dsc.p, h->ls_v.p, h->ls_u.p, h->ls_partial.p, h->ls_xpart.p, h->ls_part2.p,
-                        op.part_stride, op.bpart(), op.nblk, s0, s1, h->ls_vpart.p, op.gather3_grid(), h->ls_hbar.p, h->ls_x.p, h->ls_h.p, h->ls_cache.p, cached);
+                        op.part_stride, op.bpart(), op.nblk, s0, s1, h->ls_vpart.p, op.gather3_grid(), h->ls_hbar.p, h->ls_x.p, h->ls_h.p, h->ls_cache.p, cached, compact_tables(h));
   };
   auto gather = [&]() {   // (writes its state to the spare half of s1's buffer is not possible: a scratch copy keeps s0 untouched)
     hipLaunchKernelGGL(k_lsmr_gather3, dim3(op.gather3_grid()), dim3(LSG3_THREADS), 0, h->stream, d, (const double*)h->ls_part2.p, op.part_stride,

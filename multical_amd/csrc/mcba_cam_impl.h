@@ -166,21 +166,24 @@ void lsmr_fused(const Dims& d, const Tables& t, hipStream_t s, const int32_t* fi
 
 #define MCBA_F2_ARGS const Dims& d, const Tables& t, hipStream_t s, const int32_t* first, const double* dscale, const double* v, double* u, \
                      double* partial, double* xpart, double* part, int part_stride, double* bpart, int nblk, const double* lsIn, \
-                     double* lsOut, const double* vpart, int nv, double* hbar, double* x, double* h, double* cache, int cached
-#define MCBA_F2_PASS d, t, s, first, dscale, v, u, partial, xpart, part, part_stride, bpart, nblk, lsIn, lsOut, vpart, nv, hbar, x, h, cache, cached
-#define MCBA_F2_LAUNCH(ROB, CA) \
-    hipLaunchKernelGGL((k_lsmr_fused2<ND_, FISH_, MOTION, OPTK, ROB, CA>), dim3(nblk), dim3(64), 0, s, d, t, first, dscale, v, u, partial, xpart, part, \
-                       part_stride, bpart, lsIn, lsOut, vpart, nv, hbar, x, h, cache)
-// cached: 0 = evaluate the state of every observation (default), 1 = ... and store it (first iteration of a cached solve), 2 = stream it back
+                     double* lsOut, const double* vpart, int nv, double* hbar, double* x, double* h, double* cache, int mode, LsmrCompact cp
+#define MCBA_F2_PASS d, t, s, first, dscale, v, u, partial, xpart, part, part_stride, bpart, nblk, lsIn, lsOut, vpart, nv, hbar, x, h, cache, mode, cp
+#define MCBA_F2_LAUNCH(ROB, MO) \
+    hipLaunchKernelGGL((k_lsmr_fused2<ND_, FISH_, MOTION, OPTK, ROB, MO>), dim3(nblk), dim3(64), 0, s, d, t, first, dscale, v, u, partial, xpart, part, \
+                       part_stride, bpart, lsIn, lsOut, vpart, nv, hbar, x, h, cache, cp)
+// mode (k_lsmr_fused2's MODE): 0 = masks (boards=True), 3 = compact tables (default), 4 = compact + store the per-observation state,
+// 2 = stream the state back
 template <int MOTION, bool OPTK>
 void fus22(MCBA_F2_ARGS) {
   if (d.loss != 0) {
-    if (cached == 2) MCBA_F2_LAUNCH(true, 2);
-    else if (cached == 1) MCBA_F2_LAUNCH(true, 1);
+    if (mode == 2) MCBA_F2_LAUNCH(true, 2);
+    else if (mode == 3) MCBA_F2_LAUNCH(true, 3);
+    else if (mode == 4) MCBA_F2_LAUNCH(true, 4);
     else MCBA_F2_LAUNCH(true, 0);
   } else {
-    if (cached == 2) MCBA_F2_LAUNCH(false, 2);
-    else if (cached == 1) MCBA_F2_LAUNCH(false, 1);
+    if (mode == 2) MCBA_F2_LAUNCH(false, 2);
+    else if (mode == 3) MCBA_F2_LAUNCH(false, 3);
+    else if (mode == 4) MCBA_F2_LAUNCH(false, 4);
     else MCBA_F2_LAUNCH(false, 0);
   }
 }

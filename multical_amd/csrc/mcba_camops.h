@@ -33,7 +33,7 @@ struct CamOps {
   // k_lsmr_fused + the rotation / vector update of the previous step in its head (two-launch iteration)
   void (*lsmr_fused2)(const Dims&, const Tables&, hipStream_t, const int32_t* first, const double* dscale, const double* v, double* u,
                       double* partial, double* xpart, double* part, int part_stride, double* bpart, int nblk, const double* lsIn,
-                      double* lsOut, const double* vpart, int nv, double* hbar, double* x, double* h, double* cache, int cached);
+                      double* lsOut, const double* vpart, int nv, double* hbar, double* x, double* h, double* cache, int mode, LsmrCompact cp);
 };
 
 const CamOps* cam_ops_pin4();

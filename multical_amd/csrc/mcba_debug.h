@@ -61,6 +61,9 @@ int32_t mcba_debug_lsmr_solve(mcba_handle h, const double* x, const mcba_options
  * normA, condA, normx} (the last five NaN unless mcba_debug_set_lsmr_trace(h, 1) preceded the solve)                            */
 int32_t mcba_debug_lsmr_trace(mcba_handle h, int32_t cap, double* rows, int32_t* n_rows);
 int32_t mcba_debug_set_lsmr_trace(mcba_handle h, int32_t scalars);
+/* 1: the product kernel of the LSMR iteration reads the frame-major tables (masks compacted per view) on every rig instead of the
+ * compacted observation tables (A/B runs, tests)                                                                                  */
+int32_t mcba_debug_set_lsmr_masks_form(mcba_handle h, int32_t on);
 /* number of collective sizes mcba_allreduce_stats records per handle (default 4096; a whole sharded lsmr solve issues more)       */
 int32_t mcba_debug_set_allreduce_trace(mcba_handle h, int32_t cap);
 /* persistent workgroups of the LSMR product kernels (default 2048): summation-order experiments                                 */

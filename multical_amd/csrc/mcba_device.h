@@ -110,4 +110,15 @@ struct Tables {
   const int32_t* int2ext;      // [n] index in the CALLER's (ragged) parameter vector, -1 = padded coefficient; null = identity
 };
 
+// Compacted observation tables of the lsmr route (built once per inlier set: k_compact_views): the observations of every view in
+// the reference's RESIDUAL order -- observed point, board point (x, y) and z -- so that a product kernel streams them without mask
+// bytes, compaction or point-index gathers, and one descriptor {view, first residual pair, inliers, 0} per ACTIVE view in the
+// largest-first order of Tables::active_views.
+struct LsmrCompact {
+  const double2* obs;      // [n_inliers] observed (u, v)
+  const double2* bxy;      // [n_inliers] board point x, y
+  const double* bz;        // [n_inliers] board point z
+  const int4* desc;        // [active views] {v, first, count, 0}
+};
+
 }  // namespace mcba

@@ -797,6 +797,10 @@ __global__ __launch_bounds__(64) void k_lsmr_fused(Dims d, Tables t, const int32
       out0 += (size_t)count;
       lds_fence();
     }
+#if defined(MCBA_EXP_F2_NO_REDUCE)  // what-if (variant builds only): no butterfly over the wave, no That^T product, one store per view
+    if (lane == 0) part[lsmr_part_index(d, v, 0)] = sums[0] + sums[NS - 1];
+    continue;
+#endif
     const double tot = wave_reduce_many<NS>(sums, lane);
     if (many_writer<NS>(lane)) sl[many_index(lane)] = tot;
     lds_fence();
@@ -824,13 +828,22 @@ __global__ __launch_bounds__(64) void k_lsmr_fused(Dims d, Tables t, const int32
 // of the vectors, xpart[slice] = its part of |x|^2, and the last workgroup publishes the state (in: lsIn, written by the gather;
 // out: lsOut -- double buffer, see k_lsmr_gather3).  v is never stored normalised: v = v_raw / alpha is formed where it is read.
 // ---------------------------------------------------------------------------------------------------------------
-// The Jacobian is FIXED during an LSMR solve: what an observation contributes to both products is determined by its PointState --
+// Source of an observation's data in k_lsmr_fused2 (template MODE):
+//   0  masks: the frame-major tables -- mask bytes compacted per view in LDS, observation and board point gathered by point index
+//      (the only form with boards=True: the board-point block needs the point index, and the board points move)
+//   3  compact (default): the observations of a view streamed in residual order from the compacted tables LsmrCompact (built once
+//      per inlier set) -- no mask bytes, no compaction, no gathers, and ONE round trip per view instead of three: the view's
+//      descriptor {view, first, count} is a scalar load prefetched one view ahead, and the first chunk's loads go out together with
+//      the That / parameter staging loads.  What-if builds of the masks form (profiles/r06_f2_whatif.txt) showed the kernel
+//      latency-bound on its per-view chain of dependent loads: without ANY arithmetic 22.2 of its 26.7 us remained.
+//   4  compact + store the per-observation state (first iteration of a solve under the cached form)
+//   2  stream the state back.  The Jacobian is FIXED during an LSMR solve: what an observation contributes to both products
+//      is determined by its PointState --
 // A = d(u, v) / d X_cam, the camera-frame points of the start / end chain, the scan time (+ the robust row scales) -- 13 doubles
-// (rolling shutter; 9 static; + 2 robust).  CACHED = 1 stores them while it evaluates an iteration as before (the first iteration of
-// a solve), CACHED = 2 streams them back instead of reading masks / observations / board points and re-deriving the state: the
+// (rolling shutter; 9 static; + 2 robust): MODE 2 reads them instead of observations / board points and re-deriving the state: the
 // intrinsic columns K_c are rebuilt from X_cam by the same project_point (its A / uv halves are dead code there), everything behind the
-// state is the same source.  Layout: blocks of 64 observations in residual order, component-major inside a block (one 512-byte run
-// per component and wavefront).  mcba_debug_set_lsmr_fused(h, 3); measured in profiles/r06_lsmr_experiments.txt.
+// state is the same source.  Cache layout: blocks of 64 observations in residual order, component-major inside a block (one 512-byte
+// run per component and wavefront).  mcba_debug_set_lsmr_fused(h, 3); measured in profiles/r06_lsmr_iteration.txt.
 template <bool ROLL, bool ROBUST>
 struct LsmrCacheLayout {
   static constexpr int NC = 6 + 3 + (ROLL ? 4 : 0) + (ROBUST ? 2 : 0);
@@ -840,15 +853,22 @@ __host__ __device__ inline int lsmr_cache_components(int motion, int loss) {
   return 6 + 3 + (motion == MOTION_ROLLING ? 4 : 0) + (loss != 0 ? 2 : 0);
 }
 
-template <int ND, int FISH, int MOTION, bool OPTK, bool ROBUST, int CACHED>
-__global__ __launch_bounds__(64) void k_lsmr_fused2(Dims d, Tables t, const int32_t* __restrict__ first,
+#if defined(MCBA_EXP_F2_WAVES)       // what-if (variant builds only): force N waves per SIMD (the register allocator spills to fit)
+#define MCBA_F2_OCCUPANCY __attribute__((amdgpu_waves_per_eu(MCBA_EXP_F2_WAVES, MCBA_EXP_F2_WAVES)))
+#else
+#define MCBA_F2_OCCUPANCY
+#endif
+template <int ND, int FISH, int MOTION, bool OPTK, bool ROBUST, int MODE>
+__global__ __launch_bounds__(64) MCBA_F2_OCCUPANCY void k_lsmr_fused2(Dims d, Tables t, const int32_t* __restrict__ first,
                                                     const double* __restrict__ dscale, const double* __restrict__ vin,
                                                     double* __restrict__ u, double* __restrict__ partial, double* __restrict__ xpart,
                                                     double* __restrict__ part, int part_stride, double* __restrict__ bpart,
                                                     const double* __restrict__ lsIn, double* __restrict__ lsOut,
                                                     const double* __restrict__ vpart, int nv, double* __restrict__ hbar,
-                                                    double* __restrict__ xv, double* __restrict__ hv, double* __restrict__ cache) {
+                                                    double* __restrict__ xv, double* __restrict__ hv, double* __restrict__ cache,
+                                                    LsmrCompact cp) {
   constexpr bool ROLL = MOTION == MOTION_ROLLING;
+  constexpr bool DESC = MODE >= 2;          // the view list comes as descriptors {view, first, count}
   constexpr int DE = ROLL ? 12 : 6, NPB = MOTION == MOTION_STATIC ? 3 : 4, NPC = 6 * NPB, KI = OPTK ? 4 + ND : 0;
   constexpr int NS = DE + KI;
   using CL = LsmrCacheLayout<ROLL, ROBUST>;
@@ -882,6 +902,12 @@ __global__ __launch_bounds__(64) void k_lsmr_fused2(Dims d, Tables t, const int3
   double sums[NS];
   // one observation: uhat, its part of |uhat|^2 and of the per-view sums of row^T uhat, from the state ps (shared by all three forms)
   auto observe = [&](const PointState<ND, ROLL>& ps, double2 old, int v, int b, int p, size_t pair) {
+#if defined(MCBA_EXP_F2_NO_MATH)    // what-if (variant builds only): loads, stores and per-view work stay, the two products go
+    reinterpret_cast<double2*>(u)[pair] = old;
+    acc += old.x + ps.A[0] + ps.Xs[0];
+    sums[0] += old.y;
+    return;
+#endif
     old.x *= inv_beta_old;
     old.y *= inv_beta_old;
     double bterm[2] = {0.0, 0.0};
@@ -959,25 +985,46 @@ __global__ __launch_bounds__(64) void k_lsmr_fused2(Dims d, Tables t, const int3
   };
   // (a boustrophedon order of the largest-first list -- odd rounds backwards, pairing large with small views -- was measured:
   //  40.3 against 39.0 us per iteration; what a workgroup spends is dominated by the per-view round trips, not by its observations)
+  int4 dnext = make_int4(0, 0, 0, 0);
+  if constexpr (DESC) {
+    if ((int)blockIdx.x < n_active) dnext = cp.desc[blockIdx.x];
+  }
   for (int vi = blockIdx.x; vi < n_active; vi += gridDim.x) {
-    const int v = t.active_views[1 + vi];
+    int v, desc_first = 0, desc_count = 0;
+    if constexpr (DESC) {
+      v = dnext.x; desc_first = dnext.y; desc_count = dnext.z;
+      if (vi + (int)gridDim.x < n_active) dnext = cp.desc[vi + gridDim.x];   // (scalar load, one view ahead)
+    } else {
+      v = t.active_views[1 + vi];
+    }
     if (v < 0) continue;
     const int b = v % d.B, c = (v / d.B) % d.C, f = d.f0 + v / (d.B * d.C);
     constexpr int NPB64 = LIN_MAX_POINTS / 64;
     // the mask bytes of the first segment are requested in front of the parameter staging: one round trip for both
     uint8_t inb[NPB64];
-    int cached_count = 0;
-    if constexpr (CACHED == 2) {
-      cached_count = t.view_count[v];
-    } else {
+    if constexpr (!DESC) {
 #pragma unroll
       for (int k = 0; k < NPB64; ++k) inb[k] = masked_load_row(t.inlier + (size_t)v * d.P, k * 64 + lane, d.P);
     }
     double tl[NTL];
+    // compact form: the first chunk of the view is requested with the staging loads (same round trip)
+    double2 ob_cur = make_double2(0.0, 0.0), xy_cur = make_double2(0.0, 0.0), old_cur = make_double2(0.0, 0.0);
+    double z_cur = 0.0;
+    if constexpr (MODE >= 3) {
+      const size_t g0 = (size_t)desc_first + (size_t)(lane < desc_count ? lane : 0);
+      ob_cur = cp.obs[g0];
+      xy_cur = cp.bxy[g0];
+      z_cur = cp.bz[g0];
+      old_cur = reinterpret_cast<const double2*>(u)[g0];
+    }
     {
       const double* tg = t.tmat + (size_t)v * (DE * NPC);
 #pragma unroll
       for (int k = 0; k < NTL; ++k) tl[k] = masked_load_row(tg, k * 64 + lane, DE * NPC);
+#if defined(MCBA_EXP_F2_NO_TMAT)   // what-if (variant builds only): the 2.3 KB of That per view are not streamed
+#pragma unroll
+      for (int k = 0; k < NTL; ++k) tl[k] = 1e-3 * (double)(k * 64 + lane);
+#endif
     }
     if (lane < NPC + KI) {
       const int xi = local_to_x(d, f, c, b, lane);
@@ -998,10 +1045,42 @@ __global__ __launch_bounds__(64) void k_lsmr_fused2(Dims d, Tables t, const int3
     lds_fence();
 #pragma unroll
     for (int k = 0; k < NS; ++k) sums[k] = 0.0;
-    size_t out0 = (size_t)first[v];
-    if constexpr (CACHED == 2) {
+    size_t out0 = DESC ? (size_t)desc_first : (size_t)first[v];
+    if constexpr (MODE >= 3) {
+      // ---- compact form: observation, board point and old uhat stream in residual order; the NEXT chunk is requested before the
+      // current one is evaluated
+      const int count = desc_count;
+      for (int base = 0; base < count; base += 64) {
+        const int i = base + lane, inx = i + 64;
+        const size_t gn = out0 + (size_t)(inx < count ? inx : 0);
+        const double2 ob_nxt = cp.obs[gn], xy_nxt = cp.bxy[gn];
+        const double z_nxt = cp.bz[gn];
+        const double2 old_nxt = reinterpret_cast<const double2*>(u)[gn];
+        if (i < count) {
+          const double X_cur[3] = {xy_cur.x, xy_cur.y, z_cur};
+          PointState<ND, ROLL> ps;
+          point_state<ND, FISH, ROLL, ROBUST>(d, t, v, c, b, 0, ob_cur, ps, X_cur);
+          if constexpr (MODE == 4) {   // the state of the observation for the cached iterations that follow
+            const size_t gi = out0 + (size_t)i;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) cache[CL::index(gi, k)] = ps.A[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) cache[CL::index(gi, 6 + k)] = ps.Xs[k];
+            if constexpr (ROLL) {
+#pragma unroll
+              for (int k = 0; k < 3; ++k) cache[CL::index(gi, 9 + k)] = ps.Xe[k];
+              cache[CL::index(gi, 12)] = ps.tr;
+            }
+            if constexpr (ROBUST) { cache[CL::index(gi, CL::NC - 2)] = ps.rs[0]; cache[CL::index(gi, CL::NC - 1)] = ps.rs[1]; }
+          }
+          observe(ps, old_cur, v, b, 0, out0 + (size_t)i);
+        }
+        ob_cur = ob_nxt; xy_cur = xy_nxt; z_cur = z_nxt; old_cur = old_nxt;
+      }
+    } else if constexpr (MODE == 2) {
       // ---- the state of every observation comes back from the cache: no masks, no compaction, no observation / board-point reads
       const double* cam = t.cam + (size_t)c * CAM_STRIDE;
+      const int cached_count = desc_count;
       for (int base = 0; base < cached_count; base += 64) {
         const int i = base + lane;
         const size_t gi = out0 + (size_t)(i < cached_count ? i : 0);
@@ -1053,12 +1132,12 @@ __global__ __launch_bounds__(64) void k_lsmr_fused2(Dims d, Tables t, const int3
       lds_fence();
       // observation, board point and old uhat of the NEXT chunk are requested before the current one is evaluated (as in k_cost)
       int p_cur = lane < count ? pidx[lane] : 0;
-      double2 ob_cur = t.obs[(size_t)v * d.P + p_cur];
+      ob_cur = t.obs[(size_t)v * d.P + p_cur];
       double X_cur[3], X_nxt[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) X_cur[k] = t.board_points[3 * (size_t)(b * d.P + p_cur) + k];
       const size_t o0 = count > 0 ? out0 : 0;   // (a segment without inliers behind the last residual must not read past the vector)
-      double2 old_cur = reinterpret_cast<const double2*>(u)[o0 + (lane < count ? lane : 0)];
+      old_cur = reinterpret_cast<const double2*>(u)[o0 + (lane < count ? lane : 0)];
       for (int base = 0; base < count; base += 64) {
         const int i = base + lane, inx = i + 64;
         const int p_nxt = inx < count ? pidx[inx] : p_cur;
@@ -1069,20 +1148,14 @@ __global__ __launch_bounds__(64) void k_lsmr_fused2(Dims d, Tables t, const int3
         if (i < count) {
           const int p = p_cur;
           PointState<ND, ROLL> ps;
+#if defined(MCBA_EXP_F2_NO_STATE)   // what-if (variant builds only): the forward model + derivatives of the observation are not evaluated
+          for (int k = 0; k < 6; ++k) ps.A[k] = ob_cur.x + k;
+          for (int k = 0; k < 3; ++k) { ps.Xs[k] = X_cur[k]; ps.Xe[k] = X_cur[k] + 1.0; }
+          for (int k = 0; k < 2 * (4 + ND); ++k) ps.Kc[k] = ob_cur.y + k;
+          ps.tr = 0.5; ps.rs[0] = ps.rs[1] = 1.0;
+#else
           point_state<ND, FISH, ROLL, ROBUST>(d, t, v, c, b, p, ob_cur, ps, X_cur);
-          if constexpr (CACHED == 1) {   // the state of the observation for the cached iterations that follow
-            const size_t gi = out0 + (size_t)i;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) cache[CL::index(gi, k)] = ps.A[k];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) cache[CL::index(gi, 6 + k)] = ps.Xs[k];
-            if constexpr (ROLL) {
-#pragma unroll
-              for (int k = 0; k < 3; ++k) cache[CL::index(gi, 9 + k)] = ps.Xe[k];
-              cache[CL::index(gi, 12)] = ps.tr;
-            }
-            if constexpr (ROBUST) { cache[CL::index(gi, CL::NC - 2)] = ps.rs[0]; cache[CL::index(gi, CL::NC - 1)] = ps.rs[1]; }
-          }
+#endif
           observe(ps, old_cur, v, b, p, out0 + (size_t)i);
         }
         p_cur = p_nxt;
@@ -1095,6 +1168,10 @@ __global__ __launch_bounds__(64) void k_lsmr_fused2(Dims d, Tables t, const int3
       lds_fence();
     }
     }
+#if defined(MCBA_EXP_F2_NO_REDUCE)  // what-if (variant builds only): no butterfly over the wave, no That^T product, one store per view
+    if (lane == 0) part[lsmr_part_index(d, v, 0)] = sums[0] + sums[NS - 1];
+    continue;
+#endif
     const double tot = wave_reduce_many<NS>(sums, lane);
     if (many_writer<NS>(lane)) sl[many_index(lane)] = tot;
     lds_fence();

@@ -3406,6 +3406,33 @@ __global__ __launch_bounds__(64) void k_obs_index(Dims d, const uint8_t* __restr
   }
 }
 
+// the compacted observation tables of the lsmr route (LsmrCompact): one wavefront per ACTIVE view, in the order of the active list
+__global__ __launch_bounds__(64) void k_compact_views(Dims d, Tables t, const int32_t* __restrict__ first, double2* __restrict__ obsC,
+                                                      double2* __restrict__ bxy, double* __restrict__ bz, int4* __restrict__ desc) {
+  const int vi = blockIdx.x, lane = threadIdx.x;
+  if (vi >= t.active_views[0]) return;
+  const int v = t.active_views[1 + vi];
+  if (v < 0) { if (lane == 0) desc[vi] = make_int4(-1, 0, 0, 0); return; }
+  const int b = v % d.B;
+  const size_t s0 = (size_t)v * d.P;
+  const int f0 = first[v];
+  int base = f0;
+  for (int q0 = 0; q0 < d.P; q0 += 64) {
+    const int q = q0 + lane;
+    const bool in = q < d.P && t.inlier[s0 + q] != 0;
+    const unsigned long long m = __ballot(in);
+    if (in) {
+      const int gi = base + __popcll(m & ((1ull << lane) - 1ull));
+      obsC[gi] = t.obs[s0 + q];
+      const double* X = t.board_points + 3 * (size_t)(b * d.P + q);
+      bxy[gi] = make_double2(X[0], X[1]);
+      bz[gi] = X[2];
+    }
+    base += __popcll(m);
+  }
+  if (lane == 0) desc[vi] = make_int4(v, f0, base - f0, 0);
+}
+
 // frame-major inlier table -> reference [C,F,B,P] order (only this shard's frames are written)
 __global__ void k_inliers_to_ref(Dims d, const uint8_t* __restrict__ inlier, uint8_t* __restrict__ out) {
   const int n = d.slots();

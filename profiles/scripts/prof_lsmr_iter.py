@@ -14,8 +14,9 @@ for cfg in (sys.argv[1:] or ["cfg3"]):
   x0 = c.param_vec
   with Handle(c) as h:
     out = {}
-    for fused in (2, 3, 1, 0, 2):
-      h.set_lsmr_fused(fused)
+    for fused in (2, 3, 12, 1, 0, 2):       # (12: form 2 reading the frame-major tables -- the only source until round 6)
+      h.set_lsmr_masks_form(fused == 12)
+      h.set_lsmr_fused(2 if fused == 12 else fused)
       h.solve(x0, tr_solver="lsmr")
       ts = []
       for _ in range(3):
@@ -24,7 +25,7 @@ for cfg in (sys.argv[1:] or ["cfg3"]):
       itn = h.lsmr_iterations()
       e, v = h.reprojection_error(r.x)
       k_us = [1e3 * ms for ms in h.time_lsmr_iteration(x0, repeats=200)] if fused >= 2 else None
-      out[{3: "two_launch_cached_state", 2: "two_launch", 1: "three_launch", 0: "six_launch"}[fused]] = dict(product_gather_kernel_us=k_us, seconds=t, nfev=r.nfev, status=r.status, lsmr_iterations=itn,
+      out[{3: "two_launch_cached_state", 2: "two_launch", 12: "two_launch_masks_form", 1: "three_launch", 0: "six_launch"}[fused]] = dict(product_gather_kernel_us=k_us, seconds=t, nfev=r.nfev, status=r.status, lsmr_iterations=itn,
                                                       us_per_lsmr_iteration=t / max(itn, 1) * 1e6, cost=r.cost,
                                                       rms_px=float(np.sqrt(np.mean(e[v] ** 2))))
     print(cfg, json.dumps(out), flush=True)

@@ -59,12 +59,14 @@ def test_lsmr_two_launch_kernels_against_the_jacobian(name):
     h.set_lsmr_fused(2)          # the evaluating form (the default on rolling-shutter rigs and with boards=True)
     jv, w = h.lsmr_fused_products(x, v)
     jv2, w2 = h.lsmr_fused_products(x, v)
+    h.set_lsmr_masks_form(True)  # ... reading the frame-major tables instead of the compacted ones
+    jvm, wm = h.lsmr_fused_products(x, v)
+    h.set_lsmr_masks_form(False)
+    if name != "tiny_bigboard":
+      assert np.array_equal(jv, jvm) and np.array_equal(w, wm), (np.abs(jv - jvm).max(), np.abs(w - wm).max())
     h.set_lsmr_fused(3)          # the same step with the per-observation state streamed back from the cache (CACHED = 2)
     jv3, w3 = h.lsmr_fused_products(x, v)
-  if name == "tiny_bigboard":   # (a board of more than 512 points is walked in segments: the cached form deals its observations to other lanes)
-    assert np.abs(jv - jv3).max() <= 1e-13 * np.abs(jv).max() and np.abs(w - w3).max() <= 1e-12 * np.abs(w).max()
-  else:
-    assert np.array_equal(jv, jv3) and np.array_equal(w, w3), (np.abs(jv - jv3).max(), np.abs(w - w3).max())
+  assert np.array_equal(jv, jv3) and np.array_equal(w, w3), (np.abs(jv - jv3).max(), np.abs(w - w3).max())
   A = abs(J)
   ref = J @ v
   assert np.abs(jv - ref).max() <= 1e-12 * (A @ np.abs(v)).max()
@@ -197,6 +199,39 @@ def test_lsmr_iteration_forms_agree(name):
   if spread < 3e-7:
     assert out[0][:2] == out[1][:2] == out[2][:2] == (int(g["ba_nfev"]), int(g["ba_status"])), (name, out)
     assert max(abs(out[m][2] - out[0][2]) for m in (1, 2)) <= 1e-6, (name, out)
+
+
+@pytest.mark.parametrize("name", ["cfg1", "tiny_rolling", "tiny_fisheye", "tiny_handeye", "tiny_edge", "tiny_fishmix", "tiny_bigboard", "tiny_softl1"])
+def test_lsmr_observation_sources_agree(name):
+  """k_lsmr_fused2 reads its observations from the COMPACTED tables (residual order, built once per inlier set: one round trip per view) --
+  or, with boards=True, from the frame-major tables with the mask bytes compacted per view in LDS (the only form until round 6,
+  mcba_debug_set_lsmr_masks_form).  Same arithmetic, same lane for every observation: the two solves return the SAME bits (a board of
+  more than 512 points is walked in segments by the masks form and deals its observations to other lanes: rounding-level differences
+  there), also after an outlier rejection has changed the inlier set."""
+  import json
+  g, rig = load_golden(name)
+  kw = json.loads(str(g["ba_kwargs_json"])) if "ba_kwargs_json" in g else {}
+  opts = dict(tr_solver="lsmr", loss=kw.get("loss", "linear"), f_scale=kw.get("f_scale", 1.0))
+  with Handle(mirror(rig)) as h:
+    out = {}
+    for masks in (False, True, False):
+      h.set_lsmr_masks_form(masks)
+      res = h.solve(g["x0"], **opts)
+      out.setdefault(masks, []).append((res.x, res.nfev, res.status, res.cost, h.lsmr_iterations()))
+    e, valid = h.reprojection_error(out[False][0][0])
+    h.reject_outliers(out[False][0][0], float(np.quantile(e[valid.astype(bool)], 0.9)))
+    after = {}
+    for masks in (True, False):
+      h.set_lsmr_masks_form(masks)
+      after[masks] = h.solve(g["x0"], **opts)
+  a, a2, b = out[False][0], out[False][1], out[True][0]
+  assert np.array_equal(a[0], a2[0]) and a[1:] == a2[1:]
+  if name == "tiny_bigboard":
+    spread = float(np.abs(g["ba_pert_rms"] - g["ba_rms"]).max())
+    assert abs(a[3] - b[3]) <= max(1e-9, 10 * spread) * a[3]
+  else:
+    assert np.array_equal(a[0], b[0]) and a[1:] == b[1:], (float(np.abs(a[0] - b[0]).max()), a[1:], b[1:])
+    assert np.array_equal(after[True].x, after[False].x) and after[True].nfev == after[False].nfev
 
 
 @pytest.mark.parametrize("name", ["tiny_rolling", "tiny_boards", "cfg1"])
