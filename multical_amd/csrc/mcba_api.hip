@@ -361,9 +361,7 @@ struct mcba_handle_s {
   // solver state
   DevBuf<double> x, xnew, scale_inv, dsc, gh, gn, scal, costpart, Lf, W, yf, P, sbuf, ps;
   long long lsmr_iterations_last = 0;     // LSMR iterations of the last solve_lsmr (mcba_debug_lsmr_info)
-  int lsmr_grid_setting = 0;              // mcba_debug_set_lsmr_grid (grid experiments); 0 = automatic
-  int lsmr_grid = 2048;                   // persistent single-wave workgroups of the LSMR product kernels: one per resident wavefront --
-                                          // 2048 (2 per SIMD; rolling shutter, boards=True), 3072 where k_lsmr_fused2 runs 3 per SIMD
+  int lsmr_grid = 2048;                   // persistent single-wave workgroups of the LSMR product kernels (mcba_debug_set_lsmr_grid: grid experiments)
   // one row per LSMR call of the last solve_lsmr (mcba_debug_lsmr_trace): scipy's return tuple of `lsmr` beside the trust-region
   // quantities the call was made with
   struct LsmrCall { double tr_iteration, damp, Delta, istop, itn, normr, normar, normA, condA, normx; };
@@ -2274,8 +2272,6 @@ struct LsmrOps {
 static LsmrOps lsmr_setup(mcba_handle_s* h) {
   const Dims& d = h->d;
   h->lsmr_fused = h->lsmr_fused_setting >= 0 ? h->lsmr_fused_setting : (d.motion == MOTION_ROLLING || d.off_boards >= 0 ? 2 : 3);
-  h->lsmr_grid = h->lsmr_grid_setting > 0 ? h->lsmr_grid_setting
-                                          : ((d.motion != MOTION_ROLLING && d.off_boards < 0 && !h->lsmr_masks_form) ? 3072 : 2048);
   ensure_view_first(h);
   const size_t m = 2 * (size_t)h->n_inliers;
   const int NL = 6 * d.NPB + d.KI;
@@ -2474,7 +2470,7 @@ static void solve_lsmr(mcba_handle h, double* x_inout, const mcba_options* opt, 
   const double NaN = std::numeric_limits<double>::quiet_NaN();
   double* S = h->h_scal;
   // (persistent single-wave workgroups of the product kernels: h->lsmr_grid, default 2048; MCBA_LSMR_GRID: process-wide debug switch)
-  if (const char* gsw = dbg_switch("MCBA_LSMR_GRID")) h->lsmr_grid_setting = std::max(64, atoi(gsw));
+  if (const char* gsw = dbg_switch("MCBA_LSMR_GRID")) h->lsmr_grid = std::max(64, atoi(gsw));
   LsmrOps op = lsmr_setup(h);
   const size_t m = op.m;
   h->lsmr_trace.clear();
@@ -2799,8 +2795,8 @@ int32_t mcba_debug_set_allreduce_trace(mcba_handle h, int32_t cap) {
  * which partial sums are folded -- the summation-order experiment of profiles/r06_lsmr_sign.* */
 int32_t mcba_debug_set_lsmr_grid(mcba_handle h, int32_t grid) {
   API_BEGIN
-  REQUIRE(h && (grid == 0 || (grid >= 64 && grid <= 65536)), "bad grid (0 = automatic)");
-  h->lsmr_grid_setting = grid;
+  REQUIRE(h && grid >= 64 && grid <= 65536, "bad grid");
+  h->lsmr_grid = grid;
   API_END
 }
 

@@ -169,14 +169,8 @@ void lsmr_fused(const Dims& d, const Tables& t, hipStream_t s, const int32_t* fi
                      double* lsOut, const double* vpart, int nv, double* hbar, double* x, double* h, double* cache, int mode, LsmrCompact cp
 #define MCBA_F2_PASS d, t, s, first, dscale, v, u, partial, xpart, part, part_stride, bpart, nblk, lsIn, lsOut, vpart, nv, hbar, x, h, cache, mode, cp
 #define MCBA_F2_LAUNCH(ROB, MO) \
-    do { \
-      if constexpr (MOTION != MOTION_ROLLING && MO != 0) \
-        hipLaunchKernelGGL((k_lsmr_fused2_w3<ND_, FISH_, MOTION, OPTK, ROB, MO>), dim3(nblk), dim3(64), 0, s, d, t, first, dscale, v, u, partial, xpart, \
-                           part, part_stride, bpart, lsIn, lsOut, vpart, nv, hbar, x, h, cache, cp); \
-      else \
-        hipLaunchKernelGGL((k_lsmr_fused2<ND_, FISH_, MOTION, OPTK, ROB, MO>), dim3(nblk), dim3(64), 0, s, d, t, first, dscale, v, u, partial, xpart, \
-                           part, part_stride, bpart, lsIn, lsOut, vpart, nv, hbar, x, h, cache, cp); \
-    } while (0)
+    hipLaunchKernelGGL((k_lsmr_fused2<ND_, FISH_, MOTION, OPTK, ROB, MO>), dim3(nblk), dim3(64), 0, s, d, t, first, dscale, v, u, partial, xpart, part, \
+                       part_stride, bpart, lsIn, lsOut, vpart, nv, hbar, x, h, cache, cp)
 // mode (k_lsmr_fused2's MODE): 0 = masks (boards=True), 3 = compact tables (default), 4 = compact + store the per-observation state,
 // 2 = stream the state back
 template <int MOTION, bool OPTK>

@@ -856,16 +856,17 @@ __host__ __device__ inline int lsmr_cache_components(int motion, int loss) {
 #if defined(MCBA_EXP_F2_WAVES)       // what-if (variant builds only): force N waves per SIMD (the register allocator spills to fit)
 #define MCBA_F2_OCCUPANCY __attribute__((amdgpu_waves_per_eu(MCBA_EXP_F2_WAVES, MCBA_EXP_F2_WAVES)))
 #else
-#define MCBA_F2_OCCUPANCY __attribute__((amdgpu_waves_per_eu(2, 2)))   // (256 registers: the rolling-shutter masks form would take 280)
+#define MCBA_F2_OCCUPANCY
 #endif
-#define MCBA_F2_KPARAMS Dims d, Tables t, const int32_t* __restrict__ first, const double* __restrict__ dscale, const double* __restrict__ vin, \
-                        double* __restrict__ u, double* __restrict__ partial, double* __restrict__ xpart, double* __restrict__ part, \
-                        int part_stride, double* __restrict__ bpart, const double* __restrict__ lsIn, double* __restrict__ lsOut, \
-                        const double* __restrict__ vpart, int nv, double* __restrict__ hbar, double* __restrict__ xv, \
-                        double* __restrict__ hv, double* __restrict__ cache, LsmrCompact cp
-#define MCBA_F2_KARGS d, t, first, dscale, vin, u, partial, xpart, part, part_stride, bpart, lsIn, lsOut, vpart, nv, hbar, xv, hv, cache, cp
 template <int ND, int FISH, int MOTION, bool OPTK, bool ROBUST, int MODE>
-__device__ __forceinline__ void lsmr_fused2_body(MCBA_F2_KPARAMS) {
+__global__ __launch_bounds__(64) MCBA_F2_OCCUPANCY void k_lsmr_fused2(Dims d, Tables t, const int32_t* __restrict__ first,
+                                                    const double* __restrict__ dscale, const double* __restrict__ vin,
+                                                    double* __restrict__ u, double* __restrict__ partial, double* __restrict__ xpart,
+                                                    double* __restrict__ part, int part_stride, double* __restrict__ bpart,
+                                                    const double* __restrict__ lsIn, double* __restrict__ lsOut,
+                                                    const double* __restrict__ vpart, int nv, double* __restrict__ hbar,
+                                                    double* __restrict__ xv, double* __restrict__ hv, double* __restrict__ cache,
+                                                    LsmrCompact cp) {
   constexpr bool ROLL = MOTION == MOTION_ROLLING;
   constexpr bool DESC = MODE >= 2;          // the view list comes as descriptors {view, first, count}
   constexpr int DE = ROLL ? 12 : 6, NPB = MOTION == MOTION_STATIC ? 3 : 4, NPC = 6 * NPB, KI = OPTK ? 4 + ND : 0;
@@ -1217,20 +1218,6 @@ __device__ __forceinline__ void lsmr_fused2_body(MCBA_F2_KPARAMS) {
     }
   }
 }
-
-// the two entry points of the body: 2 waves per SIMD (rolling shutter: 231 - 256 VGPRs), and THREE for the static / hand-eye
-// instantiations, which need 166 - 182 VGPRs -- a handful over the 168 that three waves leave each (the allocator sheds them); with
-// 3072 resident wavefronts instead of 2048 the per-view chains of this latency-bound kernel overlap half as much again
-template <int ND, int FISH, int MOTION, bool OPTK, bool ROBUST, int MODE>
-__global__ __launch_bounds__(64) MCBA_F2_OCCUPANCY void k_lsmr_fused2(MCBA_F2_KPARAMS) {
-  lsmr_fused2_body<ND, FISH, MOTION, OPTK, ROBUST, MODE>(MCBA_F2_KARGS);
-}
-template <int ND, int FISH, int MOTION, bool OPTK, bool ROBUST, int MODE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_lsmr_fused2_w3(MCBA_F2_KPARAMS) {
-  lsmr_fused2_body<ND, FISH, MOTION, OPTK, ROBUST, MODE>(MCBA_F2_KARGS);
-}
-#undef MCBA_F2_KPARAMS
-#undef MCBA_F2_KARGS
 
 // ---------------------------------------------------------------------------------------------------------------
 // k_jacobian: analytic Jacobian rows in the column order of Calibration.sparsity_matrix
