@@ -675,7 +675,7 @@ def main():
       if os.path.exists(pmc_file) and args.config == "cfg3":
         try:
           pj = json.load(open(pmc_file))
-          k2 = [k for k in pj if "k_lsmr_fused2" in k]
+          k2 = sorted([k for k in pj if "k_lsmr_fused2" in k], key=lambda k: not k.rstrip().endswith(", 3>"))   # (MODE 3: the default form)
           if k2 and "FETCH_SIZE" in pj[k2[0]] and "WRITE_SIZE" in pj[k2[0]]:
             parity_route["roofline"]["traffic"] = 2 * pj[k2[0]]["FETCH_SIZE"] * 1024 + pj[k2[0]]["WRITE_SIZE"] * 1024
             parity_route["roofline"]["traffic_source"] = (os.path.relpath(pmc_file, ROOT) + ": separate --pmc FETCH_SIZE / WRITE_SIZE passes "

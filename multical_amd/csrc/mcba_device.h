@@ -4,7 +4,8 @@
 #include "mcba_math.h"
 
 #if !defined(__HIPCC__)
-struct double2 { double x, y; };   // host-only builds (tests/hostmath); hipcc provides the vector type
+struct double2 { double x, y; };   // host-only builds (tests/hostmath); hipcc provides the vector types
+struct int4 { int x, y, z, w; };
 #endif
 
 namespace mcba {
