@@ -856,7 +856,10 @@ __host__ __device__ inline int lsmr_cache_components(int motion, int loss) {
 #if defined(MCBA_EXP_F2_WAVES)       // what-if (variant builds only): force N waves per SIMD (the register allocator spills to fit)
 #define MCBA_F2_OCCUPANCY __attribute__((amdgpu_waves_per_eu(MCBA_EXP_F2_WAVES, MCBA_EXP_F2_WAVES)))
 #else
-#define MCBA_F2_OCCUPANCY
+// two waves per SIMD, pinned: the instantiations need 166 - 256 registers; without the attribute a small change of the source lets the
+// allocator drift above 256 (one wave per SIMD) silently.  Three waves cost the rolling-shutter instantiation 276 B of scratch per lane
+// (35 spilled doubles, measured 60 us instead of 24), the static ones 0 - 68 B with mixed results (profiles/r06_lsmr_experiments.txt).
+#define MCBA_F2_OCCUPANCY __attribute__((amdgpu_waves_per_eu(2, 2)))
 #endif
 template <int ND, int FISH, int MOTION, bool OPTK, bool ROBUST, int MODE>
 __global__ __launch_bounds__(64) MCBA_F2_OCCUPANCY void k_lsmr_fused2(Dims d, Tables t, const int32_t* __restrict__ first,
@@ -926,13 +929,15 @@ __global__ __launch_bounds__(64) MCBA_F2_OCCUPANCY void k_lsmr_fused2(Dims d, Ta
     constexpr int KIA = 4 + ND;
     double y[3];
     {
-      const double ys0 = wl[3] + (wl[1] * ps.Xs[2] - wl[2] * ps.Xs[1]);
-      const double ys1 = wl[4] + (wl[2] * ps.Xs[0] - wl[0] * ps.Xs[2]);
-      const double ys2 = wl[5] + (wl[0] * ps.Xs[1] - wl[1] * ps.Xs[0]);
+      const double w0 = wl[0], w1 = wl[1], w2 = wl[2];
+      const double ys0 = wl[3] + (w1 * ps.Xs[2] - w2 * ps.Xs[1]);
+      const double ys1 = wl[4] + (w2 * ps.Xs[0] - w0 * ps.Xs[2]);
+      const double ys2 = wl[5] + (w0 * ps.Xs[1] - w1 * ps.Xs[0]);
       if constexpr (ROLL) {
-        const double ye0 = wl[9] + (wl[7] * ps.Xe[2] - wl[8] * ps.Xe[1]);
-        const double ye1 = wl[10] + (wl[8] * ps.Xe[0] - wl[6] * ps.Xe[2]);
-        const double ye2 = wl[11] + (wl[6] * ps.Xe[1] - wl[7] * ps.Xe[0]);
+        const double w6 = wl[6], w7 = wl[7], w8 = wl[8];
+        const double ye0 = wl[9] + (w7 * ps.Xe[2] - w8 * ps.Xe[1]);
+        const double ye1 = wl[10] + (w8 * ps.Xe[0] - w6 * ps.Xe[2]);
+        const double ye2 = wl[11] + (w6 * ps.Xe[1] - w7 * ps.Xe[0]);
         const double ts = 1.0 - ps.tr;
         y[0] = ts * ys0 + ps.tr * ye0; y[1] = ts * ys1 + ps.tr * ye1; y[2] = ts * ys2 + ps.tr * ye2;
       } else {
@@ -941,13 +946,18 @@ __global__ __launch_bounds__(64) MCBA_F2_OCCUPANCY void k_lsmr_fused2(Dims d, Ta
     }
     double cv[2];   // c_a = rs_a uhat_a
     double2 o;
+    double dots[2] = {ps.A[0] * y[0] + ps.A[1] * y[1] + ps.A[2] * y[2], ps.A[3] * y[0] + ps.A[4] * y[1] + ps.A[5] * y[2]};
+    if constexpr (OPTK) {
+#pragma unroll
+      for (int k = 0; k < KI; ++k) {   // (row by row the same additions in the same order as before)
+        const double wk = wl[DE + k];
+        dots[0] += ps.Kc[k] * wk;
+        dots[1] += ps.Kc[KIA + k] * wk;
+      }
+    }
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
-      double dot = ps.A[3 * a] * y[0] + ps.A[3 * a + 1] * y[1] + ps.A[3 * a + 2] * y[2];
-      if constexpr (OPTK) {
-#pragma unroll
-        for (int k = 0; k < KI; ++k) dot += ps.Kc[a * KIA + k] * wl[DE + k];
-      }
+      const double dot = dots[a];
       double val = ps.rs[a] * dot;
       val += bterm[a];
       val -= alpha * (a == 0 ? old.x : old.y);

@@ -314,6 +314,29 @@ def test_outlier_loop_matches_reference(name):
   assert abs(calibration.error_stats(tight.reprojection_error).rms - float(g["ao_tight_rms"])) < 1e-6
 
 
+@pytest.mark.parametrize("name", ["tiny", "tiny_rolling", "tiny_handeye", "tiny_fisheye", "tiny_edge", "cfg1"])
+def test_outlier_loop_matches_reference_under_the_default_solver(name):
+  """The same loop (Calibration.adjust_outliers, calibration.py:254-268) under the PRODUCT DEFAULT, solver = "lsmr" -- scipy's TRF + LSMR steps
+  restated on the device: the reference's inlier mask after three rounds (up to what the reference's own perturbed re-runs flip) and the
+  reference's OWN default-tolerance end point (not the converged optimum the exact-step solver is held to above) within max(1e-6 px, 3 x the
+  reference's spread)."""
+  g, rig = load_golden(name)
+  c = mirror(rig)
+  prev = calibration.set_solver("lsmr")
+  try:
+    ao = c.adjust_outliers(num_adjustments=3, select_outliers=calibration.select_threshold(0.75, 5.0), loss='linear', tolerance=1e-4)
+  finally:
+    calibration.set_solver(prev)
+  allowed = int(g["ao_pert_mask_diff"].max()) if "ao_pert_mask_diff" in g else 0
+  diff = int((ao.inliers != g["ao_inliers"]).sum())
+  assert diff <= allowed, (diff, allowed)
+  spread = float(np.abs(g["ao_pert_rms_inliers"] - g["ao_rms_inliers"]).max())
+  rms_inl = calibration.error_stats(ao.reprojection_inliers).rms
+  assert abs(rms_inl - float(g["ao_rms_inliers"])) <= max(1e-6, 3 * spread), (rms_inl - float(g["ao_rms_inliers"]), spread)
+  if spread < 3e-7:
+    assert diff == 0
+
+
 def test_workspace_calibrate_entry_point():
   from multical_amd import Workspace
   g, rig = load_golden("cfg1")
