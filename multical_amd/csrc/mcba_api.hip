@@ -2219,7 +2219,11 @@ struct LsmrOps {
   // ... and in TWO launches: k_lsmr_fused2 carries the rotation + vector update of the previous step in its head, k_lsmr_gather3
   // folds its partials in a fifth wavefront beside the sums.  v is kept un-normalised (v = v_raw / alpha, alpha in the state).
   // State: k_lsmr_fused2 reads s0 (written by the gather / the initialisation) and writes s1; the gather reads s1 and writes s0.
-  int gather3_grid() const { return (gather_grid() + 3) / 4 + 1; }   // (+ the publisher workgroup, which has no tasks)
+  // k_lsmr_gather3: one workgroup per entry outside the frame block, one per four frames, + the publisher workgroup (no tasks)
+  int gather3_grid() const {
+    const int nfe = lsmr_gather_frame_entries(h->d);
+    return (h->d.n - nfe) + ((nfe > 0 ? h->d.Fl : 0) + 3) / 4 + 1;
+  }
   // per-view partials of the two-launch iteration in the TRANSPOSED layout (lsmr_part_index); views without inliers stay zero
   void ensure_part2(bool clear) {
     const size_t need = (size_t)std::max(h->d.views(), 1) * (size_t)(6 * h->d.NPB + h->d.KI);

@@ -2516,6 +2516,7 @@ __global__ __launch_bounds__(LSG_THREADS) void k_lsmr_gather2(Dims d, const doub
 }
 
 // Two-launch iteration (k_lsmr_fused2 -> k_lsmr_gather3): the gather of k_lsmr_gather2 with
+//   * one workgroup per entry outside the frame block, its run split over the four task wavefronts (round 6; frames: four per workgroup);
 //   * a FIFTH wavefront per workgroup that folds the |uhat|^2 partials into beta WHILE the four task wavefronts form their sums
 //     over the per-view partials -- the sums do not depend on beta; one barrier, then the finish
 //     v_raw[i] = D_i (sum / beta) - beta (v_old[i] / alpha)   (v is kept un-normalised: 1 / alpha comes from the state);
@@ -2533,16 +2534,19 @@ __global__ __launch_bounds__(LSG3_THREADS) void k_lsmr_gather3(Dims d, const dou
                                                                const double* __restrict__ xpart, int nx, unsigned long long call,
                                                                unsigned long long* host_word, LsmrGatherExtra ex) {
   __shared__ double head[5];
-  __shared__ double wsq[4];
+  __shared__ double wsq[4], qs[4];
   if (lsIn[LS_ISTOP] != 0.0) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nfe = lsmr_gather_frame_entries(d), ngen = d.n - nfe;
   const int CB = d.C * d.B;
   (void)part_stride;   // (transposed layout: lsmr_part_index)
-  // tasks are dealt round-robin over the workgroups (task = wave * (workgroups - 1) + workgroup): the heavy ones -- the entries
-  // outside the frame block come first and sum over hundreds to thousands of views -- land in different workgroups / CUs
+  // Workgroups [0, ngen): ONE entry outside the frame block each -- its run of hundreds to tens of thousands of per-view partials is
+  // split over the four task wavefronts (quarters, combined through LDS: a board-pose entry of 16 x 1000 x 5 sums 16 000 of them);
+  // workgroups behind them: four frames each, one per wavefront; the last workgroup: the publisher (no tasks).
+  // (Round 5 gave every wavefront a whole entry, dealt round-robin: the launch then waited for the wavefront with the longest run.)
   const bool publisher = blockIdx.x == gridDim.x - 1;   // one extra workgroup without tasks: stopping tests + state (off the others' path)
-  const int task = publisher ? 0x3fffffff : wave * ((int)gridDim.x - 1) + (int)blockIdx.x;
+  const bool gen_wg = !publisher && (int)blockIdx.x < ngen;
+  const int task = publisher ? 0x3fffffff : (gen_wg ? (int)blockIdx.x : ngen + ((int)blockIdx.x - ngen) * 4 + wave);
   // ---- phase 1: sums (task wavefronts) || head (fifth wavefront) ------------------------------------------------------------
   double sum = 0.0, fsum[3] = {0.0, 0.0, 0.0};
   int kind = 0, gi = -1;   // kind 1: general entry gi (lane 0 finishes it); kind 2: frame task (lanes with l16 == 0, entries g, g + 4, g + 8)
@@ -2613,7 +2617,7 @@ __global__ __launch_bounds__(LSG3_THREADS) void k_lsmr_gather3(Dims d, const dou
         int b = 0;
         while (q >= ex.board_off[b + 1]) ++b;
         const int p = q - ex.board_off[b], total = d.Fl * d.C;
-        for (int e = lane; e < total; e += 64) {
+        for (int e = wave * 64 + lane; e < total; e += 256) {
           const int idx = ex.obs_index[((size_t)e * d.B + b) * d.P + p];
           if (idx >= 0) sum += ex.bpart[3 * (size_t)idx + k];
         }
@@ -2638,17 +2642,19 @@ __global__ __launch_bounds__(LSG3_THREADS) void k_lsmr_gather3(Dims d, const dou
         }
         if (run != nullptr) {
           constexpr int UNR = 8;
-          for (int e0 = lane; e0 < total; e0 += 64 * UNR) {
+          const int q0 = (int)(((long long)total * wave) / 4), q1 = (int)(((long long)total * (wave + 1)) / 4);   // this wavefront's quarter
+          for (int e0 = q0 + lane; e0 < q1; e0 += 64 * UNR) {
             double v[UNR];
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) v[u] = run[min(e0 + 64 * u, total - 1)];
+            for (int u = 0; u < UNR; ++u) v[u] = run[min(e0 + 64 * u, q1 - 1)];
 #pragma unroll
             for (int u = 0; u < UNR; ++u)
-              if (e0 + 64 * u < total) sum += v[u];
+              if (e0 + 64 * u < q1) sum += v[u];
           }
         }
       }
       sum = wave_sum(sum);
+      if (lane == 0) qs[wave] = sum;
     }
   }
   // (what the finish reads besides beta is requested in front of the barrier: one round trip less behind it)
@@ -2661,11 +2667,12 @@ __global__ __launch_bounds__(LSG3_THREADS) void k_lsmr_gather3(Dims d, const dou
       pvo[q] = vold[i];
       pds[q] = dscale[i];
     }
-  } else if (kind == 1) {
+  } else if (kind == 1 && wave == 0) {
     pvo[0] = vold[gi];
     pds[0] = dscale[gi];
   }
   __syncthreads();
+  if (kind == 1) sum = (qs[0] + qs[1]) + (qs[2] + qs[3]);   // (the four quarters of the entry's run, fixed order)
   // ---- phase 2: finish with beta ------------------------------------------------------------------------------------------------
   const double beta = head[0], inv_beta = head[1], inv_alpha = head[4];
   const bool skip = head[2] != 0.0;
@@ -2677,7 +2684,7 @@ __global__ __launch_bounds__(LSG3_THREADS) void k_lsmr_gather3(Dims d, const dou
         const int e = g16 + 4 * q;
         if (e < DFm && l16 == 0) vout[d.off_motion + (e / 6) * 6 * d.F + 6 * (d.f0 + fl) + e % 6] = fsum[q];
       }
-    } else if (kind == 1 && lane == 0) {
+    } else if (kind == 1 && wave == 0 && lane == 0) {
       vout[gi] = sum;
     }
     return;     // (no barrier behind this point)
@@ -2695,7 +2702,7 @@ __global__ __launch_bounds__(LSG3_THREADS) void k_lsmr_gather3(Dims d, const dou
         vsq += val * val;
       }
     }
-  } else if (kind == 1 && lane == 0) {
+  } else if (kind == 1 && wave == 0 && lane == 0) {
     if (ex.raw_shared) {
       vout[gi] = sum;          // (frame-sharded: summed over the ranks, finished by k_lsmr_shard_finish)
     } else {
