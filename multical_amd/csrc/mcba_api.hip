@@ -321,8 +321,8 @@ struct mcba_handle_s {
   bool compact_dirty = true;
   DevBuf<double> ls_cache;                // lsmr_fused == 3: the per-observation state A, X_start, X_end, t (+ robust scales) of the current linearisation
   // LSMR iteration: -1 (default) = automatic: 3 for static / hand-eye rigs, 2 for rolling shutter (measured, profiles/r06_lsmr_iteration.txt:
-  // streaming the 9-double state back beats re-deriving it by 9 - 10 % per product launch, the 13 doubles of a rolling-shutter observation lose
-  // 15 %: 136 B per observation and iteration run into the memory system at 3.5 TB/s); 3 = two launches with the per-observation state cached,
+  // streaming the 9-double state back beats re-deriving it from the compacted tables by 2 - 6 % per product launch, the 13 doubles of a
+  // rolling-shutter observation lose 17 %: 136 B per observation and iteration at 3.5 TB/s); 3 = two launches with the per-observation state cached,
   // 2 = two launches (k_lsmr_fused2 / k_lsmr_gather3), 1 = three (k_lsmr_fused), 0 = the six-launch form of round 4 (A/B, tests)
   int lsmr_fused_setting = -1;
   bool lsmr_masks_form = false;           // debug (mcba_debug_set_lsmr_masks_form): k_lsmr_fused2 reads the frame-major tables on every rig (A/B, tests)
