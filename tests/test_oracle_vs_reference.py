@@ -149,3 +149,38 @@ def test_make_point_table_equals_the_reference(empty_dtype):
   assert got.valid.dtype == ref.valid.dtype == bool
   # the float32 table goes to the device as it is and is widened there exactly as numpy widens it (mcba_problem.points_f32)
   assert np.array_equal(got.points.astype(np.float64), np.asarray(ref.points, dtype=np.float64))
+
+
+def test_exact_product_end_points_regenerate_here():
+  """tests/golden/exact_products.json, regenerated on the spot for 6 x 40 x 5 (hand-eye, fisheye): scipy's own trf + lsmr on the REFERENCE's
+  residual function, once with scipy.sparse's double products and once with the products accumulated in 80-bit precision
+  (oracle/make_exact_products.py).  The committed values come back (1e-9 px), and the 80-bit run ends below the double run by more than
+  the double runs scatter -- the footprint of the reference's own product rounding (profiles/r06_lsmr_sign.md)."""
+  import json
+  import os
+  import sys
+  here = os.path.dirname(os.path.abspath(__file__))
+  sys.path.insert(0, here)
+  from multical_amd import synthetic, calibration as mirror_calibration
+  from hostmath_lib import HostMath
+  from lsmr_emulation import trf_lsmr
+  from oracle import build_reference
+  from oracle.make_golden import _evaluate
+  from oracle.make_exact_products import longdouble_solver
+  xp = json.load(open(os.path.join(here, "golden", "exact_products.json")))["cfg5_40"]
+  g = dict(np.load(os.path.join(here, "golden", "cfg5_40.npz"), allow_pickle=False))
+  rig = synthetic.make_rig(str(g["config"]))
+  calib, ref = build_reference.reference_calibration(rig)
+  error_stats = ref.optimization_calibration.error_stats
+  hm = HostMath(mirror_calibration.from_rig(rig))
+  fun = lambda x: _evaluate(calib, x)
+  out = {}
+  for kind, solver in (("double", "scipy"), ("longdouble", longdouble_solver)):
+    res = trf_lsmr(fun, hm.jacobian, g["x0"], solver=solver)
+    out[kind] = float(error_stats(calib.with_param_vec(res["x"]).reprojection_error).rms)
+    want = [r for r in xp["runs"] if r["arithmetic"] == kind and r["row_order_seed"] == 0][0]
+    assert res["nfev"] == want["nfev"] == int(g["ba_nfev"])
+    assert abs(out[kind] - want["rms"]) <= 1e-9, (kind, out[kind] - want["rms"])
+  dbl = [r["rms"] for r in xp["runs"] if r["arithmetic"] == "double"]
+  assert out["longdouble"] < min(dbl) - 3 * (max(dbl) - min(dbl)), (out, dbl)
+  assert abs(out["double"] - float(g["ba_rms"])) <= 1e-6          # scipy's arithmetic on the analytic Jacobian = the reference's end point
