@@ -379,7 +379,8 @@ def test_device_lsmr_call_matches_scipy(name, record_property):
         f"objective rel diff {abs(obj_dev - obj_ref) / obj_ref:.1e}, |x_dev - x_scipy| / |x| {np.linalg.norm(gn - ref[0]) / np.linalg.norm(ref[0]):.1e}")
   assert info["istop"] == int(ref[1]), (info, ref[1:3])
   assert abs(info["itn"] - int(ref[2])) <= max(3, 0.02 * int(ref[2])), (info["itn"], int(ref[2]))
-  assert t2_dev <= 2.0 * t2_ref + 1e-12 and t2_ref <= 2.0 * t2_dev + 1e-12, (t2_dev, t2_ref)
+  # (atol = 1e-6: below a tenth of it both solutions are converged to rounding and the ratio means nothing -- tiny_handeye: 4e-9 / 8e-9)
+  assert t2_dev <= 2.0 * t2_ref + 1e-7 and t2_ref <= 2.0 * t2_dev + 1e-7, (t2_dev, t2_ref)
   # (two approximate minimisers stopped by the same rule: their objectives differ by what atol = 1e-6 leaves open -- 1e-8 ... 1e-6
   #  relative on these fixtures, more where the call runs into maxiter, istop 7)
   assert abs(obj_dev - obj_ref) <= (1e-5 if info["istop"] in (1, 2) else 1e-3) * obj_ref
