@@ -1020,12 +1020,23 @@ __global__ __launch_bounds__(64) MCBA_F2_OCCUPANCY void k_lsmr_fused2(Dims d, Ta
     // compact form: the first chunk of the view is requested with the staging loads (same round trip)
     double2 ob_cur = make_double2(0.0, 0.0), xy_cur = make_double2(0.0, 0.0), old_cur = make_double2(0.0, 0.0);
     double z_cur = 0.0;
+    double2 ob_nxt = make_double2(0.0, 0.0), xy_nxt = make_double2(0.0, 0.0), old_nxt = make_double2(0.0, 0.0);
+    double z_nxt = 0.0;
     if constexpr (MODE >= 3) {
       const size_t g0 = (size_t)desc_first + (size_t)(lane < desc_count ? lane : 0);
       ob_cur = cp.obs[g0];
       xy_cur = cp.bxy[g0];
       z_cur = cp.bz[g0];
       old_cur = reinterpret_cast<const double2*>(u)[g0];
+#if !defined(MCBA_EXP_F2_DEPTH1)
+      // ... and the SECOND: a chunk is evaluated in ~0.6 us, a load takes 1 - 2 us under this kernel's traffic -- with one chunk in flight a
+      // wavefront waited for memory three quarters of its time (one wave per SIMD: 73 % of the throughput of two); two chunks ahead
+      const size_t g1 = (size_t)desc_first + (size_t)(lane + 64 < desc_count ? lane + 64 : 0);
+      ob_nxt = cp.obs[g1];
+      xy_nxt = cp.bxy[g1];
+      z_nxt = cp.bz[g1];
+      old_nxt = reinterpret_cast<const double2*>(u)[g1];
+#endif
     }
     {
       const double* tg = t.tmat + (size_t)v * (DE * NPC);
@@ -1057,15 +1068,22 @@ __global__ __launch_bounds__(64) MCBA_F2_OCCUPANCY void k_lsmr_fused2(Dims d, Ta
     for (int k = 0; k < NS; ++k) sums[k] = 0.0;
     size_t out0 = DESC ? (size_t)desc_first : (size_t)first[v];
     if constexpr (MODE >= 3) {
-      // ---- compact form: observation, board point and old uhat stream in residual order; the NEXT chunk is requested before the
-      // current one is evaluated
+      // ---- compact form: observation, board point and old uhat stream in residual order, TWO chunks ahead of the one being evaluated
       const int count = desc_count;
       for (int base = 0; base < count; base += 64) {
+#if defined(MCBA_EXP_F2_DEPTH1)
         const int i = base + lane, inx = i + 64;
         const size_t gn = out0 + (size_t)(inx < count ? inx : 0);
-        const double2 ob_nxt = cp.obs[gn], xy_nxt = cp.bxy[gn];
-        const double z_nxt = cp.bz[gn];
-        const double2 old_nxt = reinterpret_cast<const double2*>(u)[gn];
+        ob_nxt = cp.obs[gn]; xy_nxt = cp.bxy[gn];
+        z_nxt = cp.bz[gn];
+        old_nxt = reinterpret_cast<const double2*>(u)[gn];
+#else
+        const int i = base + lane, in2 = i + 128;
+        const size_t g2 = out0 + (size_t)(in2 < count ? in2 : 0);
+        const double2 ob_n2 = cp.obs[g2], xy_n2 = cp.bxy[g2];
+        const double z_n2 = cp.bz[g2];
+        const double2 old_n2 = reinterpret_cast<const double2*>(u)[g2];
+#endif
         if (i < count) {
           const double X_cur[3] = {xy_cur.x, xy_cur.y, z_cur};
           PointState<ND, ROLL> ps;
@@ -1086,6 +1104,9 @@ __global__ __launch_bounds__(64) MCBA_F2_OCCUPANCY void k_lsmr_fused2(Dims d, Ta
           observe(ps, old_cur, v, b, 0, out0 + (size_t)i);
         }
         ob_cur = ob_nxt; xy_cur = xy_nxt; z_cur = z_nxt; old_cur = old_nxt;
+#if !defined(MCBA_EXP_F2_DEPTH1)
+        ob_nxt = ob_n2; xy_nxt = xy_n2; z_nxt = z_n2; old_nxt = old_n2;
+#endif
       }
     } else if constexpr (MODE == 2) {
       // ---- the state of every observation comes back from the cache: no masks, no compaction, no observation / board-point reads
