@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <algorithm>
+#include <array>
 #include <dlfcn.h>
 #include <chrono>
 #include <cmath>
@@ -3556,6 +3557,37 @@ int32_t mcba_time_lsmr_iteration(mcba_handle h, const double* x, int32_t repeats
   sync(h);
   HIP_OK(hipEventElapsedTime(&t, h->ev0, h->ev1));
   ms[1] = t / repeats;
+#if defined(MCBA_EXP_F2_PROF)   // profiling build: one more product with per-workgroup stamps, summary on stderr
+  {
+    const size_t nw = 8 * (size_t)op.nblk;
+    if (h->ls_cache.n < nw) h->ls_cache.alloc(nw, true);
+    product();
+    sync(h);
+    std::vector<long long> pf(nw);
+    HIP_OK(hipMemcpy(pf.data(), h->ls_cache.p, nw * sizeof(long long), hipMemcpyDeviceToHost));
+    long long tmin = pf[0], tmax = pf[1];
+    for (int i = 0; i < op.nblk; ++i) { tmin = std::min(tmin, pf[8 * i]); tmax = std::max(tmax, pf[8 * i + 1]); }
+    std::vector<double> dur, st, ch, ep, endt;
+    double views = 0, chunks = 0;
+    for (int i = 0; i < op.nblk; ++i) {
+      dur.push_back((double)(pf[8 * i + 1] - pf[8 * i])); st.push_back((double)pf[8 * i + 2]); ch.push_back((double)pf[8 * i + 3]);
+      ep.push_back((double)pf[8 * i + 4]); endt.push_back((double)(pf[8 * i + 1] - tmin)); views += pf[8 * i + 5]; chunks += pf[8 * i + 6];
+    }
+    auto stat = [](std::vector<double> v) { std::sort(v.begin(), v.end()); double s = 0; for (double x : v) s += x;
+                                            return std::array<double, 4>{s / v.size(), v[v.size() / 2], v[v.size() * 9 / 10], v.back()}; };
+    auto pr = [&](const char* name, const std::vector<double>& v) { auto q = stat(v); fprintf(stderr, "  %-28s mean %9.0f  median %9.0f  p90 %9.0f  max %9.0f\n", name, q[0], q[1], q[2], q[3]); };
+    fprintf(stderr, "[f2 profile] %d workgroups, %.0f views, %.0f chunks; kernel span %lld clocks (clock64 units)\n", op.nblk, views, chunks, tmax - tmin);
+    pr("workgroup duration", dur); pr("workgroup end (from first start)", endt); pr("  staging + That v per wg", st); pr("  chunk loop per wg", ch); pr("  reduce + That^T + stores per wg", ep);
+    std::vector<double> startt; for (int i = 0; i < op.nblk; ++i) startt.push_back((double)(pf[8 * i] - tmin));
+    pr("workgroup start (from first)", startt);
+    // per-SIMD load: group by HW_ID (cu / simd bits) -- sum of durations per (xcc-less) hardware id
+    std::map<unsigned, double> simd;
+    for (int i = 0; i < op.nblk; ++i) simd[(unsigned)pf[8 * i + 7] & 0xfffffff0u] += dur[i];
+    std::vector<double> sv; for (auto& kv : simd) sv.push_back(kv.second);
+    fprintf(stderr, "  distinct hardware slots (HW_ID without the wave bits): %zu\n", sv.size());
+    pr("sum of wg durations per slot", sv);
+  }
+#endif
   h->h_pub_seq[1] = 0;   // (the timed gathers published progress words of call 0: forget them)
   API_END
 }

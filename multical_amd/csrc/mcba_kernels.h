@@ -999,6 +999,13 @@ __global__ __launch_bounds__(64) MCBA_F2_OCCUPANCY void k_lsmr_fused2(Dims d, Ta
   if constexpr (DESC) {
     if ((int)blockIdx.x < n_active) dnext = cp.desc[blockIdx.x];
   }
+#if defined(MCBA_EXP_F2_PROF)   // profiling build: per-workgroup stamps (shader clock) written to `cache` as long long [grid][8]
+  const long long pf_t0 = clock64();
+  long long pf_stage = 0, pf_chunks = 0, pf_epi = 0, pf_views = 0, pf_nch = 0;
+#define PF_STAMP(var) const long long var = clock64()
+#else
+#define PF_STAMP(var)
+#endif
   for (int vi = blockIdx.x; vi < n_active; vi += gridDim.x) {
     int v, desc_first = 0, desc_count = 0;
     if constexpr (DESC) {
@@ -1008,6 +1015,7 @@ __global__ __launch_bounds__(64) MCBA_F2_OCCUPANCY void k_lsmr_fused2(Dims d, Ta
       v = t.active_views[1 + vi];
     }
     if (v < 0) continue;
+    PF_STAMP(pf_a);
     const int b = v % d.B, c = (v / d.B) % d.C, f = d.f0 + v / (d.B * d.C);
     constexpr int NPB64 = LIN_MAX_POINTS / 64;
     // the mask bytes of the first segment are requested in front of the parameter staging: one round trip for both
@@ -1028,9 +1036,7 @@ __global__ __launch_bounds__(64) MCBA_F2_OCCUPANCY void k_lsmr_fused2(Dims d, Ta
       xy_cur = cp.bxy[g0];
       z_cur = cp.bz[g0];
       old_cur = reinterpret_cast<const double2*>(u)[g0];
-#if !defined(MCBA_EXP_F2_DEPTH1)
-      // ... and the SECOND: a chunk is evaluated in ~0.6 us, a load takes 1 - 2 us under this kernel's traffic -- with one chunk in flight a
-      // wavefront waited for memory three quarters of its time (one wave per SIMD: 73 % of the throughput of two); two chunks ahead
+#if defined(MCBA_EXP_F2_DEPTH2)   // experiment (variant builds): TWO chunks in flight -- measured 26.4 against 25.3 us at the north-star rig: not adopted
       const size_t g1 = (size_t)desc_first + (size_t)(lane + 64 < desc_count ? lane + 64 : 0);
       ob_nxt = cp.obs[g1];
       xy_nxt = cp.bxy[g1];
@@ -1066,12 +1072,14 @@ __global__ __launch_bounds__(64) MCBA_F2_OCCUPANCY void k_lsmr_fused2(Dims d, Ta
     lds_fence();
 #pragma unroll
     for (int k = 0; k < NS; ++k) sums[k] = 0.0;
+    PF_STAMP(pf_b);
     size_t out0 = DESC ? (size_t)desc_first : (size_t)first[v];
     if constexpr (MODE >= 3) {
-      // ---- compact form: observation, board point and old uhat stream in residual order, TWO chunks ahead of the one being evaluated
+      // ---- compact form: observation, board point and old uhat stream in residual order; the NEXT chunk is requested before the
+      // current one is evaluated
       const int count = desc_count;
       for (int base = 0; base < count; base += 64) {
-#if defined(MCBA_EXP_F2_DEPTH1)
+#if !defined(MCBA_EXP_F2_DEPTH2)
         const int i = base + lane, inx = i + 64;
         const size_t gn = out0 + (size_t)(inx < count ? inx : 0);
         ob_nxt = cp.obs[gn]; xy_nxt = cp.bxy[gn];
@@ -1104,7 +1112,7 @@ __global__ __launch_bounds__(64) MCBA_F2_OCCUPANCY void k_lsmr_fused2(Dims d, Ta
           observe(ps, old_cur, v, b, 0, out0 + (size_t)i);
         }
         ob_cur = ob_nxt; xy_cur = xy_nxt; z_cur = z_nxt; old_cur = old_nxt;
-#if !defined(MCBA_EXP_F2_DEPTH1)
+#if defined(MCBA_EXP_F2_DEPTH2)
         ob_nxt = ob_n2; xy_nxt = xy_n2; z_nxt = z_n2; old_nxt = old_n2;
 #endif
       }
@@ -1199,6 +1207,7 @@ __global__ __launch_bounds__(64) MCBA_F2_OCCUPANCY void k_lsmr_fused2(Dims d, Ta
       lds_fence();
     }
     }
+    PF_STAMP(pf_c);
 #if defined(MCBA_EXP_F2_NO_REDUCE)  // what-if (variant builds only): no butterfly over the wave, no That^T product, one store per view
     if (lane == 0) part[lsmr_part_index(d, v, 0)] = sums[0] + sums[NS - 1];
     continue;
@@ -1216,7 +1225,19 @@ __global__ __launch_bounds__(64) MCBA_F2_OCCUPANCY void k_lsmr_fused2(Dims d, Ta
       part[lsmr_part_index(d, v, lane)] = sl[DE + lane - NPC];
     }
     lds_fence();
+#if defined(MCBA_EXP_F2_PROF)
+    { const long long pf_d = clock64(); pf_stage += pf_b - pf_a; pf_chunks += pf_c - pf_b; pf_epi += pf_d - pf_c; ++pf_views; pf_nch += (desc_count + 63) / 64; }
+#endif
   }
+#if defined(MCBA_EXP_F2_PROF)
+  if (lane == 0 && cache != nullptr) {
+    long long* pf = reinterpret_cast<long long*>(cache) + 8 * (size_t)blockIdx.x;
+    pf[0] = pf_t0; pf[1] = clock64(); pf[2] = pf_stage; pf[3] = pf_chunks; pf[4] = pf_epi; pf[5] = pf_views; pf[6] = pf_nch;
+    unsigned hw;   // XCC / SE / CU / SIMD / wave slot of this wavefront
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    pf[7] = hw;
+  }
+#endif
   const double tot = wave_sum(acc);
   if (lane == 0) partial[blockIdx.x] = tot;
   // ---- tail (slice owners): rotation, vector update h_bar, x, h of slice j = entries j 64 + lane (+ multiples of 64 gridDim), the
@@ -1249,6 +1270,8 @@ __global__ __launch_bounds__(64) MCBA_F2_OCCUPANCY void k_lsmr_fused2(Dims d, Ta
     }
   }
 }
+
+#undef PF_STAMP
 
 // ---------------------------------------------------------------------------------------------------------------
 // k_jacobian: analytic Jacobian rows in the column order of Calibration.sparsity_matrix
