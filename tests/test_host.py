@@ -26,6 +26,19 @@ def test_library_exports_every_declared_symbol():
   assert declared <= bound, f"ctypes table lacks {declared - bound}"
 
 
+def test_library_exports_every_debug_symbol():
+  """csrc/mcba_debug.h (test / profiling entry points, not part of the drop-in boundary): every declared function is exported and
+  bound with a ctypes signature, so that a parity hook cannot silently go missing from the library the GPU tests load."""
+  header = open(os.path.join(ROOT, "multical_amd", "csrc", "mcba_debug.h")).read()
+  declared = set(re.findall(r"\bint32_t\s+(mcba_[a-z_0-9]+)\s*\(", header))
+  assert len(declared) >= 20
+  lib = _lib.load()
+  bound = {name for name, _, _ in _lib.SYMBOLS}
+  missing = [s for s in declared if not hasattr(lib, s)]
+  assert not missing, f"libmcba.so lacks {missing}"
+  assert declared <= bound, f"ctypes table lacks {declared - bound}"
+
+
 def test_create_fails_loudly_without_gpu():
   from util import gpu_available
   if gpu_available():
