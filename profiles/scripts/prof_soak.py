@@ -19,7 +19,8 @@ for name, n in (("tiny_rolling", n_small), ("tiny_handeye", n_small // 3), ("cfg
                 assert key == ref, (name, rep, i, r.nfev, r.status, r.cost)
     print("%-14s %4d solves identical (nfev %d, status %d, cost %.9e) in %.2f s" % (name, 3 * max(n // 3, 1), ref[0], ref[1], ref[2], time.perf_counter() - t0), flush=True)
 # solver = "lsmr": the device-resident LSMR iteration (iterations enqueued ahead of a progress word) must repeat bit for bit too
-for name, n in (("tiny_rolling", max(n_small // 10, 3)), ("cfg2", max(n_big // 6, 3))):
+for name, n in (("tiny_rolling", max(n_small // 10, 3)), ("cfg2", max(n_big // 6, 3)), ("cfg3", max(n_big // 6, 3)), ("cfg5", max(n_big // 6, 3))):
+    # (round 6: cfg3 = compacted observation tables, rolling shutter; cfg5 / cfg2 = the cached per-observation state, hand-eye / static)
     rig = synthetic.make_rig(name); c = calibration.from_rig(rig); x0 = c.param_vec
     t0 = time.perf_counter()
     ref = None
