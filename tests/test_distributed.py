@@ -248,7 +248,9 @@ def _gpu_lsmr_worker(rank, world, port, name, out, empty_last=False, boards=Fals
   h = mdist.sharded_handle(c, shards=[(0, F)] + [(F, F)] * (world - 1) if empty_last else None)
   h.set_allreduce_trace(1 << 20)
   h.allreduce_stats(reset=True)
-  res = h.solve(x0, tr_solver="lsmr")
+  import json
+  kw = json.loads(str(g["ba_kwargs_json"])) if "ba_kwargs_json" in g else {}
+  res = h.solve(x0, tr_solver="lsmr", loss=kw.get("loss", "linear"), f_scale=kw.get("f_scale", 1.0))
   ar_calls, ar_doubles, ar_sizes = h.allreduce_stats(reset=True, cap=1 << 20)
   lsmr_itn = h.lsmr_iterations()
   e, v = h.reprojection_error(res.x)
@@ -265,7 +267,8 @@ def _gpu_lsmr_worker(rank, world, port, name, out, empty_last=False, boards=Fals
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,empty_last,world", [("cfg1", False, 2), ("tiny_rolling", False, 2), ("tiny_handeye", False, 2),
-                                                   ("tiny_boards", False, 2), ("cfg1", True, 2), ("cfg1", False, 4), ("tiny_rolling", True, 4)])
+                                                   ("tiny_boards", False, 2), ("cfg1", True, 2), ("cfg1", False, 4), ("tiny_rolling", True, 4),
+                                                   ("tiny_softl1", False, 2), ("tiny_fisheye", False, 3)])
 def test_sharded_lsmr_solve_ranks_on_one_gpu(name, empty_last, world, tmp_path):
   """solver = "lsmr" on a frame-sharded problem: J v is local, J^T u is a sum over views.  Since round 6 an LSMR iteration
   carries ONE collective of ns + 5 doubles -- [shared sums of J^T uhat | |uhat|^2 | |x|^2 | a | b | c] (k_lsmr_shard_pack2 /
@@ -280,8 +283,10 @@ def test_sharded_lsmr_solve_ranks_on_one_gpu(name, empty_last, world, tmp_path):
   sh = np.load(out)
   g, rig = load_golden(name)
   c = mirror(rig)
+  import json
+  kw = json.loads(str(g["ba_kwargs_json"])) if "ba_kwargs_json" in g else {}
   with Handle(c) as h:
-    res = h.solve(c.param_vec, tr_solver="lsmr")
+    res = h.solve(c.param_vec, tr_solver="lsmr", loss=kw.get("loss", "linear"), f_scale=kw.get("f_scale", 1.0))
     itn = h.lsmr_iterations()
     calls = len(h.lsmr_trace())
     e, v = h.reprojection_error(res.x)
@@ -294,7 +299,8 @@ def test_sharded_lsmr_solve_ranks_on_one_gpu(name, empty_last, world, tmp_path):
     assert abs(float(sh["rms"]) - rms) <= 1e-6
     assert float(sh["final_cost"]) == pytest.approx(res.cost, rel=1e-6)
   else:                                         # (the shards sum in another order: the end point moves inside the reference's spread)
-    assert abs(int(sh["nfev"]) - res.nfev) <= 2
+    # (flat-valley fixtures: the reference's own perturbed re-runs take different numbers of evaluations -- tiny_fisheye 13 ... 20)
+    assert abs(int(sh["nfev"]) - res.nfev) <= max(2, int(np.abs(g["ba_pert_nfev"] - g["ba_nfev"]).max()))
     assert abs(float(sh["rms"]) - rms) <= max(1e-6, 3 * spread)
   # ---- collectives, in issue order --------------------------------------------------------------------------------
   sizes = [int(v) for v in sh["ar_sizes"]]
