@@ -358,8 +358,6 @@ struct mcba_handle_s {
 
   // linearisation
   DevBuf<double> rec, partial, Hss, Hfs, Hff, gbuf;   // gbuf = [g (n) | diag (n) | cost, count]
-  DevBuf<unsigned long long> asm_done;   // k_assemble_fin: completion counter of the chunk sums per (camera, board) pair (only ever grows)
-  unsigned long long asm_epoch = 0;      // ... and the number of k_assemble_fin launches so far
   int nchunk = 1;
   // solver state
   DevBuf<double> x, xnew, scale_inv, dsc, gh, gn, scal, costpart, Lf, W, yf, P, sbuf, ps;
@@ -678,27 +676,10 @@ void launch_assemble(mcba_handle_s* h, unsigned long long publish_seq = 0, int c
   const size_t lds = nfb ? (size_t)gviews * ne * sizeof(double) + fixed : 0;
   raise_dynamic_lds((const void*)k_assemble, h->device, lds);
   const int npair = d.C * d.B;
-  // MCBA_SHARED_FINAL_BIG=1 forces the many-pairs kernel (tests).  MCBA_MERGED_SHARED_FINAL=1: k_assemble_fin, both stages in one launch
-  // with in-kernel completion counters -- measured in round 6 and NOT adopted: evaluation step 66.0 -> 78.0 us, trial step of the exact
-  // solver 134 -> 144 us at the north-star rig (the agent-scope release behind every chunk-sum block writes back its XCD's L2, and the
-  // waiting blocks hold CUs); bit-identical results (tests/test_gpu_parity.py)
+  // MCBA_SHARED_FINAL_BIG=1 forces the many-pairs kernel (tests).  (Both stages in ONE launch with in-kernel completion counters were
+  // measured in round 6 and dropped: evaluation step + 12 us, trial step of the exact solver + 10 us at the north-star rig --
+  // profiles/r06_lsmr_experiments.txt item 9; the code lived in commit 3964829.)
   static const bool force_big = dbg_switch("MCBA_SHARED_FINAL_BIG") != nullptr && dbg_switch("MCBA_SHARED_FINAL_BIG")[0] == '1';
-  static const bool want_merged = dbg_switch("MCBA_MERGED_SHARED_FINAL") != nullptr && dbg_switch("MCBA_MERGED_SHARED_FINAL")[0] == '1';
-  const bool merged = want_merged && npair <= SHARED_FINAL_MAX_PAIRS && npair <= ASM_THREADS && !force_big;
-  if (merged) {
-    // ONE launch: frame blocks | chunk sums of the shared part | the final stage of the shared part waiting on the chunk sums' counters
-    if (h->asm_done.n < (size_t)npair + 1) h->asm_done.alloc((size_t)npair + 1, true);
-    const size_t lds_fin = (size_t)npair * 64 * sizeof(double);
-    const size_t lds2 = std::max(lds, lds_fin);
-    raise_dynamic_lds((const void*)k_assemble_fin, h->device, lds2);
-    const int nfin = (d.rec_size + 2 + 63) / 64;
-    ++h->asm_epoch;
-    hipLaunchKernelGGL(k_assemble_fin, dim3(nfb + npair * h->nchunk + nfin), dim3(ASM_THREADS), lds2, h->stream, d, h->t, h->rec.p, nfb, h->nchunk,
-                       gviews, h->ftab.p, h->nftab, h->Hff.p, h->Hfs.p, h->g(), h->diag(), h->partial.p, h->tri.p, h->Hss.p, h->costcount(),
-                       publish_seq ? h->h_scal + cost_slot : nullptr, h->h_pub_seq, publish_seq, h->asm_done.p,
-                       h->asm_epoch * (unsigned long long)h->nchunk);
-    check_launch("k_assemble_fin");
-  } else {
   // (timed apart at cfg3: frame blocks alone 10.0 us, chunk sums alone 6.9 us, together 12.4 us)
   hipLaunchKernelGGL(k_assemble, dim3(nfb + d.C * d.B * h->nchunk), dim3(ASM_THREADS), lds, h->stream, d, h->t, h->rec.p, nfb, h->nchunk, gviews,
                      h->ftab.p, h->nftab, h->Hff.p, h->Hfs.p, h->g(), h->diag(), h->partial.p);
@@ -714,7 +695,6 @@ void launch_assemble(mcba_handle_s* h, unsigned long long publish_seq = 0, int c
                          h->partial.p, h->nchunk, h->tri.p, h->Hss.p, h->g(), h->diag(), h->costcount(),
                          publish_seq ? h->h_scal + cost_slot : nullptr, h->h_pub_seq, publish_seq);
     check_launch("k_shared_final");
-  }
   }
   if (d.off_boards >= 0) {   // adjusted board points: their blocks of H_ss / H_fs / g (unique entries, plain stores)
     h->ops->points(d, h->t, h->stream, (d.n - d.off_boards) / 3, h->Hss.p, h->Hfs.p, h->g());

@@ -453,15 +453,18 @@ __device__ __forceinline__ void publish_cost(double val, double* host_cost, unsi
   __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 constexpr int SHARED_FINAL_MAX_PAIRS = 128;   // pair sums of k_shared_final: [pairs][64] doubles of LDS
-// block `fb` of the final stage (64 packed entries x all pairs), pair_sum = [C B][64] doubles of LDS
-__device__ __forceinline__ void shared_final_block(const Dims& d, const double* __restrict__ partial, int nchunk,
-                                                   const uint16_t* __restrict__ tri, double* __restrict__ Hss,
-                                                   double* __restrict__ g, double* __restrict__ diag,
-                                                   double* __restrict__ cost_count, double* host_cost,
-                                                   unsigned long long* host_seq, unsigned long long seq, int fb, double* pair_sum) {
+// (written as ONE kernel body on purpose: the same body as a __forceinline__ device function shared with a second kernel -- round 6's merged
+//  k_assemble + final-stage launch, measured and dropped, profiles/r06_lsmr_experiments.txt item 9 -- compiled to 46 instead of 98 VGPRs: the 16
+//  chunk-sum loads per pair were no longer kept in flight together and the launch took 8.6 instead of 6.2 us)
+__global__ __launch_bounds__(1024) void k_shared_final(Dims d, const double* __restrict__ partial, int nchunk,
+                                                       const uint16_t* __restrict__ tri, double* __restrict__ Hss,
+                                                       double* __restrict__ g, double* __restrict__ diag,
+                                                       double* __restrict__ cost_count, double* host_cost = nullptr,
+                                                       unsigned long long* host_seq = nullptr, unsigned long long seq = 0) {
+  extern __shared__ double pair_sum[];   // [C B][64]
   const int ns = d.ns, NL = d.NL, npose = 6 * d.NPB, npair = d.C * d.B;
   const int el = threadIdx.x & 63, pg = threadIdx.x >> 6, PG = blockDim.x >> 6;
-  const int e = fb * 64 + el;
+  const int e = blockIdx.x * 64 + el;
   // (the rows of the eliminated frame parameters hold no chunk sums: shared_partial_block walks over them)
   const int skip0 = d.DF > 0 ? tri_index(6, 6, d.N1) : 0, nskip = d.DF > 0 ? d.DF * d.N1 - (6 * d.DF + d.DF * (d.DF - 1) / 2) : 0;
   const bool in = e < d.rec_size + 2 && !(e >= skip0 && e < skip0 + nskip);
@@ -525,58 +528,6 @@ __device__ __forceinline__ void shared_final_block(const Dims& d, const double* 
       if (si != sj) Hss[(size_t)sj * ns + si] = val;
       else diag[gi] = val;
     }
-  }
-}
-
-__global__ __launch_bounds__(1024) void k_shared_final(Dims d, const double* __restrict__ partial, int nchunk,
-                                                       const uint16_t* __restrict__ tri, double* __restrict__ Hss,
-                                                       double* __restrict__ g, double* __restrict__ diag,
-                                                       double* __restrict__ cost_count, double* host_cost = nullptr,
-                                                       unsigned long long* host_seq = nullptr, unsigned long long seq = 0) {
-  extern __shared__ double pair_sum[];   // [C B][64]
-  shared_final_block(d, partial, nchunk, tri, Hss, g, diag, cost_count, host_cost, host_seq, seq, blockIdx.x, pair_sum);
-}
-
-// Round 6 EXPERIMENT (mcba_debug_set_switch("MCBA_MERGED_SHARED_FINAL", "1"); measured and NOT adopted: the evaluation step went from 66.0
-// to 78.0 us at the north-star rig -- every chunk-sum block's agent-scope release writes back its XCD's L2, and the waiting blocks hold
-// CUs the frame blocks could use): k_assemble AND k_shared_final in ONE launch.  The final stage only needs the chunk sums of the shared part, which are done
-// after ~7 of the ~10 us the frame blocks take: its blocks sit at the END of the grid (dispatched last, so every block they wait for
-// has started) and wait on one completion counter per (camera, board) pair -- each of the pair's nchunk chunk-sum blocks adds 1 behind
-// an agent-scope release; counters only ever grow (target = launches so far x nchunk), nothing is reset.  The sums themselves stay
-// deterministic: the counters order the stages, every element is still added up in a fixed order by one thread.  Saves the launch of
-// k_shared_final and hides its work under the frame blocks.  (Same-address atomics serialise at ~75 ns: 32 per counter, 16 counters
-// in parallel.)  Bit-identical to the two launches (tests/test_gpu_parity.py).
-__global__ __launch_bounds__(ASM_THREADS) void k_assemble_fin(Dims d, Tables t, const double* __restrict__ rec, int nfb, int nchunk,
-                                                              int gviews, const int4* __restrict__ ftab, int nftab,
-                                                              double* __restrict__ Hff, double* __restrict__ Hfs,
-                                                              double* __restrict__ g, double* __restrict__ diag,
-                                                              double* __restrict__ partial, const uint16_t* __restrict__ tri,
-                                                              double* __restrict__ Hss, double* __restrict__ cost_count,
-                                                              double* host_cost, unsigned long long* host_seq, unsigned long long seq,
-                                                              unsigned long long* __restrict__ done, unsigned long long target) {
-  extern __shared__ double asm_stage[];
-  const int npair = d.C * d.B, nshared = npair * nchunk;
-  if ((int)blockIdx.x < nfb) {
-    assemble_frame_block(d, t, blockIdx.x, gviews, ftab, nftab, rec, Hff, Hfs, g, diag, asm_stage);
-  } else if ((int)blockIdx.x < nfb + nshared) {
-    const int q = blockIdx.x - nfb;
-    shared_partial_block(d, t, q / nchunk, q % nchunk, rec, nchunk, partial);
-    __syncthreads();                       // every thread's chunk sums are stored ...
-    if (threadIdx.x == 0) {
-      __threadfence();                     // ... and written back to where the other XCDs read them (agent-scope release)
-      atomicAdd(done + q / nchunk, 1ull);
-    }
-  } else {
-    // wait for the chunk sums of every pair (bounded: a lost increment must not hang the queue -- the parity tests would then fail)
-    if ((int)threadIdx.x < npair) {
-      unsigned long long spins = 0;
-      while (__hip_atomic_load(done + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < (1ull << 26))
-        __builtin_amdgcn_s_sleep(8);
-    }
-    __syncthreads();
-    __threadfence();                       // (acquire: no stale line of `partial` from an earlier launch)
-    shared_final_block(d, partial, nchunk, tri, Hss, g, diag, cost_count, host_cost, host_seq, seq,
-                       (int)blockIdx.x - nfb - nshared, asm_stage);
   }
 }
 

@@ -615,7 +615,7 @@ def test_handle_cache_sees_a_changed_validity_mask_and_float32_tables():
 
 
 @pytest.mark.parametrize("switch", ["MCBA_FUSED=0", "MCBA_ASM_STAGE_KB=4", "MCBA_FUSED=0,MCBA_TMAT_GLOBAL=1",
-                                    "MCBA_NCHUNK_TARGET=1024", "MCBA_SHARED_FINAL_BIG=1", "MCBA_MERGED_SHARED_FINAL=1", "MCBA_SYRK3=1", "MCBA_SPLIT_Q00=1", "MCBA_SPEC_ACCEPT=0", "MCBA_SPEC_ACCEPT=0,MCBA_NO_PUBLISH=1"])
+                                    "MCBA_NCHUNK_TARGET=1024", "MCBA_SHARED_FINAL_BIG=1", "MCBA_SYRK3=1", "MCBA_SPLIT_Q00=1", "MCBA_SPEC_ACCEPT=0", "MCBA_SPEC_ACCEPT=0,MCBA_NO_PUBLISH=1"])
 def test_alternative_linearisation_paths_match_the_default(switch):
   """Paths of the evaluation that the fixtures do not reach by themselves, each forced with its switch in a subprocess
   (mcba_debug_set_switch, once per process -- the product library reads no MCBA_* experiment switch from the environment); all must reproduce the normal equations of the default form to round-off,
@@ -626,9 +626,7 @@ def test_alternative_linearisation_paths_match_the_default(switch):
     MCBA_SHARED_FINAL_BIG=1   the final sum of the shared part for rigs with more than 128 (camera, board) pairs
     MCBA_ASM_STAGE_KB=4       frame blocks of k_assemble stage their records in several groups (rigs with many views per frame)
     MCBA_TMAT_GLOBAL=1        k_tmat reads the global pose table (rigs whose cameras + boards exceed the local table)
-    MCBA_NCHUNK_TARGET=1024   more chunk sums than the default split of the shared part
-    MCBA_MERGED_SHARED_FINAL=1 k_assemble_fin: k_assemble and k_shared_final in one launch, the final-stage blocks waiting inside the launch
-                              for the chunk sums of the shared part (completion counters); a round-6 experiment that lost on time"""
+    MCBA_NCHUNK_TARGET=1024   more chunk sums than the default split of the shared part"""
   import os, subprocess, sys, json
   code = r'''
 import sys, json, os, numpy as np
@@ -664,48 +662,6 @@ print("RESULT" + json.dumps(out))
     Ha, Hb = np.array(a["H"]), np.array(b["H"])
     assert np.abs(Ha - Hb).max() <= 1e-11 * np.abs(Ha).max(), name
     assert b["nfev"] == a["nfev"] and b["final"] == pytest.approx(a["final"], rel=1e-9), name
-
-
-def test_merged_assembly_repeats_bit_for_bit():
-  """k_assemble_fin (experiment, MCBA_MERGED_SHARED_FINAL=1) orders its stages INSIDE one launch (the final stage of the shared part
-  waits on completion counters of the chunk sums, agent-scope release / acquire): 200 evaluations of the same point with other points
-  in between must return the same bits every time, equal to the two-launch default -- a final block that read a chunk sum too early
-  (or a stale line of the previous launch) would show up as a different H_ss / g / cost."""
-  import os, subprocess, sys, json
-  code = r'''
-import sys, json, os, numpy as np
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
-from multical_amd import synthetic, calibration, _lib
-from multical_amd.backend import Handle
-if os.environ.get("TEST_MERGED") == "1":
-  _lib.set_switch("MCBA_MERGED_SHARED_FINAL", "1")
-out = {}
-for cfg, frames in (("cfg3", 40), ("cfg4", 40), ("cfg3", 500), ("cfg5", 60)):
-  c = calibration.from_rig(synthetic.make_rig(cfg, frames=frames))
-  x0 = c.param_vec
-  rng = np.random.default_rng(2)
-  with Handle(c) as h:
-    ref = h.normal_equations(x0)
-    same = True
-    for k in range(200):
-      if k % 3 == 2:
-        h.normal_equations(x0 + 1e-3 * rng.normal(size=x0.size))
-      cost, g, diag = h.normal_equations(x0)
-      same = same and cost == ref[0] and np.array_equal(g, ref[1]) and np.array_equal(diag, ref[2])
-    out[cfg + str(frames)] = dict(same=bool(same), cost=ref[0], g=float(np.abs(ref[1]).sum()), diag=float(ref[2].sum()))
-print("RESULT" + json.dumps(out))
-'''
-  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-  base = {k: v for k, v in os.environ.items() if not k.startswith("MCBA_")}
-  res = {}
-  for merged in ("0", "1"):
-    p = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(base, TEST_MERGED=merged), capture_output=True, text=True, timeout=600)
-    assert p.returncode == 0, p.stderr[-2000:]
-    res[merged] = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT")][0][6:])
-  for k, a in res["0"].items():
-    b = res["1"][k]
-    assert a["same"] and b["same"], k
-    assert (a["cost"], a["g"], a["diag"]) == (b["cost"], b["g"], b["diag"]), k
 
 
 @pytest.mark.parametrize("name", ["tiny_rolling", "tiny", "tiny_handeye", "tiny_fisheye"])
