@@ -603,9 +603,26 @@ void check_launch(const char* what) {
 }
 
 // MCBA_FUSED=0 forces the table form (k_tmat + k_linearize); default: the table-fed fused form wherever it applies
+void ensure_compact(mcba_handle_s* h);
+LsmrCompact compact_tables(const mcba_handle_s* h);
 bool linearize_table_form() {
   static const bool table = dbg_switch("MCBA_FUSED") != nullptr && atoi(dbg_switch("MCBA_FUSED")) == 0;
   return table;
+}
+
+// the table-fed fused k_linearize at the pose / camera tables already prepared.  Round 6: its observations come from the compacted
+// tables of the lsmr route (LsmrCompact, built once per inlier set; the board points are constants here: d.off_boards < 0) -- one round
+// trip per view instead of two, bit-identical records.  MCBA_LIN_COMPACT=0 keeps the masks form (A/B runs, tests).
+void launch_fused_linearize_kernel(mcba_handle_s* h) {
+  const Dims& d = h->d;
+  static const bool masks = dbg_switch("MCBA_LIN_COMPACT") != nullptr && dbg_switch("MCBA_LIN_COMPACT")[0] == '0';
+  LsmrCompact cp{nullptr, nullptr, nullptr, nullptr};
+  if (!masks) {
+    ensure_compact(h);
+    cp = compact_tables(h);
+  }
+  h->ops->linearize(d, h->t, h->stream, h->rec.p, h->tri.p, true, h->lin_grid, nullptr, h->gbuf.p, 2 * d.n + 2, h->Hss.p,
+                    d.ns * d.ns, masks ? nullptr : &cp);
 }
 
 // fused residual+Jacobian -> block normal equations.  dx != nullptr: at the parameter vector dx (device); k_tmat then also
@@ -626,8 +643,7 @@ void launch_linearize(mcba_handle_s* h, const double* dx) {
   // step, any table kernel at all are gone.  MCBA_FUSED=0 forces the table form (k_tmat).
   if (!linearize_table_form() && h->use_mfma && d.off_boards < 0 && h->t.dbg == nullptr) {
     if (dx != nullptr) eval_pose_tables(h, dx);
-    h->ops->linearize(d, h->t, h->stream, h->rec.p, h->tri.p, true, h->lin_grid, nullptr, h->gbuf.p, 2 * d.n + 2, h->Hss.p,
-                      d.ns * d.ns);
+    launch_fused_linearize_kernel(h);
     return;
   }
   const int nb_views = std::max((d.views() + TMV - 1) / TMV, 1);
@@ -645,7 +661,7 @@ void launch_linearize(mcba_handle_s* h, const double* dx) {
   else
     hipLaunchKernelGGL(k_tmat<false>, dim3(nb_views), dim3(TM_THREADS), 0, h->stream, d, h->t, h->gbuf.p, 2 * d.n + 2,
                        h->Hss.p, d.ns * d.ns, (const double*)nullptr, nb_views);
-  h->ops->linearize(d, h->t, h->stream, h->rec.p, h->tri.p, h->use_mfma, h->lin_grid, nullptr, nullptr, 0, nullptr, 0);
+  h->ops->linearize(d, h->t, h->stream, h->rec.p, h->tri.p, h->use_mfma, h->lin_grid, nullptr, nullptr, 0, nullptr, 0, nullptr);
 }
 
 // publish_seq != 0: the kernel that forms the cost of the linearisation also writes it to h_scal[cost_slot] (pinned) and then
@@ -956,10 +972,11 @@ void ensure_compact(mcba_handle_s* h) {
   ensure_view_first(h);
   const size_t n = (size_t)std::max<int64_t>(h->n_inliers, 1) + 64;
   if (h->cp_obs.n < n) { h->cp_obs.alloc(n, false); h->cp_bxy.alloc(n, false); h->cp_bz.alloc(n, false); }
-  const size_t nv = (size_t)std::max(d.views(), 1);
+  // (one descriptor per entry of the active list: a hand-made list -- mcba_debug_set_frame_groups -- may be longer than the views, padded with -1)
+  const size_t nv = std::max<size_t>(std::max(d.views(), 1), h->active_views.n > 0 ? h->active_views.n - 1 : 0);
   if (h->cp_desc.n < nv) h->cp_desc.alloc(nv, false);
   if (d.views() > 0)
-    hipLaunchKernelGGL(k_compact_views, dim3(d.views()), dim3(64), 0, h->stream, d, h->t, (const int32_t*)h->view_first.p, h->cp_obs.p, h->cp_bxy.p,
+    hipLaunchKernelGGL(k_compact_views, dim3((unsigned)nv), dim3(64), 0, h->stream, d, h->t, (const int32_t*)h->view_first.p, h->cp_obs.p, h->cp_bxy.p,
                        h->cp_bz.p, h->cp_desc.p);
   check_launch("k_compact_views");
   h->compact_dirty = false;
@@ -1497,6 +1514,7 @@ int32_t mcba_debug_set_frame_groups(mcba_handle h, int32_t nw) {
     h->lin_grid = 0;
     refresh_active_views(h);
     sync(h);
+    h->compact_dirty = true;
     return 0;
   }
   const int cb = d.C * d.B, nv = d.views();
@@ -1537,6 +1555,7 @@ int32_t mcba_debug_set_frame_groups(mcba_handle h, int32_t nw) {
   h->t.active_views = h->active_views.p;
   HIP_OK(hipMemcpyAsync(h->active_views.p, host.data(), host.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
   sync(h);
+  h->compact_dirty = true;   // (the descriptors of the compacted tables follow the active list)
   h->lin_grid = grid;
   API_END
 }
@@ -3431,10 +3450,9 @@ int32_t mcba_time_linearize(mcba_handle h, const double* x, const mcba_options* 
   for (int i = 0; i < repeats; ++i) {   // the dominant kernel alone, as rocprofv3 reports it (table form: k_tmat ran above)
     const Dims& d = h->d;
     if (h->use_mfma && d.off_boards < 0 && !linearize_table_form())
-      h->ops->linearize(d, h->t, h->stream, h->rec.p, h->tri.p, true, h->lin_grid, nullptr, h->gbuf.p, 2 * d.n + 2, h->Hss.p,
-                        d.ns * d.ns);
+      launch_fused_linearize_kernel(h);
     else
-      h->ops->linearize(d, h->t, h->stream, h->rec.p, h->tri.p, h->use_mfma, h->lin_grid, nullptr, nullptr, 0, nullptr, 0);
+      h->ops->linearize(d, h->t, h->stream, h->rec.p, h->tri.p, h->use_mfma, h->lin_grid, nullptr, nullptr, 0, nullptr, 0, nullptr);
   }
   HIP_OK(hipEventRecord(h->ev1, h->stream));
   sync(h);

@@ -49,10 +49,12 @@ void jacobian(const Dims& d, const Tables& t, hipStream_t s, int row_nnz, double
 
 template <int MOTION, bool OPTK>
 void lin2(const Dims& d, const Tables& t, hipStream_t s, double* rec, const uint16_t* tri, bool mfma, int epoch,
-          const double* x, double* za, int na, double* zb, int nb) {
+          const double* x, double* za, int na, double* zb, int nb, const LsmrCompact* cpp) {
   // table-fed fused form: za != nullptr (pose entries / intrinsics from the pose and camera tables; zeroes the assembly
   // targets za[na], zb[nb]); za == nullptr: table form (That / chains per view from k_tmat)
   const bool fused = za != nullptr;
+  // cpp != nullptr (fused form only): the compacted observation tables of the current inlier set (form 3)
+  const LsmrCompact cp = cpp != nullptr ? *cpp : LsmrCompact{nullptr, nullptr, nullptr, nullptr};
   if (d.views() == 0 && !fused) return;   // empty frame shard (the fused form still zeroes the assembly targets)
   // persistent wavefronts: 8 single-wave workgroups per CU (2 per SIMD: 256-VGPR budget, 20 KB LDS each) x 256 CUs
   const int want = epoch > 0 ? epoch : LIN_GRID_MAX;   // the last argument carries the debug grid override
@@ -60,30 +62,31 @@ void lin2(const Dims& d, const Tables& t, hipStream_t s, double* rec, const uint
   // the linear loss (the reference's default, calibration.py:199) has its own instantiation of the MFMA kernel: no loss
   // switch and no robust-scale constants in the hot loop; the plain-FMA validation build keeps the generic form
   if (t.dbg != nullptr) {   // per-phase cycle stamps (debug API): the table form of the MFMA kernel
-    hipLaunchKernelGGL((k_linearize<ND_, FISH_, MOTION, OPTK, true, true, 0, true>), grid, block, 0, s, d, t, rec, tri, epoch, x, za, na, zb, nb);
+    hipLaunchKernelGGL((k_linearize<ND_, FISH_, MOTION, OPTK, true, true, 0, true>), grid, block, 0, s, d, t, rec, tri, epoch, x, za, na, zb, nb, cp);
     return;
   }
   const bool robust = d.loss != 0;
-#define MCBA_LIN(ROB, FM) hipLaunchKernelGGL((k_linearize<ND_, FISH_, MOTION, OPTK, true, ROB, FM>), grid, block, 0, s, d, t, rec, tri, epoch, x, za, na, zb, nb)
-  if (mfma && fused) { if (robust) MCBA_LIN(true, 2); else MCBA_LIN(false, 2); }
+#define MCBA_LIN(ROB, FM) hipLaunchKernelGGL((k_linearize<ND_, FISH_, MOTION, OPTK, true, ROB, FM>), grid, block, 0, s, d, t, rec, tri, epoch, x, za, na, zb, nb, cp)
+  if (mfma && fused && cpp != nullptr) { if (robust) MCBA_LIN(true, 3); else MCBA_LIN(false, 3); }
+  else if (mfma && fused) { if (robust) MCBA_LIN(true, 2); else MCBA_LIN(false, 2); }
   else if (mfma) { if (robust) MCBA_LIN(true, 0); else MCBA_LIN(false, 0); }
   else
-    hipLaunchKernelGGL((k_linearize<ND_, FISH_, MOTION, OPTK, false, true, 0>), grid, block, 0, s, d, t, rec, tri, epoch, x, za, na, zb, nb);
+    hipLaunchKernelGGL((k_linearize<ND_, FISH_, MOTION, OPTK, false, true, 0>), grid, block, 0, s, d, t, rec, tri, epoch, x, za, na, zb, nb, cp);
 #undef MCBA_LIN
 }
 
 template <int MOTION>
 void lin1(const Dims& d, const Tables& t, hipStream_t s, double* rec, const uint16_t* tri, bool mfma, int epoch,
-          const double* x, double* za, int na, double* zb, int nb) {
-  if (d.KI > 0) lin2<MOTION, true>(d, t, s, rec, tri, mfma, epoch, x, za, na, zb, nb);
-  else lin2<MOTION, false>(d, t, s, rec, tri, mfma, epoch, x, za, na, zb, nb);
+          const double* x, double* za, int na, double* zb, int nb, const LsmrCompact* cpp) {
+  if (d.KI > 0) lin2<MOTION, true>(d, t, s, rec, tri, mfma, epoch, x, za, na, zb, nb, cpp);
+  else lin2<MOTION, false>(d, t, s, rec, tri, mfma, epoch, x, za, na, zb, nb, cpp);
 }
 
 void linearize(const Dims& d, const Tables& t, hipStream_t s, double* rec, const uint16_t* tri, bool mfma, int epoch,
-               const double* x, double* za, int na, double* zb, int nb) {
-  if (d.motion == MOTION_STATIC) lin1<MOTION_STATIC>(d, t, s, rec, tri, mfma, epoch, x, za, na, zb, nb);
-  else if (d.motion == MOTION_ROLLING) lin1<MOTION_ROLLING>(d, t, s, rec, tri, mfma, epoch, x, za, na, zb, nb);
-  else lin1<MOTION_HAND_EYE>(d, t, s, rec, tri, mfma, epoch, x, za, na, zb, nb);
+               const double* x, double* za, int na, double* zb, int nb, const LsmrCompact* cpp) {
+  if (d.motion == MOTION_STATIC) lin1<MOTION_STATIC>(d, t, s, rec, tri, mfma, epoch, x, za, na, zb, nb, cpp);
+  else if (d.motion == MOTION_ROLLING) lin1<MOTION_ROLLING>(d, t, s, rec, tri, mfma, epoch, x, za, na, zb, nb, cpp);
+  else lin1<MOTION_HAND_EYE>(d, t, s, rec, tri, mfma, epoch, x, za, na, zb, nb, cpp);
 }
 
 template <int MOTION>

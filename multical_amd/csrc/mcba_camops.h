@@ -16,9 +16,10 @@ struct CamOps {
   void (*project_model)(const Dims&, const Tables&, hipStream_t, int iterations, double* proj);
   void (*cost)(const Dims&, const Tables&, hipStream_t, double* partial, int nblk);
   void (*jacobian)(const Dims&, const Tables&, hipStream_t, int row_nnz, double* vals, int32_t* cols);
-  // x != nullptr: the fused form (k_linearize builds That / the chains from x itself and zeroes za[na], zb[nb])
+  // za != nullptr: the table-fed fused form (k_linearize builds That / the chains from the pose table itself and zeroes za[na], zb[nb]);
+  // compact != nullptr: ... over the compacted observation tables of the current inlier set (form 3)
   void (*linearize)(const Dims&, const Tables&, hipStream_t, double* rec, const uint16_t* tri, bool mfma, int epoch,
-                    const double* x, double* za, int na, double* zb, int nb);
+                    const double* x, double* za, int na, double* zb, int nb, const LsmrCompact* compact);
   void (*points)(const Dims&, const Tables&, hipStream_t, int n_points, double* Hss, double* Hfs, double* g);
   // solver = "lsmr": u <- J_h v - alpha u (mode 0) / u <- f (mode 1), and the per-view partials of J_h^T (u inv_beta);
   // ls != nullptr: alpha / inv_beta and the stop flag come from the device-resident state of the solve (mcba_lsmr.h)

@@ -1504,12 +1504,16 @@ __global__ __launch_bounds__(64, (MOTION == MOTION_STATIC && !FISH && MFMA && !R
 void k_linearize(Dims d, Tables t, double* __restrict__ rec,
                                                      const uint16_t* __restrict__ tri, int epoch,
                                                      const double* __restrict__ x, double* __restrict__ zero_a, int na,
-                                                     double* __restrict__ zero_b, int nb) {
+                                                     double* __restrict__ zero_b, int nb, LsmrCompact cp) {
   // FUSED_MODE: 0 = table form (That / chains from k_tmat), 2 = table-fed fused form (pose entries copied from the pose table,
-  // intrinsics from the camera table)
-  static_assert(FUSED_MODE == 0 || FUSED_MODE == 2, "linearisation forms: 0 = table form, 2 = table-fed fused form");
+  // intrinsics from the camera table), 3 = the table-fed fused form over the COMPACTED observation tables (LsmrCompact: observed point
+  // and board point of every inlier in residual order + one descriptor per active view, built once per inlier set): no mask bytes, no
+  // compaction list, no point-index gathers -- the first chunk of a view is requested with its pose entries (one round trip per view
+  // instead of two); same lane for every observation, so the records are bit-identical to form 2
+  static_assert(FUSED_MODE == 0 || FUSED_MODE == 2 || FUSED_MODE == 3, "linearisation forms: 0 = table form, 2 / 3 = table-fed fused forms");
   constexpr bool FUSED = FUSED_MODE != 0;
-  (void)x;
+  constexpr bool COMPACT = FUSED_MODE == 3;
+  (void)x; (void)cp;
   constexpr bool ROLL = MOTION == MOTION_ROLLING;
   constexpr int DE = ROLL ? 12 : 6, NPB = MOTION == MOTION_STATIC ? 3 : 4, KI = OPTK ? 4 + ND : 0;
   constexpr int NV = DE + KI + 1, NT = (NV + 15) / 16, NVP = 16 * NT;
@@ -1585,9 +1589,11 @@ void k_linearize(Dims d, Tables t, double* __restrict__ rec,
   // all global loads of the front are issued back to back (mask bytes, That, chain matrices, camera): one round trip
   auto front_issue = [&](int vv, int pl) {
     const int cc = (vv / d.B) % d.C;
-    const uint8_t* mrow = t.inlier + (size_t)vv * d.P;
+    if constexpr (!COMPACT) {
+      const uint8_t* mrow = t.inlier + (size_t)vv * d.P;
 #pragma unroll
-    for (int k = 0; k < NPB64; ++k) inb[k] = masked_load_row(mrow, k * 64 + pl, d.P);
+      for (int k = 0; k < NPB64; ++k) inb[k] = masked_load_row(mrow, k * 64 + pl, d.P);
+    }
     if constexpr (!FUSED) {
       const double* tg = t.tmat + (size_t)vv * (DE * NPC);   // That of this view, precomputed by k_tmat
 #pragma unroll
@@ -1631,12 +1637,14 @@ void k_linearize(Dims d, Tables t, double* __restrict__ rec,
       extr[CAM_FIXASPECT - CAM_TILT] = uniform_f64(ext_f[1]);
     }
     int cnt = 0;
+    if constexpr (!COMPACT) {
 #pragma unroll
-    for (int k = 0; k < NPB64; ++k) {
-      const bool in = inb[k] != 0;
-      const unsigned long long m = __ballot(in);
-      if (in) pidx[cnt + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(k * 64 + lane);
-      cnt += __popcll(m);
+      for (int k = 0; k < NPB64; ++k) {
+        const bool in = inb[k] != 0;
+        const unsigned long long m = __ballot(in);
+        if (in) pidx[cnt + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(k * 64 + lane);
+        cnt += __popcll(m);
+      }
     }
     return cnt;
   };
@@ -1647,8 +1655,20 @@ void k_linearize(Dims d, Tables t, double* __restrict__ rec,
   ob_cur.x = ob_cur.y = 0.0;
   double X_cur[3] = {0.0, 0.0, 0.0}, X_nxt[3];
   bool front_ready = false;    // the front of the view about to be processed is already in LDS copy `cur` (PIPE)
+  int4 dnext = make_int4(0, 0, 0, 0);   // (COMPACT) descriptor {view, first observation, inliers} of the next view of this workgroup
+  if constexpr (COMPACT) {
+    if ((int)blockIdx.x < n_active) dnext = cp.desc[blockIdx.x];
+  }
   for (int vi = blockIdx.x; vi < n_active; vi += gridDim.x) {
-  const int v = t.active_views[1 + vi];
+  int v_, desc_first = 0, desc_count = 0;
+  if constexpr (COMPACT) {
+    v_ = dnext.x; desc_first = dnext.y; desc_count = dnext.z;
+    if (vi + (int)gridDim.x < n_active) dnext = cp.desc[vi + gridDim.x];   // (scalar load, one view ahead)
+  } else {
+    v_ = t.active_views[1 + vi];
+  }
+  const int v = v_;
+  (void)desc_first; (void)desc_count;
   if (v < 0) continue;         // (padding of a hand-made list: mcba_debug_set_frame_groups)
   const int b = v % d.B, c = (v / d.B) % d.C, fl = v / (d.B * d.C), f = d.f0 + fl;
   (void)f;
@@ -1693,11 +1713,20 @@ void k_linearize(Dims d, Tables t, double* __restrict__ rec,
                                      : d.pose_motion + (MOTION == MOTION_STATIC ? f : (MOTION == MOTION_ROLLING ? (k - 1) * d.F + f : k - 1)));
         pe_f[u] = t.pose[(size_t)gi * POSE_STRIDE + q];
       }
-      count = front_finish(cur, pl);
-      lds_fence();
-      p_cur = lane < count ? pidx[lane] : 0;
-      ob_cur = t.obs[(size_t)v * d.P + p_cur];
-      for (int k = 0; k < 3; ++k) X_cur[k] = t.board_points[3 * (size_t)(b * d.P + p_cur) + k];
+      if constexpr (COMPACT) {   // the first chunk rides in the same round trip as the pose entries and the camera
+        const size_t g0 = (size_t)desc_first + (size_t)(lane < desc_count ? lane : 0);
+        ob_cur = cp.obs[g0];
+        const double2 xy = cp.bxy[g0];
+        X_cur[0] = xy.x; X_cur[1] = xy.y; X_cur[2] = cp.bz[g0];
+        front_finish(cur, pl);
+        count = desc_count;
+      } else {
+        count = front_finish(cur, pl);
+        lds_fence();
+        p_cur = lane < count ? pidx[lane] : 0;
+        ob_cur = t.obs[(size_t)v * d.P + p_cur];
+        for (int k = 0; k < 3; ++k) X_cur[k] = t.board_points[3 * (size_t)(b * d.P + p_cur) + k];
+      }
 #pragma unroll
       for (int u = 0; u < NPE; ++u) Pl[min(pl + 64 * u, NPB * POSE_STRIDE - 1)] = pe_f[u];
     }
@@ -1749,7 +1778,7 @@ void k_linearize(Dims d, Tables t, double* __restrict__ rec,
     for (int e = lane; e < ROWS * (LDV - NV); e += 64) Vbuf[(e / (LDV - NV)) * LDV + NV + e % (LDV - NV)] = 0.0;
 
   if (prof) stamp[5] = clock64();
-  if constexpr (FUSED_MODE != 2) {   // (the table-fed fused form has compacted its masks above)
+  if constexpr (!FUSED) {   // (the table-fed fused form has compacted its masks above)
     if (!front_ready) count = front_finish(cur, pl);
   }
 
@@ -1782,7 +1811,7 @@ void k_linearize(Dims d, Tables t, double* __restrict__ rec,
 
   // software prefetch: observation + board point of the NEXT chunk are requested before the current one is processed
   // (the first chunk of a pipelined view was requested from the middle of the previous epilogue)
-  if (FUSED_MODE != 2 && !front_ready) {   // (table-fed fused form: requested before the chain arithmetic)
+  if (!FUSED && !front_ready) {   // (table-fed fused form: requested before the chain arithmetic)
     p_cur = lane < count ? pidx[lane] : 0;
     ob_cur = t.obs[(size_t)v * d.P + p_cur];
     for (int k = 0; k < 3; ++k) X_cur[k] = t.board_points[3 * (size_t)(b * d.P + p_cur) + k];
@@ -1797,9 +1826,18 @@ void k_linearize(Dims d, Tables t, double* __restrict__ rec,
     const int i = base + lane;
     const bool in = FULLC || i < count;
     const int inx = i + 64;
-    const int p_nxt = inx < count ? pidx[inx] : p_cur;
-    const double2 ob_nxt = t.obs[(size_t)v * d.P + p_nxt];
-    for (int k = 0; k < 3; ++k) X_nxt[k] = t.board_points[3 * (size_t)(b * d.P + p_nxt) + k];
+    int p_nxt = 0;
+    double2 ob_nxt;
+    if constexpr (COMPACT) {
+      const size_t gn = (size_t)desc_first + (size_t)(inx < count ? inx : 0);
+      ob_nxt = cp.obs[gn];
+      const double2 xy = cp.bxy[gn];
+      X_nxt[0] = xy.x; X_nxt[1] = xy.y; X_nxt[2] = cp.bz[gn];
+    } else {
+      p_nxt = inx < count ? pidx[inx] : p_cur;
+      ob_nxt = t.obs[(size_t)v * d.P + p_nxt];
+      for (int k = 0; k < 3; ++k) X_nxt[k] = t.board_points[3 * (size_t)(b * d.P + p_nxt) + k];
+    }
     PointState<ND, ROLL> ps;
     long long t0 = 0;
     if (prof) t0 = clock64();
@@ -1892,6 +1930,7 @@ void k_linearize(Dims d, Tables t, double* __restrict__ rec,
     for (; base + 64 <= count; base += 64) do_chunk(base, std::true_type{});
     if (base < count) do_chunk(base, std::false_type{});
   }
+  if constexpr (COMPACT) break;   // (the compacted run of a view is walked whole: no segments)
   seg0 += LIN_MAX_POINTS;
   if (seg0 >= d.P) break;
   {   // next segment of a large board: its mask bytes are compacted into the (now free) list, the accumulators carry on

@@ -615,7 +615,7 @@ def test_handle_cache_sees_a_changed_validity_mask_and_float32_tables():
 
 
 @pytest.mark.parametrize("switch", ["MCBA_FUSED=0", "MCBA_ASM_STAGE_KB=4", "MCBA_FUSED=0,MCBA_TMAT_GLOBAL=1",
-                                    "MCBA_NCHUNK_TARGET=1024", "MCBA_SHARED_FINAL_BIG=1", "MCBA_SYRK3=1", "MCBA_SPLIT_Q00=1", "MCBA_SPEC_ACCEPT=0", "MCBA_SPEC_ACCEPT=0,MCBA_NO_PUBLISH=1"])
+                                    "MCBA_NCHUNK_TARGET=1024", "MCBA_SHARED_FINAL_BIG=1", "MCBA_LIN_COMPACT=0", "MCBA_SYRK3=1", "MCBA_SPLIT_Q00=1", "MCBA_SPEC_ACCEPT=0", "MCBA_SPEC_ACCEPT=0,MCBA_NO_PUBLISH=1"])
 def test_alternative_linearisation_paths_match_the_default(switch):
   """Paths of the evaluation that the fixtures do not reach by themselves, each forced with its switch in a subprocess
   (mcba_debug_set_switch, once per process -- the product library reads no MCBA_* experiment switch from the environment); all must reproduce the normal equations of the default form to round-off,
@@ -626,7 +626,8 @@ def test_alternative_linearisation_paths_match_the_default(switch):
     MCBA_SHARED_FINAL_BIG=1   the final sum of the shared part for rigs with more than 128 (camera, board) pairs
     MCBA_ASM_STAGE_KB=4       frame blocks of k_assemble stage their records in several groups (rigs with many views per frame)
     MCBA_TMAT_GLOBAL=1        k_tmat reads the global pose table (rigs whose cameras + boards exceed the local table)
-    MCBA_NCHUNK_TARGET=1024   more chunk sums than the default split of the shared part"""
+    MCBA_NCHUNK_TARGET=1024   more chunk sums than the default split of the shared part
+    MCBA_LIN_COMPACT=0        k_linearize over the masks + slot tables instead of the compacted observation tables"""
   import os, subprocess, sys, json
   code = r'''
 import sys, json, os, numpy as np
@@ -662,6 +663,56 @@ print("RESULT" + json.dumps(out))
     Ha, Hb = np.array(a["H"]), np.array(b["H"])
     assert np.abs(Ha - Hb).max() <= 1e-11 * np.abs(Ha).max(), name
     assert b["nfev"] == a["nfev"] and b["final"] == pytest.approx(a["final"], rel=1e-9), name
+
+
+def test_linearize_observation_sources_agree():
+  """k_linearize reads its observations from the compacted tables of the inlier set (LsmrCompact: form 3, the default) or from the masks +
+  slot tables (form 2, MCBA_LIN_COMPACT=0).  Every observation sits in the same lane of the same 64-row chunk in both, so cost, gradient
+  and H come out BIT-IDENTICAL -- on every motion / camera model, with empty views and after the inlier set changed (the compacted
+  tables are rebuilt); a board with more than 512 points is walked in segments by form 2 only (chunk boundaries differ): round-off."""
+  import os, subprocess, sys, json
+  code = r"""
+import sys, json, os, numpy as np
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+from util import load_golden, mirror
+from multical_amd.backend import Handle
+from multical_amd import _lib, synthetic, calibration
+if os.environ.get("TEST_MASKS") == "1":
+  _lib.set_switch("MCBA_LIN_COMPACT", "0")
+out = {}
+def record(key, h, x):
+  cost, grad, diag = h.normal_equations(x)
+  H = h.dense_hessian()
+  out[key] = dict(cost=cost, grad=grad.tolist(), diag=diag.tolist(), H=H.ravel()[::5].tolist())
+for name in ["tiny", "tiny_rolling", "tiny_handeye", "tiny_fisheye", "tiny_edge", "tiny_pin4", "cfg1", "tiny_tilted", "tiny_fixintr",
+             "tiny_fishmix", "tiny_softl1", "tiny_bigboard"]:
+  g, rig = load_golden(name)
+  with Handle(mirror(rig)) as h:
+    record(name, h, g["x0"])
+    if name in ("tiny_rolling", "cfg1"):
+      h.reject_outliers(g["x0"], 1.0)          # another inlier set: the compacted tables follow
+      record(name + "/rejected", h, g["x0"])
+c = calibration.from_rig(synthetic.make_rig("cfg3", frames=40))
+with Handle(c) as h:
+  record("cfg3_40", h, c.param_vec)
+print("RESULT" + json.dumps(out))
+"""
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  base = {k: v for k, v in os.environ.items() if not k.startswith("MCBA_")}
+  res = {}
+  for masks in ("0", "1"):
+    p = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(base, TEST_MASKS=masks), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    res[masks] = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT")][0][6:])
+  for key, a in res["0"].items():
+    b = res["1"][key]
+    if key == "tiny_bigboard":
+      for q in ("grad", "diag", "H"):
+        va, vb = np.array(a[q]), np.array(b[q])
+        assert np.abs(va - vb).max() <= 1e-12 * np.abs(va).max(), (key, q)
+      assert b["cost"] == pytest.approx(a["cost"], rel=1e-13)
+    else:
+      assert a == b, key
 
 
 @pytest.mark.parametrize("name", ["tiny_rolling", "tiny", "tiny_handeye", "tiny_fisheye"])
