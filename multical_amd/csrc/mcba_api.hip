@@ -703,7 +703,7 @@ void launch_assemble(mcba_handle_s* h, unsigned long long publish_seq = 0, int c
   {
     const int pg = std::min(npair, 16);
     if (npair <= SHARED_FINAL_MAX_PAIRS && !force_big)   // pair sums in LDS
-      hipLaunchKernelGGL(k_shared_final, dim3((d.rec_size + 2 + 63) / 64), dim3(64 * pg), (size_t)npair * 64 * sizeof(double),
+      hipLaunchKernelGGL(k_shared_final, dim3((d.rec_size + 2 + SF_ENT - 1) / SF_ENT), dim3(64 * pg), (size_t)npair * SF_ENT * sizeof(double),
                          h->stream, d, h->partial.p, h->nchunk, h->tri.p, h->Hss.p, h->g(), h->diag(), h->costcount(),
                          publish_seq ? h->h_scal + cost_slot : nullptr, h->h_pub_seq, publish_seq);
     else                                                 // more (camera, board) pairs than the LDS table holds

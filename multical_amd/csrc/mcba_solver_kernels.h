@@ -453,38 +453,45 @@ __device__ __forceinline__ void publish_cost(double val, double* host_cost, unsi
   __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 constexpr int SHARED_FINAL_MAX_PAIRS = 128;   // pair sums of k_shared_final: [pairs][64] doubles of LDS
+// Round 6: 16 packed entries per workgroup instead of 64 (38 workgroups instead of 10 at the north-star rig: the 2.4 MB of chunk sums are
+// pulled by four times as many CUs) and the chunks of a pair split over the four 16-lane rows of its wavefront (8 loads per lane in one
+// batch instead of 32), folded with two lane-xor exchanges.
 // (written as ONE kernel body on purpose: the same body as a __forceinline__ device function shared with a second kernel -- round 6's merged
-//  k_assemble + final-stage launch, measured and dropped, profiles/r06_lsmr_experiments.txt item 9 -- compiled to 46 instead of 98 VGPRs: the 16
+//  k_assemble + final-stage launch, measured and dropped, profiles/r06_lsmr_experiments.txt item 9 -- compiled to 46 instead of 98 VGPRs: the
 //  chunk-sum loads per pair were no longer kept in flight together and the launch took 8.6 instead of 6.2 us)
+constexpr int SF_ENT = 16;   // packed entries per workgroup
 __global__ __launch_bounds__(1024) void k_shared_final(Dims d, const double* __restrict__ partial, int nchunk,
                                                        const uint16_t* __restrict__ tri, double* __restrict__ Hss,
                                                        double* __restrict__ g, double* __restrict__ diag,
                                                        double* __restrict__ cost_count, double* host_cost = nullptr,
                                                        unsigned long long* host_seq = nullptr, unsigned long long seq = 0) {
-  extern __shared__ double pair_sum[];   // [C B][64]
+  extern __shared__ double pair_sum[];   // [C B][SF_ENT]
   const int ns = d.ns, NL = d.NL, npose = 6 * d.NPB, npair = d.C * d.B;
-  const int el = threadIdx.x & 63, pg = threadIdx.x >> 6, PG = blockDim.x >> 6;
-  const int e = blockIdx.x * 64 + el;
+  const int el = threadIdx.x & (SF_ENT - 1), cq = (threadIdx.x & 63) >> 4, wv = threadIdx.x >> 6, NW = blockDim.x >> 6;
+  const int e = blockIdx.x * SF_ENT + el;
   // (the rows of the eliminated frame parameters hold no chunk sums: shared_partial_block walks over them)
   const int skip0 = d.DF > 0 ? tri_index(6, 6, d.N1) : 0, nskip = d.DF > 0 ? d.DF * d.N1 - (6 * d.DF + d.DF * (d.DF - 1) / 2) : 0;
   const bool in = e < d.rec_size + 2 && !(e >= skip0 && e < skip0 + nskip);
   const size_t rs = d.rec_stride;
   const int ij = e < d.rec_size ? tri[e] : 0;   // (issued with the chunk sums, used after them)
-  for (int pair = pg; pair < npair; pair += PG) {
-    double a[16];
+  for (int pair = wv; pair < npair; pair += NW) {
+    double a[8];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) a[u] = 0.0;
+    for (int u = 0; u < 8; ++u) a[u] = 0.0;
     if (in) {
+      // row cq of the wavefront takes chunks cq, cq + 4, ...: unconditional loads (clamped index, 0 / 1 weight), eight in flight
       const double* base = partial + (size_t)pair * nchunk * rs + e;
-      int ch = 0;
-      for (; ch + 16 <= nchunk; ch += 16)
+      for (int c0 = 0; c0 < nchunk; c0 += 32)
 #pragma unroll
-        for (int u = 0; u < 16; ++u) a[u] += base[(size_t)(ch + u) * rs];
-      for (; ch < nchunk; ++ch) a[ch & 15] += base[(size_t)ch * rs];
+        for (int u = 0; u < 8; ++u) {
+          const int c = c0 + 4 * u + cq;
+          a[u] += (c < nchunk ? 1.0 : 0.0) * base[(size_t)min(c, nchunk - 1) * rs];
+        }
     }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) a[u] += a[u + 8];
-    pair_sum[pair * 64 + el] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    double sum = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);            // (commutative pairings: the four rows hold the same bits)
+    if (cq == 0) pair_sum[pair * SF_ENT + el] = sum;
   }
   __syncthreads();
   if (!in) return;
@@ -500,7 +507,7 @@ __global__ __launch_bounds__(1024) void k_shared_final(Dims d, const double* __r
     depc = dep_c(i) || (j < NL && dep_c(j));
     depb = dep_b(i) || (j < NL && dep_b(j));
   }
-  for (int pair = pg; pair < npair; pair += PG) {
+  for (int pair = threadIdx.x / SF_ENT; pair < npair; pair += blockDim.x / SF_ENT) {
     const int c = pair / d.B, b = pair % d.B;
     if ((!depc && c != 0) || (!depb && b != 0)) continue;    // not the first pair of its class
     int gi = -1, gj = -1;
@@ -516,7 +523,7 @@ __global__ __launch_bounds__(1024) void k_shared_final(Dims d, const double* __r
     const int c0 = depc ? c : 0, c1 = depc ? c + 1 : d.C, b0 = depb ? b : 0, b1 = depb ? b + 1 : d.B;
     double val = 0.0;
     for (int cc = c0; cc < c1; ++cc)
-      for (int bb = b0; bb < b1; ++bb) val += pair_sum[(cc * d.B + bb) * 64 + el];
+      for (int bb = b0; bb < b1; ++bb) val += pair_sum[(cc * d.B + bb) * SF_ENT + el];
     if (e >= d.rec_size) {
       cost_count[e - d.rec_size] = val;
       if (host_cost != nullptr && e == d.rec_size) publish_cost(val, host_cost, host_seq, seq);
