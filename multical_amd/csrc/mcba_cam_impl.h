@@ -57,7 +57,9 @@ void lin2(const Dims& d, const Tables& t, hipStream_t s, double* rec, const uint
   const LsmrCompact cp = cpp != nullptr ? *cpp : LsmrCompact{nullptr, nullptr, nullptr, nullptr};
   if (d.views() == 0 && !fused) return;   // empty frame shard (the fused form still zeroes the assembly targets)
   // persistent wavefronts: 8 single-wave workgroups per CU (2 per SIMD: 256-VGPR budget, 20 KB LDS each) x 256 CUs
-  const int want = epoch > 0 ? epoch : LIN_GRID_MAX;   // the last argument carries the debug grid override
+  // (rigs with tens of thousands of views: four times as many workgroups for the dispatcher to hand out -- 16 x 1000 x 5, 80 000 views,
+  //  4 waves per SIMD: 4096 -> 57.8 us, 8192 -> 54.5, 16384 -> 53.5; 8 x 500 x 2 stays at 4096: 41.6 against 42.3 us -- profiles/r06_lin_compact.txt)
+  const int want = epoch > 0 ? epoch : (d.views() >= 32768 ? 4 * LIN_GRID_MAX : LIN_GRID_MAX);   // the last argument carries the debug grid override
   const dim3 grid(std::max(1, d.views() < want ? d.views() : want)), block(64);
   // the linear loss (the reference's default, calibration.py:199) has its own instantiation of the MFMA kernel: no loss
   // switch and no robust-scale constants in the hot loop; the plain-FMA validation build keeps the generic form

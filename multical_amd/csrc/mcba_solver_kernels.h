@@ -438,8 +438,8 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(Dims d, Tables t, cons
 }
 
 // shared part, stage 2: H_ss (dense ns x ns, zeroed by the caller), g, diag and the total cost from the chunk sums.
-// A block covers 64 packed local entries e x ALL pairs (c, b): thread (e, pair lane) first adds the chunk sums of its
-// pairs (independent loads, 8 in flight) into LDS.  A local entry maps to an element of H_ss that depends on the camera
+// A block covers SF_ENT (16) packed local entries e x ALL pairs (c, b): the wavefront of a pair first adds the pair's chunk sums
+// (entry = lane & 15, chunks split over the four rows of the wavefront, 8 independent loads in flight per lane) into LDS.  A local entry maps to an element of H_ss that depends on the camera
 // only (camera pose / intrinsics columns), on the board only (board pose), on both, or on neither (hand-eye blocks):
 // the thread of the FIRST pair of each equivalence class owns the element, adds the pair sums of its class from LDS in
 // a fixed order and stores -- no atomics, no read-modify-write chains, every element written once.
@@ -452,7 +452,7 @@ __device__ __forceinline__ void publish_cost(double val, double* host_cost, unsi
   __threadfence_system();
   __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-constexpr int SHARED_FINAL_MAX_PAIRS = 128;   // pair sums of k_shared_final: [pairs][64] doubles of LDS
+constexpr int SHARED_FINAL_MAX_PAIRS = 128;   // pair sums of k_shared_final: [pairs][SF_ENT] doubles of LDS
 // Round 6: 16 packed entries per workgroup instead of 64 (38 workgroups instead of 10 at the north-star rig: the 2.4 MB of chunk sums are
 // pulled by four times as many CUs) and the chunks of a pair split over the four 16-lane rows of its wavefront (8 loads per lane in one
 // batch instead of 32), folded with two lane-xor exchanges.

@@ -30,6 +30,8 @@ for CFG in cfg3 cfg4 cfg2; do
   MCBA_TIMING=1 timeout 100 python profiles/scripts/prof_workspace.py $CFG --solver native > $O/workspace_$CFG.log 2>&1; grep "calibrate ms" $O/workspace_$CFG.log
   timeout 100 python profiles/scripts/prof_workspace.py $CFG --solver lsmr > $O/workspace_lsmr_$CFG.log 2>&1; grep "calibrate ms" $O/workspace_lsmr_$CFG.log
 done
+# round 6: k_linearize over the compacted observation tables against the masks form, and the persistent grid
+(python profiles/scripts/prof_lin_compact.py; echo "masks form (MCBA_LIN_COMPACT=0)"; TEST_MASKS=1 python profiles/scripts/prof_lin_compact.py; echo "persistent grid"; python profiles/scripts/prof_lin_grid.py) > $O/lin_compact.txt 2>&1; cp $O/lin_compact.txt profiles/r06_lin_compact.txt; cat $O/lin_compact.txt
 # round 6: the sign of the default solver's offset from the reference's end point (call level, bisection, summation orders)
 timeout 900 python profiles/scripts/prof_lsmr_sign.py AB > $O/lsmr_sign.json 2> $O/lsmr_sign.log; tail -8 $O/lsmr_sign.log
 timeout 600 python profiles/scripts/prof_lsmr_bisect.py > $O/lsmr_bisect.json 2> $O/lsmr_bisect.log; tail -16 $O/lsmr_bisect.log
