@@ -317,7 +317,7 @@ struct mcba_handle_s {
   DevBuf<double> ls_u, ls_ua, ls_ub, ls_part, ls_v, ls_vraw, ls_h, ls_hbar, ls_x, ls_nrm, ls_partial, ls_out, ls_bpart, ls_comm, ls_xpart, ls_vpart, ls_part2;
   // compacted observation tables of the lsmr route (LsmrCompact; rebuilt when the inlier set changes: ensure_compact)
   DevBuf<double2> cp_obs, cp_bxy;
-  DevBuf<double> cp_bz;
+  DevBuf<double> cp_bz, cp_tr;
   DevBuf<int4> cp_desc;
   bool compact_dirty = true;
   DevBuf<double> ls_cache;                // lsmr_fused == 3: the per-observation state A, X_start, X_end, t (+ robust scales) of the current linearisation
@@ -616,7 +616,7 @@ bool linearize_table_form() {
 void launch_fused_linearize_kernel(mcba_handle_s* h) {
   const Dims& d = h->d;
   static const bool masks = dbg_switch("MCBA_LIN_COMPACT") != nullptr && dbg_switch("MCBA_LIN_COMPACT")[0] == '0';
-  LsmrCompact cp{nullptr, nullptr, nullptr, nullptr};
+  LsmrCompact cp{nullptr, nullptr, nullptr, nullptr, nullptr};
   if (!masks) {
     ensure_compact(h);
     cp = compact_tables(h);
@@ -972,16 +972,19 @@ void ensure_compact(mcba_handle_s* h) {
   ensure_view_first(h);
   const size_t n = (size_t)std::max<int64_t>(h->n_inliers, 1) + 64;
   if (h->cp_obs.n < n) { h->cp_obs.alloc(n, false); h->cp_bxy.alloc(n, false); h->cp_bz.alloc(n, false); }
+  if (d.motion == MOTION_ROLLING && h->cp_tr.n < n) h->cp_tr.alloc(n, false);
   // (one descriptor per entry of the active list: a hand-made list -- mcba_debug_set_frame_groups -- may be longer than the views, padded with -1)
   const size_t nv = std::max<size_t>(std::max(d.views(), 1), h->active_views.n > 0 ? h->active_views.n - 1 : 0);
   if (h->cp_desc.n < nv) h->cp_desc.alloc(nv, false);
   if (d.views() > 0)
     hipLaunchKernelGGL(k_compact_views, dim3((unsigned)nv), dim3(64), 0, h->stream, d, h->t, (const int32_t*)h->view_first.p, h->cp_obs.p, h->cp_bxy.p,
-                       h->cp_bz.p, h->cp_desc.p);
+                       h->cp_bz.p, d.motion == MOTION_ROLLING ? h->cp_tr.p : nullptr, h->cp_desc.p);
   check_launch("k_compact_views");
   h->compact_dirty = false;
 }
-LsmrCompact compact_tables(const mcba_handle_s* h) { return LsmrCompact{h->cp_obs.p, h->cp_bxy.p, h->cp_bz.p, h->cp_desc.p}; }
+LsmrCompact compact_tables(const mcba_handle_s* h) {
+  return LsmrCompact{h->cp_obs.p, h->cp_bxy.p, h->cp_bz.p, h->d.motion == MOTION_ROLLING ? h->cp_tr.p : nullptr, h->cp_desc.p};
+}
 
 void compute_errors(mcba_handle_s* h, const double* x) {
   const Dims& d = h->d;

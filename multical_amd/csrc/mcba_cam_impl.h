@@ -54,7 +54,7 @@ void lin2(const Dims& d, const Tables& t, hipStream_t s, double* rec, const uint
   // targets za[na], zb[nb]); za == nullptr: table form (That / chains per view from k_tmat)
   const bool fused = za != nullptr;
   // cpp != nullptr (fused form only): the compacted observation tables of the current inlier set (form 3)
-  const LsmrCompact cp = cpp != nullptr ? *cpp : LsmrCompact{nullptr, nullptr, nullptr, nullptr};
+  const LsmrCompact cp = cpp != nullptr ? *cpp : LsmrCompact{nullptr, nullptr, nullptr, nullptr, nullptr};
   if (d.views() == 0 && !fused) return;   // empty frame shard (the fused form still zeroes the assembly targets)
   // persistent wavefronts: 8 single-wave workgroups per CU (2 per SIMD: 256-VGPR budget, 20 KB LDS each) x 256 CUs
   // (rigs with tens of thousands of views: four times as many workgroups for the dispatcher to hand out -- 16 x 1000 x 5, 80 000 views,

@@ -119,6 +119,8 @@ struct LsmrCompact {
   const double2* obs;      // [n_inliers] observed (u, v)
   const double2* bxy;      // [n_inliers] board point x, y
   const double* bz;        // [n_inliers] board point z
+  const double* tr;        // [n_inliers] rolling shutter: scan time of the observation = observed row / image height (a CONSTANT of the
+                           //             observation: the division leaves the head of every evaluation's dependency chain); else null
   const int4* desc;        // [active views] {v, first, count, 0}
 };
 

@@ -1030,19 +1030,17 @@ __global__ __launch_bounds__(64) MCBA_F2_OCCUPANCY void k_lsmr_fused2(Dims d, Ta
     double z_cur = 0.0;
     double2 ob_nxt = make_double2(0.0, 0.0), xy_nxt = make_double2(0.0, 0.0), old_nxt = make_double2(0.0, 0.0);
     double z_nxt = 0.0;
+    // the observed point is only needed for the residual (robust row scaling); the products of the linear loss never read it, and the
+    // scan time of a rolling-shutter observation (observed row / image height) comes precomputed with the tables
+    constexpr bool NEED_OB = ROBUST;
+    double tr_cur = 0.0, tr_nxt = 0.0;
     if constexpr (MODE >= 3) {
       const size_t g0 = (size_t)desc_first + (size_t)(lane < desc_count ? lane : 0);
-      ob_cur = cp.obs[g0];
+      if constexpr (NEED_OB) ob_cur = cp.obs[g0];
+      if constexpr (ROLL) tr_cur = cp.tr[g0];
       xy_cur = cp.bxy[g0];
       z_cur = cp.bz[g0];
       old_cur = reinterpret_cast<const double2*>(u)[g0];
-#if defined(MCBA_EXP_F2_DEPTH2)   // experiment (variant builds): TWO chunks in flight -- measured 26.4 against 25.3 us at the north-star rig: not adopted
-      const size_t g1 = (size_t)desc_first + (size_t)(lane + 64 < desc_count ? lane + 64 : 0);
-      ob_nxt = cp.obs[g1];
-      xy_nxt = cp.bxy[g1];
-      z_nxt = cp.bz[g1];
-      old_nxt = reinterpret_cast<const double2*>(u)[g1];
-#endif
     }
     {
       const double* tg = t.tmat + (size_t)v * (DE * NPC);
@@ -1078,24 +1076,19 @@ __global__ __launch_bounds__(64) MCBA_F2_OCCUPANCY void k_lsmr_fused2(Dims d, Ta
       // ---- compact form: observation, board point and old uhat stream in residual order; the NEXT chunk is requested before the
       // current one is evaluated
       const int count = desc_count;
+      // (two chunks in flight instead of one were measured: 26.4 against 25.3 us at the north-star rig -- profiles/r06_lsmr_experiments.txt)
       for (int base = 0; base < count; base += 64) {
-#if !defined(MCBA_EXP_F2_DEPTH2)
         const int i = base + lane, inx = i + 64;
         const size_t gn = out0 + (size_t)(inx < count ? inx : 0);
-        ob_nxt = cp.obs[gn]; xy_nxt = cp.bxy[gn];
+        if constexpr (NEED_OB) ob_nxt = cp.obs[gn];
+        if constexpr (ROLL) tr_nxt = cp.tr[gn];
+        xy_nxt = cp.bxy[gn];
         z_nxt = cp.bz[gn];
         old_nxt = reinterpret_cast<const double2*>(u)[gn];
-#else
-        const int i = base + lane, in2 = i + 128;
-        const size_t g2 = out0 + (size_t)(in2 < count ? in2 : 0);
-        const double2 ob_n2 = cp.obs[g2], xy_n2 = cp.bxy[g2];
-        const double z_n2 = cp.bz[g2];
-        const double2 old_n2 = reinterpret_cast<const double2*>(u)[g2];
-#endif
         if (i < count) {
           const double X_cur[3] = {xy_cur.x, xy_cur.y, z_cur};
           PointState<ND, ROLL> ps;
-          point_state<ND, FISH, ROLL, ROBUST>(d, t, v, c, b, 0, ob_cur, ps, X_cur);
+          point_state<ND, FISH, ROLL, ROBUST>(d, t, v, c, b, 0, ob_cur, ps, X_cur, nullptr, nullptr, nullptr, ROLL ? &tr_cur : nullptr);
           if constexpr (MODE == 4) {   // the state of the observation for the cached iterations that follow
             const size_t gi = out0 + (size_t)i;
 #pragma unroll
@@ -1111,10 +1104,7 @@ __global__ __launch_bounds__(64) MCBA_F2_OCCUPANCY void k_lsmr_fused2(Dims d, Ta
           }
           observe(ps, old_cur, v, b, 0, out0 + (size_t)i);
         }
-        ob_cur = ob_nxt; xy_cur = xy_nxt; z_cur = z_nxt; old_cur = old_nxt;
-#if defined(MCBA_EXP_F2_DEPTH2)
-        ob_nxt = ob_n2; xy_nxt = xy_n2; z_nxt = z_n2; old_nxt = old_n2;
-#endif
+        ob_cur = ob_nxt; xy_cur = xy_nxt; z_cur = z_nxt; old_cur = old_nxt; tr_cur = tr_nxt;
       }
     } else if constexpr (MODE == 2) {
       // ---- the state of every observation comes back from the cache: no masks, no compaction, no observation / board-point reads
@@ -1654,6 +1644,7 @@ void k_linearize(Dims d, Tables t, double* __restrict__ rec,
   double2 ob_cur;
   ob_cur.x = ob_cur.y = 0.0;
   double X_cur[3] = {0.0, 0.0, 0.0}, X_nxt[3];
+  double tr_cur = 0.0, tr_nxt = 0.0;   // (COMPACT, rolling shutter) scan time of the observation, precomputed with the tables
   bool front_ready = false;    // the front of the view about to be processed is already in LDS copy `cur` (PIPE)
   int4 dnext = make_int4(0, 0, 0, 0);   // (COMPACT) descriptor {view, first observation, inliers} of the next view of this workgroup
   if constexpr (COMPACT) {
@@ -1718,6 +1709,7 @@ void k_linearize(Dims d, Tables t, double* __restrict__ rec,
         ob_cur = cp.obs[g0];
         const double2 xy = cp.bxy[g0];
         X_cur[0] = xy.x; X_cur[1] = xy.y; X_cur[2] = cp.bz[g0];
+        if constexpr (ROLL) tr_cur = cp.tr[g0];
         front_finish(cur, pl);
         count = desc_count;
       } else {
@@ -1833,6 +1825,7 @@ void k_linearize(Dims d, Tables t, double* __restrict__ rec,
       ob_nxt = cp.obs[gn];
       const double2 xy = cp.bxy[gn];
       X_nxt[0] = xy.x; X_nxt[1] = xy.y; X_nxt[2] = cp.bz[gn];
+      if constexpr (ROLL) tr_nxt = cp.tr[gn];
     } else {
       p_nxt = inx < count ? pidx[inx] : p_cur;
       ob_nxt = t.obs[(size_t)v * d.P + p_nxt];
@@ -1852,13 +1845,15 @@ void k_linearize(Dims d, Tables t, double* __restrict__ rec,
 #if defined(MCBA_EXP_NO_SCALAR_TABLES)   // A/B switch of the profiling builds: table reads left to the compiler
       cost += point_state<ND, FISH, ROLL, ROBUST>(d, t, v, c, b, p_cur, ob_cur, ps, X_cur, FUSED ? Vm : nullptr, camp);
 #else
-      cost += point_state<ND, FISH, ROLL, ROBUST>(d, t, v, c, b, p_cur, ob_cur, ps, X_cur, ROLL ? Vl : Vr, camr, extp);
+      cost += point_state<ND, FISH, ROLL, ROBUST>(d, t, v, c, b, p_cur, ob_cur, ps, X_cur, ROLL ? Vl : Vr, camr, extp,
+                                                  (COMPACT && ROLL) ? &tr_cur : nullptr);
 #endif
     } else {   // lanes past the end of the list stage zero rows
       ps = PointState<ND, ROLL>{};
     }
     p_cur = p_nxt;
     ob_cur = ob_nxt;
+    tr_cur = tr_nxt;
     for (int k = 0; k < 3; ++k) X_cur[k] = X_nxt[k];
     if (prof) stamp[2] += clock64() - t0;
     const int nchunk = min(64, count - base);              // observations in this chunk

@@ -3425,14 +3425,16 @@ __global__ __launch_bounds__(64) void k_obs_index(Dims d, const uint8_t* __restr
 
 // the compacted observation tables of the lsmr route (LsmrCompact): one wavefront per ACTIVE view, in the order of the active list
 __global__ __launch_bounds__(64) void k_compact_views(Dims d, Tables t, const int32_t* __restrict__ first, double2* __restrict__ obsC,
-                                                      double2* __restrict__ bxy, double* __restrict__ bz, int4* __restrict__ desc) {
+                                                      double2* __restrict__ bxy, double* __restrict__ bz, double* __restrict__ trC,
+                                                      int4* __restrict__ desc) {
   const int vi = blockIdx.x, lane = threadIdx.x;
   if (vi >= t.active_views[0]) return;
   const int v = t.active_views[1 + vi];
   if (v < 0) { if (lane == 0) desc[vi] = make_int4(-1, 0, 0, 0); return; }
-  const int b = v % d.B;
+  const int b = v % d.B, c = (v / d.B) % d.C;
   const size_t s0 = (size_t)v * d.P;
   const int f0 = first[v];
+  const double height = trC != nullptr ? t.img_h[c] : 1.0;   // (camera_entry: CAM_HEIGHT = image_height)
   int base = f0;
   for (int q0 = 0; q0 < d.P; q0 += 64) {
     const int q = q0 + lane;
@@ -3440,7 +3442,9 @@ __global__ __launch_bounds__(64) void k_compact_views(Dims d, Tables t, const in
     const unsigned long long m = __ballot(in);
     if (in) {
       const int gi = base + __popcll(m & ((1ull << lane) - 1ull));
-      obsC[gi] = t.obs[s0 + q];
+      const double2 ob = t.obs[s0 + q];
+      obsC[gi] = ob;
+      if (trC != nullptr) trC[gi] = ob.y / height;   // (the division slot_forward performs: same operands, same bits)
       const double* X = t.board_points + 3 * (size_t)(b * d.P + q);
       bxy[gi] = make_double2(X[0], X[1]);
       bz[gi] = X[2];

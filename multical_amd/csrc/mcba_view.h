@@ -53,7 +53,8 @@ MCBA_HD void slot_forward(const Dims& d, const Tables& t, int v, int c, int b, i
                                              const double* Xpre = nullptr /* prefetched board point */,
                                              const double* Vpre = nullptr /* chain matrices of the view (registers / LDS) */,
                                              const double* camp = nullptr /* the camera's parameter block (x / registers) */,
-                                             const double* extp = nullptr /* tail of the camera entry, CAM_TILT onwards */) {
+                                             const double* extp = nullptr /* tail of the camera entry, CAM_TILT onwards */,
+                                             const double* trpre = nullptr /* rolling shutter: the observation's scan time, precomputed */) {
   const double* X = Xpre != nullptr ? Xpre : t.board_points + 3 * (size_t)(b * d.P + p);
   const double* V = Vpre != nullptr ? Vpre : t.view + (size_t)v * (VIEW_STRIDE * (ROLL ? 2 : 1));
   const double* cam = t.cam + (size_t)c * CAM_STRIDE;
@@ -65,7 +66,7 @@ MCBA_HD void slot_forward(const Dims& d, const Tables& t, int v, int c, int b, i
   if constexpr (ROLL) {
     const double* W = V + VIEW_STRIDE;
     for (int i = 0; i < 3; ++i) Xe[i] = W[3 * i] * bx + W[3 * i + 1] * by + W[3 * i + 2] * bz + W[9 + i];
-    tr = ob.y / ext[CAM_HEIGHT - CAM_TILT];                       // rolling_frames.py:15-19 (observed row)
+    tr = trpre != nullptr ? *trpre : ob.y / ext[CAM_HEIGHT - CAM_TILT];   // rolling_frames.py:15-19 (observed row)
     for (int i = 0; i < 3; ++i) Xc[i] = Xs[i] * (1.0 - tr) + Xe[i] * tr;   // interpolate.py:6-8
   } else {
     tr = 0.0;
@@ -406,9 +407,9 @@ struct PointState {
 template <int ND, int FISH, bool ROLL, bool ROBUST = true>
 MCBA_HD double point_state(const Dims& d, const Tables& t, int v, int c, int b, int p, double2 ob,
                            PointState<ND, ROLL>& st, const double* Xpre = nullptr, const double* Vpre = nullptr,
-                           const double* camp = nullptr, const double* extp = nullptr) {
+                           const double* camp = nullptr, const double* extp = nullptr, const double* trpre = nullptr) {
   double uv[2];
-  slot_forward<ND, FISH, ROLL, true>(d, t, v, c, b, p, ob, uv, st.A, st.Kc, st.Xs, st.Xe, st.tr, Xpre, Vpre, camp, extp);
+  slot_forward<ND, FISH, ROLL, true>(d, t, v, c, b, p, ob, uv, st.A, st.Kc, st.Xs, st.Xe, st.tr, Xpre, Vpre, camp, extp, trpre);
   st.e[0] = uv[0] - ob.x;
   st.e[1] = uv[1] - ob.y;
   double rho = 0.0;
