@@ -680,6 +680,11 @@ def main():
             parity_route["roofline"]["traffic"] = 2 * pj[k2[0]]["FETCH_SIZE"] * 1024 + pj[k2[0]]["WRITE_SIZE"] * 1024
             parity_route["roofline"]["traffic_source"] = (os.path.relpath(pmc_file, ROOT) + ": separate --pmc FETCH_SIZE / WRITE_SIZE passes "
                                                           "(profiles/scripts/collect_r0*.sh), gfx950 x2 read correction; not measured in this run")
+            parity_route["roofline"]["traffic_note"] = ("the compacted tables STREAM the board point (24 B) and the scan time (8 B) of every observation "
+                                                        "instead of gathering board points through L2 behind mask bytes and a compaction: ~64 B per observation "
+                                                        "and iteration + 2.3 KB of That per view, by design above the 48 B + 1 B / slot of `algorithmic_bytes` "
+                                                        "-- coalesced bytes bought fewer dependent round trips per view (26.9 -> 24.3 us); at ~2.9 TB/s the kernel "
+                                                        "is not HBM-bound")
         except Exception:
           pass
     fl = parity_route["lsmr_iteration"]["flops_per_observation"] * n_obs_local
