@@ -318,6 +318,7 @@ struct mcba_handle_s {
   // compacted observation tables of the lsmr route (LsmrCompact; rebuilt when the inlier set changes: ensure_compact)
   DevBuf<double2> cp_obs, cp_bxy;
   DevBuf<double> cp_bz, cp_tr;
+  DevBuf<double> dot_part;   // wavefront totals of k_dot3_part
   DevBuf<int4> cp_desc;
   bool compact_dirty = true;
   DevBuf<double> ls_cache;                // lsmr_fused == 3: the per-observation state A, X_start, X_end, t (+ robust scales) of the current linearisation
@@ -2585,7 +2586,9 @@ static void solve_lsmr(mcba_handle h, double* x_inout, const mcba_options* opt, 
     op.jv(2, h->gn.p, 0.0, h->ls_ub.p);
     // [Jg.Jgn | Jg.Jg | Jgn.Jgn] over the m rows and [g_h.gn | g_h.g_h | gn.gn] over the n entries (reordered below); frame-sharded:
     // per-rank partials (every parameter entry counted once: k_dot_weighted), summed by ONE all-reduce of 6 doubles
-    hipLaunchKernelGGL(k_dot, dim3(1), dim3(1024), 0, h->stream, m, (const double*)h->ls_ua.p, (const double*)h->ls_ub.p, h->ls_out.p, 1);
+    if (h->dot_part.n < (size_t)3 * DOT_WAVES) h->dot_part.alloc((size_t)3 * DOT_WAVES, true);
+    hipLaunchKernelGGL(k_dot3_part, dim3(DOT_WAVES), dim3(64), 0, h->stream, m, (const double*)h->ls_ua.p, (const double*)h->ls_ub.p, h->dot_part.p);
+    hipLaunchKernelGGL(k_dot3_fin, dim3(1), dim3(64), 0, h->stream, (const double*)h->dot_part.p, h->ls_out.p);
     if (h->allreduce)
       hipLaunchKernelGGL(k_dot_weighted, dim3(1), dim3(1024), 0, h->stream, d, (const double*)h->gh.p, (const double*)h->gn.p,
                          h->ls_out.p + 3, 1);

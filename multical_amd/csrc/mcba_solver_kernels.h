@@ -2888,6 +2888,49 @@ __global__ __launch_bounds__(1024) void k_dot(size_t n, const double* __restrict
   }
 }
 
+// The same three sums over a LONG vector (the m residual rows of the subspace products J g_h, J gn) -- in k_dot's OWN order, so that not
+// a bit of a solve changes: k_dot's single workgroup walks 1.5 M entries with one load round trip per step (0.49 ms per call at the
+// north-star rig, 4 % of a default solve).  Here each of its 16 wavefronts is a workgroup of its own (16 CUs pull the vectors instead of
+// one), lane t of wavefront w still adds the entries 64 w + t, + 1024, + 2048, ... one after the other -- eight loads in flight per
+// operand instead of one -- and k_dot3_fin adds the 16 wavefront totals in block_reduce's order.
+constexpr int DOT_WAVES = 16;   // = k_dot's 1024 threads / 64
+__global__ __launch_bounds__(64) void k_dot3_part(size_t n, const double* __restrict__ a, const double* __restrict__ b,
+                                                  double* __restrict__ part /*[3][DOT_WAVES]*/) {
+  constexpr size_t STRIDE = 64 * DOT_WAVES;
+  constexpr int NB = 8;    // loads in flight per operand and lane (106 us per call at m = 1.5 M; 16 in flight: 151 us)
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  for (size_t i = (size_t)blockIdx.x * 64 + threadIdx.x; i < n; i += NB * STRIDE) {   // (lanes past the end: no iteration, as in k_dot)
+    double x[NB], y[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const size_t j = i + u * STRIDE, jc = j < n ? j : i;   // (clamped: the load is unconditional, the sum below is not)
+      x[u] = a[jc];
+      y[u] = b[jc];
+    }
+#pragma unroll
+    for (int u = 0; u < NB; ++u)
+      if (i + u * STRIDE < n) {
+        s0 += x[u] * y[u];
+        s1 += x[u] * x[u];
+        s2 += y[u] * y[u];
+      }
+  }
+  const double t0 = wave_sum(s0), t1 = wave_sum(s1), t2 = wave_sum(s2);
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = t0;
+    part[DOT_WAVES + blockIdx.x] = t1;
+    part[2 * DOT_WAVES + blockIdx.x] = t2;
+  }
+}
+// out[k] = the 16 wavefront totals of value k, added in the order of block_reduce (scratch[0] + scratch[1] + ...)
+__global__ void k_dot3_fin(const double* __restrict__ part, double* __restrict__ out) {
+  if (threadIdx.x < 3) {
+    double r = part[threadIdx.x * DOT_WAVES];
+    for (int i = 1; i < DOT_WAVES; ++i) r += part[threadIdx.x * DOT_WAVES + i];
+    out[threadIdx.x] = r;
+  }
+}
+
 // The scalar side of a device-resident LSMR solve (mcba_lsmr.h), two launches of ONE workgroup per iteration:
 //   k_lsmr_scal_a behind k_lsmr_jv:     |x|^2 of the PREVIOUS iteration's update -> its stopping tests; |u|^2 -> beta
 //   k_lsmr_scal_b behind k_lsmr_gather: |v|^2 -> alpha, the plane rotations, the coefficients of k_lsmr_update
