@@ -1644,7 +1644,6 @@ void k_linearize(Dims d, Tables t, double* __restrict__ rec,
   double2 ob_cur;
   ob_cur.x = ob_cur.y = 0.0;
   double X_cur[3] = {0.0, 0.0, 0.0}, X_nxt[3];
-  double tr_cur = 0.0, tr_nxt = 0.0;   // (COMPACT, rolling shutter) scan time of the observation, precomputed with the tables
   bool front_ready = false;    // the front of the view about to be processed is already in LDS copy `cur` (PIPE)
   int4 dnext = make_int4(0, 0, 0, 0);   // (COMPACT) descriptor {view, first observation, inliers} of the next view of this workgroup
   if constexpr (COMPACT) {
@@ -1709,7 +1708,6 @@ void k_linearize(Dims d, Tables t, double* __restrict__ rec,
         ob_cur = cp.obs[g0];
         const double2 xy = cp.bxy[g0];
         X_cur[0] = xy.x; X_cur[1] = xy.y; X_cur[2] = cp.bz[g0];
-        if constexpr (ROLL) tr_cur = cp.tr[g0];
         front_finish(cur, pl);
         count = desc_count;
       } else {
@@ -1825,7 +1823,6 @@ void k_linearize(Dims d, Tables t, double* __restrict__ rec,
       ob_nxt = cp.obs[gn];
       const double2 xy = cp.bxy[gn];
       X_nxt[0] = xy.x; X_nxt[1] = xy.y; X_nxt[2] = cp.bz[gn];
-      if constexpr (ROLL) tr_nxt = cp.tr[gn];
     } else {
       p_nxt = inx < count ? pidx[inx] : p_cur;
       ob_nxt = t.obs[(size_t)v * d.P + p_nxt];
@@ -1845,15 +1842,15 @@ void k_linearize(Dims d, Tables t, double* __restrict__ rec,
 #if defined(MCBA_EXP_NO_SCALAR_TABLES)   // A/B switch of the profiling builds: table reads left to the compiler
       cost += point_state<ND, FISH, ROLL, ROBUST>(d, t, v, c, b, p_cur, ob_cur, ps, X_cur, FUSED ? Vm : nullptr, camp);
 #else
-      cost += point_state<ND, FISH, ROLL, ROBUST>(d, t, v, c, b, p_cur, ob_cur, ps, X_cur, ROLL ? Vl : Vr, camr, extp,
-                                                  (COMPACT && ROLL) ? &tr_cur : nullptr);
+      // (the precomputed scan time of the compacted tables -- LsmrCompact::tr, read by the LSMR product kernel -- was measured here too:
+      //  no change of the step, 6 MB more traffic per launch: the division stays)
+      cost += point_state<ND, FISH, ROLL, ROBUST>(d, t, v, c, b, p_cur, ob_cur, ps, X_cur, ROLL ? Vl : Vr, camr, extp);
 #endif
     } else {   // lanes past the end of the list stage zero rows
       ps = PointState<ND, ROLL>{};
     }
     p_cur = p_nxt;
     ob_cur = ob_nxt;
-    tr_cur = tr_nxt;
     for (int k = 0; k < 3; ++k) X_cur[k] = X_nxt[k];
     if (prof) stamp[2] += clock64() - t0;
     const int nchunk = min(64, count - base);              // observations in this chunk
