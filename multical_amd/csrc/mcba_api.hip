@@ -1245,6 +1245,11 @@ int32_t mcba_create(const mcba_problem* p, void* hip_stream, mcba_handle* out) {
     const char* e = dbg_switch("MCBA_NCHUNK_TARGET");   // tuning knob: (pair, chunk) workgroups aimed at
     const int target = e ? std::max(1, atoi(e)) : 256;   // measured at cfg3: 256 -> 114.4 us / step, 512 -> 113.1, 1024 -> 119.3
     h->nchunk = std::max(1, std::min(std::min(64, (d.Fl + 7) / 8), std::max(4, target / std::max(1, d.C * d.B))));
+    // Rigs with many (camera, board) pairs AND many frames got 4 chunks of hundreds of frames: a chunk-sum block walks its frames eight
+    // views at a time, one round trip each -- 16 x 1000 x 5 (80 pairs, 250 frames per chunk): k_assemble 40.8 us.  No chunk longer than
+    // 64 frames; then about 40 (round 6, profiles/scripts/prof_nchunk.py: step 106.6 -> 97.0 us there; 8 x 500 x 2 and 6 x 400 x 5 unchanged,
+    // they lose 2 - 4 us with more chunks than they have).
+    if (!e && d.Fl > 64 * h->nchunk) h->nchunk = std::min(64, (d.Fl + 39) / 40);
   }
   h->partial.alloc((size_t)d.C * d.B * h->nchunk * d.rec_stride);
   h->Hss.alloc((size_t)d.ns * d.ns);
