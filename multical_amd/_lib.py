@@ -108,6 +108,7 @@ SYMBOLS = [
   ("mcba_debug_set_lin_grid", C.c_int32, [H, C.c_int32]),
   ("mcba_debug_set_frame_groups", C.c_int32, [H, C.c_int32]),
   ("mcba_debug_pipe_probe", C.c_int32, [C.c_int32, C.POINTER(C.c_double)]),
+  ("mcba_debug_dot3", C.c_int32, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
   ("mcba_debug_dispatch_probe", C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_longlong)]),
   ("mcba_debug_xcd_probe", C.c_int32, [C.c_int32, C.POINTER(C.c_longlong)]),
   ("mcba_debug_gn_step", C.c_int32, [H, C.c_double, c_double_p, c_double_p, c_double_p]),

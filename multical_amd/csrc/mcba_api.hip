@@ -2124,6 +2124,27 @@ int32_t mcba_debug_pipe_probe(int32_t iters, double* ms_out) {
   API_END
 }
 
+/* test hook (mcba_debug.h): [sum a b | sum a^2 | sum b^2] over n doubles by k_dot (one workgroup) and by k_dot3_part / k_dot3_fin (its 16
+ * wavefronts on 16 CUs, the order of additions unchanged): out_single[3], out_wide[3] -- must agree bit for bit.  */
+int32_t mcba_debug_dot3(const double* a, const double* b, int64_t n, double* out_single, double* out_wide) {
+  API_BEGIN
+  REQUIRE(a && b && n >= 0 && out_single && out_wide, "bad argument");
+  DevBuf<double> da, db, part, out;
+  da.alloc((size_t)std::max<int64_t>(n, 1)); db.alloc((size_t)std::max<int64_t>(n, 1)); part.alloc(3 * DOT_WAVES, true); out.alloc(6, true);
+  if (n > 0) {
+    HIP_OK(hipMemcpy(da.p, a, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(db.p, b, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+  }
+  hipLaunchKernelGGL(k_dot, dim3(1), dim3(1024), 0, 0, (size_t)n, (const double*)da.p, (const double*)db.p, out.p, 1);
+  hipLaunchKernelGGL(k_dot3_part, dim3(DOT_WAVES), dim3(64), 0, 0, (size_t)n, (const double*)da.p, (const double*)db.p, part.p);
+  hipLaunchKernelGGL(k_dot3_fin, dim3(1), dim3(64), 0, 0, (const double*)part.p, out.p + 3);
+  HIP_OK(hipDeviceSynchronize());
+  double host[6];
+  HIP_OK(hipMemcpy(host, out.p, sizeof(host), hipMemcpyDeviceToHost));
+  for (int k = 0; k < 3; ++k) { out_single[k] = host[k]; out_wide[k] = host[3 + k]; }
+  API_END
+}
+
 namespace {
 
 struct LsmrOps {

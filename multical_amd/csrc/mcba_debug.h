@@ -17,6 +17,8 @@ int32_t mcba_debug_set_lin_grid(mcba_handle h, int32_t grid);
 int32_t mcba_debug_set_frame_groups(mcba_handle h, int32_t nw);
 /* FP64 VALU vs FP64 MFMA pipe-sharing probe: ms_out[3] = all-FMA, all-MFMA, half / half        */
 int32_t mcba_debug_pipe_probe(int32_t iters, double* ms_out);
+/* [sum a b | sum a^2 | sum b^2] by the single-workgroup k_dot and by its 16-CU form (k_dot3_part / k_dot3_fin): bit-identical by design */
+int32_t mcba_debug_dot3(const double* a, const double* b, int64_t n, double* out_single, double* out_wide);
 /* workgroup dispatch rate: launches `blocks` workgroups of `threads` threads with `lds_bytes` of LDS, each running `spin`
  * dependent FMAs; out[blocks][2] = 100 MHz wall-clock ticks at the start / end of every workgroup                   */
 int32_t mcba_debug_dispatch_probe(int32_t blocks, int32_t threads, int32_t lds_bytes, int32_t spin, long long* out);

@@ -470,3 +470,26 @@ def test_default_solver_lands_on_scipys_exact_product_end_point(name, record_pro
             f"{xp['longdouble_mean_minus_reference']:+.2e}; scipy(double products, reordered) - reference {xp.get('double_mean_minus_reference', float('nan')):+.2e}")
       assert abs(rms - target) <= tol, (name, form, rms - target, tol)
       assert res.nfev == int(xp["reference_nfev"])
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 1023, 1024, 1025, 8 * 1024 + 17, 100_000, 1_527_914])
+def test_wide_dot_keeps_the_order_of_additions(n):
+  """The three sums of the 2-D subspace step over the m residual rows ([Jg.Jgn | Jg.Jg | Jgn.Jgn], once per trust-region iteration) were ONE
+  workgroup walking the vectors (k_dot, 0.49 ms at m = 1.5 M); k_dot3_part / k_dot3_fin put each of its 16 wavefronts on a CU of its own and
+  keep every lane's order of additions and the order of the wavefront totals: the same bits for every length, ragged tails included --
+  otherwise the trajectories of the chaotic fixtures move (a plain two-stage reduction took tiny_rolling from 22 to 17 evaluations)."""
+  import ctypes as C
+  from multical_amd import _lib
+  lib = _lib.load()
+  rng = np.random.default_rng(n)
+  a = np.ascontiguousarray(rng.normal(size=max(n, 1)) * np.exp(rng.normal(size=max(n, 1)) * 3))
+  b = np.ascontiguousarray(rng.normal(size=max(n, 1)) * np.exp(rng.normal(size=max(n, 1)) * 3))
+  single, wide = np.zeros(3), np.zeros(3)
+  P = C.POINTER(C.c_double)
+  rc = lib.mcba_debug_dot3(a.ctypes.data_as(P), b.ctypes.data_as(P), n, single.ctypes.data_as(P), wide.ctypes.data_as(P))
+  assert rc == 0
+  assert np.array_equal(single, wide), (single, wide)
+  if n > 0:
+    want = np.array([np.dot(a[:n], b[:n]), np.dot(a[:n], a[:n]), np.dot(b[:n], b[:n])])
+    assert np.allclose(wide, want, rtol=1e-9, atol=1e-9 * np.sqrt(want[1] * want[2]))
+
